@@ -1,0 +1,118 @@
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference (build container only).
+
+Usage:  python oracle/make_golden.py            (needs /root/reference)
+Every file holds the exact input signal and the reference's outputs, so the
+-m gpu tests never need /root/reference.  Re-running must reproduce the
+committed files bit for bit (numpy 2.2.6 / scipy 1.15.3).
+"""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import load_reference  # noqa: E402
+from synth import synth_clip  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+REF = load_reference.REFERENCE_ROOT
+
+
+def wav(path, seconds=None):
+    import warnings
+    import scipy.io.wavfile as wavfile
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fs, x = wavfile.read(os.path.join(REF, path))
+    if seconds is not None:
+        x = x[:int(seconds * fs)]
+    return fs, np.ascontiguousarray(x)
+
+
+def main():
+    ref_st, ref_mt, ref_io = load_reference.load()
+    os.makedirs(OUT, exist_ok=True)
+    written = []
+
+    def save(name, **arrays):
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+        written.append(name)
+
+    def st_case(name, sig, fs, win, step, deltas=True):
+        F, names = ref_st.feature_extraction(sig, fs, win, step, deltas)
+        save(name, kind="st", signal=sig, fs=fs, window=win, step=step, deltas=deltas,
+             features=F, names=np.array(names))
+
+    def mid_case(name, sig, fs, mw, ms, sw, ss):
+        mid, st, names = ref_mt.mid_feature_extraction(sig, fs, mw, ms, sw, ss)
+        save(name, kind="mid", signal=sig, fs=fs, mid_window=mw, mid_step=ms, window=sw, step=ss,
+             mid=mid, features=st, names=np.array(names))
+
+    def spec_case(name, sig, fs, win, step):
+        with contextlib.redirect_stdout(io.StringIO()):
+            S, t_ax, f_ax = ref_st.spectrogram(sig, fs, win, step)
+        C, ct_ax, cf_ax = ref_st.chromagram(sig, fs, win, step)
+        save(name, kind="spec", signal=sig, fs=fs, window=win, step=step, specgram=S,
+             spec_time=np.array(t_ax), spec_freq=np.array(f_ax), chromagram=C,
+             chroma_time=np.array(ct_ax), chroma_names=np.array(cf_ax))
+
+    # ---- A. in-tree WAVs --------------------------------------------------
+    fs, x = wav("pyAudioAnalysis/data/doremi.wav")
+    st_case("doremi_800_400", x, fs, 800, 400)                       # BASELINE config 1
+    fs, x = wav("pyAudioAnalysis/data/doremi.wav", 3.0)
+    st_case("doremi3s_800_800", x, fs, 800, 800)
+    st_case("doremi3s_640_640", x, fs, 640, 640)
+    st_case("doremi3s_320_160", x, fs, 320, 160)
+    st_case("doremi3s_800_400_nodelta", x, fs, 800, 400, deltas=False)
+    spec_case("doremi3s_spec_640_640", x, fs, 640, 640)              # tests/cmd_test_00/01.sh shape
+    fs, x = wav("pyAudioAnalysis/data/3WORDS.wav", 2.0)
+    st_case("3words2s_1102_441", x, fs, 0.025 * fs, 0.010 * fs)     # float args -> int() truncation
+    spec_case("3words2s_spec_1102_441", x, fs, 0.025 * fs, 0.010 * fs)
+    for stem in ("count", "diarizationExample", "speech_music_sample", "recording1"):
+        fs, x = wav("pyAudioAnalysis/data/%s.wav" % stem, 2.0)
+        st_case("%s2s_800_400" % stem, x, fs, 800, 400)
+    fs, x = wav("pytests/test_data/1_sec_wav.wav")
+    st_case("pytest_1sec", x, fs, 0.050 * fs, 0.050 * fs)            # pytests/test_feature_extraction.py:10
+    fs, x = wav("pytests/test_data/5_sec_wav.wav")
+    mid_case("pytest_5sec_mid", x, fs, 1 * fs, 1 * fs, 0.05 * fs, 0.05 * fs)   # :19
+
+    # ---- B. seeded synthetic ---------------------------------------------
+    x = synth_clip(11, 3 * 16000)
+    st_case("synth11_800_400", x, 16000, 800, 400)
+    mid_case("synth11_mid_1s_1s", x, 16000, 16000, 16000, 800, 400)
+    mid_case("synth11_mid_float", x, 16000, 1.0 * 16000, 0.1 * 16000, 800.0, 800.0)
+    xs = synth_clip(5, 44100, fs=44100, stereo=True)
+    mono = ref_io.stereo_to_mono(xs)                                  # float64 with .5 fractions
+    assert mono.dtype == np.float64
+    st_case("synth5_stereo_1102_441", mono, 44100, 1102, 441)
+    save("synth5_stereo_raw", kind="stereo", stereo=xs, mono=mono)
+    spec_case("synth5_spec_1102_441", mono, 44100, 1102, 441)
+
+    # ---- C. degenerate ------------------------------------------------------
+    st_case("zeros_2000", np.zeros(2000, dtype=np.int16), 16000, 800, 400)
+    x = synth_clip(12, 4000)
+    st_case("exact_one_window", x[:800].copy(), 16000, 800, 400)
+    st_case("w_plus_s_minus_1", x[:1199].copy(), 16000, 800, 400)
+    st_case("constant_dc", np.full(3000, 1234, dtype=np.int16), 16000, 800, 400)
+    sq = np.where((np.arange(4000) // 7) % 2 == 0, 32767, -32768).astype(np.int16)
+    st_case("square_fullscale", sq, 16000, 800, 400)
+    gap = synth_clip(13, 8000).copy()
+    gap[2000:6000] = 0                                                 # frames of exact digital silence
+    st_case("silent_gap", gap, 16000, 800, 400)
+    # fs/4 tone (5,0,-5,0,...): exact zero SAMPLES (sign()=0 half crossings) plus a zeroed span.
+    # (A pure Nyquist tone +-5 would put all energy in the dropped bin: the reference's spectrum is
+    #  then exactly 0 and every spectral feature is a function of FFT round-off -- not a parity case.)
+    alt = np.tile(np.array([5, 0, -5, 0], dtype=np.int16), 1000)
+    alt[1000:1400] = 0
+    st_case("quarter_tone_with_zeros", alt, 16000, 800, 400)
+
+    print("wrote %d golden files to %s" % (len(written), OUT))
+    tot = sum(os.path.getsize(os.path.join(OUT, n + ".npz")) for n in written)
+    print("total %.2f MB" % (tot / 1e6))
+
+
+if __name__ == "__main__":
+    main()
