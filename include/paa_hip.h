@@ -1,0 +1,159 @@
+/*
+ * paa_hip.h -- C ABI of libpaa_hip.so, the MI355X (gfx950) short-term / mid-term audio
+ * feature extractor that is a drop-in for ONE path of tyiannak/pyAudioAnalysis.
+ *
+ * The reference has no FFI layer: its boundary is the Python signature.  Each entry point
+ * below names the reference interface it replaces (paths relative to
+ * /root/reference/pyAudioAnalysis).  Plain pointers and sizes only; no torch / numpy types.
+ * INTEGRATION.md shows the ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - return value 0 (PAA_OK) = success, < 0 = error code; paa_last_error() gives the text
+ *     (thread local).  There is NO CPU fallback: without a HIP device every compute call
+ *     returns PAA_ERR_HIP.
+ *   - `window` / `step` are in samples and already int()-truncated by the caller
+ *     (ShortTermFeatures.py:563-564); num_fft = window / 2 (integer division, :575).
+ *   - host buffers are caller-owned and only touched during the call.  `*_dev_*` entry points
+ *     take HIP device pointers (from paa_dev_alloc or any hipMalloc) and are asynchronous on
+ *     the library's stream; paa_dev_sync() waits for them.
+ *   - feature matrices are float64, C-contiguous, FEATURE-major [F][T] (F = 34, or 68 with
+ *     deltas), exactly the reference's return layout (:684); spectrogram / chromagram are
+ *     TIME-major [T'][num_fft] / [T''][12] (:413, :347).
+ *   - a batch is a packed sample buffer plus n_clips+1 sample offsets; clip c's result is the
+ *     [F][T_c] slab starting at out + out_offsets[c] (in doubles).
+ */
+#ifndef PAA_HIP_H
+#define PAA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAA_OK                 0
+#define PAA_ERR_ARG          (-1)  /* bad argument (null pointer, window < 2, step < 1, ...)          */
+#define PAA_ERR_UNSUPPORTED  (-2)  /* window beyond the LDS envelope of the kernels                    */
+#define PAA_ERR_HIP          (-3)  /* HIP runtime error / no device                                    */
+#define PAA_ERR_OOM          (-4)  /* device or host allocation failed                                 */
+#define PAA_ERR_TOO_SHORT    (-5)  /* fewer samples than one window: reference raises ValueError :684  */
+#define PAA_ERR_CHROMA_VALUE (-6)  /* chroma slot > num_fft: reference raises ValueError :293          */
+#define PAA_ERR_CHROMA_INDEX (-7)  /* chroma slot == num_fft: reference raises IndexError :291         */
+#define PAA_ERR_MEL_INDEX    (-8)  /* mel filter bin >= num_fft: reference raises IndexError :230-231  */
+#define PAA_ERR_COMM         (-9)  /* RCCL error                                                       */
+
+#define PAA_N_BASE_FEATURES 34
+
+/* ---- library / device management ------------------------------------------------------ */
+const char *paa_version(void);
+const char *paa_last_error(void);
+int  paa_device_count(void);             /* >= 0, or PAA_ERR_HIP                                   */
+int  paa_init(int device_id);            /* select the device for this process (one process per GPU) */
+void paa_shutdown(void);                 /* free cached tables, scratch and the stream              */
+int  paa_dev_alloc(size_t bytes, void **out_ptr);
+int  paa_dev_free(void *ptr);
+int  paa_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);   /* synchronous */
+int  paa_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);   /* synchronous */
+int  paa_dev_sync(void);
+/* elapsed GPU milliseconds between two points of the library stream (HIP events) */
+int  paa_timer_start(void);
+int  paa_timer_stop(float *ms);
+
+/* per-launch HIP-event timing of the feature kernel inside paa_plan_execute (off by default);
+ * paa_prof_read returns the accumulated milliseconds / launch count and resets them            */
+int  paa_prof_enable(int on);
+int  paa_prof_read(double *total_ms, int64_t *launches);
+
+/* ---- shape helpers ----------------------------------------------------------------------- */
+/* T = floor((n - window)/step) + 1, 0 if n < window            (ShortTermFeatures.py:608)   */
+int64_t paa_num_frames(int64_t n_samples, int window, int step);
+/* M = ceil(T / mid_step_ratio)                                  (MidTermFeatures.py:116-124) */
+int64_t paa_num_mid_windows(int64_t n_frames, int64_t mid_step_ratio);
+/* rows allocated by spectrogram: int((n-window)/step)+1; rows actually filled in *filled     */
+int64_t paa_spectrogram_rows(int64_t n_samples, int window, int step, int64_t *filled);
+/* rows allocated by chromagram: int((n-step-window)/step)+1; filled rows in *filled          */
+int64_t paa_chromagram_rows(int64_t n_samples, int window, int step, int64_t *filled);
+
+/* ---- ShortTermFeatures.feature_extraction (ShortTermFeatures.py:543-685) ---------------- */
+/* signal: int16 PCM as scipy.io.wavfile returns it (audioBasicIO.py:99), or float64
+ * (after stereo_to_mono, audioBasicIO.py:167).  Both are scaled by 1/2^15 (:568).
+ * out: [F][T] doubles, F = 34 * (deltas ? 2 : 1).                                         */
+int paa_st_features_i16(const int16_t *signal, int64_t n, double fs, int window, int step,
+                        int deltas, double *out);
+int paa_st_features_f64(const double *signal, int64_t n, double fs, int window, int step,
+                        int deltas, double *out);
+
+/* ---- MidTermFeatures.mid_feature_extraction (MidTermFeatures.py:87-127) ----------------- */
+/* mid_ratio / mid_step_ratio are computed by the caller with Python round() (:100-102).
+ * st_out: [68][T] (deltas always on, :93-95), may be NULL; mid_out: [136][M].               */
+int paa_mid_features_i16(const int16_t *signal, int64_t n, double fs, int window, int step,
+                         int64_t mid_ratio, int64_t mid_step_ratio, double *mid_out, double *st_out);
+int paa_mid_features_f64(const double *signal, int64_t n, double fs, int window, int step,
+                         int64_t mid_ratio, int64_t mid_step_ratio, double *mid_out, double *st_out);
+
+/* ---- ShortTermFeatures.spectrogram / chromagram (:389-452 / :324-386) ------------------- */
+/* out has paa_spectrogram_rows() x (window/2) doubles; unfilled trailing rows are zeroed.   */
+int paa_spectrogram_i16(const int16_t *signal, int64_t n, double fs, int window, int step, double *out);
+int paa_spectrogram_f64(const double *signal, int64_t n, double fs, int window, int step, double *out);
+/* out has paa_chromagram_rows() x 12 doubles.  The reference may FFT a truncated last frame
+ * (:349-355); that frame is evaluated on the device as a direct DFT of its true length.      */
+int paa_chromagram_i16(const int16_t *signal, int64_t n, double fs, int window, int step, double *out);
+int paa_chromagram_f64(const double *signal, int64_t n, double fs, int window, int step, double *out);
+
+/* ---- batched many-clip path (what MidTermFeatures.directory_feature_extraction :140-221
+ *      does sequentially per file)                                                          */
+int paa_st_features_batch_i16(const int16_t *packed, const int64_t *offsets, int64_t n_clips,
+                              double fs, int window, int step, int deltas,
+                              double *out, const int64_t *out_offsets);
+/* mid_out_offsets index [136][M_c] slabs; st_out / st_out_offsets may be NULL               */
+int paa_mid_features_batch_i16(const int16_t *packed, const int64_t *offsets, int64_t n_clips,
+                               double fs, int window, int step,
+                               int64_t mid_ratio, int64_t mid_step_ratio,
+                               double *mid_out, const int64_t *mid_out_offsets,
+                               double *st_out, const int64_t *st_out_offsets);
+
+/* ---- device-resident plans (bench / pipelines: samples and results stay in HBM) --------- */
+typedef struct paa_plan paa_plan_t;
+/* offsets: n_clips+1 HOST sample offsets into the packed device buffer.  sample_kind 0 = int16,
+ * 1 = float64.  The plan owns the tables, the tile list and the per-clip statistics.        */
+int paa_plan_create(const int64_t *offsets, int64_t n_clips, int sample_kind, double fs,
+                    int window, int step, int deltas, paa_plan_t **out_plan);
+int paa_plan_destroy(paa_plan_t *plan);
+int64_t paa_plan_total_frames(const paa_plan_t *plan);
+int64_t paa_plan_out_doubles(const paa_plan_t *plan);     /* sum_c F*T_c                      */
+/* out_offsets (HOST, n_clips) receives the slab start of every clip when non-NULL           */
+int paa_plan_out_offsets(const paa_plan_t *plan, int64_t *out_offsets);
+/* asynchronous on the library stream: clip statistics -> features (+deltas) into d_out       */
+int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *d_out);
+/* optional mid-term statistics of an executed plan (deltas must be on): d_mid gets
+ * [136][M_c] slabs back to back; returns total doubles via paa_plan_mid_doubles             */
+int64_t paa_plan_mid_doubles(const paa_plan_t *plan, int64_t mid_step_ratio);
+int paa_plan_mid_execute(paa_plan_t *plan, const double *d_st, int64_t mid_ratio,
+                         int64_t mid_step_ratio, double *d_mid);
+/* name of the feature kernel the plan dispatches ("st_fast_800", "st_generic", ...)          */
+const char *paa_plan_kernel_name(const paa_plan_t *plan);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI --------------------------------------- */
+#define PAA_COMM_ID_BYTES 128
+int paa_comm_unique_id(void *id_out /* PAA_COMM_ID_BYTES, rank 0 only */);
+int paa_comm_init(int world_size, int rank, const void *id);
+int paa_comm_destroy(void);
+/* gather variable-sized double blocks to rank `root`: counts[world] doubles per rank (host);
+ * d_recv (root only) receives them back to back in rank order.  Asynchronous on the stream. */
+int paa_comm_gather_f64(const double *d_send, const int64_t *counts, int root, double *d_recv);
+int paa_comm_barrier(void);
+
+/* ---- introspection for tests (host tables built by the reference's rules) ----------------- */
+/* dense mel bank [40][num_fft], dct [13][40]; chroma gather list: returns the number of
+ * entries, fills src/weight/slot (capacity entries each) in ascending slot order.            */
+int paa_debug_mel_bank(double fs, int num_fft, double *out_dense);
+int paa_debug_dct(double *out_13x40);
+int paa_debug_chroma(double fs, int num_fft, int capacity, int32_t *src, double *weight, int32_t *slot);
+/* radix plan chosen for a window: returns number of passes, fills radices (capacity 32)      */
+int paa_debug_fft_plan(int window, int32_t *radices, int32_t *fft_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAA_HIP_H */

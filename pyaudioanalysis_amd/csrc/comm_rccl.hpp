@@ -1,0 +1,131 @@
+// RCCL gather of per-GPU feature blocks to one rank (north_star: "RCCL gather over xGMI of the
+// resulting feature matrices").  A gather is 7 independent peer->root transfers, each on its own
+// xGMI link; it is issued as one grouped ncclSend/ncclRecv batch on the library stream.
+// librccl.so is opened lazily so that hosts without a GPU can still load libpaa_hip.so.
+#pragma once
+#include <rccl/rccl.h>
+
+namespace {
+struct RcclApi {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+ncclComm_t g_comm = nullptr;
+int g_world = 1, g_rank = 0;
+int *g_bar = nullptr;
+
+int rccl_load() {
+    if (g_rccl.h) return PAA_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) return fail(PAA_ERR_COMM, "cannot dlopen librccl: %s", dlerror());
+#define PAA_SYM(field, sym)                                                      \
+    *(void **)(&g_rccl.field) = dlsym(h, sym);                                   \
+    if (!g_rccl.field) return fail(PAA_ERR_COMM, "librccl lacks %s", sym);
+    PAA_SYM(GetUniqueId, "ncclGetUniqueId")
+    PAA_SYM(CommInitRank, "ncclCommInitRank")
+    PAA_SYM(CommDestroy, "ncclCommDestroy")
+    PAA_SYM(Send, "ncclSend")
+    PAA_SYM(Recv, "ncclRecv")
+    PAA_SYM(GroupStart, "ncclGroupStart")
+    PAA_SYM(GroupEnd, "ncclGroupEnd")
+    PAA_SYM(AllReduce, "ncclAllReduce")
+    PAA_SYM(GetErrorString, "ncclGetErrorString")
+#undef PAA_SYM
+    g_rccl.h = h;
+    return PAA_OK;
+}
+}  // namespace
+
+#define NCCL_TRY(expr)                                                                       \
+    do {                                                                                     \
+        ncclResult_t r_ = (expr);                                                            \
+        if (r_ != ncclSuccess) return fail(PAA_ERR_COMM, "%s: %s", #expr, g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+static_assert(sizeof(ncclUniqueId) <= PAA_COMM_ID_BYTES, "unique id does not fit");
+
+extern "C" int paa_comm_unique_id(void *id_out) {
+    int rc = rccl_load();
+    if (rc) return rc;
+    if (!id_out) return fail(PAA_ERR_ARG, "null id");
+    ncclUniqueId id;
+    NCCL_TRY(g_rccl.GetUniqueId(&id));
+    memset(id_out, 0, PAA_COMM_ID_BYTES);
+    memcpy(id_out, &id, sizeof(id));
+    return PAA_OK;
+}
+
+extern "C" int paa_comm_init(int world_size, int rank, const void *id_bytes) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if ((rc = rccl_load())) return rc;
+    if (!id_bytes || world_size < 1 || rank < 0 || rank >= world_size) return fail(PAA_ERR_ARG, "bad comm arguments");
+    if (g_comm) paa_comm_destroy();
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof(id));
+    NCCL_TRY(g_rccl.CommInitRank(&g_comm, world_size, id, rank));
+    g_world = world_size;
+    g_rank = rank;
+    HIP_TRY(hipMalloc((void **)&g_bar, sizeof(int)));
+    HIP_TRY(hipMemset(g_bar, 0, sizeof(int)));
+    return PAA_OK;
+}
+
+extern "C" int paa_comm_destroy(void) {
+    if (g_comm) {
+        if (g_stream) (void)hipStreamSynchronize(g_stream);
+        g_rccl.CommDestroy(g_comm);
+        g_comm = nullptr;
+    }
+    if (g_bar) { (void)hipFree(g_bar); g_bar = nullptr; }
+    g_world = 1;
+    g_rank = 0;
+    return PAA_OK;
+}
+
+extern "C" int paa_comm_gather_f64(const double *d_send, const int64_t *counts, int root, double *d_recv) {
+    if (!counts) return fail(PAA_ERR_ARG, "null counts");
+    if (!g_comm) {
+        if (g_world != 1) return fail(PAA_ERR_COMM, "communicator not initialised");
+        if (d_recv && d_send && d_recv != d_send)
+            HIP_TRY(hipMemcpyAsync(d_recv, d_send, (size_t)counts[0] * 8, hipMemcpyDeviceToDevice, g_stream));
+        return PAA_OK;
+    }
+    NCCL_TRY(g_rccl.GroupStart());
+    if (g_rank == root) {
+        long long off = 0;
+        for (int r = 0; r < g_world; ++r) {
+            if (r != root && counts[r] > 0)
+                NCCL_TRY(g_rccl.Recv(d_recv + off, (size_t)counts[r], ncclDouble, r, g_comm, g_stream));
+            off += counts[r];
+        }
+    } else if (counts[g_rank] > 0) {
+        NCCL_TRY(g_rccl.Send(d_send, (size_t)counts[g_rank], ncclDouble, root, g_comm, g_stream));
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
+    if (g_rank == root && d_send && counts[root] > 0) {
+        long long off = 0;
+        for (int r = 0; r < root; ++r) off += counts[r];
+        if (d_recv + off != d_send)
+            HIP_TRY(hipMemcpyAsync(d_recv + off, d_send, (size_t)counts[root] * 8, hipMemcpyDeviceToDevice, g_stream));
+    }
+    return PAA_OK;
+}
+
+extern "C" int paa_comm_barrier(void) {
+    if (!g_comm) return PAA_OK;
+    NCCL_TRY(g_rccl.AllReduce(g_bar, g_bar, 1, ncclInt, ncclSum, g_comm, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return PAA_OK;
+}

@@ -1,0 +1,145 @@
+// Shared device-side definitions: plan / clip descriptors, wave reductions, small DFTs.
+// gfx950 only: wavefront = 64 lanes, every workgroup of the feature kernels is ONE wave, so
+// __syncthreads() is an LDS/VMEM wait plus a one-wave barrier.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace paa {
+
+constexpr int kWave = 64;
+constexpr int kBase = 34;          // base feature rows (ShortTermFeatures.py:580-585)
+constexpr int kFlush = 8;          // frames staged in LDS before a row-segment store
+constexpr double kEps = 2.220446049250313e-16;   // sys.float_info.epsilon (ShortTermFeatures.py:11)
+
+struct ClipDev {        // one per clip, built on the host
+    long long sample_off;   // first sample in the packed buffer
+    long long n;            // samples
+    long long out_off;      // start of the [F][T] slab in the output (doubles)
+    int T;                  // frames
+    int stat_first;         // first statistics chunk of this clip
+    int stat_count;
+    int pad;
+};
+
+struct ClipNorm {       // written by clip_params_kernel
+    double mean;        // mean(x / 2^15)
+    double inv;         // 1 / (max|x/2^15 - mean| + 1e-10)
+};
+
+struct Tile {           // a run of consecutive frames of one clip = one workgroup
+    int clip;
+    int t0;
+    int cnt;
+    int pad;
+};
+
+struct StatChunk {      // a span of samples of one clip = one workgroup of clip_stats_kernel
+    long long start;    // absolute sample index in the packed buffer
+    int len;
+    int clip;
+};
+
+struct PlanDev {
+    int W, S, Nf, Nc, even;
+    int n_pass;
+    int radix[24];
+    const double2 *tw;      // Nc
+    const double2 *post;    // Nc (even only)
+    const int *mel_lo, *mel_cnt, *mel_off;
+    const double *mel_w;
+    const double *dct;      // 13 x 40
+    const int *ch_start;    // 13
+    const int *ch_src;
+    const double *ch_w;
+    double fs;
+    int deltas;
+    int F;                  // 34 or 68
+    int blk_t;              // floor(W / 10)
+    int blk_f;              // floor(Nf / 10)
+    int mode;               // 0 features, 1 spectrogram, 2 chromagram
+    int frame_origin;       // first frame starts at this sample (0; W for spectrogram/chromagram)
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// inclusive prefix sum across the wave
+__device__ __forceinline__ double wave_scan_incl(double v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        double u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+// a - i*b and a + i*b
+__device__ __forceinline__ double2 sub_i(double2 a, double2 b) { return make_double2(a.x + b.y, a.y - b.x); }
+__device__ __forceinline__ double2 add_i(double2 a, double2 b) { return make_double2(a.x - b.y, a.y + b.x); }
+
+__device__ __forceinline__ void dft2(double2 *v) {
+    double2 a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+}
+__device__ __forceinline__ void dft3(double2 *v) {
+    const double h = 0.86602540378443864676;   // sin(pi/3)
+    double2 t = cadd(v[1], v[2]);
+    double2 m = make_double2(v[0].x - 0.5 * t.x, v[0].y - 0.5 * t.y);
+    double2 n = make_double2(h * (v[1].x - v[2].x), h * (v[1].y - v[2].y));
+    v[0] = cadd(v[0], t);
+    v[1] = sub_i(m, n);
+    v[2] = add_i(m, n);
+}
+__device__ __forceinline__ void dft4(double2 *v) {
+    double2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+    double2 t2 = cadd(v[1], v[3]), t3 = csub(v[1], v[3]);
+    v[0] = cadd(t0, t2);
+    v[2] = csub(t0, t2);
+    v[1] = sub_i(t1, t3);
+    v[3] = add_i(t1, t3);
+}
+__device__ __forceinline__ void dft5(double2 *v) {
+    const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+    const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
+    double2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]);
+    double2 t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+    double2 m1 = make_double2(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
+    double2 m2 = make_double2(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
+    double2 n1 = make_double2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+    double2 n2 = make_double2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+    v[0] = make_double2(v[0].x + t1.x + t2.x, v[0].y + t1.y + t2.y);
+    v[1] = sub_i(m1, n1);
+    v[4] = add_i(m1, n1);
+    v[2] = sub_i(m2, n2);
+    v[3] = add_i(m2, n2);
+}
+
+template <typename T> __device__ __forceinline__ double load_sample(const T *p);
+template <> __device__ __forceinline__ double load_sample<int16_t>(const int16_t *p) { return (double)(*p); }
+template <> __device__ __forceinline__ double load_sample<double>(const double *p) { return *p; }
+
+}  // namespace paa

@@ -1,0 +1,150 @@
+// Auxiliary kernels: clip statistics (clip-global normalisation constants) and mid-term statistics.
+#pragma once
+#include <float.h>
+
+#include "device_common.hpp"
+
+namespace paa {
+
+// ---- clip statistics: replaces the two full passes of dc_normalize (ShortTermFeatures.py:14-19)
+// and the /2^15 scaling (:567-568) with one streaming read.  Block b reduces chunk b to
+// (sum, min, max); int16 sums are exact in int64, so the clip mean is bit-identical to NumPy's.
+template <typename T> struct StatAcc;
+template <> struct StatAcc<int16_t> { typedef long long sum_t; };
+template <> struct StatAcc<double> { typedef double sum_t; };
+
+__global__ __launch_bounds__(256) void clip_stats_i16_kernel(const int16_t *__restrict__ sig,
+                                                              const StatChunk *__restrict__ chunks,
+                                                              long long *__restrict__ psum,
+                                                              int *__restrict__ pmin, int *__restrict__ pmax) {
+    const StatChunk ch = chunks[blockIdx.x];
+    const int tid = threadIdx.x;
+    const long long a0 = ch.start, a1 = ch.start + ch.len;
+    // 16-byte aligned body [b0, b1), scalar head/tail
+    long long b0 = (a0 + 7) & ~7LL;
+    if (b0 > a1) b0 = a1;
+    const long long b1 = b0 + ((a1 - b0) & ~7LL);
+    long long s = 0;
+    int mn = 32767, mx = -32768;
+    for (long long i = a0 + tid; i < b0; i += 256) { const int v = sig[i]; s += v; mn = min(mn, v); mx = max(mx, v); }
+    for (long long i = b1 + tid; i < a1; i += 256) { const int v = sig[i]; s += v; mn = min(mn, v); mx = max(mx, v); }
+    const int4 *body = reinterpret_cast<const int4 *>(sig + b0);
+    const long long nvec = (b1 - b0) >> 3;
+    int s32 = 0;
+    for (long long i = tid; i < nvec; i += 256) {
+        const int4 q = body[i];
+        const int w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lo = (int)(short)(w[j] & 0xffff), hi = w[j] >> 16;
+            s32 += lo + hi;
+            mn = min(mn, min(lo, hi));
+            mx = max(mx, max(lo, hi));
+        }
+    }
+    s += s32;
+    __shared__ long long ss[4];
+    __shared__ int smn[4], smx[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        mn = min(mn, __shfl_xor(mn, o, 64));
+        mx = max(mx, __shfl_xor(mx, o, 64));
+    }
+    if ((tid & 63) == 0) { ss[tid >> 6] = s; smn[tid >> 6] = mn; smx[tid >> 6] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+        psum[blockIdx.x] = ss[0] + ss[1] + ss[2] + ss[3];
+        pmin[blockIdx.x] = min(min(smn[0], smn[1]), min(smn[2], smn[3]));
+        pmax[blockIdx.x] = max(max(smx[0], smx[1]), max(smx[2], smx[3]));
+    }
+}
+
+__global__ __launch_bounds__(256) void clip_stats_f64_kernel(const double *__restrict__ sig,
+                                                              const StatChunk *__restrict__ chunks,
+                                                              double *__restrict__ psum,
+                                                              double *__restrict__ pmin, double *__restrict__ pmax) {
+    const StatChunk ch = chunks[blockIdx.x];
+    const int tid = threadIdx.x;
+    double s = 0.0, mn = DBL_MAX, mx = -DBL_MAX;
+    for (long long i = ch.start + tid; i < ch.start + ch.len; i += 256) {
+        const double v = sig[i];
+        s += v; mn = fmin(mn, v); mx = fmax(mx, v);
+    }
+    __shared__ double ss[4], smn[4], smx[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        mn = fmin(mn, __shfl_xor(mn, o, 64));
+        mx = fmax(mx, __shfl_xor(mx, o, 64));
+    }
+    if ((tid & 63) == 0) { ss[tid >> 6] = s; smn[tid >> 6] = mn; smx[tid >> 6] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+        psum[blockIdx.x] = (ss[0] + ss[1]) + (ss[2] + ss[3]);
+        pmin[blockIdx.x] = fmin(fmin(smn[0], smn[1]), fmin(smn[2], smn[3]));
+        pmax[blockIdx.x] = fmax(fmax(smx[0], smx[1]), fmax(smx[2], smx[3]));
+    }
+}
+
+// one thread per clip: fold the chunk partials in order, derive (mean, 1/(max|x-mean| + 1e-10))
+template <typename SumT, typename MmT>
+__global__ void clip_params_kernel(const ClipDev *__restrict__ clips, long long n_clips,
+                                   const SumT *__restrict__ psum, const MmT *__restrict__ pmin,
+                                   const MmT *__restrict__ pmax, ClipNorm *__restrict__ norms) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_clips) return;
+    const ClipDev cd = clips[c];
+    SumT s = 0;
+    double mn = DBL_MAX, mx = -DBL_MAX;
+    for (int i = 0; i < cd.stat_count; ++i) {
+        s += psum[cd.stat_first + i];
+        mn = fmin(mn, (double)pmin[cd.stat_first + i]);
+        mx = fmax(mx, (double)pmax[cd.stat_first + i]);
+    }
+    const double sc = 1.0 / 32768.0;
+    ClipNorm nm;
+    if (cd.n <= 0) { nm.mean = 0.0; nm.inv = 1.0; norms[c] = nm; return; }
+    nm.mean = ((double)s * sc) / (double)cd.n;
+    const double peak = fmax(fabs(fma(mx, sc, -nm.mean)), fabs(fma(mn, sc, -nm.mean)));
+    nm.inv = 1.0 / (peak + 1e-10);
+    norms[c] = nm;
+}
+
+// ---- mid-term statistics (MidTermFeatures.py:110-126): mean and population std of every
+// short-term row over windows [m*step, min(m*step+ratio, T)), then nan_to_num.
+__device__ __forceinline__ double nan_to_num(double v) {
+    if (isnan(v)) return 0.0;
+    if (isinf(v)) return v > 0 ? DBL_MAX : -DBL_MAX;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void mid_stats_kernel(const ClipDev *__restrict__ clips,
+                                                         const long long *__restrict__ mid_off,
+                                                         const double *__restrict__ st, int nrows,
+                                                         long long ratio, long long step, int blocks_per_clip,
+                                                         double *__restrict__ mid) {
+    const long long c = blockIdx.x / blocks_per_clip;
+    const int chunk = blockIdx.x % blocks_per_clip;
+    const ClipDev cd = clips[c];
+    const long long T = cd.T;
+    const long long M = (T + step - 1) / step;
+    const long long idx = (long long)chunk * 256 + threadIdx.x;
+    if (idx >= (long long)nrows * M) return;
+    const long long row = idx / M, m = idx % M;
+    const double *x = st + cd.out_off + row * T;
+    const long long b = m * step;
+    long long e = b + ratio;
+    if (e > T) e = T;
+    double s = 0.0;
+    for (long long i = b; i < e; ++i) s += x[i];
+    const double n = (double)(e - b);
+    const double mean = s / n;
+    double v = 0.0;
+    for (long long i = b; i < e; ++i) { const double d = x[i] - mean; v = fma(d, d, v); }
+    double *o = mid + mid_off[c];
+    o[row * M + m] = nan_to_num(mean);
+    o[(row + nrows) * M + m] = nan_to_num(sqrt(v / n));
+}
+
+}  // namespace paa

@@ -1,0 +1,826 @@
+// libpaa_hip.so -- C ABI (include/paa_hip.h) over the gfx950 kernels.
+// Host side: table cache, plans (tile lists, clip descriptors), scratch buffers, stream.
+// There is deliberately NO CPU compute path in this library.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/paa_hip.h"
+#include "kernels_aux.hpp"
+#include "kernels_fast.hpp"
+#include "kernels_generic.hpp"
+#include "tables.hpp"
+
+using namespace paa;
+
+// ------------------------------------------------------------------------------------------
+// error handling
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? PAA_ERR_OOM : PAA_ERR_HIP, "%s: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                    \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// global state (one process drives one GPU)
+// ------------------------------------------------------------------------------------------
+struct TableSet {
+    double fs;
+    int window;
+    FftPlan fft;
+    MelTable mel;
+    ChromaTable chroma;
+    // device copies
+    double2 *d_tw = nullptr, *d_post = nullptr;
+    int *d_mel_lo = nullptr, *d_mel_cnt = nullptr, *d_mel_off = nullptr;
+    double *d_mel_w = nullptr, *d_dct = nullptr;
+    int *d_ch_start = nullptr, *d_ch_src = nullptr;
+    double *d_ch_w = nullptr;
+    FastTables fast;        // extra tables of the specialised kernels (may be empty)
+};
+
+struct Scratch {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+static std::mutex g_mu;
+static int g_device = -1;
+static hipStream_t g_stream = nullptr;
+static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+static std::map<std::pair<double, int>, std::unique_ptr<TableSet>> g_tables;
+static Scratch g_in, g_out, g_mid;
+static int g_force_generic = 0;
+// optional per-launch timing of the feature kernel (bench.py's roofline leg)
+static int g_prof = 0;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev;
+static size_t g_prof_used = 0;
+static double g_prof_ms = 0.0;
+static long long g_prof_n = 0;
+
+static int ensure_init() {
+    if (g_device >= 0) return PAA_OK;
+    return paa_init(0);
+}
+
+template <typename T>
+static int upload(T **dst, const void *src, size_t count) {
+    *dst = nullptr;
+    if (count == 0) count = 1;
+    HIP_TRY(hipMalloc((void **)dst, count * sizeof(T)));
+    if (src) HIP_TRY(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return PAA_OK;
+}
+
+static int scratch_reserve(Scratch &s, size_t bytes) {
+    if (bytes <= s.cap) return PAA_OK;
+    if (s.p) { (void)hipFree(s.p); s.p = nullptr; s.cap = 0; }
+    size_t want = bytes + bytes / 8 + 4096;
+    HIP_TRY(hipMalloc(&s.p, want));
+    s.cap = want;
+    return PAA_OK;
+}
+
+static void free_tables(TableSet &t) {
+    (void)hipFree(t.d_tw); (void)hipFree(t.d_post); (void)hipFree(t.d_mel_lo); (void)hipFree(t.d_mel_cnt);
+    (void)hipFree(t.d_mel_off); (void)hipFree(t.d_mel_w); (void)hipFree(t.d_dct); (void)hipFree(t.d_ch_start);
+    (void)hipFree(t.d_ch_src); (void)hipFree(t.d_ch_w);
+    fast_tables_free(t.fast);
+}
+
+// builds (or fetches) the tables of one (fs, window); need_feat = 0 for the spectrogram
+static int get_tables(double fs, int window, bool need_mel, bool need_chroma, TableSet **out) {
+    auto key = std::make_pair(fs, window);
+    auto it = g_tables.find(key);
+    if (it == g_tables.end()) {
+        std::unique_ptr<TableSet> t(new TableSet());
+        t->fs = fs;
+        t->window = window;
+        build_fft_plan(window, t->fft);
+        int rc;
+        if ((rc = upload(&t->d_tw, t->fft.tw.data(), t->fft.tw.size() / 2))) return rc;
+        if ((rc = upload(&t->d_post, t->fft.post.data(), t->fft.post.size() / 2))) return rc;
+        double dct[kNumMfcc * kNumMel];
+        build_dct(dct);
+        if ((rc = upload(&t->d_dct, dct, (size_t)kNumMfcc * kNumMel))) return rc;
+        it = g_tables.emplace(key, std::move(t)).first;
+    }
+    TableSet *t = it->second.get();
+    const int nfft = window / 2;
+    if (need_mel && !t->d_mel_w) {
+        int rc = build_mel(fs, nfft, t->mel);
+        if (rc == PAA_ERR_MEL_INDEX)
+            return fail(rc, "mel filter bank indexes bin >= num_fft=%d at fs=%g (IndexError in the reference, "
+                            "ShortTermFeatures.py:230-231)", nfft, fs);
+        if ((rc = upload(&t->d_mel_lo, t->mel.lo.data(), t->mel.lo.size()))) return rc;
+        if ((rc = upload(&t->d_mel_cnt, t->mel.cnt.data(), t->mel.cnt.size()))) return rc;
+        if ((rc = upload(&t->d_mel_off, t->mel.off.data(), t->mel.off.size()))) return rc;
+        if ((rc = upload(&t->d_mel_w, t->mel.w.data(), t->mel.w.size()))) return rc;
+    }
+    if (need_chroma && !t->d_ch_w) {
+        int rc = build_chroma(fs, nfft, t->chroma);
+        if (rc == PAA_ERR_CHROMA_VALUE)
+            return fail(rc, "shape mismatch: chroma slot exceeds num_fft=%d (ValueError in the reference, "
+                            "ShortTermFeatures.py:293)", nfft);
+        if (rc == PAA_ERR_CHROMA_INDEX)
+            return fail(rc, "chroma slot out of bounds for num_fft=%d (IndexError in the reference, "
+                            "ShortTermFeatures.py:291)", nfft);
+        if ((rc = upload(&t->d_ch_start, t->chroma.class_start, 13))) return rc;
+        if ((rc = upload(&t->d_ch_src, t->chroma.src.data(), t->chroma.src.size()))) return rc;
+        if ((rc = upload(&t->d_ch_w, t->chroma.w.data(), t->chroma.w.size()))) return rc;
+    }
+    *out = t;
+    return PAA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// plans
+// ------------------------------------------------------------------------------------------
+constexpr int kStatChunk = 65536;
+
+struct paa_plan {
+    long long n_clips = 0;
+    int sample_kind = 0;
+    int mode = 0;                   // 0 features, 1 spectrogram, 2 chromagram
+    int row_width = 0;              // doubles per frame of the slab in modes 1/2
+    std::vector<ClipDev> clips;
+    std::vector<long long> alloc_rows;   // modes 1/2: rows the reference allocates per clip
+    long long total_frames = 0, out_doubles = 0;
+    TableSet *tab = nullptr;
+    PlanDev P;
+    ClipDev *d_clips = nullptr;
+    ClipNorm *d_norms = nullptr;
+    Tile *d_tiles = nullptr;
+    StatChunk *d_chunks = nullptr;
+    void *d_psum = nullptr, *d_pmin = nullptr, *d_pmax = nullptr;
+    long long *d_mid_off = nullptr;
+    long long mid_off_step = -1;
+    long long n_tiles = 0, n_chunks = 0;
+    size_t lds = 0;
+    int fast = 0;                    // 1: specialised kernel
+    FastLaunch fl;
+    std::string kernel_name;
+};
+
+static void plan_free(paa_plan *p) {
+    if (!p) return;
+    (void)hipFree(p->d_clips); (void)hipFree(p->d_norms); (void)hipFree(p->d_tiles); (void)hipFree(p->d_chunks);
+    (void)hipFree(p->d_psum); (void)hipFree(p->d_pmin); (void)hipFree(p->d_pmax); (void)hipFree(p->d_mid_off);
+    delete p;
+}
+
+static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, double fs, int window, int step,
+                      int deltas, int mode, paa_plan **out) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!offsets || n_clips < 1 || !out) return fail(PAA_ERR_ARG, "null offsets / no clips");
+    if (window < 2 || step < 1) return fail(PAA_ERR_ARG, "window=%d step=%d: need window >= 2, step >= 1", window, step);
+    if (sample_kind != 0 && sample_kind != 1) return fail(PAA_ERR_ARG, "sample_kind must be 0 (int16) or 1 (float64)");
+    if (!(fs > 0)) return fail(PAA_ERR_ARG, "sampling rate must be positive");
+    std::unique_ptr<paa_plan, void (*)(paa_plan *)> p(new paa_plan(), plan_free);
+    p->n_clips = n_clips;
+    p->sample_kind = sample_kind;
+    p->mode = mode;
+    TableSet *tab = nullptr;
+    if ((rc = get_tables(fs, window, mode == 0, mode != 1, &tab))) return rc;
+    p->tab = tab;
+    const int Nf = window / 2;
+    const int F = (mode == 0) ? kBase * (deltas ? 2 : 1) : 0;
+    p->row_width = (mode == 1) ? Nf : (mode == 2 ? 12 : 0);
+
+    // ---- clips
+    p->clips.resize(n_clips);
+    p->alloc_rows.assign(n_clips, 0);
+    long long out_off = 0, total_frames = 0, n_chunks = 0;
+    for (int64_t c = 0; c < n_clips; ++c) {
+        const long long n = offsets[c + 1] - offsets[c];
+        if (n < 0) return fail(PAA_ERR_ARG, "offsets must be non-decreasing (clip %lld)", (long long)c);
+        ClipDev &cd = p->clips[c];
+        cd.sample_off = offsets[c];
+        cd.n = n;
+        cd.out_off = out_off;
+        long long T = 0, rows = 0;
+        if (mode == 0) {
+            T = paa_num_frames(n, window, step);
+            if (T < 1)
+                return fail(PAA_ERR_TOO_SHORT, "need at least one array to concatenate (clip %lld has %lld samples, "
+                            "window %d)", (long long)c, n, window);
+            rows = T;
+            out_off += (long long)F * T;
+        } else {
+            int64_t filled = 0;
+            rows = (mode == 1) ? paa_spectrogram_rows(n, window, step, &filled)
+                               : paa_chromagram_rows(n, window, step, &filled);
+            if (rows < 1)
+                return fail(PAA_ERR_TOO_SHORT, "signal too short for window %d / step %d (clip %lld, %lld samples)",
+                            window, step, (long long)c, n);
+            // full-length frames only; a truncated chromagram tail frame is added by the caller
+            long long full = 0;
+            for (long long pos = window; pos + window <= n && full < filled; pos += step) ++full;
+            T = full;
+            out_off += rows * p->row_width;
+        }
+        if (T > 0x7fffffffLL) return fail(PAA_ERR_ARG, "clip %lld has too many frames", (long long)c);
+        p->alloc_rows[c] = rows;
+        cd.T = (int)T;
+        cd.stat_first = (int)n_chunks;
+        cd.stat_count = (int)((n + kStatChunk - 1) / kStatChunk);
+        cd.pad = 0;
+        n_chunks += cd.stat_count;
+        total_frames += T;
+    }
+    p->total_frames = total_frames;
+    p->out_doubles = out_off;
+    p->n_chunks = n_chunks;
+
+    // ---- device plan
+    PlanDev &P = p->P;
+    memset(&P, 0, sizeof(P));
+    P.W = window; P.S = step; P.Nf = Nf; P.Nc = tab->fft.len; P.even = tab->fft.even;
+    P.n_pass = (int)tab->fft.radix.size();
+    if (P.n_pass > 24) return fail(PAA_ERR_UNSUPPORTED, "window %d needs more than 24 FFT passes", window);
+    for (int i = 0; i < P.n_pass; ++i) P.radix[i] = tab->fft.radix[i];
+    P.tw = tab->d_tw; P.post = tab->d_post;
+    P.mel_lo = tab->d_mel_lo; P.mel_cnt = tab->d_mel_cnt; P.mel_off = tab->d_mel_off; P.mel_w = tab->d_mel_w;
+    P.dct = tab->d_dct; P.ch_start = tab->d_ch_start; P.ch_src = tab->d_ch_src; P.ch_w = tab->d_ch_w;
+    P.fs = fs; P.deltas = deltas ? 1 : 0; P.F = F;
+    P.blk_t = window / 10; P.blk_f = Nf / 10;
+    P.mode = mode;
+    P.frame_origin = (mode == 0) ? 0 : window;
+
+    // ---- kernel choice + tiles
+    p->fast = 0;
+    if (mode == 0 && !g_force_generic) {
+        rc = fast_select(window, step, sample_kind, fs, tab->fast, tab->fft, p->fl);
+        if (rc < 0) return fail(rc, "building the tables of the specialised kernel failed");
+        p->fast = rc;
+    }
+    int run;
+    if (p->fast) {
+        run = p->fl.run;
+        p->lds = p->fl.lds;
+        p->kernel_name = p->fl.name;
+    } else {
+        p->lds = generic_lds_bytes(P.Nc, Nf, F > 0 ? F : 1);
+        if (p->lds > 160 * 1024)
+            return fail(PAA_ERR_UNSUPPORTED, "window %d needs %zu bytes of LDS (> 160 KiB)", window, p->lds);
+        run = 32;
+        while (run > 4 && total_frames / run < 4096) run /= 2;
+        p->kernel_name = (mode == 0) ? "st_generic" : (mode == 1 ? "spectrogram_generic" : "chromagram_generic");
+    }
+    std::vector<Tile> tiles;
+    tiles.reserve((size_t)(total_frames / run + n_clips));
+    for (int64_t c = 0; c < n_clips; ++c)
+        for (int t0 = 0; t0 < p->clips[c].T; t0 += run) {
+            Tile tl; tl.clip = (int)c; tl.t0 = t0; tl.cnt = std::min(run, p->clips[c].T - t0); tl.pad = 0;
+            tiles.push_back(tl);
+        }
+    p->n_tiles = (long long)tiles.size();
+    std::vector<StatChunk> chunks;
+    chunks.reserve((size_t)n_chunks);
+    for (int64_t c = 0; c < n_clips; ++c)
+        for (int i = 0; i < p->clips[c].stat_count; ++i) {
+            StatChunk ch; ch.start = p->clips[c].sample_off + (long long)i * kStatChunk;
+            ch.len = (int)std::min<long long>(kStatChunk, p->clips[c].n - (long long)i * kStatChunk);
+            ch.clip = (int)c;
+            chunks.push_back(ch);
+        }
+    if ((rc = upload(&p->d_clips, p->clips.data(), p->clips.size()))) return rc;
+    if ((rc = upload(&p->d_tiles, tiles.data(), tiles.size()))) return rc;
+    if ((rc = upload(&p->d_chunks, chunks.data(), chunks.size()))) return rc;
+    if ((rc = upload(&p->d_norms, (const void *)nullptr, (size_t)n_clips))) return rc;
+    const size_t nch = (size_t)std::max<long long>(n_chunks, 1);
+    HIP_TRY(hipMalloc(&p->d_psum, nch * 8));
+    HIP_TRY(hipMalloc(&p->d_pmin, nch * 8));
+    HIP_TRY(hipMalloc(&p->d_pmax, nch * 8));
+    *out = p.release();
+    return PAA_OK;
+}
+
+static int launch_stats(paa_plan *p, const void *d_packed) {
+    if (p->n_chunks > 0) {
+        if (p->sample_kind == 0)
+            hipLaunchKernelGGL(clip_stats_i16_kernel, dim3((unsigned)p->n_chunks), dim3(256), 0, g_stream,
+                               (const int16_t *)d_packed, p->d_chunks, (long long *)p->d_psum, (int *)p->d_pmin,
+                               (int *)p->d_pmax);
+        else
+            hipLaunchKernelGGL(clip_stats_f64_kernel, dim3((unsigned)p->n_chunks), dim3(256), 0, g_stream,
+                               (const double *)d_packed, p->d_chunks, (double *)p->d_psum, (double *)p->d_pmin,
+                               (double *)p->d_pmax);
+    }
+    const unsigned gb = (unsigned)((p->n_clips + 255) / 256);
+    if (p->sample_kind == 0)
+        hipLaunchKernelGGL((clip_params_kernel<long long, int>), dim3(gb), dim3(256), 0, g_stream, p->d_clips,
+                           p->n_clips, (const long long *)p->d_psum, (const int *)p->d_pmin, (const int *)p->d_pmax,
+                           p->d_norms);
+    else
+        hipLaunchKernelGGL((clip_params_kernel<double, double>), dim3(gb), dim3(256), 0, g_stream, p->d_clips,
+                           p->n_clips, (const double *)p->d_psum, (const double *)p->d_pmin,
+                           (const double *)p->d_pmax, p->d_norms);
+    HIP_TRY(hipGetLastError());
+    return PAA_OK;
+}
+
+template <typename T>
+static int launch_generic(paa_plan *p, const void *d_packed, double *d_out) {
+    static size_t attr_set = 0;
+    if (p->lds > 64 * 1024 && p->lds > attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&st_generic_kernel<T>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds));
+        attr_set = p->lds;
+    }
+    hipLaunchKernelGGL(st_generic_kernel<T>, dim3((unsigned)p->n_tiles), dim3(64), p->lds, g_stream, p->P,
+                       (const T *)d_packed, p->d_clips, p->d_norms, p->d_tiles, d_out);
+    HIP_TRY(hipGetLastError());
+    return PAA_OK;
+}
+
+extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *d_out) {
+    if (!plan || !d_packed || !d_out) return fail(PAA_ERR_ARG, "null plan / buffer");
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = launch_stats(plan, d_packed);
+    if (rc) return rc;
+    if (plan->n_tiles == 0) return PAA_OK;
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    if (g_prof) {
+        if (g_prof_used == g_prof_ev.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            g_prof_ev.emplace_back(a, b);
+        }
+        pe0 = g_prof_ev[g_prof_used].first;
+        pe1 = g_prof_ev[g_prof_used].second;
+        ++g_prof_used;
+        HIP_TRY(hipEventRecord(pe0, g_stream));
+    }
+    struct StopEv { hipEvent_t e; ~StopEv() { if (e) (void)hipEventRecord(e, g_stream); } } stop_ev{pe1};
+    if (plan->fast) {
+        rc = fast_launch(plan->fl, plan->P, plan->tab->fast, d_packed, plan->d_clips, plan->d_norms, plan->d_tiles,
+                         plan->n_tiles, d_out, g_stream);
+        if (rc) return fail(PAA_ERR_HIP, "launch of %s failed: %s", plan->kernel_name.c_str(),
+                            hipGetErrorString(hipGetLastError()));
+        return PAA_OK;
+    }
+    return plan->sample_kind == 0 ? launch_generic<int16_t>(plan, d_packed, d_out)
+                                  : launch_generic<double>(plan, d_packed, d_out);
+}
+
+extern "C" int paa_plan_create(const int64_t *offsets, int64_t n_clips, int sample_kind, double fs, int window,
+                               int step, int deltas, paa_plan_t **out_plan) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return plan_build(offsets, n_clips, sample_kind, fs, window, step, deltas, 0, out_plan);
+}
+
+extern "C" int paa_plan_destroy(paa_plan_t *plan) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    plan_free(plan);
+    return PAA_OK;
+}
+
+extern "C" int64_t paa_plan_total_frames(const paa_plan_t *plan) { return plan ? plan->total_frames : 0; }
+extern "C" int64_t paa_plan_out_doubles(const paa_plan_t *plan) { return plan ? plan->out_doubles : 0; }
+extern "C" const char *paa_plan_kernel_name(const paa_plan_t *plan) { return plan ? plan->kernel_name.c_str() : ""; }
+
+extern "C" int paa_plan_out_offsets(const paa_plan_t *plan, int64_t *out_offsets) {
+    if (!plan || !out_offsets) return fail(PAA_ERR_ARG, "null plan / buffer");
+    for (long long c = 0; c < plan->n_clips; ++c) out_offsets[c] = plan->clips[c].out_off;
+    return PAA_OK;
+}
+
+extern "C" int64_t paa_plan_mid_doubles(const paa_plan_t *plan, int64_t mid_step_ratio) {
+    if (!plan || mid_step_ratio < 1) return 0;
+    long long tot = 0;
+    for (long long c = 0; c < plan->n_clips; ++c)
+        tot += 2LL * plan->P.F * paa_num_mid_windows(plan->clips[c].T, mid_step_ratio);
+    return tot;
+}
+
+extern "C" int paa_plan_mid_execute(paa_plan_t *plan, const double *d_st, int64_t mid_ratio, int64_t mid_step_ratio,
+                                    double *d_mid) {
+    if (!plan || !d_st || !d_mid) return fail(PAA_ERR_ARG, "null plan / buffer");
+    if (plan->mode != 0) return fail(PAA_ERR_ARG, "mid-term statistics need a feature plan");
+    if (mid_step_ratio < 1)
+        return fail(PAA_ERR_ARG, "mid_step / short_step rounds to %lld: the reference loops forever "
+                    "(MidTermFeatures.py:102,124)", (long long)mid_step_ratio);
+    std::lock_guard<std::mutex> lk(g_mu);
+    long long maxM = 0;
+    if (plan->mid_off_step != mid_step_ratio) {
+        std::vector<long long> off(plan->n_clips);
+        long long o = 0;
+        for (long long c = 0; c < plan->n_clips; ++c) {
+            off[c] = o;
+            o += 2LL * plan->P.F * paa_num_mid_windows(plan->clips[c].T, mid_step_ratio);
+        }
+        if (g_stream) HIP_TRY(hipStreamSynchronize(g_stream));
+        (void)hipFree(plan->d_mid_off);
+        int rc = upload(&plan->d_mid_off, off.data(), off.size());
+        if (rc) return rc;
+        plan->mid_off_step = mid_step_ratio;
+    }
+    for (long long c = 0; c < plan->n_clips; ++c)
+        maxM = std::max<long long>(maxM, paa_num_mid_windows(plan->clips[c].T, mid_step_ratio));
+    const long long items = (long long)plan->P.F * maxM;
+    const int bpc = (int)((items + 255) / 256);
+    const long long grid = plan->n_clips * bpc;
+    if (grid > 0x7fffffffLL) return fail(PAA_ERR_UNSUPPORTED, "mid-term grid too large");
+    hipLaunchKernelGGL(mid_stats_kernel, dim3((unsigned)grid), dim3(256), 0, g_stream, plan->d_clips, plan->d_mid_off,
+                       d_st, plan->P.F, (long long)mid_ratio, (long long)mid_step_ratio, bpc, d_mid);
+    HIP_TRY(hipGetLastError());
+    return PAA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// library / device management
+// ------------------------------------------------------------------------------------------
+extern "C" const char *paa_version(void) { return "paa_hip 0.1 (gfx950)"; }
+extern "C" const char *paa_last_error(void) { return g_err; }
+
+extern "C" int paa_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(PAA_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+extern "C" int paa_init(int device_id) {
+    if (g_device == device_id && g_stream) return PAA_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n < 1)
+        return fail(PAA_ERR_HIP, "no HIP device (%s); this library has no CPU path", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(PAA_ERR_ARG, "device %d out of range (%d devices)", device_id, n);
+    if (g_device >= 0 && g_device != device_id) paa_shutdown();
+    HIP_TRY(hipSetDevice(device_id));
+    HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&g_ev0));
+    HIP_TRY(hipEventCreate(&g_ev1));
+    g_device = device_id;
+    const char *fg = getenv("PAA_HIP_FORCE_GENERIC");
+    g_force_generic = (fg && fg[0] == '1') ? 1 : 0;
+    return PAA_OK;
+}
+
+extern "C" void paa_shutdown(void) {
+    if (g_device < 0) return;
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    for (auto &kv : g_tables) free_tables(*kv.second);
+    g_tables.clear();
+    for (Scratch *s : {&g_in, &g_out, &g_mid}) { if (s->p) (void)hipFree(s->p); s->p = nullptr; s->cap = 0; }
+    if (g_ev0) (void)hipEventDestroy(g_ev0);
+    if (g_ev1) (void)hipEventDestroy(g_ev1);
+    if (g_stream) (void)hipStreamDestroy(g_stream);
+    g_ev0 = g_ev1 = nullptr;
+    g_stream = nullptr;
+    g_device = -1;
+}
+
+extern "C" int paa_dev_alloc(size_t bytes, void **out_ptr) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!out_ptr) return fail(PAA_ERR_ARG, "null out_ptr");
+    HIP_TRY(hipMalloc(out_ptr, bytes ? bytes : 1));
+    return PAA_OK;
+}
+extern "C" int paa_dev_free(void *ptr) {
+    if (ptr) HIP_TRY(hipFree(ptr));
+    return PAA_OK;
+}
+extern "C" int paa_memcpy_h2d(void *dst, const void *src, size_t bytes) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return PAA_OK;
+}
+extern "C" int paa_memcpy_d2h(void *dst, const void *src, size_t bytes) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return PAA_OK;
+}
+extern "C" int paa_dev_sync(void) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return PAA_OK;
+}
+extern "C" int paa_timer_start(void) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(g_ev0, g_stream));
+    return PAA_OK;
+}
+extern "C" int paa_timer_stop(float *ms) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(g_ev1, g_stream));
+    HIP_TRY(hipEventSynchronize(g_ev1));
+    HIP_TRY(hipEventElapsedTime(ms, g_ev0, g_ev1));
+    return PAA_OK;
+}
+
+extern "C" int paa_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_prof = on ? 1 : 0;
+    return PAA_OK;
+}
+// folds every recorded launch into (total ms, launches) and resets the recorder
+extern "C" int paa_prof_read(double *total_ms, int64_t *launches) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    for (size_t i = 0; i < g_prof_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, g_prof_ev[i].first, g_prof_ev[i].second));
+        g_prof_ms += ms;
+        ++g_prof_n;
+    }
+    g_prof_used = 0;
+    if (total_ms) *total_ms = g_prof_ms;
+    if (launches) *launches = g_prof_n;
+    g_prof_ms = 0.0;
+    g_prof_n = 0;
+    return PAA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// shape helpers
+// ------------------------------------------------------------------------------------------
+extern "C" int64_t paa_num_frames(int64_t n, int window, int step) {
+    if (window < 1 || step < 1 || n < window) return 0;
+    return (n - window) / step + 1;
+}
+extern "C" int64_t paa_num_mid_windows(int64_t T, int64_t mid_step_ratio) {
+    if (T < 1 || mid_step_ratio < 1) return 0;
+    return (T + mid_step_ratio - 1) / mid_step_ratio;
+}
+extern "C" int64_t paa_spectrogram_rows(int64_t n, int window, int step, int64_t *filled) {
+    if (filled) *filled = 0;
+    if (window < 1 || step < 1) return 0;
+    // int((n - window) / step) + 1 with Python's true division then truncation toward zero (:413)
+    const int64_t num = n - window;
+    const int64_t rows = (num >= 0 ? num / step : -((-num) / step)) + 1;
+    int64_t f = 0;
+    for (int64_t p = window; p < n - window + 1; p += step) ++f;      // range(window, n - window + 1, step) :415
+    if (filled) *filled = f;
+    return rows;
+}
+extern "C" int64_t paa_chromagram_rows(int64_t n, int window, int step, int64_t *filled) {
+    if (filled) *filled = 0;
+    if (window < 1 || step < 1) return 0;
+    const int64_t num = n - step - window;
+    const int64_t rows = (num >= 0 ? num / step : -((-num) / step)) + 1;   // :347
+    int64_t f = 0;
+    for (int64_t p = window; p < n - step; p += step) ++f;                // range(window, n - step, step) :349
+    if (filled) *filled = f;
+    return rows;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-buffer entry points
+// ------------------------------------------------------------------------------------------
+static int run_host_st(const void *packed, const int64_t *offsets, int64_t n_clips, int sample_kind, double fs,
+                       int window, int step, int deltas, double *out, const int64_t *out_offsets,
+                       int64_t mid_ratio, int64_t mid_step, double *mid_out, const int64_t *mid_out_offsets) {
+    if (!packed || !offsets) return fail(PAA_ERR_ARG, "null signal");
+    const bool want_mid = mid_out != nullptr;
+    if (want_mid && !deltas) return fail(PAA_ERR_ARG, "mid-term features are defined over the 68 delta rows");
+    if (want_mid && mid_step < 1)
+        return fail(PAA_ERR_ARG, "mid_step / short_step rounds to %lld: the reference loops forever "
+                    "(MidTermFeatures.py:102,124)", (long long)mid_step);
+    paa_plan *plan = nullptr;
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        rc = plan_build(offsets, n_clips, sample_kind, fs, window, step, deltas, 0, &plan);
+    }
+    if (rc) return rc;
+    std::unique_ptr<paa_plan, void (*)(paa_plan *)> guard(plan, plan_free);
+    const size_t esz = sample_kind == 0 ? 2 : 8;
+    const long long base = offsets[0], n_total = offsets[n_clips] - base;
+    // samples are uploaded from offsets[0]; rebase the clip offsets accordingly
+    if (base != 0) {
+        for (auto &cd : plan->clips) cd.sample_off -= base;
+        HIP_TRY(hipMemcpy(plan->d_clips, plan->clips.data(), plan->clips.size() * sizeof(ClipDev), hipMemcpyHostToDevice));
+        std::vector<StatChunk> chunks;
+        for (int64_t c = 0; c < n_clips; ++c)
+            for (int i = 0; i < plan->clips[c].stat_count; ++i) {
+                StatChunk ch; ch.start = plan->clips[c].sample_off + (long long)i * kStatChunk;
+                ch.len = (int)std::min<long long>(kStatChunk, plan->clips[c].n - (long long)i * kStatChunk);
+                ch.clip = (int)c;
+                chunks.push_back(ch);
+            }
+        if (!chunks.empty())
+            HIP_TRY(hipMemcpy(plan->d_chunks, chunks.data(), chunks.size() * sizeof(StatChunk), hipMemcpyHostToDevice));
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if ((rc = scratch_reserve(g_in, (size_t)n_total * esz + 64))) return rc;
+        if ((rc = scratch_reserve(g_out, (size_t)plan->out_doubles * 8))) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(g_in.p, (const char *)packed + (size_t)base * esz, (size_t)n_total * esz,
+                           hipMemcpyHostToDevice, g_stream));
+    if ((rc = paa_plan_execute(plan, g_in.p, (double *)g_out.p))) return rc;
+    if (want_mid) {
+        const long long md = paa_plan_mid_doubles(plan, mid_step);
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            if ((rc = scratch_reserve(g_mid, (size_t)md * 8))) return rc;
+        }
+        if ((rc = paa_plan_mid_execute(plan, (const double *)g_out.p, mid_ratio, mid_step, (double *)g_mid.p))) return rc;
+        // slabs are back to back in clip order on the device
+        long long o = 0;
+        for (int64_t c = 0; c < n_clips; ++c) {
+            const long long cnt = 2LL * plan->P.F * paa_num_mid_windows(plan->clips[c].T, mid_step);
+            double *dst = mid_out + (mid_out_offsets ? mid_out_offsets[c] : o);
+            HIP_TRY(hipMemcpyAsync(dst, (double *)g_mid.p + o, (size_t)cnt * 8, hipMemcpyDeviceToHost, g_stream));
+            o += cnt;
+        }
+    }
+    if (out) {
+        if (!out_offsets) {
+            HIP_TRY(hipMemcpyAsync(out, g_out.p, (size_t)plan->out_doubles * 8, hipMemcpyDeviceToHost, g_stream));
+        } else {
+            // coalesce runs of clips whose destination slabs are contiguous too
+            int64_t c = 0;
+            while (c < n_clips) {
+                int64_t e = c;
+                long long cnt = 0;
+                while (e < n_clips && out_offsets[e] - out_offsets[c] == plan->clips[e].out_off - plan->clips[c].out_off) {
+                    cnt = plan->clips[e].out_off - plan->clips[c].out_off + (long long)plan->P.F * plan->clips[e].T;
+                    ++e;
+                }
+                HIP_TRY(hipMemcpyAsync(out + out_offsets[c], (double *)g_out.p + plan->clips[c].out_off,
+                                       (size_t)cnt * 8, hipMemcpyDeviceToHost, g_stream));
+                c = e;
+            }
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return PAA_OK;
+}
+
+extern "C" int paa_st_features_i16(const int16_t *signal, int64_t n, double fs, int window, int step, int deltas,
+                                   double *out) {
+    if (!out) return fail(PAA_ERR_ARG, "null out");
+    const int64_t off[2] = {0, n};
+    return run_host_st(signal, off, 1, 0, fs, window, step, deltas, out, nullptr, 0, 0, nullptr, nullptr);
+}
+extern "C" int paa_st_features_f64(const double *signal, int64_t n, double fs, int window, int step, int deltas,
+                                   double *out) {
+    if (!out) return fail(PAA_ERR_ARG, "null out");
+    const int64_t off[2] = {0, n};
+    return run_host_st(signal, off, 1, 1, fs, window, step, deltas, out, nullptr, 0, 0, nullptr, nullptr);
+}
+extern "C" int paa_mid_features_i16(const int16_t *signal, int64_t n, double fs, int window, int step,
+                                    int64_t mid_ratio, int64_t mid_step_ratio, double *mid_out, double *st_out) {
+    if (!mid_out) return fail(PAA_ERR_ARG, "null mid_out");
+    const int64_t off[2] = {0, n};
+    return run_host_st(signal, off, 1, 0, fs, window, step, 1, st_out, nullptr, mid_ratio, mid_step_ratio, mid_out, nullptr);
+}
+extern "C" int paa_mid_features_f64(const double *signal, int64_t n, double fs, int window, int step,
+                                    int64_t mid_ratio, int64_t mid_step_ratio, double *mid_out, double *st_out) {
+    if (!mid_out) return fail(PAA_ERR_ARG, "null mid_out");
+    const int64_t off[2] = {0, n};
+    return run_host_st(signal, off, 1, 1, fs, window, step, 1, st_out, nullptr, mid_ratio, mid_step_ratio, mid_out, nullptr);
+}
+extern "C" int paa_st_features_batch_i16(const int16_t *packed, const int64_t *offsets, int64_t n_clips, double fs,
+                                         int window, int step, int deltas, double *out, const int64_t *out_offsets) {
+    if (!out) return fail(PAA_ERR_ARG, "null out");
+    return run_host_st(packed, offsets, n_clips, 0, fs, window, step, deltas, out, out_offsets, 0, 0, nullptr, nullptr);
+}
+extern "C" int paa_mid_features_batch_i16(const int16_t *packed, const int64_t *offsets, int64_t n_clips, double fs,
+                                          int window, int step, int64_t mid_ratio, int64_t mid_step_ratio,
+                                          double *mid_out, const int64_t *mid_out_offsets, double *st_out,
+                                          const int64_t *st_out_offsets) {
+    if (!mid_out) return fail(PAA_ERR_ARG, "null mid_out");
+    return run_host_st(packed, offsets, n_clips, 0, fs, window, step, 1, st_out, st_out_offsets, mid_ratio,
+                       mid_step_ratio, mid_out, mid_out_offsets);
+}
+
+// ---- spectrogram / chromagram ---------------------------------------------------------------
+#include "kernels_tail.hpp"
+
+static int run_host_spec(const void *signal, int64_t n, int sample_kind, double fs, int window, int step, int mode,
+                         double *out) {
+    if (!signal || !out) return fail(PAA_ERR_ARG, "null signal / out");
+    const int64_t off[2] = {0, n};
+    paa_plan *plan = nullptr;
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        rc = plan_build(off, 1, sample_kind, fs, window, step, 0, mode, &plan);
+    }
+    if (rc) return rc;
+    std::unique_ptr<paa_plan, void (*)(paa_plan *)> guard(plan, plan_free);
+    const size_t esz = sample_kind == 0 ? 2 : 8;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if ((rc = scratch_reserve(g_in, (size_t)n * esz + 64))) return rc;
+        if ((rc = scratch_reserve(g_out, (size_t)plan->out_doubles * 8))) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(g_in.p, signal, (size_t)n * esz, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemsetAsync(g_out.p, 0, (size_t)plan->out_doubles * 8, g_stream));   // trailing rows stay 0 (:413-422)
+    if ((rc = paa_plan_execute(plan, g_in.p, (double *)g_out.p))) return rc;
+    if (mode == 2) {
+        // the reference FFTs a truncated last frame when fewer than `window` samples remain (:349-355)
+        int64_t filled = 0;
+        paa_chromagram_rows(n, window, step, &filled);
+        if (filled > plan->clips[0].T) {
+            const long long pos = (long long)window + (long long)plan->clips[0].T * step;
+            // the shortest (last) truncated frame decides whether the reference can index X[0:num_fft]
+            const long long last_len = n - ((long long)window + (filled - 1) * step);
+            if (last_len < window / 2)
+                return fail(PAA_ERR_CHROMA_VALUE, "truncated last chromagram frame shorter than num_fft "
+                            "(ValueError in the reference, ShortTermFeatures.py:288)");
+            rc = launch_chroma_tail(plan->P, sample_kind, g_in.p, pos, n, (int)(filled - plan->clips[0].T), plan->d_norms,
+                                    (double *)g_out.p + (long long)plan->clips[0].T * 12, g_stream);
+            if (rc) return fail(PAA_ERR_HIP, "chromagram tail launch failed");
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(out, g_out.p, (size_t)plan->out_doubles * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return PAA_OK;
+}
+
+extern "C" int paa_spectrogram_i16(const int16_t *s, int64_t n, double fs, int w, int st, double *out) {
+    return run_host_spec(s, n, 0, fs, w, st, 1, out);
+}
+extern "C" int paa_spectrogram_f64(const double *s, int64_t n, double fs, int w, int st, double *out) {
+    return run_host_spec(s, n, 1, fs, w, st, 1, out);
+}
+extern "C" int paa_chromagram_i16(const int16_t *s, int64_t n, double fs, int w, int st, double *out) {
+    return run_host_spec(s, n, 0, fs, w, st, 2, out);
+}
+extern "C" int paa_chromagram_f64(const double *s, int64_t n, double fs, int w, int st, double *out) {
+    return run_host_spec(s, n, 1, fs, w, st, 2, out);
+}
+
+// ------------------------------------------------------------------------------------------
+// RCCL gather (one process per GPU; librccl is loaded lazily so CPU-only hosts can load us)
+// ------------------------------------------------------------------------------------------
+#include "comm_rccl.hpp"
+
+// ------------------------------------------------------------------------------------------
+// introspection for tests
+// ------------------------------------------------------------------------------------------
+extern "C" int paa_debug_mel_bank(double fs, int num_fft, double *out_dense) {
+    if (!out_dense || num_fft < 1) return fail(PAA_ERR_ARG, "bad argument");
+    MelTable t;
+    int rc = build_mel(fs, num_fft, t);
+    if (rc) return fail(rc, "mel filter bank indexes bin >= num_fft");
+    std::fill(out_dense, out_dense + (size_t)kNumMel * num_fft, 0.0);
+    for (int m = 0; m < kNumMel; ++m)
+        for (int i = 0; i < t.cnt[m]; ++i) out_dense[(size_t)m * num_fft + t.lo[m] + i] = t.w[t.off[m] + i];
+    return PAA_OK;
+}
+extern "C" int paa_debug_dct(double *out_13x40) {
+    if (!out_13x40) return fail(PAA_ERR_ARG, "null");
+    build_dct(out_13x40);
+    return PAA_OK;
+}
+extern "C" int paa_debug_chroma(double fs, int num_fft, int capacity, int32_t *src, double *weight, int32_t *slot) {
+    ChromaTable t;
+    int rc = build_chroma(fs, num_fft, t);
+    if (rc) return fail(rc, "chroma table error");
+    const int n = (int)t.flat_src.size();
+    if (n > capacity) return fail(PAA_ERR_ARG, "capacity %d < %d entries", capacity, n);
+    for (int i = 0; i < n; ++i) { src[i] = t.flat_src[i]; weight[i] = t.flat_w[i]; slot[i] = t.flat_slot[i]; }
+    return n;
+}
+extern "C" int paa_debug_fft_plan(int window, int32_t *radices, int32_t *fft_len) {
+    if (window < 2 || !radices || !fft_len) return fail(PAA_ERR_ARG, "bad argument");
+    FftPlan p;
+    build_fft_plan(window, p);
+    *fft_len = p.len;
+    const int n = (int)p.radix.size();
+    for (int i = 0; i < n && i < 32; ++i) radices[i] = p.radix[i];
+    return n;
+}

@@ -1,0 +1,135 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol of include/paa_hip.h,
+its host tables equal the oracle's, and it refuses to compute without a GPU (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import paa_oracle as O
+from conftest import ROOT
+from pyaudioanalysis_amd import MidTermFeatures, ShortTermFeatures, _ffi
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "paa_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(paa_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_header_symbol():
+    lib = _ffi.lib()
+    syms = header_symbols()
+    assert len(syms) >= 40
+    for s in syms:
+        assert hasattr(lib, s), "libpaa_hip.so does not export %s" % s
+    assert set(syms) == set(_ffi.EXPORTED_SYMBOLS), set(syms) ^ set(_ffi.EXPORTED_SYMBOLS)
+
+
+def test_shape_helpers():
+    lib = _ffi.lib()
+    assert lib.paa_num_frames(128164, 800, 400) == 319          # doremi.wav
+    assert lib.paa_num_frames(799, 800, 400) == 0
+    assert lib.paa_num_frames(800, 800, 400) == 1
+    assert lib.paa_num_frames(1199, 800, 400) == 1
+    assert lib.paa_num_frames(1200, 800, 400) == 2
+    assert lib.paa_num_mid_windows(1199, 40) == 30               # BASELINE config 3
+    assert lib.paa_num_mid_windows(100, 100) == 1
+    import ctypes
+    filled = ctypes.c_int64()
+    for n, w, s in ((132437, 1102, 441), (48000, 640, 640), (88200, 1102, 441), (2000, 800, 400)):
+        rows = lib.paa_spectrogram_rows(n, w, s, ctypes.byref(filled))
+        assert rows == int((n - w) / s) + 1
+        assert filled.value == len(range(w, n - w + 1, s))
+        rows = lib.paa_chromagram_rows(n, w, s, ctypes.byref(filled))
+        assert rows == int((n - s - w) / s) + 1
+        assert filled.value == len(range(w, n - s, s))
+
+
+@pytest.mark.parametrize("fs,nfft", [(16000, 400), (16000, 320), (16000, 160), (44100, 551), (8000, 200),
+                                      (22050, 512), (48000, 1024)])
+def test_mel_and_chroma_tables_match_oracle(fs, nfft):
+    lib = _ffi.lib()
+    dense = np.zeros((40, nfft))
+    _ffi.check(lib.paa_debug_mel_bank(float(fs), nfft, _ffi.as_f64p(dense)))
+    ref = O.mel_bank(fs, nfft)
+    assert np.array_equal(dense != 0, ref != 0)
+    assert np.allclose(dense, ref, rtol=1e-13, atol=0)
+    cap = nfft
+    src = np.zeros(cap, dtype=np.int32)
+    slot = np.zeros(cap, dtype=np.int32)
+    w = np.zeros(cap)
+    n = lib.paa_debug_chroma(float(fs), nfft, cap, src.ctypes.data_as(_ffi.c_i32p), _ffi.as_f64p(w),
+                             slot.ctypes.data_as(_ffi.c_i32p))
+    assert n > 0
+    o_src, o_w, o_cls, o_pos = O.chroma_gather(fs, nfft)
+    assert n == len(o_src)
+    assert np.array_equal(src[:n], o_src)
+    assert np.array_equal(slot[:n], o_pos)
+    assert np.array_equal(w[:n], o_w)
+
+
+def test_dct_matches_oracle_and_scipy():
+    lib = _ffi.lib()
+    m = np.zeros((13, 40))
+    _ffi.check(lib.paa_debug_dct(_ffi.as_f64p(m)))
+    assert np.allclose(m, O.dct_matrix(), rtol=0, atol=2e-16)
+    from scipy.fft import dct
+    x = np.random.default_rng(0).standard_normal(40)
+    assert np.allclose(m @ x, dct(x, type=2, norm="ortho")[:13], rtol=0, atol=1e-13)
+
+
+def test_chroma_error_codes():
+    lib = _ffi.lib()
+    src = np.zeros(200, dtype=np.int32)
+    slot = np.zeros(200, dtype=np.int32)
+    w = np.zeros(200)
+    args = (200, src.ctypes.data_as(_ffi.c_i32p), _ffi.as_f64p(w), slot.ctypes.data_as(_ffi.c_i32p))
+    assert lib.paa_debug_chroma(16000.0, 97, *args) == _ffi.ERR_CHROMA_VALUE      # ValueError :293
+    assert lib.paa_debug_chroma(16000.0, 98, *args) == _ffi.ERR_CHROMA_INDEX      # IndexError :291
+    assert lib.paa_debug_chroma(16000.0, 99, *args) > 0
+
+
+@pytest.mark.parametrize("window", [800, 1102, 640, 320, 801, 2048, 1103, 4410])
+def test_fft_plan_factorisation(window):
+    lib = _ffi.lib()
+    import ctypes
+    rad = np.zeros(32, dtype=np.int32)
+    ln = ctypes.c_int32()
+    n = lib.paa_debug_fft_plan(window, rad.ctypes.data_as(_ffi.c_i32p), ctypes.byref(ln))
+    assert n > 0
+    assert ln.value == (window // 2 if window % 2 == 0 else window)
+    assert int(np.prod(rad[:n].astype(np.int64))) == ln.value
+
+
+def test_names_match_reference_strings():
+    assert ShortTermFeatures._feature_names(True) == O.feature_names(True)
+    assert ShortTermFeatures._feature_names(False) == O.feature_names(False)
+    assert MidTermFeatures._mid_names(O.feature_names(True)) == O.mid_feature_names()
+    assert MidTermFeatures._ratios(16000, 16000, 800, 400) == (39, 40)           # BASELINE config 3
+    assert MidTermFeatures._ratios(1.0 * 16000, 0.1 * 16000, 800.0, 800.0) == O.mid_ratios(16000.0, 1600.0, 800.0, 800.0)
+
+
+def test_python_boundary_errors_without_touching_the_gpu():
+    with pytest.raises(ValueError):                       # ShortTermFeatures.py:684
+        ShortTermFeatures.feature_extraction(np.zeros(100, dtype=np.int16), 16000, 800, 400)
+    with pytest.raises(ValueError):
+        MidTermFeatures.mid_feature_extraction(np.zeros(5000, dtype=np.int16), 16000, 16000, 100, 800, 400)
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device a compute call must raise, never silently compute on the CPU."""
+    if _ffi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_ffi.HipLibraryError):
+        ShortTermFeatures.feature_extraction(np.zeros(4000, dtype=np.int16), 16000, 800, 400)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pyaudioanalysis_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "paa_oracle" not in text and "load_reference" not in text, f
+                assert "/root/reference" not in text, f

@@ -1,0 +1,187 @@
+"""Parity of the HIP path (through the C ABI) against the goldens and the CPU oracle.  -m gpu.
+
+Tolerance (north_star: 1e-4 relative): |d| <= 1e-4*|ref| + 1e-6*max|ref_row| + 1e-9, see
+paa_oracle.mixed_tolerance_violations.  Roll-off and ZCR are integer-valued outcomes of floating
+comparisons: a vanishing fraction of frames (<= 1e-3 here, none observed) may differ by one bin."""
+import numpy as np
+import pytest
+
+import paa_oracle as O
+from conftest import golden_files, golden_id, load_golden
+from pyaudioanalysis_amd import MidTermFeatures, ShortTermFeatures, _ffi
+from synth import synth_clip
+
+pytestmark = pytest.mark.gpu
+
+REL, ROW, FLOOR = 1e-4, 1e-6, 1e-9
+DISCRETE_ROWS = (0, 7, 34, 41)      # zcr, roll-off and their deltas
+
+
+def assert_parity(got, ref, what=""):
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert got.dtype == np.float64 and got.flags["C_CONTIGUOUS"]
+    nbad, bad = O.mixed_tolerance_violations(got, ref, REL, ROW, FLOOR)
+    if nbad:
+        # allow isolated one-step flips of the discrete features
+        keep = bad.copy()
+        if ref.ndim == 2 and ref.shape[0] in (34, 68):
+            for r in DISCRETE_ROWS:
+                if r < ref.shape[0]:
+                    keep[r] = False
+            flips = int(bad.sum() - keep.sum())
+            assert flips <= max(1, int(1e-3 * ref.shape[1])), "%s: %d discrete flips" % (what, flips)
+        nbad = int(keep.sum())
+        if nbad:
+            idx = np.argwhere(keep)[:8]
+            detail = ", ".join("[%s]=%.6g vs %.6g" % (tuple(i), got[tuple(i)], ref[tuple(i)]) for i in idx)
+            raise AssertionError("%s: %d entries outside tolerance: %s" % (what, nbad, detail))
+
+
+@pytest.mark.parametrize("path", golden_files("st"), ids=golden_id)
+def test_short_term_golden(gpu_lib, path):
+    g = load_golden(path)
+    F, names = ShortTermFeatures.feature_extraction(g["signal"], g["fs"], g["window"], g["step"], g["deltas"])
+    assert names == [str(s) for s in g["names"]]
+    assert_parity(F, g["features"], golden_id(path))
+
+
+@pytest.mark.parametrize("path", golden_files("mid"), ids=golden_id)
+def test_mid_term_golden(gpu_lib, path):
+    g = load_golden(path)
+    mid, st, names = MidTermFeatures.mid_feature_extraction(g["signal"], g["fs"], g["mid_window"], g["mid_step"],
+                                                            g["window"], g["step"])
+    assert names == [str(s) for s in g["names"]]
+    assert_parity(st, g["features"], "short")
+    assert_parity(mid, g["mid"], "mid")
+
+
+@pytest.mark.parametrize("path", golden_files("spec"), ids=golden_id)
+def test_spectrogram_chromagram_golden(gpu_lib, path, capsys):
+    g = load_golden(path)
+    S, t_ax, f_ax = ShortTermFeatures.spectrogram(g["signal"], g["fs"], g["window"], g["step"])
+    assert "(%d, %d)" % g["specgram"].shape in capsys.readouterr().out       # the reference prints the shape
+    assert_parity(S, g["specgram"], "specgram")
+    assert np.array_equal(np.array(t_ax), g["spec_time"]) and np.array_equal(np.array(f_ax), g["spec_freq"])
+    C, ct_ax, names = ShortTermFeatures.chromagram(g["signal"], g["fs"], g["window"], g["step"])
+    assert_parity(C, g["chromagram"], "chromagram")
+    assert np.array_equal(np.array(ct_ax), g["chroma_time"])
+    assert names == [str(s) for s in g["chroma_names"]]
+
+
+@pytest.mark.parametrize("fs,window,step,seconds", [
+    (16000, 800, 400, 4.0),       # headline shape
+    (16000, 800, 800, 2.0),       # the reference's own pytest shape (no overlap)
+    (16000, 400, 160, 1.0),       # 25 ms / 10 ms
+    (16000, 801, 401, 1.0),       # odd window: full-length complex FFT path
+    (16000, 1024, 512, 1.5),      # power of two
+    (22050, 1103, 441, 1.0),      # prime-ish odd window -> generic radix pass
+    (44100, 1102, 441, 1.0),      # config 5 (2 * 19 * 29)
+    (8000, 400, 200, 1.5),
+    (48000, 2400, 1200, 1.0),
+])
+def test_oracle_parity_seeded(gpu_lib, fs, window, step, seconds):
+    x = synth_clip(100 + window, int(seconds * fs), fs=fs)
+    for deltas in (True, False):
+        ref, _ = O.feature_extraction(x, fs, window, step, deltas)
+        got, _ = ShortTermFeatures.feature_extraction(x, fs, window, step, deltas)
+        assert_parity(got, ref, "%d/%d@%d deltas=%s" % (window, step, fs, deltas))
+
+
+def test_float64_input_matches_oracle(gpu_lib):
+    xs = synth_clip(77, 30000, fs=44100, stereo=True)
+    mono = O.stereo_to_mono(xs)
+    assert mono.dtype == np.float64
+    ref, _ = O.feature_extraction(mono, 44100, 1102, 441)
+    got, _ = ShortTermFeatures.feature_extraction(mono, 44100, 1102, 441)
+    assert_parity(got, ref, "stereo->mono f64")
+    # other dtypes go through np.double() like the reference (:567)
+    x32 = synth_clip(78, 8000).astype(np.int32)
+    ref, _ = O.feature_extraction(x32, 16000, 800, 400)
+    got, _ = ShortTermFeatures.feature_extraction(x32, 16000, 800, 400)
+    assert_parity(got, ref, "int32 input")
+
+
+def test_known_answers(gpu_lib):
+    F, _ = ShortTermFeatures.feature_extraction(np.zeros(2000, dtype=np.int16), 16000, 800, 400)
+    assert F.shape == (68, 4)
+    assert abs(F[8, 0] + 99.00180475) < 1e-6                    # mfcc_1 of digital silence
+    others = np.delete(F, 8, axis=0)
+    assert np.all(np.abs(others) < 1e-9)
+    x = synth_clip(5, 16000)
+    F, _ = ShortTermFeatures.feature_extraction(x, 16000, 800, 400)
+    assert F[6, 0] == 0.0 and np.all(F[34:, 0] == 0.0)         # first frame: flux 0, deltas 0
+    assert np.allclose(F[34:, 1:], F[:34, 1:] - F[:34, :-1], rtol=0, atol=0)    # deltas are row differences
+
+
+def test_reference_pytests_shapes(gpu_lib):
+    """pytests/test_feature_extraction.py:10-29 re-pointed at the drop-in (1 s and 5 s clips)."""
+    fs = 16000
+    x = synth_clip(1, fs)
+    F, names = ShortTermFeatures.feature_extraction(x, fs, 0.050 * fs, 0.050 * fs)
+    assert F.shape[1] == 20 and F.shape[0] == len(names)
+    x = synth_clip(2, 5 * fs)
+    mt, st, mt_names = MidTermFeatures.mid_feature_extraction(x, fs, 1 * fs, 1 * fs, 0.05 * fs, 0.05 * fs)
+    assert mt.shape[1] == 5 and mt.shape[0] == len(mt_names)
+
+
+def test_errors_keep_reference_exception_types(gpu_lib):
+    x = np.arange(4000, dtype=np.int16)
+    with pytest.raises(ValueError):
+        ShortTermFeatures.feature_extraction(x, 16000, 2 * 97, 97)
+    with pytest.raises(IndexError):
+        ShortTermFeatures.feature_extraction(x, 16000, 2 * 98, 98)
+    ShortTermFeatures.feature_extraction(x, 16000, 2 * 99, 99)
+    with pytest.raises(IndexError):                              # mel bank bins beyond num_fft (:230)
+        ShortTermFeatures.feature_extraction(x, 4000, 800, 400)
+
+
+def test_batch_equals_single_clips(gpu_lib):
+    """Ragged batch: clips of different lengths, including one of exactly one window."""
+    lens = [800, 1199, 16000, 7777, 48000, 2000]
+    clips = [synth_clip(300 + i, n) for i, n in enumerate(lens)]
+    res, names = ShortTermFeatures.feature_extraction_batch(clips, 16000, 800, 400)
+    assert len(res) == len(clips)
+    for c, r in zip(clips, res):
+        single, _ = ShortTermFeatures.feature_extraction(c, 16000, 800, 400)
+        assert np.array_equal(single, r)                          # same kernels, same tiles -> bit equal
+        ref, _ = O.feature_extraction(c, 16000, 800, 400)
+        assert_parity(r, ref, "batch clip")
+    mids, sts, mnames = MidTermFeatures.mid_feature_extraction_batch(clips[2:], 16000, 16000, 16000, 800, 400,
+                                                                    return_short=True)
+    for c, m, s in zip(clips[2:], mids, sts):
+        ref_mid, ref_st, _ = O.mid_feature_extraction(c, 16000, 16000, 16000, 800, 400)
+        assert_parity(s, ref_st, "batch short")
+        assert_parity(m, ref_mid, "batch mid")
+
+
+def test_size_independent_properties_at_scale(gpu_lib):
+    """A 10-minute clip (24k frames): checks that do not need the oracle to run that long."""
+    fs, W, S = 16000, 800, 400
+    rng = np.random.default_rng(9)
+    base = synth_clip(9, 60 * fs)
+    x = np.tile(base, 10)
+    F, _ = ShortTermFeatures.feature_extraction(x, fs, W, S)
+    T = (len(x) - W) // S + 1
+    assert F.shape == (68, T) and np.all(np.isfinite(F))
+    # deltas are exact row differences
+    assert np.array_equal(F[34:, 1:], F[:34, 1:] - F[:34, :-1])
+    # ranges: zcr, roll-off in [0,1]; entropies in [0, log2(10)]; chroma sums to <= 1
+    assert F[0].min() >= 0 and F[0].max() <= 1 and F[7].min() >= 0 and F[7].max() < 1
+    assert F[2].max() <= np.log2(10) + 1e-9 and F[5].max() <= np.log2(10) + 1e-9
+    assert F[21:33].sum(axis=0).max() <= 1 + 1e-9
+    # tile independence: any window of frames equals the same frames computed from a sub-clip with the
+    # SAME normalisation constants -> use the oracle on a few frame ranges with the clip-global constants
+    xn = O.normalize_clip(x)
+    tab = O.Tables(fs, W)
+    for t in (0, 1, 31, 32, 33, 5000, T - 1):
+        fr = xn[t * S:t * S + W]
+        X = O.magnitude_spectrum(fr, tab.nfft)
+        Xp = X if t == 0 else O.magnitude_spectrum(xn[(t - 1) * S:(t - 1) * S + W], tab.nfft)
+        v = O.frame_vector(fr, X, Xp, tab)
+        nbad, _ = O.mixed_tolerance_violations(F[:34, t:t + 1], v[:, None], REL, ROW * 10, 1e-8)
+        assert nbad == 0, "frame %d" % t
+    # periodicity: the clip is 10 repeats of a 60 s block and 60 s is a multiple of the step, so
+    # frames one period apart see identical samples and identical clip constants
+    per = 60 * fs // S
+    a, b = F[:34, 5:per - 5], F[:34, per + 5:2 * per - 5]
+    assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
