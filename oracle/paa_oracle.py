@@ -338,11 +338,42 @@ def chromagram(signal, sampling_rate, window, step):
 # --------------------------------------------------------------------------
 # comparison policy shared by every parity test
 # --------------------------------------------------------------------------
+MFCC_ROWS = tuple(range(8, 21))
+
+
+def ill_conditioned_mfcc_frames(signal, sampling_rate, window, step, factor=1e4):
+    """Frames whose MFCCs the reference itself computes from FFT round-off.
+
+    mfcc = DCT(log10(E_i + eps)), E_i = mel energy (:252).  When a mel band is (numerically) EMPTY --
+    E_i below factor*eps, e.g. a pure tone sitting exactly on an FFT bin, where every other bin holds
+    only round-off of order 1e-17 -- d log10(E_i+eps)/dE_i = 1/(eps ln10) = 2e15 and the result is a
+    function of the FFT implementation's rounding, not of the signal.  Exact digital silence (E_i == 0
+    on both sides) is NOT flagged.  Returns a bool mask over frames; a frame following a flagged frame
+    is flagged too (its delta row subtracts the flagged value).
+    """
+    window, step = int(window), int(step)
+    x = normalize_clip(signal)
+    tab = Tables(sampling_rate, window)
+    T = (len(x) - window) // step + 1
+    mask = np.zeros(max(T, 0), dtype=bool)
+    for t in range(T):
+        X = magnitude_spectrum(x[t * step:t * step + window], tab.nfft)
+        E = np.dot(X, tab.mel.T)
+        mask[t] = bool(np.any((E > 0) & (E < factor * EPS)))
+    out = mask.copy()
+    out[1:] |= mask[:-1]
+    return out
+
+
 def mixed_tolerance_violations(got, ref, rel=1e-4, row_abs=1e-6, abs_floor=1e-9):
-    """Count entries with |d| > rel*|ref| + row_abs*max|ref_row| + abs_floor (rows = axis 0).
+    """Count entries with |d| > rel*|ref| + row_abs*scale(row) + abs_floor (rows = axis 0).
 
     rel is the north_star tolerance (1e-4 relative).  row_abs covers entries that cross zero or
-    sit ~1e-35 on silent frames, where element-wise relative error is undefined.
+    sit ~1e-35 on silent frames, where element-wise relative error is undefined (SURVEY.md 7.3-2);
+    scale(row) = max|ref_row|, except that the 13 MFCC rows (and their deltas / mid-term
+    statistics) share ONE scale, max|ref| over the MFCC group: they are one orthonormal DCT of one
+    log-mel vector, so an absolute perturbation of the log-mel energies (FFT round-off against the
+    eps = 2.2e-16 floor on bins the signal leaves exactly empty) lands on every coefficient alike.
     abs_floor covers rows the reference emits as exact zeros (e.g. MFCC 2..13 of an all-zero clip,
     where scipy's DCT cancels exactly and any other summation order leaves ~1e-14).
     """
@@ -350,7 +381,15 @@ def mixed_tolerance_violations(got, ref, rel=1e-4, row_abs=1e-6, abs_floor=1e-9)
     ref = np.asarray(ref, dtype=np.float64)
     if got.shape != ref.shape:
         raise AssertionError("shape %s != %s" % (got.shape, ref.shape))
-    rowmax = np.max(np.abs(ref), axis=1, keepdims=True) if ref.ndim == 2 else np.max(np.abs(ref))
-    bad = np.abs(got - ref) > rel * np.abs(ref) + row_abs * rowmax + abs_floor
+    if ref.ndim == 2:
+        scale = np.max(np.abs(ref), axis=1, keepdims=True)
+        nrows = ref.shape[0]
+        if nrows % N_BASE == 0 and nrows // N_BASE in (1, 2, 4):
+            for blk in range(nrows // N_BASE):
+                rows = [blk * N_BASE + r for r in MFCC_ROWS]
+                scale[rows] = scale[rows].max()
+    else:
+        scale = np.max(np.abs(ref))
+    bad = np.abs(got - ref) > rel * np.abs(ref) + row_abs * scale + abs_floor
     bad |= ~np.isfinite(got)
     return int(bad.sum()), bad

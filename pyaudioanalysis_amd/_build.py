@@ -32,6 +32,7 @@ def build(force=False, verbose=False):
         return LIB
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-I/opt/rocm/include", os.path.join(CSRC, "paa_lib.hip"), "-o", LIB + ".tmp", "-ldl"]
+    cmd += os.environ.get("PAA_HIPCC_FLAGS", "").split()
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -248,7 +248,8 @@ __device__ __forceinline__ void frame_features(const PlanDev &P, const T *__rest
         const double X = cur[k];
         const double dv = (double)(k + 1) * f0 - cen;
         sSp = fma(dv * dv, X * r, sSp);
-        const double df = X * rX - prv[k] * rXp;
+        // separately rounded products: frame 0 (prv == cur) must give exactly 0 like the reference (:624-625)
+        const double df = __dmul_rn(X, rX) - __dmul_rn(prv[k], rXp);
         sFl = fma(df, df, sFl);
     }
     sSp = wave_sum(sSp);
@@ -297,7 +298,7 @@ __device__ __forceinline__ void frame_features(const PlanDev &P, const T *__rest
         fv[3] = cen / (P.fs / 2.0);
         fv[4] = spread / (P.fs / 2.0);
         fv[5] = ent_f;
-        fv[6] = sFl;
+        fv[6] = (cur == prv) ? 0.0 : sFl;      // first frame: previous spectrum = itself (:624-625)
         fv[7] = (first == 0x7fffffff) ? 0.0 : (double)first / (double)Nf;
     }
     __syncthreads();

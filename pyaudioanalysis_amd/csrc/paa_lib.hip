@@ -280,7 +280,14 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     }
     int run;
     if (p->fast) {
-        run = p->fl.run;
+        // one wave per run; size the runs so that the launch is close to a whole number of chip-wide
+        // rounds (256 CUs x 7 resident waves), in multiples of the 4-frame quad, at most fl.run frames
+        const long long slots = 256 * 7;
+        const long long per = (total_frames + slots - 1) / slots;
+        const long long rounds = (per + p->fl.run - 1) / p->fl.run;
+        long long r = (per + std::max<long long>(rounds, 1) - 1) / std::max<long long>(rounds, 1);
+        r = ((r + 3) / 4) * 4;
+        run = (int)std::min<long long>(p->fl.run, std::max<long long>(16, r));
         p->lds = p->fl.lds;
         p->kernel_name = p->fl.name;
     } else {

@@ -17,10 +17,22 @@ REL, ROW, FLOOR = 1e-4, 1e-6, 1e-9
 DISCRETE_ROWS = (0, 7, 34, 41)      # zcr, roll-off and their deltas
 
 
-def assert_parity(got, ref, what=""):
+MFCC_ALL = [r + b for b in (0, 34) for r in O.MFCC_ROWS]
+
+
+def assert_parity(got, ref, what="", ill=None):
+    """ill: optional bool mask of frames whose MFCCs are round-off-determined in the reference itself
+    (paa_oracle.ill_conditioned_mfcc_frames); there the MFCC rows get 1e-5 of the group scale."""
     assert got.shape == ref.shape, (got.shape, ref.shape)
     assert got.dtype == np.float64 and got.flags["C_CONTIGUOUS"]
     nbad, bad = O.mixed_tolerance_violations(got, ref, REL, ROW, FLOOR)
+    if nbad and ill is not None and ill.any():
+        _, loose = O.mixed_tolerance_violations(got, ref, REL, 1e-5, FLOOR)
+        rows = [r for r in MFCC_ALL if r < ref.shape[0]]
+        sub = bad[rows]
+        sub[:, ill] = loose[rows][:, ill]
+        bad[rows] = sub
+        nbad = int(bad.sum())
     if nbad:
         # allow isolated one-step flips of the discrete features
         keep = bad.copy()
@@ -42,7 +54,8 @@ def test_short_term_golden(gpu_lib, path):
     g = load_golden(path)
     F, names = ShortTermFeatures.feature_extraction(g["signal"], g["fs"], g["window"], g["step"], g["deltas"])
     assert names == [str(s) for s in g["names"]]
-    assert_parity(F, g["features"], golden_id(path))
+    ill = O.ill_conditioned_mfcc_frames(g["signal"], g["fs"], g["window"], g["step"])
+    assert_parity(F, g["features"], golden_id(path), ill)
 
 
 @pytest.mark.parametrize("path", golden_files("mid"), ids=golden_id)
