@@ -87,21 +87,29 @@ __global__ __launch_bounds__(256) void clip_stats_f64_kernel(const double *__res
     }
 }
 
-// one thread per clip: fold the chunk partials in order, derive (mean, 1/(max|x-mean| + 1e-10))
+// one wave per clip: fold the chunk partials (lane-strided, then a fixed xor tree -> deterministic),
+// derive (mean, 1/(max|x-mean| + 1e-10))
 template <typename SumT, typename MmT>
-__global__ void clip_params_kernel(const ClipDev *__restrict__ clips, long long n_clips,
-                                   const SumT *__restrict__ psum, const MmT *__restrict__ pmin,
-                                   const MmT *__restrict__ pmax, ClipNorm *__restrict__ norms) {
-    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void clip_params_kernel(const ClipDev *__restrict__ clips, long long n_clips,
+                                                          const SumT *__restrict__ psum, const MmT *__restrict__ pmin,
+                                                          const MmT *__restrict__ pmax, ClipNorm *__restrict__ norms) {
+    const long long c = blockIdx.x;
     if (c >= n_clips) return;
     const ClipDev cd = clips[c];
     SumT s = 0;
     double mn = DBL_MAX, mx = -DBL_MAX;
-    for (int i = 0; i < cd.stat_count; ++i) {
+    for (int i = threadIdx.x; i < cd.stat_count; i += 64) {
         s += psum[cd.stat_first + i];
         mn = fmin(mn, (double)pmin[cd.stat_first + i]);
         mx = fmax(mx, (double)pmax[cd.stat_first + i]);
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        mn = fmin(mn, __shfl_xor(mn, o, 64));
+        mx = fmax(mx, __shfl_xor(mx, o, 64));
+    }
+    if (threadIdx.x != 0) return;
     const double sc = 1.0 / 32768.0;
     ClipNorm nm;
     if (cd.n <= 0) { nm.mean = 0.0; nm.inv = 1.0; norms[c] = nm; return; }

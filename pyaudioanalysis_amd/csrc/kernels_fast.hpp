@@ -28,11 +28,20 @@ namespace paa {
 struct FastTables {
     void *d_blob = nullptr;
 };
+namespace f800 {
+// shared (per workgroup) LDS tables, laid out by the host
+struct TabLayout {
+    int off_melw, off_mello, off_melcnt, off_meloff, off_dct, off_chstart, off_chsrc, off_chw;
+    int n_melw, n_ch, total;     // total: bytes, multiple of 16
+};
+}  // namespace f800
 struct FastLaunch {
     int run = 0;
     size_t lds = 0;
     const char *name = "";
     int variant = 0;
+    int waves_per_cu = 4;
+    f800::TabLayout layout;
 };
 
 inline void fast_tables_free(FastTables &t) {
@@ -123,93 +132,211 @@ __device__ __forceinline__ void dft16(double2 *v) {
 }
 #define PAA_DFT16_POS(q) (4 * ((q) % 4) + (q) / 4)
 
-__device__ __forceinline__ double group_sum(double v) {      // over a 16-lane group
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- 16-lane group reductions on DPP (no LDS traffic; every lane ends with the same bits) ----------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+// quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror, row_mirror
+#define PAA_DPP_X1 0xB1
+#define PAA_DPP_X2 0x4E
+#define PAA_DPP_HM 0x141
+#define PAA_DPP_RM 0x140
+__device__ __forceinline__ double group_sum(double v) {
+    v += dpp_mov<PAA_DPP_X1>(v);
+    v += dpp_mov<PAA_DPP_X2>(v);
+    v += dpp_mov<PAA_DPP_HM>(v);
+    v += dpp_mov<PAA_DPP_RM>(v);
     return v;
 }
 __device__ __forceinline__ double group_max(double v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    v = fmax(v, dpp_mov<PAA_DPP_X1>(v));
+    v = fmax(v, dpp_mov<PAA_DPP_X2>(v));
+    v = fmax(v, dpp_mov<PAA_DPP_HM>(v));
+    v = fmax(v, dpp_mov<PAA_DPP_RM>(v));
     return v;
 }
 __device__ __forceinline__ int group_sum_i(int v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += dpp_mov_i<PAA_DPP_X1>(v);
+    v += dpp_mov_i<PAA_DPP_X2>(v);
+    v += dpp_mov_i<PAA_DPP_HM>(v);
+    v += dpp_mov_i<PAA_DPP_RM>(v);
     return v;
 }
 __device__ __forceinline__ int group_min_i(int v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    v = min(v, dpp_mov_i<PAA_DPP_X1>(v));
+    v = min(v, dpp_mov_i<PAA_DPP_X2>(v));
+    v = min(v, dpp_mov_i<PAA_DPP_HM>(v));
+    v = min(v, dpp_mov_i<PAA_DPP_RM>(v));
+    return v;
+}
+// inclusive prefix sum over the 16-lane row: row_shr:n shifts zeros in (bound_ctrl)
+__device__ __forceinline__ double group_scan_incl(double v) {
+    v += dpp_mov<0x111>(v);
+    v += dpp_mov<0x112>(v);
+    v += dpp_mov<0x114>(v);
+    v += dpp_mov<0x118>(v);
     return v;
 }
 
-#ifndef PAA_F800_WAVES_PER_SIMD
-#define PAA_F800_WAVES_PER_SIMD 2
-#endif
-template <int DELTAS>
-__global__ __launch_bounds__(64, PAA_F800_WAVES_PER_SIMD) void st_fast_800_kernel(PlanDev P, const int16_t *__restrict__ sig,
-                                                             const ClipDev *__restrict__ clips,
-                                                             const ClipNorm *__restrict__ norms,
-                                                             const Tile *__restrict__ tiles,
-                                                             double *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *spec = reinterpret_cast<double *>(smem + OFF_SPEC);
-    int16_t *raw = reinterpret_cast<int16_t *>(smem + OFF_RAW);
-    double *msp = reinterpret_cast<double *>(smem + OFF_RAW);          // alias: raw is dead by then
-    double *cE = reinterpret_cast<double *>(smem + OFF_CE);
-    int *cZ = reinterpret_cast<int *>(smem + OFF_CZ);
-    int *cF = cZ + NCHUNK;
-    double *fv = reinterpret_cast<double *>(smem + OFF_FV);
+// sqrt for x >= 0 to ~1 ulp: v_rsq_f64 seed + two coupled Newton steps (ocml's version adds scaling for
+// sub-normal / huge arguments, which |X|^2 of a normalised frame never reaches)
+__device__ __forceinline__ double fast_sqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return (x > 0.0) ? g : 0.0;
+}
 
-    const int lane = threadIdx.x;
+// wave-local ordering point for LDS hand-offs between lanes of ONE wave: a wave's DS instructions execute
+// in program order, so only the compiler has to be kept from moving memory operations across
+__device__ __forceinline__ void wsync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+constexpr int WAVES = 4;
+constexpr int WAVE_BYTES = ((LDS_BYTES + 15) / 16) * 16;
+
+template <int DELTAS>
+__global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, TabLayout L,
+                                                                     const int16_t *__restrict__ sig,
+                                                                     const ClipDev *__restrict__ clips,
+                                                                     const ClipNorm *__restrict__ norms,
+                                                                     const Tile *__restrict__ tiles, int n_tiles,
+                                                                     double *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // ---------------- shared tables: global -> LDS once per workgroup
+    {
+        double *t_melw = reinterpret_cast<double *>(smem + L.off_melw);
+        int *t_lo = reinterpret_cast<int *>(smem + L.off_mello);
+        int *t_cnt = reinterpret_cast<int *>(smem + L.off_melcnt);
+        int *t_off = reinterpret_cast<int *>(smem + L.off_meloff);
+        double *t_dct = reinterpret_cast<double *>(smem + L.off_dct);
+        int *t_chs = reinterpret_cast<int *>(smem + L.off_chstart);
+        int *t_src = reinterpret_cast<int *>(smem + L.off_chsrc);
+        double *t_chw = reinterpret_cast<double *>(smem + L.off_chw);
+        const int tid = threadIdx.x;
+        for (int n = tid; n < L.n_melw; n += 64 * WAVES) t_melw[n] = P.mel_w[n];
+        for (int n = tid; n < 40; n += 64 * WAVES) { t_lo[n] = P.mel_lo[n]; t_cnt[n] = P.mel_cnt[n]; t_off[n] = P.mel_off[n]; }
+        for (int n = tid; n < 13 * 40; n += 64 * WAVES) t_dct[n] = P.dct[n];
+        for (int n = tid; n < 13; n += 64 * WAVES) t_chs[n] = P.ch_start[n];
+        for (int n = tid; n < L.n_ch; n += 64 * WAVES) { t_src[n] = P.ch_src[n]; t_chw[n] = P.ch_w[n]; }
+    }
+    __syncthreads();       // the only workgroup-wide barrier; from here on every wave runs on its own
+    const double *t_melw = reinterpret_cast<const double *>(smem + L.off_melw);
+    const int *t_lo = reinterpret_cast<const int *>(smem + L.off_mello);
+    const int *t_cnt = reinterpret_cast<const int *>(smem + L.off_melcnt);
+    const int *t_off = reinterpret_cast<const int *>(smem + L.off_meloff);
+    const double *t_dct = reinterpret_cast<const double *>(smem + L.off_dct);
+    const int *t_chs = reinterpret_cast<const int *>(smem + L.off_chstart);
+    const int *t_src = reinterpret_cast<const int *>(smem + L.off_chsrc);
+    const double *t_chw = reinterpret_cast<const double *>(smem + L.off_chw);
+
+    const int wave = threadIdx.x >> 6;
+    const int tile_id = blockIdx.x * WAVES + wave;
+    if (tile_id >= n_tiles) return;
+    unsigned char *wbase = smem + L.total + wave * WAVE_BYTES;
+    double *spec = reinterpret_cast<double *>(wbase + OFF_SPEC);
+    int16_t *raw = reinterpret_cast<int16_t *>(wbase + OFF_RAW);
+    double *msp = reinterpret_cast<double *>(wbase + OFF_RAW);          // alias: raw is dead by then
+    double *cE = reinterpret_cast<double *>(wbase + OFF_CE);
+    int *cZ = reinterpret_cast<int *>(wbase + OFF_CZ);
+    int *cF = cZ + NCHUNK;
+    double *fv = reinterpret_cast<double *>(wbase + OFF_FV);
+
+    const int lane = threadIdx.x & 63;
     const int g = lane >> 4, i = lane & 15;
-    const Tile tl = tiles[blockIdx.x];
+    const Tile tl = tiles[tile_id];
     const ClipDev c = clips[tl.clip];
     const ClipNorm nm = norms[tl.clip];
     const int16_t *xc = sig + c.sample_off;
     const long long Tc = c.T;
     double *oc = out + c.out_off;
-    constexpr int F = DELTAS ? 68 : 34;
 
     const double sc = 1.0 / 32768.0;
     const double f0 = P.fs / (2.0 * (double)NF);
     const double half_fs = P.fs / 2.0;
-    // integer sign thresholds: sign(x/2^15 - mean) = sign(x - mu), mu = mean * 2^15 (exact)
-    const double mu = nm.mean * 32768.0;
+    // the FFT runs on integers x - m_int (m_int = the clip mean rounded to a whole count; exact in f64).
+    // y = (x/2^15 - mean) * inv is affine, so every bin scales by inv/2^15 and only the DC bin sees the
+    // residual mean:  Y[0] = inv/2^15 * (X'[0] - 800 * (mu - m_int)).  Removing m_int first keeps the DC
+    // component (and its round-off leakage into the other bins) below half a count per sample.
+    const double mu = nm.mean * 32768.0;             // clip mean in counts (exact scaling)
+    const int m_int = (int)fmin(fmax(nearbyint(mu), -40000.0), 40000.0);
+    const double mag_scale = nm.inv * sc / (double)NF;
+    const double dc_shift = (double)W * (mu - (double)m_int);
+    // integer sign thresholds: sign(x/2^15 - mean) = sign(x - mu)
     const int thr_pos = (int)fmin(fmax(floor(mu) + 1.0, -40000.0), 40000.0);   // x >= thr_pos  <=> positive
     const int thr_neg = (int)fmin(fmax(ceil(mu) - 1.0, -40000.0), 40000.0);    // x <= thr_neg  <=> negative
+
+    // register-resident twiddles: W400^(r p), r = 1..15 (pass 2) and W800^(p + 25 q), q = 0..15 (recombination)
+    const int pa = i, pb = (i == 0) ? 0 : 25 - i;
+    const bool act = i < 13;
+    double2 tw2[16], twp[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        tw2[r] = act ? P.tw[r * pa] : make_double2(1.0, 0.0);
+        twp[r] = act ? P.post[pa + 25 * r] : make_double2(1.0, 0.0);
+    }
 
     const int t_end = tl.t0 + tl.cnt;
     int q0 = tl.t0 >= QUAD ? tl.t0 - QUAD : 0;
     int slot0 = 1;                   // slots of this quad: slot0 .. slot0+3 (mod 5); previous = slot0-1
     double vlast = 0.0;              // lane l < 34: feature l of the frame before this quad
+
+    // software prefetch of the next quad's samples (4 x 16 B per lane) into registers
+    int4 pre0 = make_int4(0, 0, 0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
+    bool pre_ok;
+#define PAA_F800_FETCH(q)                                                                              \
+    {                                                                                                  \
+        const long long base_ = (long long)(q) * S;                                                    \
+        const int16_t *src_ = xc + base_;                                                              \
+        pre_ok = ((reinterpret_cast<uintptr_t>(src_) & 15) == 0) && (c.n - base_ >= RAW_N);            \
+        if (pre_ok) {                                                                                  \
+            const int4 *s4_ = reinterpret_cast<const int4 *>(src_);                                    \
+            pre0 = s4_[lane];                                                                          \
+            pre1 = s4_[lane + 64];                                                                     \
+            pre2 = s4_[lane + 128];                                                                    \
+            if (lane + 192 < RAW_N / 8) pre3 = s4_[lane + 192];                                        \
+        }                                                                                              \
+    }
+    PAA_F800_FETCH(q0)
+
     for (; q0 < t_end; q0 += QUAD, slot0 = (slot0 + 4) % 5) {
         // ---------------- stage raw samples [q0*S - 1, q0*S + 2000)
         {
             const long long base = (long long)q0 * S;
-            const long long avail = c.n - base;        // samples of the clip from `base`
             const int16_t *src = xc + base;
-            const bool aligned = ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
-            if (aligned && avail >= RAW_N) {
-                const int4 *s4 = reinterpret_cast<const int4 *>(src);
+            if (pre_ok) {
                 int4 *d4 = reinterpret_cast<int4 *>(raw + RAW_PAD);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int idx = lane + 64 * r;
-                    if (idx < RAW_N / 8) d4[idx] = s4[idx];
-                }
+                d4[lane] = pre0;
+                d4[lane + 64] = pre1;
+                d4[lane + 128] = pre2;
+                if (lane + 192 < RAW_N / 8) d4[lane + 192] = pre3;
             } else {
+                const long long avail = c.n - base;
                 for (int n = lane; n < RAW_N; n += 64) raw[RAW_PAD + n] = (n < avail) ? src[n] : (int16_t)0;
             }
             if (lane == 0) raw[RAW_PAD - 1] = (base > 0) ? src[-1] : src[0];
+            if (q0 + QUAD < t_end) PAA_F800_FETCH(q0 + QUAD)
         }
-        __syncthreads();
+        wsync();
 
         // ---------------- time domain: chunk partials (ShortTermFeatures.py:22-51)
         if (lane < NCHUNK) {
             const int4 *p4 = reinterpret_cast<const int4 *>(raw + RAW_PAD + CHUNK * lane);
-            int prev = raw[RAW_PAD + CHUNK * lane - 1];
+            const int prev = raw[RAW_PAD + CHUNK * lane - 1];
             int sprev = (prev >= thr_pos) - (prev <= thr_neg);
             double e = 0.0;
             int z = 0, zfirst = 0;
@@ -237,76 +364,74 @@ __global__ __launch_bounds__(64, PAA_F800_WAVES_PER_SIMD) void st_fast_800_kerne
             cF[lane] = zfirst;
         }
 
-        // ---------------- pass 1: radix-25 on z[j + 16 r]  (lane = frame g, column j = i)
+        // ---------------- pass 1: radix-25 on z[j + 16 r], z = x[2n] + i x[2n+1] (raw integers, exact in f64)
         double2 v[25];
         {
             const int *r32 = reinterpret_cast<const int *>(raw + RAW_PAD) + (S / 2) * g + i;
 #pragma unroll
             for (int r = 0; r < 25; ++r) {
                 const int w = r32[16 * r];
-                const int xa = (int)(short)(w & 0xffff), xb = w >> 16;
-                v[r] = make_double2(fma((double)xa, sc, -nm.mean) * nm.inv, fma((double)xb, sc, -nm.mean) * nm.inv);
+                v[r] = make_double2((double)((int)(short)(w & 0xffff) - m_int), (double)((w >> 16) - m_int));
             }
         }
         dft25(v);
-        __syncthreads();      // raw + chunk partials complete; previous quad's readers of the slots are done
+        wsync();      // raw + chunk partials complete; the previous quad's readers of the slots are done
 
-        // exchange planes live in the 4 current slots (contiguous modulo the 5-slot ring)
+        // exchange through the quad's 4 spectrum slots: real plane, then imaginary plane.
         // element (frame g, index 25 j + q)
-        double2 a[16], b[16];
-        const int pa = i, pb = (i == 0) ? 0 : 25 - i;
-        const bool act = i < 13;
+        double ax[16], ay[16], bx[16], by[16];
         {
             double *pl = spec + ((slot0 + g) % 5) * NF;
 #pragma unroll
             for (int q = 0; q < 25; ++q) pl[25 * i + q] = v[PAA_DFT25_POS(q)].x;
-            __syncthreads();
-            if (act) {
+            wsync();
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { a[r].x = pl[pa + 25 * r]; b[r].x = pl[pb + 25 * r]; }
-            }
-            __syncthreads();
+            for (int r = 0; r < 16; ++r) { ax[r] = pl[pa + 25 * r]; bx[r] = pl[pb + 25 * r]; }
+            wsync();
 #pragma unroll
             for (int q = 0; q < 25; ++q) pl[25 * i + q] = v[PAA_DFT25_POS(q)].y;
-            __syncthreads();
-            if (act) {
+            wsync();
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { a[r].y = pl[pa + 25 * r]; b[r].y = pl[pb + 25 * r]; }
-            }
-            __syncthreads();
+            for (int r = 0; r < 16; ++r) { ay[r] = pl[pa + 25 * r]; by[r] = pl[pb + 25 * r]; }
+            wsync();
         }
 
         // ---------------- pass 2 + real-FFT recombination + magnitude (ShortTermFeatures.py:617-621)
         if (act) {
-            // twiddles W400^(r p); column 25-p uses the conjugates and a one-step output rotation
+            // column 25-p uses the conjugate twiddles and a one-step rotation of the outputs
+            double2 a[16], b[16];
+            a[0] = make_double2(ax[0], ay[0]);
+            b[0] = make_double2(bx[0], by[0]);
 #pragma unroll
             for (int r = 1; r < 16; ++r) {
-                const double2 w = P.tw[r * pa];
-                a[r] = cmul(a[r], w);
-                b[r] = cmul(b[r], make_double2(w.x, -w.y));
+                a[r] = cmul(make_double2(ax[r], ay[r]), tw2[r]);
+                b[r] = cmul(make_double2(bx[r], by[r]), make_double2(tw2[r].x, -tw2[r].y));
             }
             dft16(a);
             dft16(b);
             double *sp = spec + ((slot0 + g) % 5) * NF;
-            const double invNf = 1.0 / (double)NF;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 // Z[k], k = p + 25 q ; Z[400 - k] = column (25-p), output (15 - q) -> rotated index (16 - q) % 16
                 const double2 zk = a[PAA_DFT16_POS(q)];
                 const int qm = (16 - q) % 16;
-                const double2 zb = (i == 0) ? a[PAA_DFT16_POS(qm)] : b[PAA_DFT16_POS(qm)];
+                // (scalar selects: a select between two array ELEMENTS of struct type becomes a pointer
+                //  select and sends both arrays to scratch)
+                const double2 za = a[PAA_DFT16_POS(qm)], zq = b[PAA_DFT16_POS(qm)];
+                const double2 zb = make_double2((i == 0) ? za.x : zq.x, (i == 0) ? za.y : zq.y);
                 const int k = pa + 25 * q;
                 const double2 e = make_double2(0.5 * (zk.x + zb.x), 0.5 * (zk.y - zb.y));
                 const double2 d = make_double2(0.5 * (zk.x - zb.x), 0.5 * (zk.y + zb.y));
                 const double2 o = make_double2(d.y, -d.x);
-                const double2 t = cmul(P.post[k], o);
-                const double xr = e.x + t.x, xi = e.y + t.y;
+                const double2 t = cmul(twp[q], o);
+                double xr = e.x + t.x, xi = e.y + t.y;
                 const double yr = e.x - t.x, yi = e.y - t.y;
-                sp[k] = sqrt(fma(xr, xr, xi * xi)) * invNf;
-                if (k > 0) sp[NF - k] = sqrt(fma(yr, yr, yi * yi)) * invNf;
+                if (q == 0 && i == 0) { xr -= dc_shift; xi = 0.0; }    // DC bin: remove the residual clip mean
+                sp[k] = fast_sqrt(fma(xr, xr, xi * xi)) * mag_scale;
+                if (q > 0 || i > 0) sp[NF - k] = fast_sqrt(fma(yr, yr, yi * yi)) * mag_scale;
             }
         }
-        __syncthreads();
+        wsync();
 
         // ---------------- features: 16 lanes per frame (group g <-> frame q0 + g)
         const int t = q0 + g;
@@ -359,7 +484,7 @@ __global__ __launch_bounds__(64, PAA_F800_WAVES_PER_SIMD) void st_fast_800_kerne
             const double X = cur[k];
             const double dv = (double)(k + 1) * f0 - cen;
             sSp = fma(dv * dv, X * r, sSp);
-            const double df = __dmul_rn(X, rX) - __dmul_rn(prv[k], rXp);
+            const double df = X * rX - prv[k] * rXp;
             sFl = fma(df, df, sFl);
         }
         sSp = group_sum(sSp);
@@ -373,14 +498,14 @@ __global__ __launch_bounds__(64, PAA_F800_WAVES_PER_SIMD) void st_fast_800_kerne
             double cs = 0.0;
 #pragma unroll 5
             for (int m = 0; m < 25; ++m) { const double X = cur[25 * i + m]; cs = fma(X, X, cs); }
-            double run = cs;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { const double u = __shfl_up(run, o, 16); if (i >= o) run += u; }
-            run -= cs;
-            for (int m = 0; m < 25; ++m) {
-                const double X = cur[25 * i + m];
-                run = fma(X, X, run);
-                if (run + kEps > thr) { first = 25 * i + m; break; }
+            double run = group_scan_incl(cs) - cs;
+            // the crossing lies in exactly one lane's chunk (or none when sP == 0 ... then bin 0 crosses at once)
+            if (run + kEps <= thr || i == 0) {
+                for (int m = 0; m < 25; ++m) {
+                    const double X = cur[25 * i + m];
+                    run = fma(X, X, run);
+                    if (run + kEps > thr) { first = 25 * i + m; break; }
+                }
             }
             first = group_min_i(first);
         }
@@ -391,8 +516,8 @@ __global__ __launch_bounds__(64, PAA_F800_WAVES_PER_SIMD) void st_fast_800_kerne
         for (int fi = 0; fi < 3; ++fi) {
             const int m = i + 16 * fi;
             if (m < 40) {
-                const int lo = P.mel_lo[m], cnt = P.mel_cnt[m];
-                const double *w = P.mel_w + P.mel_off[m];
+                const int lo = t_lo[m], cnt = t_cnt[m];
+                const double *w = t_melw + t_off[m];
                 double acc = 0.0;
                 for (int n = 0; n < cnt; ++n) acc = fma(cur[lo + n], w[n], acc);
                 mg[m] = log10(acc + kEps);
@@ -401,14 +526,14 @@ __global__ __launch_bounds__(64, PAA_F800_WAVES_PER_SIMD) void st_fast_800_kerne
         // chroma (:277-321): lane i < 12 = pitch class i
         double chroma = 0.0;
         if (i < 12) {
-            const int b0 = P.ch_start[i], b1 = P.ch_start[i + 1];
-            for (int n = b0; n < b1; ++n) { const double x = cur[P.ch_src[n]]; chroma += (x * x) * P.ch_w[n]; }
+            const int b0 = t_chs[i], b1 = t_chs[i + 1];
+            for (int n = b0; n < b1; ++n) { const double x = cur[t_src[n]]; chroma += (x * x) * t_chw[n]; }
             chroma = (sP == 0.0) ? chroma / kEps : chroma / sP;
         }
-        __syncthreads();
+        wsync();
         double *fg = fv + FV_STRIDE * g;
         if (i < 13) {
-            const double *dm = P.dct + 40 * i;
+            const double *dm = t_dct + 40 * i;
             double acc = 0.0;
 #pragma unroll 8
             for (int n = 0; n < 40; ++n) acc = fma(dm[n], mg[n], acc);
@@ -425,13 +550,13 @@ __global__ __launch_bounds__(64, PAA_F800_WAVES_PER_SIMD) void st_fast_800_kerne
             fg[6] = (t == 0) ? 0.0 : sFl;      // first frame: previous spectrum = itself (:624-625)
             fg[7] = (first == 0x7fffffff) ? 0.0 : (double)first / (double)NF;
         }
-        {   // population std of the 12 chroma values (:667), by shuffles inside the group
-            double m = group_sum((i < 12) ? chroma : 0.0) / 12.0;
+        {   // population std of the 12 chroma values (:667), by DPP inside the group
+            const double m = group_sum((i < 12) ? chroma : 0.0) / 12.0;
             const double d = (i < 12) ? chroma - m : 0.0;
             const double var = group_sum(d * d) / 12.0;
             if (i == 14) fg[33] = sqrt(var);
         }
-        __syncthreads();
+        wsync();
 
         // ---------------- store: lane = feature row, 4 consecutive frames
         if (lane < kBase) {
@@ -451,7 +576,7 @@ __global__ __launch_bounds__(64, PAA_F800_WAVES_PER_SIMD) void st_fast_800_kerne
             }
             vlast = vq[QUAD - 1];
         }
-        (void)F;
+        wsync();
     }
 }
 
@@ -460,16 +585,31 @@ __global__ __launch_bounds__(64, PAA_F800_WAVES_PER_SIMD) void st_fast_800_kerne
 // returns 1 when a specialised kernel exists for this configuration (and fills fl), 0 when
 // the generic kernel must be used, < 0 on error
 inline int fast_select(int window, int step, int sample_kind, double fs, FastTables &ft, const FftPlan &fft,
-                       FastLaunch &fl) {
+                       const MelTable &mel, const ChromaTable &chroma, FastLaunch &fl) {
     (void)fs; (void)ft; (void)fft;
-    if (window == 800 && step == 400 && sample_kind == 0) {
-        fl.name = "st_fast_800";
-        fl.lds = f800::LDS_BYTES;
-        fl.variant = 800;
-        fl.run = 128;       // frames per run; the plan shrinks it to fill the chip
-        return 1;
-    }
-    return 0;
+    if (!(window == 800 && step == 400 && sample_kind == 0)) return 0;
+    const int n_melw = (int)mel.w.size(), n_ch = (int)chroma.src.size();
+    if (n_melw > 2048 || n_ch > 512) return 0;           // tables would not fit the shared LDS region
+    f800::TabLayout &L = fl.layout;
+    int off = 0;
+    auto take = [&off](int bytes) { const int o = off; off += (bytes + 15) / 16 * 16; return o; };
+    L.off_melw = take(n_melw * 8);
+    L.off_mello = take(40 * 4);
+    L.off_melcnt = take(40 * 4);
+    L.off_meloff = take(40 * 4);
+    L.off_dct = take(13 * 40 * 8);
+    L.off_chstart = take(13 * 4);
+    L.off_chsrc = take(n_ch * 4);
+    L.off_chw = take(n_ch * 8);
+    L.n_melw = n_melw;
+    L.n_ch = n_ch;
+    L.total = off;
+    fl.name = "st_fast_800";
+    fl.lds = (size_t)L.total + (size_t)f800::WAVES * f800::WAVE_BYTES;
+    fl.variant = 800;
+    fl.run = 128;       // frames per run (one wave); the plan shrinks it to fill the chip
+    fl.waves_per_cu = f800::WAVES;
+    return 1;
 }
 
 inline int fast_launch(const FastLaunch &fl, const PlanDev &P, const FastTables &ft, const void *d_packed,
@@ -477,12 +617,25 @@ inline int fast_launch(const FastLaunch &fl, const PlanDev &P, const FastTables 
                        double *d_out, hipStream_t stream) {
     (void)ft;
     if (fl.variant != 800) return -1;
-    if (P.deltas)
-        hipLaunchKernelGGL(f800::st_fast_800_kernel<1>, dim3((unsigned)n_tiles), dim3(64), fl.lds, stream, P,
-                           (const int16_t *)d_packed, clips, norms, tiles, d_out);
-    else
-        hipLaunchKernelGGL(f800::st_fast_800_kernel<0>, dim3((unsigned)n_tiles), dim3(64), fl.lds, stream, P,
-                           (const int16_t *)d_packed, clips, norms, tiles, d_out);
+    static size_t attr_done[2] = {0, 0};
+    const unsigned grid = (unsigned)((n_tiles + f800::WAVES - 1) / f800::WAVES);
+    if (P.deltas) {
+        if (attr_done[1] < fl.lds) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&f800::st_fast_800_kernel<1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl.lds) != hipSuccess) return -1;
+            attr_done[1] = fl.lds;
+        }
+        hipLaunchKernelGGL(f800::st_fast_800_kernel<1>, dim3(grid), dim3(64 * f800::WAVES), fl.lds, stream, P,
+                           fl.layout, (const int16_t *)d_packed, clips, norms, tiles, (int)n_tiles, d_out);
+    } else {
+        if (attr_done[0] < fl.lds) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&f800::st_fast_800_kernel<0>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl.lds) != hipSuccess) return -1;
+            attr_done[0] = fl.lds;
+        }
+        hipLaunchKernelGGL(f800::st_fast_800_kernel<0>, dim3(grid), dim3(64 * f800::WAVES), fl.lds, stream, P,
+                           fl.layout, (const int16_t *)d_packed, clips, norms, tiles, (int)n_tiles, d_out);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

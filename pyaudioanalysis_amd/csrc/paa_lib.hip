@@ -274,15 +274,15 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     // ---- kernel choice + tiles
     p->fast = 0;
     if (mode == 0 && !g_force_generic) {
-        rc = fast_select(window, step, sample_kind, fs, tab->fast, tab->fft, p->fl);
+        rc = fast_select(window, step, sample_kind, fs, tab->fast, tab->fft, tab->mel, tab->chroma, p->fl);
         if (rc < 0) return fail(rc, "building the tables of the specialised kernel failed");
         p->fast = rc;
     }
     int run;
     if (p->fast) {
         // one wave per run; size the runs so that the launch is close to a whole number of chip-wide
-        // rounds (256 CUs x 7 resident waves), in multiples of the 4-frame quad, at most fl.run frames
-        const long long slots = 256 * 7;
+        // rounds (256 CUs x resident waves), in multiples of the 4-frame quad, at most fl.run frames
+        const long long slots = 256LL * p->fl.waves_per_cu;
         const long long per = (total_frames + slots - 1) / slots;
         const long long rounds = (per + p->fl.run - 1) / p->fl.run;
         long long r = (per + std::max<long long>(rounds, 1) - 1) / std::max<long long>(rounds, 1);
@@ -338,13 +338,13 @@ static int launch_stats(paa_plan *p, const void *d_packed) {
                                (const double *)d_packed, p->d_chunks, (double *)p->d_psum, (double *)p->d_pmin,
                                (double *)p->d_pmax);
     }
-    const unsigned gb = (unsigned)((p->n_clips + 255) / 256);
+    const unsigned gb = (unsigned)p->n_clips;
     if (p->sample_kind == 0)
-        hipLaunchKernelGGL((clip_params_kernel<long long, int>), dim3(gb), dim3(256), 0, g_stream, p->d_clips,
+        hipLaunchKernelGGL((clip_params_kernel<long long, int>), dim3(gb), dim3(64), 0, g_stream, p->d_clips,
                            p->n_clips, (const long long *)p->d_psum, (const int *)p->d_pmin, (const int *)p->d_pmax,
                            p->d_norms);
     else
-        hipLaunchKernelGGL((clip_params_kernel<double, double>), dim3(gb), dim3(256), 0, g_stream, p->d_clips,
+        hipLaunchKernelGGL((clip_params_kernel<double, double>), dim3(gb), dim3(64), 0, g_stream, p->d_clips,
                            p->n_clips, (const double *)p->d_psum, (const double *)p->d_pmin,
                            (const double *)p->d_pmax, p->d_norms);
     HIP_TRY(hipGetLastError());
