@@ -20,6 +20,9 @@
 //
 // Replaces ShortTermFeatures.py:608-682 (+ helpers :22-140, :236-321) for this configuration.
 #pragma once
+#include <algorithm>
+#include <vector>
+
 #include "device_common.hpp"
 #include "tables.hpp"
 
@@ -31,8 +34,13 @@ struct FastTables {
 namespace f800 {
 // shared (per workgroup) LDS tables, laid out by the host
 struct TabLayout {
-    int off_melw, off_mello, off_melcnt, off_meloff, off_dct, off_chstart, off_chsrc, off_chw;
-    int n_melw, n_ch, total;     // total: bytes, multiple of 16
+    // per-lane padded lists, entry n of lane i at [n * 16 + i]  (conflict-free across the 16 lanes of a frame group)
+    int off_w0, off_k0, off_w1, off_k1, off_w2, off_k2;   // mel classes: filter i | filter 16+i | half of filter 32+(i&7)
+    int off_chw, off_chk;                                  // chroma gather list of pitch class i
+    int off_dct;                                           // 13 rows padded to 41 doubles
+    int off_tw2, off_twp;                                  // double2 [16][16]: W400^(r p) and W800^(p + 25 q) of lane p
+    int melN0, melN1, melN2, chN;                          // list lengths (multiples of 4)
+    int total;                                             // bytes, multiple of 16
 };
 }  // namespace f800
 struct FastLaunch {
@@ -184,6 +192,10 @@ __device__ __forceinline__ double group_scan_incl(double v) {
     return v;
 }
 
+// value of lane 15 of the row in every lane (v_readlane-free: row_bcast is not available inside a row, so
+// take the maximum of a non-negative non-decreasing scan instead: the inclusive scan's largest entry)
+__device__ __forceinline__ double dpp_bcast15(double v) { return group_max(v); }
+
 // sqrt for x >= 0 to ~1 ulp: v_rsq_f64 seed + two coupled Newton steps (ocml's version adds scaling for
 // sub-normal / huge arguments, which |X|^2 of a normalised frame never reaches)
 __device__ __forceinline__ double fast_sqrt(double x) {
@@ -211,38 +223,31 @@ constexpr int WAVE_BYTES = ((LDS_BYTES + 15) / 16) * 16;
 
 template <int DELTAS>
 __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, TabLayout L,
+                                                                     const unsigned char *__restrict__ blob,
                                                                      const int16_t *__restrict__ sig,
                                                                      const ClipDev *__restrict__ clips,
                                                                      const ClipNorm *__restrict__ norms,
                                                                      const Tile *__restrict__ tiles, int n_tiles,
                                                                      double *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // ---------------- shared tables: global -> LDS once per workgroup
+    // ---------------- shared tables: the host-built blob has exactly the LDS layout; copy it once per workgroup
     {
-        double *t_melw = reinterpret_cast<double *>(smem + L.off_melw);
-        int *t_lo = reinterpret_cast<int *>(smem + L.off_mello);
-        int *t_cnt = reinterpret_cast<int *>(smem + L.off_melcnt);
-        int *t_off = reinterpret_cast<int *>(smem + L.off_meloff);
-        double *t_dct = reinterpret_cast<double *>(smem + L.off_dct);
-        int *t_chs = reinterpret_cast<int *>(smem + L.off_chstart);
-        int *t_src = reinterpret_cast<int *>(smem + L.off_chsrc);
-        double *t_chw = reinterpret_cast<double *>(smem + L.off_chw);
-        const int tid = threadIdx.x;
-        for (int n = tid; n < L.n_melw; n += 64 * WAVES) t_melw[n] = P.mel_w[n];
-        for (int n = tid; n < 40; n += 64 * WAVES) { t_lo[n] = P.mel_lo[n]; t_cnt[n] = P.mel_cnt[n]; t_off[n] = P.mel_off[n]; }
-        for (int n = tid; n < 13 * 40; n += 64 * WAVES) t_dct[n] = P.dct[n];
-        for (int n = tid; n < 13; n += 64 * WAVES) t_chs[n] = P.ch_start[n];
-        for (int n = tid; n < L.n_ch; n += 64 * WAVES) { t_src[n] = P.ch_src[n]; t_chw[n] = P.ch_w[n]; }
+        const int4 *src4 = reinterpret_cast<const int4 *>(blob);
+        int4 *dst4 = reinterpret_cast<int4 *>(smem);
+        for (int n = threadIdx.x; n < L.total / 16; n += 64 * WAVES) dst4[n] = src4[n];
     }
     __syncthreads();       // the only workgroup-wide barrier; from here on every wave runs on its own
-    const double *t_melw = reinterpret_cast<const double *>(smem + L.off_melw);
-    const int *t_lo = reinterpret_cast<const int *>(smem + L.off_mello);
-    const int *t_cnt = reinterpret_cast<const int *>(smem + L.off_melcnt);
-    const int *t_off = reinterpret_cast<const int *>(smem + L.off_meloff);
-    const double *t_dct = reinterpret_cast<const double *>(smem + L.off_dct);
-    const int *t_chs = reinterpret_cast<const int *>(smem + L.off_chstart);
-    const int *t_src = reinterpret_cast<const int *>(smem + L.off_chsrc);
+    const double *t_melw0 = reinterpret_cast<const double *>(smem + L.off_w0);
+    const int *t_melk0 = reinterpret_cast<const int *>(smem + L.off_k0);
+    const double *t_melw1 = reinterpret_cast<const double *>(smem + L.off_w1);
+    const int *t_melk1 = reinterpret_cast<const int *>(smem + L.off_k1);
+    const double *t_melw2 = reinterpret_cast<const double *>(smem + L.off_w2);
+    const int *t_melk2 = reinterpret_cast<const int *>(smem + L.off_k2);
     const double *t_chw = reinterpret_cast<const double *>(smem + L.off_chw);
+    const int *t_chk = reinterpret_cast<const int *>(smem + L.off_chk);
+    const double *t_dct = reinterpret_cast<const double *>(smem + L.off_dct);
+    const double2 *t_tw2 = reinterpret_cast<const double2 *>(smem + L.off_tw2);
+    const double2 *t_twp = reinterpret_cast<const double2 *>(smem + L.off_twp);
 
     const int wave = threadIdx.x >> 6;
     const int tile_id = blockIdx.x * WAVES + wave;
@@ -280,15 +285,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, T
     const int thr_pos = (int)fmin(fmax(floor(mu) + 1.0, -40000.0), 40000.0);   // x >= thr_pos  <=> positive
     const int thr_neg = (int)fmin(fmax(ceil(mu) - 1.0, -40000.0), 40000.0);    // x <= thr_neg  <=> negative
 
-    // register-resident twiddles: W400^(r p), r = 1..15 (pass 2) and W800^(p + 25 q), q = 0..15 (recombination)
+    // pass-2 columns of this lane; the twiddles W400^(r p) and W800^(p + 25 q) sit in the shared LDS table
     const int pa = i, pb = (i == 0) ? 0 : 25 - i;
     const bool act = i < 13;
-    double2 tw2[16], twp[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        tw2[r] = act ? P.tw[r * pa] : make_double2(1.0, 0.0);
-        twp[r] = act ? P.post[pa + 25 * r] : make_double2(1.0, 0.0);
-    }
 
     const int t_end = tl.t0 + tl.cnt;
     int q0 = tl.t0 >= QUAD ? tl.t0 - QUAD : 0;
@@ -404,8 +403,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, T
             b[0] = make_double2(bx[0], by[0]);
 #pragma unroll
             for (int r = 1; r < 16; ++r) {
-                a[r] = cmul(make_double2(ax[r], ay[r]), tw2[r]);
-                b[r] = cmul(make_double2(bx[r], by[r]), make_double2(tw2[r].x, -tw2[r].y));
+                const double2 w = t_tw2[r * 16 + i];
+                a[r] = cmul(make_double2(ax[r], ay[r]), w);
+                b[r] = cmul(make_double2(bx[r], by[r]), make_double2(w.x, -w.y));
             }
             dft16(a);
             dft16(b);
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, T
                 const double2 e = make_double2(0.5 * (zk.x + zb.x), 0.5 * (zk.y - zb.y));
                 const double2 d = make_double2(0.5 * (zk.x - zb.x), 0.5 * (zk.y + zb.y));
                 const double2 o = make_double2(d.y, -d.x);
-                const double2 t = cmul(twp[q], o);
+                const double2 t = cmul(t_twp[q * 16 + i], o);
                 double xr = e.x + t.x, xi = e.y + t.y;
                 const double yr = e.x - t.x, yi = e.y - t.y;
                 if (q == 0 && i == 0) { xr -= dc_shift; xi = 0.0; }    // DC bin: remove the residual clip mean
@@ -434,31 +434,42 @@ __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, T
         wsync();
 
         // ---------------- features: 16 lanes per frame (group g <-> frame q0 + g)
+        // lane i owns bins [25 i, 25 i + 25) of its frame; current and previous spectrum are pulled into
+        // registers once (two batched LDS bursts) and serve the sums, the spread/flux pass and the roll-off scan
         const int t = q0 + g;
         const double *cur = spec + ((slot0 + g) % 5) * NF;
         const double *prv = (t == 0) ? cur : spec + ((slot0 + g + 4) % 5) * NF;
-        double sX = 0.0, sXe = 0.0, sXp = 0.0, sIX = 0.0, mx = 0.0, sP = 0.0;
-#pragma unroll 5
+        // spectral entropy operands: lane i < 10 owns block i of 40 bins (:85-107)
+        double pblk = 0.0;
+        {
+            const double2 *c2 = reinterpret_cast<const double2 *>(cur + 40 * (i < 10 ? i : 0));
+            double2 blk[20];
+#pragma unroll
+            for (int m = 0; m < 20; ++m) blk[m] = c2[m];
+#pragma unroll
+            for (int m = 0; m < 20; ++m) { pblk = fma(blk[m].x, blk[m].x, pblk); pblk = fma(blk[m].y, blk[m].y, pblk); }
+            if (i >= 10) pblk = 0.0;
+        }
+        asm volatile("" ::: "memory");
+        double Xc[25], Xv[25];
+#pragma unroll
+        for (int m = 0; m < 25; ++m) { Xc[m] = cur[25 * i + m]; Xv[m] = prv[25 * i + m]; }
+        double sX = 0.0, sXe = 0.0, sXp = 0.0, sIX = 0.0, mx = 0.0, cs = 0.0;
+#pragma unroll
         for (int m = 0; m < 25; ++m) {
-            const int k = i + 16 * m;
-            const double X = cur[k];
+            const double X = Xc[m];
             sX += X;
             sXe += X + kEps;
-            sXp += prv[k] + kEps;
-            sIX = fma((double)(k + 1) * f0, X, sIX);
+            sXp += Xv[m] + kEps;
+            sIX = fma((double)(25 * i + m + 1) * f0, X, sIX);
             mx = fmax(mx, X);
-            sP = fma(X, X, sP);
+            cs = fma(X, X, cs);
         }
         sX = group_sum(sX); sXe = group_sum(sXe); sXp = group_sum(sXp);
-        sIX = group_sum(sIX); sP = group_sum(sP); mx = group_max(mx);
+        sIX = group_sum(sIX); mx = group_max(mx);
+        const double run_incl = group_scan_incl(cs);
+        const double sP = dpp_bcast15(run_incl);            // total = inclusive scan at lane 15
 
-        // spectral entropy: lane i < 10 sums block i of 40 bins (:85-107)
-        double pblk = 0.0;
-        if (i < 10) {
-            const double2 *c2 = reinterpret_cast<const double2 *>(cur + 40 * i);
-#pragma unroll 5
-            for (int m = 0; m < 20; ++m) { const double2 x2 = c2[m]; pblk = fma(x2.x, x2.x, pblk); pblk = fma(x2.y, x2.y, pblk); }
-        }
         // energy entropy: 80-sample block i = chunks 10 g + 2 i, + 1 (:34-51)
         const double eblk = (i < 10) ? cE[10 * g + 2 * i] + cE[10 * g + 2 * i + 1] : 0.0;
         const double e_tot = group_sum(eblk);
@@ -478,64 +489,76 @@ __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, T
         const double cen = (sIX * r) / den;
         const double rX = 1.0 / sXe, rXp = 1.0 / sXp;
         double sSp = 0.0, sFl = 0.0;
-#pragma unroll 5
+#pragma unroll
         for (int m = 0; m < 25; ++m) {
-            const int k = i + 16 * m;
-            const double X = cur[k];
-            const double dv = (double)(k + 1) * f0 - cen;
+            const double X = Xc[m];
+            const double dv = (double)(25 * i + m + 1) * f0 - cen;
             sSp = fma(dv * dv, X * r, sSp);
-            const double df = X * rX - prv[k] * rXp;
+            const double df = X * rX - Xv[m] * rXp;
             sFl = fma(df, df, sFl);
         }
         sSp = group_sum(sSp);
         sFl = group_sum(sFl);
         const double spread = sqrt(sSp / den);
 
-        // roll-off (:127-140): lane i scans bins [25 i, 25 i + 25)
+        // roll-off (:127-140): first k with cumsum(X^2)[k] + eps > 0.9 sum(X^2); branch-free per lane
         int first = 0x7fffffff;
         {
             const double thr = 0.90 * sP;
-            double cs = 0.0;
-#pragma unroll 5
-            for (int m = 0; m < 25; ++m) { const double X = cur[25 * i + m]; cs = fma(X, X, cs); }
-            double run = group_scan_incl(cs) - cs;
-            // the crossing lies in exactly one lane's chunk (or none when sP == 0 ... then bin 0 crosses at once)
-            if (run + kEps <= thr || i == 0) {
-                for (int m = 0; m < 25; ++m) {
-                    const double X = cur[25 * i + m];
-                    run = fma(X, X, run);
-                    if (run + kEps > thr) { first = 25 * i + m; break; }
-                }
+            double run = run_incl - cs;
+#pragma unroll
+            for (int m = 0; m < 25; ++m) {
+                run = fma(Xc[m], Xc[m], run);
+                first = (first == 0x7fffffff && run + kEps > thr) ? 25 * i + m : first;
             }
             first = group_min_i(first);
         }
 
-        // MFCC (:236-254): filters i, i+16, i+32
+        // MFCC (:236-254): per-lane padded mel lists (host-built): class 0 = filter i, class 1 = filter 16+i,
+        // class 2 = one half of filter 32 + (i & 7); the halves meet through a row rotation by 8
         double *mg = msp + 40 * g;
+        {
+            double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+            for (int n = 0; n < L.melN0; n += 4) {
 #pragma unroll
-        for (int fi = 0; fi < 3; ++fi) {
-            const int m = i + 16 * fi;
-            if (m < 40) {
-                const int lo = t_lo[m], cnt = t_cnt[m];
-                const double *w = t_melw + t_off[m];
-                double acc = 0.0;
-                for (int n = 0; n < cnt; ++n) acc = fma(cur[lo + n], w[n], acc);
-                mg[m] = log10(acc + kEps);
+                for (int u = 0; u < 4; ++u)
+                    acc0 = fma(cur[t_melk0[(n + u) * 16 + i]], t_melw0[(n + u) * 16 + i], acc0);
             }
+            for (int n = 0; n < L.melN1; n += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc1 = fma(cur[t_melk1[(n + u) * 16 + i]], t_melw1[(n + u) * 16 + i], acc1);
+            }
+            for (int n = 0; n < L.melN2; n += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc2 = fma(cur[t_melk2[(n + u) * 16 + i]], t_melw2[(n + u) * 16 + i], acc2);
+            }
+            acc2 += dpp_mov<0x128>(acc2);                    // row_ror:8
+            mg[i] = log10(acc0 + kEps);
+            mg[16 + i] = log10(acc1 + kEps);
+            const double l2 = log10(acc2 + kEps);
+            if (i < 8) mg[32 + i] = l2;
         }
-        // chroma (:277-321): lane i < 12 = pitch class i
+        // chroma (:277-321): lane i < 12 = pitch class i, padded gather list in ascending slot order
         double chroma = 0.0;
-        if (i < 12) {
-            const int b0 = t_chs[i], b1 = t_chs[i + 1];
-            for (int n = b0; n < b1; ++n) { const double x = cur[t_src[n]]; chroma += (x * x) * t_chw[n]; }
+        {
+            for (int n = 0; n < L.chN; n += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double x = cur[t_chk[(n + u) * 16 + i]];
+                    chroma = fma(x * x, t_chw[(n + u) * 16 + i], chroma);
+                }
+            }
             chroma = (sP == 0.0) ? chroma / kEps : chroma / sP;
+            if (i >= 12) chroma = 0.0;
         }
         wsync();
         double *fg = fv + FV_STRIDE * g;
         if (i < 13) {
-            const double *dm = t_dct + 40 * i;
+            const double *dm = t_dct + 41 * i;        // rows padded to 41 doubles: conflict-free across lanes
             double acc = 0.0;
-#pragma unroll 8
+#pragma unroll
             for (int n = 0; n < 40; ++n) acc = fma(dm[n], mg[n], acc);
             fg[8 + i] = acc;
         }
@@ -586,24 +609,59 @@ __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, T
 // the generic kernel must be used, < 0 on error
 inline int fast_select(int window, int step, int sample_kind, double fs, FastTables &ft, const FftPlan &fft,
                        const MelTable &mel, const ChromaTable &chroma, FastLaunch &fl) {
-    (void)fs; (void)ft; (void)fft;
+    (void)fs;
     if (!(window == 800 && step == 400 && sample_kind == 0)) return 0;
-    const int n_melw = (int)mel.w.size(), n_ch = (int)chroma.src.size();
-    if (n_melw > 2048 || n_ch > 512) return 0;           // tables would not fit the shared LDS region
     f800::TabLayout &L = fl.layout;
+    auto up4 = [](int n) { return std::max(4, (n + 3) / 4 * 4); };
+    int c0 = 0, c1 = 0, c2 = 0, cc = 0;
+    for (int m = 0; m < 16; ++m) c0 = std::max(c0, (int)mel.cnt[m]);
+    for (int m = 16; m < 32; ++m) c1 = std::max(c1, (int)mel.cnt[m]);
+    for (int m = 32; m < 40; ++m) c2 = std::max(c2, ((int)mel.cnt[m] + 1) / 2);
+    for (int c = 0; c < 12; ++c) cc = std::max(cc, (int)(chroma.class_start[c + 1] - chroma.class_start[c]));
+    L.melN0 = up4(c0); L.melN1 = up4(c1); L.melN2 = up4(c2); L.chN = up4(cc);
     int off = 0;
     auto take = [&off](int bytes) { const int o = off; off += (bytes + 15) / 16 * 16; return o; };
-    L.off_melw = take(n_melw * 8);
-    L.off_mello = take(40 * 4);
-    L.off_melcnt = take(40 * 4);
-    L.off_meloff = take(40 * 4);
-    L.off_dct = take(13 * 40 * 8);
-    L.off_chstart = take(13 * 4);
-    L.off_chsrc = take(n_ch * 4);
-    L.off_chw = take(n_ch * 8);
-    L.n_melw = n_melw;
-    L.n_ch = n_ch;
+    L.off_w0 = take(L.melN0 * 16 * 8); L.off_k0 = take(L.melN0 * 16 * 4);
+    L.off_w1 = take(L.melN1 * 16 * 8); L.off_k1 = take(L.melN1 * 16 * 4);
+    L.off_w2 = take(L.melN2 * 16 * 8); L.off_k2 = take(L.melN2 * 16 * 4);
+    L.off_chw = take(L.chN * 16 * 8);  L.off_chk = take(L.chN * 16 * 4);
+    L.off_dct = take(13 * 41 * 8);
+    L.off_tw2 = take(16 * 16 * 16);
+    L.off_twp = take(16 * 16 * 16);
     L.total = off;
+    if ((size_t)L.total + (size_t)f800::WAVES * f800::WAVE_BYTES > 160 * 1024) return 0;   // generic kernel instead
+    if (!ft.d_blob) {
+        std::vector<unsigned char> blob((size_t)L.total, 0);
+        auto W = [&](int o) { return reinterpret_cast<double *>(blob.data() + o); };
+        auto K = [&](int o) { return reinterpret_cast<int32_t *>(blob.data() + o); };
+        for (int i = 0; i < 16; ++i) {
+            const int f0 = i, f1 = 16 + i, f2 = 32 + (i & 7);
+            for (int n = 0; n < mel.cnt[f0]; ++n) { W(L.off_w0)[n * 16 + i] = mel.w[mel.off[f0] + n]; K(L.off_k0)[n * 16 + i] = mel.lo[f0] + n; }
+            for (int n = 0; n < mel.cnt[f1]; ++n) { W(L.off_w1)[n * 16 + i] = mel.w[mel.off[f1] + n]; K(L.off_k1)[n * 16 + i] = mel.lo[f1] + n; }
+            const int half = (mel.cnt[f2] + 1) / 2;
+            const int b = (i < 8) ? 0 : half, e = (i < 8) ? half : mel.cnt[f2];
+            for (int n = b; n < e; ++n) { W(L.off_w2)[(n - b) * 16 + i] = mel.w[mel.off[f2] + n]; K(L.off_k2)[(n - b) * 16 + i] = mel.lo[f2] + n; }
+            if (i < 12)
+                for (int n = chroma.class_start[i]; n < chroma.class_start[i + 1]; ++n) {
+                    W(L.off_chw)[(n - chroma.class_start[i]) * 16 + i] = chroma.w[n];
+                    K(L.off_chk)[(n - chroma.class_start[i]) * 16 + i] = chroma.src[n];
+                }
+        }
+        double dct[kNumMfcc * kNumMel];
+        build_dct(dct);
+        for (int q = 0; q < 13; ++q)
+            for (int n = 0; n < 40; ++n) W(L.off_dct)[q * 41 + n] = dct[q * 40 + n];
+        for (int p = 0; p < 16; ++p)
+            for (int r = 0; r < 16; ++r) {
+                const int m2 = (p < 13) ? r * p : 0, mp = (p < 13) ? p + 25 * r : 0;
+                W(L.off_tw2)[2 * (r * 16 + p)] = fft.tw[2 * m2];
+                W(L.off_tw2)[2 * (r * 16 + p) + 1] = fft.tw[2 * m2 + 1];
+                W(L.off_twp)[2 * (r * 16 + p)] = fft.post[2 * mp];
+                W(L.off_twp)[2 * (r * 16 + p) + 1] = fft.post[2 * mp + 1];
+            }
+        if (hipMalloc(&ft.d_blob, blob.size()) != hipSuccess) return PAA_ERR_OOM;
+        if (hipMemcpy(ft.d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) return PAA_ERR_HIP;
+    }
     fl.name = "st_fast_800";
     fl.lds = (size_t)L.total + (size_t)f800::WAVES * f800::WAVE_BYTES;
     fl.variant = 800;
@@ -615,10 +673,10 @@ inline int fast_select(int window, int step, int sample_kind, double fs, FastTab
 inline int fast_launch(const FastLaunch &fl, const PlanDev &P, const FastTables &ft, const void *d_packed,
                        const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,
                        double *d_out, hipStream_t stream) {
-    (void)ft;
-    if (fl.variant != 800) return -1;
+    if (fl.variant != 800 || !ft.d_blob) return -1;
     static size_t attr_done[2] = {0, 0};
     const unsigned grid = (unsigned)((n_tiles + f800::WAVES - 1) / f800::WAVES);
+    const unsigned char *blob = reinterpret_cast<const unsigned char *>(ft.d_blob);
     if (P.deltas) {
         if (attr_done[1] < fl.lds) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(&f800::st_fast_800_kernel<1>),
@@ -626,7 +684,7 @@ inline int fast_launch(const FastLaunch &fl, const PlanDev &P, const FastTables 
             attr_done[1] = fl.lds;
         }
         hipLaunchKernelGGL(f800::st_fast_800_kernel<1>, dim3(grid), dim3(64 * f800::WAVES), fl.lds, stream, P,
-                           fl.layout, (const int16_t *)d_packed, clips, norms, tiles, (int)n_tiles, d_out);
+                           fl.layout, blob, (const int16_t *)d_packed, clips, norms, tiles, (int)n_tiles, d_out);
     } else {
         if (attr_done[0] < fl.lds) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(&f800::st_fast_800_kernel<0>),
@@ -634,7 +692,7 @@ inline int fast_launch(const FastLaunch &fl, const PlanDev &P, const FastTables 
             attr_done[0] = fl.lds;
         }
         hipLaunchKernelGGL(f800::st_fast_800_kernel<0>, dim3(grid), dim3(64 * f800::WAVES), fl.lds, stream, P,
-                           fl.layout, (const int16_t *)d_packed, clips, norms, tiles, (int)n_tiles, d_out);
+                           fl.layout, blob, (const int16_t *)d_packed, clips, norms, tiles, (int)n_tiles, d_out);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
