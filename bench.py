@@ -105,33 +105,30 @@ def main():
     gather_note = None
     d_all = None
     counts = np.full(world, plan.out_doubles, dtype=np.int64)
+    comm = None
     if gather:
-        try:
-            import ctypes
-            idbuf = ctypes.create_string_buffer(_ffi.COMM_ID_BYTES)
-            if rank == 0:
-                _ffi.check(lib.paa_comm_unique_id(idbuf))
-            obj = [bytes(idbuf.raw)]
+        from pyaudioanalysis_amd import distributed as D
+
+        def bcast(payload):
+            obj = [payload]
             dist.broadcast_object_list(obj, src=0)
-            idbuf = ctypes.create_string_buffer(obj[0], _ffi.COMM_ID_BYTES)
-            _ffi.check(lib.paa_comm_init(world, rank, idbuf))
+            return obj[0]
+        try:
+            comm = D.RcclGather(world, rank, bcast)
             if rank == 0:
                 d_all = _ffi.DeviceBuffer(int(counts.sum()) * 8)
+            ok = True
         except Exception as exc:       # keep the scaling run alive, say what happened
-            gather = False
-            gather_note = "RCCL init failed: %s" % exc
-        flags = [gather]
-        dist.broadcast_object_list(flags, src=0)
-        ok = [gather]
+            ok = False
+            gather_note = "RCCL init failed on rank %d: %s" % (rank, exc)
         all_ok = [None] * world
-        dist.all_gather_object(all_ok, ok[0])
+        dist.all_gather_object(all_ok, ok)
         gather = all(all_ok)
 
     def step():
         plan.execute(d_in, d_out)
         if gather:
-            recv = d_all.ptr if rank == 0 else None
-            _ffi.check(lib.paa_comm_gather_f64(d_out.ptr, _ffi.as_i64p(counts), 0, recv))
+            comm.gather(d_out, counts, 0, d_all)
 
     def barrier():
         _ffi.sync()
@@ -218,8 +215,8 @@ def main():
             result["cpu_baseline"] = None
         print(json.dumps(result))
         sys.stdout.flush()
-    if gather:
-        lib.paa_comm_destroy()
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1,0 +1,131 @@
+"""Many clips across the GPUs of one node: one process per GPU, contiguous clip ranges balanced by frame
+count, per-rank plans, and ONE gather of the result blocks to a root rank over RCCL (xGMI).
+
+Clips are independent units (normalisation is per clip, ShortTermFeatures.py:570), so there is no data-path
+collective besides that gather.  The reference has no distributed code; this is the batched form of the
+per-file loop in MidTermFeatures.directory_feature_extraction (MidTermFeatures.py:167-201).
+
+The process group used for rendezvous (unique-id broadcast, barriers) is supplied by the caller -- bench.py and
+the tests use torch.distributed with the gloo backend; the feature data itself moves GPU -> GPU through
+libpaa_hip.so's paa_comm_gather_f64 (grouped ncclSend/ncclRecv).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _ffi
+
+
+def frames_per_clip(lengths, window, step):
+    """T_c = floor((n_c - window)/step) + 1 (ShortTermFeatures.py:608), 0 when the clip is too short."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    t = (lengths - int(window)) // int(step) + 1
+    return np.where(lengths >= int(window), t, 0).astype(np.int64)
+
+
+def partition_by_frames(frames, world_size):
+    """Contiguous clip ranges [(start, end)] per rank, balanced by the running sum of frames.
+
+    Rank r takes the clips whose cumulative-frame midpoint falls into the r-th equal slice of the total, so
+    equal-length clips split evenly (12 500 each for 100 000 clips on 8 GPUs) and ragged batches stay balanced
+    to within one clip.
+    """
+    frames = np.asarray(frames, dtype=np.int64)
+    n = len(frames)
+    total = int(frames.sum())
+    if world_size < 1:
+        raise ValueError("world_size must be >= 1")
+    if n == 0 or total == 0:
+        base = [(min(r * n // world_size, n), min((r + 1) * n // world_size, n)) for r in range(world_size)]
+        return base
+    csum = np.cumsum(frames)
+    mid = csum - frames / 2.0
+    owner = np.minimum((mid * world_size / total).astype(np.int64), world_size - 1)
+    ranges = []
+    for r in range(world_size):
+        idx = np.nonzero(owner == r)[0]
+        if len(idx) == 0:
+            start = ranges[-1][1] if ranges else 0
+            ranges.append((start, start))
+        else:
+            ranges.append((int(idx[0]), int(idx[-1]) + 1))
+    return ranges
+
+
+def block_counts(frames, ranges, n_rows):
+    """float64 elements each rank contributes: n_rows * sum of its clips' frames."""
+    frames = np.asarray(frames, dtype=np.int64)
+    return np.array([n_rows * int(frames[a:b].sum()) for a, b in ranges], dtype=np.int64)
+
+
+def split_gathered(flat, frames, n_rows):
+    """Cut the rank-ordered concatenation of [n_rows][T_c] slabs back into one array per clip."""
+    out, pos = [], 0
+    for t in np.asarray(frames, dtype=np.int64):
+        cnt = n_rows * int(t)
+        out.append(np.asarray(flat[pos:pos + cnt]).reshape(n_rows, int(t)))
+        pos += cnt
+    if pos != len(flat):
+        raise ValueError("gathered buffer has %d elements, expected %d" % (len(flat), pos))
+    return out
+
+
+class RcclGather:
+    """The RCCL communicator of libpaa_hip.so for this process (one per GPU)."""
+
+    def __init__(self, world_size, rank, broadcast_bytes):
+        """broadcast_bytes(payload_or_None) -> payload: broadcast from rank 0 over any control-plane group."""
+        lib = _ffi.lib()
+        buf = ctypes.create_string_buffer(_ffi.COMM_ID_BYTES)
+        if rank == 0:
+            _ffi.check(lib.paa_comm_unique_id(buf))
+        payload = broadcast_bytes(bytes(buf.raw) if rank == 0 else None)
+        buf = ctypes.create_string_buffer(payload, _ffi.COMM_ID_BYTES)
+        _ffi.check(lib.paa_comm_init(int(world_size), int(rank), buf))
+        self.world_size, self.rank = int(world_size), int(rank)
+
+    def gather(self, d_send, counts, root, d_recv):
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        recv = d_recv.ptr if d_recv is not None else None
+        _ffi.check(_ffi.lib().paa_comm_gather_f64(d_send.ptr, _ffi.as_i64p(counts), int(root), recv))
+
+    def barrier(self):
+        _ffi.check(_ffi.lib().paa_comm_barrier())
+
+    def close(self):
+        _ffi.lib().paa_comm_destroy()
+
+
+def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank, comm, root=0):
+    """Rank-local part of a sharded batch extraction on the GPU.
+
+    clips: the FULL list of int16 clips (every rank sees the list; only its own range is uploaded).
+    Returns, on the root, the list of (F, T_c) arrays for all clips (None elsewhere).
+    """
+    window, step = int(window), int(step)
+    lengths = [len(c) for c in clips]
+    frames = frames_per_clip(lengths, window, step)
+    if np.any(frames < 1):
+        raise ValueError("need at least one array to concatenate")
+    ranges = partition_by_frames(frames, world_size)
+    F = 68 if deltas else 34
+    counts = block_counts(frames, ranges, F)
+    a, b = ranges[rank]
+    mine = [np.ascontiguousarray(c, dtype=np.int16) for c in clips[a:b]]
+    d_out = None
+    if mine:
+        offsets = np.zeros(len(mine) + 1, dtype=np.int64)
+        np.cumsum([len(c) for c in mine], out=offsets[1:])
+        d_in = _ffi.DeviceBuffer.from_host(np.concatenate(mine))
+        plan = _ffi.Plan(offsets, sampling_rate, window, step, deltas=deltas, sample_kind=0)
+        d_out = _ffi.DeviceBuffer(max(plan.out_doubles, 1) * 8)
+        plan.execute(d_in, d_out)
+    else:
+        d_out = _ffi.DeviceBuffer(8)
+    d_all = _ffi.DeviceBuffer(int(counts.sum()) * 8) if rank == root else None
+    comm.gather(d_out, counts, root, d_all)
+    _ffi.sync()
+    if rank != root:
+        return None
+    flat = d_all.to_host(np.float64, int(counts.sum()))
+    return split_gathered(flat, frames, F)

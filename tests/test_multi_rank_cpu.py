@@ -1,0 +1,101 @@
+"""World-size-2 test of the sharded many-clip path on CPU (gloo): partitioning by frames, per-rank blocks,
+gather to rank 0 and re-assembly.  The per-rank compute is the CPU oracle standing in for the GPU kernels
+(no GPU here); the exchanged bytes, counts and layout are exactly those of the RCCL path."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import paa_oracle as O
+    from synth import synth_clip
+    from pyaudioanalysis_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lens = [4000, 1600, 9000, 800, 5200, 2500, 7000]
+        clips = [synth_clip(900 + i, n) for i, n in enumerate(lens)]
+        W, S, F = 800, 400, 68
+        frames = D.frames_per_clip(lens, W, S)
+        ranges = D.partition_by_frames(frames, world)
+        counts = D.block_counts(frames, ranges, F)
+        a, b = ranges[rank]
+        block = np.concatenate([O.feature_extraction(c, 16000, W, S)[0].reshape(-1) for c in clips[a:b]]) \
+            if b > a else np.zeros(0)
+        assert len(block) == counts[rank]
+        # variable-size gather to rank 0 (what paa_comm_gather_f64 does with ncclSend/ncclRecv)
+        send = torch.from_numpy(block.copy())
+        if rank == 0:
+            parts = [send] + [torch.empty(int(counts[r]), dtype=torch.float64) for r in range(1, world)]
+            reqs = [dist.irecv(parts[r], src=r) for r in range(1, world)]
+            for r in reqs:
+                r.wait()
+            flat = torch.cat(parts).numpy()
+            per_clip = D.split_gathered(flat, frames, F)
+            ok = True
+            for c, got in zip(clips, per_clip):
+                ref, _ = O.feature_extraction(c, 16000, W, S)
+                ok &= bool(np.array_equal(got, ref))
+            q.put(("ok" if ok else "mismatch", ranges, counts.tolist()))
+        else:
+            dist.send(send, dst=0)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gather_roundtrip():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    status, ranges, counts = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert status == "ok"
+    assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == 7
+    assert sum(counts) == 68 * int(sum((n - 800) // 400 + 1 for n in [4000, 1600, 9000, 800, 5200, 2500, 7000]))
+
+
+def test_partition_properties():
+    sys.path.insert(0, ROOT)
+    from pyaudioanalysis_amd import distributed as D
+    rng = np.random.default_rng(0)
+    for world in (1, 2, 3, 4, 8):
+        for n in (1, 5, 8, 100, 1000):
+            frames = rng.integers(1, 2000, n)
+            ranges = D.partition_by_frames(frames, world)
+            assert len(ranges) == world
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            for (a, b), (c, d) in zip(ranges[:-1], ranges[1:]):
+                assert b == c and a <= b
+            loads = [int(frames[a:b].sum()) for a, b in ranges]
+            if n >= 50 * world:
+                assert max(loads) <= 1.1 * sum(loads) / world + frames.max()
+    # equal clips split evenly: BASELINE config 4 on 8 GPUs
+    ranges = D.partition_by_frames(np.full(100000, 399), 8)
+    assert [b - a for a, b in ranges] == [12500] * 8
+    assert list(D.frames_per_clip([799, 800, 1199, 1200, 160000], 800, 400)) == [0, 1, 1, 2, 399]

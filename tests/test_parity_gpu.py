@@ -198,3 +198,19 @@ def test_size_independent_properties_at_scale(gpu_lib):
     per = 60 * fs // S
     a, b = F[:34, 5:per - 5], F[:34, per + 5:2 * per - 5]
     assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
+
+
+def test_rccl_gather_world_size_1(gpu_lib):
+    """The RCCL path with a single rank: communicator init, gather (device copy into the root buffer), barrier."""
+    from pyaudioanalysis_amd import distributed as D
+    comm = D.RcclGather(1, 0, lambda payload: payload)
+    try:
+        clips = [synth_clip(500 + i, n) for i, n in enumerate([4000, 16000, 2400])]
+        res = D.extract_sharded(clips, 16000, 800, 400, True, 1, 0, comm)
+        comm.barrier()
+        assert len(res) == 3
+        for c, r in zip(clips, res):
+            single, _ = ShortTermFeatures.feature_extraction(c, 16000, 800, 400)
+            assert np.array_equal(single, r)
+    finally:
+        comm.close()
