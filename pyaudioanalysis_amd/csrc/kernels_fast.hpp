@@ -39,7 +39,7 @@ struct TabLayout {
     int off_chw, off_chk;                                  // chroma gather list of pitch class i
     int off_dct;                                           // 13 rows padded to 41 doubles
     int off_tw2, off_twp;                                  // double2 [16][16]: W400^(r p) and W800^(p + 25 q) of lane p
-    int melN0, melN1, melN2, chN;                          // list lengths (multiples of 4)
+    int melN0, melN1, melN2, chN;                          // list lengths (multiples of 8)
     int total;                                             // bytes, multiple of 16
 };
 }  // namespace f800
@@ -209,6 +209,47 @@ __device__ __forceinline__ double fast_sqrt(double x) {
     g = fma(d, h, g);
     return (x > 0.0) ? g : 0.0;
 }
+// magnitude variant: one coupled Newton step (relative error ~ (rsq error)^2, far below the 1e-4 parity bound
+// even for a 2^-20 seed); measured against the two-step version in tests/test_parity_gpu.py tolerances
+__device__ __forceinline__ double mag_sqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g = x * y;
+    const double h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    return (x > 0.0) ? fma(g, r, g) : 0.0;
+}
+
+// log2(x) for finite x > 0 (callers add eps = 2^-52 first): x = m 2^e with m in [sqrt(1/2), sqrt(2)),
+// ln m = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716, odd series to s^21 (truncation < 1e-18 relative).
+// About 35 FP64 operations instead of ~115 in the generic libm path; error a few 1e-16 relative.
+__device__ __forceinline__ double fast_log2(double x) {
+    double m = __builtin_amdgcn_frexp_mant(x);          // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double num = m - 1.0, den = m + 1.0;
+    double r = __builtin_amdgcn_rcp(den);
+    r = fma(fma(-den, r, 1.0), r, r);
+    r = fma(fma(-den, r, 1.0), r, r);
+    double s = num * r;
+    s = fma(fma(-den, s, num), r, s);
+    const double z = s * s;
+    double p = 1.0 / 21.0;
+    p = fma(p, z, 1.0 / 19.0);
+    p = fma(p, z, 1.0 / 17.0);
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    p = fma(p, z, 1.0);
+    // log2 m = (2 / ln 2) s p
+    return fma(s * p, 2.8853900817779268147, (double)e);
+}
+__device__ __forceinline__ double fast_log10(double x) { return fast_log2(x) * 0.30102999566398119521; }
 
 // wave-local ordering point for LDS hand-offs between lanes of ONE wave: a wave's DS instructions execute
 // in program order, so only the compiler has to be kept from moving memory operations across
@@ -218,11 +259,29 @@ __device__ __forceinline__ void wsync() {
     asm volatile("" ::: "memory");
 }
 
-constexpr int WAVES = 4;
+#ifndef PAA_F800_WAVES
+#define PAA_F800_WAVES 4
+#endif
+#ifndef PAA_F800_MIN_WAVES_PER_SIMD
+#define PAA_F800_MIN_WAVES_PER_SIMD 1
+#endif
+constexpr int WAVES = PAA_F800_WAVES;
 constexpr int WAVE_BYTES = ((LDS_BYTES + 15) / 16) * 16;
 
+// optional per-phase cycle accounting (build with -DPAA_F800_TIMING; read with paa_debug_phase_cycles)
+#ifdef PAA_F800_TIMING
+__device__ unsigned long long g_phase_cycles[16];
+#define PAA_T0() unsigned long long t_prev_ = __builtin_readcyclecounter(); unsigned long long t_acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+#define PAA_TICK(idx) { const unsigned long long t_now_ = __builtin_readcyclecounter(); t_acc_[idx] += t_now_ - t_prev_; t_prev_ = t_now_; }
+#define PAA_TEND() if (lane == 0) { for (int z_ = 0; z_ < 12; ++z_) atomicAdd(&g_phase_cycles[z_], t_acc_[z_]); atomicAdd(&g_phase_cycles[15], 1ULL); }
+#else
+#define PAA_T0()
+#define PAA_TICK(idx)
+#define PAA_TEND()
+#endif
+
 template <int DELTAS>
-__global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, TabLayout L,
+__global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fast_800_kernel(PlanDev P, TabLayout L,
                                                                      const unsigned char *__restrict__ blob,
                                                                      const int16_t *__restrict__ sig,
                                                                      const ClipDev *__restrict__ clips,
@@ -279,8 +338,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, T
     // component (and its round-off leakage into the other bins) below half a count per sample.
     const double mu = nm.mean * 32768.0;             // clip mean in counts (exact scaling)
     const int m_int = (int)fmin(fmax(nearbyint(mu), -40000.0), 40000.0);
-    const double mag_scale = nm.inv * sc / (double)NF;
-    const double dc_shift = (double)W * (mu - (double)m_int);
+    const double mag_scale = 0.5 * nm.inv * sc / (double)NF;       // 0.5: E and O carry a factor 1/2
+    const double dc_shift = 2.0 * (double)W * (mu - (double)m_int);
     // integer sign thresholds: sign(x/2^15 - mean) = sign(x - mu)
     const int thr_pos = (int)fmin(fmax(floor(mu) + 1.0, -40000.0), 40000.0);   // x >= thr_pos  <=> positive
     const int thr_neg = (int)fmin(fmax(ceil(mu) - 1.0, -40000.0), 40000.0);    // x <= thr_neg  <=> negative
@@ -311,6 +370,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, T
         }                                                                                              \
     }
     PAA_F800_FETCH(q0)
+    PAA_T0()
 
     for (; q0 < t_end; q0 += QUAD, slot0 = (slot0 + 4) % 5) {
         // ---------------- stage raw samples [q0*S - 1, q0*S + 2000)
@@ -331,6 +391,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, T
             if (q0 + QUAD < t_end) PAA_F800_FETCH(q0 + QUAD)
         }
         wsync();
+        PAA_TICK(0)
 
         // ---------------- time domain: chunk partials (ShortTermFeatures.py:22-51)
         if (lane < NCHUNK) {
@@ -363,6 +424,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, T
             cF[lane] = zfirst;
         }
 
+        PAA_TICK(1)
         // ---------------- pass 1: radix-25 on z[j + 16 r], z = x[2n] + i x[2n+1] (raw integers, exact in f64)
         double2 v[25];
         {
@@ -374,11 +436,15 @@ __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, T
             }
         }
         dft25(v);
-        wsync();      // raw + chunk partials complete; the previous quad's readers of the slots are done
+        wsync();
+        PAA_TICK(2)      // raw + chunk partials complete; the previous quad's readers of the slots are done
 
         // exchange through the quad's 4 spectrum slots: real plane, then imaginary plane.
         // element (frame g, index 25 j + q)
         double ax[16], ay[16], bx[16], by[16];
+        double2 w2[16];       // W400^(r p): requested before the exchange so they land while it runs
+#pragma unroll
+        for (int r = 1; r < 16; ++r) w2[r] = t_tw2[r * 16 + i];
         {
             double *pl = spec + ((slot0 + g) % 5) * NF;
 #pragma unroll
@@ -395,6 +461,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, T
             wsync();
         }
 
+        PAA_TICK(3)
         // ---------------- pass 2 + real-FFT recombination + magnitude (ShortTermFeatures.py:617-621)
         if (act) {
             // column 25-p uses the conjugate twiddles and a one-step rotation of the outputs
@@ -403,10 +470,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, T
             b[0] = make_double2(bx[0], by[0]);
 #pragma unroll
             for (int r = 1; r < 16; ++r) {
-                const double2 w = t_tw2[r * 16 + i];
-                a[r] = cmul(make_double2(ax[r], ay[r]), w);
-                b[r] = cmul(make_double2(bx[r], by[r]), make_double2(w.x, -w.y));
+                a[r] = cmul(make_double2(ax[r], ay[r]), w2[r]);
+                b[r] = cmul(make_double2(bx[r], by[r]), make_double2(w2[r].x, -w2[r].y));
             }
+            double2 wp[16];   // W800^(p + 25 q): in flight during the two radix-16 transforms
+#pragma unroll
+            for (int q = 0; q < 16; ++q) wp[q] = t_twp[q * 16 + i];
             dft16(a);
             dft16(b);
             double *sp = spec + ((slot0 + g) % 5) * NF;
@@ -420,19 +489,20 @@ __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, T
                 const double2 za = a[PAA_DFT16_POS(qm)], zq = b[PAA_DFT16_POS(qm)];
                 const double2 zb = make_double2((i == 0) ? za.x : zq.x, (i == 0) ? za.y : zq.y);
                 const int k = pa + 25 * q;
-                const double2 e = make_double2(0.5 * (zk.x + zb.x), 0.5 * (zk.y - zb.y));
-                const double2 d = make_double2(0.5 * (zk.x - zb.x), 0.5 * (zk.y + zb.y));
-                const double2 o = make_double2(d.y, -d.x);
-                const double2 t = cmul(t_twp[q * 16 + i], o);
+                // 2E = Z[k] + conj Z[400-k],  2O = -i (Z[k] - conj Z[400-k])
+                const double2 e = make_double2(zk.x + zb.x, zk.y - zb.y);
+                const double2 o = make_double2(zk.y + zb.y, zb.x - zk.x);
+                const double2 t = cmul(wp[q], o);
                 double xr = e.x + t.x, xi = e.y + t.y;
                 const double yr = e.x - t.x, yi = e.y - t.y;
                 if (q == 0 && i == 0) { xr -= dc_shift; xi = 0.0; }    // DC bin: remove the residual clip mean
-                sp[k] = fast_sqrt(fma(xr, xr, xi * xi)) * mag_scale;
-                if (q > 0 || i > 0) sp[NF - k] = fast_sqrt(fma(yr, yr, yi * yi)) * mag_scale;
+                sp[k] = mag_sqrt(fma(xr, xr, xi * xi)) * mag_scale;
+                if (q > 0 || i > 0) sp[NF - k] = mag_sqrt(fma(yr, yr, yi * yi)) * mag_scale;
             }
         }
         wsync();
 
+        PAA_TICK(4)
         // ---------------- features: 16 lanes per frame (group g <-> frame q0 + g)
         // lane i owns bins [25 i, 25 i + 25) of its frame; current and previous spectrum are pulled into
         // registers once (two batched LDS bursts) and serve the sums, the spread/flux pass and the roll-off scan
@@ -446,27 +516,41 @@ __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, T
             double2 blk[20];
 #pragma unroll
             for (int m = 0; m < 20; ++m) blk[m] = c2[m];
+            double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
 #pragma unroll
-            for (int m = 0; m < 20; ++m) { pblk = fma(blk[m].x, blk[m].x, pblk); pblk = fma(blk[m].y, blk[m].y, pblk); }
-            if (i >= 10) pblk = 0.0;
+            for (int m = 0; m < 20; m += 2) {
+                p0 = fma(blk[m].x, blk[m].x, p0); p1 = fma(blk[m].y, blk[m].y, p1);
+                p2 = fma(blk[m + 1].x, blk[m + 1].x, p2); p3 = fma(blk[m + 1].y, blk[m + 1].y, p3);
+            }
+            pblk = (i < 10) ? (p0 + p1) + (p2 + p3) : 0.0;
         }
         asm volatile("" ::: "memory");
         double Xc[25], Xv[25];
 #pragma unroll
         for (int m = 0; m < 25; ++m) { Xc[m] = cur[25 * i + m]; Xv[m] = prv[25 * i + m]; }
-        double sX = 0.0, sXe = 0.0, sXp = 0.0, sIX = 0.0, mx = 0.0, cs = 0.0;
+        // sums over the lane's 25 bins; two interleaved accumulator sets keep the dependent chains short.
+        // sum(ind * X) with ind = (k+1) f0 is f0 * [(25 i + 1) * sum X + sum m X]   (small exact integers)
+        double sXa = 0.0, sXb = 0.0, sPa = 0.0, sPb = 0.0, sMa = 0.0, sMb = 0.0, sVa = 0.0, sVb = 0.0, mx = 0.0;
 #pragma unroll
-        for (int m = 0; m < 25; ++m) {
-            const double X = Xc[m];
-            sX += X;
-            sXe += X + kEps;
-            sXp += Xv[m] + kEps;
-            sIX = fma((double)(25 * i + m + 1) * f0, X, sIX);
-            mx = fmax(mx, X);
-            cs = fma(X, X, cs);
+        for (int m = 0; m < 24; m += 2) {
+            const double X0 = Xc[m], X1 = Xc[m + 1];
+            sXa += X0; sXb += X1;
+            sVa += Xv[m]; sVb += Xv[m + 1];
+            sMa = fma((double)m, X0, sMa); sMb = fma((double)(m + 1), X1, sMb);
+            sPa = fma(X0, X0, sPa); sPb = fma(X1, X1, sPb);
+            mx = fmax(mx, fmax(X0, X1));
         }
-        sX = group_sum(sX); sXe = group_sum(sXe); sXp = group_sum(sXp);
+        sXa += Xc[24]; sVa += Xv[24]; sMa = fma(24.0, Xc[24], sMa); sPa = fma(Xc[24], Xc[24], sPa); mx = fmax(mx, Xc[24]);
+        const double cs = sPa + sPb;
+        const double base_k = (double)(25 * i + 1);
+        double sX = sXa + sXb;
+        double sIX = f0 * fma(base_k, sX, sMa + sMb);
+        double sXp = sVa + sVb;
+        sX = group_sum(sX); sXp = group_sum(sXp);
         sIX = group_sum(sIX); mx = group_max(mx);
+        // np.sum(X + eps) (:118-119) = sum X + 400 eps up to rounding
+        const double sXe = sX + (double)NF * kEps;
+        sXp += (double)NF * kEps;
         const double run_incl = group_scan_incl(cs);
         const double sP = dpp_bcast15(run_incl);            // total = inclusive scan at lane 15
 
@@ -476,27 +560,38 @@ __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, T
         double ent_f, ent_e;
         {
             const double sf = pblk / (sP + kEps), se = eblk / (e_tot + kEps);
-            ent_f = group_sum((i < 10) ? -(sf * log2(sf + kEps)) : 0.0);
-            ent_e = group_sum((i < 10) ? -(se * log2(se + kEps)) : 0.0);
+            ent_f = group_sum((i < 10) ? -(sf * fast_log2(sf + kEps)) : 0.0);
+            ent_e = group_sum((i < 10) ? -(se * fast_log2(se + kEps)) : 0.0);
         }
         // zero crossings: 20 chunks of the frame minus the pair that straddles the frame start (:22-26)
         int zc = cZ[10 * g + i] + ((i < 4) ? cZ[10 * g + 16 + i] : 0) - ((i == 0) ? cF[10 * g] : 0);
         zc = group_sum_i(zc);
 
+        PAA_TICK(5)
         // centroid, spread, flux (:57-82, :110-124)
         const double r = (mx == 0.0) ? 1.0 / kEps : 1.0 / mx;
         const double den = sX * r + kEps;
         const double cen = (sIX * r) / den;
         const double rX = 1.0 / sXe, rXp = 1.0 / sXp;
-        double sSp = 0.0, sFl = 0.0;
+        // spread: sum (ind - C)^2 X / max = f0^2/max * sum ((k+1) - C/f0)^2 X
+        const double cb = base_k - cen / f0;
+        double sSa = 0.0, sSb = 0.0, sFa = 0.0, sFb = 0.0;
 #pragma unroll
-        for (int m = 0; m < 25; ++m) {
-            const double X = Xc[m];
-            const double dv = (double)(25 * i + m + 1) * f0 - cen;
-            sSp = fma(dv * dv, X * r, sSp);
-            const double df = X * rX - Xv[m] * rXp;
-            sFl = fma(df, df, sFl);
+        for (int m = 0; m < 24; m += 2) {
+            const double d0 = cb + (double)m, d1 = cb + (double)(m + 1);
+            sSa = fma(d0 * d0, Xc[m], sSa);
+            sSb = fma(d1 * d1, Xc[m + 1], sSb);
+            const double f0d = Xc[m] * rX - Xv[m] * rXp, f1d = Xc[m + 1] * rX - Xv[m + 1] * rXp;
+            sFa = fma(f0d, f0d, sFa);
+            sFb = fma(f1d, f1d, sFb);
         }
+        {
+            const double d0 = cb + 24.0;
+            sSa = fma(d0 * d0, Xc[24], sSa);
+            const double f0d = Xc[24] * rX - Xv[24] * rXp;
+            sFa = fma(f0d, f0d, sFa);
+        }
+        double sSp = (sSa + sSb) * (f0 * f0 * r), sFl = sFa + sFb;
         sSp = group_sum(sSp);
         sFl = group_sum(sFl);
         const double spread = sqrt(sSp / den);
@@ -514,53 +609,77 @@ __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, T
             first = group_min_i(first);
         }
 
+        PAA_TICK(6)
         // MFCC (:236-254): per-lane padded mel lists (host-built): class 0 = filter i, class 1 = filter 16+i,
         // class 2 = one half of filter 32 + (i & 7); the halves meet through a row rotation by 8
         double *mg = msp + 40 * g;
         {
+            // a filter covers consecutive bins, so only its first bin is tabulated (k*[i]); weights are
+            // zero-padded to the class length and the bin index is clamped into the spectrum
             double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-            for (int n = 0; n < L.melN0; n += 4) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    acc0 = fma(cur[t_melk0[(n + u) * 16 + i]], t_melw0[(n + u) * 16 + i], acc0);
+            const int lo0 = t_melk0[i], lo1 = t_melk1[i], lo2 = t_melk2[i];
+            // each trip issues its 16 LDS loads back to back (one wait), then runs two 4-long FMA chains
+#define PAA_MEL_CLASS(acc, lo, N, tw)                                                                   \
+            for (int n = 0; n < (N); n += 8) {                                                          \
+                double xv_[8], wv_[8];                                                                  \
+                _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                         \
+                    xv_[u] = cur[min((lo) + n + u, NF - 1)];                                            \
+                    wv_[u] = (tw)[(n + u) * 16 + i];                                                    \
+                }                                                                                       \
+                double ea_ = 0.0, eb_ = 0.0;                                                            \
+                _Pragma("unroll") for (int u = 0; u < 8; u += 2) {                                      \
+                    ea_ = fma(xv_[u], wv_[u], ea_);                                                     \
+                    eb_ = fma(xv_[u + 1], wv_[u + 1], eb_);                                             \
+                }                                                                                       \
+                acc += ea_ + eb_;                                                                       \
             }
-            for (int n = 0; n < L.melN1; n += 4) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    acc1 = fma(cur[t_melk1[(n + u) * 16 + i]], t_melw1[(n + u) * 16 + i], acc1);
-            }
-            for (int n = 0; n < L.melN2; n += 4) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    acc2 = fma(cur[t_melk2[(n + u) * 16 + i]], t_melw2[(n + u) * 16 + i], acc2);
-            }
+            PAA_MEL_CLASS(acc0, lo0, L.melN0, t_melw0)
+            PAA_MEL_CLASS(acc1, lo1, L.melN1, t_melw1)
+            PAA_MEL_CLASS(acc2, lo2, L.melN2, t_melw2)
+#undef PAA_MEL_CLASS
             acc2 += dpp_mov<0x128>(acc2);                    // row_ror:8
-            mg[i] = log10(acc0 + kEps);
-            mg[16 + i] = log10(acc1 + kEps);
-            const double l2 = log10(acc2 + kEps);
+            mg[i] = fast_log10(acc0 + kEps);
+            mg[16 + i] = fast_log10(acc1 + kEps);
+            const double l2 = fast_log10(acc2 + kEps);
             if (i < 8) mg[32 + i] = l2;
         }
+        PAA_TICK(7)
         // chroma (:277-321): lane i < 12 = pitch class i, padded gather list in ascending slot order
         double chroma = 0.0;
         {
-            for (int n = 0; n < L.chN; n += 4) {
+            for (int n = 0; n < L.chN; n += 8) {
+                int kv[8];
+                double wv[8], xv[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const double x = cur[t_chk[(n + u) * 16 + i]];
-                    chroma = fma(x * x, t_chw[(n + u) * 16 + i], chroma);
-                }
+                for (int u = 0; u < 8; ++u) { kv[u] = t_chk[(n + u) * 16 + i]; wv[u] = t_chw[(n + u) * 16 + i]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xv[u] = cur[kv[u]];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) chroma = fma(xv[u] * xv[u], wv[u], chroma);     // ascending slot order (:299-302)
             }
             chroma = (sP == 0.0) ? chroma / kEps : chroma / sP;
             if (i >= 12) chroma = 0.0;
         }
         wsync();
+        PAA_TICK(8)
         double *fg = fv + FV_STRIDE * g;
         if (i < 13) {
             const double *dm = t_dct + 41 * i;        // rows padded to 41 doubles: conflict-free across lanes
-            double acc = 0.0;
+            double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
 #pragma unroll
-            for (int n = 0; n < 40; ++n) acc = fma(dm[n], mg[n], acc);
-            fg[8 + i] = acc;
+            for (int h = 0; h < 2; ++h) {
+                double dv[20], mv[20];
+#pragma unroll
+                for (int n = 0; n < 20; ++n) { dv[n] = dm[20 * h + n]; mv[n] = mg[20 * h + n]; }
+#pragma unroll
+                for (int n = 0; n < 20; n += 4) {
+                    c0 = fma(dv[n], mv[n], c0);
+                    c1 = fma(dv[n + 1], mv[n + 1], c1);
+                    c2 = fma(dv[n + 2], mv[n + 2], c2);
+                    c3 = fma(dv[n + 3], mv[n + 3], c3);
+                }
+            }
+            fg[8 + i] = (c0 + c1) + (c2 + c3);
         }
         if (i < 12) fg[21 + i] = chroma;
         if (i == 15) {
@@ -581,6 +700,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, T
         }
         wsync();
 
+        PAA_TICK(9)
         // ---------------- store: lane = feature row, 4 consecutive frames
         if (lane < kBase) {
             double vq[QUAD];
@@ -600,7 +720,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_kernel(PlanDev P, T
             vlast = vq[QUAD - 1];
         }
         wsync();
+        PAA_TICK(10)
     }
+    PAA_TEND()
 }
 
 }  // namespace f800
@@ -612,7 +734,7 @@ inline int fast_select(int window, int step, int sample_kind, double fs, FastTab
     (void)fs;
     if (!(window == 800 && step == 400 && sample_kind == 0)) return 0;
     f800::TabLayout &L = fl.layout;
-    auto up4 = [](int n) { return std::max(4, (n + 3) / 4 * 4); };
+    auto up4 = [](int n) { return std::max(8, (n + 7) / 8 * 8); };      // lists are unrolled by 8 on the device
     int c0 = 0, c1 = 0, c2 = 0, cc = 0;
     for (int m = 0; m < 16; ++m) c0 = std::max(c0, (int)mel.cnt[m]);
     for (int m = 16; m < 32; ++m) c1 = std::max(c1, (int)mel.cnt[m]);
@@ -665,7 +787,7 @@ inline int fast_select(int window, int step, int sample_kind, double fs, FastTab
     fl.name = "st_fast_800";
     fl.lds = (size_t)L.total + (size_t)f800::WAVES * f800::WAVE_BYTES;
     fl.variant = 800;
-    fl.run = 128;       // frames per run (one wave); the plan shrinks it to fill the chip
+    fl.run = 256;       // longest run (frames) given to one wave; the plan shrinks it to fill the chip
     fl.waves_per_cu = f800::WAVES;
     return 1;
 }

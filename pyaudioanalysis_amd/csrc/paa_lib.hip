@@ -284,7 +284,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         // rounds (256 CUs x resident waves), in multiples of the 4-frame quad, at most fl.run frames
         const long long slots = 256LL * p->fl.waves_per_cu;
         const long long per = (total_frames + slots - 1) / slots;
-        const long long rounds = (per + p->fl.run - 1) / p->fl.run;
+        const long long rounds = (per + p->fl.run - 1) / p->fl.run;     // fl.run = longest run worth one wave
         long long r = (per + std::max<long long>(rounds, 1) - 1) / std::max<long long>(rounds, 1);
         r = ((r + 3) / 4) * 4;
         run = (int)std::min<long long>(p->fl.run, std::max<long long>(16, r));
@@ -798,6 +798,23 @@ extern "C" int paa_chromagram_f64(const double *s, int64_t n, double fs, int w, 
 // ------------------------------------------------------------------------------------------
 // introspection for tests
 // ------------------------------------------------------------------------------------------
+// per-phase cycle totals of st_fast_800 (only in builds with -DPAA_F800_TIMING; zeros otherwise); resets them
+extern "C" int paa_debug_phase_cycles(uint64_t *out16) {
+    if (!out16) return fail(PAA_ERR_ARG, "null");
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+#ifdef PAA_F800_TIMING
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    unsigned long long host[16];
+    HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(f800::g_phase_cycles), sizeof(host)));
+    for (int i = 0; i < 16; ++i) out16[i] = host[i];
+    unsigned long long zero[16] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(f800::g_phase_cycles), zero, sizeof(zero)));
+#endif
+    return PAA_OK;
+}
+
 extern "C" int paa_debug_mel_bank(double fs, int num_fft, double *out_dense) {
     if (!out_dense || num_fft < 1) return fail(PAA_ERR_ARG, "bad argument");
     MelTable t;
