@@ -99,6 +99,7 @@ def main():
     plan = _ffi.Plan(offsets, FS, WINDOW, STEP, deltas=bool(args.deltas), sample_kind=0)
     F = plan.F
     d_out = _ffi.DeviceBuffer(plan.out_doubles * 8)
+    d_out2 = _ffi.DeviceBuffer(plan.out_doubles * 8) if world > 1 else d_out   # N>1: the gather of step k overlaps step k+1
     frames = plan.total_frames
 
     gather = world > 1 and not args.no_gather
@@ -125,10 +126,16 @@ def main():
         dist.all_gather_object(all_ok, ok)
         gather = all(all_ok)
 
+    bufs = [d_out, d_out2]
+    state = {"k": 0}
+
     def step():
-        plan.execute(d_in, d_out)
+        buf = bufs[state["k"] & 1]
+        state["k"] += 1
+        plan.execute(d_in, buf)
         if gather:
-            comm.gather(d_out, counts, 0, d_all)
+            # runs on the library's communication stream; the next write of `buf` waits for it
+            comm.gather(buf, counts, 0, d_all)
 
     def barrier():
         _ffi.sync()
@@ -168,6 +175,23 @@ def main():
     _ffi.check(lib.paa_prof_read(ctypes.byref(kms), ctypes.byref(kn)))
     _ffi.check(lib.paa_prof_enable(0))
 
+    # N > 1: also time the same steps without the gather (reported beside the headline value)
+    value_no_gather = None
+    if gather:
+        saved, gather = gather, False
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        _ffi.sync()
+        el2 = time.perf_counter() - t1
+        dist.barrier()
+        import torch
+        tt = torch.tensor([el2], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        value_no_gather = frames * world * args.steps / float(tt.item())
+        gather = saved
+
     if rank == 0:
         total_frames = frames * world
         ms_per_step = 1e3 * elapsed / args.steps
@@ -193,6 +217,23 @@ def main():
         }
         if gather_note:
             result["config"]["gather_note"] = gather_note
+        if value_no_gather is not None:
+            result["config"]["frames_per_s_without_gather"] = value_no_gather
+            result["config"]["gather_bytes_per_step_into_root"] = int(plan.out_doubles * 8 * (world - 1))
+        # HBM traffic of the feature kernel from the committed rocprofv3 PMC pass of this same command
+        # (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as reported), per launch
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json")))
+            if prof.get("kernel") == plan.kernel_name and prof.get("frames") == int(frames) and prof.get("rows") == F:
+                result["roofline"]["traffic"] = prof["hbm_bytes_per_launch"]
+                result["roofline"]["traffic_over_algorithmic"] = prof["hbm_bytes_per_launch"] / float(bytes_per_frame * frames)
+                result["roofline"]["traffic_source"] = prof.get("source")
+        except Exception:
+            pass
+        # informational: executed FP64 work against the vector FP64 peak (the roofline that actually binds)
+        result["roofline"]["fp64_valu"] = {"algorithmic_kflop_per_frame": 45.0,
+                                           "achieved_tflops": 45.0e3 * frames / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0,
+                                           "peak_tflops": FP64_VALU_PEAK_TFLOPS}
         if args.check:
             import paa_oracle as O
             got = d_out.to_host(np.float64, plan.out_doubles).reshape(-1)

@@ -22,6 +22,11 @@ RcclApi g_rccl;
 ncclComm_t g_comm = nullptr;
 int g_world = 1, g_rank = 0;
 int *g_bar = nullptr;
+// the gather runs on its own stream so that it overlaps the next batch's kernels: g_ev_ready orders it
+// after the producing kernels, g_gather_done[send buffer] orders the next writer of that buffer after it
+hipStream_t g_comm_stream = nullptr;
+hipEvent_t g_ev_ready = nullptr;
+std::map<const void *, hipEvent_t> g_gather_done;
 
 int rccl_load() {
     if (g_rccl.h) return PAA_OK;
@@ -79,15 +84,22 @@ extern "C" int paa_comm_init(int world_size, int rank, const void *id_bytes) {
     g_rank = rank;
     HIP_TRY(hipMalloc((void **)&g_bar, sizeof(int)));
     HIP_TRY(hipMemset(g_bar, 0, sizeof(int)));
+    HIP_TRY(hipStreamCreateWithFlags(&g_comm_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&g_ev_ready, hipEventDisableTiming));
     return PAA_OK;
 }
 
 extern "C" int paa_comm_destroy(void) {
     if (g_comm) {
         if (g_stream) (void)hipStreamSynchronize(g_stream);
+        if (g_comm_stream) (void)hipStreamSynchronize(g_comm_stream);
         g_rccl.CommDestroy(g_comm);
         g_comm = nullptr;
     }
+    for (auto &kv : g_gather_done) (void)hipEventDestroy(kv.second);
+    g_gather_done.clear();
+    if (g_ev_ready) { (void)hipEventDestroy(g_ev_ready); g_ev_ready = nullptr; }
+    if (g_comm_stream) { (void)hipStreamDestroy(g_comm_stream); g_comm_stream = nullptr; }
     if (g_bar) { (void)hipFree(g_bar); g_bar = nullptr; }
     g_world = 1;
     g_rank = 0;
@@ -102,30 +114,50 @@ extern "C" int paa_comm_gather_f64(const double *d_send, const int64_t *counts, 
             HIP_TRY(hipMemcpyAsync(d_recv, d_send, (size_t)counts[0] * 8, hipMemcpyDeviceToDevice, g_stream));
         return PAA_OK;
     }
+    // order the gather after everything queued so far on the compute stream
+    HIP_TRY(hipEventRecord(g_ev_ready, g_stream));
+    HIP_TRY(hipStreamWaitEvent(g_comm_stream, g_ev_ready, 0));
     NCCL_TRY(g_rccl.GroupStart());
     if (g_rank == root) {
         long long off = 0;
         for (int r = 0; r < g_world; ++r) {
             if (r != root && counts[r] > 0)
-                NCCL_TRY(g_rccl.Recv(d_recv + off, (size_t)counts[r], ncclDouble, r, g_comm, g_stream));
+                NCCL_TRY(g_rccl.Recv(d_recv + off, (size_t)counts[r], ncclDouble, r, g_comm, g_comm_stream));
             off += counts[r];
         }
     } else if (counts[g_rank] > 0) {
-        NCCL_TRY(g_rccl.Send(d_send, (size_t)counts[g_rank], ncclDouble, root, g_comm, g_stream));
+        NCCL_TRY(g_rccl.Send(d_send, (size_t)counts[g_rank], ncclDouble, root, g_comm, g_comm_stream));
     }
     NCCL_TRY(g_rccl.GroupEnd());
     if (g_rank == root && d_send && counts[root] > 0) {
         long long off = 0;
         for (int r = 0; r < root; ++r) off += counts[r];
         if (d_recv + off != d_send)
-            HIP_TRY(hipMemcpyAsync(d_recv + off, d_send, (size_t)counts[root] * 8, hipMemcpyDeviceToDevice, g_stream));
+            HIP_TRY(hipMemcpyAsync(d_recv + off, d_send, (size_t)counts[root] * 8, hipMemcpyDeviceToDevice, g_comm_stream));
     }
+    if (d_send) {       // the next kernel that writes d_send must wait for this gather (see paa_plan_execute)
+        hipEvent_t &ev = g_gather_done[d_send];
+        if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev, g_comm_stream));
+    }
+    return PAA_OK;
+}
+
+// called by paa_plan_execute before it overwrites d_out
+static int comm_wait_buffer_free(const void *d_out) {
+    auto it = g_gather_done.find(d_out);
+    if (it != g_gather_done.end() && it->second) HIP_TRY(hipStreamWaitEvent(g_stream, it->second, 0));
+    return PAA_OK;
+}
+static int comm_sync() {
+    if (g_comm_stream) HIP_TRY(hipStreamSynchronize(g_comm_stream));
     return PAA_OK;
 }
 
 extern "C" int paa_comm_barrier(void) {
     if (!g_comm) return PAA_OK;
-    NCCL_TRY(g_rccl.AllReduce(g_bar, g_bar, 1, ncclInt, ncclSum, g_comm, g_stream));
     HIP_TRY(hipStreamSynchronize(g_stream));
+    NCCL_TRY(g_rccl.AllReduce(g_bar, g_bar, 1, ncclInt, ncclSum, g_comm, g_comm_stream));
+    HIP_TRY(hipStreamSynchronize(g_comm_stream));
     return PAA_OK;
 }

@@ -81,6 +81,9 @@ static size_t g_prof_used = 0;
 static double g_prof_ms = 0.0;
 static long long g_prof_n = 0;
 
+static int comm_wait_buffer_free(const void *d_out);
+static int comm_sync();
+
 static int ensure_init() {
     if (g_device >= 0) return PAA_OK;
     return paa_init(0);
@@ -368,7 +371,9 @@ static int launch_generic(paa_plan *p, const void *d_packed, double *d_out) {
 extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *d_out) {
     if (!plan || !d_packed || !d_out) return fail(PAA_ERR_ARG, "null plan / buffer");
     std::lock_guard<std::mutex> lk(g_mu);
-    int rc = launch_stats(plan, d_packed);
+    int rc = comm_wait_buffer_free(d_out);      // a gather of this buffer may still be in flight
+    if (rc) return rc;
+    rc = launch_stats(plan, d_packed);
     if (rc) return rc;
     if (plan->n_tiles == 0) return PAA_OK;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
@@ -535,7 +540,7 @@ extern "C" int paa_dev_sync(void) {
     int rc = ensure_init();
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(g_stream));
-    return PAA_OK;
+    return comm_sync();
 }
 extern "C" int paa_timer_start(void) {
     int rc = ensure_init();
