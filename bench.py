@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--deltas", type=int, default=0, help="1: 68-row output (reference default), 0: the 34-feature metric")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather to rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=24000)
+    ap.add_argument("--cpu-frames", type=int, default=144000, help="frames of the clip prefix timed on the CPU (about 8 s of CPU)")
     ap.add_argument("--check", type=int, default=1, help="verify a few frames against the oracle after timing")
     args = ap.parse_args()
 

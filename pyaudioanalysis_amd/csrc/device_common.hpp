@@ -138,6 +138,59 @@ __device__ __forceinline__ void dft5(double2 *v) {
     v[3] = add_i(m2, n2);
 }
 
+// ---- 16-lane group reductions on DPP (no LDS traffic; every lane ends with the same bits) ----------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+// quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror, row_mirror
+#define PAA_DPP_X1 0xB1
+#define PAA_DPP_X2 0x4E
+#define PAA_DPP_HM 0x141
+#define PAA_DPP_RM 0x140
+__device__ __forceinline__ double group_sum(double v) {
+    v += dpp_mov<PAA_DPP_X1>(v);
+    v += dpp_mov<PAA_DPP_X2>(v);
+    v += dpp_mov<PAA_DPP_HM>(v);
+    v += dpp_mov<PAA_DPP_RM>(v);
+    return v;
+}
+__device__ __forceinline__ double group_max(double v) {
+    v = fmax(v, dpp_mov<PAA_DPP_X1>(v));
+    v = fmax(v, dpp_mov<PAA_DPP_X2>(v));
+    v = fmax(v, dpp_mov<PAA_DPP_HM>(v));
+    v = fmax(v, dpp_mov<PAA_DPP_RM>(v));
+    return v;
+}
+__device__ __forceinline__ int group_sum_i(int v) {
+    v += dpp_mov_i<PAA_DPP_X1>(v);
+    v += dpp_mov_i<PAA_DPP_X2>(v);
+    v += dpp_mov_i<PAA_DPP_HM>(v);
+    v += dpp_mov_i<PAA_DPP_RM>(v);
+    return v;
+}
+__device__ __forceinline__ int group_min_i(int v) {
+    v = min(v, dpp_mov_i<PAA_DPP_X1>(v));
+    v = min(v, dpp_mov_i<PAA_DPP_X2>(v));
+    v = min(v, dpp_mov_i<PAA_DPP_HM>(v));
+    v = min(v, dpp_mov_i<PAA_DPP_RM>(v));
+    return v;
+}
+// inclusive prefix sum over the 16-lane row: row_shr:n shifts zeros in (bound_ctrl)
+__device__ __forceinline__ double group_scan_incl(double v) {
+    v += dpp_mov<0x111>(v);
+    v += dpp_mov<0x112>(v);
+    v += dpp_mov<0x114>(v);
+    v += dpp_mov<0x118>(v);
+    return v;
+}
+
+
 template <typename T> __device__ __forceinline__ double load_sample(const T *p);
 template <> __device__ __forceinline__ double load_sample<int16_t>(const int16_t *p) { return (double)(*p); }
 template <> __device__ __forceinline__ double load_sample<double>(const double *p) { return *p; }

@@ -127,6 +127,8 @@ __device__ __forceinline__ double nan_to_num(double v) {
     return v;
 }
 
+// 16 lanes per (row, mid window): the window's values are read as 128-byte segments, summed with DPP
+// reductions (4 windows per wave at a time); the second pass re-reads from L1/L2.
 __global__ __launch_bounds__(256) void mid_stats_kernel(const ClipDev *__restrict__ clips,
                                                          const long long *__restrict__ mid_off,
                                                          const double *__restrict__ st, int nrows,
@@ -137,22 +139,28 @@ __global__ __launch_bounds__(256) void mid_stats_kernel(const ClipDev *__restric
     const ClipDev cd = clips[c];
     const long long T = cd.T;
     const long long M = (T + step - 1) / step;
-    const long long idx = (long long)chunk * 256 + threadIdx.x;
-    if (idx >= (long long)nrows * M) return;
-    const long long row = idx / M, m = idx % M;
+    const int i = threadIdx.x & 15;
+    const long long idx = (long long)chunk * 16 + (threadIdx.x >> 4);      // 16 windows per block
+    const bool live = idx < (long long)nrows * M;
+    const long long row = live ? idx / M : 0, m = live ? idx % M : 0;
     const double *x = st + cd.out_off + row * T;
     const long long b = m * step;
     long long e = b + ratio;
     if (e > T) e = T;
+    if (!live) e = b;
     double s = 0.0;
-    for (long long i = b; i < e; ++i) s += x[i];
+    for (long long k = b + i; k < e; k += 16) s += x[k];
+    s = group_sum(s);
     const double n = (double)(e - b);
     const double mean = s / n;
     double v = 0.0;
-    for (long long i = b; i < e; ++i) { const double d = x[i] - mean; v = fma(d, d, v); }
-    double *o = mid + mid_off[c];
-    o[row * M + m] = nan_to_num(mean);
-    o[(row + nrows) * M + m] = nan_to_num(sqrt(v / n));
+    for (long long k = b + i; k < e; k += 16) { const double d = x[k] - mean; v = fma(d, d, v); }
+    v = group_sum(v);
+    if (live && i == 0) {
+        double *o = mid + mid_off[c];
+        o[row * M + m] = nan_to_num(mean);
+        o[(row + nrows) * M + m] = nan_to_num(sqrt(v / n));
+    }
 }
 
 }  // namespace paa

@@ -140,58 +140,6 @@ __device__ __forceinline__ void dft16(double2 *v) {
 }
 #define PAA_DFT16_POS(q) (4 * ((q) % 4) + (q) / 4)
 
-// ---- 16-lane group reductions on DPP (no LDS traffic; every lane ends with the same bits) ----------
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_mov_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
-// quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror, row_mirror
-#define PAA_DPP_X1 0xB1
-#define PAA_DPP_X2 0x4E
-#define PAA_DPP_HM 0x141
-#define PAA_DPP_RM 0x140
-__device__ __forceinline__ double group_sum(double v) {
-    v += dpp_mov<PAA_DPP_X1>(v);
-    v += dpp_mov<PAA_DPP_X2>(v);
-    v += dpp_mov<PAA_DPP_HM>(v);
-    v += dpp_mov<PAA_DPP_RM>(v);
-    return v;
-}
-__device__ __forceinline__ double group_max(double v) {
-    v = fmax(v, dpp_mov<PAA_DPP_X1>(v));
-    v = fmax(v, dpp_mov<PAA_DPP_X2>(v));
-    v = fmax(v, dpp_mov<PAA_DPP_HM>(v));
-    v = fmax(v, dpp_mov<PAA_DPP_RM>(v));
-    return v;
-}
-__device__ __forceinline__ int group_sum_i(int v) {
-    v += dpp_mov_i<PAA_DPP_X1>(v);
-    v += dpp_mov_i<PAA_DPP_X2>(v);
-    v += dpp_mov_i<PAA_DPP_HM>(v);
-    v += dpp_mov_i<PAA_DPP_RM>(v);
-    return v;
-}
-__device__ __forceinline__ int group_min_i(int v) {
-    v = min(v, dpp_mov_i<PAA_DPP_X1>(v));
-    v = min(v, dpp_mov_i<PAA_DPP_X2>(v));
-    v = min(v, dpp_mov_i<PAA_DPP_HM>(v));
-    v = min(v, dpp_mov_i<PAA_DPP_RM>(v));
-    return v;
-}
-// inclusive prefix sum over the 16-lane row: row_shr:n shifts zeros in (bound_ctrl)
-__device__ __forceinline__ double group_scan_incl(double v) {
-    v += dpp_mov<0x111>(v);
-    v += dpp_mov<0x112>(v);
-    v += dpp_mov<0x114>(v);
-    v += dpp_mov<0x118>(v);
-    return v;
-}
-
 // value of lane 15 of the row in every lane (v_readlane-free: row_bcast is not available inside a row, so
 // take the maximum of a non-negative non-decreasing scan instead: the inclusive scan's largest entry)
 __device__ __forceinline__ double dpp_bcast15(double v) { return group_max(v); }
@@ -484,10 +432,9 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
                 // Z[k], k = p + 25 q ; Z[400 - k] = column (25-p), output (15 - q) -> rotated index (16 - q) % 16
                 const double2 zk = a[PAA_DFT16_POS(q)];
                 const int qm = (16 - q) % 16;
-                // (scalar selects: a select between two array ELEMENTS of struct type becomes a pointer
-                //  select and sends both arrays to scratch)
-                const double2 za = a[PAA_DFT16_POS(qm)], zq = b[PAA_DFT16_POS(qm)];
-                const double2 zb = make_double2((i == 0) ? za.x : zq.x, (i == 0) ? za.y : zq.y);
+                // lane 0 (p = 0) has b == a bit for bit (same column, unit twiddles), so no select is needed:
+                // Z[400 - 25 q] = A[(16 - q) % 16] = b[...] there as well
+                const double2 zb = b[PAA_DFT16_POS(qm)];
                 const int k = pa + 25 * q;
                 // 2E = Z[k] + conj Z[400-k],  2O = -i (Z[k] - conj Z[400-k])
                 const double2 e = make_double2(zk.x + zb.x, zk.y - zb.y);

@@ -457,7 +457,7 @@ extern "C" int paa_plan_mid_execute(paa_plan_t *plan, const double *d_st, int64_
     for (long long c = 0; c < plan->n_clips; ++c)
         maxM = std::max<long long>(maxM, paa_num_mid_windows(plan->clips[c].T, mid_step_ratio));
     const long long items = (long long)plan->P.F * maxM;
-    const int bpc = (int)((items + 255) / 256);
+    const int bpc = (int)((items + 15) / 16);          // 16 (row, window) items per 256-thread block
     const long long grid = plan->n_clips * bpc;
     if (grid > 0x7fffffffLL) return fail(PAA_ERR_UNSUPPORTED, "mid-term grid too large");
     hipLaunchKernelGGL(mid_stats_kernel, dim3((unsigned)grid), dim3(256), 0, g_stream, plan->d_clips, plan->d_mid_off,
