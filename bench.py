@@ -137,14 +137,19 @@ def main():
             # runs on the library's communication stream; the next write of `buf` waits for it
             comm.gather(buf, counts, 0, d_all)
 
+    def device_sync():
+        _ffi.sync()                      # both library streams (compute + communication)
+        if dist is not None:             # N > 1 also drains torch's view of this rank's device
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+                    torch.cuda.synchronize()
+            except Exception:
+                pass
+
     def barrier():
-        _ffi.sync()
-        try:
-            import torch
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()
-        except Exception:
-            pass
+        device_sync()
         if dist is not None:
             dist.barrier()
 
@@ -155,13 +160,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    _ffi.sync()
-    try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-    except Exception:
-        pass
+    device_sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
