@@ -190,6 +190,58 @@ __device__ __forceinline__ double group_scan_incl(double v) {
     return v;
 }
 
+// wave-local ordering point for LDS hand-offs between lanes of ONE wave: a wave's DS instructions execute
+// in program order, so only the compiler has to be kept from moving memory operations across
+__device__ __forceinline__ void wsync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+
+// ---- full-wave (64-lane) reductions on DPP: row reduction, then row_bcast15 / row_bcast31 carry the row
+// totals forward; lane 63 ends with the total, which v_readlane broadcasts (identical bits in every lane)
+__device__ __forceinline__ double readlane63(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_mov_rows(double v) {      // masked-off rows receive 0
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wsum(double v) {
+    v = group_sum(v);
+    v += dpp_mov_rows<0x142, 0xA>(v);
+    v += dpp_mov_rows<0x143, 0xC>(v);
+    return readlane63(v);
+}
+__device__ __forceinline__ double wmax_nonneg(double v) {      // operands >= 0 (masked rows contribute 0)
+    v = group_max(v);
+    v = fmax(v, dpp_mov_rows<0x142, 0xA>(v));
+    v = fmax(v, dpp_mov_rows<0x143, 0xC>(v));
+    return readlane63(v);
+}
+__device__ __forceinline__ int wsum_i(int v) {
+    v = group_sum_i(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wmin_i(int v) {                 // via max of negated non-positive... keep simple: xor tree
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ double wscan_incl(double v) {
+    v = group_scan_incl(v);
+    v += dpp_mov_rows<0x142, 0xA>(v);
+    v += dpp_mov_rows<0x143, 0xC>(v);
+    return v;
+}
 
 template <typename T> __device__ __forceinline__ double load_sample(const T *p);
 template <> __device__ __forceinline__ double load_sample<int16_t>(const int16_t *p) { return (double)(*p); }

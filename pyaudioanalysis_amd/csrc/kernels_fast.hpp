@@ -59,21 +59,31 @@ inline void fast_tables_free(FastTables &t) {
 
 namespace f800 {
 
-constexpr int W = 800, S = 400, NF = 400, QUAD = 4;
-constexpr int RAW_N = (QUAD - 1) * S + W;          // 2000 samples per quad
+constexpr int W = 800, NF = 400, QUAD = 4;
 constexpr int RAW_PAD = 8;                          // raw[RAW_PAD + i]; raw[RAW_PAD - 1] = sample before
-constexpr int CHUNK = 40, NCHUNK = RAW_N / CHUNK;   // 50 chunks of 40 samples
+constexpr int CHUNK = 40;                           // time-domain partials are formed over 40-sample chunks
 constexpr int FV_STRIDE = 34;
 
-// LDS carve (bytes)
-constexpr int OFF_SPEC = 0;                                   // 5 slots x 400 doubles
-constexpr int OFF_RAW = OFF_SPEC + 5 * NF * 8;                // int16 raw[2016]; aliased by msp[4][40] later
-constexpr int OFF_CE = OFF_RAW + (RAW_N + 2 * RAW_PAD) * 2;   // double cE[50]
-constexpr int OFF_CZ = OFF_CE + NCHUNK * 8;                   // int cZ[50], cF[50]
-constexpr int OFF_FV = OFF_CZ + 2 * NCHUNK * 4;               // double fv[4][34]
-constexpr int LDS_BYTES = OFF_FV + QUAD * FV_STRIDE * 8;
-static_assert(OFF_RAW % 16 == 0 && OFF_CE % 8 == 0 && OFF_FV % 8 == 0, "LDS alignment");
-static_assert(QUAD * 40 * 8 <= (RAW_N + 2 * RAW_PAD) * 2, "msp alias fits in the raw buffer");
+// step-dependent geometry (S = 400: 50 % overlap, the BASELINE shape; S = 800: back-to-back frames, the
+// reference's own default 50 ms / 50 ms)
+template <int S>
+struct Geo {
+    static_assert(S % CHUNK == 0 && S % 8 == 0, "step must be a multiple of the 40-sample chunk");
+    static constexpr int RAW_N = (QUAD - 1) * S + W;            // samples per quad: 2000 / 3200
+    static constexpr int NCHUNK = RAW_N / CHUNK;                // 50 / 80
+    static constexpr int CPF = S / CHUNK;                       // chunks per frame step: 10 / 20
+    static constexpr int NPRE = (RAW_N / 8 + 63) / 64;          // 16-byte prefetch registers per lane: 4 / 7
+    // LDS carve (bytes)
+    static constexpr int OFF_SPEC = 0;                                   // 5 slots x 400 doubles
+    static constexpr int OFF_RAW = OFF_SPEC + 5 * NF * 8;                // int16 raw[]; aliased by msp[4][40] later
+    static constexpr int OFF_CE = OFF_RAW + (RAW_N + 2 * RAW_PAD) * 2;   // double cE[NCHUNK]
+    static constexpr int OFF_CZ = OFF_CE + NCHUNK * 8;                   // int cZ[NCHUNK], cF[NCHUNK]
+    static constexpr int OFF_FV = OFF_CZ + 2 * NCHUNK * 4;               // double fv[4][34]
+    static constexpr int LDS_BYTES = OFF_FV + QUAD * FV_STRIDE * 8;
+    static constexpr int WAVE_BYTES = ((LDS_BYTES + 15) / 16) * 16;
+    static_assert(OFF_RAW % 16 == 0 && OFF_CE % 8 == 0 && OFF_FV % 8 == 0, "LDS alignment");
+    static_assert(QUAD * 40 * 8 <= (RAW_N + 2 * RAW_PAD) * 2, "msp alias fits in the raw buffer");
+};
 
 // ---- register DFTs ------------------------------------------------------------------------
 __device__ __forceinline__ void dft5r(double2 &a0, double2 &a1, double2 &a2, double2 &a3, double2 &a4) {
@@ -199,14 +209,6 @@ __device__ __forceinline__ double fast_log2(double x) {
 }
 __device__ __forceinline__ double fast_log10(double x) { return fast_log2(x) * 0.30102999566398119521; }
 
-// wave-local ordering point for LDS hand-offs between lanes of ONE wave: a wave's DS instructions execute
-// in program order, so only the compiler has to be kept from moving memory operations across
-__device__ __forceinline__ void wsync() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
-}
-
 #ifndef PAA_F800_WAVES
 #define PAA_F800_WAVES 4
 #endif
@@ -214,7 +216,6 @@ __device__ __forceinline__ void wsync() {
 #define PAA_F800_MIN_WAVES_PER_SIMD 1
 #endif
 constexpr int WAVES = PAA_F800_WAVES;
-constexpr int WAVE_BYTES = ((LDS_BYTES + 15) / 16) * 16;
 
 // optional per-phase cycle accounting (build with -DPAA_F800_TIMING; read with paa_debug_phase_cycles)
 #ifdef PAA_F800_TIMING
@@ -228,7 +229,7 @@ __device__ unsigned long long g_phase_cycles[16];
 #define PAA_TEND()
 #endif
 
-template <int DELTAS>
+template <int S, int DELTAS>
 __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fast_800_kernel(PlanDev P, TabLayout L,
                                                                      const unsigned char *__restrict__ blob,
                                                                      const int16_t *__restrict__ sig,
@@ -259,14 +260,16 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
     const int wave = threadIdx.x >> 6;
     const int tile_id = blockIdx.x * WAVES + wave;
     if (tile_id >= n_tiles) return;
-    unsigned char *wbase = smem + L.total + wave * WAVE_BYTES;
-    double *spec = reinterpret_cast<double *>(wbase + OFF_SPEC);
-    int16_t *raw = reinterpret_cast<int16_t *>(wbase + OFF_RAW);
-    double *msp = reinterpret_cast<double *>(wbase + OFF_RAW);          // alias: raw is dead by then
-    double *cE = reinterpret_cast<double *>(wbase + OFF_CE);
-    int *cZ = reinterpret_cast<int *>(wbase + OFF_CZ);
+    using G = Geo<S>;
+    constexpr int RAW_N = G::RAW_N, NCHUNK = G::NCHUNK, CPF = G::CPF;
+    unsigned char *wbase = smem + L.total + wave * G::WAVE_BYTES;
+    double *spec = reinterpret_cast<double *>(wbase + G::OFF_SPEC);
+    int16_t *raw = reinterpret_cast<int16_t *>(wbase + G::OFF_RAW);
+    double *msp = reinterpret_cast<double *>(wbase + G::OFF_RAW);          // alias: raw is dead by then
+    double *cE = reinterpret_cast<double *>(wbase + G::OFF_CE);
+    int *cZ = reinterpret_cast<int *>(wbase + G::OFF_CZ);
     int *cF = cZ + NCHUNK;
-    double *fv = reinterpret_cast<double *>(wbase + OFF_FV);
+    double *fv = reinterpret_cast<double *>(wbase + G::OFF_FV);
 
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, i = lane & 15;
@@ -301,8 +304,10 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
     int slot0 = 1;                   // slots of this quad: slot0 .. slot0+3 (mod 5); previous = slot0-1
     double vlast = 0.0;              // lane l < 34: feature l of the frame before this quad
 
-    // software prefetch of the next quad's samples (4 x 16 B per lane) into registers
-    int4 pre0 = make_int4(0, 0, 0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
+    // software prefetch of the next quad's samples (NPRE x 16 B per lane) into registers
+    int4 pre[G::NPRE];
+#pragma unroll
+    for (int r = 0; r < G::NPRE; ++r) pre[r] = make_int4(0, 0, 0, 0);
     bool pre_ok;
 #define PAA_F800_FETCH(q)                                                                              \
     {                                                                                                  \
@@ -311,10 +316,8 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
         pre_ok = ((reinterpret_cast<uintptr_t>(src_) & 15) == 0) && (c.n - base_ >= RAW_N);            \
         if (pre_ok) {                                                                                  \
             const int4 *s4_ = reinterpret_cast<const int4 *>(src_);                                    \
-            pre0 = s4_[lane];                                                                          \
-            pre1 = s4_[lane + 64];                                                                     \
-            pre2 = s4_[lane + 128];                                                                    \
-            if (lane + 192 < RAW_N / 8) pre3 = s4_[lane + 192];                                        \
+            _Pragma("unroll") for (int r_ = 0; r_ < G::NPRE; ++r_)                                     \
+                if (lane + 64 * r_ < RAW_N / 8) pre[r_] = s4_[lane + 64 * r_];                         \
         }                                                                                              \
     }
     PAA_F800_FETCH(q0)
@@ -327,10 +330,9 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
             const int16_t *src = xc + base;
             if (pre_ok) {
                 int4 *d4 = reinterpret_cast<int4 *>(raw + RAW_PAD);
-                d4[lane] = pre0;
-                d4[lane + 64] = pre1;
-                d4[lane + 128] = pre2;
-                if (lane + 192 < RAW_N / 8) d4[lane + 192] = pre3;
+#pragma unroll
+                for (int r = 0; r < G::NPRE; ++r)
+                    if (lane + 64 * r < RAW_N / 8) d4[lane + 64 * r] = pre[r];
             } else {
                 const long long avail = c.n - base;
                 for (int n = lane; n < RAW_N; n += 64) raw[RAW_PAD + n] = (n < avail) ? src[n] : (int16_t)0;
@@ -342,9 +344,9 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
         PAA_TICK(0)
 
         // ---------------- time domain: chunk partials (ShortTermFeatures.py:22-51)
-        if (lane < NCHUNK) {
-            const int4 *p4 = reinterpret_cast<const int4 *>(raw + RAW_PAD + CHUNK * lane);
-            const int prev = raw[RAW_PAD + CHUNK * lane - 1];
+        for (int ch = lane; ch < NCHUNK; ch += 64) {
+            const int4 *p4 = reinterpret_cast<const int4 *>(raw + RAW_PAD + CHUNK * ch);
+            const int prev = raw[RAW_PAD + CHUNK * ch - 1];
             int sprev = (prev >= thr_pos) - (prev <= thr_neg);
             double e = 0.0;
             int z = 0, zfirst = 0;
@@ -367,9 +369,9 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
                     sprev = sb;
                 }
             }
-            cE[lane] = e;
-            cZ[lane] = z;
-            cF[lane] = zfirst;
+            cE[ch] = e;
+            cZ[ch] = z;
+            cF[ch] = zfirst;
         }
 
         PAA_TICK(1)
@@ -501,8 +503,8 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
         const double run_incl = group_scan_incl(cs);
         const double sP = dpp_bcast15(run_incl);            // total = inclusive scan at lane 15
 
-        // energy entropy: 80-sample block i = chunks 10 g + 2 i, + 1 (:34-51)
-        const double eblk = (i < 10) ? cE[10 * g + 2 * i] + cE[10 * g + 2 * i + 1] : 0.0;
+        // energy entropy: 80-sample block i = chunks CPF g + 2 i, + 1 (:34-51)
+        const double eblk = (i < 10) ? cE[CPF * g + 2 * i] + cE[CPF * g + 2 * i + 1] : 0.0;
         const double e_tot = group_sum(eblk);
         double ent_f, ent_e;
         {
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
             ent_e = group_sum((i < 10) ? -(se * fast_log2(se + kEps)) : 0.0);
         }
         // zero crossings: 20 chunks of the frame minus the pair that straddles the frame start (:22-26)
-        int zc = cZ[10 * g + i] + ((i < 4) ? cZ[10 * g + 16 + i] : 0) - ((i == 0) ? cF[10 * g] : 0);
+        int zc = cZ[CPF * g + i] + ((i < 4) ? cZ[CPF * g + 16 + i] : 0) - ((i == 0) ? cF[CPF * g] : 0);
         zc = group_sum_i(zc);
 
         PAA_TICK(5)
@@ -679,7 +681,8 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
 inline int fast_select(int window, int step, int sample_kind, double fs, FastTables &ft, const FftPlan &fft,
                        const MelTable &mel, const ChromaTable &chroma, FastLaunch &fl) {
     (void)fs;
-    if (!(window == 800 && step == 400 && sample_kind == 0)) return 0;
+    if (!(window == 800 && (step == 400 || step == 800) && sample_kind == 0)) return 0;
+    const int wave_bytes = (step == 400) ? f800::Geo<400>::WAVE_BYTES : f800::Geo<800>::WAVE_BYTES;
     f800::TabLayout &L = fl.layout;
     auto up4 = [](int n) { return std::max(8, (n + 7) / 8 * 8); };      // lists are unrolled by 8 on the device
     int c0 = 0, c1 = 0, c2 = 0, cc = 0;
@@ -698,7 +701,7 @@ inline int fast_select(int window, int step, int sample_kind, double fs, FastTab
     L.off_tw2 = take(16 * 16 * 16);
     L.off_twp = take(16 * 16 * 16);
     L.total = off;
-    if ((size_t)L.total + (size_t)f800::WAVES * f800::WAVE_BYTES > 160 * 1024) return 0;   // generic kernel instead
+    if ((size_t)L.total + (size_t)f800::WAVES * wave_bytes > 160 * 1024) return 0;   // generic kernel instead
     if (!ft.d_blob) {
         std::vector<unsigned char> blob((size_t)L.total, 0);
         auto W = [&](int o) { return reinterpret_cast<double *>(blob.data() + o); };
@@ -731,39 +734,42 @@ inline int fast_select(int window, int step, int sample_kind, double fs, FastTab
         if (hipMalloc(&ft.d_blob, blob.size()) != hipSuccess) return PAA_ERR_OOM;
         if (hipMemcpy(ft.d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) return PAA_ERR_HIP;
     }
-    fl.name = "st_fast_800";
-    fl.lds = (size_t)L.total + (size_t)f800::WAVES * f800::WAVE_BYTES;
-    fl.variant = 800;
+    fl.name = (step == 400) ? "st_fast_800" : "st_fast_800_s800";
+    fl.lds = (size_t)L.total + (size_t)f800::WAVES * wave_bytes;
+    fl.variant = (step == 400) ? 800 : 1600;
     fl.run = 256;       // longest run (frames) given to one wave; the plan shrinks it to fill the chip
     fl.waves_per_cu = f800::WAVES;
     return 1;
 }
 
+template <int S, int DELTAS>
+inline int fast_launch_one(const FastLaunch &fl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
+                           const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,
+                           double *d_out, hipStream_t stream) {
+    static size_t attr_done = 0;
+    if (attr_done < fl.lds) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&f800::st_fast_800_kernel<S, DELTAS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl.lds) != hipSuccess) return -1;
+        attr_done = fl.lds;
+    }
+    const unsigned grid = (unsigned)((n_tiles + f800::WAVES - 1) / f800::WAVES);
+    hipLaunchKernelGGL((f800::st_fast_800_kernel<S, DELTAS>), dim3(grid), dim3(64 * f800::WAVES), fl.lds, stream, P,
+                       fl.layout, blob, (const int16_t *)d_packed, clips, norms, tiles, (int)n_tiles, d_out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 inline int fast_launch(const FastLaunch &fl, const PlanDev &P, const FastTables &ft, const void *d_packed,
                        const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,
                        double *d_out, hipStream_t stream) {
-    if (fl.variant != 800 || !ft.d_blob) return -1;
-    static size_t attr_done[2] = {0, 0};
-    const unsigned grid = (unsigned)((n_tiles + f800::WAVES - 1) / f800::WAVES);
+    if (!ft.d_blob) return -1;
     const unsigned char *blob = reinterpret_cast<const unsigned char *>(ft.d_blob);
-    if (P.deltas) {
-        if (attr_done[1] < fl.lds) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&f800::st_fast_800_kernel<1>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl.lds) != hipSuccess) return -1;
-            attr_done[1] = fl.lds;
-        }
-        hipLaunchKernelGGL(f800::st_fast_800_kernel<1>, dim3(grid), dim3(64 * f800::WAVES), fl.lds, stream, P,
-                           fl.layout, blob, (const int16_t *)d_packed, clips, norms, tiles, (int)n_tiles, d_out);
-    } else {
-        if (attr_done[0] < fl.lds) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&f800::st_fast_800_kernel<0>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl.lds) != hipSuccess) return -1;
-            attr_done[0] = fl.lds;
-        }
-        hipLaunchKernelGGL(f800::st_fast_800_kernel<0>, dim3(grid), dim3(64 * f800::WAVES), fl.lds, stream, P,
-                           fl.layout, blob, (const int16_t *)d_packed, clips, norms, tiles, (int)n_tiles, d_out);
-    }
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    if (fl.variant == 800)
+        return P.deltas ? fast_launch_one<400, 1>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream)
+                        : fast_launch_one<400, 0>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+    if (fl.variant == 1600)
+        return P.deltas ? fast_launch_one<800, 1>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream)
+                        : fast_launch_one<800, 0>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+    return -1;
 }
 
 }  // namespace paa

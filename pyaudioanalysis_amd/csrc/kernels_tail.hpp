@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void chroma_tail_kernel(PlanDev P, const T *__
     __syncthreads();
     const double sP = (red[0] + red[1]) + (red[2] + red[3]);
     if (threadIdx.x < 64) {
-        const double ch = chroma_class(P, spec, sP, threadIdx.x);
+        const double ch = chroma_class(tabs_global(P), spec, sP, threadIdx.x);
         if (threadIdx.x < 12) out[(long long)blockIdx.x * 12 + threadIdx.x] = ch;
     }
 }

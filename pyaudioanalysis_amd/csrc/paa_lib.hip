@@ -180,6 +180,8 @@ struct paa_plan {
     StatChunk *d_chunks = nullptr;
     void *d_psum = nullptr, *d_pmin = nullptr, *d_pmax = nullptr;
     long long *d_mid_off = nullptr;
+    GenLayout gl;                    // generic kernel: LDS layout + table blob
+    unsigned char *d_gen_blob = nullptr;
     long long mid_off_step = -1;
     long long n_tiles = 0, n_chunks = 0;
     size_t lds = 0;
@@ -191,7 +193,7 @@ struct paa_plan {
 static void plan_free(paa_plan *p) {
     if (!p) return;
     (void)hipFree(p->d_clips); (void)hipFree(p->d_norms); (void)hipFree(p->d_tiles); (void)hipFree(p->d_chunks);
-    (void)hipFree(p->d_psum); (void)hipFree(p->d_pmin); (void)hipFree(p->d_pmax); (void)hipFree(p->d_mid_off);
+    (void)hipFree(p->d_psum); (void)hipFree(p->d_pmin); (void)hipFree(p->d_pmax); (void)hipFree(p->d_mid_off); (void)hipFree(p->d_gen_blob);
     delete p;
 }
 
@@ -294,11 +296,18 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         p->lds = p->fl.lds;
         p->kernel_name = p->fl.name;
     } else {
-        p->lds = generic_lds_bytes(P.Nc, Nf, F > 0 ? F : 1);
+        std::vector<unsigned char> blob;
+        generic_layout(tab->fft, mode == 0 ? &tab->mel : nullptr, mode != 1 ? &tab->chroma : nullptr, F, p->gl, &blob);
+        p->lds = generic_lds_bytes(p->gl);
         if (p->lds > 160 * 1024)
             return fail(PAA_ERR_UNSUPPORTED, "window %d needs %zu bytes of LDS (> 160 KiB)", window, p->lds);
-        run = 32;
-        while (run > 4 && total_frames / run < 4096) run /= 2;
+        if ((rc = upload(&p->d_gen_blob, blob.data(), blob.size()))) return rc;
+        // one wave per run: about two chip-wide rounds of (256 CUs x waves per workgroup), 8..64 frames per run
+        {
+            const long long slots = 256LL * p->gl.waves * 2;
+            const long long per = (total_frames + slots - 1) / slots;
+            run = (int)std::min<long long>(64, std::max<long long>(8, (per + 3) / 4 * 4));
+        }
         p->kernel_name = (mode == 0) ? "st_generic" : (mode == 1 ? "spectrogram_generic" : "chromagram_generic");
     }
     std::vector<Tile> tiles;
@@ -357,13 +366,14 @@ static int launch_stats(paa_plan *p, const void *d_packed) {
 template <typename T>
 static int launch_generic(paa_plan *p, const void *d_packed, double *d_out) {
     static size_t attr_set = 0;
-    if (p->lds > 64 * 1024 && p->lds > attr_set) {
+    if (p->lds > attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&st_generic_kernel<T>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds));
-        attr_set = p->lds;
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(p->lds, 64 * 1024)));
+        attr_set = std::max<size_t>(p->lds, 64 * 1024);
     }
-    hipLaunchKernelGGL(st_generic_kernel<T>, dim3((unsigned)p->n_tiles), dim3(64), p->lds, g_stream, p->P,
-                       (const T *)d_packed, p->d_clips, p->d_norms, p->d_tiles, d_out);
+    const unsigned grid = (unsigned)((p->n_tiles + p->gl.waves - 1) / p->gl.waves);
+    hipLaunchKernelGGL(st_generic_kernel<T>, dim3(grid), dim3(64 * p->gl.waves), p->lds, g_stream, p->P, p->gl,
+                       p->d_gen_blob, (const T *)d_packed, p->d_clips, p->d_norms, p->d_tiles, (int)p->n_tiles, d_out);
     HIP_TRY(hipGetLastError());
     return PAA_OK;
 }

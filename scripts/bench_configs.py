@@ -56,10 +56,14 @@ plan, d_in, d_out = plan_case("cfg4_shard_12500_clips_34rows", packed, offsets, 
 del plan, d_in, d_out
 
 # cfg5: 44.1 kHz stereo -> mono (float64), 1102/441: features (generic kernel)
-xs = synth_clip(5, 44100 * 120, fs=44100, stereo=True)
+xs = synth_clip(5, 44100 * 600, fs=44100, stereo=True)
 mono = O.stereo_to_mono(xs)
-plan_case("cfg5_features_1102_441_f64_120s", mono, np.array([0, len(mono)], dtype=np.int64), 44100, 1102, 441, True, 1)
+plan_case("cfg5_features_1102_441_f64_600s", mono, np.array([0, len(mono)], dtype=np.int64), 44100, 1102, 441, True, 1)
 # reference default 50 ms / 50 ms
+xl = synth_clip(8, 3600 * 16000)
+plan_case("st_800_800_int16_3600s", xl, np.array([0, len(xl)], dtype=np.int64), 16000, 800, 800, True, 0)
+plan_case("st_640_320_int16_3600s", xl, np.array([0, len(xl)], dtype=np.int64), 16000, 640, 320, True, 0)
+plan_case("st_400_160_int16_3600s", xl, np.array([0, len(xl)], dtype=np.int64), 16000, 400, 160, True, 0)
 x = synth_clip(7, 600 * 16000)
 plan_case("st_800_800_int16_600s", x, np.array([0, len(x)], dtype=np.int64), 16000, 800, 800, True, 0)
 plan_case("st_640_320_int16_600s", x, np.array([0, len(x)], dtype=np.int64), 16000, 640, 320, True, 0)
