@@ -48,6 +48,12 @@ __global__ __launch_bounds__(256) void chroma_tail_kernel(PlanDev P, const T *__
 inline int launch_chroma_tail(const PlanDev &P, int sample_kind, const void *d_sig, long long pos0, long long n_total,
                               int count, const ClipNorm *norms, double *d_out, hipStream_t stream) {
     const size_t lds = (size_t)P.Nf * 8 + 16;
+    if (lds > 160 * 1024) return -2;          // spectrum of the tail frame does not fit LDS
+    if (lds > 64 * 1024) {
+        const void *fn = sample_kind == 0 ? reinterpret_cast<const void *>(&chroma_tail_kernel<int16_t>)
+                                          : reinterpret_cast<const void *>(&chroma_tail_kernel<double>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    }
     if (sample_kind == 0)
         hipLaunchKernelGGL(chroma_tail_kernel<int16_t>, dim3(count), dim3(256), lds, stream, P, (const int16_t *)d_sig,
                            pos0, n_total, norms, d_out);

@@ -17,6 +17,7 @@
 
 #include "../../include/paa_hip.h"
 #include "kernels_aux.hpp"
+#include "kernels_big.hpp"
 #include "kernels_fast.hpp"
 #include "kernels_generic.hpp"
 #include "tables.hpp"
@@ -182,6 +183,9 @@ struct paa_plan {
     long long *d_mid_off = nullptr;
     GenLayout gl;                    // generic kernel: LDS layout + table blob
     unsigned char *d_gen_blob = nullptr;
+    int big = 0;                     // window beyond the LDS envelope: Stockham passes through HBM scratch
+    void *d_big = nullptr;
+    size_t big_bytes = 0;
     long long mid_off_step = -1;
     long long n_tiles = 0, n_chunks = 0;
     size_t lds = 0;
@@ -193,7 +197,7 @@ struct paa_plan {
 static void plan_free(paa_plan *p) {
     if (!p) return;
     (void)hipFree(p->d_clips); (void)hipFree(p->d_norms); (void)hipFree(p->d_tiles); (void)hipFree(p->d_chunks);
-    (void)hipFree(p->d_psum); (void)hipFree(p->d_pmin); (void)hipFree(p->d_pmax); (void)hipFree(p->d_mid_off); (void)hipFree(p->d_gen_blob);
+    (void)hipFree(p->d_psum); (void)hipFree(p->d_pmin); (void)hipFree(p->d_pmax); (void)hipFree(p->d_mid_off); (void)hipFree(p->d_gen_blob); (void)hipFree(p->d_big);
     delete p;
 }
 
@@ -299,16 +303,20 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         std::vector<unsigned char> blob;
         generic_layout(tab->fft, mode == 0 ? &tab->mel : nullptr, mode != 1 ? &tab->chroma : nullptr, F, p->gl, &blob);
         p->lds = generic_lds_bytes(p->gl);
-        if (p->lds > 160 * 1024)
-            return fail(PAA_ERR_UNSUPPORTED, "window %d needs %zu bytes of LDS (> 160 KiB)", window, p->lds);
-        if ((rc = upload(&p->d_gen_blob, blob.data(), blob.size()))) return rc;
+        if (p->lds > 160 * 1024) {
+            p->big = 1;                 // no CPU fallback: the same passes run through HBM scratch instead
+            p->lds = 0;
+        } else if ((rc = upload(&p->d_gen_blob, blob.data(), blob.size()))) {
+            return rc;
+        }
         // one wave per run: about two chip-wide rounds of (256 CUs x waves per workgroup), 8..64 frames per run
         {
             const long long slots = 256LL * p->gl.waves * 2;
             const long long per = (total_frames + slots - 1) / slots;
             run = (int)std::min<long long>(64, std::max<long long>(8, (per + 3) / 4 * 4));
         }
-        p->kernel_name = (mode == 0) ? "st_generic" : (mode == 1 ? "spectrogram_generic" : "chromagram_generic");
+        p->kernel_name = p->big ? "big_window_hbm_passes"
+                                : (mode == 0) ? "st_generic" : (mode == 1 ? "spectrogram_generic" : "chromagram_generic");
     }
     std::vector<Tile> tiles;
     tiles.reserve((size_t)(total_frames / run + n_clips));
@@ -378,6 +386,68 @@ static int launch_generic(paa_plan *p, const void *d_packed, double *d_out) {
     return PAA_OK;
 }
 
+// windows beyond the LDS envelope: chunked Stockham passes through HBM scratch (kernels_big.hpp)
+template <typename T>
+static int run_big(paa_plan *p, const void *d_packed, double *d_out) {
+    const PlanDev &P = p->P;
+    const long long Nc = P.Nc, Nf = P.Nf;
+    const size_t per_frame = (size_t)Nc * 32 + (size_t)Nf * 8 + 24;
+    long long maxT = 0;
+    for (auto &cd : p->clips) maxT = std::max<long long>(maxT, cd.T);
+    long long C = (long long)std::max<size_t>(1, ((size_t)1 << 30) / per_frame);
+    C = std::min<long long>(std::min<long long>(C, 65535), std::max<long long>(maxT, 1));
+    const size_t need = (size_t)C * Nc * 32 + (size_t)(C + 1) * Nf * 8 + (size_t)C * 24 + 256;
+    if (need > p->big_bytes) {
+        if (p->d_big) { HIP_TRY(hipStreamSynchronize(g_stream)); (void)hipFree(p->d_big); p->d_big = nullptr; }
+        HIP_TRY(hipMalloc(&p->d_big, need));
+        p->big_bytes = need;
+    }
+    double2 *bufA = reinterpret_cast<double2 *>(p->d_big);
+    double2 *bufB = bufA + C * Nc;
+    double *spec = reinterpret_cast<double *>(bufB + C * Nc);
+    double *tfeat = spec + (C + 1) * Nf;
+    const unsigned gx = (unsigned)std::min<long long>(64, (std::max<long long>(Nc, P.W) + 255) / 256);
+    for (long long c = 0; c < p->n_clips; ++c) {
+        const ClipDev &cd = p->clips[c];
+        const T *x0 = (const T *)d_packed + cd.sample_off + P.frame_origin;
+        double *oc = d_out + cd.out_off;
+        long long prev_n = 0;
+        for (long long t0 = 0; t0 < cd.T; t0 += C) {
+            const long long n = std::min<long long>(C, cd.T - t0);
+            if (t0 > 0 && P.mode != 1)       // carry the last spectrum of the previous chunk into row 0
+                HIP_TRY(hipMemcpyAsync(spec, spec + prev_n * Nf, (size_t)Nf * 8, hipMemcpyDeviceToDevice, g_stream));
+            hipLaunchKernelGGL(big_load_kernel<T>, dim3(gx, (unsigned)n), dim3(256), 0, g_stream, P, x0, t0, ClipNorm(),
+                               p->d_norms, (int)c, bufA);
+            if (P.mode == 0)
+                hipLaunchKernelGGL(big_time_kernel, dim3((unsigned)n), dim3(64), 0, g_stream, P, bufA, tfeat);
+            double2 *src = bufA, *dst = bufB;
+            int Ns = 1;
+            for (int q = 0; q < P.n_pass; ++q) {
+                hipLaunchKernelGGL(big_pass_kernel, dim3(gx, (unsigned)n), dim3(256), 0, g_stream, (int)Nc, P.radix[q], Ns,
+                                   P.tw, src, dst);
+                Ns *= P.radix[q];
+                std::swap(src, dst);
+            }
+            if (P.mode == 1) {
+                hipLaunchKernelGGL(big_post_kernel, dim3(gx, (unsigned)n), dim3(256), 0, g_stream, P, src, oc, t0);
+            } else {
+                hipLaunchKernelGGL(big_post_kernel, dim3(gx, (unsigned)n), dim3(256), 0, g_stream, P, src, spec, 1LL);
+                hipLaunchKernelGGL(big_feat_kernel, dim3((unsigned)n), dim3(64), 0, g_stream, P, spec, tfeat, t0,
+                                   (long long)cd.T, oc);
+            }
+            HIP_TRY(hipGetLastError());
+            prev_n = n;
+        }
+        if (P.mode == 0 && P.deltas) {
+            const long long items = (long long)kBase * cd.T;
+            hipLaunchKernelGGL(big_delta_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, g_stream,
+                               (long long)cd.T, oc);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return PAA_OK;
+}
+
 extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *d_out) {
     if (!plan || !d_packed || !d_out) return fail(PAA_ERR_ARG, "null plan / buffer");
     std::lock_guard<std::mutex> lk(g_mu);
@@ -385,6 +455,8 @@ extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *
     if (rc) return rc;
     rc = launch_stats(plan, d_packed);
     if (rc) return rc;
+    if (plan->big)
+        return plan->sample_kind == 0 ? run_big<int16_t>(plan, d_packed, d_out) : run_big<double>(plan, d_packed, d_out);
     if (plan->n_tiles == 0) return PAA_OK;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (g_prof) {
@@ -784,6 +856,7 @@ static int run_host_spec(const void *signal, int64_t n, int sample_kind, double 
                             "(ValueError in the reference, ShortTermFeatures.py:288)");
             rc = launch_chroma_tail(plan->P, sample_kind, g_in.p, pos, n, (int)(filled - plan->clips[0].T), plan->d_norms,
                                     (double *)g_out.p + (long long)plan->clips[0].T * 12, g_stream);
+            if (rc == -2) return fail(PAA_ERR_UNSUPPORTED, "truncated chromagram tail frame with window %d does not fit LDS", window);
             if (rc) return fail(PAA_ERR_HIP, "chromagram tail launch failed");
         }
     }

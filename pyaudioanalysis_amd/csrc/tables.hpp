@@ -97,11 +97,24 @@ inline int build_chroma(double fs, int nfft, ChromaTable &t) {
         return any_over ? PAA_ERR_CHROMA_VALUE : PAA_ERR_CHROMA_INDEX;
     }
     if (smin < -(long)nfft) return PAA_ERR_CHROMA_INDEX;
+    // number of bins sharing a bin's slot value (:267-272); slots are non-decreasing in f, so equal values
+    // form runs (the quadratic count is kept for the impossible non-monotone case)
     std::vector<double> count(nfft, 0.0);
-    for (int f = 0; f < nfft; ++f) {
-        long c = 0;
-        for (int g = 0; g < nfft; ++g) c += (slot[g] == slot[f]);
-        count[f] = (double)c;
+    bool monotone = true;
+    for (int f = 1; f < nfft; ++f) monotone &= slot[f] >= slot[f - 1];
+    if (monotone) {
+        for (int f = 0; f < nfft;) {
+            int e = f;
+            while (e < nfft && slot[e] == slot[f]) ++e;
+            for (int g = f; g < e; ++g) count[g] = (double)(e - f);
+            f = e;
+        }
+    } else {
+        for (int f = 0; f < nfft; ++f) {
+            long c = 0;
+            for (int g = 0; g < nfft; ++g) c += (slot[g] == slot[f]);
+            count[f] = (double)c;
+        }
     }
     std::vector<int32_t> owner(nfft, -1);
     auto wrap = [nfft](long s) { return (int)(s < 0 ? s + nfft : s); };

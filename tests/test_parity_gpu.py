@@ -214,3 +214,23 @@ def test_rccl_gather_world_size_1(gpu_lib):
             assert np.array_equal(single, r)
     finally:
         comm.close()
+
+
+@pytest.mark.parametrize("fs,window,step,seconds", [
+    (16000, 8000, 4000, 6.0),       # 0.5 s window: beyond the LDS envelope -> Stockham passes through HBM scratch
+    (16000, 16000, 16000, 8.0),     # 1 s / 1 s, the music_thumbnailing shape (audioSegmentation.py:1137)
+    (16000, 9001, 4500, 3.0),       # odd prime window: one O(N^2) pass
+])
+def test_big_windows_match_oracle(gpu_lib, fs, window, step, seconds):
+    x = synth_clip(700 + window, int(seconds * fs), fs=fs)
+    ref, _ = O.feature_extraction(x, fs, window, step)
+    got, _ = ShortTermFeatures.feature_extraction(x, fs, window, step)
+    assert_parity(got, ref, "big window %d/%d" % (window, step))
+
+
+def test_big_window_spectrogram(gpu_lib, capsys):
+    x = synth_clip(801, 5 * 16000)
+    S, _, _ = ShortTermFeatures.spectrogram(x, 16000, 8000, 4000)
+    capsys.readouterr()
+    ref, _, _ = O.spectrogram(x, 16000, 8000, 4000)
+    assert_parity(S, ref, "big spectrogram")
