@@ -31,6 +31,13 @@ def load():
                 stub.AudioSegment = object
             sys.modules[name] = stub
     os.environ.setdefault("MPLBACKEND", "Agg")
+    import numpy
+    # utilities.peakdet (utilities.py:74-75) still spells numpy.Inf / numpy.NaN, removed in NumPy 2.0: restore the
+    # aliases so that the UNMODIFIED reference runs under the installed numpy 2.2 (environment shim only)
+    if not hasattr(numpy, "Inf"):
+        numpy.Inf = numpy.inf
+    if not hasattr(numpy, "NaN"):
+        numpy.NaN = numpy.nan
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     with warnings.catch_warnings():

@@ -114,5 +114,48 @@ def main():
     print("total %.2f MB" % (tot / 1e6))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--dir" not in sys.argv:
     main()
+
+
+def directory_goldens():
+    """Row f1/f2 of SURVEY 8f: directory walkers + beat extraction, run by the unmodified reference on a small
+    directory of synthetic WAV files (written here with scipy.io.wavfile; the arrays are stored in the golden)."""
+    import tempfile
+    import scipy.io.wavfile as wavfile
+    ref_st, ref_mt, ref_io = load_reference.load()
+    files = {
+        "a_mono16k_3s.wav": (16000, synth_clip(21, 48000)),
+        "b_mono16k_1s2.wav": (16000, synth_clip(22, 19200)),
+        "c_stereo16k_2s.wav": (16000, synth_clip(23, 32000, stereo=True)),
+        "d_mono8k_2s.wav": (8000, synth_clip(24, 16000, fs=8000)),
+        "e_tiny.wav": (16000, synth_clip(25, 1600)),            # < fs/5 samples: skipped (:181-183)
+    }
+    out = {"kind": "dir", "file_names": np.array(sorted(files)), "mid_window": 1.0, "mid_step": 1.0,
+           "short_window": 0.05, "short_step": 0.05}
+    with tempfile.TemporaryDirectory() as d:
+        for name, (fs, x) in files.items():
+            wavfile.write(os.path.join(d, name), fs, x)
+            out["wav_fs_" + name] = fs
+            out["wav_x_" + name] = x
+        open(os.path.join(d, "f_empty.wav"), "wb").close()      # zero bytes: skipped (:168-170)
+        with contextlib.redirect_stdout(io.StringIO()):
+            f_beat, list_beat, names_beat = ref_mt.directory_feature_extraction(d, 1.0, 1.0, 0.05, 0.05, compute_beat=True)
+            f_nobeat, list_nb, names_nb = ref_mt.directory_feature_extraction(d, 1.0, 1.0, 0.05, 0.05, compute_beat=False)
+            X, Y, flist = ref_mt.directory_feature_extraction_no_avg(d, 1.0, 1.0, 0.05, 0.05) if False else (None, None, None)
+        out.update(features_beat=f_beat, files_beat=np.array([os.path.basename(p) for p in list_beat]),
+                   names_beat=np.array(names_beat), features_nobeat=f_nobeat,
+                   files_nobeat=np.array([os.path.basename(p) for p in list_nb]), names_nobeat=np.array(names_nb))
+        # beat extraction alone on a longer clip (0.05 and 0.025 s steps)
+        x = synth_clip(26, 10 * 16000)
+        st, _ = ref_st.feature_extraction(x, 16000, 800, 800)
+        bpm, ratio = ref_mt.beat_extraction(st, 0.05)
+        st2, _ = ref_st.feature_extraction(x, 16000, 800, 400)
+        bpm2, ratio2 = ref_mt.beat_extraction(st2, 0.025)
+        out.update(beat_signal=x, beat_050=np.array([bpm, ratio]), beat_025=np.array([bpm2, ratio2]))
+    np.savez_compressed(os.path.join(OUT, "directory_small.npz"), **out)
+    print("wrote directory_small.npz: %s files -> %s" % (len(files) + 1, f_beat.shape))
+
+
+if __name__ == "__main__" and "--dir" in sys.argv:
+    directory_goldens()

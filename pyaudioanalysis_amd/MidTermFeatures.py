@@ -1,9 +1,17 @@
-"""Drop-in for pyAudioAnalysis.MidTermFeatures.mid_feature_extraction (reference:
-pyAudioAnalysis/MidTermFeatures.py:87-127) plus a batched many-clip form.  HIP only, no CPU path.
+"""Drop-in for pyAudioAnalysis.MidTermFeatures (reference: pyAudioAnalysis/MidTermFeatures.py).
+
+mid_feature_extraction (:87-127) and its batched many-clip form run on the GPU (HIP only, no CPU path).
+Around it, the host-side callers of SURVEY 8f-1/2: beat_extraction (:18-84, a sequential peak detector over
+18 short-term rows -- host NumPy) and the directory walkers (:140-309), which read the files on the host
+and push every int16 mono file of one sampling rate through ONE batched GPU call.
 """
+import glob
+import os
+import time
+
 import numpy as np
 
-from . import ShortTermFeatures, _ffi
+from . import ShortTermFeatures, _ffi, audioBasicIO
 
 eps = 0.00000001                          # MidTermFeatures.py:13
 
@@ -90,3 +98,192 @@ def mid_feature_extraction_batch(signals, sampling_rate, mid_window, mid_step, s
         sts = [st[int(o):int(o) + F * int(t)].reshape(F, int(t)) for o, t in zip(st_off, T)]
         return mids, sts, _mid_names(short_names)
     return mids, _mid_names(short_names)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# beat extraction (reference :18-84 + utilities.peakdet, utilities.py:33-102)
+# ---------------------------------------------------------------------------------------------------------
+def _peak_positions(v, delta):
+    """Positions of the maxima of Billauer's peakdet: a maximum is recorded once the signal has dropped by more
+    than delta below the running maximum, a minimum once it rose by more than delta above the running minimum."""
+    peaks = []
+    lo, hi = np.inf, -np.inf
+    hi_pos = 0
+    seek_max = True
+    for k in range(len(v)):
+        cur = v[k]
+        if cur > hi:
+            hi, hi_pos = cur, k
+        if cur < lo:
+            lo = cur
+        if seek_max:
+            if cur < hi - delta:
+                peaks.append(hi_pos)
+                lo = cur
+                seek_max = False
+        elif cur > lo + delta:
+            hi, hi_pos = cur, k
+            seek_max = True
+    return peaks
+
+
+def beat_extraction(short_features, window_size, plot=False):
+    """Estimate of the beat rate of a musical signal (reference :18-84).
+
+    ARGUMENTS: short_features (n_feats x numOfShortTermWindows), window_size = short-term step in seconds
+    RETURNS:   bpm (beats per minute), ratio (confidence)
+    """
+    rows = [0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18]      # :30-31
+    max_beat_time = int(round(2.0 / window_size))
+    hist_all = np.zeros((max_beat_time,))
+    n_frames = short_features.shape[1]
+    edges = np.arange(0.5, max_beat_time + 1.5)
+    for r in rows:
+        v = np.asarray(short_features[r, :])
+        thr = 2.0 * (np.abs(v[0:-1] - v[1::])).mean()                            # :37-38
+        if thr <= 0:
+            thr = 0.0000000000000001
+        pos = _peak_positions(v, thr)
+        gaps = [pos[j + 1] - pos[j] for j in range(len(pos) - 1)]
+        counts, _ = np.histogram(gaps, edges)
+        hist_all += counts.astype(float) / n_frames
+    centers = (edges[0:-1] + edges[1::]) / 2.0
+    best = np.argmax(hist_all)
+    bpms = 60 / (centers * window_size)
+    bpm = bpms[best]
+    ratio = hist_all[best] / (hist_all.sum() + eps)
+    if plot:
+        import matplotlib.pyplot as plt
+        keep = bpms < 500
+        plt.plot(bpms[keep], hist_all[keep], 'k')
+        plt.xlabel('Beats per minute')
+        plt.ylabel('Freq Count')
+        plt.show(block=True)
+    return bpm, ratio
+
+
+# ---------------------------------------------------------------------------------------------------------
+# directory walkers (reference :140-309)
+# ---------------------------------------------------------------------------------------------------------
+def _list_audio(folder_path, types):
+    files = []
+    for pattern in types:
+        files.extend(glob.glob(os.path.join(folder_path, pattern)))
+    return sorted(files)
+
+
+def _mid_for_files(entries, mid_window, mid_step, short_window, short_step, want_short):
+    """entries: list of (sampling_rate, mono signal).  int16 clips that share a sampling rate go through ONE
+    batched launch; float64 clips (stereo -> mono) take the single-clip float path.  Returns per-entry
+    (mid [136 x M], short [68 x T] or None, names)."""
+    out = [None] * len(entries)
+    names = _mid_names(ShortTermFeatures._feature_names(True))
+    groups = {}
+    for idx, (fs, sig) in enumerate(entries):
+        if np.asarray(sig).dtype == np.int16 and np.asarray(sig).ndim == 1:
+            groups.setdefault(fs, []).append(idx)
+        else:
+            mid, st, _ = mid_feature_extraction(sig, fs, round(mid_window * fs), round(mid_step * fs),
+                                                round(fs * short_window), round(fs * short_step))
+            out[idx] = (mid, st if want_short else None)
+    for fs, members in groups.items():
+        res = mid_feature_extraction_batch([entries[i][1] for i in members], fs, round(mid_window * fs),
+                                           round(mid_step * fs), round(fs * short_window), round(fs * short_step),
+                                           return_short=want_short)
+        mids = res[0]
+        sts = res[1] if want_short else [None] * len(members)
+        for i, m, s in zip(members, mids, sts):
+            out[i] = (m, s)
+    return out, names
+
+
+def directory_feature_extraction(folder_path, mid_window, mid_step, short_window, short_step, compute_beat=True):
+    """One long-term-averaged feature vector per audio file of a folder (reference :140-221).
+
+    Windows and steps are in SECONDS here (the reference multiplies by each file's sampling rate, :187-190).
+    RETURNS (features [n_files x 136(+2)], kept file list, feature names)
+    """
+    mid_term_features = np.array([])
+    wav_file_list = _list_audio(folder_path, ('*.wav', '*.aif', '*.aiff', '*.mp3', '*.au', '*.ogg'))
+    kept, entries = [], []
+    t_start = time.time()
+    for i, file_path in enumerate(wav_file_list):
+        print("Analyzing file {0:d} of {1:d}: {2:s}".format(i + 1, len(wav_file_list), file_path))
+        if os.stat(file_path).st_size == 0:
+            print("   (EMPTY FILE -- SKIPPING)")
+            continue
+        sampling_rate, signal = audioBasicIO.read_audio_file(file_path)
+        if sampling_rate <= 0:
+            continue
+        signal = audioBasicIO.stereo_to_mono(signal)
+        if signal.shape[0] < float(sampling_rate) / 5:
+            print("  (AUDIO FILE TOO SMALL - SKIPPING)")
+            continue
+        kept.append(file_path)
+        entries.append((sampling_rate, signal))
+    mid_feature_names = []
+    total_audio = 0.0
+    if entries:
+        results, mid_feature_names = _mid_for_files(entries, mid_window, mid_step, short_window, short_step,
+                                                    want_short=compute_beat)
+        mid_feature_names = list(mid_feature_names)
+        added_names = False
+        for (fs, signal), (mid, st) in zip(entries, results):
+            vec = np.transpose(mid).mean(axis=0)                       # long-term averaging (:199-201)
+            if (not np.isnan(vec).any()) and (not np.isinf(vec).any()):
+                if compute_beat:
+                    beat, beat_conf = beat_extraction(st, short_step)
+                    vec = np.append(vec, beat)
+                    vec = np.append(vec, beat_conf)
+                    if not added_names:
+                        mid_feature_names += ["bpm", "ratio"]
+                        added_names = True
+                mid_term_features = vec if len(mid_term_features) == 0 else np.vstack((mid_term_features, vec))
+                total_audio += float(len(signal)) / fs
+    elapsed = time.time() - t_start
+    if total_audio > 0 and elapsed > 0:
+        print("Feature extraction complexity ratio: {0:.1f} x realtime".format(total_audio / elapsed))
+    return mid_term_features, kept, mid_feature_names
+
+
+def multiple_directory_feature_extraction(path_list, mid_window, mid_step, short_window, short_step,
+                                          compute_beat=False):
+    """List of folders -> list of feature matrices, class names (folder names), file lists (reference :224-260)."""
+    features, class_names, file_names = [], [], []
+    for d in path_list:
+        f, fn, _ = directory_feature_extraction(d, mid_window, mid_step, short_window, short_step,
+                                                compute_beat=compute_beat)
+        if f.shape[0] > 0:
+            features.append(f)
+            file_names.append(fn)
+            if d[-1] == os.sep:
+                class_names.append(d.split(os.sep)[-2])
+            else:
+                class_names.append(d.split(os.sep)[-1])
+    return features, class_names, file_names
+
+
+def directory_feature_extraction_no_avg(folder_path, mid_window, mid_step, short_window, short_step):
+    """All mid-term vectors of every file, no averaging (reference :263-309).
+    RETURNS (X [sum_M x 136], file index of every row, file list)"""
+    wav_file_list = _list_audio(folder_path, ('*.wav', '*.aif', '*.aiff', '*.ogg'))
+    entries, index = [], []
+    for i, file_path in enumerate(wav_file_list):
+        sampling_rate, signal = audioBasicIO.read_audio_file(file_path)
+        if sampling_rate <= 0:
+            continue
+        entries.append((sampling_rate, audioBasicIO.stereo_to_mono(signal)))
+        index.append(i)
+    mid_features = np.array([])
+    signal_idx = np.array([])
+    if entries:
+        results, _ = _mid_for_files(entries, mid_window, mid_step, short_window, short_step, want_short=False)
+        for i, (mid, _) in zip(index, results):
+            vec = np.transpose(mid)
+            if len(mid_features) == 0:
+                mid_features = vec
+                signal_idx = np.zeros((vec.shape[0],))
+            else:
+                mid_features = np.vstack((mid_features, vec))
+                signal_idx = np.append(signal_idx, i * np.ones((vec.shape[0],)))
+    return mid_features, signal_idx, wav_file_list

@@ -1,0 +1,61 @@
+"""beat extraction (host) and the directory walkers (host I/O + batched GPU mid-term path),
+against outputs of the unmodified reference stored in tests/golden/directory_small.npz."""
+import os
+
+import numpy as np
+import pytest
+import scipy.io.wavfile as wavfile
+
+import paa_oracle as O
+from conftest import GOLDEN_DIR
+from pyaudioanalysis_amd import MidTermFeatures
+
+
+def _golden():
+    with np.load(os.path.join(GOLDEN_DIR, "directory_small.npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def test_beat_extraction_matches_reference_on_oracle_features():
+    """CPU: the short-term matrix comes from the oracle (pinned to the reference), so this isolates beat_extraction."""
+    g = _golden()
+    x = g["beat_signal"]
+    st, _ = O.feature_extraction(x, 16000, 800, 800)
+    bpm, ratio = MidTermFeatures.beat_extraction(st, 0.05)
+    assert np.allclose([bpm, ratio], g["beat_050"], rtol=1e-9, atol=1e-12)
+    st, _ = O.feature_extraction(x, 16000, 800, 400)
+    bpm, ratio = MidTermFeatures.beat_extraction(st, 0.025)
+    assert np.allclose([bpm, ratio], g["beat_025"], rtol=1e-9, atol=1e-12)
+
+
+def _write_dir(g, d):
+    for name in g["file_names"]:
+        name = str(name)
+        wavfile.write(os.path.join(d, name), int(g["wav_fs_" + name]), g["wav_x_" + name])
+    open(os.path.join(d, "f_empty.wav"), "wb").close()
+
+
+@pytest.mark.gpu
+def test_directory_feature_extraction_matches_reference(gpu_lib, tmp_path, capsys):
+    g = _golden()
+    d = str(tmp_path)
+    _write_dir(g, d)
+    for beat, key in ((True, "beat"), (False, "nobeat")):
+        F, files, names = MidTermFeatures.directory_feature_extraction(d, 1.0, 1.0, 0.05, 0.05, compute_beat=beat)
+        out = capsys.readouterr().out
+        assert "(EMPTY FILE -- SKIPPING)" in out and "(AUDIO FILE TOO SMALL - SKIPPING)" in out
+        assert [os.path.basename(p) for p in files] == [str(s) for s in g["files_" + key]]
+        assert names == [str(s) for s in g["names_" + key]]
+        ref = g["features_" + key]
+        assert F.shape == ref.shape
+        nbad, _ = O.mixed_tolerance_violations(F.T, ref.T)       # rows = features
+        assert nbad == 0
+    feats, classes, fnames = MidTermFeatures.multiple_directory_feature_extraction([d], 1.0, 1.0, 0.05, 0.05)
+    capsys.readouterr()
+    assert classes == [os.path.basename(d)] and feats[0].shape == g["features_nobeat"].shape
+    X, idx, flist = MidTermFeatures.directory_feature_extraction_no_avg(d, 1.0, 1.0, 0.05, 0.05)
+    assert X.shape[1] == 136 and len(idx) == X.shape[0] and len(flist) == 6
+    # first file: 3 s -> 3 mid windows, averaged they give the directory row
+    first = X[idx == 0]
+    nbad, _ = O.mixed_tolerance_violations(first.mean(axis=0)[:, None], g["features_nobeat"][0][:, None])
+    assert nbad == 0
