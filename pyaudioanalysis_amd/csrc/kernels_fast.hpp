@@ -177,6 +177,16 @@ __device__ __forceinline__ double mag_sqrt(double x) {
     return (x > 0.0) ? fma(g, r, g) : 0.0;
 }
 
+// a / b for finite b != 0 to ~1 ulp: v_rcp_f64 seed, two Newton steps, one residual correction (the IEEE
+// division sequence -- div_scale / div_fmas / div_fixup -- is a ~150-cycle dependent chain per quotient)
+__device__ __forceinline__ double fast_div(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+
 // log2(x) for finite x > 0 (callers add eps = 2^-52 first): x = m 2^e with m in [sqrt(1/2), sqrt(2)),
 // ln m = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716, odd series to s^21 (truncation < 1e-18 relative).
 // About 35 FP64 operations instead of ~115 in the generic libm path; error a few 1e-16 relative.
@@ -282,7 +292,9 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
 
     const double sc = 1.0 / 32768.0;
     const double f0 = P.fs / (2.0 * (double)NF);
+    const double rf0 = 1.0 / f0;
     const double half_fs = P.fs / 2.0;
+    const double r_half_fs = 1.0 / half_fs;
     // the FFT runs on integers x - m_int (m_int = the clip mean rounded to a whole count; exact in f64).
     // y = (x/2^15 - mean) * inv is affine, so every bin scales by inv/2^15 and only the DC bin sees the
     // residual mean:  Y[0] = inv/2^15 * (X'[0] - 800 * (mu - m_int)).  Removing m_int first keeps the DC
@@ -508,7 +520,7 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
         const double e_tot = group_sum(eblk);
         double ent_f, ent_e;
         {
-            const double sf = pblk / (sP + kEps), se = eblk / (e_tot + kEps);
+            const double sf = fast_div(pblk, sP + kEps), se = fast_div(eblk, e_tot + kEps);
             ent_f = group_sum((i < 10) ? -(sf * fast_log2(sf + kEps)) : 0.0);
             ent_e = group_sum((i < 10) ? -(se * fast_log2(se + kEps)) : 0.0);
         }
@@ -518,12 +530,13 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
 
         PAA_TICK(5)
         // centroid, spread, flux (:57-82, :110-124)
-        const double r = (mx == 0.0) ? 1.0 / kEps : 1.0 / mx;
+        const double r = (mx == 0.0) ? 1.0 / kEps : fast_div(1.0, mx);
         const double den = sX * r + kEps;
-        const double cen = (sIX * r) / den;
-        const double rX = 1.0 / sXe, rXp = 1.0 / sXp;
+        const double rden = fast_div(1.0, den);
+        const double cen = (sIX * r) * rden;
+        const double rX = fast_div(1.0, sXe), rXp = fast_div(1.0, sXp);
         // spread: sum (ind - C)^2 X / max = f0^2/max * sum ((k+1) - C/f0)^2 X
-        const double cb = base_k - cen / f0;
+        const double cb = base_k - cen * rf0;
         double sSa = 0.0, sSb = 0.0, sFa = 0.0, sFb = 0.0;
 #pragma unroll
         for (int m = 0; m < 24; m += 2) {
@@ -543,7 +556,7 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
         double sSp = (sSa + sSb) * (f0 * f0 * r), sFl = sFa + sFb;
         sSp = group_sum(sSp);
         sFl = group_sum(sFl);
-        const double spread = sqrt(sSp / den);
+        const double spread = fast_sqrt(sSp * rden);
 
         // roll-off (:127-140): first k with cumsum(X^2)[k] + eps > 0.9 sum(X^2); branch-free per lane
         int first = 0x7fffffff;
@@ -606,7 +619,7 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
 #pragma unroll
                 for (int u = 0; u < 8; ++u) chroma = fma(xv[u] * xv[u], wv[u], chroma);     // ascending slot order (:299-302)
             }
-            chroma = (sP == 0.0) ? chroma / kEps : chroma / sP;
+            chroma = (sP == 0.0) ? chroma / kEps : fast_div(chroma, sP);
             if (i >= 12) chroma = 0.0;
         }
         wsync();
@@ -632,20 +645,20 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
         }
         if (i < 12) fg[21 + i] = chroma;
         if (i == 15) {
-            fg[0] = ((double)zc / 2.0) / (double)(W - 1);
-            fg[1] = e_tot / (double)W;
+            fg[0] = ((double)zc * 0.5) * (1.0 / (double)(W - 1));
+            fg[1] = e_tot * (1.0 / (double)W);
             fg[2] = ent_e;
-            fg[3] = cen / half_fs;
-            fg[4] = spread / half_fs;
+            fg[3] = cen * r_half_fs;
+            fg[4] = spread * r_half_fs;
             fg[5] = ent_f;
             fg[6] = (t == 0) ? 0.0 : sFl;      // first frame: previous spectrum = itself (:624-625)
-            fg[7] = (first == 0x7fffffff) ? 0.0 : (double)first / (double)NF;
+            fg[7] = (first == 0x7fffffff) ? 0.0 : (double)first * (1.0 / (double)NF);
         }
         {   // population std of the 12 chroma values (:667), by DPP inside the group
             const double m = group_sum((i < 12) ? chroma : 0.0) / 12.0;
             const double d = (i < 12) ? chroma - m : 0.0;
             const double var = group_sum(d * d) / 12.0;
-            if (i == 14) fg[33] = sqrt(var);
+            if (i == 14) fg[33] = fast_sqrt(var);
         }
         wsync();
 
