@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void st_generic_kernel(PlanDev P, GenLayout
     tb.ch_src = reinterpret_cast<const int *>(smem + L.off_chsrc);
     tb.ch_w = reinterpret_cast<const double *>(smem + L.off_chw);
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int tile_id = blockIdx.x * L.waves + wave;
     if (tile_id >= n_tiles) return;
     const int Nc = P.Nc, Nf = P.Nf, F = P.F > 0 ? P.F : 1;

@@ -75,6 +75,7 @@ static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 static std::map<std::pair<double, int>, std::unique_ptr<TableSet>> g_tables;
 static Scratch g_in, g_out, g_mid;
 static int g_force_generic = 0;
+static int g_fast_ws = 0;          // PAA_HIP_FAST_WS=1: wave-specialised variant of the fast kernel
 // optional per-launch timing of the feature kernel (bench.py's roofline leg)
 static int g_prof = 0;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev;
@@ -283,7 +284,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     // ---- kernel choice + tiles
     p->fast = 0;
     if (mode == 0 && !g_force_generic) {
-        rc = fast_select(window, step, sample_kind, fs, tab->fast, tab->fft, tab->mel, tab->chroma, p->fl);
+        rc = fast_select(window, step, sample_kind, fs, tab->fast, tab->fft, tab->mel, tab->chroma, p->fl, g_fast_ws);
         if (rc < 0) return fail(rc, "building the tables of the specialised kernel failed");
         p->fast = rc;
     }
@@ -576,6 +577,8 @@ extern "C" int paa_init(int device_id) {
     g_device = device_id;
     const char *fg = getenv("PAA_HIP_FORCE_GENERIC");
     g_force_generic = (fg && fg[0] == '1') ? 1 : 0;
+    const char *ws = getenv("PAA_HIP_FAST_WS");
+    g_fast_ws = (ws && ws[0] == '1') ? 1 : 0;
     return PAA_OK;
 }
 
