@@ -687,478 +687,12 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
     PAA_TEND()
 }
 
-// ---- wave-specialised variant ------------------------------------------------------------------------------
-// Workgroup = 8 waves = 4 PAIRS; each pair owns a run of frames.  Wave p (0..3) is the pair's PRODUCER (staging,
-// time-domain partials, the register FFT up to the magnitudes), wave p+4 its CONSUMER (the feature stage and
-// the stores of the PREVIOUS quad).  Waves w and w+4 of a workgroup land on the same SIMD, so every SIMD hosts
-// one FFT-heavy and one latency-heavy wave whose stalls hide each other (<= 256 registers each).  The quad's
-// spectra are double-buffered: in round r the producer uses buffer r&1 (raw staging -> exchange plane -> final
-// spectra) while the consumer reads buffer (r-1)&1; ONE workgroup barrier per round swaps the roles.
-template <int S>
-struct GeoWS {
-    using G = Geo<S>;
-    static constexpr int OFF_PLANE = 0;                                     // buffer 0: 4 x 400 doubles (raw int16 aliased at its start)
-    static constexpr int OFF_SPEC = OFF_PLANE + 4 * NF * 8;                 // buffer 1
-    static constexpr int OFF_PREV = OFF_SPEC + 4 * NF * 8;                  // last spectrum of the previous quad
-    static constexpr int OFF_PART = OFF_PREV + NF * 8;                      // 2 x {cE[NCHUNK] f64, cZ[NCHUNK], cF[NCHUNK] i32}
-    static constexpr int PART_BYTES = 16 * G::NCHUNK;
-    static constexpr int OFF_FV = OFF_PART + 2 * PART_BYTES;
-    static constexpr int OFF_MSP = OFF_FV + QUAD * FV_STRIDE * 8;
-    static constexpr int PAIR_BYTES = ((OFF_MSP + QUAD * 40 * 8 + 15) / 16) * 16;
-    static_assert((G::RAW_N + 2 * RAW_PAD) * 2 <= 4 * NF * 8, "raw samples alias the exchange plane");
-};
-constexpr int WS_PAIRS = 4;
-
-template <int S, int DELTAS>
-__global__ __launch_bounds__(128 * WS_PAIRS, 2) void st_fast_800_ws_kernel(PlanDev P, TabLayout L,
-                                                                           const unsigned char *__restrict__ blob,
-                                                                           const int16_t *__restrict__ sig,
-                                                                           const ClipDev *__restrict__ clips,
-                                                                           const ClipNorm *__restrict__ norms,
-                                                                           const Tile *__restrict__ tiles, int n_tiles,
-                                                                           double *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    {
-        const int4 *src4 = reinterpret_cast<const int4 *>(blob);
-        int4 *dst4 = reinterpret_cast<int4 *>(smem);
-        for (int n = threadIdx.x; n < L.total / 16; n += 128 * WS_PAIRS) dst4[n] = src4[n];
-    }
-    __syncthreads();
-    const double *t_melw0 = reinterpret_cast<const double *>(smem + L.off_w0);
-    const int *t_melk0 = reinterpret_cast<const int *>(smem + L.off_k0);
-    const double *t_melw1 = reinterpret_cast<const double *>(smem + L.off_w1);
-    const int *t_melk1 = reinterpret_cast<const int *>(smem + L.off_k1);
-    const double *t_melw2 = reinterpret_cast<const double *>(smem + L.off_w2);
-    const int *t_melk2 = reinterpret_cast<const int *>(smem + L.off_k2);
-    const double *t_chw = reinterpret_cast<const double *>(smem + L.off_chw);
-    const int *t_chk = reinterpret_cast<const int *>(smem + L.off_chk);
-    const double *t_dct = reinterpret_cast<const double *>(smem + L.off_dct);
-    const double2 *t_tw2 = reinterpret_cast<const double2 *>(smem + L.off_tw2);
-    const double2 *t_twp = reinterpret_cast<const double2 *>(smem + L.off_twp);
-
-    using G = Geo<S>;
-    using GW = GeoWS<S>;
-    constexpr int RAW_N = G::RAW_N, NCHUNK = G::NCHUNK, CPF = G::CPF;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // wave-uniform: keeps per-wave constants in SGPRs
-    const int pair = wave & (WS_PAIRS - 1);
-    const bool producer = wave < WS_PAIRS;
-    const int lane = threadIdx.x & 63;
-    const int g = lane >> 4, i = lane & 15;
-
-    // every wave of the workgroup runs the same number of rounds (the barriers are workgroup-wide)
-    int rounds_max = 0;
-#pragma unroll
-    for (int pp = 0; pp < WS_PAIRS; ++pp) {
-        const int tid = blockIdx.x * WS_PAIRS + pp;
-        if (tid < n_tiles) {
-            const Tile tq = tiles[tid];
-            const int qs = tq.t0 >= QUAD ? tq.t0 - QUAD : 0;
-            rounds_max = max(rounds_max, (tq.t0 + tq.cnt - qs + QUAD - 1) / QUAD);
-        }
-    }
-    const int tile_id = blockIdx.x * WS_PAIRS + pair;
-    const bool valid = tile_id < n_tiles;
-    Tile tl;
-    tl.clip = 0; tl.t0 = 0; tl.cnt = 0; tl.pad = 0;
-    if (valid) tl = tiles[tile_id];
-    const ClipDev c = clips[tl.clip];
-    const ClipNorm nm = norms[tl.clip];
-    const int16_t *xc = sig + c.sample_off;
-    const long long Tc = c.T;
-    double *oc = out + c.out_off;
-
-    unsigned char *pbase = smem + L.total + pair * GW::PAIR_BYTES;
-    double *buf0 = reinterpret_cast<double *>(pbase + GW::OFF_PLANE);
-    double *buf1 = reinterpret_cast<double *>(pbase + GW::OFF_SPEC);
-    double *prev = reinterpret_cast<double *>(pbase + GW::OFF_PREV);
-    double *fv = reinterpret_cast<double *>(pbase + GW::OFF_FV);
-    double *msp = reinterpret_cast<double *>(pbase + GW::OFF_MSP);
-
-    const double sc = 1.0 / 32768.0;
-    const double f0 = P.fs / (2.0 * (double)NF);
-    const double rf0 = 1.0 / f0;
-    const double half_fs = P.fs / 2.0;
-    const double r_half_fs = 1.0 / half_fs;
-    const double mu = nm.mean * 32768.0;             // clip mean in counts (exact scaling)
-    const int m_int = (int)fmin(fmax(nearbyint(mu), -40000.0), 40000.0);
-    const double mag_scale = 0.5 * nm.inv * sc / (double)NF;       // 0.5: E and O carry a factor 1/2
-    const double dc_shift = 2.0 * (double)W * (mu - (double)m_int);
-    const int thr_pos = (int)fmin(fmax(floor(mu) + 1.0, -40000.0), 40000.0);   // x >= thr_pos  <=> positive
-    const int thr_neg = (int)fmin(fmax(ceil(mu) - 1.0, -40000.0), 40000.0);    // x <= thr_neg  <=> negative
-    const int pa = i, pb = (i == 0) ? 0 : 25 - i;
-    const bool act = i < 13;
-
-    const int t_end = tl.t0 + tl.cnt;
-    const int q_start = tl.t0 >= QUAD ? tl.t0 - QUAD : 0;
-    const int n_q = valid ? (t_end - q_start + QUAD - 1) / QUAD : 0;
-    double vlast = 0.0;              // consumer, lane l < 34: feature l of the frame before this quad
-
-
-    // the consumer's work is latency-bound chains: give it issue priority, the dense producer fills the gaps
-    if (!producer) __builtin_amdgcn_s_setprio(PAA_WS_CONSUMER_PRIO);
-    PAA_T0()
-    for (int rnd = 0; rnd <= rounds_max; ++rnd) {
-#ifdef PAA_WS_NO_PRODUCER
-        const bool p_live = false;
-#else
-        const bool p_live = producer && rnd < n_q;
-#endif
-        if (p_live) {
-            const int q0 = q_start + QUAD * rnd;
-            double *plane = (rnd & 1) ? buf1 : buf0;          // this round's buffer: raw -> exchange plane -> spectra
-            int16_t *raw = reinterpret_cast<int16_t *>(plane);
-            double *cE = reinterpret_cast<double *>(pbase + GW::OFF_PART + (rnd & 1) * GW::PART_BYTES);
-            int *cZ = reinterpret_cast<int *>(cE + NCHUNK);
-            int *cF = cZ + NCHUNK;
-            // ---------------- stage raw samples [q0*S - 1, q0*S + 2000)
-            {
-                const long long base = (long long)q0 * S;
-                const int16_t *src = xc + base;
-                const long long avail = c.n - base;
-                if (((reinterpret_cast<uintptr_t>(src) & 15) == 0) && avail >= RAW_N) {
-                    const int4 *s4 = reinterpret_cast<const int4 *>(src);
-                    int4 *d4 = reinterpret_cast<int4 *>(raw + RAW_PAD);
-    #pragma unroll
-                    for (int r = 0; r < G::NPRE; ++r)
-                        if (lane + 64 * r < RAW_N / 8) d4[lane + 64 * r] = s4[lane + 64 * r];
-                } else {
-                    for (int n = lane; n < RAW_N; n += 64) raw[RAW_PAD + n] = (n < avail) ? src[n] : (int16_t)0;
-                }
-                if (lane == 0) raw[RAW_PAD - 1] = (base > 0) ? src[-1] : src[0];
-            }
-            wsync();
-            // ---------------- time domain: chunk partials (ShortTermFeatures.py:22-51)
-            for (int ch = lane; ch < NCHUNK; ch += 64) {
-                const int4 *p4 = reinterpret_cast<const int4 *>(raw + RAW_PAD + CHUNK * ch);
-                const int prev = raw[RAW_PAD + CHUNK * ch - 1];
-                int sprev = (prev >= thr_pos) - (prev <= thr_neg);
-                double e = 0.0;
-                int z = 0, zfirst = 0;
-    #pragma unroll
-                for (int v4 = 0; v4 < CHUNK / 8; ++v4) {
-                    const int4 q = p4[v4];
-                    const int w[4] = {q.x, q.y, q.z, q.w};
-    #pragma unroll
-                    for (int h = 0; h < 4; ++h) {
-                        const int xa = (int)(short)(w[h] & 0xffff), xb = w[h] >> 16;
-                        const double ya = fma((double)xa, sc, -nm.mean) * nm.inv;
-                        const double yb = fma((double)xb, sc, -nm.mean) * nm.inv;
-                        e = fma(ya, ya, e);
-                        e = fma(yb, yb, e);
-                        const int sa = (xa >= thr_pos) - (xa <= thr_neg);
-                        const int sb = (xb >= thr_pos) - (xb <= thr_neg);
-                        const int da = abs(sa - sprev);
-                        if (v4 == 0 && h == 0) zfirst = da;
-                        z += da + abs(sb - sa);
-                        sprev = sb;
-                    }
-                }
-                cE[ch] = e;
-                cZ[ch] = z;
-                cF[ch] = zfirst;
-            }
-            // ---------------- pass 1: radix-25 on z[j + 16 r], z = x[2n] + i x[2n+1] (raw integers, exact in f64)
-            double2 v[25];
-            {
-                const int *r32 = reinterpret_cast<const int *>(raw + RAW_PAD) + (S / 2) * g + i;
-    #pragma unroll
-                for (int r = 0; r < 25; ++r) {
-                    const int w = r32[16 * r];
-                    v[r] = make_double2((double)((int)(short)(w & 0xffff) - m_int), (double)((w >> 16) - m_int));
-                }
-            }
-            dft25(v);
-            wsync();
-            // exchange through the quad's 4 spectrum slots: real plane, then imaginary plane.
-            // element (frame g, index 25 j + q)
-            double ax[16], ay[16], bx[16], by[16];
-            {
-                double *pl = plane + g * NF;
-    #pragma unroll
-                for (int q = 0; q < 25; ++q) pl[25 * i + q] = v[PAA_DFT25_POS(q)].x;
-                wsync();
-    #pragma unroll
-                for (int r = 0; r < 16; ++r) { ax[r] = pl[pa + 25 * r]; bx[r] = pl[pb + 25 * r]; }
-                wsync();
-    #pragma unroll
-                for (int q = 0; q < 25; ++q) pl[25 * i + q] = v[PAA_DFT25_POS(q)].y;
-                wsync();
-    #pragma unroll
-                for (int r = 0; r < 16; ++r) { ay[r] = pl[pa + 25 * r]; by[r] = pl[pb + 25 * r]; }
-                wsync();
-            }
-            // ---------------- pass 2 + real-FFT recombination + magnitude (ShortTermFeatures.py:617-621)
-            if (act) {
-                // column 25-p uses the conjugate twiddles and a one-step rotation of the outputs
-                double2 a[16], b[16];
-                a[0] = make_double2(ax[0], ay[0]);
-                b[0] = make_double2(bx[0], by[0]);
-    #pragma unroll
-                for (int r = 1; r < 16; ++r) {
-                    const double2 w2 = t_tw2[r * 16 + i];       // the partner wave on this SIMD covers the LDS latency
-                    a[r] = cmul(make_double2(ax[r], ay[r]), w2);
-                    b[r] = cmul(make_double2(bx[r], by[r]), make_double2(w2.x, -w2.y));
-                }
-                dft16(a);
-                dft16(b);
-                double *sp = plane + g * NF;
-    #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    // Z[k], k = p + 25 q ; Z[400 - k] = column (25-p), output (15 - q) -> rotated index (16 - q) % 16
-                    const double2 zk = a[PAA_DFT16_POS(q)];
-                    const int qm = (16 - q) % 16;
-                    // lane 0 (p = 0) has b == a bit for bit (same column, unit twiddles), so no select is needed:
-                    // Z[400 - 25 q] = A[(16 - q) % 16] = b[...] there as well
-                    const double2 zb = b[PAA_DFT16_POS(qm)];
-                    // 2E = Z[k] + conj Z[400-k],  2O = -i (Z[k] - conj Z[400-k])
-                    const double2 e = make_double2(zk.x + zb.x, zk.y - zb.y);
-                    const double2 o = make_double2(zk.y + zb.y, zb.x - zk.x);
-                    const double2 t = cmul(t_twp[q * 16 + i], o);
-                    double xr = e.x + t.x, xi = e.y + t.y;
-                    const double yr = e.x - t.x, yi = e.y - t.y;
-                    if (q == 0 && i == 0) { xr -= dc_shift; xi = 0.0; }    // DC bin: remove the residual clip mean
-                    const int k = pa + 25 * q;
-                    sp[k] = mag_sqrt(fma(xr, xr, xi * xi)) * mag_scale;
-                    if (q > 0 || i > 0) sp[NF - k] = mag_sqrt(fma(yr, yr, yi * yi)) * mag_scale;
-                }
-            }
-#ifdef PAA_WS_NO_CONSUMER
-        } else if (false) {
-#else
-        } else if (!producer && rnd >= 1 && rnd - 1 < n_q) {
-#endif
-            const int q0 = q_start + QUAD * (rnd - 1);
-            const double *spec = ((rnd - 1) & 1) ? buf1 : buf0;    // the buffer the producer finished last round
-            const double *cE = reinterpret_cast<const double *>(pbase + GW::OFF_PART + ((rnd - 1) & 1) * GW::PART_BYTES);
-            const int *cZ = reinterpret_cast<const int *>(cE + NCHUNK);
-            const int *cF = cZ + NCHUNK;
-            // ---------------- features: 16 lanes per frame (group g <-> frame q0 + g)
-            // lane i owns bins [25 i, 25 i + 25) of its frame; current and previous spectrum are pulled into
-            // registers once (two batched LDS bursts) and serve the sums, the spread/flux pass and the roll-off scan
-            const int t = q0 + g;
-            const double *cur = spec + g * NF;
-            const double *prv = (t == 0) ? cur : ((g == 0) ? prev : spec + (g - 1) * NF);
-            // spectral entropy operands: lane i < 10 owns block i of 40 bins (:85-107)
-            double pblk = 0.0;
-            {
-                const double2 *c2 = reinterpret_cast<const double2 *>(cur + 40 * (i < 10 ? i : 0));
-                double2 blk[20];
-    #pragma unroll
-                for (int m = 0; m < 20; ++m) blk[m] = c2[m];
-                double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-    #pragma unroll
-                for (int m = 0; m < 20; m += 2) {
-                    p0 = fma(blk[m].x, blk[m].x, p0); p1 = fma(blk[m].y, blk[m].y, p1);
-                    p2 = fma(blk[m + 1].x, blk[m + 1].x, p2); p3 = fma(blk[m + 1].y, blk[m + 1].y, p3);
-                }
-                pblk = (i < 10) ? (p0 + p1) + (p2 + p3) : 0.0;
-            }
-            asm volatile("" ::: "memory");
-            double Xc[25];
-    #pragma unroll
-    for (int m = 0; m < 25; ++m) Xc[m] = cur[25 * i + m];
-    const double *Xv = prv + 25 * i;      // re-read from LDS where needed (the partner wave hides the latency)
-            // sums over the lane's 25 bins; two interleaved accumulator sets keep the dependent chains short.
-            // sum(ind * X) with ind = (k+1) f0 is f0 * [(25 i + 1) * sum X + sum m X]   (small exact integers)
-            double sXa = 0.0, sXb = 0.0, sPa = 0.0, sPb = 0.0, sMa = 0.0, sMb = 0.0, sVa = 0.0, sVb = 0.0, mx = 0.0;
-    #pragma unroll
-            for (int m = 0; m < 24; m += 2) {
-                const double X0 = Xc[m], X1 = Xc[m + 1];
-                sXa += X0; sXb += X1;
-                sVa += Xv[m]; sVb += Xv[m + 1];
-                sMa = fma((double)m, X0, sMa); sMb = fma((double)(m + 1), X1, sMb);
-                sPa = fma(X0, X0, sPa); sPb = fma(X1, X1, sPb);
-                mx = fmax(mx, fmax(X0, X1));
-            }
-            sXa += Xc[24]; sVa += Xv[24]; sMa = fma(24.0, Xc[24], sMa); sPa = fma(Xc[24], Xc[24], sPa); mx = fmax(mx, Xc[24]);
-            const double cs = sPa + sPb;
-            const double base_k = (double)(25 * i + 1);
-            double sX = sXa + sXb;
-            double sIX = f0 * fma(base_k, sX, sMa + sMb);
-            double sXp = sVa + sVb;
-            sX = group_sum(sX); sXp = group_sum(sXp);
-            sIX = group_sum(sIX); mx = group_max(mx);
-            // np.sum(X + eps) (:118-119) = sum X + 400 eps up to rounding
-            const double sXe = sX + (double)NF * kEps;
-            sXp += (double)NF * kEps;
-            const double run_incl = group_scan_incl(cs);
-            const double sP = dpp_bcast15(run_incl);            // total = inclusive scan at lane 15
-
-            // energy entropy: 80-sample block i = chunks CPF g + 2 i, + 1 (:34-51)
-            const double eblk = (i < 10) ? cE[CPF * g + 2 * i] + cE[CPF * g + 2 * i + 1] : 0.0;
-            const double e_tot = group_sum(eblk);
-            double ent_f, ent_e;
-            {
-                const double sf = fast_div(pblk, sP + kEps), se = fast_div(eblk, e_tot + kEps);
-                ent_f = group_sum((i < 10) ? -(sf * fast_log2(sf + kEps)) : 0.0);
-                ent_e = group_sum((i < 10) ? -(se * fast_log2(se + kEps)) : 0.0);
-            }
-            // zero crossings: 20 chunks of the frame minus the pair that straddles the frame start (:22-26)
-            int zc = cZ[CPF * g + i] + ((i < 4) ? cZ[CPF * g + 16 + i] : 0) - ((i == 0) ? cF[CPF * g] : 0);
-            zc = group_sum_i(zc);
-            // centroid, spread, flux (:57-82, :110-124)
-            const double r = (mx == 0.0) ? 1.0 / kEps : fast_div(1.0, mx);
-            const double den = sX * r + kEps;
-            const double rden = fast_div(1.0, den);
-            const double cen = (sIX * r) * rden;
-            const double rX = fast_div(1.0, sXe), rXp = fast_div(1.0, sXp);
-            // spread: sum (ind - C)^2 X / max = f0^2/max * sum ((k+1) - C/f0)^2 X
-            const double cb = base_k - cen * rf0;
-            double sSa = 0.0, sSb = 0.0, sFa = 0.0, sFb = 0.0;
-    #pragma unroll
-            for (int m = 0; m < 24; m += 2) {
-                const double d0 = cb + (double)m, d1 = cb + (double)(m + 1);
-                sSa = fma(d0 * d0, Xc[m], sSa);
-                sSb = fma(d1 * d1, Xc[m + 1], sSb);
-                const double f0d = Xc[m] * rX - Xv[m] * rXp, f1d = Xc[m + 1] * rX - Xv[m + 1] * rXp;
-                sFa = fma(f0d, f0d, sFa);
-                sFb = fma(f1d, f1d, sFb);
-            }
-            {
-                const double d0 = cb + 24.0;
-                sSa = fma(d0 * d0, Xc[24], sSa);
-                const double f0d = Xc[24] * rX - Xv[24] * rXp;
-                sFa = fma(f0d, f0d, sFa);
-            }
-            double sSp = (sSa + sSb) * (f0 * f0 * r), sFl = sFa + sFb;
-            sSp = group_sum(sSp);
-            sFl = group_sum(sFl);
-            const double spread = fast_sqrt(sSp * rden);
-
-            // roll-off (:127-140): first k with cumsum(X^2)[k] + eps > 0.9 sum(X^2); branch-free per lane
-            int first = 0x7fffffff;
-            {
-                const double thr = 0.90 * sP;
-                double run = run_incl - cs;
-    #pragma unroll
-                for (int m = 0; m < 25; ++m) {
-                    run = fma(Xc[m], Xc[m], run);
-                    first = (first == 0x7fffffff && run + kEps > thr) ? 25 * i + m : first;
-                }
-                first = group_min_i(first);
-            }
-            // MFCC (:236-254): per-lane padded mel lists (host-built): class 0 = filter i, class 1 = filter 16+i,
-            // class 2 = one half of filter 32 + (i & 7); the halves meet through a row rotation by 8
-            double *mg = msp + 40 * g;
-            {
-                // a filter covers consecutive bins, so only its first bin is tabulated (k*[i]); weights are
-                // zero-padded to the class length and the bin index is clamped into the spectrum
-                double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-                const int lo0 = t_melk0[i], lo1 = t_melk1[i], lo2 = t_melk2[i];
-                // each trip issues its 16 LDS loads back to back (one wait), then runs two 4-long FMA chains
-    #define PAA_MEL_CLASS(acc, lo, N, tw)                                                                   \
-                for (int n = 0; n < (N); n += 8) {                                                          \
-                    double xv_[8], wv_[8];                                                                  \
-                    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                         \
-                        xv_[u] = cur[min((lo) + n + u, NF - 1)];                                            \
-                        wv_[u] = (tw)[(n + u) * 16 + i];                                                    \
-                    }                                                                                       \
-                    double ea_ = 0.0, eb_ = 0.0;                                                            \
-                    _Pragma("unroll") for (int u = 0; u < 8; u += 2) {                                      \
-                        ea_ = fma(xv_[u], wv_[u], ea_);                                                     \
-                        eb_ = fma(xv_[u + 1], wv_[u + 1], eb_);                                             \
-                    }                                                                                       \
-                    acc += ea_ + eb_;                                                                       \
-                }
-                PAA_MEL_CLASS(acc0, lo0, L.melN0, t_melw0)
-                PAA_MEL_CLASS(acc1, lo1, L.melN1, t_melw1)
-                PAA_MEL_CLASS(acc2, lo2, L.melN2, t_melw2)
-    #undef PAA_MEL_CLASS
-                acc2 += dpp_mov<0x128>(acc2);                    // row_ror:8
-                mg[i] = fast_log10(acc0 + kEps);
-                mg[16 + i] = fast_log10(acc1 + kEps);
-                const double l2 = fast_log10(acc2 + kEps);
-                if (i < 8) mg[32 + i] = l2;
-            }
-            // chroma (:277-321): lane i < 12 = pitch class i, padded gather list in ascending slot order
-            double chroma = 0.0;
-            {
-                for (int n = 0; n < L.chN; n += 8) {
-                    int kv[8];
-                    double wv[8], xv[8];
-    #pragma unroll
-                    for (int u = 0; u < 8; ++u) { kv[u] = t_chk[(n + u) * 16 + i]; wv[u] = t_chw[(n + u) * 16 + i]; }
-    #pragma unroll
-                    for (int u = 0; u < 8; ++u) xv[u] = cur[kv[u]];
-    #pragma unroll
-                    for (int u = 0; u < 8; ++u) chroma = fma(xv[u] * xv[u], wv[u], chroma);     // ascending slot order (:299-302)
-                }
-                chroma = (sP == 0.0) ? chroma / kEps : fast_div(chroma, sP);
-                if (i >= 12) chroma = 0.0;
-            }
-            wsync();
-            double *fg = fv + FV_STRIDE * g;
-            if (i < 13) {
-                const double *dm = t_dct + 41 * i;        // rows padded to 41 doubles: conflict-free across lanes
-                double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
-    #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    double dv[20], mv[20];
-    #pragma unroll
-                    for (int n = 0; n < 20; ++n) { dv[n] = dm[20 * h + n]; mv[n] = mg[20 * h + n]; }
-    #pragma unroll
-                    for (int n = 0; n < 20; n += 4) {
-                        c0 = fma(dv[n], mv[n], c0);
-                        c1 = fma(dv[n + 1], mv[n + 1], c1);
-                        c2 = fma(dv[n + 2], mv[n + 2], c2);
-                        c3 = fma(dv[n + 3], mv[n + 3], c3);
-                    }
-                }
-                fg[8 + i] = (c0 + c1) + (c2 + c3);
-            }
-            if (i < 12) fg[21 + i] = chroma;
-            if (i == 15) {
-                fg[0] = ((double)zc * 0.5) * (1.0 / (double)(W - 1));
-                fg[1] = e_tot * (1.0 / (double)W);
-                fg[2] = ent_e;
-                fg[3] = cen * r_half_fs;
-                fg[4] = spread * r_half_fs;
-                fg[5] = ent_f;
-                fg[6] = (t == 0) ? 0.0 : sFl;      // first frame: previous spectrum = itself (:624-625)
-                fg[7] = (first == 0x7fffffff) ? 0.0 : (double)first * (1.0 / (double)NF);
-            }
-            {   // population std of the 12 chroma values (:667), by DPP inside the group
-                const double m = group_sum((i < 12) ? chroma : 0.0) / 12.0;
-                const double d = (i < 12) ? chroma - m : 0.0;
-                const double var = group_sum(d * d) / 12.0;
-                if (i == 14) fg[33] = fast_sqrt(var);
-            }
-            wsync();
-            // ---------------- store: lane = feature row, 4 consecutive frames
-            if (lane < kBase) {
-                double vq[QUAD];
-    #pragma unroll
-                for (int s = 0; s < QUAD; ++s) vq[s] = fv[FV_STRIDE * s + lane];
-    #pragma unroll
-                for (int s = 0; s < QUAD; ++s) {
-                    const int ts = q0 + s;
-                    if (ts >= tl.t0 && ts < t_end) {
-                        oc[(long long)lane * Tc + ts] = vq[s];
-                        if (DELTAS) {
-                            const double pv = (s == 0) ? vlast : vq[s - 1];
-                            oc[(long long)(kBase + lane) * Tc + ts] = (ts == 0) ? 0.0 : vq[s] - pv;
-                        }
-                    }
-                }
-                vlast = vq[QUAD - 1];
-            }
-            wsync();
-            // keep the quad's last spectrum for the flux of the next quad's first frame
-            for (int k = lane; k < NF; k += 64) prev[k] = spec[3 * NF + k];
-        }
-        if (producer) { PAA_TICK(0) } else { PAA_TICK(1) }
-        __syncthreads();            // swap: buffer rnd&1 now holds finished spectra, the other one is free
-        if (producer) { PAA_TICK(2) } else { PAA_TICK(3) }
-    }
-    PAA_TEND()
-}
-
 }  // namespace f800
 
 // returns 1 when a specialised kernel exists for this configuration (and fills fl), 0 when
 // the generic kernel must be used, < 0 on error
 inline int fast_select(int window, int step, int sample_kind, double fs, FastTables &ft, const FftPlan &fft,
-                       const MelTable &mel, const ChromaTable &chroma, FastLaunch &fl, int wave_specialised) {
+                       const MelTable &mel, const ChromaTable &chroma, FastLaunch &fl) {
     (void)fs;
     if (!(window == 800 && (step == 400 || step == 800) && sample_kind == 0)) return 0;
     const int wave_bytes = (step == 400) ? f800::Geo<400>::WAVE_BYTES : f800::Geo<800>::WAVE_BYTES;
@@ -1216,15 +750,6 @@ inline int fast_select(int window, int step, int sample_kind, double fs, FastTab
     fl.name = (step == 400) ? "st_fast_800" : "st_fast_800_s800";
     fl.lds = (size_t)L.total + (size_t)f800::WAVES * wave_bytes;
     fl.variant = (step == 400) ? 800 : 1600;
-    if (wave_specialised) {
-        const size_t pair_bytes = (step == 400) ? f800::GeoWS<400>::PAIR_BYTES : f800::GeoWS<800>::PAIR_BYTES;
-        const size_t lds_ws = (size_t)L.total + (size_t)f800::WS_PAIRS * pair_bytes;
-        if (lds_ws <= 160 * 1024) {
-            fl.name = (step == 400) ? "st_fast_800_ws" : "st_fast_800_s800_ws";
-            fl.lds = lds_ws;
-            fl.variant += 1;        // 801 / 1601
-        }
-    }
     fl.run = 256;       // longest run (frames) given to one wave; the plan shrinks it to fill the chip
     fl.waves_per_cu = f800::WAVES;
     return 1;
@@ -1246,33 +771,11 @@ inline int fast_launch_one(const FastLaunch &fl, const PlanDev &P, const unsigne
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-template <int S, int DELTAS>
-inline int fast_launch_ws(const FastLaunch &fl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
-                          const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,
-                          double *d_out, hipStream_t stream) {
-    static size_t attr_done = 0;
-    if (attr_done < fl.lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&f800::st_fast_800_ws_kernel<S, DELTAS>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl.lds) != hipSuccess) return -1;
-        attr_done = fl.lds;
-    }
-    const unsigned grid = (unsigned)((n_tiles + f800::WS_PAIRS - 1) / f800::WS_PAIRS);
-    hipLaunchKernelGGL((f800::st_fast_800_ws_kernel<S, DELTAS>), dim3(grid), dim3(128 * f800::WS_PAIRS), fl.lds, stream,
-                       P, fl.layout, blob, (const int16_t *)d_packed, clips, norms, tiles, (int)n_tiles, d_out);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-
 inline int fast_launch(const FastLaunch &fl, const PlanDev &P, const FastTables &ft, const void *d_packed,
                        const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,
                        double *d_out, hipStream_t stream) {
     if (!ft.d_blob) return -1;
     const unsigned char *blob = reinterpret_cast<const unsigned char *>(ft.d_blob);
-    if (fl.variant == 801)
-        return P.deltas ? fast_launch_ws<400, 1>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream)
-                        : fast_launch_ws<400, 0>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
-    if (fl.variant == 1601)
-        return P.deltas ? fast_launch_ws<800, 1>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream)
-                        : fast_launch_ws<800, 0>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
     if (fl.variant == 800)
         return P.deltas ? fast_launch_one<400, 1>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream)
                         : fast_launch_one<400, 0>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);

@@ -69,13 +69,13 @@ struct Scratch {
 };
 
 static std::mutex g_mu;
+static std::mutex g_api_mu;     // host-buffer entry points share the scratch buffers: one call at a time
 static int g_device = -1;
 static hipStream_t g_stream = nullptr;
 static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 static std::map<std::pair<double, int>, std::unique_ptr<TableSet>> g_tables;
 static Scratch g_in, g_out, g_mid;
 static int g_force_generic = 0;
-static int g_fast_ws = 0;          // PAA_HIP_FAST_WS=1: wave-specialised variant of the fast kernel
 // optional per-launch timing of the feature kernel (bench.py's roofline leg)
 static int g_prof = 0;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev;
@@ -284,7 +284,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     // ---- kernel choice + tiles
     p->fast = 0;
     if (mode == 0 && !g_force_generic) {
-        rc = fast_select(window, step, sample_kind, fs, tab->fast, tab->fft, tab->mel, tab->chroma, p->fl, g_fast_ws);
+        rc = fast_select(window, step, sample_kind, fs, tab->fast, tab->fft, tab->mel, tab->chroma, p->fl);
         if (rc < 0) return fail(rc, "building the tables of the specialised kernel failed");
         p->fast = rc;
     }
@@ -577,8 +577,6 @@ extern "C" int paa_init(int device_id) {
     g_device = device_id;
     const char *fg = getenv("PAA_HIP_FORCE_GENERIC");
     g_force_generic = (fg && fg[0] == '1') ? 1 : 0;
-    const char *ws = getenv("PAA_HIP_FAST_WS");
-    g_fast_ws = (ws && ws[0] == '1') ? 1 : 0;
     return PAA_OK;
 }
 
@@ -707,6 +705,7 @@ static int run_host_st(const void *packed, const int64_t *offsets, int64_t n_cli
                        int window, int step, int deltas, double *out, const int64_t *out_offsets,
                        int64_t mid_ratio, int64_t mid_step, double *mid_out, const int64_t *mid_out_offsets) {
     if (!packed || !offsets) return fail(PAA_ERR_ARG, "null signal");
+    std::lock_guard<std::mutex> api_lock(g_api_mu);
     const bool want_mid = mid_out != nullptr;
     if (want_mid && !deltas) return fail(PAA_ERR_ARG, "mid-term features are defined over the 68 delta rows");
     if (want_mid && mid_step < 1)
@@ -828,6 +827,7 @@ extern "C" int paa_mid_features_batch_i16(const int16_t *packed, const int64_t *
 static int run_host_spec(const void *signal, int64_t n, int sample_kind, double fs, int window, int step, int mode,
                          double *out) {
     if (!signal || !out) return fail(PAA_ERR_ARG, "null signal / out");
+    std::lock_guard<std::mutex> api_lock(g_api_mu);
     const int64_t off[2] = {0, n};
     paa_plan *plan = nullptr;
     int rc;

@@ -234,3 +234,22 @@ def test_big_window_spectrogram(gpu_lib, capsys):
     capsys.readouterr()
     ref, _, _ = O.spectrogram(x, 16000, 8000, 4000)
     assert_parity(S, ref, "big spectrogram")
+
+
+def test_concurrent_python_threads(gpu_lib):
+    """ctypes releases the GIL: host-buffer entry points must be safe to call from several threads."""
+    import threading
+    clips = [synth_clip(900 + i, 16000 * (1 + i % 3)) for i in range(6)]
+    expect = [ShortTermFeatures.feature_extraction(c, 16000, 800, 400)[0] for c in clips]
+    got = [None] * len(clips)
+
+    def work(k):
+        for _ in range(5):
+            got[k] = ShortTermFeatures.feature_extraction(clips[k], 16000, 800, 400)[0]
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(clips))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e, g_ in zip(expect, got):
+        assert np.array_equal(e, g_)
