@@ -1,52 +1,64 @@
-"""The two audioBasicIO functions the feature path touches (reference: pyAudioAnalysis/audioBasicIO.py).
+"""Host-side audio file access used by the directory walkers.
 
-Host-side file I/O only -- nothing here runs on the GPU.  WAV goes through scipy.io.wavfile exactly like the
-reference (:99); AIFF through the stdlib `aifc`; mp3/au/ogg need pydub/ffmpeg in the reference (:100-101) and
-report a decoding failure here.
+Only what the feature path needs from the reference's audioBasicIO: opening a file as (sampling rate, samples)
+and collapsing two channels into one.  Nothing here touches the GPU.
+  * WAV  -> scipy.io.wavfile, as the reference does (audioBasicIO.py:99)
+  * AIFF -> stdlib `aifc` (the reference's read_aif, :113-127)
+  * mp3 / au / ogg need pydub + ffmpeg in the reference (:130-153); they are reported as undecodable here.
+A file that cannot be decoded yields sampling rate -1 and an empty array, like the reference's readers.
 """
 import os
 
 import numpy as np
 
+_PCM_CONTAINERS = (".aif", ".aiff")
+_NEEDS_FFMPEG = (".mp3", ".au", ".ogg")
+
+
+def _undecodable(message):
+    print(message)
+    return -1, np.array([])
+
 
 def read_audio_file(input_file):
-    """Returns (sampling_rate, signal) like audioBasicIO.read_audio_file (:86-110); (-1, []) on decode failure."""
-    sampling_rate = 0
-    signal = np.array([])
-    extension = os.path.splitext(str(input_file))[1].lower()
-    if extension == ".wav":
+    """(sampling_rate, signal) of an audio file; signal is 1-D for mono and (n, channels) otherwise."""
+    suffix = os.path.splitext(str(input_file))[1].lower()
+    if suffix == ".wav":
         from scipy.io import wavfile
         try:
-            sampling_rate, signal = wavfile.read(input_file)
-        except Exception:         # the reference lets scipy's error escape (:99); a directory walk skips the file
-            sampling_rate, signal = -1, np.array([])
-            print("Error: read wav file. (DECODING FAILED)")
-    elif extension in (".aif", ".aiff"):
-        sampling_rate = -1
+            rate, samples = wavfile.read(input_file)
+        except Exception:      # the reference lets scipy's error escape; a directory walk skips the file instead
+            return _undecodable("Error: read wav file. (DECODING FAILED)")
+    elif suffix in _PCM_CONTAINERS:
         try:
             import aifc
-            with aifc.open(input_file, "r") as s:
-                raw = s.readframes(s.getnframes())
-                signal = np.frombuffer(raw, np.short).byteswap()
-                sampling_rate = s.getframerate()
+            with aifc.open(input_file, "r") as handle:
+                payload = handle.readframes(handle.getnframes())
+                rate = handle.getframerate()
+            samples = np.frombuffer(payload, np.short).byteswap()
         except Exception:
-            print("Error: read aif file. (DECODING FAILED)")
-    elif extension in (".mp3", ".au", ".ogg"):
-        sampling_rate = -1
-        print("Error: file not found or other I/O error. (DECODING FAILED)")
+            return _undecodable("Error: read aif file. (DECODING FAILED)")
+    elif suffix in _NEEDS_FFMPEG:
+        return _undecodable("Error: file not found or other I/O error. (DECODING FAILED)")
     else:
-        print("Error: unknown file type {extension}")
-    if signal.ndim == 2 and signal.shape[1] == 1:
-        signal = signal.flatten()
-    return sampling_rate, signal
+        print("Error: unknown file type {0:s}".format(suffix))
+        return 0, np.array([])
+    samples = np.asarray(samples)
+    if samples.ndim == 2 and samples.shape[1] == 1:
+        samples = samples.reshape(-1)
+    return rate, samples
 
 
 def stereo_to_mono(signal):
-    """(:156-168): two channels -> (R/2) + (L/2) as float64; one-column input is flattened."""
-    if signal.ndim == 2:
-        if signal.shape[1] == 1:
-            signal = signal.flatten()
-        else:
-            if signal.shape[1] == 2:
-                signal = (signal[:, 1] / 2) + (signal[:, 0] / 2)
+    """Two channels -> half the right plus half the left channel (float64, audioBasicIO.py:156-168);
+    a single column is flattened; anything else is returned untouched."""
+    data = np.asarray(signal)
+    if data.ndim != 2:
+        return signal
+    channels = data.shape[1]
+    if channels == 1:
+        return data.reshape(-1)
+    if channels == 2:
+        right, left = data[:, 1], data[:, 0]
+        return (right / 2) + (left / 2)
     return signal
