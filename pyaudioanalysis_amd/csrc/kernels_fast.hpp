@@ -40,6 +40,7 @@ struct TabLayout {
     int off_dct;                                           // 13 rows padded to 41 doubles
     int off_tw2, off_twp;                                  // double2 [16][16]: W400^(r p) and W800^(p + 25 q) of lane p
     int melN0, melN1, melN2, chN;                          // list lengths (multiples of 8)
+    int mel_clamp;                                         // 1: some padded list reaches past bin 399
     int total;                                             // bytes, multiple of 16
 };
 }  // namespace f800
@@ -302,7 +303,9 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
     const double mu = nm.mean * 32768.0;             // clip mean in counts (exact scaling)
     const int m_int = (int)fmin(fmax(nearbyint(mu), -40000.0), 40000.0);
     const double mag_scale = 0.5 * nm.inv * sc / (double)NF;       // 0.5: E and O carry a factor 1/2
-    const double dc_shift = 2.0 * (double)W * (mu - (double)m_int);
+    const double delta_mu = mu - (double)m_int;                    // |.| <= 1/2
+    const double dc_shift = 2.0 * (double)W * delta_mu;
+    const double y_scale2 = (nm.inv * sc) * (nm.inv * sc);         // y = (x' - delta) * inv / 2^15
     // integer sign thresholds: sign(x/2^15 - mean) = sign(x - mu)
     const int thr_pos = (int)fmin(fmax(floor(mu) + 1.0, -40000.0), 40000.0);   // x >= thr_pos  <=> positive
     const int thr_neg = (int)fmin(fmax(ceil(mu) - 1.0, -40000.0), 40000.0);    // x <= thr_neg  <=> negative
@@ -360,7 +363,10 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
             const int4 *p4 = reinterpret_cast<const int4 *>(raw + RAW_PAD + CHUNK * ch);
             const int prev = raw[RAW_PAD + CHUNK * ch - 1];
             int sprev = (prev >= thr_pos) - (prev <= thr_neg);
-            double e = 0.0;
+            // sum y^2 over the chunk = (inv/2^15)^2 * sum (x' - delta)^2 with x' = x - m_int an exact integer and
+            // |delta| = |mu - m_int| <= 1/2, so the expansion below has no cancellation to speak of
+            double e2 = 0.0;
+            int s1 = 0;
             int z = 0, zfirst = 0;
 #pragma unroll
             for (int v4 = 0; v4 < CHUNK / 8; ++v4) {
@@ -369,10 +375,11 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     const int xa = (int)(short)(w[h] & 0xffff), xb = w[h] >> 16;
-                    const double ya = fma((double)xa, sc, -nm.mean) * nm.inv;
-                    const double yb = fma((double)xb, sc, -nm.mean) * nm.inv;
-                    e = fma(ya, ya, e);
-                    e = fma(yb, yb, e);
+                    const int ca = xa - m_int, cb = xb - m_int;
+                    const double fa = (double)ca, fb = (double)cb;
+                    e2 = fma(fa, fa, e2);
+                    e2 = fma(fb, fb, e2);
+                    s1 += ca + cb;
                     const int sa = (xa >= thr_pos) - (xa <= thr_neg);
                     const int sb = (xb >= thr_pos) - (xb <= thr_neg);
                     const int da = abs(sa - sprev);
@@ -381,6 +388,7 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
                     sprev = sb;
                 }
             }
+            const double e = y_scale2 * fma(delta_mu, fma(-2.0, (double)s1, (double)CHUNK * delta_mu), e2);
             cE[ch] = e;
             cZ[ch] = z;
             cF[ch] = zfirst;
@@ -581,11 +589,11 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
             double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
             const int lo0 = t_melk0[i], lo1 = t_melk1[i], lo2 = t_melk2[i];
             // each trip issues its 16 LDS loads back to back (one wait), then runs two 4-long FMA chains
-#define PAA_MEL_CLASS(acc, lo, N, tw)                                                                   \
+#define PAA_MEL_CLASS(acc, lo, N, tw, IDX)                                                              \
             for (int n = 0; n < (N); n += 8) {                                                          \
                 double xv_[8], wv_[8];                                                                  \
                 _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                         \
-                    xv_[u] = cur[min((lo) + n + u, NF - 1)];                                            \
+                    xv_[u] = cur[IDX((lo) + n + u)];                                                    \
                     wv_[u] = (tw)[(n + u) * 16 + i];                                                    \
                 }                                                                                       \
                 double ea_ = 0.0, eb_ = 0.0;                                                            \
@@ -595,9 +603,19 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
                 }                                                                                       \
                 acc += ea_ + eb_;                                                                       \
             }
-            PAA_MEL_CLASS(acc0, lo0, L.melN0, t_melw0)
-            PAA_MEL_CLASS(acc1, lo1, L.melN1, t_melw1)
-            PAA_MEL_CLASS(acc2, lo2, L.melN2, t_melw2)
+#define PAA_IDX_CLAMP(k) min((k), NF - 1)
+#define PAA_IDX_PLAIN(k) (k)
+            if (L.mel_clamp) {
+                PAA_MEL_CLASS(acc0, lo0, L.melN0, t_melw0, PAA_IDX_CLAMP)
+                PAA_MEL_CLASS(acc1, lo1, L.melN1, t_melw1, PAA_IDX_CLAMP)
+                PAA_MEL_CLASS(acc2, lo2, L.melN2, t_melw2, PAA_IDX_CLAMP)
+            } else {        // the usual case: every padded list stays inside the 400 bins
+                PAA_MEL_CLASS(acc0, lo0, L.melN0, t_melw0, PAA_IDX_PLAIN)
+                PAA_MEL_CLASS(acc1, lo1, L.melN1, t_melw1, PAA_IDX_PLAIN)
+                PAA_MEL_CLASS(acc2, lo2, L.melN2, t_melw2, PAA_IDX_PLAIN)
+            }
+#undef PAA_IDX_CLAMP
+#undef PAA_IDX_PLAIN
 #undef PAA_MEL_CLASS
             acc2 += dpp_mov<0x128>(acc2);                    // row_ror:8
             mg[i] = fast_log10(acc0 + kEps);
@@ -704,6 +722,12 @@ inline int fast_select(int window, int step, int sample_kind, double fs, FastTab
     for (int m = 32; m < 40; ++m) c2 = std::max(c2, ((int)mel.cnt[m] + 1) / 2);
     for (int c = 0; c < 12; ++c) cc = std::max(cc, (int)(chroma.class_start[c + 1] - chroma.class_start[c]));
     L.melN0 = up4(c0); L.melN1 = up4(c1); L.melN2 = up4(c2); L.chN = up4(cc);
+    L.mel_clamp = 0;
+    for (int i = 0; i < 16; ++i) {
+        const int f2 = 32 + (i & 7), half = (mel.cnt[f2] + 1) / 2;
+        const int lo2 = mel.lo[f2] + ((i < 8) ? 0 : half);
+        if (mel.lo[i] + L.melN0 > f800::NF || mel.lo[16 + i] + L.melN1 > f800::NF || lo2 + L.melN2 > f800::NF) L.mel_clamp = 1;
+    }
     int off = 0;
     auto take = [&off](int bytes) { const int o = off; off += (bytes + 15) / 16 * 16; return o; };
     L.off_w0 = take(L.melN0 * 16 * 8); L.off_k0 = take(L.melN0 * 16 * 4);
