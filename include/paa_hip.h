@@ -131,6 +131,9 @@ int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *d_out);
 int64_t paa_plan_mid_doubles(const paa_plan_t *plan, int64_t mid_step_ratio);
 int paa_plan_mid_execute(paa_plan_t *plan, const double *d_st, int64_t mid_ratio,
                          int64_t mid_step_ratio, double *d_mid);
+/* MidTermFeatures.beat_extraction (MidTermFeatures.py:18-84) for every clip of an executed plan:
+ * d_beat receives [n_clips][2] = (bpm, confidence); window_size = short-term step in seconds          */
+int paa_plan_beat_execute(paa_plan_t *plan, const double *d_st, double window_size, double *d_beat);
 /* name of the feature kernel the plan dispatches ("st_fast_800", "st_generic", ...)          */
 const char *paa_plan_kernel_name(const paa_plan_t *plan);
 

@@ -172,6 +172,47 @@ def _list_audio(folder_path, types):
     return sorted(files)
 
 
+def mid_and_beat_batch(signals, sampling_rate, mid_window, mid_step, short_window, short_step,
+                       beat_window_seconds=None):
+    """Device-resident batch: int16 clips -> list of (136, M_c) mid-term matrices and, when beat_window_seconds
+    is given, an (n_clips, 2) array of (bpm, confidence) from the GPU beat kernel.  The short-term matrices
+    never leave HBM."""
+    ratio, step_ratio = _ratios(mid_window, mid_step, short_window, short_step)
+    if step_ratio < 1:
+        raise ValueError("mid_step / short_step rounds to 0: the reference never terminates")
+    window, step = int(short_window), int(short_step)
+    clips = [np.ascontiguousarray(s, dtype=np.int16) for s in signals]
+    lib = _ffi.lib()
+    lens = np.array([c.shape[0] for c in clips], dtype=np.int64)
+    if np.any(lens < window):
+        raise ValueError("need at least one array to concatenate")
+    offsets = np.zeros(len(clips) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    F = 68
+    T = (lens - window) // step + 1
+    M = -(-T // step_ratio)
+    d_in = _ffi.DeviceBuffer.from_host(np.concatenate(clips) if len(clips) > 1 else clips[0])
+    plan = _ffi.Plan(offsets, sampling_rate, window, step, deltas=True, sample_kind=0)
+    d_st = _ffi.DeviceBuffer(plan.out_doubles * 8)
+    plan.execute(d_in, d_st)
+    n_mid = plan.mid_doubles(step_ratio)
+    d_mid = _ffi.DeviceBuffer(n_mid * 8)
+    plan.mid_execute(d_st, ratio, step_ratio, d_mid)
+    beats = None
+    if beat_window_seconds is not None:
+        d_beat = _ffi.DeviceBuffer(len(clips) * 16)
+        plan.beat_execute(d_st, beat_window_seconds, d_beat)
+        beats = d_beat.to_host(np.float64, 2 * len(clips)).reshape(len(clips), 2)
+    flat = d_mid.to_host(np.float64, n_mid)
+    mids, pos = [], 0
+    for m in M:
+        cnt = 2 * F * int(m)
+        mids.append(flat[pos:pos + cnt].reshape(2 * F, int(m)))
+        pos += cnt
+    plan.destroy()
+    return mids, beats
+
+
 def _mid_for_files(entries, mid_window, mid_step, short_window, short_step, want_short):
     """entries: list of (sampling_rate, mono signal).  int16 clips that share a sampling rate go through ONE
     batched launch; float64 clips (stereo -> mono) take the single-clip float path.  Returns per-entry
@@ -187,13 +228,13 @@ def _mid_for_files(entries, mid_window, mid_step, short_window, short_step, want
                                                 round(fs * short_window), round(fs * short_step))
             out[idx] = (mid, st if want_short else None)
     for fs, members in groups.items():
-        res = mid_feature_extraction_batch([entries[i][1] for i in members], fs, round(mid_window * fs),
-                                           round(mid_step * fs), round(fs * short_window), round(fs * short_step),
-                                           return_short=want_short)
-        mids = res[0]
-        sts = res[1] if want_short else [None] * len(members)
-        for i, m, s in zip(members, mids, sts):
-            out[i] = (m, s)
+        # want_short here means "the caller needs the beat": computed on the GPU from the resident short-term
+        # matrix, returned in place of the matrix as a (bpm, confidence) pair
+        mids, beats = mid_and_beat_batch([entries[i][1] for i in members], fs, round(mid_window * fs),
+                                         round(mid_step * fs), round(fs * short_window), round(fs * short_step),
+                                         beat_window_seconds=short_step if want_short else None)
+        for k, i in enumerate(members):
+            out[i] = (mids[k], tuple(beats[k]) if want_short else None)
     return out, names
 
 
@@ -232,7 +273,8 @@ def directory_feature_extraction(folder_path, mid_window, mid_step, short_window
             vec = np.transpose(mid).mean(axis=0)                       # long-term averaging (:199-201)
             if (not np.isnan(vec).any()) and (not np.isinf(vec).any()):
                 if compute_beat:
-                    beat, beat_conf = beat_extraction(st, short_step)
+                    # int16 files: (bpm, confidence) straight from the GPU beat kernel; float files: host scan
+                    beat, beat_conf = st if isinstance(st, tuple) else beat_extraction(st, short_step)
                     vec = np.append(vec, beat)
                     vec = np.append(vec, beat_conf)
                     if not added_names:

@@ -68,6 +68,7 @@ _SIGNATURES = {
     "paa_plan_execute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "paa_plan_mid_doubles": (C.c_int64, [C.c_void_p, C.c_int64]),
     "paa_plan_mid_execute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "paa_plan_beat_execute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
     "paa_plan_kernel_name": (C.c_char_p, [C.c_void_p]),
     "paa_comm_unique_id": (C.c_int, [C.c_void_p]),
     "paa_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
@@ -241,6 +242,9 @@ class Plan:
 
     def mid_execute(self, d_st, mid_ratio, mid_step_ratio, d_mid):
         check(lib().paa_plan_mid_execute(self.handle, d_st.ptr, int(mid_ratio), int(mid_step_ratio), d_mid.ptr))
+
+    def beat_execute(self, d_st, window_size, d_beat):
+        check(lib().paa_plan_beat_execute(self.handle, d_st.ptr, float(window_size), d_beat.ptr))
 
     def destroy(self):
         if self.handle is not None:

@@ -163,4 +163,88 @@ __global__ __launch_bounds__(256) void mid_stats_kernel(const ClipDev *__restric
     }
 }
 
+
+// ---- beat extraction (MidTermFeatures.py:18-84 + utilities.peakdet, utilities.py:33-102), one wave per clip.
+// 18 short-term rows; per row: threshold = 2 mean|diff|, Billauer's peak detector (a sequential scan: lane r
+// scans row r from an LDS tile that all 64 lanes fill with coalesced loads), histogram of the gaps between
+// successive maxima; then the rows' histograms / T are added in row order, argmax -> (bpm, confidence).
+constexpr int kBeatRows = 18;
+constexpr int kBeatTile = 128;          // frames per LDS tile
+
+__global__ __launch_bounds__(64) void beat_kernel(const ClipDev *__restrict__ clips, const double *__restrict__ st,
+                                                   double window_size, int max_beat, double *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_beat[];
+    double *tile = reinterpret_cast<double *>(smem_beat);                         // [18][kBeatTile + 1]
+    int *hist = reinterpret_cast<int *>(tile + kBeatRows * (kBeatTile + 1));       // [18][max_beat]
+    const int rows[kBeatRows] = {0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18};
+    const ClipDev cd = clips[blockIdx.x];
+    const long long T = cd.T;
+    const double *base = st + cd.out_off;
+    const int lane = threadIdx.x;
+    for (int k = lane; k < kBeatRows * max_beat; k += 64) hist[k] = 0;
+
+    // pass 1: threshold of every row (coalesced sweeps, wave reductions)
+    double thr = 0.0;
+    for (int r = 0; r < kBeatRows; ++r) {
+        const double *x = base + (long long)rows[r] * T;
+        double s = 0.0;
+        for (long long t = lane; t + 1 < T; t += 64) s += fabs(x[t] - x[t + 1]);
+        s = wsum(s);
+        double d = 2.0 * (s / (double)(T - 1));                  // T == 1: 0/0 = NaN, like np.mean of an empty slice
+        if (d <= 0.0) d = 0.0000000000000001;
+        if (lane == r) thr = d;
+    }
+    // pass 2: sequential peak detection, lane r <-> row r
+    double lo = INFINITY, hi = -INFINITY;
+    long long hi_pos = 0, last_peak = -1;
+    bool seek_max = true;
+    wsync();
+    for (long long t0 = 0; t0 < T; t0 += kBeatTile) {
+        const int n = (int)min((long long)kBeatTile, T - t0);
+        for (int r = 0; r < kBeatRows; ++r) {
+            const double *x = base + (long long)rows[r] * T + t0;
+            for (int k = lane; k < n; k += 64) tile[r * (kBeatTile + 1) + k] = x[k];
+        }
+        wsync();
+        if (lane < kBeatRows) {
+            const double *v = tile + lane * (kBeatTile + 1);
+            for (int k = 0; k < n; ++k) {
+                const double cur = v[k];
+                if (cur > hi) { hi = cur; hi_pos = t0 + k; }
+                if (cur < lo) lo = cur;
+                if (seek_max) {
+                    if (cur < hi - thr) {
+                        if (last_peak >= 0) {
+                            const long long gap = hi_pos - last_peak;
+                            if (gap >= 1 && gap <= max_beat) hist[lane * max_beat + (int)gap - 1] += 1;
+                        }
+                        last_peak = hi_pos;
+                        lo = cur;
+                        seek_max = false;
+                    }
+                } else if (cur > lo + thr) {
+                    hi = cur;
+                    hi_pos = t0 + k;
+                    seek_max = true;
+                }
+            }
+        }
+        wsync();
+    }
+    // aggregate: hist_all[b] = sum over rows (in order) of count / T
+    double best = -1.0, total = 0.0;
+    int best_b = 0;
+    if (lane == 0) {
+        for (int b = 0; b < max_beat; ++b) {
+            double h = 0.0;
+            for (int r = 0; r < kBeatRows; ++r) h += (double)hist[r * max_beat + b] / (double)T;
+            total += h;
+            if (h > best) { best = h; best_b = b; }
+        }
+        const double center = (double)best_b + 1.0;              // edges k + 0.5 -> centers 1, 2, ...
+        out[2 * blockIdx.x] = 60.0 / (center * window_size);
+        out[2 * blockIdx.x + 1] = best / (total + 0.00000001);
+    }
+}
+
 }  // namespace paa

@@ -549,6 +549,23 @@ extern "C" int paa_plan_mid_execute(paa_plan_t *plan, const double *d_st, int64_
     return PAA_OK;
 }
 
+// beat rate of every clip of an executed plan (deltas on or off: rows 0..18 are used)
+extern "C" int paa_plan_beat_execute(paa_plan_t *plan, const double *d_st, double window_size, double *d_beat) {
+    if (!plan || !d_st || !d_beat) return fail(PAA_ERR_ARG, "null plan / buffer");
+    if (plan->mode != 0) return fail(PAA_ERR_ARG, "beat extraction needs a feature plan");
+    if (!(window_size > 0)) return fail(PAA_ERR_ARG, "window_size must be positive");
+    const int max_beat = (int)nearbyint(2.0 / window_size);          // int(round(2.0 / window_size)), :33
+    if (max_beat < 1 || max_beat > 4096) return fail(PAA_ERR_UNSUPPORTED, "beat histogram of %d bins", max_beat);
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t lds = (size_t)kBeatRows * (kBeatTile + 1) * 8 + (size_t)kBeatRows * max_beat * 4;
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&beat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(beat_kernel, dim3((unsigned)plan->n_clips), dim3(64), lds, g_stream, plan->d_clips, d_st,
+                       window_size, max_beat, d_beat);
+    HIP_TRY(hipGetLastError());
+    return PAA_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // library / device management
 // ------------------------------------------------------------------------------------------

@@ -59,3 +59,17 @@ def test_directory_feature_extraction_matches_reference(gpu_lib, tmp_path, capsy
     first = X[idx == 0]
     nbad, _ = O.mixed_tolerance_violations(first.mean(axis=0)[:, None], g["features_nobeat"][0][:, None])
     assert nbad == 0
+
+
+@pytest.mark.gpu
+def test_gpu_beat_kernel_equals_host_beat_extraction(gpu_lib):
+    """The beat kernel (one wave per clip) against the host restatement on the same GPU short-term features."""
+    from pyaudioanalysis_amd import ShortTermFeatures
+    from synth import synth_clip
+    clips = [synth_clip(60 + k, n) for k, n in enumerate([160000, 48000, 16000, 800, 20000])]
+    for ws, step in ((0.05, 800), (0.025, 400)):
+        mids, beats = MidTermFeatures.mid_and_beat_batch(clips, 16000, 16000, 16000, 800, step, beat_window_seconds=ws)
+        for c, b in zip(clips, beats):
+            st, _ = ShortTermFeatures.feature_extraction(c, 16000, 800, step)
+            bpm, ratio = MidTermFeatures.beat_extraction(st, ws)
+            assert np.allclose(b, [bpm, ratio], rtol=1e-9, atol=1e-12), (ws, len(c), b, bpm, ratio)

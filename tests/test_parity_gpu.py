@@ -167,12 +167,13 @@ def test_batch_equals_single_clips(gpu_lib):
         assert_parity(m, ref_mid, "batch mid")
 
 
-def test_size_independent_properties_at_scale(gpu_lib):
-    """A 10-minute clip (24k frames): checks that do not need the oracle to run that long."""
+@pytest.mark.parametrize("minutes", [10, 60])
+def test_size_independent_properties_at_scale(gpu_lib, minutes):
+    """A 10-minute and the full 1-hour clip of BASELINE config 2 (143 999 frames): checks that do not need the
+    oracle to run that long."""
     fs, W, S = 16000, 800, 400
-    rng = np.random.default_rng(9)
     base = synth_clip(9, 60 * fs)
-    x = np.tile(base, 10)
+    x = np.tile(base, minutes)
     F, _ = ShortTermFeatures.feature_extraction(x, fs, W, S)
     T = (len(x) - W) // S + 1
     assert F.shape == (68, T) and np.all(np.isfinite(F))
@@ -253,3 +254,24 @@ def test_concurrent_python_threads(gpu_lib):
         t.join()
     for e, g_ in zip(expect, got):
         assert np.array_equal(e, g_)
+
+
+def test_many_clip_batch_properties(gpu_lib):
+    """BASELINE config 3/4 shapes at reduced count: identical clips give identical slabs wherever they sit in the
+    batch (tiles never span clips, per-clip normalisation), and a clip's slab equals its single-clip result."""
+    fs = 16000
+    a, b = synth_clip(41, 10 * fs), synth_clip(42, 10 * fs)
+    clips = [a, b] * 150                                   # 300 x 10 s, like a shard of config 4
+    res, _ = ShortTermFeatures.feature_extraction_batch(clips, fs, 800, 400, deltas=False)
+    ra, _ = ShortTermFeatures.feature_extraction(a, fs, 800, 400, deltas=False)
+    rb, _ = ShortTermFeatures.feature_extraction(b, fs, 800, 400, deltas=False)
+    assert ra.shape == (34, 399)
+    for k, r in enumerate(res):
+        assert np.array_equal(r, ra if k % 2 == 0 else rb)
+    c30 = synth_clip(43, 30 * fs)
+    mids, _ = MidTermFeatures.mid_feature_extraction_batch([c30] * 40, fs, fs, fs, 800, 400)   # config 3 shape
+    ref_mid, _, _ = O.mid_feature_extraction(c30, fs, fs, fs, 800, 400)
+    assert mids[0].shape == (136, 30)
+    assert_parity(mids[0], ref_mid, "config 3 clip")
+    for m in mids[1:]:
+        assert np.array_equal(m, mids[0])
