@@ -41,6 +41,7 @@ struct TabLayout {
     int off_tw2, off_twp;                                  // double2 [16][16]: W400^(r p) and W800^(p + 25 q) of lane p
     int melN0, melN1, melN2, chN;                          // list lengths (multiples of 8)
     int mel_clamp;                                         // 1: some padded list reaches past bin 399
+    int fixed_lists;                                       // 1: lengths are exactly 8/16/16/8 without clamping
     int total;                                             // bytes, multiple of 16
 };
 }  // namespace f800
@@ -240,7 +241,10 @@ __device__ unsigned long long g_phase_cycles[16];
 #define PAA_TEND()
 #endif
 
-template <int S, int DELTAS>
+// FIXED = 1: the mel / chroma list lengths are the compile-time constants of the usual 16 kHz tables (8, 16, 16, 8,
+// no clamping), which turns the whole feature stage into straight-line code the scheduler can interleave;
+// FIXED = 0: run-time lengths from the layout (other sampling rates).
+template <int S, int DELTAS, int FIXED>
 __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fast_800_kernel(PlanDev P, TabLayout L,
                                                                      const unsigned char *__restrict__ blob,
                                                                      const int16_t *__restrict__ sig,
@@ -590,7 +594,7 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
             const int lo0 = t_melk0[i], lo1 = t_melk1[i], lo2 = t_melk2[i];
             // each trip issues its 16 LDS loads back to back (one wait), then runs two 4-long FMA chains
 #define PAA_MEL_CLASS(acc, lo, N, tw, IDX)                                                              \
-            for (int n = 0; n < (N); n += 8) {                                                          \
+            _Pragma("unroll") for (int n = 0; n < (N); n += 8) {                                        \
                 double xv_[8], wv_[8];                                                                  \
                 _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                         \
                     xv_[u] = cur[IDX((lo) + n + u)];                                                    \
@@ -605,11 +609,15 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
             }
 #define PAA_IDX_CLAMP(k) min((k), NF - 1)
 #define PAA_IDX_PLAIN(k) (k)
-            if (L.mel_clamp) {
+            if (FIXED) {
+                PAA_MEL_CLASS(acc0, lo0, 8, t_melw0, PAA_IDX_PLAIN)
+                PAA_MEL_CLASS(acc1, lo1, 16, t_melw1, PAA_IDX_PLAIN)
+                PAA_MEL_CLASS(acc2, lo2, 16, t_melw2, PAA_IDX_PLAIN)
+            } else if (L.mel_clamp) {
                 PAA_MEL_CLASS(acc0, lo0, L.melN0, t_melw0, PAA_IDX_CLAMP)
                 PAA_MEL_CLASS(acc1, lo1, L.melN1, t_melw1, PAA_IDX_CLAMP)
                 PAA_MEL_CLASS(acc2, lo2, L.melN2, t_melw2, PAA_IDX_CLAMP)
-            } else {        // the usual case: every padded list stays inside the 400 bins
+            } else {        // every padded list stays inside the 400 bins
                 PAA_MEL_CLASS(acc0, lo0, L.melN0, t_melw0, PAA_IDX_PLAIN)
                 PAA_MEL_CLASS(acc1, lo1, L.melN1, t_melw1, PAA_IDX_PLAIN)
                 PAA_MEL_CLASS(acc2, lo2, L.melN2, t_melw2, PAA_IDX_PLAIN)
@@ -627,7 +635,9 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
         // chroma (:277-321): lane i < 12 = pitch class i, padded gather list in ascending slot order
         double chroma = 0.0;
         {
-            for (int n = 0; n < L.chN; n += 8) {
+            const int ch_len = FIXED ? 8 : L.chN;
+#pragma unroll
+            for (int n = 0; n < ch_len; n += 8) {
                 int kv[8];
                 double wv[8], xv[8];
 #pragma unroll
@@ -728,6 +738,7 @@ inline int fast_select(int window, int step, int sample_kind, double fs, FastTab
         const int lo2 = mel.lo[f2] + ((i < 8) ? 0 : half);
         if (mel.lo[i] + L.melN0 > f800::NF || mel.lo[16 + i] + L.melN1 > f800::NF || lo2 + L.melN2 > f800::NF) L.mel_clamp = 1;
     }
+    L.fixed_lists = (L.melN0 == 8 && L.melN1 == 16 && L.melN2 == 16 && L.chN == 8 && !L.mel_clamp) ? 1 : 0;
     int off = 0;
     auto take = [&off](int bytes) { const int o = off; off += (bytes + 15) / 16 * 16; return o; };
     L.off_w0 = take(L.melN0 * 16 * 8); L.off_k0 = take(L.melN0 * 16 * 4);
@@ -779,20 +790,31 @@ inline int fast_select(int window, int step, int sample_kind, double fs, FastTab
     return 1;
 }
 
-template <int S, int DELTAS>
+template <int S, int DELTAS, int FIXED>
 inline int fast_launch_one(const FastLaunch &fl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                            const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,
                            double *d_out, hipStream_t stream) {
     static size_t attr_done = 0;
     if (attr_done < fl.lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&f800::st_fast_800_kernel<S, DELTAS>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&f800::st_fast_800_kernel<S, DELTAS, FIXED>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl.lds) != hipSuccess) return -1;
         attr_done = fl.lds;
     }
     const unsigned grid = (unsigned)((n_tiles + f800::WAVES - 1) / f800::WAVES);
-    hipLaunchKernelGGL((f800::st_fast_800_kernel<S, DELTAS>), dim3(grid), dim3(64 * f800::WAVES), fl.lds, stream, P,
-                       fl.layout, blob, (const int16_t *)d_packed, clips, norms, tiles, (int)n_tiles, d_out);
+    hipLaunchKernelGGL((f800::st_fast_800_kernel<S, DELTAS, FIXED>), dim3(grid), dim3(64 * f800::WAVES), fl.lds, stream,
+                       P, fl.layout, blob, (const int16_t *)d_packed, clips, norms, tiles, (int)n_tiles, d_out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <int S>
+inline int fast_launch_step(const FastLaunch &fl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
+                            const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,
+                            double *d_out, hipStream_t stream) {
+    if (fl.layout.fixed_lists)
+        return P.deltas ? fast_launch_one<S, 1, 1>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream)
+                        : fast_launch_one<S, 0, 1>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+    return P.deltas ? fast_launch_one<S, 1, 0>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream)
+                    : fast_launch_one<S, 0, 0>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
 }
 
 inline int fast_launch(const FastLaunch &fl, const PlanDev &P, const FastTables &ft, const void *d_packed,
@@ -800,12 +822,8 @@ inline int fast_launch(const FastLaunch &fl, const PlanDev &P, const FastTables 
                        double *d_out, hipStream_t stream) {
     if (!ft.d_blob) return -1;
     const unsigned char *blob = reinterpret_cast<const unsigned char *>(ft.d_blob);
-    if (fl.variant == 800)
-        return P.deltas ? fast_launch_one<400, 1>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream)
-                        : fast_launch_one<400, 0>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
-    if (fl.variant == 1600)
-        return P.deltas ? fast_launch_one<800, 1>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream)
-                        : fast_launch_one<800, 0>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+    if (fl.variant == 800) return fast_launch_step<400>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+    if (fl.variant == 1600) return fast_launch_step<800>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
     return -1;
 }
 

@@ -90,6 +90,10 @@ def test_spectrogram_chromagram_golden(gpu_lib, path, capsys):
     (22050, 1103, 441, 1.0),      # prime-ish odd window -> generic radix pass
     (44100, 1102, 441, 1.0),      # config 5 (2 * 19 * 29)
     (8000, 400, 200, 1.5),
+    (8000, 800, 400, 2.0),        # fast kernel, run-time mel list lengths (wider filters in bins)
+    (7000, 800, 400, 2.0),        # fast kernel, padded mel lists reach the last bins (clamped index path)
+    (44100, 800, 400, 1.0),       # fast kernel at another sampling rate
+    (22050, 800, 800, 1.0),       # fast kernel, step 800
     (48000, 2400, 1200, 1.0),
 ])
 def test_oracle_parity_seeded(gpu_lib, fs, window, step, seconds):
