@@ -84,6 +84,14 @@ int paa_st_features_i16(const int16_t *signal, int64_t n, double fs, int window,
 int paa_st_features_f64(const double *signal, int64_t n, double fs, int window, int step,
                         int deltas, double *out);
 
+/* interleaved stereo int16 (L0 R0 L1 R1 ..., n frames): audioBasicIO.stereo_to_mono (audioBasicIO.py:156-168) is
+ * fused on the device as exact int32 sums L + R, so stereo files cost 4 B/sample over PCIe instead of the 8 B of
+ * the float64 mono copy the reference makes on the host                                                  */
+int paa_st_features_stereo_i16(const int16_t *interleaved, int64_t n, double fs, int window, int step,
+                               int deltas, double *out);
+int paa_mid_features_stereo_i16(const int16_t *interleaved, int64_t n, double fs, int window, int step,
+                                int64_t mid_ratio, int64_t mid_step_ratio, double *mid_out, double *st_out);
+
 /* ---- MidTermFeatures.mid_feature_extraction (MidTermFeatures.py:87-127) ----------------- */
 /* mid_ratio / mid_step_ratio are computed by the caller with Python round() (:100-102).
  * st_out: [68][T] (deltas always on, :93-95), may be NULL; mid_out: [136][M].               */
@@ -116,7 +124,7 @@ int paa_mid_features_batch_i16(const int16_t *packed, const int64_t *offsets, in
 /* ---- device-resident plans (bench / pipelines: samples and results stay in HBM) --------- */
 typedef struct paa_plan paa_plan_t;
 /* offsets: n_clips+1 HOST sample offsets into the packed device buffer.  sample_kind 0 = int16,
- * 1 = float64.  The plan owns the tables, the tile list and the per-clip statistics.        */
+ * 1 = float64, 2 = int32 stereo sums L + R (scaled by 2^-16).  The plan owns the tables, the tile list and the per-clip statistics.        */
 int paa_plan_create(const int64_t *offsets, int64_t n_clips, int sample_kind, double fs,
                     int window, int step, int deltas, paa_plan_t **out_plan);
 int paa_plan_destroy(paa_plan_t *plan);

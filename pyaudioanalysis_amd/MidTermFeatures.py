@@ -53,6 +53,9 @@ def mid_feature_extraction(signal, sampling_rate, mid_window, mid_step, short_wi
     if kind == 0:
         rc = lib.paa_mid_features_i16(_ffi.as_i16p(sig), sig.shape[0], float(sampling_rate), window, step,
                                       ratio, step_ratio, _ffi.as_f64p(mid), _ffi.as_f64p(st))
+    elif kind == 2:
+        rc = lib.paa_mid_features_stereo_i16(_ffi.as_i16p(sig), sig.shape[0], float(sampling_rate), window, step,
+                                             ratio, step_ratio, _ffi.as_f64p(mid), _ffi.as_f64p(st))
     else:
         rc = lib.paa_mid_features_f64(_ffi.as_f64p(sig), sig.shape[0], float(sampling_rate), window, step,
                                       ratio, step_ratio, _ffi.as_f64p(mid), _ffi.as_f64p(st))
@@ -256,7 +259,8 @@ def directory_feature_extraction(folder_path, mid_window, mid_step, short_window
         sampling_rate, signal = audioBasicIO.read_audio_file(file_path)
         if sampling_rate <= 0:
             continue
-        signal = audioBasicIO.stereo_to_mono(signal)
+        if not (signal.ndim == 2 and signal.shape[1] == 2 and signal.dtype == np.int16):
+            signal = audioBasicIO.stereo_to_mono(signal)      # int16 stereo is reduced to mono on the device
         if signal.shape[0] < float(sampling_rate) / 5:
             print("  (AUDIO FILE TOO SMALL - SKIPPING)")
             continue

@@ -34,7 +34,9 @@ def feature_extraction(signal, sampling_rate, window, step, deltas=True):
     """Short-term windowing and feature extraction (reference :543-685).
 
     ARGUMENTS
-        signal:         the input signal samples (1-D; int16 PCM or anything np.double() accepts)
+        signal:         the input signal samples (1-D; int16 PCM or anything np.double() accepts; an (n, 2)
+                        int16 array is taken as stereo and reduced to mono on the device like
+                        audioBasicIO.stereo_to_mono)
         sampling_rate:  the sampling freq (in Hz)
         window:         the short-term window size (in samples; floats are int()-truncated, :563)
         step:           the short-term window step (in samples)
@@ -56,6 +58,9 @@ def feature_extraction(signal, sampling_rate, window, step, deltas=True):
     if kind == 0:
         rc = lib.paa_st_features_i16(_ffi.as_i16p(sig), sig.shape[0], float(sampling_rate), window, step,
                                      1 if deltas else 0, _ffi.as_f64p(out))
+    elif kind == 2:       # (n, 2) int16: stereo_to_mono fused on the device
+        rc = lib.paa_st_features_stereo_i16(_ffi.as_i16p(sig), sig.shape[0], float(sampling_rate), window, step,
+                                            1 if deltas else 0, _ffi.as_f64p(out))
     else:
         rc = lib.paa_st_features_f64(_ffi.as_f64p(sig), sig.shape[0], float(sampling_rate), window, step,
                                      1 if deltas else 0, _ffi.as_f64p(out))

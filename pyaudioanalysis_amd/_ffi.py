@@ -47,6 +47,9 @@ _SIGNATURES = {
     "paa_chromagram_rows": (C.c_int64, [C.c_int64, C.c_int, C.c_int, c_i64p]),
     "paa_st_features_i16": (C.c_int, [c_i16p, C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int, c_f64p]),
     "paa_st_features_f64": (C.c_int, [c_f64p, C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int, c_f64p]),
+    "paa_st_features_stereo_i16": (C.c_int, [c_i16p, C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int, c_f64p]),
+    "paa_mid_features_stereo_i16": (C.c_int, [c_i16p, C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                              c_f64p, c_f64p]),
     "paa_mid_features_i16": (C.c_int, [c_i16p, C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                        c_f64p, c_f64p]),
     "paa_mid_features_f64": (C.c_int, [c_f64p, C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int64, C.c_int64,
@@ -171,6 +174,10 @@ def classify_signal(signal):
     int16 (2 B/sample over PCIe and HBM), every other dtype goes through the same np.double().
     """
     a = np.asarray(signal)
+    if a.ndim == 2 and a.shape[1] == 2 and a.dtype == np.int16:
+        # extension over the reference (which needs stereo_to_mono first): interleaved stereo int16 goes to the
+        # device as is and is summed there (kind 2)
+        return 2, np.ascontiguousarray(a)
     if a.ndim != 1:
         a = a.reshape(-1) if a.ndim == 0 else a
         if a.ndim != 1:

@@ -246,5 +246,10 @@ __device__ __forceinline__ double wscan_incl(double v) {
 template <typename T> __device__ __forceinline__ double load_sample(const T *p);
 template <> __device__ __forceinline__ double load_sample<int16_t>(const int16_t *p) { return (double)(*p); }
 template <> __device__ __forceinline__ double load_sample<double>(const double *p) { return *p; }
+// int32 samples are the SUMS L + R of a stereo int16 pair (fused stereo_to_mono, audioBasicIO.py:156-168):
+// mono = L/2 + R/2 exactly, so x / 2^15 = (L + R) / 2^16
+template <> __device__ __forceinline__ double load_sample<int>(const int *p) { return (double)(*p); }
+template <typename T> __host__ __device__ constexpr double sample_scale() { return 1.0 / 32768.0; }
+template <> __host__ __device__ constexpr double sample_scale<int>() { return 1.0 / 65536.0; }
 
 }  // namespace paa

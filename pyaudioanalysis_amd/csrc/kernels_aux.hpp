@@ -60,6 +60,56 @@ __global__ __launch_bounds__(256) void clip_stats_i16_kernel(const int16_t *__re
     }
 }
 
+// int32 samples (stereo sums L + R): same reduction, sums still exact in int64
+__global__ __launch_bounds__(256) void clip_stats_i32_kernel(const int *__restrict__ sig,
+                                                              const StatChunk *__restrict__ chunks,
+                                                              long long *__restrict__ psum,
+                                                              int *__restrict__ pmin, int *__restrict__ pmax) {
+    const StatChunk ch = chunks[blockIdx.x];
+    const int tid = threadIdx.x;
+    long long s = 0;
+    int mn = 0x7fffffff, mx = -0x7fffffff - 1;
+    for (long long i = ch.start + tid; i < ch.start + ch.len; i += 256) {
+        const int v = sig[i];
+        s += v; mn = min(mn, v); mx = max(mx, v);
+    }
+    __shared__ long long ss[4];
+    __shared__ int smn[4], smx[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        mn = min(mn, __shfl_xor(mn, o, 64));
+        mx = max(mx, __shfl_xor(mx, o, 64));
+    }
+    if ((tid & 63) == 0) { ss[tid >> 6] = s; smn[tid >> 6] = mn; smx[tid >> 6] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+        psum[blockIdx.x] = ss[0] + ss[1] + ss[2] + ss[3];
+        pmin[blockIdx.x] = min(min(smn[0], smn[1]), min(smn[2], smn[3]));
+        pmax[blockIdx.x] = max(max(smx[0], smx[1]), max(smx[2], smx[3]));
+    }
+}
+
+// interleaved stereo int16 (L0 R0 L1 R1 ...) -> int32 sums L + R: the device half of stereo_to_mono
+// (audioBasicIO.py:156-168); 16 bytes in, 16 bytes out per thread-iteration
+__global__ __launch_bounds__(256) void stereo_sum_kernel(const int16_t *__restrict__ lr, long long n_frames,
+                                                          int *__restrict__ sums) {
+    const long long nvec = n_frames >> 2;
+    const int4 *in4 = reinterpret_cast<const int4 *>(lr);
+    int4 *out4 = reinterpret_cast<int4 *>(sums);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const int4 q = in4[i];
+        int4 r;
+        r.x = (int)(short)(q.x & 0xffff) + (q.x >> 16);
+        r.y = (int)(short)(q.y & 0xffff) + (q.y >> 16);
+        r.z = (int)(short)(q.z & 0xffff) + (q.z >> 16);
+        r.w = (int)(short)(q.w & 0xffff) + (q.w >> 16);
+        out4[i] = r;
+    }
+    if (blockIdx.x == 0)
+        for (long long i = (nvec << 2) + threadIdx.x; i < n_frames; i += 256) sums[i] = (int)lr[2 * i] + (int)lr[2 * i + 1];
+}
+
 __global__ __launch_bounds__(256) void clip_stats_f64_kernel(const double *__restrict__ sig,
                                                               const StatChunk *__restrict__ chunks,
                                                               double *__restrict__ psum,
@@ -92,7 +142,8 @@ __global__ __launch_bounds__(256) void clip_stats_f64_kernel(const double *__res
 template <typename SumT, typename MmT>
 __global__ __launch_bounds__(64) void clip_params_kernel(const ClipDev *__restrict__ clips, long long n_clips,
                                                           const SumT *__restrict__ psum, const MmT *__restrict__ pmin,
-                                                          const MmT *__restrict__ pmax, ClipNorm *__restrict__ norms) {
+                                                          const MmT *__restrict__ pmax, double sc,
+                                                          ClipNorm *__restrict__ norms) {
     const long long c = blockIdx.x;
     if (c >= n_clips) return;
     const ClipDev cd = clips[c];
@@ -110,7 +161,6 @@ __global__ __launch_bounds__(64) void clip_params_kernel(const ClipDev *__restri
         mx = fmax(mx, __shfl_xor(mx, o, 64));
     }
     if (threadIdx.x != 0) return;
-    const double sc = 1.0 / 32768.0;
     ClipNorm nm;
     if (cd.n <= 0) { nm.mean = 0.0; nm.inv = 1.0; norms[c] = nm; return; }
     nm.mean = ((double)s * sc) / (double)cd.n;

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void big_load_kernel(PlanDev P, const T *__res
     const long long f = blockIdx.y;
     const T *x = x0 + (t_first + f) * (long long)P.S;
     double2 *dst = bufA + f * (long long)P.Nc;
-    const double sc = 1.0 / 32768.0;
+    const double sc = sample_scale<T>();
     for (int n = blockIdx.x * 256 + threadIdx.x; n < P.W; n += gridDim.x * 256) {
         const double y = fma(load_sample<T>(x + n), sc, -nm.mean) * nm.inv;
         if (P.even) reinterpret_cast<double *>(dst)[n] = y;

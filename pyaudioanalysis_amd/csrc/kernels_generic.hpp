@@ -168,7 +168,7 @@ __device__ __forceinline__ void frame_fft(const PlanDev &P, const Tabs &tb, doub
 template <typename T>
 __device__ __forceinline__ void frame_load(const PlanDev &P, const T *__restrict__ x, ClipNorm nm, double2 *bufA,
                                            int lane) {
-    const double sc = 1.0 / 32768.0;
+    const double sc = sample_scale<T>();
     if (P.even) {
         double *y = reinterpret_cast<double *>(bufA);
         for (int n = lane; n < P.W; n += kWave) y[n] = fma(load_sample<T>(x + n), sc, -nm.mean) * nm.inv;

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void chroma_tail_kernel(PlanDev P, const T *__
     const int L = (int)(n_total - pos);
     const ClipNorm nm = norms[0];
     const T *x = sig + pos;
-    const double sc = 1.0 / 32768.0;
+    const double sc = sample_scale<T>();
     double p = 0.0;
     for (int k = threadIdx.x; k < P.Nf; k += 256) {
         double re = 0.0, im = 0.0;

@@ -74,7 +74,7 @@ static int g_device = -1;
 static hipStream_t g_stream = nullptr;
 static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 static std::map<std::pair<double, int>, std::unique_ptr<TableSet>> g_tables;
-static Scratch g_in, g_out, g_mid;
+static Scratch g_in, g_in2, g_out, g_mid;
 static int g_force_generic = 0;
 // optional per-launch timing of the feature kernel (bench.py's roofline leg)
 static int g_prof = 0;
@@ -208,7 +208,8 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     if (rc) return rc;
     if (!offsets || n_clips < 1 || !out) return fail(PAA_ERR_ARG, "null offsets / no clips");
     if (window < 2 || step < 1) return fail(PAA_ERR_ARG, "window=%d step=%d: need window >= 2, step >= 1", window, step);
-    if (sample_kind != 0 && sample_kind != 1) return fail(PAA_ERR_ARG, "sample_kind must be 0 (int16) or 1 (float64)");
+    if (sample_kind < 0 || sample_kind > 2)
+        return fail(PAA_ERR_ARG, "sample_kind must be 0 (int16), 1 (float64) or 2 (int32 stereo sums)");
     if (!(fs > 0)) return fail(PAA_ERR_ARG, "sampling rate must be positive");
     std::unique_ptr<paa_plan, void (*)(paa_plan *)> p(new paa_plan(), plan_free);
     p->n_clips = n_clips;
@@ -354,20 +355,24 @@ static int launch_stats(paa_plan *p, const void *d_packed) {
             hipLaunchKernelGGL(clip_stats_i16_kernel, dim3((unsigned)p->n_chunks), dim3(256), 0, g_stream,
                                (const int16_t *)d_packed, p->d_chunks, (long long *)p->d_psum, (int *)p->d_pmin,
                                (int *)p->d_pmax);
+        else if (p->sample_kind == 2)
+            hipLaunchKernelGGL(clip_stats_i32_kernel, dim3((unsigned)p->n_chunks), dim3(256), 0, g_stream,
+                               (const int *)d_packed, p->d_chunks, (long long *)p->d_psum, (int *)p->d_pmin,
+                               (int *)p->d_pmax);
         else
             hipLaunchKernelGGL(clip_stats_f64_kernel, dim3((unsigned)p->n_chunks), dim3(256), 0, g_stream,
                                (const double *)d_packed, p->d_chunks, (double *)p->d_psum, (double *)p->d_pmin,
                                (double *)p->d_pmax);
     }
     const unsigned gb = (unsigned)p->n_clips;
-    if (p->sample_kind == 0)
-        hipLaunchKernelGGL((clip_params_kernel<long long, int>), dim3(gb), dim3(64), 0, g_stream, p->d_clips,
-                           p->n_clips, (const long long *)p->d_psum, (const int *)p->d_pmin, (const int *)p->d_pmax,
-                           p->d_norms);
-    else
+    if (p->sample_kind == 1)
         hipLaunchKernelGGL((clip_params_kernel<double, double>), dim3(gb), dim3(64), 0, g_stream, p->d_clips,
                            p->n_clips, (const double *)p->d_psum, (const double *)p->d_pmin,
-                           (const double *)p->d_pmax, p->d_norms);
+                           (const double *)p->d_pmax, sample_scale<double>(), p->d_norms);
+    else
+        hipLaunchKernelGGL((clip_params_kernel<long long, int>), dim3(gb), dim3(64), 0, g_stream, p->d_clips,
+                           p->n_clips, (const long long *)p->d_psum, (const int *)p->d_pmin, (const int *)p->d_pmax,
+                           p->sample_kind == 2 ? sample_scale<int>() : sample_scale<int16_t>(), p->d_norms);
     HIP_TRY(hipGetLastError());
     return PAA_OK;
 }
@@ -457,7 +462,8 @@ extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *
     rc = launch_stats(plan, d_packed);
     if (rc) return rc;
     if (plan->big)
-        return plan->sample_kind == 0 ? run_big<int16_t>(plan, d_packed, d_out) : run_big<double>(plan, d_packed, d_out);
+        return plan->sample_kind == 0 ? run_big<int16_t>(plan, d_packed, d_out)
+             : plan->sample_kind == 2 ? run_big<int>(plan, d_packed, d_out) : run_big<double>(plan, d_packed, d_out);
     if (plan->n_tiles == 0) return PAA_OK;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (g_prof) {
@@ -481,6 +487,7 @@ extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *
         return PAA_OK;
     }
     return plan->sample_kind == 0 ? launch_generic<int16_t>(plan, d_packed, d_out)
+         : plan->sample_kind == 2 ? launch_generic<int>(plan, d_packed, d_out)
                                   : launch_generic<double>(plan, d_packed, d_out);
 }
 
@@ -602,7 +609,7 @@ extern "C" void paa_shutdown(void) {
     if (g_stream) (void)hipStreamSynchronize(g_stream);
     for (auto &kv : g_tables) free_tables(*kv.second);
     g_tables.clear();
-    for (Scratch *s : {&g_in, &g_out, &g_mid}) { if (s->p) (void)hipFree(s->p); s->p = nullptr; s->cap = 0; }
+    for (Scratch *s : {&g_in, &g_in2, &g_out, &g_mid}) { if (s->p) (void)hipFree(s->p); s->p = nullptr; s->cap = 0; }
     if (g_ev0) (void)hipEventDestroy(g_ev0);
     if (g_ev1) (void)hipEventDestroy(g_ev1);
     if (g_stream) (void)hipStreamDestroy(g_stream);
@@ -736,7 +743,9 @@ static int run_host_st(const void *packed, const int64_t *offsets, int64_t n_cli
     }
     if (rc) return rc;
     std::unique_ptr<paa_plan, void (*)(paa_plan *)> guard(plan, plan_free);
-    const size_t esz = sample_kind == 0 ? 2 : 8;
+    // sample_kind 2: the host buffer holds interleaved stereo int16 (4 bytes per frame); the device turns it
+    // into int32 sums L + R before anything else (fused stereo_to_mono)
+    const size_t esz = sample_kind == 0 ? 2 : (sample_kind == 2 ? 4 : 8);
     const long long base = offsets[0], n_total = offsets[n_clips] - base;
     // samples are uploaded from offsets[0]; rebase the clip offsets accordingly
     if (base != 0) {
@@ -760,7 +769,19 @@ static int run_host_st(const void *packed, const int64_t *offsets, int64_t n_cli
     }
     HIP_TRY(hipMemcpyAsync(g_in.p, (const char *)packed + (size_t)base * esz, (size_t)n_total * esz,
                            hipMemcpyHostToDevice, g_stream));
-    if ((rc = paa_plan_execute(plan, g_in.p, (double *)g_out.p))) return rc;
+    const void *d_samples = g_in.p;
+    if (sample_kind == 2) {
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            if ((rc = scratch_reserve(g_in2, (size_t)n_total * 4 + 64))) return rc;
+        }
+        const unsigned gs = (unsigned)std::min<long long>(4096, (n_total / 4 + 255) / 256 + 1);
+        hipLaunchKernelGGL(stereo_sum_kernel, dim3(gs), dim3(256), 0, g_stream, (const int16_t *)g_in.p, n_total,
+                           (int *)g_in2.p);
+        HIP_TRY(hipGetLastError());
+        d_samples = g_in2.p;
+    }
+    if ((rc = paa_plan_execute(plan, d_samples, (double *)g_out.p))) return rc;
     if (want_mid) {
         const long long md = paa_plan_mid_doubles(plan, mid_step);
         {
@@ -811,6 +832,18 @@ extern "C" int paa_st_features_f64(const double *signal, int64_t n, double fs, i
     if (!out) return fail(PAA_ERR_ARG, "null out");
     const int64_t off[2] = {0, n};
     return run_host_st(signal, off, 1, 1, fs, window, step, deltas, out, nullptr, 0, 0, nullptr, nullptr);
+}
+extern "C" int paa_st_features_stereo_i16(const int16_t *interleaved, int64_t n, double fs, int window, int step,
+                                          int deltas, double *out) {
+    if (!out) return fail(PAA_ERR_ARG, "null out");
+    const int64_t off[2] = {0, n};
+    return run_host_st(interleaved, off, 1, 2, fs, window, step, deltas, out, nullptr, 0, 0, nullptr, nullptr);
+}
+extern "C" int paa_mid_features_stereo_i16(const int16_t *interleaved, int64_t n, double fs, int window, int step,
+                                           int64_t mid_ratio, int64_t mid_step_ratio, double *mid_out, double *st_out) {
+    if (!mid_out) return fail(PAA_ERR_ARG, "null mid_out");
+    const int64_t off[2] = {0, n};
+    return run_host_st(interleaved, off, 1, 2, fs, window, step, 1, st_out, nullptr, mid_ratio, mid_step_ratio, mid_out, nullptr);
 }
 extern "C" int paa_mid_features_i16(const int16_t *signal, int64_t n, double fs, int window, int step,
                                     int64_t mid_ratio, int64_t mid_step_ratio, double *mid_out, double *st_out) {

@@ -3,6 +3,8 @@
 Tolerance (north_star: 1e-4 relative): |d| <= 1e-4*|ref| + 1e-6*max|ref_row| + 1e-9, see
 paa_oracle.mixed_tolerance_violations.  Roll-off and ZCR are integer-valued outcomes of floating
 comparisons: a vanishing fraction of frames (<= 1e-3 here, none observed) may differ by one bin."""
+import os
+
 import numpy as np
 import pytest
 
@@ -279,3 +281,19 @@ def test_many_clip_batch_properties(gpu_lib):
     assert_parity(mids[0], ref_mid, "config 3 clip")
     for m in mids[1:]:
         assert np.array_equal(m, mids[0])
+
+
+def test_fused_stereo_to_mono(gpu_lib):
+    """(n, 2) int16 input: L + R summed on the device == audioBasicIO.stereo_to_mono on the host, bit for bit in
+    the samples, so the features equal the float64 mono path and the reference golden."""
+    g = load_golden([p for p in golden_files("stereo")][0])
+    st = load_golden(os.path.join(os.path.dirname(golden_files("stereo")[0]), "synth5_stereo_1102_441.npz"))
+    fused, _ = ShortTermFeatures.feature_extraction(g["stereo"], 44100, 1102, 441)
+    assert_parity(fused, st["features"], "fused stereo vs reference")
+    mono_path, _ = ShortTermFeatures.feature_extraction(g["mono"], 44100, 1102, 441)
+    assert np.allclose(fused, mono_path, rtol=1e-12, atol=1e-13)
+    xs = synth_clip(88, 3 * 16000 + 3, stereo=True)                 # odd length: scalar tail of the sum kernel
+    ref_mid, ref_st, _ = O.mid_feature_extraction(O.stereo_to_mono(xs), 16000, 16000, 16000, 800, 400)
+    mid, st2, _ = MidTermFeatures.mid_feature_extraction(xs, 16000, 16000, 16000, 800, 400)
+    assert_parity(st2, ref_st, "fused stereo short")
+    assert_parity(mid, ref_mid, "fused stereo mid")
