@@ -30,6 +30,16 @@ def _feature_names(deltas=True):
     return names
 
 
+def _mono_only(signal):
+    """spectrogram / chromagram have no fused stereo entry point: an (n, 2) int16 array is reduced to mono on
+    the host exactly like audioBasicIO.stereo_to_mono (float64) and takes the float64 path."""
+    kind, sig = _ffi.classify_signal(signal)
+    if kind == 2:
+        sig = np.ascontiguousarray((sig[:, 1] / 2) + (sig[:, 0] / 2))
+        kind = 1
+    return kind, sig
+
+
 def feature_extraction(signal, sampling_rate, window, step, deltas=True):
     """Short-term windowing and feature extraction (reference :543-685).
 
@@ -106,7 +116,7 @@ def spectrogram(signal, sampling_rate, window, step, plot=False, show_progress=F
     """
     window = int(window)
     step = int(step)
-    kind, sig = _ffi.classify_signal(signal)
+    kind, sig = _mono_only(signal)
     lib = _ffi.lib()
     num_fft = int(window / 2)
     rows = int(lib.paa_spectrogram_rows(sig.shape[0], window, step, None)) if window >= 1 and step >= 1 else 0
@@ -128,7 +138,7 @@ def chromagram(signal, sampling_rate, window, step, plot=False, show_progress=Fa
     """Chromagram (reference :324-386).  Returns (chromogram [T x 12], time_axis, freq_axis)."""
     window = int(window)
     step = int(step)
-    kind, sig = _ffi.classify_signal(signal)
+    kind, sig = _mono_only(signal)
     lib = _ffi.lib()
     rows = int(lib.paa_chromagram_rows(sig.shape[0], window, step, None)) if window >= 1 and step >= 1 else 0
     if rows < 1:

@@ -133,3 +133,20 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "paa_oracle" not in text and "load_reference" not in text, f
                 assert "/root/reference" not in text, f
+
+
+def test_classify_signal_kinds():
+    k, a = _ffi.classify_signal(np.zeros(10, dtype=np.int16))
+    assert k == 0 and a.dtype == np.int16
+    k, a = _ffi.classify_signal(np.zeros(10, dtype=np.float32))
+    assert k == 1 and a.dtype == np.float64
+    k, a = _ffi.classify_signal([1, 2, 3])
+    assert k == 1 and a.dtype == np.float64
+    k, a = _ffi.classify_signal(np.zeros((10, 2), dtype=np.int16))
+    assert k == 2 and a.shape == (10, 2) and a.flags["C_CONTIGUOUS"]
+    k, a = _ffi.classify_signal(np.zeros((10, 2), dtype=np.int16)[:, ::-1])     # non-contiguous view
+    assert k == 2 and a.flags["C_CONTIGUOUS"]
+    k, a = ShortTermFeatures._mono_only(np.array([[2, 4], [1, 3]], dtype=np.int16))
+    assert k == 1 and np.array_equal(a, [3.0, 2.0])
+    with pytest.raises(ValueError):
+        _ffi.classify_signal(np.zeros((4, 3)))
