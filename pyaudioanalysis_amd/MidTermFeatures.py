@@ -333,3 +333,39 @@ def directory_feature_extraction_no_avg(folder_path, mid_window, mid_step, short
                 mid_features = np.vstack((mid_features, vec))
                 signal_idx = np.append(signal_idx, i * np.ones((vec.shape[0],)))
     return mid_features, signal_idx, wav_file_list
+
+
+# ---------------------------------------------------------------------------------------------------------
+# file writers (reference :324-377): feature sequences of one file / every WAV of a folder -> .npy (.csv)
+# ---------------------------------------------------------------------------------------------------------
+def mid_feature_extraction_to_file(file_path, mid_window, mid_step, short_window, short_step, output_file,
+                                   store_short_features=False, store_csv=False, plot=False):
+    """Read one audio file, extract its mid-term (and optionally short-term) feature sequences on the GPU and
+    save them as <output_file>_mt.npy / _st.npy (and .csv, one row per window) -- no long-term averaging."""
+    sampling_rate, signal = audioBasicIO.read_audio_file(file_path)
+    if not (signal.ndim == 2 and signal.shape[1] == 2 and signal.dtype == np.int16):
+        signal = audioBasicIO.stereo_to_mono(signal)          # int16 stereo is reduced to mono on the device
+    mid_features, short_features, _ = mid_feature_extraction(signal, sampling_rate,
+                                                             round(sampling_rate * mid_window),
+                                                             round(sampling_rate * mid_step),
+                                                             round(sampling_rate * short_window),
+                                                             round(sampling_rate * short_step))
+    outputs = [("_mt", "Mid-term", mid_features)]
+    if store_short_features:
+        outputs.insert(0, ("_st", "Short-term", short_features))
+    for suffix, label, matrix in outputs:
+        np.save(output_file + suffix, matrix)
+        if plot:
+            print(label + " np file: " + output_file + suffix + ".npy saved")
+        if store_csv:
+            np.savetxt(output_file + suffix + ".csv", matrix.T, delimiter=",")
+            if plot:
+                print(label + " CSV file: " + output_file + suffix + ".csv saved")
+
+
+def mid_feature_extraction_file_dir(folder_path, mid_window, mid_step, short_window, short_step,
+                                    store_short_features=False, store_csv=False, plot=False):
+    """mid_feature_extraction_to_file for every *.wav of a folder; outputs are written next to the inputs."""
+    for wav in glob.glob(folder_path + os.sep + '*.wav'):
+        mid_feature_extraction_to_file(wav, mid_window, mid_step, short_window, short_step, wav,
+                                       store_short_features, store_csv, plot)

@@ -593,8 +593,8 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
             double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
             const int lo0 = t_melk0[i], lo1 = t_melk1[i], lo2 = t_melk2[i];
             // each trip issues its 16 LDS loads back to back (one wait), then runs two 4-long FMA chains
-#define PAA_MEL_CLASS(acc, lo, N, tw, IDX)                                                              \
-            _Pragma("unroll") for (int n = 0; n < (N); n += 8) {                                        \
+#define PAA_MEL_CLASS(acc, lo, N, tw, IDX, UNROLL)                                                      \
+            UNROLL for (int n = 0; n < (N); n += 8) {                                                   \
                 double xv_[8], wv_[8];                                                                  \
                 _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                         \
                     xv_[u] = cur[IDX((lo) + n + u)];                                                    \
@@ -610,17 +610,17 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
 #define PAA_IDX_CLAMP(k) min((k), NF - 1)
 #define PAA_IDX_PLAIN(k) (k)
             if (FIXED) {
-                PAA_MEL_CLASS(acc0, lo0, 8, t_melw0, PAA_IDX_PLAIN)
-                PAA_MEL_CLASS(acc1, lo1, 16, t_melw1, PAA_IDX_PLAIN)
-                PAA_MEL_CLASS(acc2, lo2, 16, t_melw2, PAA_IDX_PLAIN)
+                PAA_MEL_CLASS(acc0, lo0, 8, t_melw0, PAA_IDX_PLAIN, _Pragma("unroll"))
+                PAA_MEL_CLASS(acc1, lo1, 16, t_melw1, PAA_IDX_PLAIN, _Pragma("unroll"))
+                PAA_MEL_CLASS(acc2, lo2, 16, t_melw2, PAA_IDX_PLAIN, _Pragma("unroll"))
             } else if (L.mel_clamp) {
-                PAA_MEL_CLASS(acc0, lo0, L.melN0, t_melw0, PAA_IDX_CLAMP)
-                PAA_MEL_CLASS(acc1, lo1, L.melN1, t_melw1, PAA_IDX_CLAMP)
-                PAA_MEL_CLASS(acc2, lo2, L.melN2, t_melw2, PAA_IDX_CLAMP)
+                PAA_MEL_CLASS(acc0, lo0, L.melN0, t_melw0, PAA_IDX_CLAMP, )
+                PAA_MEL_CLASS(acc1, lo1, L.melN1, t_melw1, PAA_IDX_CLAMP, )
+                PAA_MEL_CLASS(acc2, lo2, L.melN2, t_melw2, PAA_IDX_CLAMP, )
             } else {        // every padded list stays inside the 400 bins
-                PAA_MEL_CLASS(acc0, lo0, L.melN0, t_melw0, PAA_IDX_PLAIN)
-                PAA_MEL_CLASS(acc1, lo1, L.melN1, t_melw1, PAA_IDX_PLAIN)
-                PAA_MEL_CLASS(acc2, lo2, L.melN2, t_melw2, PAA_IDX_PLAIN)
+                PAA_MEL_CLASS(acc0, lo0, L.melN0, t_melw0, PAA_IDX_PLAIN, )
+                PAA_MEL_CLASS(acc1, lo1, L.melN1, t_melw1, PAA_IDX_PLAIN, )
+                PAA_MEL_CLASS(acc2, lo2, L.melN2, t_melw2, PAA_IDX_PLAIN, )
             }
 #undef PAA_IDX_CLAMP
 #undef PAA_IDX_PLAIN
@@ -636,7 +636,6 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
         double chroma = 0.0;
         {
             const int ch_len = FIXED ? 8 : L.chN;
-#pragma unroll
             for (int n = 0; n < ch_len; n += 8) {
                 int kv[8];
                 double wv[8], xv[8];

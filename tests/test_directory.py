@@ -73,3 +73,19 @@ def test_gpu_beat_kernel_equals_host_beat_extraction(gpu_lib):
             st, _ = ShortTermFeatures.feature_extraction(c, 16000, 800, step)
             bpm, ratio = MidTermFeatures.beat_extraction(st, ws)
             assert np.allclose(b, [bpm, ratio], rtol=1e-9, atol=1e-12), (ws, len(c), b, bpm, ratio)
+
+
+@pytest.mark.gpu
+def test_mid_feature_extraction_to_file(gpu_lib, tmp_path):
+    """File writers (reference :324-377): .npy / .csv of the mid- and short-term sequences."""
+    g = _golden()
+    d = str(tmp_path)
+    name = "a_mono16k_3s.wav"
+    wavfile.write(os.path.join(d, name), int(g["wav_fs_" + name]), g["wav_x_" + name])
+    MidTermFeatures.mid_feature_extraction_file_dir(d, 1.0, 1.0, 0.05, 0.05, store_short_features=True, store_csv=True)
+    base = os.path.join(d, name)
+    mt, st = np.load(base + "_mt.npy"), np.load(base + "_st.npy")
+    ref_mid, ref_st, _ = O.mid_feature_extraction(g["wav_x_" + name], 16000, 16000, 16000, 800, 800)
+    assert O.mixed_tolerance_violations(mt, ref_mid)[0] == 0 and O.mixed_tolerance_violations(st, ref_st)[0] == 0
+    csv = np.loadtxt(base + "_mt.csv", delimiter=",")
+    assert csv.shape == mt.T.shape and np.allclose(csv, mt.T, rtol=1e-12, atol=0)
