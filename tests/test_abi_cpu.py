@@ -150,3 +150,23 @@ def test_classify_signal_kinds():
     assert k == 1 and np.array_equal(a, [3.0, 2.0])
     with pytest.raises(ValueError):
         _ffi.classify_signal(np.zeros((4, 3)))
+
+
+def test_c_client_links_and_fails_loudly_without_gpu(tmp_path):
+    """examples/c_api_demo.c: a plain C program links against the C ABI (no Python, no torch in the signatures)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    _ffi.lib()      # make sure the library is built
+    exe = str(tmp_path / "c_api_demo")
+    libdir = os.path.dirname(_ffi.library_path())
+    cmd = ["gcc", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_api_demo.c"), "-o", exe,
+           "-L" + libdir, "-lpaa_hip", "-Wl,-rpath," + libdir, "-lm"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    if _ffi.device_count() > 0:
+        assert run.returncode == 0 and "frames 79" in run.stdout, run.stdout + run.stderr
+    else:
+        assert run.returncode == 2 and "no HIP device" in run.stdout, run.stdout + run.stderr

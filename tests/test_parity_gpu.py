@@ -297,3 +297,30 @@ def test_fused_stereo_to_mono(gpu_lib):
     mid, st2, _ = MidTermFeatures.mid_feature_extraction(xs, 16000, 16000, 16000, 800, 400)
     assert_parity(st2, ref_st, "fused stereo short")
     assert_parity(mid, ref_mid, "fused stereo mid")
+
+
+def test_c_client_on_gpu(gpu_lib, tmp_path):
+    """The plain C client of examples/c_api_demo.c runs the hot path through the C ABI without Python."""
+    from test_abi_cpu import test_c_client_links_and_fails_loudly_without_gpu as run_c_client
+    run_c_client(tmp_path)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_window_step_sweep(gpu_lib, seed):
+    """Seeded sweep over (fs, window, step): odd / prime / composite windows, overlapping and gapped steps."""
+    rng = np.random.default_rng(1000 + seed)
+    fs = int(rng.choice([8000, 11025, 16000, 22050, 32000, 44100, 48000]))
+    window = int(rng.integers(max(200, fs // 60), fs // 12))
+    if window / 2 < 12 * np.log2((fs / 2) / 27.5) + 2:       # chroma needs max slot < num_fft (reference :286)
+        window = int(fs // 20)
+    step = int(rng.integers(window // 4, window + window // 4))
+    x = synth_clip(2000 + seed, int(fs * 0.6) + window, fs=fs)
+    try:
+        ref, _ = O.feature_extraction(x, fs, window, step)
+    except (ValueError, IndexError) as exc:                  # the reference rejects the configuration ...
+        with pytest.raises(type(exc)):                       # ... and so must the drop-in, with the same type
+            ShortTermFeatures.feature_extraction(x, fs, window, step)
+        return
+    got, _ = ShortTermFeatures.feature_extraction(x, fs, window, step)
+    ill = O.ill_conditioned_mfcc_frames(x, fs, window, step)
+    assert_parity(got, ref, "fs=%d W=%d S=%d" % (fs, window, step), ill)
