@@ -717,480 +717,12 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
     PAA_TEND()
 }
 
-// ---- octet variant (step 400 only) -----------------------------------------------------------------------------
-// Same per-quad FFT stage, but the feature stage runs on TWO quads (8 frames) at once: the code of both quads
-// sits in the same scheduling regions, so the dependent FP64 chains (DPP reductions, reciprocals, logarithms) and
-// the LDS latencies of one quad are filled with the other quad's independent work -- instruction-level
-// parallelism in place of the second wave per SIMD that the register budget rules out.
-// LDS per wave: 9 spectrum slots (8 + the previous quad's last), raw samples (aliased by the 2 x 4 x 40 log-mel
-// values), two sets of chunk partials, two 4 x 34 feature staging blocks.
-struct GeoOct {
-    using G = Geo<400>;
-    static constexpr int NSLOT = 9;
-    static constexpr int OFF_SPEC = 0;
-    static constexpr int OFF_RAW = OFF_SPEC + NSLOT * NF * 8;
-    static constexpr int OFF_PART = OFF_RAW + (G::RAW_N + 2 * RAW_PAD) * 2;      // 2 x {cE f64[50], cZ i32[50], cF i32[50]}
-    static constexpr int PART_BYTES = 16 * G::NCHUNK;
-    static constexpr int OFF_FV = OFF_PART + 2 * PART_BYTES;                      // 2 x [4][34] f64
-    static constexpr int WAVE_BYTES = ((OFF_FV + 2 * QUAD * FV_STRIDE * 8 + 15) / 16) * 16;
-    static_assert(2 * QUAD * 40 * 8 <= (G::RAW_N + 2 * RAW_PAD) * 2, "log-mel values alias the raw buffer");
-    static_assert(OFF_RAW % 16 == 0 && OFF_PART % 8 == 0 && OFF_FV % 8 == 0, "LDS alignment");
-};
-
-struct OctTables {
-    const double *melw0, *melw1, *melw2, *chw, *dct;
-    const int *melk0, *melk1, *melk2, *chk;
-    const double2 *tw2, *twp;
-};
-struct FeatHalf {          // what the first half of the feature stage hands to the second
-    double e_tot, ent_e, ent_f, cen, spread, sFl, chroma;
-    int zc, first;
-};
-
-// first half: everything up to the log-mel values (written to mg) and the chroma value of this lane's class
-template <int FIXED>
-__device__ __forceinline__ FeatHalf feat_half1(const OctTables &T, const TabLayout &L, const double *cur, const double *prv,
-                                               const double *cE, const int *cZ, const int *cF, double *mg, int g, int i,
-                                               double f0, double rf0) {
-    constexpr int CPF = 10;
-    FeatHalf R;
-    double pblk = 0.0;
-    {
-        const double2 *c2 = reinterpret_cast<const double2 *>(cur + 40 * (i < 10 ? i : 0));
-        double2 blk[20];
-#pragma unroll
-        for (int m = 0; m < 20; ++m) blk[m] = c2[m];
-        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-#pragma unroll
-        for (int m = 0; m < 20; m += 2) {
-            p0 = fma(blk[m].x, blk[m].x, p0); p1 = fma(blk[m].y, blk[m].y, p1);
-            p2 = fma(blk[m + 1].x, blk[m + 1].x, p2); p3 = fma(blk[m + 1].y, blk[m + 1].y, p3);
-        }
-        pblk = (i < 10) ? (p0 + p1) + (p2 + p3) : 0.0;
-    }
-    double Xc[25];
-#pragma unroll
-    for (int m = 0; m < 25; ++m) Xc[m] = cur[25 * i + m];
-    const double *Xv = prv + 25 * i;          // the previous spectrum is re-read where needed (register budget)
-    double sXa = 0.0, sXb = 0.0, sPa = 0.0, sPb = 0.0, sMa = 0.0, sMb = 0.0, sVa = 0.0, sVb = 0.0, mx = 0.0;
-#pragma unroll
-    for (int m = 0; m < 24; m += 2) {
-        const double X0 = Xc[m], X1 = Xc[m + 1];
-        sXa += X0; sXb += X1;
-        sVa += Xv[m]; sVb += Xv[m + 1];
-        sMa = fma((double)m, X0, sMa); sMb = fma((double)(m + 1), X1, sMb);
-        sPa = fma(X0, X0, sPa); sPb = fma(X1, X1, sPb);
-        mx = fmax(mx, fmax(X0, X1));
-    }
-    sXa += Xc[24]; sVa += Xv[24]; sMa = fma(24.0, Xc[24], sMa); sPa = fma(Xc[24], Xc[24], sPa); mx = fmax(mx, Xc[24]);
-    const double cs = sPa + sPb;
-    const double base_k = (double)(25 * i + 1);
-    double sX = sXa + sXb;
-    double sIX = f0 * fma(base_k, sX, sMa + sMb);
-    double sXp = sVa + sVb;
-    sX = group_sum(sX); sXp = group_sum(sXp);
-    sIX = group_sum(sIX); mx = group_max(mx);
-    const double sXe = sX + (double)NF * kEps;           // np.sum(X + eps) (:118-119)
-    sXp += (double)NF * kEps;
-    const double run_incl = group_scan_incl(cs);
-    const double sP = dpp_bcast15(run_incl);
-
-    const double eblk = (i < 10) ? cE[CPF * g + 2 * i] + cE[CPF * g + 2 * i + 1] : 0.0;
-    R.e_tot = group_sum(eblk);
-    {
-        const double sf = fast_div(pblk, sP + kEps), se = fast_div(eblk, R.e_tot + kEps);
-        R.ent_f = group_sum((i < 10) ? -(sf * fast_log2(sf + kEps)) : 0.0);
-        R.ent_e = group_sum((i < 10) ? -(se * fast_log2(se + kEps)) : 0.0);
-    }
-    int zc = cZ[CPF * g + i] + ((i < 4) ? cZ[CPF * g + 16 + i] : 0) - ((i == 0) ? cF[CPF * g] : 0);
-    R.zc = group_sum_i(zc);
-
-    const double r = (mx == 0.0) ? 1.0 / kEps : fast_div(1.0, mx);
-    const double den = sX * r + kEps;
-    const double rden = fast_div(1.0, den);
-    R.cen = (sIX * r) * rden;
-    const double rX = fast_div(1.0, sXe), rXp = fast_div(1.0, sXp);
-    const double cb = base_k - R.cen * rf0;
-    double sSa = 0.0, sSb = 0.0, sFa = 0.0, sFb = 0.0;
-#pragma unroll
-    for (int m = 0; m < 24; m += 2) {
-        const double d0 = cb + (double)m, d1 = cb + (double)(m + 1);
-        sSa = fma(d0 * d0, Xc[m], sSa);
-        sSb = fma(d1 * d1, Xc[m + 1], sSb);
-        const double f0d = Xc[m] * rX - Xv[m] * rXp, f1d = Xc[m + 1] * rX - Xv[m + 1] * rXp;
-        sFa = fma(f0d, f0d, sFa);
-        sFb = fma(f1d, f1d, sFb);
-    }
-    {
-        const double d0 = cb + 24.0;
-        sSa = fma(d0 * d0, Xc[24], sSa);
-        const double f0d = Xc[24] * rX - Xv[24] * rXp;
-        sFa = fma(f0d, f0d, sFa);
-    }
-    double sSp = (sSa + sSb) * (f0 * f0 * r), sFl = sFa + sFb;
-    sSp = group_sum(sSp);
-    R.sFl = group_sum(sFl);
-    R.spread = fast_sqrt(sSp * rden);
-
-    int first = 0x7fffffff;
-    {
-        const double thr = 0.90 * sP;
-        double run = run_incl - cs;
-#pragma unroll
-        for (int m = 0; m < 25; ++m) {
-            run = fma(Xc[m], Xc[m], run);
-            first = (first == 0x7fffffff && run + kEps > thr) ? 25 * i + m : first;
-        }
-        R.first = group_min_i(first);
-    }
-
-    {   // log-mel values: filters i, 16 + i and one half of 32 + (i & 7)
-        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-        const int lo0 = T.melk0[i], lo1 = T.melk1[i], lo2 = T.melk2[i];
-#define PAA_MEL_CLASS(acc, lo, N, tw, IDX, UNROLL)                                                      \
-        UNROLL for (int n = 0; n < (N); n += 8) {                                                       \
-            double xv_[8], wv_[8];                                                                      \
-            _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                             \
-                xv_[u] = cur[IDX((lo) + n + u)];                                                        \
-                wv_[u] = (tw)[(n + u) * 16 + i];                                                        \
-            }                                                                                           \
-            double ea_ = 0.0, eb_ = 0.0;                                                                \
-            _Pragma("unroll") for (int u = 0; u < 8; u += 2) {                                          \
-                ea_ = fma(xv_[u], wv_[u], ea_);                                                         \
-                eb_ = fma(xv_[u + 1], wv_[u + 1], eb_);                                                 \
-            }                                                                                           \
-            acc += ea_ + eb_;                                                                           \
-        }
-#define PAA_IDX_CLAMP(k) min((k), NF - 1)
-#define PAA_IDX_PLAIN(k) (k)
-        if (FIXED) {
-            PAA_MEL_CLASS(acc0, lo0, 8, T.melw0, PAA_IDX_PLAIN, _Pragma("unroll"))
-            PAA_MEL_CLASS(acc1, lo1, 16, T.melw1, PAA_IDX_PLAIN, _Pragma("unroll"))
-            PAA_MEL_CLASS(acc2, lo2, 16, T.melw2, PAA_IDX_PLAIN, _Pragma("unroll"))
-        } else if (L.mel_clamp) {
-            PAA_MEL_CLASS(acc0, lo0, L.melN0, T.melw0, PAA_IDX_CLAMP, )
-            PAA_MEL_CLASS(acc1, lo1, L.melN1, T.melw1, PAA_IDX_CLAMP, )
-            PAA_MEL_CLASS(acc2, lo2, L.melN2, T.melw2, PAA_IDX_CLAMP, )
-        } else {
-            PAA_MEL_CLASS(acc0, lo0, L.melN0, T.melw0, PAA_IDX_PLAIN, )
-            PAA_MEL_CLASS(acc1, lo1, L.melN1, T.melw1, PAA_IDX_PLAIN, )
-            PAA_MEL_CLASS(acc2, lo2, L.melN2, T.melw2, PAA_IDX_PLAIN, )
-        }
-#undef PAA_IDX_CLAMP
-#undef PAA_IDX_PLAIN
-#undef PAA_MEL_CLASS
-        acc2 += dpp_mov<0x128>(acc2);                    // row_ror:8 joins the two halves of filter 32 + (i & 7)
-        mg[i] = fast_log10(acc0 + kEps);
-        mg[16 + i] = fast_log10(acc1 + kEps);
-        const double l2 = fast_log10(acc2 + kEps);
-        if (i < 8) mg[32 + i] = l2;
-    }
-    double chroma = 0.0;
-    {
-        const int ich = min(i, CH_STRIDE - 1);
-        const int ch_len = FIXED ? 8 : L.chN;
-        for (int n = 0; n < ch_len; n += 8) {
-            int kv[8];
-            double wv[8], xv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { kv[u] = T.chk[(n + u) * CH_STRIDE + ich]; wv[u] = T.chw[(n + u) * CH_STRIDE + ich]; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = cur[kv[u]];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) chroma = fma(xv[u] * xv[u], wv[u], chroma);
-        }
-        chroma = (sP == 0.0) ? chroma / kEps : fast_div(chroma, sP);
-        if (i >= 12) chroma = 0.0;
-    }
-    R.chroma = chroma;
-    return R;
-}
-
-// second half: DCT of the log-mel values, chroma std, the eight scalar rows -> fg[0..33]
-__device__ __forceinline__ void feat_half2(const OctTables &T, const FeatHalf &R, double *fg, const double *mg, int i, int t,
-                                           double r_half_fs) {
-    if (i < 13) {
-        const double *dm = T.dct + 41 * i;
-        double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            double dv[20], mv[20];
-#pragma unroll
-            for (int n = 0; n < 20; ++n) { dv[n] = dm[20 * h + n]; mv[n] = mg[20 * h + n]; }
-#pragma unroll
-            for (int n = 0; n < 20; n += 4) {
-                c0 = fma(dv[n], mv[n], c0);
-                c1 = fma(dv[n + 1], mv[n + 1], c1);
-                c2 = fma(dv[n + 2], mv[n + 2], c2);
-                c3 = fma(dv[n + 3], mv[n + 3], c3);
-            }
-        }
-        fg[8 + i] = (c0 + c1) + (c2 + c3);
-    }
-    if (i < 12) fg[21 + i] = R.chroma;
-    if (i == 15) {
-        fg[0] = ((double)R.zc * 0.5) * (1.0 / (double)(W - 1));
-        fg[1] = R.e_tot * (1.0 / (double)W);
-        fg[2] = R.ent_e;
-        fg[3] = R.cen * r_half_fs;
-        fg[4] = R.spread * r_half_fs;
-        fg[5] = R.ent_f;
-        fg[6] = (t == 0) ? 0.0 : R.sFl;
-        fg[7] = (R.first == 0x7fffffff) ? 0.0 : (double)R.first * (1.0 / (double)NF);
-    }
-    const double m = group_sum((i < 12) ? R.chroma : 0.0) / 12.0;
-    const double d = (i < 12) ? R.chroma - m : 0.0;
-    const double var = group_sum(d * d) / 12.0;
-    if (i == 14) fg[33] = fast_sqrt(var);
-}
-
-template <int DELTAS, int FIXED>
-__global__ __launch_bounds__(64 * WAVES, 1) void st_fast_800_oct_kernel(PlanDev P, TabLayout L,
-                                                                        const unsigned char *__restrict__ blob,
-                                                                        const int16_t *__restrict__ sig,
-                                                                        const ClipDev *__restrict__ clips,
-                                                                        const ClipNorm *__restrict__ norms,
-                                                                        const Tile *__restrict__ tiles, int n_tiles,
-                                                                        double *__restrict__ out) {
-    constexpr int S = 400;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    {
-        const int4 *src4 = reinterpret_cast<const int4 *>(blob);
-        int4 *dst4 = reinterpret_cast<int4 *>(smem);
-        for (int n = threadIdx.x; n < L.total / 16; n += 64 * WAVES) dst4[n] = src4[n];
-    }
-    __syncthreads();       // the only workgroup-wide barrier
-    OctTables T;
-    T.melw0 = reinterpret_cast<const double *>(smem + L.off_w0);
-    T.melk0 = reinterpret_cast<const int *>(smem + L.off_k0);
-    T.melw1 = reinterpret_cast<const double *>(smem + L.off_w1);
-    T.melk1 = reinterpret_cast<const int *>(smem + L.off_k1);
-    T.melw2 = reinterpret_cast<const double *>(smem + L.off_w2);
-    T.melk2 = reinterpret_cast<const int *>(smem + L.off_k2);
-    T.chw = reinterpret_cast<const double *>(smem + L.off_chw);
-    T.chk = reinterpret_cast<const int *>(smem + L.off_chk);
-    T.dct = reinterpret_cast<const double *>(smem + L.off_dct);
-    T.tw2 = reinterpret_cast<const double2 *>(smem + L.off_tw2);
-    T.twp = reinterpret_cast<const double2 *>(smem + L.off_twp);
-
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile_id = blockIdx.x * WAVES + wave;
-    if (tile_id >= n_tiles) return;
-    using G = Geo<S>;
-    using GO = GeoOct;
-    constexpr int RAW_N = G::RAW_N, NCHUNK = G::NCHUNK;
-    unsigned char *wbase = smem + L.total + wave * GO::WAVE_BYTES;
-    double *spec = reinterpret_cast<double *>(wbase + GO::OFF_SPEC);
-    int16_t *raw = reinterpret_cast<int16_t *>(wbase + GO::OFF_RAW);
-    double *msp = reinterpret_cast<double *>(wbase + GO::OFF_RAW);          // [2][4][40], raw is dead by then
-    double *fv = reinterpret_cast<double *>(wbase + GO::OFF_FV);            // [2][4][34]
-
-    const int lane = threadIdx.x & 63;
-    const int g = lane >> 4, i = lane & 15;
-    const Tile tl = tiles[tile_id];
-    const ClipDev c = clips[tl.clip];
-    const ClipNorm nm = norms[tl.clip];
-    const int16_t *xc = sig + c.sample_off;
-    const long long Tc = c.T;
-    double *oc = out + c.out_off;
-
-    const double sc = 1.0 / 32768.0;
-    const double f0 = P.fs / (2.0 * (double)NF);
-    const double rf0 = 1.0 / f0;
-    const double r_half_fs = 1.0 / (P.fs / 2.0);
-    const double mu = nm.mean * 32768.0;
-    const int m_int = (int)fmin(fmax(nearbyint(mu), -40000.0), 40000.0);
-    const double mag_scale = 0.5 * nm.inv * sc / (double)NF;
-    const double delta_mu = mu - (double)m_int;
-    const double dc_shift = 2.0 * (double)W * delta_mu;
-    const double y_scale2 = (nm.inv * sc) * (nm.inv * sc);
-    const int thr_pos = (int)fmin(fmax(floor(mu) + 1.0, -40000.0), 40000.0);
-    const int thr_neg = (int)fmin(fmax(ceil(mu) - 1.0, -40000.0), 40000.0);
-    const int pa = i, pb = (i == 0) ? 0 : 25 - i;
-    const bool act = i < 13;
-    const int itw = min(i, TW_STRIDE - 1);
-
-    const int t_end = tl.t0 + tl.cnt;
-    int q0 = tl.t0 >= QUAD ? tl.t0 - QUAD : 0;
-    int slot0 = 1;                   // slots of this octet: slot0 .. slot0+7 (mod 9); previous = slot0-1
-    double vlast = 0.0;              // lane l < 34: feature l of the frame before this octet
-
-    int4 pre[G::NPRE];
-#pragma unroll
-    for (int r = 0; r < G::NPRE; ++r) pre[r] = make_int4(0, 0, 0, 0);
-    bool pre_ok;
-    PAA_F800_FETCH(q0)
-
-    for (; q0 < t_end; q0 += 2 * QUAD, slot0 = (slot0 + 8) % GO::NSLOT) {
-        // ================= FFT stage, quad A (h = 0) then quad B (h = 1) =================
-        for (int h = 0; h < 2; ++h) {
-            const int qh = q0 + QUAD * h;
-            if (qh >= t_end) break;
-            double *cE = reinterpret_cast<double *>(wbase + GO::OFF_PART + h * GO::PART_BYTES);
-            int *cZ = reinterpret_cast<int *>(cE + NCHUNK);
-            int *cF = cZ + NCHUNK;
-            {   // stage raw samples [qh*S - 1, qh*S + 2000)
-                const long long base = (long long)qh * S;
-                const int16_t *src = xc + base;
-                if (pre_ok) {
-                    int4 *d4 = reinterpret_cast<int4 *>(raw + RAW_PAD);
-#pragma unroll
-                    for (int r = 0; r < G::NPRE; ++r)
-                        if (lane + 64 * r < RAW_N / 8) d4[lane + 64 * r] = pre[r];
-                } else {
-                    const long long avail = c.n - base;
-                    for (int n = lane; n < RAW_N; n += 64) raw[RAW_PAD + n] = (n < avail) ? src[n] : (int16_t)0;
-                }
-                if (lane == 0) raw[RAW_PAD - 1] = (base > 0) ? src[-1] : src[0];
-                if (qh + QUAD < t_end) PAA_F800_FETCH(qh + QUAD)
-            }
-            wsync();
-            // time domain: chunk partials (ShortTermFeatures.py:22-51)
-            if (lane < NCHUNK) {
-                const int ch = lane;
-                const int4 *p4 = reinterpret_cast<const int4 *>(raw + RAW_PAD + CHUNK * ch);
-                const int prev = raw[RAW_PAD + CHUNK * ch - 1];
-                int sprev = (prev >= thr_pos) - (prev <= thr_neg);
-                double e2 = 0.0;
-                int s1 = 0;
-                int z = 0, zfirst = 0;
-#pragma unroll
-                for (int v4 = 0; v4 < CHUNK / 8; ++v4) {
-                    const int4 q = p4[v4];
-                    const int w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-                    for (int hh = 0; hh < 4; ++hh) {
-                        const int xa = (int)(short)(w[hh] & 0xffff), xb = w[hh] >> 16;
-                        const int ca = xa - m_int, cb = xb - m_int;
-                        const double fa = (double)ca, fb = (double)cb;
-                        e2 = fma(fa, fa, e2);
-                        e2 = fma(fb, fb, e2);
-                        s1 += ca + cb;
-                        const int sa = (xa >= thr_pos) - (xa <= thr_neg);
-                        const int sb = (xb >= thr_pos) - (xb <= thr_neg);
-                        const int da = abs(sa - sprev);
-                        if (v4 == 0 && hh == 0) zfirst = da;
-                        z += da + abs(sb - sa);
-                        sprev = sb;
-                    }
-                }
-                cE[ch] = y_scale2 * fma(delta_mu, fma(-2.0, (double)s1, (double)CHUNK * delta_mu), e2);
-                cZ[ch] = z;
-                cF[ch] = zfirst;
-            }
-            // pass 1: radix-25 on z[j + 16 r]
-            double2 v[25];
-            {
-                const int *r32 = reinterpret_cast<const int *>(raw + RAW_PAD) + (S / 2) * g + i;
-#pragma unroll
-                for (int r = 0; r < 25; ++r) {
-                    const int w = r32[16 * r];
-                    v[r] = make_double2((double)((int)(short)(w & 0xffff) - m_int), (double)((w >> 16) - m_int));
-                }
-            }
-            dft25(v);
-            wsync();
-            double ax[16], ay[16], bx[16], by[16];
-            double2 w2[16];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) w2[r] = T.tw2[r * TW_STRIDE + itw];
-            double *pl = spec + ((slot0 + 4 * h + g) % GO::NSLOT) * NF;
-            {
-#pragma unroll
-                for (int q = 0; q < 25; ++q) pl[25 * i + q] = v[PAA_DFT25_POS(q)].x;
-                wsync();
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { ax[r] = pl[pa + 25 * r]; bx[r] = pl[pb + 25 * r]; }
-                wsync();
-#pragma unroll
-                for (int q = 0; q < 25; ++q) pl[25 * i + q] = v[PAA_DFT25_POS(q)].y;
-                wsync();
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { ay[r] = pl[pa + 25 * r]; by[r] = pl[pb + 25 * r]; }
-                wsync();
-            }
-            if (act) {
-                double2 a[16], b[16];
-                a[0] = make_double2(ax[0], ay[0]);
-                b[0] = make_double2(bx[0], by[0]);
-#pragma unroll
-                for (int r = 1; r < 16; ++r) {
-                    a[r] = cmul(make_double2(ax[r], ay[r]), w2[r]);
-                    b[r] = cmul(make_double2(bx[r], by[r]), make_double2(w2[r].x, -w2[r].y));
-                }
-                double2 wp[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) wp[q] = T.twp[q * TW_STRIDE + itw];
-                dft16(a);
-                dft16(b);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const double2 zk = a[PAA_DFT16_POS(q)];
-                    const int qm = (16 - q) % 16;
-                    const double2 zb = b[PAA_DFT16_POS(qm)];
-                    const int k = pa + 25 * q;
-                    const double2 e = make_double2(zk.x + zb.x, zk.y - zb.y);
-                    const double2 o = make_double2(zk.y + zb.y, zb.x - zk.x);
-                    const double2 t = cmul(wp[q], o);
-                    double xr = e.x + t.x, xi = e.y + t.y;
-                    const double yr = e.x - t.x, yi = e.y - t.y;
-                    if (q == 0 && i == 0) { xr -= dc_shift; xi = 0.0; }
-                    pl[k] = mag_sqrt(fma(xr, xr, xi * xi)) * mag_scale;
-                    if (q > 0 || i > 0) pl[NF - k] = mag_sqrt(fma(yr, yr, yi * yi)) * mag_scale;
-                }
-            }
-            wsync();
-        }
-
-        // ================= feature stage: both quads in the same scheduling regions =================
-        const int tA = q0 + g, tB = q0 + QUAD + g;
-        const double *curA = spec + ((slot0 + g) % GO::NSLOT) * NF;
-        const double *prvA = (tA == 0) ? curA : spec + ((slot0 + g + GO::NSLOT - 1) % GO::NSLOT) * NF;
-        const double *curB = spec + ((slot0 + 4 + g) % GO::NSLOT) * NF;
-        const double *prvB = spec + ((slot0 + 3 + g) % GO::NSLOT) * NF;
-        const double *cEA = reinterpret_cast<const double *>(wbase + GO::OFF_PART);
-        const int *cZA = reinterpret_cast<const int *>(cEA + NCHUNK);
-        const int *cFA = cZA + NCHUNK;
-        const double *cEB = reinterpret_cast<const double *>(wbase + GO::OFF_PART + GO::PART_BYTES);
-        const int *cZB = reinterpret_cast<const int *>(cEB + NCHUNK);
-        const int *cFB = cZB + NCHUNK;
-        double *mgA = msp + 40 * g, *mgB = msp + 160 + 40 * g;
-        const FeatHalf RA = feat_half1<FIXED>(T, L, curA, prvA, cEA, cZA, cFA, mgA, g, i, f0, rf0);
-        const FeatHalf RB = feat_half1<FIXED>(T, L, curB, prvB, cEB, cZB, cFB, mgB, g, i, f0, rf0);
-        wsync();
-        feat_half2(T, RA, fv + FV_STRIDE * g, mgA, i, tA, r_half_fs);
-        feat_half2(T, RB, fv + QUAD * FV_STRIDE + FV_STRIDE * g, mgB, i, tB, r_half_fs);
-        wsync();
-
-        // ================= store: lane = feature row, 8 consecutive frames (64 B per row) =================
-        if (lane < kBase) {
-            double vq[2 * QUAD];
-#pragma unroll
-            for (int s = 0; s < 2 * QUAD; ++s) vq[s] = fv[FV_STRIDE * s + lane];
-#pragma unroll
-            for (int s = 0; s < 2 * QUAD; ++s) {
-                const int ts = q0 + s;
-                if (ts >= tl.t0 && ts < t_end) {
-                    oc[(long long)lane * Tc + ts] = vq[s];
-                    if (DELTAS) {
-                        const double pv = (s == 0) ? vlast : vq[s - 1];
-                        oc[(long long)(kBase + lane) * Tc + ts] = (ts == 0) ? 0.0 : vq[s] - pv;
-                    }
-                }
-            }
-            // the column before the next octet: frame q0 + 7 when quad B exists, else q0 + 3 (last octet anyway)
-            vlast = vq[2 * QUAD - 1];
-        }
-        wsync();
-    }
-}
-
 }  // namespace f800
 
 // returns 1 when a specialised kernel exists for this configuration (and fills fl), 0 when
 // the generic kernel must be used, < 0 on error
 inline int fast_select(int window, int step, int sample_kind, double fs, FastTables &ft, const FftPlan &fft,
-                       const MelTable &mel, const ChromaTable &chroma, FastLaunch &fl, int use_octets) {
+                       const MelTable &mel, const ChromaTable &chroma, FastLaunch &fl) {
     (void)fs;
     if (!(window == 800 && (step == 400 || step == 800) && sample_kind == 0)) return 0;
     const int wave_bytes = (step == 400) ? f800::Geo<400>::WAVE_BYTES : f800::Geo<800>::WAVE_BYTES;
@@ -1259,11 +791,6 @@ inline int fast_select(int window, int step, int sample_kind, double fs, FastTab
     fl.name = (step == 400) ? "st_fast_800" : "st_fast_800_s800";
     fl.lds = (size_t)L.total + (size_t)f800::WAVES * wave_bytes;
     fl.variant = (step == 400) ? 800 : 1600;
-    if (step == 400 && use_octets && (size_t)L.total + (size_t)f800::WAVES * f800::GeoOct::WAVE_BYTES <= 160 * 1024) {
-        fl.name = "st_fast_800_oct";
-        fl.lds = (size_t)L.total + (size_t)f800::WAVES * f800::GeoOct::WAVE_BYTES;
-        fl.variant = 808;
-    }
     fl.run = 256;       // longest run (frames) given to one wave; the plan shrinks it to fill the chip
     fl.waves_per_cu = f800::WAVES;
     return 1;
@@ -1285,22 +812,6 @@ inline int fast_launch_one(const FastLaunch &fl, const PlanDev &P, const unsigne
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-template <int DELTAS, int FIXED>
-inline int fast_launch_oct(const FastLaunch &fl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
-                           const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,
-                           double *d_out, hipStream_t stream) {
-    static size_t attr_done = 0;
-    if (attr_done < fl.lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&f800::st_fast_800_oct_kernel<DELTAS, FIXED>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl.lds) != hipSuccess) return -1;
-        attr_done = fl.lds;
-    }
-    const unsigned grid = (unsigned)((n_tiles + f800::WAVES - 1) / f800::WAVES);
-    hipLaunchKernelGGL((f800::st_fast_800_oct_kernel<DELTAS, FIXED>), dim3(grid), dim3(64 * f800::WAVES), fl.lds, stream,
-                       P, fl.layout, blob, (const int16_t *)d_packed, clips, norms, tiles, (int)n_tiles, d_out);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-
 template <int S>
 inline int fast_launch_step(const FastLaunch &fl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                             const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,
@@ -1317,13 +828,6 @@ inline int fast_launch(const FastLaunch &fl, const PlanDev &P, const FastTables 
                        double *d_out, hipStream_t stream) {
     if (!ft.d_blob) return -1;
     const unsigned char *blob = reinterpret_cast<const unsigned char *>(ft.d_blob);
-    if (fl.variant == 808) {
-        if (fl.layout.fixed_lists)
-            return P.deltas ? fast_launch_oct<1, 1>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream)
-                            : fast_launch_oct<0, 1>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
-        return P.deltas ? fast_launch_oct<1, 0>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream)
-                        : fast_launch_oct<0, 0>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
-    }
     if (fl.variant == 800) return fast_launch_step<400>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
     if (fl.variant == 1600) return fast_launch_step<800>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
     return -1;

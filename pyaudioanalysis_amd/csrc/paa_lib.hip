@@ -76,7 +76,6 @@ static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 static std::map<std::pair<double, int>, std::unique_ptr<TableSet>> g_tables;
 static Scratch g_in, g_in2, g_out, g_mid;
 static int g_force_generic = 0;
-static int g_fast_oct = 0;         // PAA_HIP_FAST_OCT=1: 8-frame feature stage variant of the fast kernel
 // optional per-launch timing of the feature kernel (bench.py's roofline leg)
 static int g_prof = 0;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev;
@@ -286,7 +285,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     // ---- kernel choice + tiles
     p->fast = 0;
     if (mode == 0 && !g_force_generic) {
-        rc = fast_select(window, step, sample_kind, fs, tab->fast, tab->fft, tab->mel, tab->chroma, p->fl, g_fast_oct);
+        rc = fast_select(window, step, sample_kind, fs, tab->fast, tab->fft, tab->mel, tab->chroma, p->fl);
         if (rc < 0) return fail(rc, "building the tables of the specialised kernel failed");
         p->fast = rc;
     }
@@ -298,7 +297,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         const long long per = (total_frames + slots - 1) / slots;
         const long long rounds = (per + p->fl.run - 1) / p->fl.run;     // fl.run = longest run worth one wave
         long long r = (per + std::max<long long>(rounds, 1) - 1) / std::max<long long>(rounds, 1);
-        r = (p->fl.variant == 808) ? ((r + 7) / 8) * 8 : ((r + 3) / 4) * 4;
+        r = ((r + 3) / 4) * 4;
         run = (int)std::min<long long>(p->fl.run, std::max<long long>(16, r));
         p->lds = p->fl.lds;
         p->kernel_name = p->fl.name;
@@ -602,8 +601,6 @@ extern "C" int paa_init(int device_id) {
     g_device = device_id;
     const char *fg = getenv("PAA_HIP_FORCE_GENERIC");
     g_force_generic = (fg && fg[0] == '1') ? 1 : 0;
-    const char *oc = getenv("PAA_HIP_FAST_OCT");
-    g_fast_oct = (oc && oc[0] == '1') ? 1 : 0;
     return PAA_OK;
 }
 
