@@ -46,3 +46,24 @@ def load():
         from pyAudioAnalysis import MidTermFeatures as ref_mt
         from pyAudioAnalysis import audioBasicIO as ref_io
     return ref_st, ref_mt, ref_io
+
+
+def load_segmentation():
+    """The reference's audioSegmentation module (for the self-similarity / thumbnailing goldens).  Its imports of
+    hmmlearn, imblearn, plotly (via audioTrainTest) are not installed and are not used by
+    self_similarity_matrix / music_thumbnailing: empty stub modules stand in for them."""
+    load()
+    stubs = ["hmmlearn", "hmmlearn.hmm", "imblearn", "imblearn.under_sampling", "imblearn.over_sampling",
+             "plotly", "plotly.subplots", "plotly.graph_objs", "simplejson"]
+    for name in stubs:
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["imblearn.under_sampling"].RandomUnderSampler = object
+    sys.modules["imblearn.over_sampling"].SMOTE = object
+    sys.modules["hmmlearn"].hmm = sys.modules["hmmlearn.hmm"]
+    sys.modules["plotly"].subplots = sys.modules["plotly.subplots"]
+    sys.modules["plotly"].graph_objs = sys.modules["plotly.graph_objs"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from pyAudioAnalysis import audioSegmentation as ref_seg
+    return ref_seg

@@ -114,7 +114,7 @@ def main():
     print("total %.2f MB" % (tot / 1e6))
 
 
-if __name__ == "__main__" and "--dir" not in sys.argv:
+if __name__ == "__main__" and "--dir" not in sys.argv and "--thumb" not in sys.argv:
     main()
 
 
@@ -159,3 +159,43 @@ def directory_goldens():
 
 if __name__ == "__main__" and "--dir" in sys.argv:
     directory_goldens()
+
+
+def thumbnail_goldens():
+    """Row f4 of SURVEY 8f: audioSegmentation.self_similarity_matrix / music_thumbnailing run by the unmodified
+    reference.  Song inputs are regenerated from their seed (synth.synth_song); a checksum guards the bytes."""
+    from synth import synth_song
+    ref_st, _, _ = load_reference.load()
+    ref_seg = load_reference.load_segmentation()
+
+    def thumb_case(name, seed, seconds, fs, sw, ss, thumb, l1, l2):
+        x = synth_song(seed, seconds, fs)
+        st, _ = ref_st.feature_extraction(x, fs, fs * sw, fs * ss)
+        sim = ref_seg.self_similarity_matrix(st)
+        a1, a2, b1, b2, filt = ref_seg.music_thumbnailing(x, fs, sw, ss, thumb, l1, l2)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="thumb", seed=seed, seconds=seconds, fs=fs,
+                            short_window=sw, short_step=ss, thumb_size=thumb, limit_1=l1, limit_2=l2,
+                            checksum=np.int64(np.sum(x.astype(np.int64) * (np.arange(len(x)) % 251 + 1))),
+                            features=st, sim=sim, filtered=filt, pos=np.array([a1, a2, b1, b2]))
+        print(name, st.shape, filt.shape, (a1, a2, b1, b2))
+
+    thumb_case("thumb_song40s", 31, 40.0, 16000, 1.0, 0.5, 5.0, 0, 1)
+    thumb_case("thumb_song40s_limits", 31, 40.0, 16000, 1.0, 0.5, 5.0, 0.1, 0.9)
+    thumb_case("thumb_song30s_half", 32, 30.0, 16000, 0.5, 0.25, 4.0, 0, 1)
+    thumb_case("thumb_song24s_8k", 33, 24.0, 8000, 1.0, 0.5, 4.0, 0, 1)
+
+    def sim_case(name, src):
+        with np.load(os.path.join(OUT, src + ".npz")) as z:
+            F = z["features"]
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="sim", source=src, features=F,
+                            sim=ref_seg.self_similarity_matrix(F))
+        print(name, F.shape)
+
+    sim_case("sim_count2s", "count2s_800_400")
+    sim_case("sim_doremi3s_nodelta", "doremi3s_800_400_nodelta")
+    sim_case("sim_constant_dc", "constant_dc")           # every row constant -> zero vectors -> NaN off the diagonal
+    sim_case("sim_zeros_2000", "zeros_2000")
+
+
+if __name__ == "__main__" and "--thumb" in sys.argv:
+    thumbnail_goldens()

@@ -24,6 +24,10 @@ What is restated (reference file:line, relative to /root/reference/pyAudioAnalys
   spectrogram / chromagram ........ ShortTermFeatures.py:324-452
   mid-term mean/std ............... MidTermFeatures.py:87-127
   stereo -> mono .................. audioBasicIO.py:156-168
+  self-similarity / thumbnailing .. audioSegmentation.py:40-55, 1096-1190  (StandardScaler from
+                                    scikit-learn and pdist('cosine') / convolve2d from SciPy are third-party
+                                    dependencies that are not in /root/reference: their published algorithms
+                                    are restated below and pinned by tests/golden/thumb_*.npz / sim_*.npz)
 The FFT itself is SciPy's pocketfft (scipy>=1.6.3, requirements.txt:3) in the
 reference; it is not in /root/reference, so this oracle calls scipy.fft.fft (the
 same pocketfft entry, bit-identical to scipy.fftpack.fft on real input -- checked
@@ -339,6 +343,94 @@ def chromagram(signal, sampling_rate, window, step):
 # comparison policy shared by every parity test
 # --------------------------------------------------------------------------
 MFCC_ROWS = tuple(range(8, 21))
+
+
+# --------------------------------------------------------------------------
+# self-similarity matrix and music thumbnailing
+# --------------------------------------------------------------------------
+def standardize_rows(feature_vectors):
+    """StandardScaler().fit_transform(F.T).T (audioSegmentation.py:51-52).
+
+    scikit-learn (>=0.24 rule, installed 1.7.2): mean = sum/n; variance by the corrected two-pass formula
+    [sum (x-m)^2 - (sum (x-m))^2/n] / n; a feature with var <= n*eps*var + (n*mean*eps)^2 counts as constant
+    and gets scale 1 instead of sqrt(var)."""
+    X = np.asarray(feature_vectors, dtype=np.float64)
+    n = X.shape[1]
+    mean = X.sum(axis=1) / n
+    d = X - mean[:, None]
+    corr = d.sum(axis=1)
+    var = ((d * d).sum(axis=1) - corr * corr / n) / n
+    constant = var <= n * EPS * var + (n * mean * EPS) ** 2
+    scale = np.sqrt(var)
+    scale[constant] = 1.0
+    return d / scale[:, None]
+
+
+def self_similarity_matrix(feature_vectors):
+    """audioSegmentation.py:40-55: 1 - squareform(pdist(Z.T, 'cosine')) on the standardised vectors.
+
+    SciPy's cosine distance: 1 - clip(u.v / (|u| |v|), -1, 1) with |u| = sqrt(sum u^2); squareform puts exact
+    zeros on the diagonal, so the similarity diagonal is exactly 1 (also for zero vectors, whose off-diagonal
+    entries are NaN = 0/0 -- kept)."""
+    Z = standardize_rows(feature_vectors)
+    norms = np.sqrt((Z * Z).sum(axis=0))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        cos = (Z.T @ Z) / (norms[:, None] * norms[None, :])
+    big = np.abs(cos) > 1.0
+    cos[big] = np.copysign(1.0, cos[big])
+    sim = 1.0 - (1.0 - cos)
+    np.fill_diagonal(sim, 1.0)
+    return sim
+
+
+def thumbnail_filter(sim_matrix, m_filter, short_step, limit_1=0, limit_2=1):
+    """audioSegmentation.py:1146-1163: diagonal moving sum (convolve2d with eye(M), 'valid'), masking of the
+    near-diagonal band and the lower triangle with the global minimum, limit masks.  Returns the masked matrix."""
+    T = sim_matrix.shape[0]
+    R = T - m_filter + 1
+    if R < 1:
+        raise ValueError("fewer feature vectors (%d) than the thumbnail filter length (%d)" % (T, m_filter))
+    out = np.zeros((R, R))
+    for k in range(m_filter):
+        out += sim_matrix[k:k + R, k:k + R]
+    min_sm = np.min(out)
+    i = np.arange(R)
+    band = (np.abs(i[:, None] - i[None, :]) < 5.0 / short_step) | (i[:, None] > i[None, :])
+    out[band] = min_sm
+    out[0:int(limit_1 * R), :] = min_sm
+    out[:, 0:int(limit_1 * R)] = min_sm
+    out[int(limit_2 * R):, :] = min_sm
+    out[:, int(limit_2 * R):] = min_sm
+    return out
+
+
+def thumbnail_grow(filtered, m_filter):
+    """audioSegmentation.py:1165-1182: start at the arg-max and grow along the diagonal to m_filter cells."""
+    rows, cols = np.unravel_index(filtered.argmax(), filtered.shape)
+    i1 = i2 = int(rows)
+    j1 = j2 = int(cols)
+    while i2 - i1 < m_filter:
+        if i1 <= 0 or j1 <= 0 or i2 >= filtered.shape[0] - 2 or j2 >= filtered.shape[1] - 2:
+            break
+        if filtered[i1 - 1, j1 - 1] > filtered[i2 + 1, j2 + 1]:
+            i1 -= 1
+            j1 -= 1
+        else:
+            i2 += 1
+            j2 += 1
+    return i1, i2, j1, j2
+
+
+def music_thumbnailing(signal, sampling_rate, short_window=1.0, short_step=0.5, thumb_size=10.0,
+                       limit_1=0, limit_2=1):
+    """audioSegmentation.py:1096-1190.  Returns (A1, A2, B1, B2, filtered similarity matrix)."""
+    signal = stereo_to_mono(signal)
+    st, _ = feature_extraction(signal, sampling_rate, sampling_rate * short_window, sampling_rate * short_step)
+    sim = self_similarity_matrix(st)
+    m_filter = int(round(thumb_size / short_step))
+    filt = thumbnail_filter(sim, m_filter, short_step, limit_1, limit_2)
+    i1, i2, j1, j2 = thumbnail_grow(filt, m_filter)
+    return short_step * i1, short_step * i2, short_step * j1, short_step * j2, filt
 
 
 def ill_conditioned_mfcc_frames(signal, sampling_rate, window, step, factor=1e4):

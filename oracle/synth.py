@@ -45,3 +45,25 @@ def fast_noise_clip(seed, n_samples):
     rng = np.random.default_rng(seed)
     x = rng.integers(-3000, 3000, n_samples, dtype=np.int16)
     return x
+
+
+def synth_song(seed, seconds, fs=16000, section=4.0):
+    """int16 "song" for the thumbnailing row: sections of `section` seconds in the pattern
+    A B A C A B ..., each section type a fixed chord of 4 partials + noise, so that the self-similarity matrix has
+    pronounced off-diagonal stripes.  Draw order: 3 x (4 frequencies, 4 amplitudes), then the noise vector."""
+    rng = np.random.default_rng(seed)
+    n = int(seconds * fs)
+    t = np.arange(n, dtype=np.float64) / fs
+    kinds = []
+    for _ in range(3):
+        kinds.append((rng.uniform(100.0, 0.3 * fs, 4), rng.uniform(0.3, 1.0, 4)))
+    pattern = [0, 1, 0, 2]
+    x = np.zeros(n)
+    sec_n = int(section * fs)
+    for b in range((n + sec_n - 1) // sec_n):
+        f, a = kinds[pattern[b % len(pattern)]]
+        sl = slice(b * sec_n, min(n, (b + 1) * sec_n))
+        for j in range(4):
+            x[sl] += a[j] * np.sin(2.0 * np.pi * f[j] * t[sl])
+    x = 5000.0 * x + 800.0 * rng.standard_normal(n)
+    return np.clip(np.round(x), -32768, 32767).astype(np.int16)
