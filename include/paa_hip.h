@@ -145,6 +145,27 @@ int paa_plan_beat_execute(paa_plan_t *plan, const double *d_st, double window_si
 /* name of the feature kernel the plan dispatches ("st_fast_800", "st_generic", ...)          */
 const char *paa_plan_kernel_name(const paa_plan_t *plan);
 
+/* ---- self-similarity matrix / music thumbnailing ----------------------------- */
+/* audioSegmentation.self_similarity_matrix (audioSegmentation.py:40-55): rows standardised like scikit-learn's
+ * StandardScaler, sim[i][j] = 1 - cosine distance of columns i, j (SciPy pdist semantics: clipped cosine, exact 1
+ * on the diagonal, NaN for zero vectors).  feats is [n_dims][n_vec] row-major -- the layout feature_extraction
+ * returns; sim is [n_vec][n_vec].  Host buffers:                                                */
+int paa_self_similarity_f64(const double *feats, int n_dims, int64_t n_vec, double *sim);
+/* the same on device buffers (asynchronous on the library stream); ld = row pitch of d_feats in doubles, so the
+ * output of paa_plan_execute for a one-clip plan can be passed as is                            */
+int paa_dev_self_similarity(const double *d_feats, int n_dims, int64_t n_vec, int64_t ld, double *d_sim);
+/* matrix part of audioSegmentation.music_thumbnailing (:1141-1165): moving sum of m_filter cells along the
+ * diagonals (convolve2d with eye(m_filter), 'valid'), cells with |i-j| < band, i > j or outside
+ * [int(limit_1 R), int(limit_2 R)) set to the global minimum, then the arg-max (first maximum in row-major
+ * order).  R = paa_thumbnail_rows(n_vec, m_filter) = n_vec - m_filter + 1; filt is [R][R]; pos2 (HOST) receives
+ * (row, column).  n_vec < m_filter is rejected with PAA_ERR_ARG.                                */
+int64_t paa_thumbnail_rows(int64_t n_vec, int m_filter);
+int paa_thumbnail_f64(const double *feats, int n_dims, int64_t n_vec, int m_filter, double band, double limit_1,
+                      double limit_2, double *filt, int64_t *pos2);
+/* device buffers in and out; synchronises the library stream before returning pos2             */
+int paa_dev_thumbnail_filter(const double *d_sim, int64_t n_vec, int m_filter, double band, double limit_1,
+                             double limit_2, double *d_filt, int64_t *pos2);
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI --------------------------------------- */
 #define PAA_COMM_ID_BYTES 128
 int paa_comm_unique_id(void *id_out /* PAA_COMM_ID_BYTES, rank 0 only */);

@@ -73,6 +73,13 @@ _SIGNATURES = {
     "paa_plan_mid_execute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "paa_plan_beat_execute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
     "paa_plan_kernel_name": (C.c_char_p, [C.c_void_p]),
+    "paa_self_similarity_f64": (C.c_int, [c_f64p, C.c_int, C.c_int64, c_f64p]),
+    "paa_dev_self_similarity": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
+    "paa_thumbnail_rows": (C.c_int64, [C.c_int64, C.c_int]),
+    "paa_thumbnail_f64": (C.c_int, [c_f64p, C.c_int, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double, c_f64p,
+                                    c_i64p]),
+    "paa_dev_thumbnail_filter": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double,
+                                           C.c_void_p, c_i64p]),
     "paa_comm_unique_id": (C.c_int, [C.c_void_p]),
     "paa_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
     "paa_comm_destroy": (C.c_int, []),

@@ -20,6 +20,7 @@
 #include "kernels_big.hpp"
 #include "kernels_fast.hpp"
 #include "kernels_generic.hpp"
+#include "kernels_sim.hpp"
 #include "tables.hpp"
 
 using namespace paa;
@@ -75,7 +76,9 @@ static hipStream_t g_stream = nullptr;
 static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 static std::map<std::pair<double, int>, std::unique_ptr<TableSet>> g_tables;
 static Scratch g_in, g_in2, g_out, g_mid;
+static Scratch g_sim_z, g_sim_small, g_sim_cand, g_sim_in, g_sim_out, g_sim_filt;     // self-similarity row
 static int g_force_generic = 0;
+static int g_num_cu = 256;       // multiProcessorCount of the selected device (MI355X: 256)
 // optional per-launch timing of the feature kernel (bench.py's roofline leg)
 static int g_prof = 0;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev;
@@ -574,6 +577,133 @@ extern "C" int paa_plan_beat_execute(paa_plan_t *plan, const double *d_st, doubl
 }
 
 // ------------------------------------------------------------------------------------------
+// self-similarity matrix / thumbnail filter (audioSegmentation.py:40-55, 1141-1165)
+// ------------------------------------------------------------------------------------------
+static std::mutex g_sim_mu;      // the scratch buffers below are shared: one enqueue sequence at a time
+
+extern "C" int64_t paa_thumbnail_rows(int64_t n_vec, int m_filter) {
+    if (m_filter < 1 || n_vec < m_filter) return 0;
+    return n_vec - m_filter + 1;
+}
+
+extern "C" int paa_dev_self_similarity(const double *d_feats, int n_dims, int64_t n_vec, int64_t ld, double *d_sim) {
+    if (!d_feats || !d_sim) return fail(PAA_ERR_ARG, "null buffer");
+    if (n_dims < 1 || n_vec < 1 || ld < n_vec) return fail(PAA_ERR_ARG, "bad feature matrix shape %d x %lld (ld %lld)", n_dims, (long long)n_vec, (long long)ld);
+    if (n_vec > 46340LL * 4) return fail(PAA_ERR_UNSUPPORTED, "%lld vectors: similarity matrix too large", (long long)n_vec);
+    int rc = ensure_init();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_sim_mu);
+    const int dims_pad = (n_dims + 3) / 4 * 4;
+    const long long ldz = (n_vec + kSimTile - 1) / kSimTile * kSimTile;
+    {
+        std::lock_guard<std::mutex> lk2(g_mu);
+        if ((rc = scratch_reserve(g_sim_z, (size_t)dims_pad * ldz * 8))) return rc;
+        if ((rc = scratch_reserve(g_sim_small, (size_t)(2 * n_dims + ldz) * 8))) return rc;
+    }
+    double *d_mean = (double *)g_sim_small.p, *d_scale = d_mean + n_dims, *d_norm = d_scale + n_dims;
+    hipLaunchKernelGGL(sim_row_stats_kernel, dim3((unsigned)n_dims), dim3(256), 0, g_stream, d_feats, (long long)n_vec,
+                       (long long)ld, d_mean, d_scale);
+    hipLaunchKernelGGL(sim_normalize_kernel, dim3((unsigned)((ldz + 255) / 256)), dim3(256), 0, g_stream, d_feats,
+                       n_dims, dims_pad, (long long)n_vec, (long long)ld, ldz, d_mean, d_scale, (double *)g_sim_z.p,
+                       d_norm);
+    const unsigned tiles = (unsigned)(ldz / kSimTile);
+    const size_t lds = (size_t)2 * kSimChunk * kSimPitch * 8;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sim_gram_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(sim_gram_kernel, dim3((unsigned)std::min<long long>((long long)tiles * tiles, 2LL * g_num_cu)), dim3(512), lds, g_stream, (const double *)g_sim_z.p, dims_pad,
+                       (long long)n_vec, ldz, d_norm, d_sim);
+    HIP_TRY(hipGetLastError());
+    return PAA_OK;
+}
+
+extern "C" int paa_dev_thumbnail_filter(const double *d_sim, int64_t n_vec, int m_filter, double band, double limit_1,
+                                        double limit_2, double *d_filt, int64_t *pos2) {
+    if (!d_sim || !d_filt || !pos2) return fail(PAA_ERR_ARG, "null buffer");
+    const long long R = paa_thumbnail_rows(n_vec, m_filter);
+    if (R < 1)
+        return fail(PAA_ERR_ARG, "fewer feature vectors (%lld) than the thumbnail filter length (%d)",
+                    (long long)n_vec, m_filter);
+    if (!(limit_1 >= 0.0) || !(limit_2 >= 0.0)) return fail(PAA_ERR_ARG, "limit_1 / limit_2 must be >= 0");
+    int rc = ensure_init();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_sim_mu);
+    const long long lim_lo = (long long)(limit_1 * (double)R), lim_hi = (long long)(limit_2 * (double)R);   // int(), :1157-1160
+    const unsigned gx = (unsigned)((R + kDiagRun - 1 + 255) / 256), gy = (unsigned)((R + kDiagRun - 1) / kDiagRun);
+    const unsigned mx = (unsigned)((R + 1023) / 1024), my = (unsigned)((R + kMaskRows - 1) / kMaskRows);
+    if (my > 65535u) return fail(PAA_ERR_UNSUPPORTED, "%lld rows: thumbnail matrix too large", R);
+    const long long n_min = (long long)gx * gy, n_cand = (long long)mx * my;
+    {
+        std::lock_guard<std::mutex> lk2(g_mu);
+        if ((rc = scratch_reserve(g_sim_cand, (size_t)(n_min + 2 * n_cand + 4) * 8))) return rc;
+    }
+    double *d_min = (double *)g_sim_cand.p, *d_cval = d_min + n_min + 1;
+    long long *d_cidx = (long long *)(d_cval + n_cand), *d_best = d_cidx + n_cand;
+    hipLaunchKernelGGL(thumb_diag_kernel, dim3(gx, gy), dim3(256), 0, g_stream, d_sim, (long long)n_vec, m_filter, R,
+                       d_filt, d_min);
+    hipLaunchKernelGGL(thumb_min_kernel, dim3(1), dim3(1024), 0, g_stream, (const double *)d_min, n_min, d_min + n_min);
+    hipLaunchKernelGGL(thumb_mask_kernel, dim3(mx, my), dim3(256), 0, g_stream, d_filt, R, band, lim_lo, lim_hi,
+                       (const double *)(d_min + n_min), d_cval, d_cidx);
+    hipLaunchKernelGGL(thumb_argmax_kernel, dim3(1), dim3(1024), 0, g_stream, (const double *)d_cval,
+                       (const long long *)d_cidx, n_cand, d_best);
+    HIP_TRY(hipGetLastError());
+    long long best = 0;
+    HIP_TRY(hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    pos2[0] = best / R;
+    pos2[1] = best % R;
+    return PAA_OK;
+}
+
+
+extern "C" int paa_self_similarity_f64(const double *feats, int n_dims, int64_t n_vec, double *sim) {
+    if (!feats || !sim) return fail(PAA_ERR_ARG, "null buffer");
+    if (n_dims < 1 || n_vec < 1) return fail(PAA_ERR_ARG, "empty feature matrix");
+    int rc = ensure_init();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> api_lock(g_api_mu);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if ((rc = scratch_reserve(g_sim_in, (size_t)n_dims * n_vec * 8))) return rc;
+        if ((rc = scratch_reserve(g_sim_out, (size_t)n_vec * n_vec * 8))) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(g_sim_in.p, feats, (size_t)n_dims * n_vec * 8, hipMemcpyHostToDevice, g_stream));
+    if ((rc = paa_dev_self_similarity((const double *)g_sim_in.p, n_dims, n_vec, n_vec, (double *)g_sim_out.p))) return rc;
+    HIP_TRY(hipMemcpyAsync(sim, g_sim_out.p, (size_t)n_vec * n_vec * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return PAA_OK;
+}
+
+extern "C" int paa_thumbnail_f64(const double *feats, int n_dims, int64_t n_vec, int m_filter, double band,
+                                 double limit_1, double limit_2, double *filt, int64_t *pos2) {
+    if (!feats || !filt || !pos2) return fail(PAA_ERR_ARG, "null buffer");
+    if (n_dims < 1 || n_vec < 1) return fail(PAA_ERR_ARG, "empty feature matrix");
+    const long long R = paa_thumbnail_rows(n_vec, m_filter);
+    if (R < 1)
+        return fail(PAA_ERR_ARG, "fewer feature vectors (%lld) than the thumbnail filter length (%d)",
+                    (long long)n_vec, m_filter);
+    int rc = ensure_init();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> api_lock(g_api_mu);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if ((rc = scratch_reserve(g_sim_in, (size_t)n_dims * n_vec * 8))) return rc;
+        if ((rc = scratch_reserve(g_sim_out, (size_t)n_vec * n_vec * 8))) return rc;
+        if ((rc = scratch_reserve(g_sim_filt, (size_t)R * R * 8))) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(g_sim_in.p, feats, (size_t)n_dims * n_vec * 8, hipMemcpyHostToDevice, g_stream));
+    if ((rc = paa_dev_self_similarity((const double *)g_sim_in.p, n_dims, n_vec, n_vec, (double *)g_sim_out.p))) return rc;
+    if ((rc = paa_dev_thumbnail_filter((const double *)g_sim_out.p, n_vec, m_filter, band, limit_1, limit_2,
+                                       (double *)g_sim_filt.p, pos2))) return rc;
+    HIP_TRY(hipMemcpyAsync(filt, g_sim_filt.p, (size_t)R * R * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return PAA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // library / device management
 // ------------------------------------------------------------------------------------------
 extern "C" const char *paa_version(void) { return "paa_hip 0.1 (gfx950)"; }
@@ -599,6 +729,10 @@ extern "C" int paa_init(int device_id) {
     HIP_TRY(hipEventCreate(&g_ev0));
     HIP_TRY(hipEventCreate(&g_ev1));
     g_device = device_id;
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && ncu > 0) g_num_cu = ncu;
+    }
     const char *fg = getenv("PAA_HIP_FORCE_GENERIC");
     g_force_generic = (fg && fg[0] == '1') ? 1 : 0;
     return PAA_OK;
@@ -609,7 +743,7 @@ extern "C" void paa_shutdown(void) {
     if (g_stream) (void)hipStreamSynchronize(g_stream);
     for (auto &kv : g_tables) free_tables(*kv.second);
     g_tables.clear();
-    for (Scratch *s : {&g_in, &g_in2, &g_out, &g_mid}) { if (s->p) (void)hipFree(s->p); s->p = nullptr; s->cap = 0; }
+    for (Scratch *s : {&g_in, &g_in2, &g_out, &g_mid, &g_sim_z, &g_sim_small, &g_sim_cand, &g_sim_in, &g_sim_out, &g_sim_filt}) { if (s->p) (void)hipFree(s->p); s->p = nullptr; s->cap = 0; }
     if (g_ev0) (void)hipEventDestroy(g_ev0);
     if (g_ev1) (void)hipEventDestroy(g_ev1);
     if (g_stream) (void)hipStreamDestroy(g_stream);
