@@ -78,7 +78,6 @@ static std::map<std::pair<double, int>, std::unique_ptr<TableSet>> g_tables;
 static Scratch g_in, g_in2, g_out, g_mid;
 static Scratch g_sim_z, g_sim_small, g_sim_cand, g_sim_in, g_sim_out, g_sim_filt;     // self-similarity row
 static int g_force_generic = 0;
-static int g_f800_w8 = 0;        // PAA_F800_W8=1: two waves per SIMD for the 800/400 kernel
 static int g_num_cu = 256;       // multiProcessorCount of the selected device (MI355X: 256)
 // optional per-launch timing of the feature kernel (bench.py's roofline leg)
 static int g_prof = 0;
@@ -289,7 +288,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     // ---- kernel choice + tiles
     p->fast = 0;
     if (mode == 0 && !g_force_generic) {
-        rc = fast_select(window, step, sample_kind, fs, tab->fast, tab->fft, tab->mel, tab->chroma, p->fl, g_f800_w8);
+        rc = fast_select(window, step, sample_kind, fs, tab->fast, tab->fft, tab->mel, tab->chroma, p->fl);
         if (rc < 0) return fail(rc, "building the tables of the specialised kernel failed");
         p->fast = rc;
     }
@@ -736,8 +735,6 @@ extern "C" int paa_init(int device_id) {
     }
     const char *fg = getenv("PAA_HIP_FORCE_GENERIC");
     g_force_generic = (fg && fg[0] == '1') ? 1 : 0;
-    const char *w8 = getenv("PAA_F800_W8");
-    g_f800_w8 = (w8 && w8[0] == '1') ? 1 : 0;
     return PAA_OK;
 }
 
