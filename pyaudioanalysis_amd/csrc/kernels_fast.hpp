@@ -65,6 +65,7 @@ constexpr int W = 800, NF = 400, QUAD = 4;
 constexpr int RAW_PAD = 8;                          // raw[RAW_PAD + i]; raw[RAW_PAD - 1] = sample before
 constexpr int CHUNK = 40;                           // time-domain partials are formed over 40-sample chunks
 constexpr int FV_STRIDE = 34;
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 constexpr int TW_STRIDE = 13;                       // twiddle tables: one column per ACTIVE pass-2 lane (p = 0..12)
 constexpr int CH_STRIDE = 12;                       // chroma gather lists: one column per pitch class
 
@@ -174,11 +175,13 @@ __device__ __forceinline__ double fast_sqrt(double x) {
 // magnitude variant: one coupled Newton step (relative error ~ (rsq error)^2, far below the 1e-4 parity bound
 // even for a 2^-20 seed); measured against the two-step version in tests/test_parity_gpu.py tolerances
 __device__ __forceinline__ double mag_sqrt(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
+    // x is either exactly 0 or far above 1e-300 (squares of sums of integers and their round-off), so clamping the
+    // seed's argument replaces the x > 0 select: 0 * rsq(1e-300) = 0 goes through the Newton step unchanged
+    const double y = __builtin_amdgcn_rsq(fmax(x, 1e-300));
     const double g = x * y;
     const double h = 0.5 * y;
     const double r = fma(-h, g, 0.5);
-    return (x > 0.0) ? fma(g, r, g) : 0.0;
+    return fma(g, r, g);
 }
 
 // a / b for finite b != 0 to ~1 ulp: v_rcp_f64 seed, two Newton steps, one residual correction (the IEEE
@@ -312,9 +315,15 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
     const double delta_mu = mu - (double)m_int;                    // |.| <= 1/2
     const double dc_shift = 2.0 * (double)W * delta_mu;
     const double y_scale2 = (nm.inv * sc) * (nm.inv * sc);         // y = (x' - delta) * inv / 2^15
-    // integer sign thresholds: sign(x/2^15 - mean) = sign(x - mu)
-    const int thr_pos = (int)fmin(fmax(floor(mu) + 1.0, -40000.0), 40000.0);   // x >= thr_pos  <=> positive
-    const int thr_neg = (int)fmin(fmax(ceil(mu) - 1.0, -40000.0), 40000.0);    // x <= thr_neg  <=> negative
+    // sign(x/2^15 - mean) = sign(x - mu) in packed 16-bit integers (mu lies inside the int16 range: it is a mean of int16)
+    const double mu_fl = floor(mu);
+    const bool mu_whole = (mu_fl == mu);
+    const short zb_ = (short)(int)fmin(fmax(mu_fl, -32768.0), 32767.0);
+    const s16x2 zc_b = {zb_, zb_};
+    const s16x2 zc_lo = mu_whole ? (s16x2){-1, -1} : (s16x2){0, 0};
+    const s16x2 zc_mul = mu_whole ? (s16x2){1, 1} : (s16x2){2, 2};
+    const s16x2 zc_add = mu_whole ? (s16x2){0, 0} : (s16x2){-1, -1};
+    const s16x2 zc_one = {1, 1};
 
     // pass-2 columns of this lane; the twiddles W400^(r p) and W800^(p + 25 q) sit in the shared LDS table
     const int pa = i, pb = (i == 0) ? 0 : 25 - i;
@@ -366,38 +375,45 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
         PAA_TICK(0)
 
         // ---------------- time domain: chunk partials (ShortTermFeatures.py:22-51)
+        // Two samples per 32-bit lane operation: v_dot2 gives x0^2 + x1^2 and x0 + x1, the sign of x - mu comes from
+        // packed 16-bit saturating arithmetic:  s = clamp(sat(x - floor(mu)), lo, 1) * a + c  with (lo, a, c) =
+        // (-1, 1, 0) when mu is a whole number (sign 0 exists) and (0, 2, -1) otherwise (x - floor(mu) >= 1 <=> +1).
         for (int ch = lane; ch < NCHUNK; ch += 64) {
             const int4 *p4 = reinterpret_cast<const int4 *>(raw + RAW_PAD + CHUNK * ch);
-            const int prev = raw[RAW_PAD + CHUNK * ch - 1];
-            int sprev = (prev >= thr_pos) - (prev <= thr_neg);
-            // sum y^2 over the chunk = (inv/2^15)^2 * sum (x' - delta)^2 with x' = x - m_int an exact integer and
-            // |delta| = |mu - m_int| <= 1/2, so the expansion below has no cancellation to speak of
-            double e2 = 0.0;
-            int s1 = 0;
-            int z = 0, zfirst = 0;
+            // the dword before the chunk holds the previous sample in its upper half
+            s16x2 sp = __builtin_bit_cast(s16x2, reinterpret_cast<const int *>(raw + RAW_PAD + CHUNK * ch)[-1]);
+            sp = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_elementwise_sub_sat(sp, zc_b), zc_lo), zc_one) * zc_mul + zc_add;
+            double sx2 = 0.0;            // sum x^2 (exact: every term is an integer below 2^31, the sum below 2^53)
+            int sx = 0;                  // sum x
+            s16x2 zacc = {0, 0};
+            int zfirst = 0;
 #pragma unroll
             for (int v4 = 0; v4 < CHUNK / 8; ++v4) {
                 const int4 q = p4[v4];
                 const int w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
-                    const int xa = (int)(short)(w[h] & 0xffff), xb = w[h] >> 16;
-                    const int ca = xa - m_int, cb = xb - m_int;
-                    const double fa = (double)ca, fb = (double)cb;
-                    e2 = fma(fa, fa, e2);
-                    e2 = fma(fb, fb, e2);
-                    s1 += ca + cb;
-                    const int sa = (xa >= thr_pos) - (xa <= thr_neg);
-                    const int sb = (xb >= thr_pos) - (xb <= thr_neg);
-                    const int da = abs(sa - sprev);
-                    if (v4 == 0 && h == 0) zfirst = da;
-                    z += da + abs(sb - sa);
-                    sprev = sb;
+                    const s16x2 cur = __builtin_bit_cast(s16x2, w[h]);
+                    const s16x2 sg = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_elementwise_sub_sat(cur, zc_b), zc_lo), zc_one) * zc_mul + zc_add;
+                    // (sign of the sample before the pair, sign of its first sample)
+                    const s16x2 sh = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(__builtin_bit_cast(unsigned, sg), __builtin_bit_cast(unsigned, sp), 16));
+                    const s16x2 df = sg - sh;
+                    const s16x2 ad = __builtin_elementwise_max(df, -df);
+                    if (v4 == 0 && h == 0) zfirst = ad.x;
+                    zacc += ad;
+                    sp = sg;
+                    sx2 += (double)(unsigned)__builtin_amdgcn_sdot2(cur, cur, 0, false);     // 2^31 for (-32768, -32768)
+                    sx = __builtin_amdgcn_sdot2(cur, zc_one, sx, false);
                 }
             }
+            // sum (x - m_int)^2 and sum (x - m_int) in exact integer arithmetic, then the residual mean as before:
+            // sum y^2 over the chunk = (inv/2^15)^2 * sum (x' - delta)^2 with x' = x - m_int, |delta| <= 1/2
+            const double mi = (double)m_int;
+            const double e2 = fma(mi, fma((double)CHUNK, mi, -2.0 * (double)sx), sx2);
+            const int s1 = sx - CHUNK * m_int;
             const double e = y_scale2 * fma(delta_mu, fma(-2.0, (double)s1, (double)CHUNK * delta_mu), e2);
             cE[ch] = e;
-            cZ[ch] = z;
+            cZ[ch] = (int)zacc.x + (int)zacc.y;
             cF[ch] = zfirst;
         }
 
