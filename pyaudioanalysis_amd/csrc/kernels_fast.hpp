@@ -332,6 +332,7 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
 
     const int t_end = tl.t0 + tl.cnt;
     int q0 = tl.t0 >= QUAD ? tl.t0 - QUAD : 0;
+    const int q_first = q0;
     int slot0 = 1;                   // slots of this quad: slot0 .. slot0+3 (mod 5); previous = slot0-1
     double vlast = 0.0;              // lane l < 34: feature l of the frame before this quad
 
@@ -359,6 +360,10 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
         {
             const long long base = (long long)q0 * S;
             const int16_t *src = xc + base;
+            // the sample before the quad: the previous iteration's staging still holds it (one global load per run
+            // instead of an exposed one per iteration)
+            int16_t before = 0;
+            if (lane == 0) before = (q0 != q_first) ? raw[RAW_PAD + QUAD * S - 1] : ((base > 0) ? src[-1] : src[0]);
             if (pre_ok) {
                 int4 *d4 = reinterpret_cast<int4 *>(raw + RAW_PAD);
 #pragma unroll
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
                 const long long avail = c.n - base;
                 for (int n = lane; n < RAW_N; n += 64) raw[RAW_PAD + n] = (n < avail) ? src[n] : (int16_t)0;
             }
-            if (lane == 0) raw[RAW_PAD - 1] = (base > 0) ? src[-1] : src[0];
+            if (lane == 0) raw[RAW_PAD - 1] = before;
             if (q0 + QUAD < t_end) PAA_F800_FETCH(q0 + QUAD)
         }
         wsync();
