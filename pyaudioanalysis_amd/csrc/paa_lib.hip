@@ -96,6 +96,7 @@ static int ensure_init() {
 
 template <typename T>
 static int upload(T **dst, const void *src, size_t count) {
+    if (*dst) (void)hipFree(*dst);          // a retry after a failed build must not leak the earlier copy
     *dst = nullptr;
     if (count == 0) count = 1;
     HIP_TRY(hipMalloc((void **)dst, count * sizeof(T)));
@@ -129,11 +130,14 @@ static int get_tables(double fs, int window, bool need_mel, bool need_chroma, Ta
         t->window = window;
         build_fft_plan(window, t->fft);
         int rc;
-        if ((rc = upload(&t->d_tw, t->fft.tw.data(), t->fft.tw.size() / 2))) return rc;
-        if ((rc = upload(&t->d_post, t->fft.post.data(), t->fft.post.size() / 2))) return rc;
         double dct[kNumMfcc * kNumMel];
         build_dct(dct);
-        if ((rc = upload(&t->d_dct, dct, (size_t)kNumMfcc * kNumMel))) return rc;
+        if ((rc = upload(&t->d_tw, t->fft.tw.data(), t->fft.tw.size() / 2)) ||
+            (rc = upload(&t->d_post, t->fft.post.data(), t->fft.post.size() / 2)) ||
+            (rc = upload(&t->d_dct, dct, (size_t)kNumMfcc * kNumMel))) {
+            free_tables(*t);
+            return rc;
+        }
         it = g_tables.emplace(key, std::move(t)).first;
     }
     TableSet *t = it->second.get();
@@ -331,6 +335,9 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
             tiles.push_back(tl);
         }
     p->n_tiles = (long long)tiles.size();
+    if (p->n_tiles > 0x7fffffffLL || n_chunks > 0x7fffffffLL || n_clips > 0x7fffffffLL)
+        return fail(PAA_ERR_UNSUPPORTED, "batch too large for one launch (%lld runs, %lld statistics chunks, %lld clips)",
+                    p->n_tiles, n_chunks, (long long)n_clips);
     std::vector<StatChunk> chunks;
     chunks.reserve((size_t)n_chunks);
     for (int64_t c = 0; c < n_clips; ++c)
@@ -542,7 +549,6 @@ extern "C" int paa_plan_mid_execute(paa_plan_t *plan, const double *d_st, int64_
             o += 2LL * plan->P.F * paa_num_mid_windows(plan->clips[c].T, mid_step_ratio);
         }
         if (g_stream) HIP_TRY(hipStreamSynchronize(g_stream));
-        (void)hipFree(plan->d_mid_off);
         int rc = upload(&plan->d_mid_off, off.data(), off.size());
         if (rc) return rc;
         plan->mid_off_step = mid_step_ratio;
