@@ -506,39 +506,44 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
         const int t = q0 + g;
         const double *cur = spec + ((slot0 + g) % 5) * NF;
         const double *prv = (t == 0) ? cur : spec + ((slot0 + g + 4) % 5) * NF;
-        // spectral entropy operands: lane i < 10 owns block i of 40 bins (:85-107)
-        double pblk = 0.0;
-        {
-            const double2 *c2 = reinterpret_cast<const double2 *>(cur + 40 * (i < 10 ? i : 0));
-            double2 blk[20];
-#pragma unroll
-            for (int m = 0; m < 20; ++m) blk[m] = c2[m];
-            double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-#pragma unroll
-            for (int m = 0; m < 20; m += 2) {
-                p0 = fma(blk[m].x, blk[m].x, p0); p1 = fma(blk[m].y, blk[m].y, p1);
-                p2 = fma(blk[m + 1].x, blk[m + 1].x, p2); p3 = fma(blk[m + 1].y, blk[m + 1].y, p3);
-            }
-            pblk = (i < 10) ? (p0 + p1) + (p2 + p3) : 0.0;
-        }
-        asm volatile("" ::: "memory");
         double Xc[25], Xv[25];
 #pragma unroll
         for (int m = 0; m < 25; ++m) { Xc[m] = cur[25 * i + m]; Xv[m] = prv[25 * i + m]; }
         // sums over the lane's 25 bins; two interleaved accumulator sets keep the dependent chains short.
         // sum(ind * X) with ind = (k+1) f0 is f0 * [(25 i + 1) * sum X + sum m X]   (small exact integers)
-        double sXa = 0.0, sXb = 0.0, sPa = 0.0, sPb = 0.0, sMa = 0.0, sMb = 0.0, sVa = 0.0, sVb = 0.0, mx = 0.0;
+        // X^2 is accumulated in five 5-bin chunks: their sum is the lane total (roll-off scan), and cut at the lane's
+        // 40-bin block boundary they give the spectral-entropy block energies (:85-107) without a second sweep.
+        double sXa = 0.0, sXb = 0.0, sMa = 0.0, sMb = 0.0, sVa = 0.0, sVb = 0.0, mx = 0.0;
+        double c5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int m = 0; m < 24; m += 2) {
             const double X0 = Xc[m], X1 = Xc[m + 1];
             sXa += X0; sXb += X1;
             sVa += Xv[m]; sVb += Xv[m + 1];
             sMa = fma((double)m, X0, sMa); sMb = fma((double)(m + 1), X1, sMb);
-            sPa = fma(X0, X0, sPa); sPb = fma(X1, X1, sPb);
+            c5[m / 5] = fma(X0, X0, c5[m / 5]); c5[(m + 1) / 5] = fma(X1, X1, c5[(m + 1) / 5]);
             mx = fmax(mx, fmax(X0, X1));
         }
-        sXa += Xc[24]; sVa += Xv[24]; sMa = fma(24.0, Xc[24], sMa); sPa = fma(Xc[24], Xc[24], sPa); mx = fmax(mx, Xc[24]);
-        const double cs = sPa + sPb;
+        sXa += Xc[24]; sVa += Xv[24]; sMa = fma(24.0, Xc[24], sMa); c5[4] = fma(Xc[24], Xc[24], c5[4]); mx = fmax(mx, Xc[24]);
+        const double cs = ((c5[0] + c5[1]) + (c5[2] + c5[3])) + c5[4];
+        // Lane i holds bins [25 i, 25 i + 25); block b holds bins [40 b, 40 b + 40).  The first kcut chunks of the lane
+        // lie in block floor(25 i / 40), the rest in the next one; the pattern repeats every 8 lanes (200 bins):
+        // kcut = 5 3 5 1 4 5 2 5.  "Home" lanes (i & 7 in {0,2,4,5,7}) are the first lane of a block: block energy =
+        // own lower part + upper part of the lane before + lower part of the lane after when that one is not a home.
+        double pblk;
+        {
+            const int i7 = i & 7;
+            const int kcut = (0x52541535u >> (4 * i7)) & 7;
+            const double pL = c5[0] + ((kcut > 1) ? c5[1] : 0.0) + ((kcut > 2) ? c5[2] : 0.0) + ((kcut > 3) ? c5[3] : 0.0) +
+                              ((kcut > 4) ? c5[4] : 0.0);
+            const double pH = ((kcut > 1) ? 0.0 : c5[1]) + ((kcut > 2) ? 0.0 : c5[2]) + ((kcut > 3) ? 0.0 : c5[3]) +
+                              ((kcut > 4) ? 0.0 : c5[4]);
+            const double from_prev = dpp_mov<0x111>(pH);        // row_shr:1, lane 0 of the row receives 0
+            const double from_next = dpp_mov<0x101>(pL);        // row_shl:1, lane 15 receives 0
+            const bool next_joins = (i7 == 0) || (i7 == 2) || (i7 == 5);      // lane i + 1 is not a home
+            pblk = pL + from_prev + (next_joins ? from_next : 0.0);
+        }
+        const bool home = ((0xB5u >> (i & 7)) & 1u) != 0;          // i & 7 in {0, 2, 4, 5, 7}
         const double base_k = (double)(25 * i + 1);
         double sX = sXa + sXb;
         double sIX = f0 * fma(base_k, sX, sMa + sMb);
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
         double ent_f, ent_e;
         {
             const double sf = fast_div(pblk, sP + kEps), se = fast_div(eblk, e_tot + kEps);
-            ent_f = group_sum((i < 10) ? -(sf * fast_log2(sf + kEps)) : 0.0);
+            ent_f = group_sum(home ? -(sf * fast_log2(sf + kEps)) : 0.0);
             ent_e = group_sum((i < 10) ? -(se * fast_log2(se + kEps)) : 0.0);
         }
         // zero crossings: 20 chunks of the frame minus the pair that straddles the frame start (:22-26)
