@@ -98,7 +98,24 @@ __global__ __launch_bounds__(512, 4) void sim_gram_kernel(const double *__restri
     const int wi = 32 * (wave >> 1), wj = 64 * (wave & 1);
     const int lm = lane & 15, lk = lane >> 4;
     // persistent workgroups: the stores of one tile drain while the next tile's panels load and multiply
+    // (requesting the next tile's first chunk BEFORE the epilogue was measured: the 16 extra live registers spill at
+    // the 128-register budget and the kernel gets slower)
     const long long tiles = ld / kSimTile;
+    constexpr int PF = kSimChunk * 64 / 512;                         // double2 per thread and panel: 4
+    double fax[PF], fay[PF], fbx[PF], fby[PF];                       // scalar arrays: these stay in registers
+    const int prow = threadIdx.x >> 6, pc2 = threadIdx.x & 63;       // element e = threadIdx.x + 512 q -> row prow + 8 q
+    // rows past the end of Z are replaced by its last row: they land in LDS rows no k-step reads
+#define PAA_SIM_FETCH(k0_, i0_, j0_)                                                                         \
+    _Pragma("unroll") for (int q = 0; q < PF; ++q) {                                                         \
+        const long long grow = min((k0_) + prow + 8 * q, dims_pad - 1);                                      \
+        const double2 ta_ = *reinterpret_cast<const double2 *>(z + grow * ld + (i0_) + 2 * pc2);             \
+        const double2 tb_ = *reinterpret_cast<const double2 *>(z + grow * ld + (j0_) + 2 * pc2);             \
+        fax[q] = ta_.x; fay[q] = ta_.y; fbx[q] = tb_.x; fby[q] = tb_.y;                                      \
+    }
+    if ((long long)blockIdx.x < tiles * tiles) {
+        const long long t0 = blockIdx.x;
+        PAA_SIM_FETCH(0, (t0 / tiles) * kSimTile, (t0 % tiles) * kSimTile)
+    }
     for (long long tile = blockIdx.x; tile < tiles * tiles; tile += gridDim.x) {
     const long long i0 = (tile / tiles) * kSimTile, j0 = (tile % tiles) * kSimTile;
     f64x4 acc[2][4];
@@ -106,19 +123,6 @@ __global__ __launch_bounds__(512, 4) void sim_gram_kernel(const double *__restri
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
-    // software pipeline: the next chunk's global loads are in flight while the matrix cores work on the current one
-    constexpr int PF = kSimChunk * 64 / 512;                         // double2 per thread and panel: 4
-    double fax[PF], fay[PF], fbx[PF], fby[PF];                       // scalar arrays: these stay in registers
-    const int prow = threadIdx.x >> 6, pc2 = threadIdx.x & 63;       // element e = threadIdx.x + 512 q -> row prow + 8 q
-    // rows past the end of Z are replaced by its last row: they land in LDS rows no k-step reads
-#define PAA_SIM_FETCH(k0_)                                                                                   \
-    _Pragma("unroll") for (int q = 0; q < PF; ++q) {                                                         \
-        const long long grow = min((k0_) + prow + 8 * q, dims_pad - 1);                                      \
-        const double2 ta_ = *reinterpret_cast<const double2 *>(z + grow * ld + i0 + 2 * pc2);                \
-        const double2 tb_ = *reinterpret_cast<const double2 *>(z + grow * ld + j0 + 2 * pc2);                \
-        fax[q] = ta_.x; fay[q] = ta_.y; fbx[q] = tb_.x; fby[q] = tb_.y;                                      \
-    }
-    PAA_SIM_FETCH(0)
     for (int k0 = 0; k0 < dims_pad; k0 += kSimChunk) {
         const int kc = min(kSimChunk, dims_pad - k0);                // multiple of 4
         __syncthreads();                                             // previous chunk fully consumed
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(512, 4) void sim_gram_kernel(const double *__restri
             *reinterpret_cast<double2 *>(pb + (prow + 8 * q) * kSimPitch + 2 * pc2) = make_double2(fbx[q], fby[q]);
         }
         __syncthreads();
-        if (k0 + kSimChunk < dims_pad) PAA_SIM_FETCH(k0 + kSimChunk)
+        if (k0 + kSimChunk < dims_pad) PAA_SIM_FETCH(k0 + kSimChunk, i0, j0)
         // operand maps of v_mfma_f64_16x16x4_f64: A[m = lane & 15][k = lane >> 4], B[k = lane >> 4][n = lane & 15];
         // A = Z^T, so both operands are read with the same (k, column) pattern
         for (int kk = 0; kk < kc; kk += 4) {
@@ -146,29 +150,44 @@ __global__ __launch_bounds__(512, 4) void sim_gram_kernel(const double *__restri
                     acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
     }
-#undef PAA_SIM_FETCH
-    // C/D map of the f64 form: column = lane & 15, row = (lane >> 4) + 4 * reg
+    // C/D map of the f64 form: column = lane & 15, row = (lane >> 4) + 4 * reg.  Rows of one lane are 4 apart, so one
+    // running pointer (step 4 n) serves the lane's 8 rows of a column block.
+    const long long n4 = 4 * n;
+    // the lane's 8 row norms and 4 column norms in one batch of loads (rnorm is padded to ld entries), so that the
+    // stores below do not each wait for a load of their own
+    double rr[8], cc[4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) rr[u] = rnorm[i0 + wi + lk + 4 * u];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) cc[b] = rnorm[j0 + wj + 16 * b + lm];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const long long col = j0 + wj + 16 * b + lm;
-        const double nc = rnorm[col];
+        long long row = i0 + wi + lk;
+        double *dst = sim + row * n + col;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const long long row = i0 + wi + 16 * a + lk + 4 * r;
                 if (row < n && col < n) {
                     // scipy's cosine distance: 1 - clip(u.v / (|u| |v|)); similarity = 1 - distance (:53-54).
                     // The reciprocal norms are multiplied first so that sim[i][j] and sim[j][i] round identically;
                     // 0 * inf = NaN for zero vectors mirrors scipy's 0/0; squareform's zero diagonal -> exactly 1
-                    double cosv = acc[a][b][r] * (rnorm[row] * nc);
+                    double cosv = acc[a][b][r] * (rr[4 * a + r] * cc[b]);
                     if (fabs(cosv) > 1.0) cosv = copysign(1.0, cosv);
                     const double dist = 1.0 - cosv;
-                    sim[row * n + col] = (row == col) ? 1.0 : 1.0 - dist;
+                    *dst = (row == col) ? 1.0 : 1.0 - dist;
                 }
+                row += 4;
+                dst += n4;
             }
     }
+    if (tile + gridDim.x < tiles * tiles) {       // first chunk of this workgroup's next tile
+        const long long tn = tile + gridDim.x;
+        PAA_SIM_FETCH(0, (tn / tiles) * kSimTile, (tn % tiles) * kSimTile)
+    }
     }   // tile loop
+#undef PAA_SIM_FETCH
 }
 
 // out[i][j] = sum_{k < M} S[i + k][j + k],  R = n - M + 1.  Thread (run, c): cells (i0 + s, c + s), s < kDiagRun,
