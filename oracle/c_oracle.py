@@ -30,6 +30,13 @@ def lib():
         L.paa_c_feature_extraction.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_longlong, ctypes.c_double,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.POINTER(ctypes.c_double)]
+        f64p = ctypes.POINTER(ctypes.c_double)
+        L.paa_c_spectrogram.restype = ctypes.c_longlong
+        L.paa_c_spectrogram.argtypes = [f64p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, f64p]
+        L.paa_c_chromagram.restype = ctypes.c_longlong
+        L.paa_c_chromagram.argtypes = [f64p, ctypes.c_longlong, ctypes.c_double, ctypes.c_int, ctypes.c_int, f64p]
+        L.paa_c_mid_statistics.restype = ctypes.c_longlong
+        L.paa_c_mid_statistics.argtypes = [f64p, ctypes.c_int, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, f64p]
         _lib = L
     return _lib
 
@@ -49,4 +56,41 @@ def feature_extraction(signal, fs, window, step, deltas=True):
     if rc in (-7, -8):
         raise IndexError("chroma / mel table index out of range")
     assert rc == n_frames, rc
+    return out
+
+
+def _f64(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def spectrogram(signal, window, step):
+    """ShortTermFeatures.spectrogram (:389-452) without the axes; returns the (rows, window // 2) matrix."""
+    window, step = int(window), int(step)
+    sig = np.ascontiguousarray(np.double(signal))
+    rows = int((len(sig) - window) / step) + 1
+    out = np.zeros((max(rows, 1), window // 2))
+    got = lib().paa_c_spectrogram(_f64(sig), len(sig), window, step, _f64(out))
+    assert got == rows, (got, rows)
+    return out
+
+
+def chromagram(signal, fs, window, step):
+    """ShortTermFeatures.chromagram (:324-386) without the axes; returns the (rows, 12) matrix."""
+    window, step = int(window), int(step)
+    sig = np.ascontiguousarray(np.double(signal))
+    rows = int((len(sig) - step - window) / step) + 1
+    out = np.zeros((max(rows, 1), 12))
+    got = lib().paa_c_chromagram(_f64(sig), len(sig), float(fs), window, step, _f64(out))
+    assert got == rows, (got, rows)
+    return out
+
+
+def mid_statistics(short_features, ratio, step_ratio):
+    """MidTermFeatures.py:110-126 on a (F, T) matrix."""
+    st = np.ascontiguousarray(short_features, dtype=np.float64)
+    F, T = st.shape
+    M = (T + step_ratio - 1) // step_ratio
+    out = np.empty((2 * F, M))
+    got = lib().paa_c_mid_statistics(_f64(st), F, T, int(ratio), int(step_ratio), _f64(out))
+    assert got == M, (got, M)
     return out

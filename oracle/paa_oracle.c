@@ -12,6 +12,8 @@
  *                              restated here as a recursive mixed-radix DFT, O(N sum of prime factors))
  *   34 features .............. ShortTermFeatures.py:22-140, 191-321, 626-667
  *   deltas / layout .......... ShortTermFeatures.py:668-685
+ *   spectrogram / chromagram . ShortTermFeatures.py:324-452 (incl. the truncated last chromagram frame)
+ *   mid-term mean / std ...... MidTermFeatures.py:110-126
  *
  * Build: gcc -O2 -shared -fPIC oracle/paa_oracle.c -o oracle/_build/libpaa_oracle.so -lm   (oracle/Makefile)
  */
@@ -275,4 +277,94 @@ long long paa_c_feature_extraction(const double *signal, long long n, double fs,
     free(x); free(X); free(Xp); free(tmp);
     tables_free(&t);
     return T;
+}
+
+
+/* ---- spectrogram / chromagram / mid-term statistics (ShortTermFeatures.py:324-452, MidTermFeatures.py:110-126) ---- */
+static double *normalized_copy(const double *signal, long long n) {
+    double *x = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    double mean = 0.0, peak = 0.0;
+    for (long long i = 0; i < n; ++i) { x[i] = signal[i] / 32768.0; mean += x[i]; }
+    mean /= (double)n;
+    for (long long i = 0; i < n; ++i) { x[i] -= mean; if (fabs(x[i]) > peak) peak = fabs(x[i]); }
+    for (long long i = 0; i < n; ++i) x[i] /= (peak + 1e-10);
+    return x;
+}
+
+/* |DFT_m(x)|[0:nf] / nf for a frame of m samples (m < window for the truncated chromagram tail) */
+static void magnitude_any(const double *x, int m, int nf, double *X) {
+    cpx *tw = (cpx *)malloc(sizeof(cpx) * (size_t)m), *in = (cpx *)malloc(sizeof(cpx) * (size_t)m);
+    cpx *out = (cpx *)malloc(sizeof(cpx) * (size_t)m), *scr = (cpx *)malloc(sizeof(cpx) * (size_t)(4 * m + 64));
+    for (int j = 0; j < m; ++j) {
+        const long double a = -6.283185307179586476925286766559L * (long double)j / (long double)m;
+        tw[j].re = (double)cosl(a); tw[j].im = (double)sinl(a);
+        in[j].re = x[j]; in[j].im = 0.0;
+    }
+    dft_rec(in, 1, out, m, m, tw, scr);
+    for (int k = 0; k < nf; ++k) X[k] = hypot(out[k].re, out[k].im) / (double)nf;
+    free(tw); free(in); free(out); free(scr);
+}
+
+/* rows = int((n - W) / S) + 1 are allocated, frame i starts at W + i S (:413-422); out is [rows][W/2], zero-filled
+ * rows stay zero.  Returns rows, 0 when too short. */
+long long paa_c_spectrogram(const double *signal, long long n, int window, int step, double *out) {
+    if (window < 2 || step < 1 || n < window) return 0;
+    const int nf = window / 2;
+    const long long rows = (n - window) / step + 1;
+    memset(out, 0, sizeof(double) * (size_t)(rows * nf));
+    double *x = normalized_copy(signal, n);
+    long long i = 0;
+    for (long long p = window; p < n - window + 1; p += step, ++i) magnitude_any(x + p, window, nf, out + i * nf);
+    free(x);
+    return rows;
+}
+
+/* rows = int((n - S - W) / S) + 1 (:347); loop range(W, n - S, S); the last frame may be shorter than W (:349-355).
+ * out is [rows][12].  Returns rows (>= 1), 0 when too short, or a negative table error. */
+long long paa_c_chromagram(const double *signal, long long n, double fs, int window, int step, double *out) {
+    if (window < 2 || step < 1 || n - step - window < 0) return 0;
+    tables_t t;
+    const int rc = tables_build(&t, fs, window);
+    if (rc) { tables_free(&t); return rc; }
+    const int nf = t.nfft;
+    const long long rows = (n - step - window) / step + 1;
+    memset(out, 0, sizeof(double) * (size_t)(rows * 12));
+    double *x = normalized_copy(signal, n);
+    double *X = (double *)malloc(sizeof(double) * (size_t)nf);
+    long long i = 0;
+    for (long long p = window; p < n - step; p += step, ++i) {
+        const long long len = (p + window <= n) ? window : n - p;
+        if (len < nf) { free(x); free(X); tables_free(&t); return -6; }      /* X[0:nf] cannot be taken (:354) */
+        magnitude_any(x + p, (int)len, nf, X);
+        double tot = 0.0, c[12] = {0};
+        for (int k = 0; k < nf; ++k) tot += X[k] * X[k];
+        for (int e = 0; e < t.n_ch; ++e) c[t.ch_slot[e] % 12] += X[t.ch_src[e]] * X[t.ch_src[e]] * t.ch_w[e];
+        for (int k = 0; k < 12; ++k) out[i * 12 + k] = (tot == 0.0) ? c[k] / EPS : c[k] / tot;
+    }
+    free(x); free(X);
+    tables_free(&t);
+    return rows;
+}
+
+/* st is [F][T]; out is [2F][M], M = ceil(T / step_ratio): mean and population std of st[i][c : min(c + ratio, T)],
+ * non-finite values replaced like numpy.nan_to_num */
+long long paa_c_mid_statistics(const double *st, int F, long long T, long long ratio, long long step_ratio, double *out) {
+    if (F < 1 || T < 1 || step_ratio < 1) return 0;
+    const long long M = (T + step_ratio - 1) / step_ratio;
+    for (int i = 0; i < F; ++i)
+        for (long long m = 0; m < M; ++m) {
+            const long long c0 = m * step_ratio, c1 = (c0 + ratio < T) ? c0 + ratio : T;
+            double mean = 0.0, var = 0.0;
+            for (long long k = c0; k < c1; ++k) mean += st[(long long)i * T + k];
+            mean /= (double)(c1 - c0);
+            for (long long k = c0; k < c1; ++k) { const double d = st[(long long)i * T + k] - mean; var += d * d; }
+            double sd = sqrt(var / (double)(c1 - c0));
+            if (isnan(mean)) mean = 0.0;
+            if (isnan(sd)) sd = 0.0;
+            if (isinf(mean)) mean = mean > 0 ? 1.7976931348623157e308 : -1.7976931348623157e308;
+            if (isinf(sd)) sd = 1.7976931348623157e308;
+            out[(long long)i * M + m] = mean;
+            out[(long long)(F + i) * M + m] = sd;
+        }
+    return M;
 }
