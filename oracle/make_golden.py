@@ -114,7 +114,7 @@ def main():
     print("total %.2f MB" % (tot / 1e6))
 
 
-if __name__ == "__main__" and "--dir" not in sys.argv and "--thumb" not in sys.argv:
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--dir", "--thumb", "--wide")):
     main()
 
 
@@ -142,7 +142,18 @@ def directory_goldens():
         with contextlib.redirect_stdout(io.StringIO()):
             f_beat, list_beat, names_beat = ref_mt.directory_feature_extraction(d, 1.0, 1.0, 0.05, 0.05, compute_beat=True)
             f_nobeat, list_nb, names_nb = ref_mt.directory_feature_extraction(d, 1.0, 1.0, 0.05, 0.05, compute_beat=False)
-            X, Y, flist = ref_mt.directory_feature_extraction_no_avg(d, 1.0, 1.0, 0.05, 0.05) if False else (None, None, None)
+        # directory_feature_extraction_no_avg (:263-309) has no size check: the reference dies on the zero-byte file
+        # (scipy.io.wavfile: ValueError "File format b'' not understood") -- recorded, then run without that file
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                ref_mt.directory_feature_extraction_no_avg(d, 1.0, 1.0, 0.05, 0.05)
+            out["noavg_empty_file_error"] = np.array("")
+        except Exception as exc:
+            out["noavg_empty_file_error"] = np.array(type(exc).__name__)
+        os.remove(os.path.join(d, "f_empty.wav"))
+        with contextlib.redirect_stdout(io.StringIO()):
+            X, Y, flist = ref_mt.directory_feature_extraction_no_avg(d, 1.0, 1.0, 0.05, 0.05)
+        out.update(noavg_features=X, noavg_index=Y, noavg_files=np.array([os.path.basename(p) for p in flist]))
         out.update(features_beat=f_beat, files_beat=np.array([os.path.basename(p) for p in list_beat]),
                    names_beat=np.array(names_beat), features_nobeat=f_nobeat,
                    files_nobeat=np.array([os.path.basename(p) for p in list_nb]), names_nobeat=np.array(names_nb))
@@ -199,3 +210,52 @@ def thumbnail_goldens():
 
 if __name__ == "__main__" and "--thumb" in sys.argv:
     thumbnail_goldens()
+
+
+def wide_goldens():
+    """Round 2: the rest of SURVEY 8c's list -- the in-tree WAVs round 1 left out (count2, diarizationExample2,
+    recording2/3), full-length files where the .npz stays small, and the (800,800) / (640,640) / (320,160) shapes on
+    two more files.  Separate entry point so that the round-1 files are not rewritten."""
+    ref_st, ref_mt, ref_io = load_reference.load()
+
+    def st_case(name, sig, fs, win, step, deltas=True):
+        F, names = ref_st.feature_extraction(sig, fs, win, step, deltas)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="st", signal=sig, fs=fs, window=win, step=step,
+                            deltas=deltas, features=F, names=np.array(names))
+        print(name, F.shape)
+
+    def spec_case(name, sig, fs, win, step):
+        with contextlib.redirect_stdout(io.StringIO()):
+            S, t_ax, f_ax = ref_st.spectrogram(sig, fs, win, step)
+        C, ct_ax, cf_ax = ref_st.chromagram(sig, fs, win, step)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="spec", signal=sig, fs=fs, window=win, step=step,
+                            specgram=S, spec_time=np.array(t_ax), spec_freq=np.array(f_ax), chromagram=C,
+                            chroma_time=np.array(ct_ax), chroma_names=np.array(cf_ax))
+        print(name, S.shape, C.shape)
+
+    for stem in ("count2", "diarizationExample2", "recording2", "recording3"):
+        fs, x = wav("pyAudioAnalysis/data/%s.wav" % stem, 2.0)
+        st_case("%s2s_800_400" % stem, x, fs, 800, 400)
+    # full-length files (5.9 s, 7 s, 10.5 s, 22.3 s)
+    fs, x = wav("pyAudioAnalysis/data/count.wav")
+    st_case("count_full_800_400", x, fs, 800, 400)
+    st_case("count_full_800_800", x, fs, 800, 800)
+    st_case("count_full_640_640", x, fs, 640, 640)
+    st_case("count_full_320_160", x, fs, 320, 160, deltas=False)
+    fs, x = wav("pyAudioAnalysis/data/speech_music_sample.wav")
+    st_case("speech_music_full_800_800", x, fs, 800, 800)
+    st_case("speech_music_full_640_640", x, fs, 640, 640)
+    st_case("speech_music_full_320_160", x, fs, 320, 160, deltas=False)
+    fs, x = wav("pyAudioAnalysis/data/count2.wav")
+    st_case("count2_full_800_400", x, fs, 800, 400)
+    fs, x = wav("pyAudioAnalysis/data/diarizationExample2.wav")
+    st_case("diarizationExample2_full_800_400_nodelta", x, fs, 800, 400, deltas=False)
+    # 44.1 kHz speech at the cfg5 shape, longer than the 2 s of round 1; spectrogram + chromagram with a ragged tail
+    fs, x = wav("pyAudioAnalysis/data/3WORDS.wav", 5.0)
+    st_case("3words5s_1102_441_nodelta", x, fs, 1102, 441, deltas=False)
+    fs, x = wav("pyAudioAnalysis/data/doremi.wav")
+    spec_case("doremi_full_spec_640_640", x, fs, 640, 640)           # tests/cmd_test_00/01.sh on the whole file
+
+
+if __name__ == "__main__" and "--wide" in sys.argv:
+    wide_goldens()

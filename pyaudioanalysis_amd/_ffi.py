@@ -107,12 +107,17 @@ def lib():
         path = library_path()
         if _build.is_stale():
             try:
-                _build.build()
-            except Exception as exc:          # no hipcc on this host and no prebuilt library
+                _build.hipcc_path()
+            except RuntimeError as exc:       # no hipcc on this host: only a prebuilt library can serve
                 if not os.path.exists(path):
                     raise HipLibraryError(
                         "libpaa_hip.so is not built and cannot be built here (%s). "
                         "pyaudioanalysis_amd has no CPU path." % exc)
+            else:
+                try:
+                    _build.build()
+                except Exception as exc:      # a compile error must never fall back to a stale binary
+                    raise HipLibraryError("libpaa_hip.so is older than its sources and the rebuild failed:\n%s" % exc)
         try:
             handle = C.CDLL(path)
         except OSError as exc:

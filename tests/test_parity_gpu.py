@@ -1,8 +1,18 @@
 """Parity of the HIP path (through the C ABI) against the goldens and the CPU oracle.  -m gpu.
 
-Tolerance (north_star: 1e-4 relative): |d| <= 1e-4*|ref| + 1e-6*max|ref_row| + 1e-9, see
-paa_oracle.mixed_tolerance_violations.  Roll-off and ZCR are integer-valued outcomes of floating
-comparisons: a vanishing fraction of frames (<= 1e-3 here, none observed) may differ by one bin."""
+Two gates, both applied by assert_parity():
+
+* the CONTRACT (north_star: 1e-4 relative): |d| <= 1e-4*|ref| + 1e-6*max|ref_row| + 1e-9, see
+  paa_oracle.mixed_tolerance_violations;
+* a TIGHT engineering gate that keeps the kernels honest (the observed error is ~1e-14, scripts/parity_margin.py):
+  |d| <= 1e-9*|ref| + 1e-10*scale(row) + 1e-12, where a delta row inherits the scale of its base row (a delta is a
+  difference of two base values, so its error lives on the base row's scale) and the 13 MFCC rows share one scale.
+  Two documented exceptions, both places where the REFERENCE's own value is a function of round-off:
+  (i) MFCC rows of the frames paa_oracle.ill_conditioned_mfcc_frames flags (log10 of an empty mel band);
+  (ii) spectral spread (:80) is the square root of a cancelling sum: on digitally silent frames the reference itself
+  returns sqrt(round-off ~1e-17) ~ 3e-9 (oracle/paa_oracle.c differs from it by as much), so rows 4 / 38 get
+  2e-8*scale.
+  ZCR and roll-off are integer-valued outcomes of exact / floating comparisons: ZERO flips are allowed."""
 import os
 
 import numpy as np
@@ -15,20 +25,63 @@ from synth import synth_clip
 
 pytestmark = pytest.mark.gpu
 
-REL, ROW, FLOOR = 1e-4, 1e-6, 1e-9
+REL, ROW, FLOOR = 1e-4, 1e-6, 1e-9                 # the contract
+T_REL, T_ROW, T_FLOOR = 1e-9, 1e-10, 1e-12          # the tight gate
+T_ROW_SPREAD = 2e-8
 DISCRETE_ROWS = (0, 7, 34, 41)      # zcr, roll-off and their deltas
+SPREAD_ROWS = (4, 38)
 
 
 MFCC_ALL = [r + b for b in (0, 34) for r in O.MFCC_ROWS]
 
 
-def assert_parity(got, ref, what="", ill=None):
-    """ill: optional bool mask of frames whose MFCCs are round-off-determined in the reference itself
-    (paa_oracle.ill_conditioned_mfcc_frames); there the MFCC rows get 1e-5 of the group scale."""
+def tight_violations(got, ref, ill=None):
+    """-> (count, bool mask) of entries outside the tight gate (see the module docstring)."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    feature_rows = ref.ndim == 2 and ref.shape[0] in (34, 68)
+    if ref.ndim == 2:
+        scale = np.max(np.abs(ref), axis=1, keepdims=True)
+        if ref.shape[0] % 34 == 0 and ref.shape[0] // 34 in (1, 2, 4):
+            nb = ref.shape[0] // 34
+            if nb in (2, 4):          # delta rows (short-term) / delta-mean, std rows (mid-term): base-row scale
+                base = scale[:34].copy()
+                for blk in range(1, nb):
+                    scale[blk * 34:(blk + 1) * 34] = np.maximum(scale[blk * 34:(blk + 1) * 34], base)
+            for blk in range(nb):
+                rows = [blk * 34 + r for r in O.MFCC_ROWS]
+                scale[rows] = scale[rows].max()
+    else:
+        scale = np.max(np.abs(ref))
+    row_tol = np.full_like(scale, T_ROW, dtype=np.float64) if ref.ndim == 2 else T_ROW
+    if ref.ndim == 2 and ref.shape[0] % 34 == 0 and ref.shape[0] // 34 in (1, 2, 4):
+        for blk in range(ref.shape[0] // 34):
+            row_tol[blk * 34 + 4] = T_ROW_SPREAD
+    bad = np.abs(got - ref) > T_REL * np.abs(ref) + row_tol * scale + T_FLOOR
+    bad |= ~np.isfinite(got)
+    if feature_rows and ill is not None and ill.any():
+        rows = [r for r in MFCC_ALL if r < ref.shape[0]]
+        sub = bad[rows]
+        sub[:, ill] = False
+        bad[rows] = sub
+    elif ref.ndim == 2 and ref.shape[0] == 136 and ill is not None and ill.any():
+        # mid-term statistics of MFCC rows that contain a flagged frame: contract gate only
+        for blk in range(4):
+            bad[[blk * 34 + r for r in O.MFCC_ROWS]] = False
+    return int(bad.sum()), bad
+
+
+def assert_parity(got, ref, what="", ill=None, tight=True, sig=None):
+    """sig = (signal, fs, window, step): derive the ill-conditioned-frame mask from the input.
+    ill: optional bool mask of frames whose MFCCs are round-off-determined in the reference itself
+    (paa_oracle.ill_conditioned_mfcc_frames); there the MFCC rows get 1e-5 of the group scale (contract) and are
+    exempt from the tight gate."""
     assert got.shape == ref.shape, (got.shape, ref.shape)
     assert got.dtype == np.float64 and got.flags["C_CONTIGUOUS"]
+    if ill is None and sig is not None:
+        ill = O.ill_conditioned_mfcc_frames(*sig)
     nbad, bad = O.mixed_tolerance_violations(got, ref, REL, ROW, FLOOR)
-    if nbad and ill is not None and ill.any():
+    if nbad and ill is not None and ill.any() and ref.shape[0] in (34, 68):
         _, loose = O.mixed_tolerance_violations(got, ref, REL, 1e-5, FLOOR)
         rows = [r for r in MFCC_ALL if r < ref.shape[0]]
         sub = bad[rows]
@@ -36,19 +89,16 @@ def assert_parity(got, ref, what="", ill=None):
         bad[rows] = sub
         nbad = int(bad.sum())
     if nbad:
-        # allow isolated one-step flips of the discrete features
-        keep = bad.copy()
-        if ref.ndim == 2 and ref.shape[0] in (34, 68):
-            for r in DISCRETE_ROWS:
-                if r < ref.shape[0]:
-                    keep[r] = False
-            flips = int(bad.sum() - keep.sum())
-            assert flips <= max(1, int(1e-3 * ref.shape[1])), "%s: %d discrete flips" % (what, flips)
-        nbad = int(keep.sum())
-        if nbad:
-            idx = np.argwhere(keep)[:8]
-            detail = ", ".join("[%s]=%.6g vs %.6g" % (tuple(i), got[tuple(i)], ref[tuple(i)]) for i in idx)
-            raise AssertionError("%s: %d entries outside tolerance: %s" % (what, nbad, detail))
+        idx = np.argwhere(bad)[:8]
+        detail = ", ".join("[%s]=%.6g vs %.6g" % (tuple(i), got[tuple(i)], ref[tuple(i)]) for i in idx)
+        raise AssertionError("%s: %d entries outside the 1e-4 contract: %s" % (what, nbad, detail))
+    if tight:
+        nt, tb = tight_violations(got, ref, ill)
+        if nt:
+            idx = np.argwhere(tb)[:8]
+            detail = ", ".join("[%s]=%.17g vs %.17g" % (tuple(i), got[tuple(i)], ref[tuple(i)]) for i in idx)
+            raise AssertionError("%s: %d entries outside the tight gate (discrete rows: any flip counts): %s"
+                                 % (what, nt, detail))
 
 
 @pytest.mark.parametrize("path", golden_files("st"), ids=golden_id)
@@ -66,8 +116,9 @@ def test_mid_term_golden(gpu_lib, path):
     mid, st, names = MidTermFeatures.mid_feature_extraction(g["signal"], g["fs"], g["mid_window"], g["mid_step"],
                                                             g["window"], g["step"])
     assert names == [str(s) for s in g["names"]]
-    assert_parity(st, g["features"], "short")
-    assert_parity(mid, g["mid"], "mid")
+    sig = (g["signal"], g["fs"], g["window"], g["step"])
+    assert_parity(st, g["features"], "short", sig=sig)
+    assert_parity(mid, g["mid"], "mid", sig=sig)
 
 
 @pytest.mark.parametrize("path", golden_files("spec"), ids=golden_id)
@@ -103,7 +154,7 @@ def test_oracle_parity_seeded(gpu_lib, fs, window, step, seconds):
     for deltas in (True, False):
         ref, _ = O.feature_extraction(x, fs, window, step, deltas)
         got, _ = ShortTermFeatures.feature_extraction(x, fs, window, step, deltas)
-        assert_parity(got, ref, "%d/%d@%d deltas=%s" % (window, step, fs, deltas))
+        assert_parity(got, ref, "%d/%d@%d deltas=%s" % (window, step, fs, deltas), sig=(x, fs, window, step))
 
 
 def test_float64_input_matches_oracle(gpu_lib):
@@ -112,12 +163,12 @@ def test_float64_input_matches_oracle(gpu_lib):
     assert mono.dtype == np.float64
     ref, _ = O.feature_extraction(mono, 44100, 1102, 441)
     got, _ = ShortTermFeatures.feature_extraction(mono, 44100, 1102, 441)
-    assert_parity(got, ref, "stereo->mono f64")
+    assert_parity(got, ref, "stereo->mono f64", sig=(mono, 44100, 1102, 441))
     # other dtypes go through np.double() like the reference (:567)
     x32 = synth_clip(78, 8000).astype(np.int32)
     ref, _ = O.feature_extraction(x32, 16000, 800, 400)
     got, _ = ShortTermFeatures.feature_extraction(x32, 16000, 800, 400)
-    assert_parity(got, ref, "int32 input")
+    assert_parity(got, ref, "int32 input", sig=(x32, 16000, 800, 400))
 
 
 def test_known_answers(gpu_lib):
@@ -164,13 +215,13 @@ def test_batch_equals_single_clips(gpu_lib):
         single, _ = ShortTermFeatures.feature_extraction(c, 16000, 800, 400)
         assert np.array_equal(single, r)                          # same kernels, same tiles -> bit equal
         ref, _ = O.feature_extraction(c, 16000, 800, 400)
-        assert_parity(r, ref, "batch clip")
+        assert_parity(r, ref, "batch clip", sig=(c, 16000, 800, 400))
     mids, sts, mnames = MidTermFeatures.mid_feature_extraction_batch(clips[2:], 16000, 16000, 16000, 800, 400,
                                                                     return_short=True)
     for c, m, s in zip(clips[2:], mids, sts):
         ref_mid, ref_st, _ = O.mid_feature_extraction(c, 16000, 16000, 16000, 800, 400)
-        assert_parity(s, ref_st, "batch short")
-        assert_parity(m, ref_mid, "batch mid")
+        assert_parity(s, ref_st, "batch short", sig=(c, 16000, 800, 400))
+        assert_parity(m, ref_mid, "batch mid", sig=(c, 16000, 800, 400))
 
 
 @pytest.mark.parametrize("minutes", [10, 60])
@@ -232,7 +283,7 @@ def test_big_windows_match_oracle(gpu_lib, fs, window, step, seconds):
     x = synth_clip(700 + window, int(seconds * fs), fs=fs)
     ref, _ = O.feature_extraction(x, fs, window, step)
     got, _ = ShortTermFeatures.feature_extraction(x, fs, window, step)
-    assert_parity(got, ref, "big window %d/%d" % (window, step))
+    assert_parity(got, ref, "big window %d/%d" % (window, step), sig=(x, fs, window, step))
 
 
 def test_big_window_spectrogram(gpu_lib, capsys):
@@ -278,7 +329,7 @@ def test_many_clip_batch_properties(gpu_lib):
     mids, _ = MidTermFeatures.mid_feature_extraction_batch([c30] * 40, fs, fs, fs, 800, 400)   # config 3 shape
     ref_mid, _, _ = O.mid_feature_extraction(c30, fs, fs, fs, 800, 400)
     assert mids[0].shape == (136, 30)
-    assert_parity(mids[0], ref_mid, "config 3 clip")
+    assert_parity(mids[0], ref_mid, "config 3 clip", sig=(c30, fs, 800, 400))
     for m in mids[1:]:
         assert np.array_equal(m, mids[0])
 
@@ -289,14 +340,15 @@ def test_fused_stereo_to_mono(gpu_lib):
     g = load_golden([p for p in golden_files("stereo")][0])
     st = load_golden(os.path.join(os.path.dirname(golden_files("stereo")[0]), "synth5_stereo_1102_441.npz"))
     fused, _ = ShortTermFeatures.feature_extraction(g["stereo"], 44100, 1102, 441)
-    assert_parity(fused, st["features"], "fused stereo vs reference")
+    assert_parity(fused, st["features"], "fused stereo vs reference", sig=(g["mono"], 44100, 1102, 441))
     mono_path, _ = ShortTermFeatures.feature_extraction(g["mono"], 44100, 1102, 441)
     assert np.allclose(fused, mono_path, rtol=1e-12, atol=1e-13)
     xs = synth_clip(88, 3 * 16000 + 3, stereo=True)                 # odd length: scalar tail of the sum kernel
     ref_mid, ref_st, _ = O.mid_feature_extraction(O.stereo_to_mono(xs), 16000, 16000, 16000, 800, 400)
     mid, st2, _ = MidTermFeatures.mid_feature_extraction(xs, 16000, 16000, 16000, 800, 400)
-    assert_parity(st2, ref_st, "fused stereo short")
-    assert_parity(mid, ref_mid, "fused stereo mid")
+    sig2 = (O.stereo_to_mono(xs), 16000, 800, 400)
+    assert_parity(st2, ref_st, "fused stereo short", sig=sig2)
+    assert_parity(mid, ref_mid, "fused stereo mid", sig=sig2)
 
 
 def test_c_client_on_gpu(gpu_lib, tmp_path):
