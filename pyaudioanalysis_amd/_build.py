@@ -30,7 +30,10 @@ def build(force=False, verbose=False):
     """Compile csrc/paa_lib.hip -> libpaa_hip.so (gfx950 only).  Returns the library path."""
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+    # -disable-machine-licm: the feature kernels' loop bodies are thousands of instructions long; hoisting every FP64
+    # literal and per-lane LDS address out of them creates >100 loop-invariant registers that then spill (AGPR copies at
+    # one wave per SIMD, scratch at two).  Re-materialising a literal at its use costs two s_mov / v_mov.
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-mllvm", "-disable-machine-licm",
            "-I/opt/rocm/include", os.path.join(CSRC, "paa_lib.hip"), "-o", LIB + ".tmp", "-ldl"]
     cmd += os.environ.get("PAA_HIPCC_FLAGS", "").split()
     if verbose:

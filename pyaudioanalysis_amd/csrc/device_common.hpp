@@ -25,6 +25,23 @@ struct ClipDev {        // one per clip, built on the host
 struct ClipNorm {       // written by clip_params_kernel
     double mean;        // mean(x / 2^15)
     double inv;         // 1 / (max|x/2^15 - mean| + 1e-10)
+    // derived constants of the integer-input kernels (wave-uniform there: fetched with scalar loads).
+    // The FFT runs on integers x - m_int (m_int = the clip mean rounded to a whole count; exact in f64).
+    // y = (x/2^15 - mean) * inv is affine, so every bin scales by inv/2^15 and only the DC bin sees the
+    // residual mean:  Y[0] = inv/2^15 * (X'[0] - W * (mu - m_int)).  Removing m_int first keeps the DC
+    // component (and its round-off leakage into the other bins) below half a count per sample.
+    double mu;          // clip mean in counts = mean * 2^15 (exact scaling)
+    double delta_mu;    // mu - m_int, |.| <= 1/2
+    double inv_sc;      // inv / 2^15: y = (x' - delta_mu) * inv_sc with x' = x - m_int
+    double y_scale2;    // inv_sc^2
+    double mi;          // (double)m_int
+    double mag_scale;   // inv_sc * 0.5 / Nf: magnitude of a bin from the packed real-FFT recombination (E, O carry 1/2)
+    double dc_shift;    // 2 W delta_mu: what the DC bin of the integer FFT carries too much
+    double chunk_dmu;   // 40 delta_mu (time-domain partials are formed over 40-sample chunks)
+    int m_int;          // nearbyint(mu)
+    int zb;             // floor(mu) clamped into int16: sign(x/2^15 - mean) = sign(x - mu) in 16-bit arithmetic
+    int mu_whole;       // 1: mu is a whole number (a sample can sit exactly on the mean: sign 0)
+    int pad;
 };
 
 struct Tile {           // a run of consecutive frames of one clip = one workgroup

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void clip_stats_f64_kernel(const double *__res
 template <typename SumT, typename MmT>
 __global__ __launch_bounds__(64) void clip_params_kernel(const ClipDev *__restrict__ clips, long long n_clips,
                                                           const SumT *__restrict__ psum, const MmT *__restrict__ pmin,
-                                                          const MmT *__restrict__ pmax, double sc,
+                                                          const MmT *__restrict__ pmax, double sc, int window,
                                                           ClipNorm *__restrict__ norms) {
     const long long c = blockIdx.x;
     if (c >= n_clips) return;
@@ -162,10 +162,25 @@ __global__ __launch_bounds__(64) void clip_params_kernel(const ClipDev *__restri
     }
     if (threadIdx.x != 0) return;
     ClipNorm nm;
-    if (cd.n <= 0) { nm.mean = 0.0; nm.inv = 1.0; norms[c] = nm; return; }
-    nm.mean = ((double)s * sc) / (double)cd.n;
-    const double peak = fmax(fabs(fma(mx, sc, -nm.mean)), fabs(fma(mn, sc, -nm.mean)));
-    nm.inv = 1.0 / (peak + 1e-10);
+    if (cd.n <= 0) { nm.mean = 0.0; nm.inv = 1.0; }
+    else {
+        nm.mean = ((double)s * sc) / (double)cd.n;
+        const double peak = fmax(fabs(fma(mx, sc, -nm.mean)), fabs(fma(mn, sc, -nm.mean)));
+        nm.inv = 1.0 / (peak + 1e-10);
+    }
+    nm.mu = nm.mean * 32768.0;
+    nm.m_int = (int)fmin(fmax(nearbyint(nm.mu), -40000.0), 40000.0);
+    nm.delta_mu = nm.mu - (double)nm.m_int;
+    nm.inv_sc = nm.inv * (1.0 / 32768.0);
+    nm.y_scale2 = nm.inv_sc * nm.inv_sc;
+    nm.mi = (double)nm.m_int;
+    nm.mag_scale = nm.inv_sc * (0.5 / (double)(window / 2));
+    nm.dc_shift = 2.0 * (double)window * nm.delta_mu;
+    nm.chunk_dmu = 40.0 * nm.delta_mu;
+    const double mu_fl = floor(nm.mu);
+    nm.zb = (int)fmin(fmax(mu_fl, -32768.0), 32767.0);
+    nm.mu_whole = (mu_fl == nm.mu) ? 1 : 0;
+    nm.pad = 0;
     norms[c] = nm;
 }
 

@@ -41,6 +41,7 @@ struct TabLayout {
     int off_tw2, off_twp;                                  // double2 [16][13]: W400^(r p) and W800^(p + 25 q) of lane p
     int melN0, melN1, melN2, chN;                          // list lengths (multiples of 8)
     int mel_clamp;                                         // 1: some padded list reaches past bin 399
+    double f0, rf0, r_half_fs, f0sq;                       // fs / 800, its reciprocal, 2 / fs, f0^2 (host-computed: scalar registers)
     int fixed_lists;                                       // 1: lengths are exactly 8/16/16/8 without clamping
     int total;                                             // bytes, multiple of 16
 };
@@ -71,23 +72,30 @@ constexpr int CH_STRIDE = 12;                       // chroma gather lists: one 
 
 // step-dependent geometry (S = 400: 50 % overlap, the BASELINE shape; S = 800: back-to-back frames, the
 // reference's own default 50 ms / 50 ms)
-template <int S>
+template <int S, int NW = 4>
 struct Geo {
     static_assert(S % CHUNK == 0 && S % 8 == 0, "step must be a multiple of the 40-sample chunk");
     static constexpr int RAW_N = (QUAD - 1) * S + W;            // samples per quad: 2000 / 3200
     static constexpr int NCHUNK = RAW_N / CHUNK;                // 50 / 80
     static constexpr int CPF = S / CHUNK;                       // chunks per frame step: 10 / 20
     static constexpr int NPRE = (RAW_N / 8 + 63) / 64;          // 16-byte prefetch registers per lane: 4 / 7
+    static constexpr int RAW_BYTES = (RAW_N + 2 * RAW_PAD) * 2;
+    // NW = 8 (two waves per SIMD): the per-wave LDS must stay below 17.5 KB, so the transient buffers live inside the
+    // spectrum ring: raw[] in two index-adjacent TARGET slots of the quad (dead until the exchange writes them),
+    // msp[] / fv[] in the PREVIOUS-spectrum slot (dead once the flux operands are in registers)
+    static constexpr bool ALIAS = (NW == 8);
     // LDS carve (bytes)
     static constexpr int OFF_SPEC = 0;                                   // 5 slots x 400 doubles
     static constexpr int OFF_RAW = OFF_SPEC + 5 * NF * 8;                // int16 raw[]; aliased by msp[4][40] later
-    static constexpr int OFF_CE = OFF_RAW + (RAW_N + 2 * RAW_PAD) * 2;   // double cE[NCHUNK]
+    static constexpr int OFF_CE = ALIAS ? OFF_RAW : OFF_RAW + RAW_BYTES; // double cE[NCHUNK]
     static constexpr int OFF_CZ = OFF_CE + NCHUNK * 8;                   // int cZ[NCHUNK], cF[NCHUNK]
     static constexpr int OFF_FV = OFF_CZ + 2 * NCHUNK * 4;               // double fv[4][34]
-    static constexpr int LDS_BYTES = OFF_FV + QUAD * FV_STRIDE * 8;
+    static constexpr int LDS_BYTES = ALIAS ? OFF_FV : OFF_FV + QUAD * FV_STRIDE * 8;
     static constexpr int WAVE_BYTES = ((LDS_BYTES + 15) / 16) * 16;
     static_assert(OFF_RAW % 16 == 0 && OFF_CE % 8 == 0 && OFF_FV % 8 == 0, "LDS alignment");
-    static_assert(QUAD * 40 * 8 <= (RAW_N + 2 * RAW_PAD) * 2, "msp alias fits in the raw buffer");
+    static_assert(QUAD * 40 * 8 <= RAW_BYTES, "msp alias fits in the raw buffer");
+    static_assert(!ALIAS || RAW_BYTES <= 2 * NF * 8, "raw[] fits in two spectrum slots");
+    static_assert(!ALIAS || QUAD * 40 * 8 + QUAD * FV_STRIDE * 8 <= NF * 8, "msp + fv fit in one spectrum slot");
 };
 
 // ---- register DFTs ------------------------------------------------------------------------
@@ -113,9 +121,16 @@ __device__ __forceinline__ void dft4r(double2 &a0, double2 &a1, double2 &a2, dou
     a3 = add_i(t1, t3);
 }
 // v[r], r = 5 r1 + r2  ->  result for output q stored at v[5 (q % 5) + q / 5]
+// SERIAL = 1 (two waves per SIMD): every butterfly finishes in place before the next one starts.  Dependent FP64
+// operations issue back to back on gfx950 (profiles/microbench_r02.txt), so nothing is lost, and the scheduler
+// cannot run all butterflies of a stage side by side (which doubles the live registers).
+template <int SERIAL = 0>
 __device__ __forceinline__ void dft25(double2 *v) {
 #pragma unroll
-    for (int r2 = 0; r2 < 5; ++r2) dft5r(v[r2], v[5 + r2], v[10 + r2], v[15 + r2], v[20 + r2]);
+    for (int r2 = 0; r2 < 5; ++r2) {
+        dft5r(v[r2], v[5 + r2], v[10 + r2], v[15 + r2], v[20 + r2]);
+        if (SERIAL) __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int q1 = 1; q1 < 5; ++q1)
 #pragma unroll
@@ -130,16 +145,24 @@ __device__ __forceinline__ void dft25(double2 *v) {
                             : (m == 9) ? -0.77051324277578925 : (m == 12) ? -0.12533323356430426 : 0.77051324277578925;
             v[5 * q1 + r2] = cmul(v[5 * q1 + r2], make_double2(cr, ci));
         }
+    if (SERIAL) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q1 = 0; q1 < 5; ++q1) dft5r(v[5 * q1], v[5 * q1 + 1], v[5 * q1 + 2], v[5 * q1 + 3], v[5 * q1 + 4]);
+    for (int q1 = 0; q1 < 5; ++q1) {
+        dft5r(v[5 * q1], v[5 * q1 + 1], v[5 * q1 + 2], v[5 * q1 + 3], v[5 * q1 + 4]);
+        if (SERIAL) __builtin_amdgcn_sched_barrier(0);
+    }
 }
 #define PAA_DFT25_POS(q) (5 * ((q) % 5) + (q) / 5)
 
 // v[r], r = 4 r1 + r2  ->  result for output q stored at v[4 (q % 4) + q / 4]
+template <int SERIAL = 0>
 __device__ __forceinline__ void dft16(double2 *v) {
     const double c = 0.92387953251128676, s = 0.38268343236508977, h = 0.70710678118654752;
 #pragma unroll
-    for (int r2 = 0; r2 < 4; ++r2) dft4r(v[r2], v[4 + r2], v[8 + r2], v[12 + r2]);
+    for (int r2 = 0; r2 < 4; ++r2) {
+        dft4r(v[r2], v[4 + r2], v[8 + r2], v[12 + r2]);
+        if (SERIAL) __builtin_amdgcn_sched_barrier(0);
+    }
     // twiddles W16^(r2 q1) at index 4 q1 + r2
     v[5] = cmul(v[5], make_double2(c, -s));        // m = 1
     v[6] = make_double2(h * (v[6].x + v[6].y), h * (v[6].y - v[6].x));    // m = 2: (h, -h)
@@ -150,8 +173,12 @@ __device__ __forceinline__ void dft16(double2 *v) {
     v[13] = cmul(v[13], make_double2(s, -c));      // m = 3
     v[14] = make_double2(h * (v[14].y - v[14].x), -h * (v[14].x + v[14].y));   // m = 6
     v[15] = cmul(v[15], make_double2(-c, s));      // m = 9
+    if (SERIAL) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q1 = 0; q1 < 4; ++q1) dft4r(v[4 * q1], v[4 * q1 + 1], v[4 * q1 + 2], v[4 * q1 + 3]);
+    for (int q1 = 0; q1 < 4; ++q1) {
+        dft4r(v[4 * q1], v[4 * q1 + 1], v[4 * q1 + 2], v[4 * q1 + 3]);
+        if (SERIAL) __builtin_amdgcn_sched_barrier(0);
+    }
 }
 #define PAA_DFT16_POS(q) (4 * ((q) % 4) + (q) / 4)
 
@@ -226,13 +253,13 @@ __device__ __forceinline__ double fast_log2(double x) {
 }
 __device__ __forceinline__ double fast_log10(double x) { return fast_log2(x) * 0.30102999566398119521; }
 
-#ifndef PAA_F800_WAVES
-#define PAA_F800_WAVES 4
-#endif
-#ifndef PAA_F800_MIN_WAVES_PER_SIMD
-#define PAA_F800_MIN_WAVES_PER_SIMD 1
-#endif
-constexpr int WAVES = PAA_F800_WAVES;
+// wave-uniform values computed with vector instructions: pin them into scalar registers
+__device__ __forceinline__ double uni(double v) {
+    const unsigned long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // optional per-phase cycle accounting (build with -DPAA_F800_TIMING; read with paa_debug_phase_cycles)
 #ifdef PAA_F800_TIMING
@@ -249,8 +276,11 @@ __device__ unsigned long long g_phase_cycles[16];
 // FIXED = 1: the mel / chroma list lengths are the compile-time constants of the usual 16 kHz tables (8, 16, 16, 8,
 // no clamping), which turns the whole feature stage into straight-line code the scheduler can interleave;
 // FIXED = 0: run-time lengths from the layout (other sampling rates).
-template <int S, int DELTAS, int FIXED>
-__global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fast_800_kernel(PlanDev P, TabLayout L,
+// NW = waves per workgroup: 4 (one wave per SIMD, up to 512 registers: loads are software-pipelined far ahead) or
+// 8 (two per SIMD, <= 256 registers and 16.8 KB of LDS per wave: the partner wave hides the latencies instead, so table
+// values are fetched right before their use and the transient LDS buffers live inside the spectrum ring).
+template <int S, int DELTAS, int FIXED, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P, TabLayout L,
                                                                      const unsigned char *__restrict__ blob,
                                                                      const int16_t *__restrict__ sig,
                                                                      const ClipDev *__restrict__ clips,
@@ -262,7 +292,7 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
     {
         const int4 *src4 = reinterpret_cast<const int4 *>(blob);
         int4 *dst4 = reinterpret_cast<int4 *>(smem);
-        for (int n = threadIdx.x; n < L.total / 16; n += 64 * WAVES) dst4[n] = src4[n];
+        for (int n = threadIdx.x; n < L.total / 16; n += 64 * NW) dst4[n] = src4[n];
     }
     __syncthreads();       // the only workgroup-wide barrier; from here on every wave runs on its own
     const double *t_melw0 = reinterpret_cast<const double *>(smem + L.off_w0);
@@ -278,21 +308,22 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
     const double2 *t_twp = reinterpret_cast<const double2 *>(smem + L.off_twp);
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // wave-uniform: keeps per-wave constants in SGPRs
-    const int tile_id = blockIdx.x * WAVES + wave;
+    const int tile_id = blockIdx.x * NW + wave;
     if (tile_id >= n_tiles) return;
-    using G = Geo<S>;
+    using G = Geo<S, NW>;
     constexpr int RAW_N = G::RAW_N, NCHUNK = G::NCHUNK, CPF = G::CPF;
     unsigned char *wbase = smem + L.total + wave * G::WAVE_BYTES;
     double *spec = reinterpret_cast<double *>(wbase + G::OFF_SPEC);
-    int16_t *raw = reinterpret_cast<int16_t *>(wbase + G::OFF_RAW);
-    double *msp = reinterpret_cast<double *>(wbase + G::OFF_RAW);          // alias: raw is dead by then
+    // NW = 4: fixed buffers.  NW = 8: re-pointed every iteration into the spectrum ring (see Geo)
+    int16_t *raw = reinterpret_cast<int16_t *>(wbase + (G::ALIAS ? 0 : G::OFF_RAW));
+    double *msp = reinterpret_cast<double *>(wbase + (G::ALIAS ? 0 : G::OFF_RAW));   // alias: raw is dead by then
     double *cE = reinterpret_cast<double *>(wbase + G::OFF_CE);
     int *cZ = reinterpret_cast<int *>(wbase + G::OFF_CZ);
     int *cF = cZ + NCHUNK;
-    double *fv = reinterpret_cast<double *>(wbase + G::OFF_FV);
+    double *fv = reinterpret_cast<double *>(wbase + (G::ALIAS ? 0 : G::OFF_FV));
 
     const int lane = threadIdx.x & 63;
-    const int g = lane >> 4, i = lane & 15;
+    int g = lane >> 4, i = lane & 15;          // NW = 8 makes them opaque per iteration (see the loop head)
     const Tile tl = tiles[tile_id];
     const ClipDev c = clips[tl.clip];
     const ClipNorm nm = norms[tl.clip];
@@ -300,35 +331,22 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
     const long long Tc = c.T;
     double *oc = out + c.out_off;
 
-    const double sc = 1.0 / 32768.0;
-    const double f0 = P.fs / (2.0 * (double)NF);
-    const double rf0 = 1.0 / f0;
-    const double half_fs = P.fs / 2.0;
-    const double r_half_fs = 1.0 / half_fs;
-    // the FFT runs on integers x - m_int (m_int = the clip mean rounded to a whole count; exact in f64).
-    // y = (x/2^15 - mean) * inv is affine, so every bin scales by inv/2^15 and only the DC bin sees the
-    // residual mean:  Y[0] = inv/2^15 * (X'[0] - 800 * (mu - m_int)).  Removing m_int first keeps the DC
-    // component (and its round-off leakage into the other bins) below half a count per sample.
-    const double mu = nm.mean * 32768.0;             // clip mean in counts (exact scaling)
-    const int m_int = (int)fmin(fmax(nearbyint(mu), -40000.0), 40000.0);
-    const double mag_scale = 0.5 * nm.inv * sc / (double)NF;       // 0.5: E and O carry a factor 1/2
-    const double delta_mu = mu - (double)m_int;                    // |.| <= 1/2
-    const double dc_shift = 2.0 * (double)W * delta_mu;
-    const double y_scale2 = (nm.inv * sc) * (nm.inv * sc);         // y = (x' - delta) * inv / 2^15
+    // everything below is wave-uniform (one tile per wave): the clip constants come precomputed from
+    // clip_params_kernel (see ClipNorm) through scalar loads, the rest is pinned into scalar registers
+    const double f0 = L.f0, rf0 = L.rf0, r_half_fs = L.r_half_fs, f0sq = L.f0sq;
+    const int m_int = nm.m_int;
+    const double delta_mu = nm.delta_mu;                                         // |.| <= 1/2
+    const double y_scale2 = nm.y_scale2;                                         // y = (x' - delta) * inv / 2^15
+    const double mag_scale = nm.mag_scale;                                       // 0.5: E and O carry a factor 1/2
+    const double dc_shift = nm.dc_shift;
     // sign(x/2^15 - mean) = sign(x - mu) in packed 16-bit integers (mu lies inside the int16 range: it is a mean of int16)
-    const double mu_fl = floor(mu);
-    const bool mu_whole = (mu_fl == mu);
-    const short zb_ = (short)(int)fmin(fmax(mu_fl, -32768.0), 32767.0);
+    const bool mu_whole = nm.mu_whole != 0;
+    const short zb_ = (short)nm.zb;
     const s16x2 zc_b = {zb_, zb_};
     const s16x2 zc_lo = mu_whole ? (s16x2){-1, -1} : (s16x2){0, 0};
     const s16x2 zc_mul = mu_whole ? (s16x2){1, 1} : (s16x2){2, 2};
     const s16x2 zc_add = mu_whole ? (s16x2){0, 0} : (s16x2){-1, -1};
     const s16x2 zc_one = {1, 1};
-
-    // pass-2 columns of this lane; the twiddles W400^(r p) and W800^(p + 25 q) sit in the shared LDS table
-    const int pa = i, pb = (i == 0) ? 0 : 25 - i;
-    const bool act = i < 13;
-    const int itw = min(i, TW_STRIDE - 1), ich = min(i, CH_STRIDE - 1);     // idle lanes re-read a valid column
 
     const int t_end = tl.t0 + tl.cnt;
     int q0 = tl.t0 >= QUAD ? tl.t0 - QUAD : 0;
@@ -352,18 +370,40 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
                 if (lane + 64 * r_ < RAW_N / 8) pre[r_] = s4_[lane + 64 * r_];                         \
         }                                                                                              \
     }
-    PAA_F800_FETCH(q0)
+    if (NW == 4) PAA_F800_FETCH(q0)
     PAA_T0()
 
+    int16_t before_next = 0;         // lane 0: the sample just before the NEXT quad (saved while raw[] still holds it)
     for (; q0 < t_end; q0 += QUAD, slot0 = (slot0 + 4) % 5) {
+        // NW = 8: hide the lane indices from loop-invariant code motion -- the dozens of per-lane LDS addresses the
+        // compiler would otherwise keep in registers across the whole iteration cost more than re-deriving them
+        if (NW != 4) asm volatile("" : "+v"(g), "+v"(i));
+        // pass-2 columns of this lane; the twiddles W400^(r p) and W800^(p + 25 q) sit in the shared LDS table
+        const int pa = i, pb = (i == 0) ? 0 : 25 - i;
+        const bool act = i < 13;
+        const int itw = min(i, TW_STRIDE - 1), ich = min(i, CH_STRIDE - 1);     // idle lanes re-read a valid column
+        if (G::ALIAS) {
+            // previous-spectrum slot = slot0 - 1; the quad's four target slots are the others.  Two index-adjacent
+            // target slots always exist: (3, 4) unless the previous slot is 3 or 4, then (0, 1)
+            const int prev_slot = (slot0 + 4) % 5;
+            raw = reinterpret_cast<int16_t *>(spec + ((prev_slot <= 2) ? 3 : 0) * NF);
+            msp = spec + prev_slot * NF;
+            fv = msp + QUAD * 40;
+        }
+        // a halo quad of a 34-row run only has to leave its last spectrum behind (flux of the first stored frame):
+        // no time-domain stage, no features, no store
+        const bool spec_only = (DELTAS == 0) && (q0 + QUAD <= tl.t0);
         // ---------------- stage raw samples [q0*S - 1, q0*S + 2000)
         {
             const long long base = (long long)q0 * S;
             const int16_t *src = xc + base;
-            // the sample before the quad: the previous iteration's staging still holds it (one global load per run
+            // the sample before the quad: saved from the previous iteration's staging (one global load per run
             // instead of an exposed one per iteration)
             int16_t before = 0;
-            if (lane == 0) before = (q0 != q_first) ? raw[RAW_PAD + QUAD * S - 1] : ((base > 0) ? src[-1] : src[0]);
+            if (lane == 0) before = (q0 != q_first) ? before_next : ((base > 0) ? src[-1] : src[0]);
+            // NW = 8: no register prefetch across the loop edge (16 live registers through every stage would cost more
+            // than the exposed load: the partner wave of the SIMD computes meanwhile)
+            if (NW != 4) PAA_F800_FETCH(q0)
             if (pre_ok) {
                 int4 *d4 = reinterpret_cast<int4 *>(raw + RAW_PAD);
 #pragma unroll
@@ -374,16 +414,17 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
                 for (int n = lane; n < RAW_N; n += 64) raw[RAW_PAD + n] = (n < avail) ? src[n] : (int16_t)0;
             }
             if (lane == 0) raw[RAW_PAD - 1] = before;
-            if (q0 + QUAD < t_end) PAA_F800_FETCH(q0 + QUAD)
+            if (NW == 4 && q0 + QUAD < t_end) PAA_F800_FETCH(q0 + QUAD)
         }
         wsync();
+        if (lane == 0) before_next = raw[RAW_PAD + QUAD * S - 1];
         PAA_TICK(0)
 
         // ---------------- time domain: chunk partials (ShortTermFeatures.py:22-51)
         // Two samples per 32-bit lane operation: v_dot2 gives x0^2 + x1^2 and x0 + x1, the sign of x - mu comes from
         // packed 16-bit saturating arithmetic:  s = clamp(sat(x - floor(mu)), lo, 1) * a + c  with (lo, a, c) =
         // (-1, 1, 0) when mu is a whole number (sign 0 exists) and (0, 2, -1) otherwise (x - floor(mu) >= 1 <=> +1).
-        for (int ch = lane; ch < NCHUNK; ch += 64) {
+        for (int ch = spec_only ? NCHUNK : lane; ch < NCHUNK; ch += 64) {
             const int4 *p4 = reinterpret_cast<const int4 *>(raw + RAW_PAD + CHUNK * ch);
             // the dword before the chunk holds the previous sample in its upper half
             s16x2 sp = __builtin_bit_cast(s16x2, reinterpret_cast<const int *>(raw + RAW_PAD + CHUNK * ch)[-1]);
@@ -413,10 +454,10 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
             }
             // sum (x - m_int)^2 and sum (x - m_int) in exact integer arithmetic, then the residual mean as before:
             // sum y^2 over the chunk = (inv/2^15)^2 * sum (x' - delta)^2 with x' = x - m_int, |delta| <= 1/2
-            const double mi = (double)m_int;
+            const double mi = nm.mi;
             const double e2 = fma(mi, fma((double)CHUNK, mi, -2.0 * (double)sx), sx2);
             const int s1 = sx - CHUNK * m_int;
-            const double e = y_scale2 * fma(delta_mu, fma(-2.0, (double)s1, (double)CHUNK * delta_mu), e2);
+            const double e = y_scale2 * fma(delta_mu, fma(-2.0, (double)s1, nm.chunk_dmu), e2);
             cE[ch] = e;
             cZ[ch] = (int)zacc.x + (int)zacc.y;
             cF[ch] = zfirst;
@@ -433,16 +474,18 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
                 v[r] = make_double2((double)((int)(short)(w & 0xffff) - m_int), (double)((w >> 16) - m_int));
             }
         }
-        dft25(v);
+        dft25<(NW != 4)>(v);
         wsync();
         PAA_TICK(2)      // raw + chunk partials complete; the previous quad's readers of the slots are done
 
         // exchange through the quad's 4 spectrum slots: real plane, then imaginary plane.
         // element (frame g, index 25 j + q)
         double ax[16], ay[16], bx[16], by[16];
-        double2 w2[16];       // W400^(r p): requested before the exchange so they land while it runs
+        double2 w2[16];       // W400^(r p): NW = 4 requests them before the exchange so they land while it runs
+        if (NW == 4) {
 #pragma unroll
-        for (int r = 1; r < 16; ++r) w2[r] = t_tw2[r * TW_STRIDE + itw];
+            for (int r = 1; r < 16; ++r) w2[r] = t_tw2[r * TW_STRIDE + itw];
+        }
         {
             double *pl = spec + ((slot0 + g) % 5) * NF;
 #pragma unroll
@@ -466,38 +509,80 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
             double2 a[16], b[16];
             a[0] = make_double2(ax[0], ay[0]);
             b[0] = make_double2(bx[0], by[0]);
-#pragma unroll
-            for (int r = 1; r < 16; ++r) {
-                a[r] = cmul(make_double2(ax[r], ay[r]), w2[r]);
-                b[r] = cmul(make_double2(bx[r], by[r]), make_double2(w2[r].x, -w2[r].y));
-            }
-            double2 wp[16];   // W800^(p + 25 q): in flight during the two radix-16 transforms
-#pragma unroll
-            for (int q = 0; q < 16; ++q) wp[q] = t_twp[q * TW_STRIDE + itw];
-            dft16(a);
-            dft16(b);
             double *sp = spec + ((slot0 + g) % 5) * NF;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                // Z[k], k = p + 25 q ; Z[400 - k] = column (25-p), output (15 - q) -> rotated index (16 - q) % 16
-                const double2 zk = a[PAA_DFT16_POS(q)];
-                const int qm = (16 - q) % 16;
-                // lane 0 (p = 0) has b == a bit for bit (same column, unit twiddles), so no select is needed:
-                // Z[400 - 25 q] = A[(16 - q) % 16] = b[...] there as well
-                const double2 zb = b[PAA_DFT16_POS(qm)];
-                const int k = pa + 25 * q;
-                // 2E = Z[k] + conj Z[400-k],  2O = -i (Z[k] - conj Z[400-k])
-                const double2 e = make_double2(zk.x + zb.x, zk.y - zb.y);
-                const double2 o = make_double2(zk.y + zb.y, zb.x - zk.x);
-                const double2 t = cmul(wp[q], o);
-                double xr = e.x + t.x, xi = e.y + t.y;
-                const double yr = e.x - t.x, yi = e.y - t.y;
-                if (q == 0 && i == 0) { xr -= dc_shift; xi = 0.0; }    // DC bin: remove the residual clip mean
-                sp[k] = mag_sqrt(fma(xr, xr, xi * xi)) * mag_scale;
-                if (q > 0 || i > 0) sp[NF - k] = mag_sqrt(fma(yr, yr, yi * yi)) * mag_scale;
+            // Z[k], k = p + 25 q ; Z[400 - k] = column (25-p), output (15 - q) -> rotated index (16 - q) % 16.
+            // Lane 0 (p = 0) has b == a bit for bit (same column, unit twiddles), so no select is needed:
+            // Z[400 - 25 q] = A[(16 - q) % 16] = b[...] there as well.
+            // 2E = Z[k] + conj Z[400-k],  2O = -i (Z[k] - conj Z[400-k])
+#define PAA_F800_BIN(q, wpq)                                                                               \
+            {                                                                                              \
+                const double2 zk = a[PAA_DFT16_POS(q)];                                                    \
+                const double2 zb = b[PAA_DFT16_POS((16 - (q)) % 16)];                                      \
+                const int k = pa + 25 * (q);                                                               \
+                const double2 e = make_double2(zk.x + zb.x, zk.y - zb.y);                                  \
+                const double2 o = make_double2(zk.y + zb.y, zb.x - zk.x);                                  \
+                const double2 t = cmul((wpq), o);                                                          \
+                double xr = e.x + t.x, xi = e.y + t.y;                                                     \
+                const double yr = e.x - t.x, yi = e.y - t.y;                                               \
+                /* DC bin (q = 0 in lane 0): remove the residual clip mean; straight-line selects, no branch */ \
+                const bool dc_ = ((q) == 0) && (i == 0);                                                   \
+                xr = dc_ ? xr - dc_shift : xr;                                                             \
+                xi = dc_ ? 0.0 : xi;                                                                       \
+                const double mk_ = mag_sqrt(fma(xr, xr, xi * xi)) * mag_scale;                             \
+                sp[k] = mk_;                                                                               \
+                /* bin 400 - k; the DC lane has no partner bin and stores |X[0]| to bin 0 a second time */ \
+                const double mm_ = mag_sqrt(fma(yr, yr, yi * yi)) * mag_scale;                             \
+                if ((q) == 0) sp[dc_ ? 0 : NF - k] = dc_ ? mk_ : mm_;                                      \
+                else sp[NF - k] = mm_;                                                                     \
             }
+            if (NW == 4) {
+#pragma unroll
+                for (int r = 1; r < 16; ++r) {
+                    a[r] = cmul(make_double2(ax[r], ay[r]), w2[r]);
+                    b[r] = cmul(make_double2(bx[r], by[r]), make_double2(w2[r].x, -w2[r].y));
+                }
+                double2 wp[16];   // W800^(p + 25 q): in flight during the two radix-16 transforms
+#pragma unroll
+                for (int q = 0; q < 16; ++q) wp[q] = t_twp[q * TW_STRIDE + itw];
+                dft16<0>(a);
+                dft16<0>(b);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) PAA_F800_BIN(q, wp[q])
+            } else {
+                // two waves per SIMD: registers matter more than latency (the partner wave hides it), so the table
+                // values are fetched in small groups right before their use and the scheduler may not hoist them
+#pragma unroll
+                for (int r0 = 1; r0 < 16; r0 += 3) {
+                    double2 wg[3];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) wg[u] = t_tw2[(r0 + u) * TW_STRIDE + itw];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        a[r0 + u] = cmul(make_double2(ax[r0 + u], ay[r0 + u]), wg[u]);
+                        b[r0 + u] = cmul(make_double2(bx[r0 + u], by[r0 + u]), make_double2(wg[u].x, -wg[u].y));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                dft16<1>(a);
+                dft16<1>(b);
+                // pin the transforms here: without it the optimiser sinks their second stages into the bin loop below
+                // and both input sets stay live next to the partial results
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(a[r].x), "+v"(a[r].y), "+v"(b[r].x), "+v"(b[r].y));
+#pragma unroll
+                for (int q0_ = 0; q0_ < 16; q0_ += 2) {
+                    double2 wg[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) wg[u] = t_twp[(q0_ + u) * TW_STRIDE + itw];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) PAA_F800_BIN(q0_ + u, wg[u])
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#undef PAA_F800_BIN
         }
         wsync();
+        if (spec_only) continue;
 
         PAA_TICK(4)
         // ---------------- features: 16 lanes per frame (group g <-> frame q0 + g)
@@ -509,6 +594,7 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
         double Xc[25], Xv[25];
 #pragma unroll
         for (int m = 0; m < 25; ++m) { Xc[m] = cur[25 * i + m]; Xv[m] = prv[25 * i + m]; }
+        if (G::ALIAS) wsync();       // the previous-spectrum slot becomes msp[] / fv[] below
         // sums over the lane's 25 bins; two interleaved accumulator sets keep the dependent chains short.
         // sum(ind * X) with ind = (k+1) f0 is f0 * [(25 i + 1) * sum X + sum m X]   (small exact integers)
         // X^2 is accumulated in five 5-bin chunks: their sum is the lane total (roll-off scan), and cut at the lane's
@@ -594,7 +680,7 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
             const double f0d = Xc[24] * rX - Xv[24] * rXp;
             sFa = fma(f0d, f0d, sFa);
         }
-        double sSp = (sSa + sSb) * (f0 * f0 * r), sFl = sFa + sFb;
+        double sSp = (sSa + sSb) * (f0sq * r), sFl = sFa + sFb;
         sSp = group_sum(sSp);
         sFl = group_sum(sFl);
         const double spread = fast_sqrt(sSp * rden);
@@ -748,10 +834,12 @@ __global__ __launch_bounds__(64 * WAVES, PAA_F800_MIN_WAVES_PER_SIMD) void st_fa
 // returns 1 when a specialised kernel exists for this configuration (and fills fl), 0 when
 // the generic kernel must be used, < 0 on error
 inline int fast_select(int window, int step, int sample_kind, double fs, FastTables &ft, const FftPlan &fft,
-                       const MelTable &mel, const ChromaTable &chroma, FastLaunch &fl) {
-    (void)fs;
+                       const MelTable &mel, const ChromaTable &chroma, FastLaunch &fl, int want_waves) {
     if (!(window == 800 && (step == 400 || step == 800) && sample_kind == 0)) return 0;
-    const int wave_bytes = (step == 400) ? f800::Geo<400>::WAVE_BYTES : f800::Geo<800>::WAVE_BYTES;
+    // 8 waves per workgroup (two per SIMD) exist for the 50 %-overlap shape only
+    int nw = (want_waves == 8 && step == 400) ? 8 : 4;
+    int wave_bytes = (step == 400) ? (nw == 8 ? f800::Geo<400, 8>::WAVE_BYTES : f800::Geo<400, 4>::WAVE_BYTES)
+                                   : f800::Geo<800, 4>::WAVE_BYTES;
     f800::TabLayout &L = fl.layout;
     auto up4 = [](int n) { return std::max(8, (n + 7) / 8 * 8); };      // lists are unrolled by 8 on the device
     int c0 = 0, c1 = 0, c2 = 0, cc = 0;
@@ -778,7 +866,15 @@ inline int fast_select(int window, int step, int sample_kind, double fs, FastTab
     L.off_tw2 = take(16 * f800::TW_STRIDE * 16);
     L.off_twp = take(16 * f800::TW_STRIDE * 16);
     L.total = off;
-    if ((size_t)L.total + (size_t)f800::WAVES * wave_bytes > 160 * 1024) return 0;   // generic kernel instead
+    L.f0 = fs / (2.0 * (double)f800::NF);
+    L.rf0 = 1.0 / L.f0;
+    L.r_half_fs = 1.0 / (fs / 2.0);
+    L.f0sq = L.f0 * L.f0;
+    if (nw == 8 && (size_t)L.total + (size_t)nw * wave_bytes > 160 * 1024) {      // tables too large: one wave per SIMD
+        nw = 4;
+        wave_bytes = f800::Geo<400, 4>::WAVE_BYTES;
+    }
+    if ((size_t)L.total + (size_t)nw * wave_bytes > 160 * 1024) return 0;   // generic kernel instead
     if (!ft.d_blob) {
         std::vector<unsigned char> blob((size_t)L.total, 0);
         auto W = [&](int o) { return reinterpret_cast<double *>(blob.data() + o); };
@@ -814,39 +910,39 @@ inline int fast_select(int window, int step, int sample_kind, double fs, FastTab
         if (hipMalloc(&ft.d_blob, blob.size()) != hipSuccess) return PAA_ERR_OOM;
         if (hipMemcpy(ft.d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) return PAA_ERR_HIP;
     }
-    fl.name = (step == 400) ? "st_fast_800" : "st_fast_800_s800";
-    fl.lds = (size_t)L.total + (size_t)f800::WAVES * wave_bytes;
+    fl.name = (step == 400) ? (nw == 8 ? "st_fast_800_w8" : "st_fast_800") : "st_fast_800_s800";
+    fl.lds = (size_t)L.total + (size_t)nw * wave_bytes;
     fl.variant = (step == 400) ? 800 : 1600;
     fl.run = 256;       // longest run (frames) given to one wave; the plan shrinks it to fill the chip
-    fl.waves_per_cu = f800::WAVES;
+    fl.waves_per_cu = nw;
     return 1;
 }
 
-template <int S, int DELTAS, int FIXED>
+template <int S, int DELTAS, int FIXED, int NW>
 inline int fast_launch_one(const FastLaunch &fl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                            const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,
                            double *d_out, hipStream_t stream) {
     static size_t attr_done = 0;
     if (attr_done < fl.lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&f800::st_fast_800_kernel<S, DELTAS, FIXED>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&f800::st_fast_800_kernel<S, DELTAS, FIXED, NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl.lds) != hipSuccess) return -1;
         attr_done = fl.lds;
     }
-    const unsigned grid = (unsigned)((n_tiles + f800::WAVES - 1) / f800::WAVES);
-    hipLaunchKernelGGL((f800::st_fast_800_kernel<S, DELTAS, FIXED>), dim3(grid), dim3(64 * f800::WAVES), fl.lds, stream,
+    const unsigned grid = (unsigned)((n_tiles + NW - 1) / NW);
+    hipLaunchKernelGGL((f800::st_fast_800_kernel<S, DELTAS, FIXED, NW>), dim3(grid), dim3(64 * NW), fl.lds, stream,
                        P, fl.layout, blob, (const int16_t *)d_packed, clips, norms, tiles, (int)n_tiles, d_out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-template <int S>
+template <int S, int NW>
 inline int fast_launch_step(const FastLaunch &fl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                             const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,
                             double *d_out, hipStream_t stream) {
     if (fl.layout.fixed_lists)
-        return P.deltas ? fast_launch_one<S, 1, 1>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream)
-                        : fast_launch_one<S, 0, 1>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
-    return P.deltas ? fast_launch_one<S, 1, 0>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream)
-                    : fast_launch_one<S, 0, 0>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+        return P.deltas ? fast_launch_one<S, 1, 1, NW>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream)
+                        : fast_launch_one<S, 0, 1, NW>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+    return P.deltas ? fast_launch_one<S, 1, 0, NW>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream)
+                    : fast_launch_one<S, 0, 0, NW>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
 }
 
 inline int fast_launch(const FastLaunch &fl, const PlanDev &P, const FastTables &ft, const void *d_packed,
@@ -854,8 +950,10 @@ inline int fast_launch(const FastLaunch &fl, const PlanDev &P, const FastTables 
                        double *d_out, hipStream_t stream) {
     if (!ft.d_blob) return -1;
     const unsigned char *blob = reinterpret_cast<const unsigned char *>(ft.d_blob);
-    if (fl.variant == 800) return fast_launch_step<400>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
-    if (fl.variant == 1600) return fast_launch_step<800>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+    if (fl.variant == 800 && fl.waves_per_cu == 8)
+        return fast_launch_step<400, 8>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+    if (fl.variant == 800) return fast_launch_step<400, 4>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+    if (fl.variant == 1600) return fast_launch_step<800, 4>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
     return -1;
 }
 

@@ -78,6 +78,7 @@ static std::map<std::pair<double, int>, std::unique_ptr<TableSet>> g_tables;
 static Scratch g_in, g_in2, g_out, g_mid;
 static Scratch g_sim_z, g_sim_small, g_sim_cand, g_sim_in, g_sim_out, g_sim_filt;     // self-similarity row
 static int g_force_generic = 0;
+static int g_f800_waves = 8;          // PAA_F800_WAVES: waves per workgroup of the 800/400 kernel (4 or 8)
 static int g_num_cu = 256;       // multiProcessorCount of the selected device (MI355X: 256)
 // optional per-launch timing of the feature kernel (bench.py's roofline leg)
 static int g_prof = 0;
@@ -292,7 +293,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     // ---- kernel choice + tiles
     p->fast = 0;
     if (mode == 0 && !g_force_generic) {
-        rc = fast_select(window, step, sample_kind, fs, tab->fast, tab->fft, tab->mel, tab->chroma, p->fl);
+        rc = fast_select(window, step, sample_kind, fs, tab->fast, tab->fft, tab->mel, tab->chroma, p->fl, g_f800_waves);
         if (rc < 0) return fail(rc, "building the tables of the specialised kernel failed");
         p->fast = rc;
     }
@@ -378,11 +379,11 @@ static int launch_stats(paa_plan *p, const void *d_packed) {
     if (p->sample_kind == 1)
         hipLaunchKernelGGL((clip_params_kernel<double, double>), dim3(gb), dim3(64), 0, g_stream, p->d_clips,
                            p->n_clips, (const double *)p->d_psum, (const double *)p->d_pmin,
-                           (const double *)p->d_pmax, sample_scale<double>(), p->d_norms);
+                           (const double *)p->d_pmax, sample_scale<double>(), p->P.W, p->d_norms);
     else
         hipLaunchKernelGGL((clip_params_kernel<long long, int>), dim3(gb), dim3(64), 0, g_stream, p->d_clips,
                            p->n_clips, (const long long *)p->d_psum, (const int *)p->d_pmin, (const int *)p->d_pmax,
-                           p->sample_kind == 2 ? sample_scale<int>() : sample_scale<int16_t>(), p->d_norms);
+                           p->sample_kind == 2 ? sample_scale<int>() : sample_scale<int16_t>(), p->P.W, p->d_norms);
     HIP_TRY(hipGetLastError());
     return PAA_OK;
 }
@@ -741,6 +742,8 @@ extern "C" int paa_init(int device_id) {
     }
     const char *fg = getenv("PAA_HIP_FORCE_GENERIC");
     g_force_generic = (fg && fg[0] == '1') ? 1 : 0;
+    const char *fw = getenv("PAA_F800_WAVES");          // 4: one wave per SIMD, 8: two (A/B switch, default 8)
+    g_f800_waves = (fw && fw[0] == '4') ? 4 : 8;
     return PAA_OK;
 }
 
