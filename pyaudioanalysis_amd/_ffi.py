@@ -89,6 +89,7 @@ _SIGNATURES = {
     "paa_debug_dct": (C.c_int, [c_f64p]),
     "paa_debug_chroma": (C.c_int, [C.c_double, C.c_int, C.c_int, c_i32p, c_f64p, c_i32p]),
     "paa_debug_phase_cycles": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "paa_debug_wave_trace": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
     "paa_debug_fft_plan": (C.c_int, [C.c_int, c_i32p, c_i32p]),
 }
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))

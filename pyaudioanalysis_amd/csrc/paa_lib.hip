@@ -1086,7 +1086,7 @@ extern "C" int paa_chromagram_f64(const double *s, int64_t n, double fs, int w, 
 extern "C" int paa_debug_phase_cycles(uint64_t *out16) {
     if (!out16) return fail(PAA_ERR_ARG, "null");
     for (int i = 0; i < 16; ++i) out16[i] = 0;
-#ifdef PAA_F800_TIMING
+#if defined(PAA_F800_TIMING) || defined(PAA_F800_TRACE)
     int rc = ensure_init();
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(g_stream));
@@ -1097,6 +1097,21 @@ extern "C" int paa_debug_phase_cycles(uint64_t *out16) {
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(f800::g_phase_cycles), zero, sizeof(zero)));
 #endif
     return PAA_OK;
+}
+
+// per-wave trace of the last st_fast_800 launch (PAA_F800_TIMING builds): 4 words per run, up to 4096 runs
+extern "C" int paa_debug_wave_trace(uint64_t *out, int max_waves) {
+    if (!out || max_waves < 1) return fail(PAA_ERR_ARG, "null");
+#if defined(PAA_F800_TIMING) || defined(PAA_F800_TRACE)
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    const size_t n = (size_t)std::min(max_waves, 4096) * 4 * sizeof(unsigned long long);
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(f800::g_wave_trace), n));
+    return std::min(max_waves, 4096);
+#else
+    return 0;
+#endif
 }
 
 extern "C" int paa_debug_mel_bank(double fs, int num_fft, double *out_dense) {

@@ -1,4 +1,4 @@
-"""Per-phase cycle split of st_fast_800 (needs a build with PAA_HIPCC_FLAGS=-DPAA_F800_TIMING)."""
+"""Per-phase cycle split and per-wave life times of st_fast_800 (needs a build with PAA_HIPCC_FLAGS=-DPAA_F800_TIMING)."""
 import ctypes, sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,5 +20,37 @@ lib.paa_debug_phase_cycles(buf)
 v = np.array(list(buf), dtype=np.float64)
 names = ["stage", "time-domain", "pass1 dft25", "exchange", "pass2+post", "sweepA+entropy", "spread/flux/rolloff", "mel", "chroma", "dct/fv", "store"]
 tot = v[:11].sum()
-print("waves", int(v[15]), "cycles/wave %.0f" % (tot / max(v[15], 1)))
-for n, c in zip(names, v[:11]): print("%-22s %6.2f %%   %.0f cycles/wave-iteration" % (n, 100 * c / tot, c / max(v[15], 1) / 37.0))
+print(plan.kernel_name, "waves", int(v[15]), "cycles/wave %.0f" % (tot / max(v[15], 1)), "steals per launch %.0f" % (v[14] / 5))
+tot = max(tot, 1.0)
+for n, c in zip(names, v[:11]): print("%-22s %6.2f %%   %.0f cycles/wave" % (n, 100 * c / tot, c / max(v[15], 1)))
+tr = (ctypes.c_uint64 * (4096 * 4))()
+n = lib.paa_debug_wave_trace(tr, 4096)
+if n > 0:
+    t = np.array(list(tr), dtype=np.uint64).reshape(-1, 4)
+    nw = min(int(v[15]) // 5, 4096)
+    t = t[:nw]
+    t0 = t[:, 0].astype(np.float64); t1 = t[:, 1].astype(np.float64)
+    base = t0.min()
+    print("waves traced", nw, "kernel span (first start -> last end) %.1f us" % ((t1.max() - base) / 100.0))
+    print("start offsets us: min %.2f median %.2f p90 %.2f max %.2f" % tuple(np.percentile((t0 - base) / 100.0, [0, 50, 90, 100])))
+    life = (t1 - t0) / 100.0
+    print("wave life us: min %.1f median %.1f p90 %.1f max %.1f" % tuple(np.percentile(life, [0, 50, 90, 100])))
+    cyc = t[:, 2].astype(np.float64)
+    print("wave cycles: min %.0f median %.0f max %.0f  -> clock %.2f GHz" % (cyc.min(), np.median(cyc), cyc.max(), np.median(cyc / (life * 1e3))))
+    hw = t[:, 3]
+    cu = (hw >> np.uint64(8)) & np.uint64(15); se = (hw >> np.uint64(13)) & np.uint64(7); sh = (hw >> np.uint64(12)) & np.uint64(1); xcc = (hw >> np.uint64(32)) & np.uint64(15)
+    key = (xcc.astype(np.int64) << 12) | (se.astype(np.int64) << 8) | (sh.astype(np.int64) << 4) | cu.astype(np.int64)
+    uniq, counts = np.unique(key, return_counts=True)
+    print("distinct CUs used", len(uniq), "waves per CU: min %d max %d" % (counts.min(), counts.max()), "histogram", np.bincount(counts))
+    late = np.argsort(t1)[-8:]
+    print("last finishers: start us", np.round((t0[late] - base) / 100.0, 1), "life", np.round(life[late], 1), "tile", late)
+if n > 0:
+    simd = ((hw >> np.uint64(4)) & np.uint64(3)).astype(int)
+    slot = (hw & np.uint64(15)).astype(int)
+    widx = np.arange(nw) % (8 if "w8" in plan.kernel_name else 4)
+    for w in range(widx.max() + 1):
+        m = widx == w
+        print("wave %d of the workgroup: life us mean %.1f min %.1f max %.1f | simd %s slot %s" % (w, life[m].mean(), life[m].min(), life[m].max(), np.bincount(simd[m], minlength=4), np.bincount(slot[m])[:6]))
+    for b in (0, 1, 100, 249):
+        sl = slice(8 * b, 8 * b + 8) if "w8" in plan.kernel_name else slice(4 * b, 4 * b + 4)
+        print("block", b, "life", np.round(life[sl], 0), "simd", simd[sl], "slot", slot[sl], "xcc", xcc[sl][:1])
