@@ -131,6 +131,8 @@ __device__ __forceinline__ void dft4r(double2 &a0, double2 &a1, double2 &a2, dou
 // SERIAL = 1 (two waves per SIMD): every butterfly finishes in place before the next one starts.  Dependent FP64
 // operations issue back to back on gfx950 (profiles/microbench_r02.txt), so nothing is lost, and the scheduler
 // cannot run all butterflies of a stage side by side (which doubles the live registers).
+template <int SERIAL>
+__device__ __forceinline__ void dft25_tail(double2 *v);
 template <int SERIAL = 0>
 __device__ __forceinline__ void dft25(double2 *v) {
 #pragma unroll
@@ -138,6 +140,11 @@ __device__ __forceinline__ void dft25(double2 *v) {
         dft5r(v[r2], v[5 + r2], v[10 + r2], v[15 + r2], v[20 + r2]);
         if (SERIAL) __builtin_amdgcn_sched_barrier(0);
     }
+    dft25_tail<SERIAL>(v);
+}
+// twiddles W25^(r2 q1) and the second stage
+template <int SERIAL>
+__device__ __forceinline__ void dft25_tail(double2 *v) {
 #pragma unroll
     for (int q1 = 1; q1 < 5; ++q1)
 #pragma unroll
@@ -160,6 +167,45 @@ __device__ __forceinline__ void dft25(double2 *v) {
     }
 }
 #define PAA_DFT25_POS(q) (5 * ((q) % 5) + (q) / 5)
+
+// First-stage radix-5 butterfly straight from five packed int16 pairs (lo = real, hi = imaginary part) minus the
+// integer clip mean m: the sums and differences a1 +- a4, a2 +- a3 and a0 + a1 + .. + a4 are whole numbers, so they
+// are formed in 32-bit integer arithmetic (half the issue cost of FP64 on gfx950) and converted once.  Bit-identical to
+// dft5r on the converted samples (every integer involved is exact in f64).
+__device__ __forceinline__ void dft5r_first(int w0, int w1, int w2, int w3, int w4, int m, double2 &a0, double2 &a1,
+                                            double2 &a2, double2 &a3, double2 &a4) {
+    const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+    const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
+    const int x0r = (int)(short)(w0 & 0xffff), x0i = w0 >> 16, x1r = (int)(short)(w1 & 0xffff), x1i = w1 >> 16;
+    const int x2r = (int)(short)(w2 & 0xffff), x2i = w2 >> 16, x3r = (int)(short)(w3 & 0xffff), x3i = w3 >> 16;
+    const int x4r = (int)(short)(w4 & 0xffff), x4i = w4 >> 16;
+    const int m2 = 2 * m;
+    const int t1r = x1r + x4r - m2, t1i = x1i + x4i - m2, t2r = x2r + x3r - m2, t2i = x2i + x3i - m2;
+    const int t3r = x1r - x4r, t3i = x1i - x4i, t4r = x2r - x3r, t4i = x2i - x3i;
+    const int b0r = x0r - m, b0i = x0i - m;
+    const double2 A0 = make_double2((double)b0r, (double)b0i);
+    const double2 T1 = make_double2((double)t1r, (double)t1i), T2 = make_double2((double)t2r, (double)t2i);
+    const double2 T3 = make_double2((double)t3r, (double)t3i), T4 = make_double2((double)t4r, (double)t4i);
+    const double2 M1 = make_double2(fma(c2, T2.x, fma(c1, T1.x, A0.x)), fma(c2, T2.y, fma(c1, T1.y, A0.y)));
+    const double2 M2 = make_double2(fma(c1, T2.x, fma(c2, T1.x, A0.x)), fma(c1, T2.y, fma(c2, T1.y, A0.y)));
+    const double2 N1 = make_double2(fma(s2, T4.x, s1 * T3.x), fma(s2, T4.y, s1 * T3.y));
+    const double2 N2 = make_double2(fma(-s1, T4.x, s2 * T3.x), fma(-s1, T4.y, s2 * T3.y));
+    a0 = make_double2((double)(b0r + t1r + t2r), (double)(b0i + t1i + t2i));
+    a1 = sub_i(M1, N1);
+    a4 = add_i(M1, N1);
+    a2 = sub_i(M2, N2);
+    a3 = add_i(M2, N2);
+}
+// dft25 whose first stage reads the packed samples w[r] (r = 5 r1 + r2 like v[])
+template <int SERIAL>
+__device__ __forceinline__ void dft25_packed(const int *w, int m, double2 *v) {
+#pragma unroll
+    for (int r2 = 0; r2 < 5; ++r2) {
+        dft5r_first(w[r2], w[5 + r2], w[10 + r2], w[15 + r2], w[20 + r2], m, v[r2], v[5 + r2], v[10 + r2], v[15 + r2], v[20 + r2]);
+        if (SERIAL) __builtin_amdgcn_sched_barrier(0);
+    }
+    dft25_tail<SERIAL>(v);
+}
 
 // v[r], r = 4 r1 + r2  ->  result for output q stored at v[4 (q % 4) + q / 4]
 template <int SERIAL = 0>
@@ -211,7 +257,9 @@ __device__ __forceinline__ double fast_sqrt(double x) {
 __device__ __forceinline__ double mag_sqrt(double x) {
     // x is either exactly 0 or far above 1e-300 (squares of sums of integers and their round-off), so clamping the
     // seed's argument replaces the x > 0 select: 0 * rsq(1e-300) = 0 goes through the Newton step unchanged
-    const double y = __builtin_amdgcn_rsq(fmax(x, 1e-300));
+    // (the clamp is an unsigned max on the high dword -- x >= 0 -- which costs half an FP64 issue slot)
+    const unsigned hi_ = max((unsigned)__double2hiint(x), 0x01a56e1fu);         // high dword of 1e-300
+    const double y = __builtin_amdgcn_rsq(__hiloint2double((int)hi_, __double2loint(x)));
     const double g = x * y;
     const double h = 0.5 * y;
     const double r = fma(-h, g, 0.5);
@@ -597,13 +645,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
         double2 v[25];
         {
             const int *r32 = reinterpret_cast<const int *>(raw + RAW_PAD) + (S / 2) * g + i;
+            int w25[25];
 #pragma unroll
-            for (int r = 0; r < 25; ++r) {
-                const int w = r32[16 * r];
-                v[r] = make_double2((double)((int)(short)(w & 0xffff) - m_int), (double)((w >> 16) - m_int));
-            }
+            for (int r = 0; r < 25; ++r) w25[r] = r32[16 * r];
+            dft25_packed<(NW != 4)>(w25, m_int, v);
         }
-        dft25<(NW != 4)>(v);
         wsync();
         PAA_TICK(2)      // raw + chunk partials complete; the previous quad's readers of the slots are done
 
@@ -675,6 +721,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
                 for (int q = 0; q < 16; ++q) wp[q] = t_twp[q * TW_STRIDE + itw];
                 dft16<0>(a);
                 dft16<0>(b);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(a[r].x), "+v"(a[r].y), "+v"(b[r].x), "+v"(b[r].y));
 #pragma unroll
                 for (int q = 0; q < 16; ++q) PAA_F800_BIN(q, wp[q])
             } else {
