@@ -54,6 +54,7 @@ void paa_shutdown(void);                 /* free cached tables, scratch and the 
 int  paa_dev_alloc(size_t bytes, void **out_ptr);
 int  paa_dev_free(void *ptr);
 int  paa_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);   /* synchronous */
+int  paa_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes);    /* queued on the library stream */
 int  paa_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);   /* synchronous */
 int  paa_dev_sync(void);
 /* elapsed GPU milliseconds between two points of the library stream (HIP events) */

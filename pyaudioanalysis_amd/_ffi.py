@@ -36,6 +36,7 @@ _SIGNATURES = {
     "paa_dev_free": (C.c_int, [C.c_void_p]),
     "paa_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "paa_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "paa_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "paa_dev_sync": (C.c_int, []),
     "paa_timer_start": (C.c_int, []),
     "paa_timer_stop": (C.c_int, [C.POINTER(C.c_float)]),

@@ -76,6 +76,16 @@ extern "C" int paa_comm_init(int world_size, int rank, const void *id_bytes) {
     if (rc) return rc;
     if ((rc = rccl_load())) return rc;
     if (!id_bytes || world_size < 1 || rank < 0 || rank >= world_size) return fail(PAA_ERR_ARG, "bad comm arguments");
+    {
+        // One process per GPU.  Two ranks on ONE device make ncclCommInitRank wait forever on this stack (measured: no
+        // "duplicate GPU" error, a hang), so the case is refused before RCCL is called.  Ranks that are each restricted
+        // to their own single device (HIP_VISIBLE_DEVICES per rank) opt in with PAA_COMM_SHARED_DEVICES=1.
+        int n_dev = 0;
+        const char *opt = getenv("PAA_COMM_SHARED_DEVICES");
+        if (hipGetDeviceCount(&n_dev) == hipSuccess && world_size > n_dev && !(opt && opt[0] == '1'))
+            return fail(PAA_ERR_COMM, "paa_comm_init: %d ranks but only %d visible device(s): one process per GPU "
+                        "(set PAA_COMM_SHARED_DEVICES=1 if every rank sees only its own device)", world_size, n_dev);
+    }
     if (g_comm) paa_comm_destroy();
     ncclUniqueId id;
     memcpy(&id, id_bytes, sizeof(id));
@@ -108,6 +118,7 @@ extern "C" int paa_comm_destroy(void) {
 
 extern "C" int paa_comm_gather_f64(const double *d_send, const int64_t *counts, int root, double *d_recv) {
     if (!counts) return fail(PAA_ERR_ARG, "null counts");
+    std::lock_guard<std::mutex> lk(g_mu);      // g_gather_done is shared with paa_plan_execute
     if (!g_comm) {
         if (g_world != 1) return fail(PAA_ERR_COMM, "communicator not initialised");
         if (d_recv && d_send && d_recv != d_send)

@@ -106,12 +106,20 @@ struct Geo {
 };
 
 // ---- register DFTs ------------------------------------------------------------------------
+// cos(144 deg) = -1/2 - cos(72 deg), so  a0 + c1 t1 + c2 t2 = (a0 - t2/2) + c1 (t1 - t2)  and
+// a0 + c2 t1 + c1 t2 = (a0 - t1/2) - c1 (t1 - t2).  In this form five EQUAL inputs give exactly zero in the four
+// non-DC outputs (t1 = t2 = 2 a0: every bracket is an exact zero), where the textbook form leaves a0 * 1e-16.  Frames of
+// digital silence are constant after the clip mean is removed; the reference (pocketfft: radix-4 passes first, plain
+// differences of equal numbers) returns exact zeros for their non-DC bins, and log10(E + eps) of a mel band resolves 1e-24.
 __device__ __forceinline__ void dft5r(double2 &a0, double2 &a1, double2 &a2, double2 &a3, double2 &a4) {
-    const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+    const double c1 = 0.30901699437494742410;
     const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
     const double2 t1 = cadd(a1, a4), t2 = cadd(a2, a3), t3 = csub(a1, a4), t4 = csub(a2, a3);
-    const double2 m1 = make_double2(fma(c2, t2.x, fma(c1, t1.x, a0.x)), fma(c2, t2.y, fma(c1, t1.y, a0.y)));
-    const double2 m2 = make_double2(fma(c1, t2.x, fma(c2, t1.x, a0.x)), fma(c1, t2.y, fma(c2, t1.y, a0.y)));
+    const double2 d = csub(t1, t2);
+    const double2 h1 = make_double2(fma(-0.5, t1.x, a0.x), fma(-0.5, t1.y, a0.y));
+    const double2 h2 = make_double2(fma(-0.5, t2.x, a0.x), fma(-0.5, t2.y, a0.y));
+    const double2 m1 = make_double2(fma(c1, d.x, h2.x), fma(c1, d.y, h2.y));
+    const double2 m2 = make_double2(fma(-c1, d.x, h1.x), fma(-c1, d.y, h1.y));
     const double2 n1 = make_double2(fma(s2, t4.x, s1 * t3.x), fma(s2, t4.y, s1 * t3.y));
     const double2 n2 = make_double2(fma(-s1, t4.x, s2 * t3.x), fma(-s1, t4.y, s2 * t3.y));
     a0 = make_double2(a0.x + t1.x + t2.x, a0.y + t1.y + t2.y);
@@ -170,11 +178,11 @@ __device__ __forceinline__ void dft25_tail(double2 *v) {
 
 // First-stage radix-5 butterfly straight from five packed int16 pairs (lo = real, hi = imaginary part) minus the
 // integer clip mean m: the sums and differences a1 +- a4, a2 +- a3 and a0 + a1 + .. + a4 are whole numbers, so they
-// are formed in 32-bit integer arithmetic (half the issue cost of FP64 on gfx950) and converted once.  Bit-identical to
+// are formed in 32-bit integer arithmetic (half the issue cost of FP64 on gfx950) and converted once.  Same values as
 // dft5r on the converted samples (every integer involved is exact in f64).
 __device__ __forceinline__ void dft5r_first(int w0, int w1, int w2, int w3, int w4, int m, double2 &a0, double2 &a1,
                                             double2 &a2, double2 &a3, double2 &a4) {
-    const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+    const double c1 = 0.30901699437494742410;
     const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
     const int x0r = (int)(short)(w0 & 0xffff), x0i = w0 >> 16, x1r = (int)(short)(w1 & 0xffff), x1i = w1 >> 16;
     const int x2r = (int)(short)(w2 & 0xffff), x2i = w2 >> 16, x3r = (int)(short)(w3 & 0xffff), x3i = w3 >> 16;
@@ -183,11 +191,13 @@ __device__ __forceinline__ void dft5r_first(int w0, int w1, int w2, int w3, int 
     const int t1r = x1r + x4r - m2, t1i = x1i + x4i - m2, t2r = x2r + x3r - m2, t2i = x2i + x3i - m2;
     const int t3r = x1r - x4r, t3i = x1i - x4i, t4r = x2r - x3r, t4i = x2i - x3i;
     const int b0r = x0r - m, b0i = x0i - m;
-    const double2 A0 = make_double2((double)b0r, (double)b0i);
-    const double2 T1 = make_double2((double)t1r, (double)t1i), T2 = make_double2((double)t2r, (double)t2i);
+    // the brackets of dft5r's exact-zero form, still in integers: d = t1 - t2, 2 h1 = 2 a0 - t1, 2 h2 = 2 a0 - t2
+    const double2 D = make_double2((double)(t1r - t2r), (double)(t1i - t2i));
+    const double2 H1 = make_double2(0.5 * (double)(2 * b0r - t1r), 0.5 * (double)(2 * b0i - t1i));
+    const double2 H2 = make_double2(0.5 * (double)(2 * b0r - t2r), 0.5 * (double)(2 * b0i - t2i));
     const double2 T3 = make_double2((double)t3r, (double)t3i), T4 = make_double2((double)t4r, (double)t4i);
-    const double2 M1 = make_double2(fma(c2, T2.x, fma(c1, T1.x, A0.x)), fma(c2, T2.y, fma(c1, T1.y, A0.y)));
-    const double2 M2 = make_double2(fma(c1, T2.x, fma(c2, T1.x, A0.x)), fma(c1, T2.y, fma(c2, T1.y, A0.y)));
+    const double2 M1 = make_double2(fma(c1, D.x, H2.x), fma(c1, D.y, H2.y));
+    const double2 M2 = make_double2(fma(-c1, D.x, H1.x), fma(-c1, D.y, H1.y));
     const double2 N1 = make_double2(fma(s2, T4.x, s1 * T3.x), fma(s2, T4.y, s1 * T3.y));
     const double2 N2 = make_double2(fma(-s1, T4.x, s2 * T3.x), fma(-s1, T4.y, s2 * T3.y));
     a0 = make_double2((double)(b0r + t1r + t2r), (double)(b0i + t1i + t2i));

@@ -203,8 +203,10 @@ struct paa_plan {
     std::string kernel_name;
 };
 
+static int g_live_plans = 0;          // plans hold raw pointers into the device's table sets
 static void plan_free(paa_plan *p) {
     if (!p) return;
+    --g_live_plans;
     (void)hipFree(p->d_clips); (void)hipFree(p->d_norms); (void)hipFree(p->d_tiles); (void)hipFree(p->d_chunks);
     (void)hipFree(p->d_psum); (void)hipFree(p->d_pmin); (void)hipFree(p->d_pmax); (void)hipFree(p->d_mid_off); (void)hipFree(p->d_gen_blob); (void)hipFree(p->d_big);
     delete p;
@@ -220,6 +222,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         return fail(PAA_ERR_ARG, "sample_kind must be 0 (int16), 1 (float64) or 2 (int32 stereo sums)");
     if (!(fs > 0)) return fail(PAA_ERR_ARG, "sampling rate must be positive");
     std::unique_ptr<paa_plan, void (*)(paa_plan *)> p(new paa_plan(), plan_free);
+    ++g_live_plans;
     p->n_clips = n_clips;
     p->sample_kind = sample_kind;
     p->mode = mode;
@@ -301,7 +304,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     if (p->fast) {
         // one wave per run; size the runs so that the launch is close to a whole number of chip-wide
         // rounds (256 CUs x resident waves), in multiples of the 4-frame quad, at most fl.run frames
-        const long long slots = 256LL * p->fl.waves_per_cu;
+        const long long slots = (long long)g_num_cu * p->fl.waves_per_cu;
         const long long per = (total_frames + slots - 1) / slots;
         const long long rounds = (per + p->fl.run - 1) / p->fl.run;     // fl.run = longest run worth one wave
         long long r = (per + std::max<long long>(rounds, 1) - 1) / std::max<long long>(rounds, 1);
@@ -321,7 +324,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         }
         // one wave per run: about two chip-wide rounds of (256 CUs x waves per workgroup), 8..64 frames per run
         {
-            const long long slots = 256LL * p->gl.waves * 2;
+            const long long slots = (long long)g_num_cu * p->gl.waves * 2;
             const long long per = (total_frames + slots - 1) / slots;
             run = (int)std::min<long long>(64, std::max<long long>(8, (per + 3) / 4 * 4));
         }
@@ -730,7 +733,13 @@ extern "C" int paa_init(int device_id) {
     if (e != hipSuccess || n < 1)
         return fail(PAA_ERR_HIP, "no HIP device (%s); this library has no CPU path", hipGetErrorString(e));
     if (device_id < 0 || device_id >= n) return fail(PAA_ERR_ARG, "device %d out of range (%d devices)", device_id, n);
-    if (g_device >= 0 && g_device != device_id) paa_shutdown();
+    if (g_device >= 0 && g_device != device_id) {
+        // live plans and caller-owned device buffers point into the current device: switching would leave them dangling
+        if (g_live_plans > 0)
+            return fail(PAA_ERR_ARG, "paa_init(%d): %d plan(s) of device %d are still alive; destroy them first",
+                        device_id, g_live_plans, g_device);
+        paa_shutdown();
+    }
     HIP_TRY(hipSetDevice(device_id));
     HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&g_ev0));
@@ -749,6 +758,7 @@ extern "C" int paa_init(int device_id) {
 
 extern "C" void paa_shutdown(void) {
     if (g_device < 0) return;
+    (void)paa_comm_destroy();          // communicator, its stream and events
     if (g_stream) (void)hipStreamSynchronize(g_stream);
     for (auto &kv : g_tables) free_tables(*kv.second);
     g_tables.clear();
@@ -772,6 +782,12 @@ extern "C" int paa_dev_free(void *ptr) {
     if (ptr) HIP_TRY(hipFree(ptr));
     return PAA_OK;
 }
+extern "C" int paa_memcpy_d2d(void *dst, const void *src, size_t bytes) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream));
+    return PAA_OK;
+}
 extern "C" int paa_memcpy_h2d(void *dst, const void *src, size_t bytes) {
     int rc = ensure_init();
     if (rc) return rc;
@@ -782,6 +798,7 @@ extern "C" int paa_memcpy_h2d(void *dst, const void *src, size_t bytes) {
 extern "C" int paa_memcpy_d2h(void *dst, const void *src, size_t bytes) {
     int rc = ensure_init();
     if (rc) return rc;
+    if ((rc = comm_sync())) return rc;       // a gather into src may still run on the communication stream
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream));
     HIP_TRY(hipStreamSynchronize(g_stream));
     return PAA_OK;

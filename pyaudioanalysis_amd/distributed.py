@@ -71,7 +71,10 @@ def split_gathered(flat, frames, n_rows):
 
 
 class RcclGather:
-    """The RCCL communicator of libpaa_hip.so for this process (one per GPU)."""
+    """The RCCL communicator of libpaa_hip.so for this process (one per GPU).
+
+    The interface extract_sharded() needs from a communicator is gather / barrier / close; the CPU tests inject a
+    gloo-backed object with the same three methods."""
 
     def __init__(self, world_size, rank, broadcast_bytes):
         """broadcast_bytes(payload_or_None) -> payload: broadcast from rank 0 over any control-plane group."""
@@ -79,6 +82,7 @@ class RcclGather:
         buf = ctypes.create_string_buffer(_ffi.COMM_ID_BYTES)
         if rank == 0:
             _ffi.check(lib.paa_comm_unique_id(buf))
+        # (a control plane that already holds an id -- e.g. one created by a launcher process -- may return that one)
         payload = broadcast_bytes(bytes(buf.raw) if rank == 0 else None)
         buf = ctypes.create_string_buffer(payload, _ffi.COMM_ID_BYTES)
         _ffi.check(lib.paa_comm_init(int(world_size), int(rank), buf))
@@ -96,12 +100,40 @@ class RcclGather:
         _ffi.lib().paa_comm_destroy()
 
 
-def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank, comm, root=0):
-    """Rank-local part of a sharded batch extraction on the GPU.
+class HipEngine:
+    """The compute / memory side of extract_sharded() on the GPU (libpaa_hip.so).  The CPU tests inject an object with
+    the same four methods (extract, alloc, to_host, sync) so that the sharding logic itself runs without a device."""
+
+    def extract(self, clips, sampling_rate, window, step, deltas):
+        """int16 clips -> device buffer holding their [F][T_c] slabs back to back (kept in HBM)."""
+        offsets = np.zeros(len(clips) + 1, dtype=np.int64)
+        np.cumsum([len(c) for c in clips], out=offsets[1:])
+        d_in = _ffi.DeviceBuffer.from_host(np.concatenate(clips) if len(clips) > 1 else clips[0])
+        plan = _ffi.Plan(offsets, sampling_rate, window, step, deltas=deltas, sample_kind=0)
+        d_out = _ffi.DeviceBuffer(max(plan.out_doubles, 1) * 8)
+        plan.execute(d_in, d_out)
+        d_out._keep = (d_in, plan)          # the launch is asynchronous: inputs live as long as the result
+        return d_out
+
+    def alloc(self, n_doubles):
+        return _ffi.DeviceBuffer(max(int(n_doubles), 1) * 8)
+
+    def to_host(self, buf, n_doubles):
+        return buf.to_host(np.float64, int(n_doubles))
+
+    def sync(self):
+        _ffi.sync()
+
+
+def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank, comm, root=0, engine=None):
+    """Rank-local part of a sharded batch extraction.
 
     clips: the FULL list of int16 clips (every rank sees the list; only its own range is uploaded).
+    comm: gather(send, counts, root, recv) / barrier() / close() -- RcclGather on the GPU.
+    engine: extract / alloc / to_host / sync -- HipEngine (default) on the GPU.
     Returns, on the root, the list of (F, T_c) arrays for all clips (None elsewhere).
     """
+    engine = engine or HipEngine()
     window, step = int(window), int(step)
     lengths = [len(c) for c in clips]
     frames = frames_per_clip(lengths, window, step)
@@ -112,20 +144,11 @@ def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank
     counts = block_counts(frames, ranges, F)
     a, b = ranges[rank]
     mine = [np.ascontiguousarray(c, dtype=np.int16) for c in clips[a:b]]
-    d_out = None
-    if mine:
-        offsets = np.zeros(len(mine) + 1, dtype=np.int64)
-        np.cumsum([len(c) for c in mine], out=offsets[1:])
-        d_in = _ffi.DeviceBuffer.from_host(np.concatenate(mine))
-        plan = _ffi.Plan(offsets, sampling_rate, window, step, deltas=deltas, sample_kind=0)
-        d_out = _ffi.DeviceBuffer(max(plan.out_doubles, 1) * 8)
-        plan.execute(d_in, d_out)
-    else:
-        d_out = _ffi.DeviceBuffer(8)
-    d_all = _ffi.DeviceBuffer(int(counts.sum()) * 8) if rank == root else None
+    d_out = engine.extract(mine, sampling_rate, window, step, deltas) if mine else engine.alloc(1)
+    d_all = engine.alloc(int(counts.sum())) if rank == root else None
     comm.gather(d_out, counts, root, d_all)
-    _ffi.sync()
+    engine.sync()
     if rank != root:
         return None
-    flat = d_all.to_host(np.float64, int(counts.sum()))
+    flat = engine.to_host(d_all, int(counts.sum()))
     return split_gathered(flat, frames, F)

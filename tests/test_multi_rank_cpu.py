@@ -1,6 +1,7 @@
-"""World-size-2 test of the sharded many-clip path on CPU (gloo): partitioning by frames, per-rank blocks,
-gather to rank 0 and re-assembly.  The per-rank compute is the CPU oracle standing in for the GPU kernels
-(no GPU here); the exchanged bytes, counts and layout are exactly those of the RCCL path."""
+"""World-size-2 test of the sharded many-clip path on CPU (gloo): the workers call the product's own
+distributed.extract_sharded() -- partitioning by frames, per-rank blocks, gather to rank 0, re-assembly -- with a gloo
+communicator and an oracle-backed engine injected in place of RcclGather / HipEngine (no GPU here); the exchanged bytes,
+counts and layout are exactly those of the RCCL path."""
 import os
 import socket
 import sys
@@ -17,6 +18,64 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+class _HostBuf:
+    def __init__(self, arr):
+        self.arr = arr
+
+
+class _OracleEngine:
+    """Stands in for distributed.HipEngine on a host without a GPU: same four methods, NumPy buffers, the CPU oracle as
+    the per-rank compute (test infrastructure -- the product module never imports it)."""
+
+    def __init__(self, oracle):
+        self.O = oracle
+
+    def extract(self, clips, sampling_rate, window, step, deltas):
+        return _HostBuf(np.concatenate([self.O.feature_extraction(c, sampling_rate, window, step, deltas)[0].reshape(-1)
+                                        for c in clips]))
+
+    def alloc(self, n_doubles):
+        return _HostBuf(np.zeros(max(int(n_doubles), 1)))
+
+    def to_host(self, buf, n_doubles):
+        return buf.arr[:int(n_doubles)]
+
+    def sync(self):
+        pass
+
+
+class _GlooGather:
+    """Stands in for distributed.RcclGather: the same variable-size gather to the root (what paa_comm_gather_f64 does with
+    grouped ncclSend / ncclRecv), over torch.distributed point-to-point on gloo."""
+
+    def __init__(self, dist, torch, world_size, rank):
+        self.dist, self.torch, self.world_size, self.rank = dist, torch, world_size, rank
+
+    def gather(self, send, counts, root, recv):
+        counts = [int(c) for c in counts]
+        if self.rank == root:
+            off, reqs, parts = 0, [], {}
+            for r in range(self.world_size):
+                if r != root and counts[r] > 0:
+                    parts[r] = (off, self.torch.empty(counts[r], dtype=self.torch.float64))
+                    reqs.append(self.dist.irecv(parts[r][1], src=r))
+                elif r == root:
+                    recv.arr[off:off + counts[r]] = send.arr[:counts[r]]
+                off += counts[r]
+            for q in reqs:
+                q.wait()
+            for r, (o, t) in parts.items():
+                recv.arr[o:o + counts[r]] = t.numpy()
+        elif counts[self.rank] > 0:
+            self.dist.send(self.torch.from_numpy(send.arr[:counts[self.rank]].copy()), dst=root)
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def close(self):
+        pass
 
 
 def _worker(rank, world, port, q):
@@ -38,27 +97,18 @@ def _worker(rank, world, port, q):
         frames = D.frames_per_clip(lens, W, S)
         ranges = D.partition_by_frames(frames, world)
         counts = D.block_counts(frames, ranges, F)
-        a, b = ranges[rank]
-        block = np.concatenate([O.feature_extraction(c, 16000, W, S)[0].reshape(-1) for c in clips[a:b]]) \
-            if b > a else np.zeros(0)
-        assert len(block) == counts[rank]
-        # variable-size gather to rank 0 (what paa_comm_gather_f64 does with ncclSend/ncclRecv)
-        send = torch.from_numpy(block.copy())
+        comm = _GlooGather(dist, torch, world, rank)
+        # the product's own sharding function, with the communicator and the engine injected
+        per_clip = D.extract_sharded(clips, 16000, W, S, True, world, rank, comm, root=0, engine=_OracleEngine(O))
+        comm.barrier()
         if rank == 0:
-            parts = [send] + [torch.empty(int(counts[r]), dtype=torch.float64) for r in range(1, world)]
-            reqs = [dist.irecv(parts[r], src=r) for r in range(1, world)]
-            for r in reqs:
-                r.wait()
-            flat = torch.cat(parts).numpy()
-            per_clip = D.split_gathered(flat, frames, F)
-            ok = True
-            for c, got in zip(clips, per_clip):
+            ok = per_clip is not None and len(per_clip) == len(clips)
+            for c, got in zip(clips, per_clip or []):
                 ref, _ = O.feature_extraction(c, 16000, W, S)
                 ok &= bool(np.array_equal(got, ref))
             q.put(("ok" if ok else "mismatch", ranges, counts.tolist()))
         else:
-            dist.send(send, dst=0)
-        dist.barrier()
+            assert per_clip is None
     finally:
         dist.destroy_process_group()
 

@@ -1,0 +1,106 @@
+"""Parity at BASELINE.json's FULL sizes for the configurations the golden / seeded tests only cover small
+(configs[2..4]): the whole batch runs through the C ABI, a strided sample of its units is checked against the CPU
+oracle with the tight gate of test_parity_gpu, and size-independent properties cover the rest (identical clips give
+identical slabs wherever they sit, rows the reference leaves zero stay zero, deltas are exact differences).  -m gpu."""
+import numpy as np
+import pytest
+
+import paa_oracle as O
+from pyaudioanalysis_amd import MidTermFeatures, ShortTermFeatures
+from synth import synth_clip
+from test_parity_gpu import assert_parity
+
+pytestmark = pytest.mark.gpu
+FS = 16000
+
+
+def test_config4_shard_12500_clips(gpu_lib):
+    """One GPU's share of config 4: 12 500 x 10 s clips (16 distinct seeded clips, tiled), 800/400, 34 rows."""
+    pool = [synth_clip(40000 + i, 10 * FS) for i in range(16)]
+    clips = [pool[k % 16] for k in range(12500)]
+    res, names = ShortTermFeatures.feature_extraction_batch(clips, FS, 800, 400, deltas=False)
+    assert len(res) == 12500 and len(names) == 34 and res[0].shape == (34, 399)
+    for k in range(16, 12500):                       # position in the batch never changes a clip's bits
+        assert np.array_equal(res[k], res[k % 16]), k
+    for k in (0, 5, 1037, 6250, 12499):              # distinct clips at distinct places against the oracle
+        ref, _ = O.feature_extraction(clips[k], FS, 800, 400, deltas=False)
+        assert_parity(res[k], ref, "config 4 clip %d" % k, sig=(clips[k], FS, 800, 400))
+
+
+def test_config3_1000_clips_mid_term(gpu_lib):
+    """Config 3: mid_feature_extraction (1.0 s / 1.0 s over 50 ms / 25 ms) on 1000 x 30 s clips in one batch."""
+    pool = [synth_clip(3000 + i, 30 * FS) for i in range(8)]
+    clips = [pool[k % 8] for k in range(1000)]
+    mids, sts, names = MidTermFeatures.mid_feature_extraction_batch(clips, FS, FS, FS, 800, 400, return_short=True)
+    assert len(mids) == 1000 and mids[0].shape == (136, 30) and sts[0].shape == (68, 1199) and len(names) == 136
+    for k in range(8, 1000):
+        assert np.array_equal(mids[k], mids[k % 8]), k
+    for k in (0, 3, 501, 999):
+        ref_mid, ref_st, _ = O.mid_feature_extraction(clips[k], FS, FS, FS, 800, 400)
+        sig = (clips[k], FS, 800, 400)
+        assert_parity(sts[k], ref_st, "config 3 short %d" % k, sig=sig)
+        assert_parity(mids[k], ref_mid, "config 3 mid %d" % k, sig=sig)
+
+
+@pytest.fixture(scope="module")
+def cfg5_clip():
+    fs = 44100
+    xs = synth_clip(5, 600 * fs, fs=fs, stereo=True)          # SEED = 5, 600 s, stereo int16
+    mono = O.stereo_to_mono(xs)
+    return fs, xs, mono, O.normalize_clip(mono)
+
+
+def test_config5_features_600s_stereo(gpu_lib, cfg5_clip):
+    """Config 5: 44.1 kHz stereo -> mono fused on the device, window 25 ms / step 10 ms (1102 / 441)."""
+    fs, xs, mono, xn = cfg5_clip
+    W, S = int(0.025 * fs), int(0.010 * fs)
+    F, _ = ShortTermFeatures.feature_extraction(xs, fs, 0.025 * fs, 0.010 * fs)
+    T = (len(mono) - W) // S + 1
+    assert F.shape == (68, T) and np.all(np.isfinite(F))
+    assert np.array_equal(F[34:, 1:], F[:34, 1:] - F[:34, :-1]) and np.all(F[34:, 0] == 0.0)
+    tab = O.Tables(fs, W)
+    frames = [0, 1, 2, 77, T // 3, T // 2, T - 2, T - 1]
+    ref = np.empty((34, len(frames)))
+    for n, t in enumerate(frames):
+        fr = xn[t * S:t * S + W]
+        X = O.magnitude_spectrum(fr, tab.nfft)
+        Xp = X if t == 0 else O.magnitude_spectrum(xn[(t - 1) * S:(t - 1) * S + W], tab.nfft)
+        ref[:, n] = O.frame_vector(fr, X, Xp, tab)
+    assert_parity(np.ascontiguousarray(F[:34, frames]), ref, "config 5 sampled frames")
+
+
+def test_config5_spectrogram_chromagram_600s(gpu_lib, cfg5_clip, capsys):
+    """Config 5's own path: spectrogram (:389-452) and chromagram (:324-386) of the 600 s clip, including the rows the
+    reference allocates but never fills and the truncated tail frame of the chromagram."""
+    fs, xs, mono, xn = cfg5_clip
+    W, S = 1102, 441
+    n = len(mono)
+    spec, t_ax, f_ax = ShortTermFeatures.spectrogram(xs, fs, W, S)
+    assert "(%d, %d)" % spec.shape in capsys.readouterr().out
+    rows = int((n - W) / S) + 1
+    starts = list(range(W, n - W + 1, S))
+    assert spec.shape == (rows, W // 2) and len(t_ax) == rows and len(f_ax) == W // 2
+    assert np.all(spec[len(starts):] == 0.0)                     # allocated, never filled (:413-415)
+    pick = [0, 1, 2, len(starts) // 2, len(starts) - 2, len(starts) - 1]
+    ref = np.stack([O.magnitude_spectrum(xn[starts[i]:starts[i] + W], W // 2) for i in pick])
+    assert_parity(np.ascontiguousarray(spec[pick].T), np.ascontiguousarray(ref.T), "config 5 spectrogram rows")
+
+    chroma, ct_ax, cnames = ShortTermFeatures.chromagram(xs, fs, W, S)
+    crows = int((n - S - W) / S) + 1
+    cstarts = list(range(W, n - S, S))
+    assert chroma.shape == (crows, 12) and len(ct_ax) == crows and cnames == O.CHROMA_NAMES
+    assert len(xn[cstarts[-1]:cstarts[-1] + W]) < W              # the last frame really is truncated (:349-355)
+    assert np.all(chroma[len(cstarts):] == 0.0)
+    tab = O.Tables(fs, W)
+    pick = [0, 1, len(cstarts) // 2, len(cstarts) - 3, len(cstarts) - 2, len(cstarts) - 1]
+    ref = np.zeros((len(pick), 12))
+    for m, i in enumerate(pick):
+        x = xn[cstarts[i]:cstarts[i] + W]
+        X = np.abs(np.fft.fft(x))[0:W // 2]
+        X = X / len(X)
+        P = X ** 2
+        grid = np.zeros((int(np.ceil((W // 2) / 12.0)) * 12,))
+        grid[tab.ch_pos] = P[tab.ch_src] * tab.ch_w
+        c = grid.reshape(-1, 12).sum(axis=0)
+        ref[m] = c / O.EPS if P.sum() == 0 else c / P.sum()
+    assert_parity(np.ascontiguousarray(chroma[pick].T), np.ascontiguousarray(ref.T), "config 5 chromagram rows")
