@@ -4,17 +4,27 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = one pass of the hot path (clip statistics -> features) over one batch of synthetic
+A "step" = one pass of the hot path (clip statistics -> clip constants -> features) over one batch of synthetic
 16 kHz int16 PCM that is already resident in HBM; the [34][T] float64 result stays in HBM.
-Workload per rank (weak scaling): BASELINE config 2 -- one synthetic 1-hour 16 kHz mono clip,
-window 50 ms / step 25 ms (800/400 samples), 143 999 frames, full 34-feature vector.
-With N > 1 every rank processes its own 1-hour clip (seed 2 + rank) and the [34][T] blocks are
-gathered to rank 0 with RCCL (paa_comm_gather_f64) inside the timed step.
 
-torch is used for process-group plumbing only (rendezvous, barrier, max over ranks): the compute
-path is ctypes -> libpaa_hip.so.  Prints ONE JSON line on rank 0.
+N = 1 (the headline): BASELINE config 2 -- one synthetic 1-hour 16 kHz mono clip, window 50 ms / step 25 ms
+  (800/400 samples), 143 999 frames, full 34-feature vector.  The steps rotate over THREE distinct clips (3 x 115 MB of
+  input: more than the 256 MiB Infinity Cache) so that the input really comes from HBM.
+N > 1 (default): BASELINE config 4, strong scaling -- 100 000 synthetic 10 s clips (64 distinct seeded clips, tiled)
+  split into contiguous ranges with distributed.partition_by_frames, every rank extracts its range and the [34][399]
+  slabs are gathered to rank 0 with RCCL (paa_comm_gather_f64, own stream, overlapping the next step) inside the timed
+  region; the same steps are also timed without the gather.  --workload cfg2 gives one 1-hour clip per rank instead
+  (weak scaling).
+
+The line also carries (N = 1): the other BASELINE configurations kernel-resident (config.others: config 3 mid-term
+batch, a config-4 shard, config 5 features / spectrogram / chromagram), the host-to-host rate of the drop-in API,
+a >= 2 s sustained loop, and the CPU ports on one core and on all host cores.
+
+torch is used for process-group plumbing only (rendezvous, barrier, max over ranks): the compute path is
+ctypes -> libpaa_hip.so.  Prints ONE JSON line on rank 0.  Nothing here reads /root/reference.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -30,63 +40,138 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 FS, WINDOW, STEP = 16000, 800, 400
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6          # datasheet; informational only
+KFLOP_PER_FRAME = 45.0                # ~35-55 kflop of FP64 per 800/400 frame
+CFG4_TOTAL_CLIPS = 100000
 
 
-def make_workload(name, rank, seconds):
-    """-> (packed int16, offsets int64, description)."""
+def replicate_on_device(ffi, pool_host, n_units):
+    """Device buffer holding n_units copies-in-rotation of the pool's units (pool_host: [n_pool, unit] array): the pool
+    goes over PCIe once, the tiling is device-to-device."""
+    lib = ffi.lib()
+    n_pool, unit = pool_host.shape
+    unit_bytes = unit * pool_host.itemsize
+    d_pool = ffi.DeviceBuffer.from_host(pool_host.reshape(-1))
+    d_all = ffi.DeviceBuffer(n_units * unit_bytes)
+    done = 0
+    while done < n_units:
+        cnt = min(n_pool, n_units - done)
+        ffi.check(lib.paa_memcpy_d2d(ctypes.c_void_p(d_all.ptr.value + done * unit_bytes), d_pool.ptr, cnt * unit_bytes))
+        done += cnt
+    ffi.sync()
+    return d_all
+
+
+def timed(ffi, fn, steps, warmup):
+    """HIP-event time per call of fn() on the library stream (ms)."""
+    lib = ffi.lib()
+    for _ in range(warmup):
+        fn()
+    ffi.sync()
+    ffi.check(lib.paa_timer_start())
+    for _ in range(steps):
+        fn()
+    ms = ctypes.c_float()
+    ffi.check(lib.paa_timer_stop(ctypes.byref(ms)))
+    return ms.value / steps
+
+
+def other_configs(ffi, steps=8):
+    """BASELINE configs 3, 4 (one GPU's shard) and 5, kernel-resident, with SURVEY 8d's algorithmic bytes per frame."""
     from synth import synth_clip
-    if name == "cfg2":
-        n = int(seconds * FS)
-        x = synth_clip(2 + rank, n, FS)
-        return x, np.array([0, n], dtype=np.int64), "cfg2: 1 clip x %d s, 16 kHz mono int16, 800/400, 34 features" % seconds
-    if name == "cfg4":
-        # many 10 s clips; a pool of 64 distinct seeded clips is tiled to the batch size
-        n_clips = int(seconds)
-        n = 10 * FS
-        pool = [synth_clip(40000 + 1000 * rank + i, n, FS) for i in range(min(64, n_clips))]
-        packed = np.concatenate([pool[i % len(pool)] for i in range(n_clips)])
-        return packed, np.arange(n_clips + 1, dtype=np.int64) * n, "cfg4-shard: %d clips x 10 s (64 distinct, tiled)" % n_clips
-    raise SystemExit("unknown workload " + name)
+    out = {}
+
+    def entry(frames, ms, bytes_per_frame, kernel, extra=None):
+        e = {"frames_per_step": int(frames), "ms_per_step": ms, "frames_per_s": frames / (ms * 1e-3),
+             "algorithmic_bytes_per_frame": bytes_per_frame,
+             "achieved_GBps": bytes_per_frame * frames / (ms * 1e-3) / 1e9, "kernel": kernel}
+        e["hbm_frac"] = e["achieved_GBps"] / HBM_PEAK_GBS
+        if extra:
+            e.update(extra)
+        return e
+
+    # ---- config 3: 1000 x 30 s, short 800/400 with deltas (what mid_feature_extraction computes), mid 1.0 s / 1.0 s
+    n3 = 30 * FS
+    pool = np.stack([synth_clip(3000 + i, n3, FS) for i in range(8)])
+    d_in = replicate_on_device(ffi, pool, 1000)
+    plan = ffi.Plan(np.arange(1001, dtype=np.int64) * n3, FS, WINDOW, STEP, deltas=True)
+    d_st = ffi.DeviceBuffer(plan.out_doubles * 8)
+    d_mid = ffi.DeviceBuffer(plan.mid_doubles(40) * 8)
+
+    def step3():
+        plan.execute(d_in, d_st)
+        plan.mid_execute(d_st, 39, 40, d_mid)          # ratio / step ratio of 1.0 s / 1.0 s over 50 ms / 25 ms (:100-102)
+    ms = timed(ffi, step3, steps, 2)
+    out["cfg3"] = entry(plan.total_frames, ms, 2 * STEP + 8 * 68 + 8 * 136 * 30 / 1199.0, plan.kernel_name,
+                        {"workload": "1000 clips x 30 s (8 distinct, tiled), 68 short-term rows + (136, 30) mid-term per clip",
+                         "clips_per_s": 1000 / (ms * 1e-3)})
+    plan.destroy()
+    del d_in, d_st, d_mid
+    # ---- config 4, one GPU's shard: 12 500 x 10 s
+    n4 = 10 * FS
+    pool = np.stack([synth_clip(40000 + i, n4, FS) for i in range(64)])
+    d_in = replicate_on_device(ffi, pool, 12500)
+    plan = ffi.Plan(np.arange(12501, dtype=np.int64) * n4, FS, WINDOW, STEP, deltas=False)
+    d_out = ffi.DeviceBuffer(plan.out_doubles * 8)
+    ms = timed(ffi, lambda: plan.execute(d_in, d_out), steps, 2)
+    out["cfg4_shard"] = entry(plan.total_frames, ms, 2 * STEP + 8 * 34, plan.kernel_name,
+                              {"workload": "12 500 clips x 10 s (64 distinct, tiled), 34 rows: one GPU's share of config 4"})
+    plan.destroy()
+    del d_in, d_out
+    # ---- config 5: 44.1 kHz stereo -> mono (audioBasicIO.py:167: float64 with .5 fractions), 1102 / 441, 600 s
+    fs5, w5, s5 = 44100, 1102, 441
+    xs = synth_clip(5, 100 * fs5, fs=fs5, stereo=True)          # 100 s synthesised, tiled to 600 s (keeps the bench short)
+    mono = np.ascontiguousarray(np.tile((xs[:, 1] / 2) + (xs[:, 0] / 2), 6))
+    offs = np.array([0, len(mono)], dtype=np.int64)
+    d_in = ffi.DeviceBuffer.from_host(mono)
+    for name, mode, row_bytes in (("cfg5_features", 0, 8 * 34), ("cfg5_spectrogram", 1, 8 * (w5 // 2)),
+                                  ("cfg5_chromagram", 2, 8 * 12)):
+        plan = ffi.Plan(offs, fs5, w5, s5, deltas=False, sample_kind=1, mode=mode)
+        d_out = ffi.DeviceBuffer(plan.out_doubles * 8)
+        ms = timed(ffi, lambda: plan.execute(d_in, d_out), steps, 2)
+        out[name] = entry(plan.total_frames, ms, 8 * s5 + row_bytes, plan.kernel_name,
+                          {"workload": "600 s of 44.1 kHz audio (100 s seeded stereo clip reduced to mono, tiled x6), float64 "
+                                       "mono samples resident (stereo_to_mono output), window 1102 / step 441",
+                           "algorithmic_bytes_note": "8 B/sample float64 input (SURVEY 8d's 882 B assumes int16 mono)"})
+        plan.destroy()
+        del d_out
+    return out
 
 
-def cpu_baseline(x, budget_frames):
-    """Both CPU oracles (the NumPy port of the reference loop and the plain-C port) on a bounded prefix of the
-    same clip; `value` is the faster of the two so that the GPU/CPU ratio is the conservative one."""
-    import paa_oracle as O
-    n = min(len(x), WINDOW + STEP * (budget_frames - 1))
-    t0 = time.perf_counter()
-    F, _ = O.feature_extraction(x[:n], FS, WINDOW, STEP, deltas=False)
-    dt_np = time.perf_counter() - t0
-    rate_np = F.shape[1] / dt_np
-    rate_c, dt_c = None, 0.0
-    try:
-        import c_oracle
-        if c_oracle.available():
+def host_to_host(ffi, clip):
+    """The drop-in API as a caller sees it: NumPy in -> NumPy out, PCIe included (fresh output array per call)."""
+    from pyaudioanalysis_amd import ShortTermFeatures
+    res = {}
+    for label, seconds, reps in (("10_min_clip", 600, 5), ("1_hour_clip", 3600, 3)):
+        if len(clip) < seconds * FS:
+            continue
+        x = np.ascontiguousarray(clip[:seconds * FS])
+        ShortTermFeatures.feature_extraction(x, FS, WINDOW, STEP, deltas=False)
+        best = 1e9
+        for _ in range(reps):
             t0 = time.perf_counter()
-            Fc = c_oracle.feature_extraction(x[:n], FS, WINDOW, STEP, deltas=False)
-            dt_c = time.perf_counter() - t0
-            rate_c = Fc.shape[1] / dt_c
-    except Exception as exc:  # the C oracle is optional test infrastructure
-        print("C oracle not timed:", exc, file=sys.stderr)
-    best = max(rate_np, rate_c or 0.0)
-    return {"value": best, "unit": "frames/s", "cores": 1, "kind": "port",
-            "numpy_port": rate_np, "c_port": rate_c,
-            "sample": "first %.0f s of the same clip (%d frames; %.1f s of CPU for oracle/paa_oracle.py, %.1f s for "
-                      "oracle/paa_oracle.c), deltas off, single thread; host has %d cores"
-                      % (n / FS, F.shape[1], dt_np, dt_c, os.cpu_count() or 0)}
+            F, _ = ShortTermFeatures.feature_extraction(x, FS, WINDOW, STEP, deltas=False)
+            best = min(best, time.perf_counter() - t0)
+        res[label] = {"frames": int(F.shape[1]), "ms": best * 1e3, "frames_per_s": F.shape[1] / best,
+                      "pcie_GBps": (x.nbytes + F.nbytes) / best / 1e9}
+    res["note"] = "ShortTermFeatures.feature_extraction(int16 ndarray) -> fresh (34, T) float64 ndarray, best of a few calls"
+    return res
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4"])
-    ap.add_argument("--seconds", type=float, default=3600.0, help="cfg2: clip length; cfg4: number of clips")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg4"],
+                    help="default: cfg2 at N = 1 (headline), cfg4 strong scaling at N > 1")
+    ap.add_argument("--seconds", type=float, default=3600.0, help="cfg2: clip length")
+    ap.add_argument("--clips", type=int, default=CFG4_TOTAL_CLIPS, help="cfg4: clips in the whole job")
     ap.add_argument("--deltas", type=int, default=0, help="1: 68-row output (reference default), 0: the 34-feature metric")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather to rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=144000, help="frames of the clip prefix timed on the CPU (about 8 s of CPU)")
+    ap.add_argument("--no-extras", action="store_true", help="skip config.others, host_to_host and the sustained loop")
+    ap.add_argument("--cpu-frames", type=int, default=60000, help="frames of the clip prefix timed on one CPU core")
+    ap.add_argument("--sustain-seconds", type=float, default=2.5)
     ap.add_argument("--check", type=int, default=1, help="verify a few frames against the oracle after timing")
     args = ap.parse_args()
 
@@ -95,6 +180,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    workload = args.workload or ("cfg2" if world == 1 else "cfg4")
 
     dist = None
     if world > 1:
@@ -103,28 +189,75 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
+    # the all-cores CPU leg runs FIRST, before this process loads HIP, so that its workers can simply be forked
+    cpu_all = None
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            import cpu_bench
+            cpu_all = cpu_bench.all_cores(FS, WINDOW, STEP)
+        except Exception as exc:
+            cpu_all = {"error": repr(exc)}
+
     from pyaudioanalysis_amd import _ffi
+    from pyaudioanalysis_amd import distributed as D
+    from synth import synth_clip
     lib = _ffi.lib()
     if _ffi.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     _ffi.init(local_rank % _ffi.device_count())
 
-    x, offsets, desc = make_workload(args.workload, rank, args.seconds)
-    d_in = _ffi.DeviceBuffer.from_host(x)
+    # ------------------------------------------------------------------ workload
+    host_clip = None                    # rank 0 keeps what the spot check and the CPU baseline need
+    if workload == "cfg2":
+        n = int(args.seconds * FS)
+        seeds = [2 + rank, 1002 + rank, 2002 + rank]          # three distinct clips: inputs rotate through > 256 MiB
+        d_inputs = []
+        for sd in seeds:
+            x = synth_clip(sd, n, FS)
+            if host_clip is None:
+                host_clip = x
+            d_inputs.append(_ffi.DeviceBuffer.from_host(x))
+        offsets = np.array([0, n], dtype=np.int64)
+        desc = "cfg2: 1 clip x %d s, 16 kHz mono int16, 800/400, %d rows; 3 distinct clips rotate (seeds %s)" % (
+            args.seconds, 68 if args.deltas else 34, seeds)
+        scaling = "weak"
+        job_clips = world
+    else:
+        n = 10 * FS
+        frames_all = np.full(args.clips, (n - WINDOW) // STEP + 1, dtype=np.int64)
+        a, b = D.partition_by_frames(frames_all, world)[rank]
+        my_clips = b - a
+        pool = np.stack([synth_clip(40000 + i, n, FS) for i in range(64)])
+        # clip k of the job is pool[k % 64]: rotate the pool so that this rank's first clip lines up
+        pool = np.roll(pool, -(a % 64), axis=0)
+        host_clip = pool[0].copy()
+        d_inputs = [replicate_on_device(_ffi, pool, my_clips)]
+        offsets = np.arange(my_clips + 1, dtype=np.int64) * n
+        desc = "cfg4: %d clips x 10 s in the job (64 distinct seeded clips, tiled), %d on this rank, 800/400, %d rows" % (
+            args.clips, my_clips, 68 if args.deltas else 34)
+        scaling = "strong"
+        job_clips = args.clips
+
     plan = _ffi.Plan(offsets, FS, WINDOW, STEP, deltas=bool(args.deltas), sample_kind=0)
     F = plan.F
+    frames = plan.total_frames
     d_out = _ffi.DeviceBuffer(plan.out_doubles * 8)
     d_out2 = _ffi.DeviceBuffer(plan.out_doubles * 8) if world > 1 else d_out   # N>1: the gather of step k overlaps step k+1
-    frames = plan.total_frames
+
+    # frames / result sizes of every rank (equal for cfg2; cfg4 follows the partition)
+    if dist is not None:
+        sizes = [None] * world
+        dist.all_gather_object(sizes, (int(frames), int(plan.out_doubles)))
+    else:
+        sizes = [(int(frames), int(plan.out_doubles))]
+    total_frames = sum(s[0] for s in sizes)
+    counts = np.array([s[1] for s in sizes], dtype=np.int64)
 
     gather = world > 1 and not args.no_gather
     gather_note = None
     d_all = None
-    counts = np.full(world, plan.out_doubles, dtype=np.int64)
     comm = None
     if gather:
-        from pyaudioanalysis_amd import distributed as D
-
         def bcast(payload):
             obj = [payload]
             dist.broadcast_object_list(obj, src=0)
@@ -145,9 +278,10 @@ def main():
     state = {"k": 0}
 
     def step():
-        buf = bufs[state["k"] & 1]
-        state["k"] += 1
-        plan.execute(d_in, buf)
+        k = state["k"]
+        state["k"] = k + 1
+        buf = bufs[k & 1]
+        plan.execute(d_inputs[k % len(d_inputs)], buf)
         if gather:
             # runs on the library's communication stream; the next write of `buf` waits for it
             comm.gather(buf, counts, 0, d_all)
@@ -168,6 +302,14 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def max_over_ranks(seconds):
+        if dist is None:
+            return seconds
+        import torch
+        tt = torch.tensor([seconds], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -179,11 +321,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    import ctypes
+    elapsed = max_over_ranks(elapsed)
     kms = ctypes.c_double()
     kn = ctypes.c_int64()
     _ffi.check(lib.paa_prof_read(ctypes.byref(kms), ctypes.byref(kn)))
@@ -200,14 +338,23 @@ def main():
         _ffi.sync()
         el2 = time.perf_counter() - t1
         dist.barrier()
-        import torch
-        tt = torch.tensor([el2], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        value_no_gather = frames * world * args.steps / float(tt.item())
+        value_no_gather = total_frames * args.steps / max_over_ranks(el2)
         gather = saved
 
+    # a sustained loop of the same step (>= 2 s of continuous GPU work: visible to an external smi sampler)
+    sustained = None
+    if not args.no_extras and world == 1:
+        t1 = time.perf_counter()
+        n_sus = 0
+        while time.perf_counter() - t1 < args.sustain_seconds:
+            for _ in range(50):
+                step()
+            _ffi.sync()
+            n_sus += 50
+        sustained = {"seconds": time.perf_counter() - t1, "steps": n_sus}
+        sustained["frames_per_s"] = frames * n_sus / sustained["seconds"]
+
     if rank == 0:
-        total_frames = frames * world
         ms_per_step = 1e3 * elapsed / args.steps
         value = total_frames * args.steps / elapsed
         bytes_per_frame = 2 * STEP + 8 * F               # int16 in once + f64 out once
@@ -216,12 +363,16 @@ def main():
         result = {
             "metric": "short-term frames/sec (34-feat, 16 kHz, 50 ms/25 ms) + HBM GB/s vs peak",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic (oracle/synth.py, seed 2+rank)",
-            "config": {"workload": desc, "frames_per_step_per_gpu": int(frames), "window": WINDOW, "step": STEP,
-                       "rows": F, "kernel": plan.kernel_name,
-                       "multi_gpu": ("one clip per rank, RCCL gather to rank 0" if gather else
-                                     ("one clip per rank, no gather" if world > 1 else "single GPU"))},
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic (oracle/synth.py; SURVEY 8d seeds)",
+            "config": {"workload": desc, "frames_per_step_job": int(total_frames),
+                       "frames_per_step_rank0": int(frames), "clips_in_job": int(job_clips),
+                       "window": WINDOW, "step": STEP, "rows": F, "kernel": plan.kernel_name,
+                       "input_buffers_rotated": len(d_inputs),
+                       "multi_gpu": ("contiguous clip ranges per rank (partition_by_frames), RCCL gather of the slabs to "
+                                     "rank 0 overlapped with the next step" if (gather and workload == "cfg4") else
+                                     "one clip per rank, RCCL gather to rank 0" if gather else
+                                     ("no gather" if world > 1 else "single GPU"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": plan.kernel_name, "kernel_avg_ms": k_avg_ms, "launches_timed": int(kn.value),
@@ -233,27 +384,34 @@ def main():
             result["config"]["gather_note"] = gather_note
         if value_no_gather is not None:
             result["config"]["frames_per_s_without_gather"] = value_no_gather
-            result["config"]["gather_bytes_per_step_into_root"] = int(plan.out_doubles * 8 * (world - 1))
-        # HBM traffic of the feature kernel from the committed rocprofv3 PMC pass of this same command
-        # (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as reported), per launch
+            result["config"]["gather_bytes_per_step_into_root"] = int(counts[1:].sum() * 8)
+        if sustained:
+            result["sustained_frames_per_s"] = sustained["frames_per_s"]
+            result["sustained"] = sustained
+        # HBM traffic of the feature kernel: NOT measured in this run -- taken from the committed rocprofv3 PMC pass of
+        # this same command (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as reported)
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json")))
             if prof.get("kernel") == plan.kernel_name and prof.get("frames") == int(frames) and prof.get("rows") == F:
                 result["roofline"]["traffic"] = prof["hbm_bytes_per_launch"]
+                result["roofline"]["traffic_from_profile"] = prof["hbm_bytes_per_launch"]
                 result["roofline"]["traffic_over_algorithmic"] = prof["hbm_bytes_per_launch"] / float(bytes_per_frame * frames)
-                result["roofline"]["traffic_source"] = prof.get("source")
+                result["roofline"]["traffic_source"] = "not measured in this run: " + str(prof.get("source"))
         except Exception:
             pass
         # informational: executed FP64 work against the vector FP64 peak (the roofline that actually binds)
-        result["roofline"]["fp64_valu"] = {"algorithmic_kflop_per_frame": 45.0,
-                                           "achieved_tflops": 45.0e3 * frames / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0,
+        result["roofline"]["fp64_valu"] = {"algorithmic_kflop_per_frame": KFLOP_PER_FRAME,
+                                           "achieved_tflops": KFLOP_PER_FRAME * 1e3 * frames / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0,
                                            "peak_tflops": FP64_VALU_PEAK_TFLOPS}
+        result["roofline"]["fp64_valu"]["frac"] = result["roofline"]["fp64_valu"]["achieved_tflops"] / FP64_VALU_PEAK_TFLOPS
         if args.check:
             import paa_oracle as O
-            got = d_out.to_host(np.float64, plan.out_doubles).reshape(-1)
+            # the buffer the last step wrote holds clip (k-1) % len(d_inputs); re-run clip 0 into d_out for the check
+            plan.execute(d_inputs[0], d_out)
+            _ffi.sync()
             T0 = int(lib.paa_num_frames(int(offsets[1] - offsets[0]), WINDOW, STEP))
-            slab = got[:F * T0].reshape(F, T0)
-            xn = O.normalize_clip(x[offsets[0]:offsets[1]])
+            slab = d_out.to_host(np.float64, F * T0).reshape(F, T0)
+            xn = O.normalize_clip(host_clip)
             tab = O.Tables(FS, WINDOW)
             worst = 0
             for t in (0, 1, 63, 64, 65, T0 // 2, T0 - 1):
@@ -264,8 +422,30 @@ def main():
                 nb, _ = O.mixed_tolerance_violations(slab[:34, t:t + 1], v[:, None], 1e-4, 1e-5, 1e-8)
                 worst += nb
             result["parity_spot_check"] = "ok" if worst == 0 else "FAILED (%d entries)" % worst
+        if not args.no_extras and world == 1:
+            try:
+                result["config"]["others"] = other_configs(_ffi)
+            except Exception as exc:
+                result["config"]["others"] = {"error": repr(exc)}
+            try:
+                result["host_to_host"] = host_to_host(_ffi, host_clip)
+            except Exception as exc:
+                result["host_to_host"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(x[offsets[0]:offsets[1]], args.cpu_frames)
+            import cpu_bench
+            one = cpu_bench.single_core(host_clip, FS, WINDOW, STEP, args.cpu_frames)
+            best = max(one["numpy_port"], one["c_port"] or 0.0)
+            cb = {"value": best, "unit": "frames/s", "cores": 1, "kind": "port",
+                  "numpy_port": one["numpy_port"], "c_port": one["c_port"], "cpu_model": cpu_bench.cpu_model(),
+                  "host_cores": os.cpu_count(),
+                  "sample": "first %.0f s of the bench clip (%d frames; %.1f s of CPU for oracle/paa_oracle.py, %.1f s for "
+                            "oracle/paa_oracle.c), deltas off, single thread" % (
+                                one["seconds_of_audio"], one["frames"], one["numpy_port_seconds"], one["c_port_seconds"]),
+                  "unmodified_reference_note": "the unmodified reference does about 2.5 k frames/s/core (SURVEY 6; "
+                                               "profiles/reference_cpu_r02.json was timed in the build container); both "
+                                               "ports hoist the frame-invariant tables and are 8-18x faster than it"}
+            cb["all_cores"] = cpu_all
+            result["cpu_baseline"] = cb
         elif not args.no_cpu_baseline:
             result["cpu_baseline"] = None
         print(json.dumps(result))

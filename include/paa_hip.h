@@ -128,6 +128,10 @@ typedef struct paa_plan paa_plan_t;
  * 1 = float64, 2 = int32 stereo sums L + R (scaled by 2^-16).  The plan owns the tables, the tile list and the per-clip statistics.        */
 int paa_plan_create(const int64_t *offsets, int64_t n_clips, int sample_kind, double fs,
                     int window, int step, int deltas, paa_plan_t **out_plan);
+/* spectrogram (mode 1) / chromagram (mode 2) rows kept in HBM (ShortTermFeatures.py:389-452, :324-386); mode 0 = features
+ * without deltas.  paa_plan_out_doubles() gives the size of the row block, paa_plan_total_frames() the full-length frames. */
+int paa_plan_create_mode(const int64_t *offsets, int64_t n_clips, int sample_kind, double fs, int window, int step,
+                         int mode, paa_plan_t **out_plan);
 int paa_plan_destroy(paa_plan_t *plan);
 int64_t paa_plan_total_frames(const paa_plan_t *plan);
 int64_t paa_plan_out_doubles(const paa_plan_t *plan);     /* sum_c F*T_c                      */

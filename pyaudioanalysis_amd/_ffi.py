@@ -65,6 +65,8 @@ _SIGNATURES = {
                                              C.c_int64, C.c_int64, c_f64p, c_i64p, c_f64p, c_i64p]),
     "paa_plan_create": (C.c_int, [c_i64p, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
                                   C.POINTER(C.c_void_p)]),
+    "paa_plan_create_mode": (C.c_int, [c_i64p, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
+                                       C.POINTER(C.c_void_p)]),
     "paa_plan_destroy": (C.c_int, [C.c_void_p]),
     "paa_plan_total_frames": (C.c_int64, [C.c_void_p]),
     "paa_plan_out_doubles": (C.c_int64, [C.c_void_p]),
@@ -238,14 +240,20 @@ class DeviceBuffer:
 class Plan:
     """Device-resident batch plan (paa_plan_*): samples and results stay in HBM."""
 
-    def __init__(self, offsets, fs, window, step, deltas=True, sample_kind=0):
+    def __init__(self, offsets, fs, window, step, deltas=True, sample_kind=0, mode=0):
+        """mode 0: short-term features; 1: spectrogram rows; 2: chromagram rows (full-length frames, see paa_hip.h)."""
         self.offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         self.n_clips = len(self.offsets) - 1
         h = C.c_void_p()
-        check(lib().paa_plan_create(as_i64p(self.offsets), self.n_clips, int(sample_kind), float(fs), int(window),
-                                    int(step), 1 if deltas else 0, C.byref(h)))
+        if mode == 0:
+            check(lib().paa_plan_create(as_i64p(self.offsets), self.n_clips, int(sample_kind), float(fs), int(window),
+                                        int(step), 1 if deltas else 0, C.byref(h)))
+        else:
+            check(lib().paa_plan_create_mode(as_i64p(self.offsets), self.n_clips, int(sample_kind), float(fs),
+                                             int(window), int(step), int(mode), C.byref(h)))
         self.handle = h
-        self.F = 68 if deltas else 34
+        self.mode = int(mode)
+        self.F = (68 if deltas else 34) if mode == 0 else (int(window) // 2 if mode == 1 else 12)
         self.total_frames = int(lib().paa_plan_total_frames(h))
         self.out_doubles = int(lib().paa_plan_out_doubles(h))
         self.kernel_name = lib().paa_plan_kernel_name(h).decode()

@@ -999,14 +999,26 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
             double vq[QUAD];
 #pragma unroll
             for (int s = 0; s < QUAD; ++s) vq[s] = fv[FV_STRIDE * s + lane];
+            if (q0 >= r0 && q0 + QUAD <= t_end) {
+                // the whole quad belongs to this run (the usual case): one 32-byte store per row (the rows are only
+                // 8-byte aligned -- T is odd -- which global_store_dwordx4 does not mind)
+                typedef double f64x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+                f64x4_a8 row = {vq[0], vq[1], vq[2], vq[3]};
+                *reinterpret_cast<f64x4_a8 *>(&oc[(long long)lane * Tc + q0]) = row;
+                if (DELTAS) {
+                    f64x4_a8 dl = {(q0 == 0) ? 0.0 : vq[0] - vlast, vq[1] - vq[0], vq[2] - vq[1], vq[3] - vq[2]};
+                    *reinterpret_cast<f64x4_a8 *>(&oc[(long long)(kBase + lane) * Tc + q0]) = dl;
+                }
+            } else {
 #pragma unroll
-            for (int s = 0; s < QUAD; ++s) {
-                const int ts = q0 + s;
-                if (ts >= r0 && ts < t_end) {
-                    oc[(long long)lane * Tc + ts] = vq[s];
-                    if (DELTAS) {
-                        const double pv = (s == 0) ? vlast : vq[s - 1];
-                        oc[(long long)(kBase + lane) * Tc + ts] = (ts == 0) ? 0.0 : vq[s] - pv;
+                for (int s = 0; s < QUAD; ++s) {
+                    const int ts = q0 + s;
+                    if (ts >= r0 && ts < t_end) {
+                        oc[(long long)lane * Tc + ts] = vq[s];
+                        if (DELTAS) {
+                            const double pv = (s == 0) ? vlast : vq[s - 1];
+                            oc[(long long)(kBase + lane) * Tc + ts] = (ts == 0) ? 0.0 : vq[s] - pv;
+                        }
                     }
                 }
             }

@@ -511,6 +511,16 @@ extern "C" int paa_plan_create(const int64_t *offsets, int64_t n_clips, int samp
     return plan_build(offsets, n_clips, sample_kind, fs, window, step, deltas, 0, out_plan);
 }
 
+// device-resident plan of the spectrogram (mode 1, :389-452) / chromagram (mode 2, :324-386) rows of one or more clips:
+// full-length frames only, row t of a clip at out + out_offset(clip) + t * row_width (Nf or 12 doubles); rows the reference
+// allocates but never fills, and the truncated chromagram tail frame, are the host entry points' business
+extern "C" int paa_plan_create_mode(const int64_t *offsets, int64_t n_clips, int sample_kind, double fs, int window,
+                                    int step, int mode, paa_plan_t **out_plan) {
+    if (mode < 0 || mode > 2) return fail(PAA_ERR_ARG, "mode must be 0 (features), 1 (spectrogram) or 2 (chromagram)");
+    std::lock_guard<std::mutex> lk(g_mu);
+    return plan_build(offsets, n_clips, sample_kind, fs, window, step, 0, mode, out_plan);
+}
+
 extern "C" int paa_plan_destroy(paa_plan_t *plan) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_stream) (void)hipStreamSynchronize(g_stream);
