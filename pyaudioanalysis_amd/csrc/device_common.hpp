@@ -76,6 +76,7 @@ struct PlanDev {
     int blk_f;              // floor(Nf / 10)
     int mode;               // 0 features, 1 spectrogram, 2 chromagram
     int frame_origin;       // first frame starts at this sample (0; W for spectrogram/chromagram)
+    int debug;              // PAA_KERNEL_DEBUG bit mask (ablation experiments only; 0 in production)
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -259,6 +260,77 @@ __device__ __forceinline__ double wscan_incl(double v) {
     v += dpp_mov_rows<0x143, 0xC>(v);
     return v;
 }
+
+// ---- FP64 helpers of the feature stages: hardware seeds (v_rsq_f64 / v_rcp_f64) + Newton steps instead of libm's
+// general-purpose sequences (which also handle sub-normals, infinities and the IEEE division corner cases)
+// sqrt for x >= 0 to ~1 ulp: v_rsq_f64 seed + two coupled Newton steps (ocml's version adds scaling for
+// sub-normal / huge arguments, which |X|^2 of a normalised frame never reaches)
+__device__ __forceinline__ double fast_sqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return (x > 0.0) ? g : 0.0;
+}
+// magnitude variant: one coupled Newton step (relative error ~ (rsq error)^2, far below the 1e-4 parity bound
+// even for a 2^-20 seed); measured against the two-step version in tests/test_parity_gpu.py tolerances
+__device__ __forceinline__ double mag_sqrt(double x) {
+    // x is either exactly 0 or far above 1e-300 (squares of sums of integers and their round-off), so clamping the
+    // seed's argument replaces the x > 0 select: 0 * rsq(1e-300) = 0 goes through the Newton step unchanged
+    // (the clamp is an unsigned max on the high dword -- x >= 0 -- which costs half an FP64 issue slot)
+    const unsigned hi_ = max((unsigned)__double2hiint(x), 0x01a56e1fu);         // high dword of 1e-300
+    const double y = __builtin_amdgcn_rsq(__hiloint2double((int)hi_, __double2loint(x)));
+    const double g = x * y;
+    const double h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    return fma(g, r, g);
+}
+
+// a / b for finite b != 0 to ~1 ulp: v_rcp_f64 seed, two Newton steps, one residual correction (the IEEE
+// division sequence -- div_scale / div_fmas / div_fixup -- is a ~150-cycle dependent chain per quotient)
+__device__ __forceinline__ double fast_div(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+
+// log2(x) for finite x > 0 (callers add eps = 2^-52 first): x = m 2^e with m in [sqrt(1/2), sqrt(2)),
+// ln m = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716, odd series to s^21 (truncation < 1e-18 relative).
+// About 35 FP64 operations instead of ~115 in the generic libm path; error a few 1e-16 relative.
+__device__ __forceinline__ double fast_log2(double x) {
+    double m = __builtin_amdgcn_frexp_mant(x);          // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double num = m - 1.0, den = m + 1.0;
+    double r = __builtin_amdgcn_rcp(den);
+    r = fma(fma(-den, r, 1.0), r, r);
+    r = fma(fma(-den, r, 1.0), r, r);
+    double s = num * r;
+    s = fma(fma(-den, s, num), r, s);
+    const double z = s * s;
+    double p = 1.0 / 21.0;
+    p = fma(p, z, 1.0 / 19.0);
+    p = fma(p, z, 1.0 / 17.0);
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    p = fma(p, z, 1.0);
+    // log2 m = (2 / ln 2) s p
+    return fma(s * p, 2.8853900817779268147, (double)e);
+}
+__device__ __forceinline__ double fast_log10(double x) { return fast_log2(x) * 0.30102999566398119521; }
 
 template <typename T> __device__ __forceinline__ double load_sample(const T *p);
 template <> __device__ __forceinline__ double load_sample<int16_t>(const int16_t *p) { return (double)(*p); }

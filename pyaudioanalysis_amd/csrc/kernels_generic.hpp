@@ -153,12 +153,12 @@ __device__ __forceinline__ void frame_fft(const PlanDev &P, const Tabs &tb, doub
             const double2 o = make_double2(0.5 * (zk.y + zm.y), 0.5 * (zm.x - zk.x));
             const double2 wo = cmul(tb.post[k], o);
             const double xr = e.x + wo.x, xi = e.y + wo.y;
-            spec[k] = sqrt(fma(xr, xr, xi * xi)) * invNf;
+            spec[k] = mag_sqrt(fma(xr, xr, xi * xi)) * invNf;
         }
     } else {
         for (int k = lane; k < P.Nf; k += kWave) {
             const double2 z = src[k];
-            spec[k] = sqrt(fma(z.x, z.x, z.y * z.y)) * invNf;
+            spec[k] = mag_sqrt(fma(z.x, z.x, z.y * z.y)) * invNf;
         }
     }
     wsync();
@@ -188,7 +188,7 @@ __device__ __forceinline__ double chroma_class(const Tabs &tb, const double *spe
             const double x = spec[tb.ch_src[i]];
             acc += (x * x) * tb.ch_w[i];
         }
-        acc = (sP == 0.0) ? acc / kEps : acc / sP;
+        acc = (sP == 0.0) ? acc / kEps : fast_div(acc, sP);
     }
     return acc;
 }
@@ -216,8 +216,11 @@ __device__ __forceinline__ TimeFeat time_features(const PlanDev &P, const double
                 zc += abs(((v > 0.0) - (v < 0.0)) - ((u > 0.0) - (u < 0.0)));
             }
         }
-        eblk[j] = wsum(p);
+        eblk[j] = p;
     }
+    // the ten wave reductions are independent chains: issued together they overlap instead of exposing ten latencies
+#pragma unroll
+    for (int j = 0; j < 10; ++j) eblk[j] = wsum(eblk[j]);
     double e_tail = 0.0;
     for (int n = 10 * L + lane; n < W; n += kWave) {
         const double v = y[n * st];
@@ -236,8 +239,8 @@ __device__ __forceinline__ TimeFeat time_features(const PlanDev &P, const double
 #pragma unroll
     for (int j = 0; j < 10; ++j)
         if (lane == j) num = eblk[j];
-    const double s = num / (tf.e_tot + kEps);
-    tf.ent_e = wsum((lane < 10) ? -(s * log2(s + kEps)) : 0.0);
+    const double s = fast_div(num, tf.e_tot + kEps);
+    tf.ent_e = wsum((lane < 10) ? -(s * fast_log2(s + kEps)) : 0.0);
     return tf;
 }
 
@@ -263,7 +266,7 @@ __device__ __forceinline__ void frame_features(const PlanDev &P, const Tabs &tb,
                 mx = fmax(mx, X);
                 p = fma(X, X, p);
             }
-            pblk[j] = wsum(p);
+            pblk[j] = p;
         }
         for (int k = 10 * L + lane; k < Nf; k += kWave) {
             const double X = cur[k];
@@ -275,6 +278,9 @@ __device__ __forceinline__ void frame_features(const PlanDev &P, const Tabs &tb,
         }
         p_tail = wsum(p_tail);
     }
+    // independent reduction chains, issued together
+#pragma unroll
+    for (int j = 0; j < 10; ++j) pblk[j] = wsum(pblk[j]);
     sX = wsum(sX);
     sXp = wsum(sXp);
     sIX = wsum(sIX) * f0;
@@ -293,15 +299,15 @@ __device__ __forceinline__ void frame_features(const PlanDev &P, const Tabs &tb,
 #pragma unroll
         for (int j = 0; j < 10; ++j)
             if (lane == j) num = pblk[j];
-        const double s = num / (sP + kEps);
-        ent_f = wsum((lane < 10) ? -(s * log2(s + kEps)) : 0.0);
+        const double s = fast_div(num, sP + kEps);
+        ent_f = wsum((lane < 10) ? -(s * fast_log2(s + kEps)) : 0.0);
     }
 
     // ---------- centroid, then sweep B: spread + flux (:57-82, :110-124)
-    const double r = (mx == 0.0) ? 1.0 / kEps : 1.0 / mx;
+    const double r = (mx == 0.0) ? 1.0 / kEps : fast_div(1.0, mx);
     const double den = sX * r + kEps;
-    const double cen = (sIX * r) / den;
-    const double rX = 1.0 / sXe, rXp = 1.0 / sXp;
+    const double cen = fast_div(sIX * r, den);
+    const double rX = fast_div(1.0, sXe), rXp = fast_div(1.0, sXp);
     double sSp = 0.0, sFl = 0.0;
     for (int k = lane; k < Nf; k += kWave) {
         const double X = cur[k];
@@ -312,7 +318,7 @@ __device__ __forceinline__ void frame_features(const PlanDev &P, const Tabs &tb,
     }
     sSp = wsum(sSp);
     sFl = wsum(sFl);
-    const double spread = sqrt(sSp / den);
+    const double spread = fast_sqrt(fast_div(sSp, den));
 
     // ---------- roll-off: first k with cumsum(X^2)[k] + eps > 0.9 * sum(X^2) (:127-140)
     int first = 0x7fffffff;
@@ -342,7 +348,7 @@ __device__ __forceinline__ void frame_features(const PlanDev &P, const Tabs &tb,
             a1 = fma(cur[lo + i + 1], w[i + 1], a1);
         }
         if (i < cnt) a0 = fma(cur[lo + i], w[i], a0);
-        msp[lane] = log10((a0 + a1) + kEps);
+        msp[lane] = fast_log10((a0 + a1) + kEps);
     }
     // ---------- chroma (:277-321)
     const double chroma = chroma_class(tb, cur, sP, lane);
@@ -377,7 +383,7 @@ __device__ __forceinline__ void frame_features(const PlanDev &P, const Tabs &tb,
         m /= 12.0;
         double v = 0.0;
         for (int i = 0; i < 12; ++i) { const double d = fv[21 + i] - m; v = fma(d, d, v); }
-        fv[33] = sqrt(v / 12.0);
+        fv[33] = fast_sqrt(v / 12.0);
     }
     wsync();
 }

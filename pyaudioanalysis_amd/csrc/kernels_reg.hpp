@@ -1,0 +1,462 @@
+// Register-FFT feature kernel for windows W = 2 R1 R2 with two coprime odd primes (BASELINE config 5: 1102 = 2 x 29 x 19
+// at 44.1 kHz / 25 ms): several frames per wave-iteration, both FFT passes in registers, int16 / int32 (stereo sums) /
+// float64 samples; also produces spectrogram / chromagram rows (modes 1 / 2).
+//
+// The complex FFT of length Nc = R1 R2 (real-input trick: z[n] = y[2n] + i y[2n+1]) is a PRIME-FACTOR transform: with
+// n = (R2 n1 + R1 n2) mod Nc and k = (c1 k1 + c2 k2) mod Nc (c1 = R2 (R2^-1 mod R1), c2 = R1 (R1^-1 mod R2)) there are
+// no twiddle factors between the passes.  Per iteration a wave handles Q frames:
+//   time    : the time-domain features of each frame, read straight from HBM/L2 with all 64 lanes
+//   pass A  : lane (frame f, n2 < R2): radix-R1 DFT over n1 of samples fetched (normalised) from global memory; the
+//             O(R^2) prime butterfly uses the cos/sin symmetry (x_j +- x_{R-j}): (R-1)^2 FMAs; outputs leave the lane as
+//             they are produced: real parts into the frame's spectrum slot (used as a plane), imaginary parts are kept
+//   exchange: real plane, then imaginary plane (the slot holds Nc doubles = exactly one plane)
+//   pass B  : lane (frame f, p <= R1/2): the two radix-R2 DFTs of columns k1 = p and R1 - p, produced output pair by
+//             output pair; Z[k] and Z[Nc-k] = (column R1-p, output R2-q) meet in the lane, so the real-FFT recombination
+//             and |X| happen in registers and each magnitude is written once into the slot
+//   features: per frame with the full wave (the generic kernel's reductions), row segments staged in LDS
+// Halo: a run that starts at t0 > 0 first processes frames t0-Q .. t0-1 without storing them.
+//
+// Replaces the while loop at ShortTermFeatures.py:608-682 and its helpers (:22-140, :236-321), and the loops of
+// spectrogram (:415-422) / chromagram (:349-359), for these window sizes.
+#pragma once
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "device_common.hpp"
+#include "kernels_generic.hpp"
+#include "tables.hpp"
+
+namespace paa {
+namespace reg {
+
+template <int R> struct PrimeTab;
+// cos / sin (2 pi m / R), m = 1 .. (R-1)/2, for the odd primes the register-FFT kernel instantiates
+// (generated with mpmath at 40 digits, printed to 21: scripts/gen_prime_tables.py)
+template <> struct PrimeTab<3> {
+    static constexpr double c[1] = {-0.500000000000000000000};
+    static constexpr double s[1] = {0.866025403784438646764};
+};
+template <> struct PrimeTab<5> {
+    static constexpr double c[2] = {0.309016994374947424102, -0.809016994374947424102};
+    static constexpr double s[2] = {0.951056516295153572116, 0.587785252292473129169};
+};
+template <> struct PrimeTab<7> {
+    static constexpr double c[3] = {0.623489801858733530525, -0.222520933956314404289, -0.900968867902419126236};
+    static constexpr double s[3] = {0.781831482468029808708, 0.974927912181823607018, 0.433883739117558120476};
+};
+template <> struct PrimeTab<11> {
+    static constexpr double c[5] = {0.841253532831181168862, 0.415415013001886425529, -0.142314838273285140444, -0.654860733945285064057, -0.959492973614497389890};
+    static constexpr double s[5] = {0.540640817455597582108, 0.909631995354518371412, 0.989821441880932732376, 0.755749574354258283774, 0.281732556841429697711};
+};
+template <> struct PrimeTab<13> {
+    static constexpr double c[6] = {0.885456025653209895900, 0.568064746731155802512, 0.120536680255323053349, -0.354604887042535625970, -0.748510748171101098635, -0.970941817426052027157};
+    static constexpr double s[6] = {0.464723172043768545656, 0.822983865893656394580, 0.992708874098053992801, 0.935016242685414823440, 0.663122658240795202377, 0.239315664287557767149};
+};
+template <> struct PrimeTab<17> {
+    static constexpr double c[8] = {0.932472229404355804573, 0.739008917220659115925, 0.445738355776538267396, 0.0922683594633019952397, -0.273662990072082863539, -0.602634636379256389179, -0.850217135729614152134, -0.982973099683901778282};
+    static constexpr double s[8] = {0.361241666187152948745, 0.673695643646557211713, 0.895163291355062322067, 0.995734176295034521871, 0.961825643172819070409, 0.798017227280239503333, 0.526432162877355800245, 0.183749517816570331574};
+};
+template <> struct PrimeTab<19> {
+    static constexpr double c[9] = {0.945817241700634679020, 0.789140509396393599219, 0.546948158122426874712, 0.245485487140799148922, -0.0825793454723323246003, -0.401695424652969457517, -0.677281571625741074762, -0.879473751206489071391, -0.986361303402722373603};
+    static constexpr double s[9] = {0.324699469204683487408, 0.614212712689667817444, 0.837166478262528574806, 0.969400265939330416736, 0.996584493006669849819, 0.915773326655057439919, 0.735723910673131624774, 0.475947393037073544431, 0.164594590280733894144};
+};
+template <> struct PrimeTab<23> {
+    static constexpr double c[11] = {0.962917287347799295015, 0.854419404546488552548, 0.682553143218654082875, 0.460065037731152126042, 0.203456013052633789878, -0.0682424133646709759212, -0.334879612170986151958, -0.576680322114867141251, -0.775711290704419807041, -0.917211301505453017844, -0.990685946036330752342};
+    static constexpr double s[11] = {0.269796771157024271245, 0.519583950035433578133, 0.730835964278124101651, 0.887885218402375234984, 0.979084087682322875633, 0.997668769190539198454, 0.942260922118820495618, 0.816969893010442016973, 0.631087944326052789367, 0.398401089846241457998, 0.136166649096246590761};
+};
+template <> struct PrimeTab<29> {
+    static constexpr double c[14] = {0.976620555710086683208, 0.907575419670957053620, 0.796093065705643745998, 0.647386284781827639182, 0.468408440699790139216, 0.267528338529220821195, 0.0541389085854175261499, -0.161781996552764726544, -0.370138155339914356864, -0.561187065362382369270, -0.725995491923130858138, -0.856857176167589244523, -0.947653171182802444274, -0.994137957154359608955};
+    static constexpr double s[14] = {0.214970440211024067182, 0.419889101560264576974, 0.605174215193765165924, 0.762162055127636463256, 0.883512044446022922827, 0.963549992519222960043, 0.998533413851123864572, 0.986826522541526151769, 0.928976719816791441790, 0.827688998156890556136, 0.687699458853423293084, 0.515553857177021739710, 0.319301530135979973197, 0.108119018423941763031};
+};
+template <> struct PrimeTab<31> {
+    static constexpr double c[15] = {0.979529941252494493938, 0.918957811620230629127, 0.820763441207276326364, 0.688966919075686567801, 0.528964010326962457365, 0.347305252844820285542, 0.151427777504576663657, -0.0506491688387127122788, -0.250652532258720539315, -0.440394151557634309516, -0.612105982547662844147, -0.758758122692790901913, -0.874346616144582118827, -0.954139256400048851476, -0.994869323391895146321};
+    static constexpr double s[15] = {0.201298520088660079142, 0.394355855113318580102, 0.571268215094792279157, 0.724792787229119958865, 0.848644257494750950464, 0.937752132147080458429, 0.988468324328111399162, 0.998716507171052807146, 0.968077118866204305153, 0.897804539570741657137, 0.790775736937698582078, 0.651372482722222207454, 0.485301962531081025215, 0.299363122973357954008, 0.101168321987432177786};
+};
+
+// output pair (k, R-k), 1 <= k <= (R-1)/2, of the length-R DFT from v0 and the sums / differences s_j = v_j + v_{R-j},
+// d_j = v_j - v_{R-j}:  X[k] = A - iB, X[R-k] = A + iB with A = v0 + sum_j s_j cos(2 pi jk/R), B = sum_j d_j sin(2 pi jk/R)
+template <int R, int K>
+__device__ __forceinline__ void prime_pair(const double2 &v0, const double2 *s, const double2 *d, double2 &xk,
+                                           double2 &xrk) {
+    constexpr int H = (R - 1) / 2;
+    double ax = v0.x, ay = v0.y, bx = 0.0, by = 0.0;
+#pragma unroll
+    for (int j = 1; j <= H; ++j) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int m = (j * K) % R;                         // compile-time after unrolling
+        const int mm = (m <= H) ? m : R - m;
+        const double c = PrimeTab<R>::c[mm - 1];
+        const double sn = (m <= H) ? PrimeTab<R>::s[mm - 1] : -PrimeTab<R>::s[mm - 1];
+        ax = fma(s[j - 1].x, c, ax);
+        ay = fma(s[j - 1].y, c, ay);
+        bx = fma(d[j - 1].x, sn, bx);
+        by = fma(d[j - 1].y, sn, by);
+    }
+    xk = make_double2(ax + by, ay - bx);
+    xrk = make_double2(ax - by, ay + bx);
+}
+template <int R>
+__device__ __forceinline__ double2 prime_dc(const double2 &v0, const double2 *s) {
+    constexpr int H = (R - 1) / 2;
+    double x = v0.x, y = v0.y;
+#pragma unroll
+    for (int j = 0; j < H; ++j) { x += s[j].x; y += s[j].y; }
+    return make_double2(x, y);
+}
+template <int R>
+__device__ __forceinline__ void prime_fold(const double2 *v, double2 *s, double2 *d) {
+    constexpr int H = (R - 1) / 2;
+#pragma unroll
+    for (int j = 1; j <= H; ++j) { s[j - 1] = cadd(v[j], v[R - j]); d[j - 1] = csub(v[j], v[R - j]); }
+}
+
+// compile-time loop over the output pairs
+template <int R, int K, typename F>
+__device__ __forceinline__ void for_pairs(F &&f) {
+    if constexpr (K <= (R - 1) / 2) {
+        f(std::integral_constant<int, K>{});
+        for_pairs<R, K + 1>(f);
+    }
+}
+
+constexpr int inv_mod(int a, int m) {
+    int r = 1;
+    for (int i = 1; i < m; ++i)
+        if ((a * i) % m == 1) r = i;
+    return r;
+}
+
+template <int R1_, int R2_, int Q_>
+struct Shape {
+    static constexpr int R1 = R1_, R2 = R2_, Q = Q_;
+    static constexpr int NC = R1 * R2, W = 2 * NC, NF = NC;
+    static constexpr int NP = (R1 + 1) / 2;                            // pass-B lanes per frame
+    static constexpr int C1 = R2 * inv_mod(R2 % R1, R1);               // k = (C1 k1 + C2 k2) mod NC
+    static constexpr int C2 = R1 * inv_mod(R1 % R2, R2);
+    static constexpr int NFP = (NF + 1) & ~1;
+    static_assert(Q * R2 <= 64 && Q * NP <= 64, "Q frames must fit the wave in both passes");
+    static_assert((C1 % R1) == 0 || true, "");
+};
+
+// LDS layout: shared tables, then per wave: (Q + 1) spectrum slots, the output staging tile, fv / msp
+struct RegLayout {
+    int off_post, off_mello, off_melcnt, off_meloff, off_melw, off_dct, off_chstart, off_chsrc, off_chw;
+    int table_bytes, wave_bytes, waves;
+};
+
+// zcr count, energy and energy entropy of one frame read from global memory (ShortTermFeatures.py:22-51)
+template <typename T>
+__device__ __forceinline__ TimeFeat time_features_global(const PlanDev &P, const T *__restrict__ x, const ClipNorm &nm,
+                                                         int lane) {
+    const int W = P.W, L = P.blk_t;
+    const double sc = sample_scale<T>();
+    auto y = [&](int n) { return fma(load_sample<T>(x + n), sc, -nm.mean) * nm.inv; };
+    auto sgn = [](double v) { return (v > 0.0) - (v < 0.0); };
+    double eblk[10];
+    int zc = 0;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        double p = 0.0;
+        for (int n = j * L + lane; n < (j + 1) * L; n += kWave) {
+            const double v = y(n);
+            p = fma(v, v, p);
+            if (n > 0) zc += abs(sgn(v) - sgn(y(n - 1)));
+        }
+        eblk[j] = p;
+    }
+    // the ten wave reductions are independent chains: issued together they overlap instead of exposing ten latencies
+#pragma unroll
+    for (int j = 0; j < 10; ++j) eblk[j] = wsum(eblk[j]);
+    double e_tail = 0.0;
+    for (int n = 10 * L + lane; n < W; n += kWave) {
+        const double v = y(n);
+        e_tail = fma(v, v, e_tail);
+        if (n > 0) zc += abs(sgn(v) - sgn(y(n - 1)));
+    }
+    TimeFeat tf;
+    tf.e_tot = wsum(e_tail);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) tf.e_tot += eblk[j];
+    tf.zc = wsum_i(zc);
+    double num = 0.0;
+#pragma unroll
+    for (int j = 0; j < 10; ++j)
+        if (lane == j) num = eblk[j];
+    const double s = fast_div(num, tf.e_tot + kEps);
+    tf.ent_e = wsum((lane < 10) ? -(s * fast_log2(s + kEps)) : 0.0);
+    return tf;
+}
+
+template <typename SH, typename T>
+__global__ __launch_bounds__(384) void st_reg_kernel(PlanDev P, RegLayout L, const unsigned char *__restrict__ blob,
+                                                      const T *__restrict__ sig, const ClipDev *__restrict__ clips,
+                                                      const ClipNorm *__restrict__ norms,
+                                                      const Tile *__restrict__ tiles, int n_tiles,
+                                                      double *__restrict__ out) {
+    constexpr int R1 = SH::R1, R2 = SH::R2, Q = SH::Q, NC = SH::NC, NF = SH::NF, NP = SH::NP, NFP = SH::NFP;
+    constexpr int H1 = (R1 - 1) / 2, H2 = (R2 - 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    {
+        const int4 *src4 = reinterpret_cast<const int4 *>(blob);
+        int4 *dst4 = reinterpret_cast<int4 *>(smem);
+        for (int n = threadIdx.x; n < L.table_bytes / 16; n += blockDim.x) dst4[n] = src4[n];
+    }
+    __syncthreads();       // the only workgroup-wide barrier
+    Tabs tb;
+    tb.tw = nullptr;
+    tb.post = reinterpret_cast<const double2 *>(smem + L.off_post);
+    tb.mel_lo = reinterpret_cast<const int *>(smem + L.off_mello);
+    tb.mel_cnt = reinterpret_cast<const int *>(smem + L.off_melcnt);
+    tb.mel_off = reinterpret_cast<const int *>(smem + L.off_meloff);
+    tb.mel_w = reinterpret_cast<const double *>(smem + L.off_melw);
+    tb.dct = reinterpret_cast<const double *>(smem + L.off_dct);
+    tb.dct_stride = 41;
+    tb.ch_start = reinterpret_cast<const int *>(smem + L.off_chstart);
+    tb.ch_src = reinterpret_cast<const int *>(smem + L.off_chsrc);
+    tb.ch_w = reinterpret_cast<const double *>(smem + L.off_chw);
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int tile_id = blockIdx.x * L.waves + wave;
+    if (tile_id >= n_tiles) return;
+    const int F = P.F > 0 ? P.F : 1;
+    unsigned char *wb = smem + L.table_bytes + wave * L.wave_bytes;
+    double *slots = reinterpret_cast<double *>(wb);                    // (Q + 1) x NFP doubles
+    double *otile = slots + (Q + 1) * NFP;
+    double *fv = otile + kFlush * F;
+    double *msp = fv + 48;
+    double *tfs = msp + 40;                                            // Q x 4: time-domain results of the iteration
+
+    const Tile tl = tiles[tile_id];
+    const ClipDev c = clips[tl.clip];
+    const ClipNorm nm = norms[tl.clip];
+    const T *x0 = sig + c.sample_off + P.frame_origin;
+    const long long Tc = c.T;
+    double *oc = out + c.out_off;
+    const double sc = sample_scale<T>();
+
+
+    const int tend = tl.t0 + tl.cnt;
+    const bool halo = (P.mode == 0) && tl.t0 >= Q;
+    int slot0 = 1;                                          // slots of the iteration: slot0 .. slot0+Q-1 (mod Q+1); previous = slot0-1
+    double vprev = 0.0;
+    int nslot = 0, tbase = tl.t0;
+    for (int tq = halo ? tl.t0 - Q : tl.t0; tq < tend; tq += Q, slot0 = (slot0 + Q) % (Q + 1)) {
+        const bool store_it = tq >= tl.t0;
+        // lane roles, re-derived every iteration from an opaque copy of the lane index: otherwise the optimiser hoists
+        // every lane-dependent address and bin index of the unrolled passes out of the loop and spills them
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int fa = lane_o / R2, n2 = lane_o - fa * R2;      // pass A: frame fa, input residue n2
+        const bool act_a = fa < Q;
+        const int fb = lane_o / NP, pcol = lane_o - fb * NP;    // pass B: frame fb, column pair (pcol, R1 - pcol)
+        const bool act_b = fb < Q;
+        const int pcolb = (pcol == 0) ? 0 : R1 - pcol;
+        // ---------------- time-domain features of the iteration's frames (uniform values)
+        // (ONE instance of the stage in a run-time loop over the frames: the iteration's code has to stay inside the
+        //  instruction cache -- unrolled over the frames the kernel ran 40 % slower; results pass through LDS)
+        if (P.mode == 0) {
+#pragma nounroll
+            for (int f = 0; f < Q; ++f) {
+                const int t = tq + f;
+                // with deltas the last halo frame needs its full feature vector (previous column of the first stored frame)
+                const bool want = t < tend && (store_it || (P.deltas && f == Q - 1));
+                if (want && !(P.debug & 1)) {
+                    const TimeFeat tf = time_features_global<T>(P, x0 + (long long)t * P.S, nm, lane_o);
+                    if (lane_o == 0) { tfs[4 * f] = tf.e_tot; tfs[4 * f + 1] = tf.ent_e; tfs[4 * f + 2] = (double)tf.zc; }
+                }
+            }
+        }
+        // ---------------- pass A: radix-R1 over n1, inputs z[(R2 n1 + R1 n2) mod NC] from global memory
+        double yim[R1];
+        {
+            const int ta = tq + fa;
+            const bool ok = act_a && ta < tend;
+            double2 s[H1 > 0 ? H1 : 1], d[H1 > 0 ? H1 : 1];
+            double2 v0;
+            {
+                double2 v[R1];
+                const T *xf = x0 + (long long)(ok ? ta : tq) * P.S;
+#pragma unroll
+                for (int n1 = 0; n1 < R1; ++n1) {
+                    int idx = R2 * n1 + R1 * n2;                    // < 2 NC: one conditional wrap
+                    idx = (idx >= NC) ? idx - NC : idx;
+                    const double a = load_sample<T>(xf + 2 * idx), b = load_sample<T>(xf + 2 * idx + 1);
+                    v[n1] = make_double2(fma(a, sc, -nm.mean) * nm.inv, fma(b, sc, -nm.mean) * nm.inv);
+                }
+                v0 = v[0];
+                prime_fold<R1>(v, s, d);
+            }
+            double *pl = slots + ((slot0 + (act_a ? fa : 0)) % (Q + 1)) * NFP;
+            const double2 x0c = prime_dc<R1>(v0, s);
+            if (ok) pl[n2] = x0c.x;
+            yim[0] = x0c.y;
+            for_pairs<R1, 1>([&](auto kc) {
+                constexpr int K = decltype(kc)::value;
+                double2 xk, xr;
+                prime_pair<R1, K>(v0, s, d, xk, xr);
+                if (ok) { pl[K * R2 + n2] = xk.x; pl[(R1 - K) * R2 + n2] = xr.x; }
+                yim[K] = xk.y;
+                yim[R1 - K] = xr.y;
+                // one output pair at a time: dependent FP64 operations issue back to back on gfx950, and the scheduler
+                // would otherwise run all (R-1)/2 accumulations side by side and spill
+                asm volatile("" : "+v"(yim[K]), "+v"(yim[R1 - K]));
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        wsync();
+        // ---------------- exchange: real plane, then imaginary plane
+        double2 a[R2], b[R2];
+        {
+            const double *pl = slots + ((slot0 + (act_b ? fb : 0)) % (Q + 1)) * NFP;
+#pragma unroll
+            for (int r = 0; r < R2; ++r) { a[r].x = pl[pcol * R2 + r]; b[r].x = pl[pcolb * R2 + r]; }
+            wsync();
+            if (act_a && tq + fa < tend) {
+                double *pw = slots + ((slot0 + fa) % (Q + 1)) * NFP;
+#pragma unroll
+                for (int k1 = 0; k1 < R1; ++k1) pw[k1 * R2 + n2] = yim[k1];
+            }
+            wsync();
+#pragma unroll
+            for (int r = 0; r < R2; ++r) { a[r].y = pl[pcol * R2 + r]; b[r].y = pl[pcolb * R2 + r]; }
+            wsync();
+        }
+        // ---------------- pass B: two radix-R2 DFTs, real-FFT recombination, magnitudes (ShortTermFeatures.py:617-621)
+        if (act_b && tq + fb < tend) {
+            double *sp = slots + ((slot0 + fb) % (Q + 1)) * NFP;
+            double2 sa[H2], da[H2], sb[H2], db[H2];
+            const double2 a0 = a[0], b0 = b[0];
+            prime_fold<R2>(a, sa, da);
+            prime_fold<R2>(b, sb, db);
+            const double mscale = 0.5 / (double)NF;            // E and O carry 1/2; X / len(X) (:621)
+            // bin of (column p, output q): k = (C1 p + C2 q) mod NC; its partner NC - k is (column R1 - p, output R2 - q)
+            const int k_p0 = (SH::C1 * pcol) % NC;
+            auto bins = [&](int k, const double2 &zk, const double2 &zm) {
+                // 2E = Z[k] + conj Z[NC-k], 2O = -i (Z[k] - conj Z[NC-k]); X[k] = E + w^k O, |X[NC-k]| = |E - w^k O|
+                const double2 e = make_double2(zk.x + zm.x, zk.y - zm.y);
+                const double2 o = make_double2(zk.y + zm.y, zm.x - zk.x);
+                const double2 t = cmul(tb.post[k], o);
+                const double xr = e.x + t.x, xi = e.y + t.y, yr = e.x - t.x, yi = e.y - t.y;
+                sp[k] = mag_sqrt(fma(xr, xr, xi * xi)) * mscale;
+                if (k != 0) sp[NC - k] = mag_sqrt(fma(yr, yr, yi * yi)) * mscale;
+            };
+            bins(k_p0, prime_dc<R2>(a0, sa), prime_dc<R2>(b0, sb));
+            int k_up = k_p0, k_dn = k_p0;
+            for_pairs<R2, 1>([&](auto qc) {
+                constexpr int QK = decltype(qc)::value;
+                double2 xa, xar, xb, xbr;
+                prime_pair<R2, QK>(a0, sa, da, xa, xar);
+                prime_pair<R2, QK>(b0, sb, db, xb, xbr);
+                k_up += SH::C2; k_up = (k_up >= NC) ? k_up - NC : k_up;          // k(p, q)
+                k_dn -= SH::C2; k_dn = (k_dn < 0) ? k_dn + NC : k_dn;            // k(p, R2 - q)
+                bins(k_up, xa, xbr);          // Z[k(p,q)] with Z[NC - k] = column R1-p, output R2-q
+                bins(k_dn, xar, xb);          // Z[k(p,R2-q)] with column R1-p, output q
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        wsync();
+        // ---------------- per frame: spectrogram row / chromagram row / the 34 features (one code instance, see above)
+#pragma nounroll
+        for (int f = 0; f < Q; ++f) {
+            const int t = tq + f;
+            if (t >= tend) break;
+            const double *cur = slots + ((slot0 + f) % (Q + 1)) * NFP;
+            const double *prv = slots + ((slot0 + f + Q) % (Q + 1)) * NFP;
+            if (P.mode == 1) {            // spectrogram row (ShortTermFeatures.py:422)
+                double *row = oc + (long long)t * NF;
+                for (int k = lane_o; k < NF; k += kWave) row[k] = cur[k];
+            } else if (P.mode == 2) {     // chromagram row (:356-359)
+                double p = 0.0;
+                for (int k = lane_o; k < NF; k += kWave) { const double X = cur[k]; p = fma(X, X, p); }
+                p = wsum(p);
+                const double ch = chroma_class(tb, cur, p, lane_o);
+                if (lane_o < 12) oc[(long long)t * 12 + lane_o] = ch;
+            } else {
+                const bool want = store_it || (P.deltas && f == Q - 1);
+                if (want) {
+                    TimeFeat tf;
+                    tf.e_tot = tfs[4 * f]; tf.ent_e = tfs[4 * f + 1]; tf.zc = (int)tfs[4 * f + 2];
+                    if (!(P.debug & 2)) frame_features(P, tb, tf, cur, (t == 0) ? cur : prv, fv, msp, lane_o);
+                    const double v = (lane_o < kBase) ? fv[lane_o] : 0.0;
+                    if (store_it) {
+                        if (lane_o < kBase) {
+                            otile[nslot * F + lane_o] = v;
+                            if (P.deltas) otile[nslot * F + kBase + lane_o] = (t == 0) ? 0.0 : v - vprev;
+                        }
+                        ++nslot;
+                    }
+                    vprev = v;
+                }
+                if (nslot == kFlush || (t == tend - 1 && nslot > 0)) {
+                    wsync();
+                    // row segments: nslot consecutive frames of feature row fr are contiguous in [F][T]
+                    for (int idx = lane_o; idx < F * kFlush; idx += kWave) {
+                        const int fr = idx / kFlush, i = idx % kFlush;
+                        if (i < nslot) oc[(long long)fr * Tc + tbase + i] = otile[i * F + fr];
+                    }
+                    wsync();
+                    tbase += nslot;
+                    nslot = 0;
+                }
+            }
+        }
+        wsync();
+    }
+}
+
+// ---- host: which windows have an instance, LDS layout + table blob ----------------------------------------
+typedef Shape<29, 19, 3> Shape1102;
+
+inline bool reg_supported(int window) { return window == Shape1102::W; }
+
+inline size_t reg_wave_bytes(int nfp, int q, int F) {
+    size_t b = (size_t)(q + 1) * nfp * 8 + (size_t)kFlush * F * 8 + (48 + 40) * 8 + (size_t)q * 4 * 8;
+    return (b + 15) / 16 * 16;
+}
+
+// fills the layout and the host image of the shared table region (no Stockham twiddles: prime-factor transform)
+inline void reg_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable *chroma, int F, int nfp, int q,
+                       RegLayout &L, std::vector<unsigned char> *blob) {
+    int off = 0;
+    auto take = [&off](size_t bytes) { const int o = off; off += (int)((bytes + 15) / 16 * 16); return o; };
+    const int Nc = fft.len;
+    const size_t n_melw = mel ? mel->w.size() : 0, n_ch = chroma ? chroma->src.size() : 0;
+    L.off_post = take((size_t)Nc * 16);
+    L.off_mello = take(40 * 4);
+    L.off_melcnt = take(40 * 4);
+    L.off_meloff = take(40 * 4);
+    L.off_melw = take(std::max<size_t>(n_melw, 1) * 8);
+    L.off_dct = take(13 * 41 * 8);
+    L.off_chstart = take(13 * 4);
+    L.off_chsrc = take(std::max<size_t>(n_ch, 1) * 4);
+    L.off_chw = take(std::max<size_t>(n_ch, 1) * 8);
+    L.table_bytes = off;
+    L.wave_bytes = (int)reg_wave_bytes(nfp, q, F > 0 ? F : 1);
+    L.waves = 6;
+    while (L.waves > 1 && (size_t)L.table_bytes + (size_t)L.waves * L.wave_bytes > 160 * 1024) --L.waves;
+    if (!blob) return;
+    blob->assign((size_t)L.table_bytes, 0);
+    unsigned char *b = blob->data();
+    memcpy(b + L.off_post, fft.post.data(), (size_t)Nc * 16);
+    if (mel && !mel->w.empty()) {
+        memcpy(b + L.off_mello, mel->lo.data(), 40 * 4);
+        memcpy(b + L.off_melcnt, mel->cnt.data(), 40 * 4);
+        memcpy(b + L.off_meloff, mel->off.data(), 40 * 4);
+        memcpy(b + L.off_melw, mel->w.data(), n_melw * 8);
+        double dct[kNumMfcc * kNumMel];
+        build_dct(dct);
+        double *dd = reinterpret_cast<double *>(b + L.off_dct);
+        for (int qq = 0; qq < 13; ++qq)
+            for (int n = 0; n < 40; ++n) dd[qq * 41 + n] = dct[qq * 40 + n];
+    }
+    if (chroma && !chroma->src.empty()) {
+        memcpy(b + L.off_chstart, chroma->class_start, 13 * 4);
+        memcpy(b + L.off_chsrc, chroma->src.data(), n_ch * 4);
+        memcpy(b + L.off_chw, chroma->w.data(), n_ch * 8);
+    }
+}
+
+}  // namespace reg
+}  // namespace paa

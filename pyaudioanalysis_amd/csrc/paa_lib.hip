@@ -20,6 +20,7 @@
 #include "kernels_big.hpp"
 #include "kernels_fast.hpp"
 #include "kernels_generic.hpp"
+#include "kernels_reg.hpp"
 #include "kernels_sim.hpp"
 #include "tables.hpp"
 
@@ -191,6 +192,8 @@ struct paa_plan {
     void *d_psum = nullptr, *d_pmin = nullptr, *d_pmax = nullptr;
     long long *d_mid_off = nullptr;
     GenLayout gl;                    // generic kernel: LDS layout + table blob
+    reg::RegLayout rl;               // register-FFT kernel (windows 2 R1 R2): LDS layout, blob in d_gen_blob
+    int reg = 0;
     unsigned char *d_gen_blob = nullptr;
     int big = 0;                     // window beyond the LDS envelope: Stockham passes through HBM scratch
     void *d_big = nullptr;
@@ -292,6 +295,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     P.blk_t = window / 10; P.blk_f = Nf / 10;
     P.mode = mode;
     P.frame_origin = (mode == 0) ? 0 : window;
+    { const char *dbg = getenv("PAA_KERNEL_DEBUG"); P.debug = dbg ? atoi(dbg) : 0; }
 
     // ---- kernel choice + tiles
     p->fast = 0;
@@ -301,7 +305,26 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         p->fast = rc;
     }
     int run;
-    if (p->fast) {
+    if (!p->fast && !g_force_generic && tab->fft.even && reg::reg_supported(window)) {
+        // windows 2 R1 R2 with coprime primes (config 5: 1102): several frames per wave, prime-factor FFT in registers
+        using SH = reg::Shape1102;
+        std::vector<unsigned char> blob;
+        reg::reg_layout(tab->fft, mode == 0 ? &tab->mel : nullptr, mode != 1 ? &tab->chroma : nullptr, F, SH::NFP, SH::Q,
+                        p->rl, &blob);
+        if ((size_t)p->rl.table_bytes + (size_t)p->rl.wave_bytes <= 160 * 1024) {
+            if ((rc = upload(&p->d_gen_blob, blob.data(), blob.size()))) return rc;
+            p->reg = 1;
+        }
+    }
+    if (p->reg) {
+        p->lds = (size_t)p->rl.table_bytes + (size_t)p->rl.waves * p->rl.wave_bytes;
+        // about two chip-wide rounds of (CUs x waves per workgroup); runs are multiples of Q frames (halo = one iteration)
+        const long long slots = (long long)g_num_cu * p->rl.waves * 2;
+        const long long per = (total_frames + slots - 1) / slots;
+        const int q = reg::Shape1102::Q;
+        run = (int)std::min<long long>(32 * q, std::max<long long>(4 * q, (per + q - 1) / q * q));
+        p->kernel_name = (mode == 0) ? "st_reg_29x19" : (mode == 1 ? "spectrogram_reg_29x19" : "chromagram_reg_29x19");
+    } else if (p->fast) {
         // one wave per run; size the runs so that the launch is close to a whole number of chip-wide
         // rounds (256 CUs x resident waves), in multiples of the 4-frame quad, at most fl.run frames
         const long long slots = (long long)g_num_cu * p->fl.waves_per_cu;
@@ -406,6 +429,22 @@ static int launch_generic(paa_plan *p, const void *d_packed, double *d_out) {
     return PAA_OK;
 }
 
+template <typename T>
+static int launch_reg(paa_plan *p, const void *d_packed, double *d_out) {
+    using SH = reg::Shape1102;
+    static size_t attr_set = 0;
+    if (p->lds > attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&reg::st_reg_kernel<SH, T>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(p->lds, 64 * 1024)));
+        attr_set = std::max<size_t>(p->lds, 64 * 1024);
+    }
+    const unsigned grid = (unsigned)((p->n_tiles + p->rl.waves - 1) / p->rl.waves);
+    hipLaunchKernelGGL((reg::st_reg_kernel<SH, T>), dim3(grid), dim3(64 * p->rl.waves), p->lds, g_stream, p->P, p->rl,
+                       p->d_gen_blob, (const T *)d_packed, p->d_clips, p->d_norms, p->d_tiles, (int)p->n_tiles, d_out);
+    HIP_TRY(hipGetLastError());
+    return PAA_OK;
+}
+
 // windows beyond the LDS envelope: chunked Stockham passes through HBM scratch (kernels_big.hpp)
 template <typename T>
 static int run_big(paa_plan *p, const void *d_packed, double *d_out) {
@@ -500,6 +539,9 @@ extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *
                             hipGetErrorString(hipGetLastError()));
         return PAA_OK;
     }
+    if (plan->reg)
+        return plan->sample_kind == 0 ? launch_reg<int16_t>(plan, d_packed, d_out)
+             : plan->sample_kind == 2 ? launch_reg<int>(plan, d_packed, d_out) : launch_reg<double>(plan, d_packed, d_out);
     return plan->sample_kind == 0 ? launch_generic<int16_t>(plan, d_packed, d_out)
          : plan->sample_kind == 2 ? launch_generic<int>(plan, d_packed, d_out)
                                   : launch_generic<double>(plan, d_packed, d_out);
