@@ -117,23 +117,28 @@ def other_configs(ffi, steps=8):
                               {"workload": "12 500 clips x 10 s (64 distinct, tiled), 34 rows: one GPU's share of config 4"})
     plan.destroy()
     del d_in, d_out
-    # ---- config 5: 44.1 kHz stereo -> mono (audioBasicIO.py:167: float64 with .5 fractions), 1102 / 441, 600 s
+    # ---- config 5: 44.1 kHz, window 25 ms / step 10 ms (1102 / 441), 600 s.  Two resident input forms: int16 mono (the
+    # accounting of SURVEY 8d: 882 B of input per frame) and the float64 mono array audioBasicIO.stereo_to_mono hands the
+    # reference for a stereo file (audioBasicIO.py:167: .5 fractions; 3 528 B of input per frame)
     fs5, w5, s5 = 44100, 1102, 441
     xs = synth_clip(5, 100 * fs5, fs=fs5, stereo=True)          # 100 s synthesised, tiled to 600 s (keeps the bench short)
-    mono = np.ascontiguousarray(np.tile((xs[:, 1] / 2) + (xs[:, 0] / 2), 6))
-    offs = np.array([0, len(mono)], dtype=np.int64)
-    d_in = ffi.DeviceBuffer.from_host(mono)
-    for name, mode, row_bytes in (("cfg5_features", 0, 8 * 34), ("cfg5_spectrogram", 1, 8 * (w5 // 2)),
-                                  ("cfg5_chromagram", 2, 8 * 12)):
-        plan = ffi.Plan(offs, fs5, w5, s5, deltas=False, sample_kind=1, mode=mode)
-        d_out = ffi.DeviceBuffer(plan.out_doubles * 8)
-        ms = timed(ffi, lambda: plan.execute(d_in, d_out), steps, 2)
-        out[name] = entry(plan.total_frames, ms, 8 * s5 + row_bytes, plan.kernel_name,
-                          {"workload": "600 s of 44.1 kHz audio (100 s seeded stereo clip reduced to mono, tiled x6), float64 "
-                                       "mono samples resident (stereo_to_mono output), window 1102 / step 441",
-                           "algorithmic_bytes_note": "8 B/sample float64 input (SURVEY 8d's 882 B assumes int16 mono)"})
-        plan.destroy()
-        del d_out
+    forms = (("", np.ascontiguousarray(np.tile(xs[:, 0], 6)), 0, 2, "int16 mono samples resident (left channel)"),
+             ("_f64", np.ascontiguousarray(np.tile((xs[:, 1] / 2) + (xs[:, 0] / 2), 6)), 1, 8,
+              "float64 mono samples resident (stereo_to_mono output)"))
+    for suffix, sig5, kind, esz, what in forms:
+        offs = np.array([0, len(sig5)], dtype=np.int64)
+        d_in = ffi.DeviceBuffer.from_host(sig5)
+        for name, mode, row_bytes in (("cfg5_features", 0, 8 * 34), ("cfg5_spectrogram", 1, 8 * (w5 // 2)),
+                                      ("cfg5_chromagram", 2, 8 * 12)):
+            plan = ffi.Plan(offs, fs5, w5, s5, deltas=False, sample_kind=kind, mode=mode)
+            d_out = ffi.DeviceBuffer(plan.out_doubles * 8)
+            ms = timed(ffi, lambda: plan.execute(d_in, d_out), steps, 2)
+            out[name + suffix] = entry(plan.total_frames, ms, esz * s5 + row_bytes, plan.kernel_name,
+                                       {"workload": "600 s of 44.1 kHz audio (100 s seeded clip, tiled x6), %s, window 1102 / "
+                                                    "step 441" % what})
+            plan.destroy()
+            del d_out
+        del d_in
     return out
 
 

@@ -189,6 +189,197 @@ __device__ __forceinline__ TimeFeat time_features_global(const PlanDev &P, const
     return tf;
 }
 
+// ---- per-frame stages with the window known at compile time ----------------------------------------------
+// The generic kernel's stages walk the frame in ten run-time loops (one per entropy block), each with its own
+// dependent global / LDS loads and its own wave reduction: latency-bound (0.35 ms each on config 5).  With W and NF
+// template constants every load of the frame is issued up front, the block a sample / bin belongs to is static, and the
+// spectral block energies come from ONE wave scan (differences of the cumulative energy at the block boundaries).
+
+// zcr count, energy and energy entropy of one frame read from global memory (ShortTermFeatures.py:22-51).
+// Sample n = 64 r + lane sits in register row r of its lane (coalesced loads).
+template <typename SH, typename T>
+__device__ __forceinline__ TimeFeat time_features_fixed(const T *__restrict__ x, const ClipNorm &nm, int lane) {
+    constexpr int W = SH::W, L = W / 10, NR = (W + kWave - 1) / kWave;
+    static_assert(L >= kWave, "a 64-sample row may span at most two entropy blocks");
+    const double sc = sample_scale<T>();
+    double y[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int n = kWave * r + lane;
+        // (rows are full except the last; clamp the address instead of branching, mask the value)
+        const double v = load_sample<T>(x + min(n, W - 1));
+        y[r] = (n < W) ? fma(v, sc, -nm.mean) * nm.inv : 0.0;
+    }
+    double eb[11];                 // ten blocks of L samples + the tail beyond 10 L
+#pragma unroll
+    for (int j = 0; j < 11; ++j) eb[j] = 0.0;
+    int zc = 0, carry = 0;         // carry: sign of the last sample of the previous row
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const double v = y[r];
+        const int sg = (v > 0.0) - (v < 0.0);
+        // sign of sample n - 1: the lane below (wave_shr:1), lane 0 takes the previous row's lane 63
+        const int sp = __builtin_amdgcn_update_dpp(carry, sg, 0x138, 0xF, 0xF, false);
+        const int n = kWave * r + lane;
+        zc += (n >= 1 && n < W) ? abs(sg - sp) : 0;
+        carry = __builtin_amdgcn_readlane(sg, 63);
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int jlo = (kWave * r) / L;                               // static after unrolling
+        const int bl = (jlo + 1) * L - kWave * r;                      // first lane of the row in block jlo + 1
+        const double v2 = v * v;
+        const int ja = jlo < 10 ? jlo : 10, jb = jlo + 1 < 10 ? jlo + 1 : 10;
+        eb[ja] += (lane < bl) ? v2 : 0.0;
+        if (bl < kWave) eb[jb] += (lane >= bl) ? v2 : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 11; ++j) eb[j] = wsum(eb[j]);                  // independent chains
+    TimeFeat tf;
+    tf.e_tot = eb[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) tf.e_tot += eb[j];
+    tf.zc = wsum_i(zc);
+    double num = 0.0;
+#pragma unroll
+    for (int j = 0; j < 10; ++j)
+        if (lane == j) num = eb[j];
+    const double s = fast_div(num, tf.e_tot + kEps);
+    tf.ent_e = wsum((lane < 10) ? -(s * fast_log2(s + kEps)) : 0.0);
+    return tf;
+}
+
+// the 34 base features of one frame into fv[0..33] (ShortTermFeatures.py:626-667); lane l owns the C consecutive bins
+// [C l, C l + C) (C odd: conflict-free LDS reads), both spectra are pulled into registers once.  tmp: 12 doubles of LDS.
+template <typename SH>
+__device__ __forceinline__ void frame_features_fixed(const PlanDev &P, const Tabs &tb, const TimeFeat &tf,
+                                                     const double *cur, const double *prv, double *fv, double *msp,
+                                                     double *tmp, int lane) {
+    constexpr int W = SH::W, NF = SH::NF, LB = NF / 10;
+    constexpr int C0 = (NF + kWave - 1) / kWave, C = C0 | 1;
+    static_assert(LB > C, "a lane's chunk may contain at most one block boundary");
+    const double f0 = P.fs / (2.0 * (double)NF);
+    const int kb = C * lane;
+    double Xc[C], Xv[C];
+#pragma unroll
+    for (int m = 0; m < C; ++m) {
+        const int k = min(kb + m, NF - 1);
+        const double a = cur[k], b = prv[k];
+        Xc[m] = (kb + m < NF) ? a : 0.0;
+        Xv[m] = (kb + m < NF) ? b : 0.0;
+    }
+    // sweep A: sums, max, the lane's energy (:57-107)
+    double sX = 0.0, sXp = 0.0, sM = 0.0, mx = 0.0, cs = 0.0;
+#pragma unroll
+    for (int m = 0; m < C; ++m) {
+        sX += Xc[m];
+        sXp += Xv[m];
+        sM = fma((double)m, Xc[m], sM);
+        mx = fmax(mx, Xc[m]);
+        cs = fma(Xc[m], Xc[m], cs);
+    }
+    double sIX = f0 * fma((double)(kb + 1), sX, sM);                   // sum (k + 1) f0 X
+    const double incl = wscan_incl(cs);
+    const double excl = incl - cs;
+    const double sP = readlane63(incl);
+    sX = wsum(sX);
+    sXp = wsum(sXp);
+    sIX = wsum(sIX);
+    mx = wmax_nonneg(mx);
+    // cumulative energy at the block boundaries 0, LB, 2 LB, .. 10 LB: the lane whose chunk holds a boundary writes it
+    {
+        const int jb = (kb + LB - 1) / LB;                             // first boundary at or after the chunk start
+        const int mb = jb * LB - kb;                                   // its offset inside the chunk
+        double part = 0.0, cumb = excl;
+#pragma unroll
+        for (int m = 0; m < C; ++m) {
+            cumb = (m == mb) ? excl + part : cumb;
+            part = fma(Xc[m], Xc[m], part);
+        }
+        if (mb < C && jb <= 10 && kb < NF) tmp[jb] = cumb;
+    }
+    wsync();
+    double ent_f;
+    {
+        const double num = (lane < 10) ? tmp[lane + 1] - tmp[lane] : 0.0;
+        const double s = fast_div(num, sP + kEps);
+        ent_f = wsum((lane < 10) ? -(s * fast_log2(s + kEps)) : 0.0);
+    }
+    const double sXe = sX + (double)NF * kEps;                         // np.sum(X + eps) (:118-119)
+    sXp += (double)NF * kEps;
+    // centroid, spread, flux (:57-82, :110-124)
+    const double r = (mx == 0.0) ? 1.0 / kEps : fast_div(1.0, mx);
+    const double den = sX * r + kEps;
+    const double cen = fast_div(sIX * r, den);
+    const double rX = fast_div(1.0, sXe), rXp = fast_div(1.0, sXp);
+    double sSp = 0.0, sFl = 0.0;
+#pragma unroll
+    for (int m = 0; m < C; ++m) {
+        const double dv = (double)(kb + m + 1) * f0 - cen;
+        sSp = fma(dv * dv, Xc[m] * r, sSp);
+        const double df = Xc[m] * rX - Xv[m] * rXp;
+        sFl = fma(df, df, sFl);
+    }
+    sSp = wsum(sSp);
+    sFl = wsum(sFl);
+    const double spread = fast_sqrt(fast_div(sSp, den));
+    // roll-off: first k with cumsum(X^2)[k] + eps > 0.9 * sum(X^2) (:127-140)
+    int first = 0x7fffffff;
+    {
+        const double thr = 0.90 * sP;
+        double run = excl;
+#pragma unroll
+        for (int m = 0; m < C; ++m) {
+            run = fma(Xc[m], Xc[m], run);
+            first = (first == 0x7fffffff && kb + m < NF && run + kEps > thr) ? kb + m : first;
+        }
+        first = wmin_i(first);
+    }
+    // MFCC: sparse mel dot, log10, 13 x 40 DCT (:236-254)
+    if (lane < 40) {
+        const int lo = tb.mel_lo[lane], cnt = tb.mel_cnt[lane];
+        const double *w = tb.mel_w + tb.mel_off[lane];
+        double a0 = 0.0, a1 = 0.0;
+        int i = 0;
+        for (; i + 2 <= cnt; i += 2) {
+            a0 = fma(cur[lo + i], w[i], a0);
+            a1 = fma(cur[lo + i + 1], w[i + 1], a1);
+        }
+        if (i < cnt) a0 = fma(cur[lo + i], w[i], a0);
+        msp[lane] = fast_log10((a0 + a1) + kEps);
+    }
+    const double chroma = chroma_class(tb, cur, sP, lane);             // (:277-321)
+    wsync();
+    if (lane < 13) {
+        const double *m = tb.dct + lane * tb.dct_stride;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int n = 0; n < 40; n += 4) {
+            a0 = fma(m[n], msp[n], a0);
+            a1 = fma(m[n + 1], msp[n + 1], a1);
+            a2 = fma(m[n + 2], msp[n + 2], a2);
+            a3 = fma(m[n + 3], msp[n + 3], a3);
+        }
+        fv[8 + lane] = (a0 + a1) + (a2 + a3);
+    }
+    if (lane < 12) fv[21 + lane] = chroma;
+    // population std of the 12 chroma values (:667)
+    const double cmean = wsum((lane < 12) ? chroma : 0.0) * (1.0 / 12.0);
+    const double cd = (lane < 12) ? chroma - cmean : 0.0;
+    const double cvar = wsum(cd * cd) * (1.0 / 12.0);
+    if (lane == 0) {
+        fv[0] = ((double)tf.zc / 2.0) / (double)(W - 1);
+        fv[1] = tf.e_tot / (double)W;
+        fv[2] = tf.ent_e;
+        fv[3] = cen / (P.fs / 2.0);
+        fv[4] = spread / (P.fs / 2.0);
+        fv[5] = ent_f;
+        fv[6] = (cur == prv) ? 0.0 : sFl;      // first frame: previous spectrum = itself (:624-625)
+        fv[7] = (first == 0x7fffffff) ? 0.0 : (double)first / (double)NF;
+        fv[33] = fast_sqrt(cvar);
+    }
+    wsync();
+}
+
 template <typename SH, typename T>
 __global__ __launch_bounds__(384) void st_reg_kernel(PlanDev P, RegLayout L, const unsigned char *__restrict__ blob,
                                                       const T *__restrict__ sig, const ClipDev *__restrict__ clips,
@@ -263,7 +454,7 @@ __global__ __launch_bounds__(384) void st_reg_kernel(PlanDev P, RegLayout L, con
                 // with deltas the last halo frame needs its full feature vector (previous column of the first stored frame)
                 const bool want = t < tend && (store_it || (P.deltas && f == Q - 1));
                 if (want && !(P.debug & 1)) {
-                    const TimeFeat tf = time_features_global<T>(P, x0 + (long long)t * P.S, nm, lane_o);
+                    const TimeFeat tf = time_features_fixed<SH, T>(x0 + (long long)t * P.S, nm, lane_o);
                     if (lane_o == 0) { tfs[4 * f] = tf.e_tot; tfs[4 * f + 1] = tf.ent_e; tfs[4 * f + 2] = (double)tf.zc; }
                 }
             }
@@ -378,7 +569,7 @@ __global__ __launch_bounds__(384) void st_reg_kernel(PlanDev P, RegLayout L, con
                 if (want) {
                     TimeFeat tf;
                     tf.e_tot = tfs[4 * f]; tf.ent_e = tfs[4 * f + 1]; tf.zc = (int)tfs[4 * f + 2];
-                    if (!(P.debug & 2)) frame_features(P, tb, tf, cur, (t == 0) ? cur : prv, fv, msp, lane_o);
+                    if (!(P.debug & 2)) frame_features_fixed<SH>(P, tb, tf, cur, (t == 0) ? cur : prv, fv, msp, tfs + 4 * Q, lane_o);
                     const double v = (lane_o < kBase) ? fv[lane_o] : 0.0;
                     if (store_it) {
                         if (lane_o < kBase) {
@@ -412,7 +603,7 @@ typedef Shape<29, 19, 3> Shape1102;
 inline bool reg_supported(int window) { return window == Shape1102::W; }
 
 inline size_t reg_wave_bytes(int nfp, int q, int F) {
-    size_t b = (size_t)(q + 1) * nfp * 8 + (size_t)kFlush * F * 8 + (48 + 40) * 8 + (size_t)q * 4 * 8;
+    size_t b = (size_t)(q + 1) * nfp * 8 + (size_t)kFlush * F * 8 + (48 + 40) * 8 + (size_t)q * 4 * 8 + 16 * 8;
     return (b + 15) / 16 * 16;
 }
 
