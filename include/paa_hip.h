@@ -171,6 +171,16 @@ int paa_thumbnail_f64(const double *feats, int n_dims, int64_t n_vec, int m_filt
 int paa_dev_thumbnail_filter(const double *d_sim, int64_t n_vec, int m_filter, double band, double limit_1,
                              double limit_2, double *d_filt, int64_t *pos2);
 
+/* ---- silence_removal's per-frame SVM loop (audioSegmentation.py:744-748) ------------------------------
+ * P(class index 1) of a TRAINED binary probabilistic scikit-learn SVC for every column of feats [n_dims][n_frames]
+ * (host, feature-major like the short-term matrix): (x - mean) / scale (:746), decision value from the support vectors
+ * (support_vectors [n_sv][n_dims], dual_coef [n_sv], intercept; gamma > 0: RBF kernel, gamma <= 0: linear), Platt
+ * sigmoid with (prob_a, prob_b) and libsvm's two-class multiclass_probability -- svm.predict_proba(..)[0][1] per frame.
+ * Training (:739) stays with scikit-learn.                                                                  */
+int paa_svm_binary_proba_f64(const double *feats, int n_dims, int64_t n_frames, const double *mean, const double *scale,
+                             const double *support_vectors, const double *dual_coef, int n_sv, double intercept,
+                             double gamma, double prob_a, double prob_b, double *prob1);
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI --------------------------------------- */
 #define PAA_COMM_ID_BYTES 128
 int paa_comm_unique_id(void *id_out /* PAA_COMM_ID_BYTES, rank 0 only */);

@@ -114,7 +114,7 @@ def main():
     print("total %.2f MB" % (tot / 1e6))
 
 
-if __name__ == "__main__" and not any(a in sys.argv for a in ("--dir", "--thumb", "--wide")):
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--dir", "--thumb", "--wide", "--silence")):
     main()
 
 
@@ -259,3 +259,33 @@ def wide_goldens():
 
 if __name__ == "__main__" and "--wide" in sys.argv:
     wide_goldens()
+
+
+def silence_goldens():
+    """Row f4 (remainder) of SURVEY 8f: audioSegmentation.silence_removal run by the unmodified reference.  Its SVM is
+    trained inside the call with scikit-learn (probability=True: libsvm's internal cross-validation draws from NumPy's
+    global random state), so the global seed is fixed before every call and stored with the result."""
+    ref_st, _, _ = load_reference.load()
+    ref_seg = load_reference.load_segmentation()
+
+    def case(name, sig, fs, st_win, st_step, smooth_window, weight, seed=1234):
+        np.random.seed(seed)
+        segs = ref_seg.silence_removal(sig, fs, st_win, st_step, smooth_window, weight)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="silence", signal=sig, fs=fs, st_win=st_win,
+                            st_step=st_step, smooth_window=smooth_window, weight=weight, seed=seed,
+                            segments=np.array(segs, dtype=np.float64).reshape(-1, 2))
+        print(name, len(segs), segs[:4])
+
+    fs, x = wav("pyAudioAnalysis/data/count.wav")
+    case("silence_count_020_020", x, fs, 0.020, 0.020, 1.0, 0.3)                # the CLI's defaults (audioAnalysis.py)
+    case("silence_count_050_050", x, fs, 0.050, 0.050, 0.5, 0.5)
+    fs, x = wav("pyAudioAnalysis/data/recording1.wav", 20.0)
+    case("silence_recording1_20s", x, fs, 0.050, 0.050, 0.5, 0.5)
+    g = synth_clip(71, 8 * 16000).copy()
+    for a, b in ((0.0, 1.0), (2.5, 3.5), (5.0, 5.6), (7.2, 8.0)):               # digital silence between bursts
+        g[int(a * 16000):int(b * 16000)] = 0
+    case("silence_synth_gaps", g, 16000, 0.050, 0.025, 0.5, 0.5)
+
+
+if __name__ == "__main__" and "--silence" in sys.argv:
+    silence_goldens()

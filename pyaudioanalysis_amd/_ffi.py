@@ -83,6 +83,8 @@ _SIGNATURES = {
                                     c_i64p]),
     "paa_dev_thumbnail_filter": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double,
                                            C.c_void_p, c_i64p]),
+    "paa_svm_binary_proba_f64": (C.c_int, [c_f64p, C.c_int, C.c_int64, c_f64p, c_f64p, c_f64p, c_f64p, C.c_int, C.c_double,
+                                           C.c_double, C.c_double, C.c_double, c_f64p]),
     "paa_comm_unique_id": (C.c_int, [C.c_void_p]),
     "paa_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
     "paa_comm_destroy": (C.c_int, []),

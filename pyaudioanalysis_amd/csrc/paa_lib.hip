@@ -22,6 +22,7 @@
 #include "kernels_generic.hpp"
 #include "kernels_reg.hpp"
 #include "kernels_sim.hpp"
+#include "kernels_svm.hpp"
 #include "tables.hpp"
 
 using namespace paa;
@@ -1141,6 +1142,43 @@ extern "C" int paa_chromagram_i16(const int16_t *s, int64_t n, double fs, int w,
 }
 extern "C" int paa_chromagram_f64(const double *s, int64_t n, double fs, int w, int st, double *out) {
     return run_host_spec(s, n, 1, fs, w, st, 2, out);
+}
+
+// ------------------------------------------------------------------------------------------
+// onset probability of silence_removal: binary probabilistic SVC over all frames (audioSegmentation.py:744-748)
+// ------------------------------------------------------------------------------------------
+extern "C" int paa_svm_binary_proba_f64(const double *feats, int n_dims, int64_t n_frames, const double *mean,
+                                        const double *scale, const double *support_vectors, const double *dual_coef,
+                                        int n_sv, double intercept, double gamma, double prob_a, double prob_b,
+                                        double *prob1) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!feats || !mean || !scale || !support_vectors || !dual_coef || !prob1) return fail(PAA_ERR_ARG, "null argument");
+    if (n_dims < 1 || n_dims > kSvmMaxDims) return fail(PAA_ERR_ARG, "n_dims must be 1..%d", kSvmMaxDims);
+    if (n_frames < 1 || n_sv < 1) return fail(PAA_ERR_ARG, "need at least one frame and one support vector");
+    std::lock_guard<std::mutex> api_lock(g_api_mu);
+    const size_t fb = (size_t)n_dims * n_frames * 8, sb = (size_t)n_sv * n_dims * 8;
+    const size_t small = (size_t)(2 * n_dims + n_sv) * 8 + sb;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if ((rc = scratch_reserve(g_in, fb + 64))) return rc;
+        if ((rc = scratch_reserve(g_sim_small, small + 64))) return rc;
+        if ((rc = scratch_reserve(g_out, (size_t)n_frames * 8))) return rc;
+    }
+    double *d_small = (double *)g_sim_small.p;
+    double *d_mean = d_small, *d_scale = d_small + n_dims, *d_coef = d_small + 2 * n_dims, *d_sv = d_coef + n_sv;
+    HIP_TRY(hipMemcpyAsync(g_in.p, feats, fb, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(d_mean, mean, (size_t)n_dims * 8, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(d_scale, scale, (size_t)n_dims * 8, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(d_coef, dual_coef, (size_t)n_sv * 8, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(d_sv, support_vectors, sb, hipMemcpyHostToDevice, g_stream));
+    hipLaunchKernelGGL(svm_binary_proba_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, g_stream,
+                       (const double *)g_in.p, n_dims, (long long)n_frames, (long long)n_frames, d_mean, d_scale, d_sv,
+                       d_coef, n_sv, intercept, gamma, prob_a, prob_b, (double *)g_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(prob1, g_out.p, (size_t)n_frames * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return PAA_OK;
 }
 
 // ------------------------------------------------------------------------------------------
