@@ -199,6 +199,7 @@ int paa_debug_dct(double *out_13x40);
 int paa_debug_chroma(double fs, int num_fft, int capacity, int32_t *src, double *weight, int32_t *slot);
 /* per-phase cycle totals of the fast kernel (diagnostic builds with -DPAA_F800_TIMING; zeros otherwise) */
 int paa_debug_wave_trace(uint64_t *out, int max_waves);
+int paa_debug_lane_peak(void);     /* most host-buffer calls in flight at once since the last query */
 int paa_debug_phase_cycles(uint64_t *out16);
 /* radix plan chosen for a window: returns number of passes, fills radices (capacity 32)      */
 int paa_debug_fft_plan(int window, int32_t *radices, int32_t *fft_len);

@@ -48,7 +48,7 @@ def mid_feature_extraction(signal, sampling_rate, mid_window, mid_step, short_wi
     if T < 1:
         raise ValueError("need at least one array to concatenate")  # ShortTermFeatures.py:684
     M = int(lib.paa_num_mid_windows(T, step_ratio))
-    st = np.empty((len(short_names), T), dtype=np.float64)
+    st = _ffi.result_array((len(short_names), T))
     mid = np.empty((2 * len(short_names), M), dtype=np.float64)
     if kind == 0:
         rc = lib.paa_mid_features_i16(_ffi.as_i16p(sig), sig.shape[0], float(sampling_rate), window, step,
@@ -91,7 +91,7 @@ def mid_feature_extraction_batch(signals, sampling_rate, mid_window, mid_step, s
     if return_short:
         st_off = np.zeros(len(clips), dtype=np.int64)
         np.cumsum(F * T[:-1], out=st_off[1:])
-        st = np.empty(int(F * T.sum()), dtype=np.float64)
+        st = _ffi.result_array((int(F * T.sum()),))
     _ffi.check(lib.paa_mid_features_batch_i16(
         _ffi.as_i16p(packed), _ffi.as_i64p(offsets), len(clips), float(sampling_rate), window, step,
         ratio, step_ratio, _ffi.as_f64p(mid), _ffi.as_i64p(mid_off),

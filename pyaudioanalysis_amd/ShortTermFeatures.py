@@ -64,7 +64,7 @@ def feature_extraction(signal, sampling_rate, window, step, deltas=True):
     if n_frames < 1:
         # np.concatenate([]) at ShortTermFeatures.py:684
         raise ValueError("need at least one array to concatenate")
-    out = np.empty((len(names), n_frames), dtype=np.float64)
+    out = _ffi.result_array((len(names), n_frames))
     if kind == 0:
         rc = lib.paa_st_features_i16(_ffi.as_i16p(sig), sig.shape[0], float(sampling_rate), window, step,
                                      1 if deltas else 0, _ffi.as_f64p(out))
@@ -100,7 +100,7 @@ def feature_extraction_batch(signals, sampling_rate, window, step, deltas=True):
     F = len(names)
     out_off = np.zeros(len(clips), dtype=np.int64)
     np.cumsum(F * frames[:-1], out=out_off[1:])
-    out = np.empty(int(F * frames.sum()), dtype=np.float64)
+    out = _ffi.result_array((int(F * frames.sum()),))
     _ffi.check(lib.paa_st_features_batch_i16(_ffi.as_i16p(packed), _ffi.as_i64p(offsets), len(clips),
                                              float(sampling_rate), window, step, 1 if deltas else 0,
                                              _ffi.as_f64p(out), _ffi.as_i64p(out_off)))
@@ -122,7 +122,7 @@ def spectrogram(signal, sampling_rate, window, step, plot=False, show_progress=F
     rows = int(lib.paa_spectrogram_rows(sig.shape[0], window, step, None)) if window >= 1 and step >= 1 else 0
     if rows < 1:
         raise ValueError("negative dimensions are not allowed")     # np.zeros((<=0, num_fft)) at :413
-    specgram = np.empty((rows, num_fft), dtype=np.float64)
+    specgram = _ffi.result_array((rows, num_fft))
     fn = lib.paa_spectrogram_i16 if kind == 0 else lib.paa_spectrogram_f64
     ptr = _ffi.as_i16p(sig) if kind == 0 else _ffi.as_f64p(sig)
     _ffi.check(fn(ptr, sig.shape[0], float(sampling_rate), window, step, _ffi.as_f64p(specgram)))

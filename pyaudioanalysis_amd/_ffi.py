@@ -95,6 +95,7 @@ _SIGNATURES = {
     "paa_debug_chroma": (C.c_int, [C.c_double, C.c_int, C.c_int, c_i32p, c_f64p, c_i32p]),
     "paa_debug_phase_cycles": (C.c_int, [C.POINTER(C.c_uint64)]),
     "paa_debug_wave_trace": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
+    "paa_debug_lane_peak": (C.c_int, []),
     "paa_debug_fft_plan": (C.c_int, [C.c_int, c_i32p, c_i32p]),
 }
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
@@ -291,3 +292,44 @@ class Plan:
 
 def sync():
     check(lib().paa_dev_sync())
+
+
+# ---- recycled result arrays ------------------------------------------------------------------------------
+# A fresh 39 MB NumPy array (one hour of features) costs ~2 ms of mmap/munmap plus ~1 ms of first-touch page faults during
+# the device-to-host copy -- as much as the copy itself.  Result arrays are therefore views of pooled base buffers; a
+# buffer is handed out again only when NOTHING refers to it any more (every view keeps a reference to its base, so the
+# reference count tells), which keeps the reference's contract: the caller owns what it gets for as long as it keeps it.
+_POOL_LOCK = threading.Lock()
+_POOL = []
+_POOL_MAX_BYTES = 1 << 30
+_POOL_MIN_BYTES = 1 << 20
+
+
+def result_array(shape, dtype=np.float64):
+    """Uninitialised C-contiguous array of `shape`, from the pool when a retired buffer fits."""
+    import sys
+    n = int(np.prod(shape))
+    nbytes = n * np.dtype(dtype).itemsize
+    if nbytes < _POOL_MIN_BYTES:
+        return np.empty(shape, dtype=dtype)
+    with _POOL_LOCK:
+        best = None
+        for k in range(len(_POOL)):
+            buf = _POOL[k]
+            # references of a retired buffer: the pool list, `buf`, getrefcount's argument
+            if sys.getrefcount(buf) <= 3 and buf.nbytes >= nbytes and (best is None or buf.nbytes < _POOL[best].nbytes):
+                best = k
+        if best is not None and _POOL[best].nbytes <= 2 * nbytes + (1 << 22):
+            base = _POOL[best]
+        else:
+            base = np.empty(nbytes, dtype=np.uint8)
+            _POOL.append(base)
+            total = sum(b.nbytes for b in _POOL)
+            k = 0
+            while total > _POOL_MAX_BYTES and k < len(_POOL):       # drop retired buffers, oldest first
+                if sys.getrefcount(_POOL[k]) <= 2 and _POOL[k] is not base:
+                    total -= _POOL[k].nbytes
+                    del _POOL[k]
+                else:
+                    k += 1
+        return base[:nbytes].view(dtype).reshape(shape)

@@ -29,7 +29,7 @@ def self_similarity_matrix(feature_vectors):
     F = np.ascontiguousarray(np.asarray(feature_vectors, dtype=np.float64))
     if F.ndim != 2 or F.shape[0] < 1 or F.shape[1] < 1:
         raise ValueError("feature_vectors must be a non-empty (nDims x nVectors) matrix")
-    sim = np.empty((F.shape[1], F.shape[1]))
+    sim = _ffi.result_array((F.shape[1], F.shape[1]))
     _ffi.check(_ffi.lib().paa_self_similarity_f64(_ffi.as_f64p(F), F.shape[0], F.shape[1], _ffi.as_f64p(sim)))
     return sim
 

@@ -101,7 +101,7 @@ extern "C" int paa_comm_init(int world_size, int rank, const void *id_bytes) {
 
 extern "C" int paa_comm_destroy(void) {
     if (g_comm) {
-        if (g_stream) (void)hipStreamSynchronize(g_stream);
+        if (g_main_stream) (void)hipStreamSynchronize(g_main_stream);
         if (g_comm_stream) (void)hipStreamSynchronize(g_comm_stream);
         g_rccl.CommDestroy(g_comm);
         g_comm = nullptr;
@@ -122,11 +122,11 @@ extern "C" int paa_comm_gather_f64(const double *d_send, const int64_t *counts, 
     if (!g_comm) {
         if (g_world != 1) return fail(PAA_ERR_COMM, "communicator not initialised");
         if (d_recv && d_send && d_recv != d_send)
-            HIP_TRY(hipMemcpyAsync(d_recv, d_send, (size_t)counts[0] * 8, hipMemcpyDeviceToDevice, g_stream));
+            HIP_TRY(hipMemcpyAsync(d_recv, d_send, (size_t)counts[0] * 8, hipMemcpyDeviceToDevice, g_main_stream));
         return PAA_OK;
     }
     // order the gather after everything queued so far on the compute stream
-    HIP_TRY(hipEventRecord(g_ev_ready, g_stream));
+    HIP_TRY(hipEventRecord(g_ev_ready, g_main_stream));
     HIP_TRY(hipStreamWaitEvent(g_comm_stream, g_ev_ready, 0));
     NCCL_TRY(g_rccl.GroupStart());
     if (g_rank == root) {
@@ -157,7 +157,7 @@ extern "C" int paa_comm_gather_f64(const double *d_send, const int64_t *counts, 
 // called by paa_plan_execute before it overwrites d_out
 static int comm_wait_buffer_free(const void *d_out) {
     auto it = g_gather_done.find(d_out);
-    if (it != g_gather_done.end() && it->second) HIP_TRY(hipStreamWaitEvent(g_stream, it->second, 0));
+    if (it != g_gather_done.end() && it->second) HIP_TRY(hipStreamWaitEvent(g_main_stream, it->second, 0));
     return PAA_OK;
 }
 static int comm_sync() {
@@ -167,7 +167,7 @@ static int comm_sync() {
 
 extern "C" int paa_comm_barrier(void) {
     if (!g_comm) return PAA_OK;
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipStreamSynchronize(g_main_stream));
     NCCL_TRY(g_rccl.AllReduce(g_bar, g_bar, 1, ncclInt, ncclSum, g_comm, g_comm_stream));
     HIP_TRY(hipStreamSynchronize(g_comm_stream));
     return PAA_OK;

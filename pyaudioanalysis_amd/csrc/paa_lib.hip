@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -72,12 +73,53 @@ struct Scratch {
 };
 
 static std::mutex g_mu;
-static std::mutex g_api_mu;     // host-buffer entry points share the scratch buffers: one call at a time
+static std::mutex g_api_mu;     // the self-similarity entry points share their scratch buffers: one call at a time
 static int g_device = -1;
-static hipStream_t g_stream = nullptr;
+static hipStream_t g_main_stream = nullptr;     // plan API, RCCL ordering, everything not running in a lane
 static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 static std::map<std::pair<double, int>, std::unique_ptr<TableSet>> g_tables;
-static Scratch g_in, g_in2, g_out, g_mid;
+// Host-buffer entry points (NumPy in -> NumPy out) run in LANES: each lane has its own stream and scratch buffers, so
+// calls from several host threads overlap on the device and on both PCIe directions instead of queueing behind one
+// mutex.  A thread holds a lane for the duration of one call; every launch / copy of that call goes to cs().
+struct Lane {
+    hipStream_t stream = nullptr;
+    Scratch in, in2, out, mid;
+    bool busy = false;
+};
+constexpr int kLanes = 4;
+static Lane g_lanes[kLanes];
+static std::mutex g_lane_mu;
+static std::condition_variable g_lane_cv;
+static int g_lanes_active = 0, g_lanes_peak = 0;
+static thread_local Lane *tl_lane = nullptr;
+static inline hipStream_t cs() { return tl_lane ? tl_lane->stream : g_main_stream; }
+struct LaneGuard {
+    Lane *l = nullptr;
+    bool nested = false;
+    LaneGuard() {
+        if (tl_lane) { l = tl_lane; nested = true; return; }
+        std::unique_lock<std::mutex> lk(g_lane_mu);
+        for (;;) {
+            for (int i = 0; i < kLanes; ++i)
+                if (!g_lanes[i].busy && g_lanes[i].stream) { l = &g_lanes[i]; break; }
+            if (l) break;
+            g_lane_cv.wait(lk);
+        }
+        l->busy = true;
+        g_lanes_peak = std::max(g_lanes_peak, ++g_lanes_active);
+        tl_lane = l;
+    }
+    ~LaneGuard() {
+        if (nested || !l) return;
+        tl_lane = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_lane_mu);
+            l->busy = false;
+            --g_lanes_active;
+        }
+        g_lane_cv.notify_one();
+    }
+};
 static Scratch g_sim_z, g_sim_small, g_sim_cand, g_sim_in, g_sim_out, g_sim_filt;     // self-similarity row
 static int g_force_generic = 0;
 static int g_f800_waves = 8;          // PAA_F800_WAVES: waves per workgroup of the 800/400 kernel (4 or 8)
@@ -390,25 +432,25 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
 static int launch_stats(paa_plan *p, const void *d_packed) {
     if (p->n_chunks > 0) {
         if (p->sample_kind == 0)
-            hipLaunchKernelGGL(clip_stats_i16_kernel, dim3((unsigned)p->n_chunks), dim3(256), 0, g_stream,
+            hipLaunchKernelGGL(clip_stats_i16_kernel, dim3((unsigned)p->n_chunks), dim3(256), 0, cs(),
                                (const int16_t *)d_packed, p->d_chunks, (long long *)p->d_psum, (int *)p->d_pmin,
                                (int *)p->d_pmax);
         else if (p->sample_kind == 2)
-            hipLaunchKernelGGL(clip_stats_i32_kernel, dim3((unsigned)p->n_chunks), dim3(256), 0, g_stream,
+            hipLaunchKernelGGL(clip_stats_i32_kernel, dim3((unsigned)p->n_chunks), dim3(256), 0, cs(),
                                (const int *)d_packed, p->d_chunks, (long long *)p->d_psum, (int *)p->d_pmin,
                                (int *)p->d_pmax);
         else
-            hipLaunchKernelGGL(clip_stats_f64_kernel, dim3((unsigned)p->n_chunks), dim3(256), 0, g_stream,
+            hipLaunchKernelGGL(clip_stats_f64_kernel, dim3((unsigned)p->n_chunks), dim3(256), 0, cs(),
                                (const double *)d_packed, p->d_chunks, (double *)p->d_psum, (double *)p->d_pmin,
                                (double *)p->d_pmax);
     }
     const unsigned gb = (unsigned)p->n_clips;
     if (p->sample_kind == 1)
-        hipLaunchKernelGGL((clip_params_kernel<double, double>), dim3(gb), dim3(64), 0, g_stream, p->d_clips,
+        hipLaunchKernelGGL((clip_params_kernel<double, double>), dim3(gb), dim3(64), 0, cs(), p->d_clips,
                            p->n_clips, (const double *)p->d_psum, (const double *)p->d_pmin,
                            (const double *)p->d_pmax, sample_scale<double>(), p->P.W, p->d_norms);
     else
-        hipLaunchKernelGGL((clip_params_kernel<long long, int>), dim3(gb), dim3(64), 0, g_stream, p->d_clips,
+        hipLaunchKernelGGL((clip_params_kernel<long long, int>), dim3(gb), dim3(64), 0, cs(), p->d_clips,
                            p->n_clips, (const long long *)p->d_psum, (const int *)p->d_pmin, (const int *)p->d_pmax,
                            p->sample_kind == 2 ? sample_scale<int>() : sample_scale<int16_t>(), p->P.W, p->d_norms);
     HIP_TRY(hipGetLastError());
@@ -424,7 +466,7 @@ static int launch_generic(paa_plan *p, const void *d_packed, double *d_out) {
         attr_set = std::max<size_t>(p->lds, 64 * 1024);
     }
     const unsigned grid = (unsigned)((p->n_tiles + p->gl.waves - 1) / p->gl.waves);
-    hipLaunchKernelGGL(st_generic_kernel<T>, dim3(grid), dim3(64 * p->gl.waves), p->lds, g_stream, p->P, p->gl,
+    hipLaunchKernelGGL(st_generic_kernel<T>, dim3(grid), dim3(64 * p->gl.waves), p->lds, cs(), p->P, p->gl,
                        p->d_gen_blob, (const T *)d_packed, p->d_clips, p->d_norms, p->d_tiles, (int)p->n_tiles, d_out);
     HIP_TRY(hipGetLastError());
     return PAA_OK;
@@ -440,7 +482,7 @@ static int launch_reg(paa_plan *p, const void *d_packed, double *d_out) {
         attr_set = std::max<size_t>(p->lds, 64 * 1024);
     }
     const unsigned grid = (unsigned)((p->n_tiles + p->rl.waves - 1) / p->rl.waves);
-    hipLaunchKernelGGL((reg::st_reg_kernel<SH, T>), dim3(grid), dim3(64 * p->rl.waves), p->lds, g_stream, p->P, p->rl,
+    hipLaunchKernelGGL((reg::st_reg_kernel<SH, T>), dim3(grid), dim3(64 * p->rl.waves), p->lds, cs(), p->P, p->rl,
                        p->d_gen_blob, (const T *)d_packed, p->d_clips, p->d_norms, p->d_tiles, (int)p->n_tiles, d_out);
     HIP_TRY(hipGetLastError());
     return PAA_OK;
@@ -458,7 +500,7 @@ static int run_big(paa_plan *p, const void *d_packed, double *d_out) {
     C = std::min<long long>(std::min<long long>(C, 65535), std::max<long long>(maxT, 1));
     const size_t need = (size_t)C * Nc * 32 + (size_t)(C + 1) * Nf * 8 + (size_t)C * 24 + 256;
     if (need > p->big_bytes) {
-        if (p->d_big) { HIP_TRY(hipStreamSynchronize(g_stream)); (void)hipFree(p->d_big); p->d_big = nullptr; }
+        if (p->d_big) { HIP_TRY(hipStreamSynchronize(cs())); (void)hipFree(p->d_big); p->d_big = nullptr; }
         HIP_TRY(hipMalloc(&p->d_big, need));
         p->big_bytes = need;
     }
@@ -475,24 +517,24 @@ static int run_big(paa_plan *p, const void *d_packed, double *d_out) {
         for (long long t0 = 0; t0 < cd.T; t0 += C) {
             const long long n = std::min<long long>(C, cd.T - t0);
             if (t0 > 0 && P.mode != 1)       // carry the last spectrum of the previous chunk into row 0
-                HIP_TRY(hipMemcpyAsync(spec, spec + prev_n * Nf, (size_t)Nf * 8, hipMemcpyDeviceToDevice, g_stream));
-            hipLaunchKernelGGL(big_load_kernel<T>, dim3(gx, (unsigned)n), dim3(256), 0, g_stream, P, x0, t0, ClipNorm(),
+                HIP_TRY(hipMemcpyAsync(spec, spec + prev_n * Nf, (size_t)Nf * 8, hipMemcpyDeviceToDevice, cs()));
+            hipLaunchKernelGGL(big_load_kernel<T>, dim3(gx, (unsigned)n), dim3(256), 0, cs(), P, x0, t0, ClipNorm(),
                                p->d_norms, (int)c, bufA);
             if (P.mode == 0)
-                hipLaunchKernelGGL(big_time_kernel, dim3((unsigned)n), dim3(64), 0, g_stream, P, bufA, tfeat);
+                hipLaunchKernelGGL(big_time_kernel, dim3((unsigned)n), dim3(64), 0, cs(), P, bufA, tfeat);
             double2 *src = bufA, *dst = bufB;
             int Ns = 1;
             for (int q = 0; q < P.n_pass; ++q) {
-                hipLaunchKernelGGL(big_pass_kernel, dim3(gx, (unsigned)n), dim3(256), 0, g_stream, (int)Nc, P.radix[q], Ns,
+                hipLaunchKernelGGL(big_pass_kernel, dim3(gx, (unsigned)n), dim3(256), 0, cs(), (int)Nc, P.radix[q], Ns,
                                    P.tw, src, dst);
                 Ns *= P.radix[q];
                 std::swap(src, dst);
             }
             if (P.mode == 1) {
-                hipLaunchKernelGGL(big_post_kernel, dim3(gx, (unsigned)n), dim3(256), 0, g_stream, P, src, oc, t0);
+                hipLaunchKernelGGL(big_post_kernel, dim3(gx, (unsigned)n), dim3(256), 0, cs(), P, src, oc, t0);
             } else {
-                hipLaunchKernelGGL(big_post_kernel, dim3(gx, (unsigned)n), dim3(256), 0, g_stream, P, src, spec, 1LL);
-                hipLaunchKernelGGL(big_feat_kernel, dim3((unsigned)n), dim3(64), 0, g_stream, P, spec, tfeat, t0,
+                hipLaunchKernelGGL(big_post_kernel, dim3(gx, (unsigned)n), dim3(256), 0, cs(), P, src, spec, 1LL);
+                hipLaunchKernelGGL(big_feat_kernel, dim3((unsigned)n), dim3(64), 0, cs(), P, spec, tfeat, t0,
                                    (long long)cd.T, oc);
             }
             HIP_TRY(hipGetLastError());
@@ -500,7 +542,7 @@ static int run_big(paa_plan *p, const void *d_packed, double *d_out) {
         }
         if (P.mode == 0 && P.deltas) {
             const long long items = (long long)kBase * cd.T;
-            hipLaunchKernelGGL(big_delta_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, g_stream,
+            hipLaunchKernelGGL(big_delta_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, cs(),
                                (long long)cd.T, oc);
             HIP_TRY(hipGetLastError());
         }
@@ -530,12 +572,12 @@ extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *
         pe0 = g_prof_ev[g_prof_used].first;
         pe1 = g_prof_ev[g_prof_used].second;
         ++g_prof_used;
-        HIP_TRY(hipEventRecord(pe0, g_stream));
+        HIP_TRY(hipEventRecord(pe0, cs()));
     }
-    struct StopEv { hipEvent_t e; ~StopEv() { if (e) (void)hipEventRecord(e, g_stream); } } stop_ev{pe1};
+    struct StopEv { hipEvent_t e; ~StopEv() { if (e) (void)hipEventRecord(e, cs()); } } stop_ev{pe1};
     if (plan->fast) {
         rc = fast_launch(plan->fl, plan->P, plan->tab->fast, d_packed, plan->d_clips, plan->d_norms, plan->d_tiles,
-                         plan->n_tiles, d_out, g_stream);
+                         plan->n_tiles, d_out, cs());
         if (rc) return fail(PAA_ERR_HIP, "launch of %s failed: %s", plan->kernel_name.c_str(),
                             hipGetErrorString(hipGetLastError()));
         return PAA_OK;
@@ -566,7 +608,7 @@ extern "C" int paa_plan_create_mode(const int64_t *offsets, int64_t n_clips, int
 
 extern "C" int paa_plan_destroy(paa_plan_t *plan) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    if (cs()) (void)hipStreamSynchronize(cs());
     plan_free(plan);
     return PAA_OK;
 }
@@ -605,7 +647,7 @@ extern "C" int paa_plan_mid_execute(paa_plan_t *plan, const double *d_st, int64_
             off[c] = o;
             o += 2LL * plan->P.F * paa_num_mid_windows(plan->clips[c].T, mid_step_ratio);
         }
-        if (g_stream) HIP_TRY(hipStreamSynchronize(g_stream));
+        if (cs()) HIP_TRY(hipStreamSynchronize(cs()));
         int rc = upload(&plan->d_mid_off, off.data(), off.size());
         if (rc) return rc;
         plan->mid_off_step = mid_step_ratio;
@@ -616,7 +658,7 @@ extern "C" int paa_plan_mid_execute(paa_plan_t *plan, const double *d_st, int64_
     const int bpc = (int)((items + 15) / 16);          // 16 (row, window) items per 256-thread block
     const long long grid = plan->n_clips * bpc;
     if (grid > 0x7fffffffLL) return fail(PAA_ERR_UNSUPPORTED, "mid-term grid too large");
-    hipLaunchKernelGGL(mid_stats_kernel, dim3((unsigned)grid), dim3(256), 0, g_stream, plan->d_clips, plan->d_mid_off,
+    hipLaunchKernelGGL(mid_stats_kernel, dim3((unsigned)grid), dim3(256), 0, cs(), plan->d_clips, plan->d_mid_off,
                        d_st, plan->P.F, (long long)mid_ratio, (long long)mid_step_ratio, bpc, d_mid);
     HIP_TRY(hipGetLastError());
     return PAA_OK;
@@ -633,7 +675,7 @@ extern "C" int paa_plan_beat_execute(paa_plan_t *plan, const double *d_st, doubl
     const size_t lds = (size_t)kBeatRows * (kBeatTile + 1) * 8 + (size_t)kBeatRows * max_beat * 4;
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&beat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(beat_kernel, dim3((unsigned)plan->n_clips), dim3(64), lds, g_stream, plan->d_clips, d_st,
+    hipLaunchKernelGGL(beat_kernel, dim3((unsigned)plan->n_clips), dim3(64), lds, cs(), plan->d_clips, d_st,
                        window_size, max_beat, d_beat);
     HIP_TRY(hipGetLastError());
     return PAA_OK;
@@ -664,9 +706,9 @@ extern "C" int paa_dev_self_similarity(const double *d_feats, int n_dims, int64_
         if ((rc = scratch_reserve(g_sim_small, (size_t)(2 * n_dims + ldz) * 8))) return rc;
     }
     double *d_mean = (double *)g_sim_small.p, *d_scale = d_mean + n_dims, *d_norm = d_scale + n_dims;
-    hipLaunchKernelGGL(sim_row_stats_kernel, dim3((unsigned)n_dims), dim3(256), 0, g_stream, d_feats, (long long)n_vec,
+    hipLaunchKernelGGL(sim_row_stats_kernel, dim3((unsigned)n_dims), dim3(256), 0, cs(), d_feats, (long long)n_vec,
                        (long long)ld, d_mean, d_scale);
-    hipLaunchKernelGGL(sim_normalize_kernel, dim3((unsigned)((ldz + 255) / 256)), dim3(256), 0, g_stream, d_feats,
+    hipLaunchKernelGGL(sim_normalize_kernel, dim3((unsigned)((ldz + 255) / 256)), dim3(256), 0, cs(), d_feats,
                        n_dims, dims_pad, (long long)n_vec, (long long)ld, ldz, d_mean, d_scale, (double *)g_sim_z.p,
                        d_norm);
     const unsigned tiles = (unsigned)(ldz / kSimTile);
@@ -677,7 +719,7 @@ extern "C" int paa_dev_self_similarity(const double *d_feats, int n_dims, int64_
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(sim_gram_kernel, dim3((unsigned)std::min<long long>((long long)tiles * tiles, 2LL * g_num_cu)), dim3(512), lds, g_stream, (const double *)g_sim_z.p, dims_pad,
+    hipLaunchKernelGGL(sim_gram_kernel, dim3((unsigned)std::min<long long>((long long)tiles * tiles, 2LL * g_num_cu)), dim3(512), lds, cs(), (const double *)g_sim_z.p, dims_pad,
                        (long long)n_vec, ldz, d_norm, d_sim);
     HIP_TRY(hipGetLastError());
     return PAA_OK;
@@ -705,17 +747,17 @@ extern "C" int paa_dev_thumbnail_filter(const double *d_sim, int64_t n_vec, int 
     }
     double *d_min = (double *)g_sim_cand.p, *d_cval = d_min + n_min + 1;
     long long *d_cidx = (long long *)(d_cval + n_cand), *d_best = d_cidx + n_cand;
-    hipLaunchKernelGGL(thumb_diag_kernel, dim3(gx, gy), dim3(256), 0, g_stream, d_sim, (long long)n_vec, m_filter, R,
+    hipLaunchKernelGGL(thumb_diag_kernel, dim3(gx, gy), dim3(256), 0, cs(), d_sim, (long long)n_vec, m_filter, R,
                        d_filt, d_min);
-    hipLaunchKernelGGL(thumb_min_kernel, dim3(1), dim3(1024), 0, g_stream, (const double *)d_min, n_min, d_min + n_min);
-    hipLaunchKernelGGL(thumb_mask_kernel, dim3(mx, my), dim3(256), 0, g_stream, d_filt, R, band, lim_lo, lim_hi,
+    hipLaunchKernelGGL(thumb_min_kernel, dim3(1), dim3(1024), 0, cs(), (const double *)d_min, n_min, d_min + n_min);
+    hipLaunchKernelGGL(thumb_mask_kernel, dim3(mx, my), dim3(256), 0, cs(), d_filt, R, band, lim_lo, lim_hi,
                        (const double *)(d_min + n_min), d_cval, d_cidx);
-    hipLaunchKernelGGL(thumb_argmax_kernel, dim3(1), dim3(1024), 0, g_stream, (const double *)d_cval,
+    hipLaunchKernelGGL(thumb_argmax_kernel, dim3(1), dim3(1024), 0, cs(), (const double *)d_cval,
                        (const long long *)d_cidx, n_cand, d_best);
     HIP_TRY(hipGetLastError());
     long long best = 0;
-    HIP_TRY(hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, cs()));
+    HIP_TRY(hipStreamSynchronize(cs()));
     pos2[0] = best / R;
     pos2[1] = best % R;
     return PAA_OK;
@@ -733,10 +775,10 @@ extern "C" int paa_self_similarity_f64(const double *feats, int n_dims, int64_t 
         if ((rc = scratch_reserve(g_sim_in, (size_t)n_dims * n_vec * 8))) return rc;
         if ((rc = scratch_reserve(g_sim_out, (size_t)n_vec * n_vec * 8))) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(g_sim_in.p, feats, (size_t)n_dims * n_vec * 8, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(g_sim_in.p, feats, (size_t)n_dims * n_vec * 8, hipMemcpyHostToDevice, cs()));
     if ((rc = paa_dev_self_similarity((const double *)g_sim_in.p, n_dims, n_vec, n_vec, (double *)g_sim_out.p))) return rc;
-    HIP_TRY(hipMemcpyAsync(sim, g_sim_out.p, (size_t)n_vec * n_vec * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpyAsync(sim, g_sim_out.p, (size_t)n_vec * n_vec * 8, hipMemcpyDeviceToHost, cs()));
+    HIP_TRY(hipStreamSynchronize(cs()));
     return PAA_OK;
 }
 
@@ -757,12 +799,12 @@ extern "C" int paa_thumbnail_f64(const double *feats, int n_dims, int64_t n_vec,
         if ((rc = scratch_reserve(g_sim_out, (size_t)n_vec * n_vec * 8))) return rc;
         if ((rc = scratch_reserve(g_sim_filt, (size_t)R * R * 8))) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(g_sim_in.p, feats, (size_t)n_dims * n_vec * 8, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(g_sim_in.p, feats, (size_t)n_dims * n_vec * 8, hipMemcpyHostToDevice, cs()));
     if ((rc = paa_dev_self_similarity((const double *)g_sim_in.p, n_dims, n_vec, n_vec, (double *)g_sim_out.p))) return rc;
     if ((rc = paa_dev_thumbnail_filter((const double *)g_sim_out.p, n_vec, m_filter, band, limit_1, limit_2,
                                        (double *)g_sim_filt.p, pos2))) return rc;
-    HIP_TRY(hipMemcpyAsync(filt, g_sim_filt.p, (size_t)R * R * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpyAsync(filt, g_sim_filt.p, (size_t)R * R * 8, hipMemcpyDeviceToHost, cs()));
+    HIP_TRY(hipStreamSynchronize(cs()));
     return PAA_OK;
 }
 
@@ -780,7 +822,7 @@ extern "C" int paa_device_count(void) {
 }
 
 extern "C" int paa_init(int device_id) {
-    if (g_device == device_id && g_stream) return PAA_OK;
+    if (g_device == device_id && cs()) return PAA_OK;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n < 1)
@@ -794,7 +836,8 @@ extern "C" int paa_init(int device_id) {
         paa_shutdown();
     }
     HIP_TRY(hipSetDevice(device_id));
-    HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&g_main_stream, hipStreamNonBlocking));
+    for (int i = 0; i < kLanes; ++i) HIP_TRY(hipStreamCreateWithFlags(&g_lanes[i].stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&g_ev0));
     HIP_TRY(hipEventCreate(&g_ev1));
     g_device = device_id;
@@ -812,15 +855,19 @@ extern "C" int paa_init(int device_id) {
 extern "C" void paa_shutdown(void) {
     if (g_device < 0) return;
     (void)paa_comm_destroy();          // communicator, its stream and events
-    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    if (g_main_stream) (void)hipStreamSynchronize(g_main_stream);
     for (auto &kv : g_tables) free_tables(*kv.second);
     g_tables.clear();
-    for (Scratch *s : {&g_in, &g_in2, &g_out, &g_mid, &g_sim_z, &g_sim_small, &g_sim_cand, &g_sim_in, &g_sim_out, &g_sim_filt}) { if (s->p) (void)hipFree(s->p); s->p = nullptr; s->cap = 0; }
+    for (Scratch *s : {&g_sim_z, &g_sim_small, &g_sim_cand, &g_sim_in, &g_sim_out, &g_sim_filt}) { if (s->p) (void)hipFree(s->p); s->p = nullptr; s->cap = 0; }
+    for (Lane &ln : g_lanes) {
+        if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); ln.stream = nullptr; }
+        for (Scratch *s : {&ln.in, &ln.in2, &ln.out, &ln.mid}) { if (s->p) (void)hipFree(s->p); s->p = nullptr; s->cap = 0; }
+    }
     if (g_ev0) (void)hipEventDestroy(g_ev0);
     if (g_ev1) (void)hipEventDestroy(g_ev1);
-    if (g_stream) (void)hipStreamDestroy(g_stream);
+    if (g_main_stream) (void)hipStreamDestroy(g_main_stream);
     g_ev0 = g_ev1 = nullptr;
-    g_stream = nullptr;
+    g_main_stream = nullptr;
     g_device = -1;
 }
 
@@ -838,40 +885,40 @@ extern "C" int paa_dev_free(void *ptr) {
 extern "C" int paa_memcpy_d2d(void *dst, const void *src, size_t bytes) {
     int rc = ensure_init();
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, cs()));
     return PAA_OK;
 }
 extern "C" int paa_memcpy_h2d(void *dst, const void *src, size_t bytes) {
     int rc = ensure_init();
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cs()));
+    HIP_TRY(hipStreamSynchronize(cs()));
     return PAA_OK;
 }
 extern "C" int paa_memcpy_d2h(void *dst, const void *src, size_t bytes) {
     int rc = ensure_init();
     if (rc) return rc;
     if ((rc = comm_sync())) return rc;       // a gather into src may still run on the communication stream
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, cs()));
+    HIP_TRY(hipStreamSynchronize(cs()));
     return PAA_OK;
 }
 extern "C" int paa_dev_sync(void) {
     int rc = ensure_init();
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipStreamSynchronize(cs()));
     return comm_sync();
 }
 extern "C" int paa_timer_start(void) {
     int rc = ensure_init();
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(g_ev0, g_stream));
+    HIP_TRY(hipEventRecord(g_ev0, cs()));
     return PAA_OK;
 }
 extern "C" int paa_timer_stop(float *ms) {
     int rc = ensure_init();
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(g_ev1, g_stream));
+    HIP_TRY(hipEventRecord(g_ev1, cs()));
     HIP_TRY(hipEventSynchronize(g_ev1));
     HIP_TRY(hipEventElapsedTime(ms, g_ev0, g_ev1));
     return PAA_OK;
@@ -887,7 +934,7 @@ extern "C" int paa_prof_read(double *total_ms, int64_t *launches) {
     int rc = ensure_init();
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g_mu);
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipStreamSynchronize(cs()));
     for (size_t i = 0; i < g_prof_used; ++i) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, g_prof_ev[i].first, g_prof_ev[i].second));
@@ -942,7 +989,8 @@ static int run_host_st(const void *packed, const int64_t *offsets, int64_t n_cli
                        int window, int step, int deltas, double *out, const int64_t *out_offsets,
                        int64_t mid_ratio, int64_t mid_step, double *mid_out, const int64_t *mid_out_offsets) {
     if (!packed || !offsets) return fail(PAA_ERR_ARG, "null signal");
-    std::lock_guard<std::mutex> api_lock(g_api_mu);
+    { const int rc0 = ensure_init(); if (rc0) return rc0; }      // the lanes exist once a device is selected
+    LaneGuard lane;       // own stream + scratch for this call (see Lane)
     const bool want_mid = mid_out != nullptr;
     if (want_mid && !deltas) return fail(PAA_ERR_ARG, "mid-term features are defined over the 68 delta rows");
     if (want_mid && mid_step < 1)
@@ -977,43 +1025,43 @@ static int run_host_st(const void *packed, const int64_t *offsets, int64_t n_cli
     }
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        if ((rc = scratch_reserve(g_in, (size_t)n_total * esz + 64))) return rc;
-        if ((rc = scratch_reserve(g_out, (size_t)plan->out_doubles * 8))) return rc;
+        if ((rc = scratch_reserve(lane.l->in, (size_t)n_total * esz + 64))) return rc;
+        if ((rc = scratch_reserve(lane.l->out, (size_t)plan->out_doubles * 8))) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(g_in.p, (const char *)packed + (size_t)base * esz, (size_t)n_total * esz,
-                           hipMemcpyHostToDevice, g_stream));
-    const void *d_samples = g_in.p;
+    HIP_TRY(hipMemcpyAsync(lane.l->in.p, (const char *)packed + (size_t)base * esz, (size_t)n_total * esz,
+                           hipMemcpyHostToDevice, cs()));
+    const void *d_samples = lane.l->in.p;
     if (sample_kind == 2) {
         {
             std::lock_guard<std::mutex> lk(g_mu);
-            if ((rc = scratch_reserve(g_in2, (size_t)n_total * 4 + 64))) return rc;
+            if ((rc = scratch_reserve(lane.l->in2, (size_t)n_total * 4 + 64))) return rc;
         }
         const unsigned gs = (unsigned)std::min<long long>(4096, (n_total / 4 + 255) / 256 + 1);
-        hipLaunchKernelGGL(stereo_sum_kernel, dim3(gs), dim3(256), 0, g_stream, (const int16_t *)g_in.p, n_total,
-                           (int *)g_in2.p);
+        hipLaunchKernelGGL(stereo_sum_kernel, dim3(gs), dim3(256), 0, cs(), (const int16_t *)lane.l->in.p, n_total,
+                           (int *)lane.l->in2.p);
         HIP_TRY(hipGetLastError());
-        d_samples = g_in2.p;
+        d_samples = lane.l->in2.p;
     }
-    if ((rc = paa_plan_execute(plan, d_samples, (double *)g_out.p))) return rc;
+    if ((rc = paa_plan_execute(plan, d_samples, (double *)lane.l->out.p))) return rc;
     if (want_mid) {
         const long long md = paa_plan_mid_doubles(plan, mid_step);
         {
             std::lock_guard<std::mutex> lk(g_mu);
-            if ((rc = scratch_reserve(g_mid, (size_t)md * 8))) return rc;
+            if ((rc = scratch_reserve(lane.l->mid, (size_t)md * 8))) return rc;
         }
-        if ((rc = paa_plan_mid_execute(plan, (const double *)g_out.p, mid_ratio, mid_step, (double *)g_mid.p))) return rc;
+        if ((rc = paa_plan_mid_execute(plan, (const double *)lane.l->out.p, mid_ratio, mid_step, (double *)lane.l->mid.p))) return rc;
         // slabs are back to back in clip order on the device
         long long o = 0;
         for (int64_t c = 0; c < n_clips; ++c) {
             const long long cnt = 2LL * plan->P.F * paa_num_mid_windows(plan->clips[c].T, mid_step);
             double *dst = mid_out + (mid_out_offsets ? mid_out_offsets[c] : o);
-            HIP_TRY(hipMemcpyAsync(dst, (double *)g_mid.p + o, (size_t)cnt * 8, hipMemcpyDeviceToHost, g_stream));
+            HIP_TRY(hipMemcpyAsync(dst, (double *)lane.l->mid.p + o, (size_t)cnt * 8, hipMemcpyDeviceToHost, cs()));
             o += cnt;
         }
     }
     if (out) {
         if (!out_offsets) {
-            HIP_TRY(hipMemcpyAsync(out, g_out.p, (size_t)plan->out_doubles * 8, hipMemcpyDeviceToHost, g_stream));
+            HIP_TRY(hipMemcpyAsync(out, lane.l->out.p, (size_t)plan->out_doubles * 8, hipMemcpyDeviceToHost, cs()));
         } else {
             // coalesce runs of clips whose destination slabs are contiguous too
             int64_t c = 0;
@@ -1024,13 +1072,13 @@ static int run_host_st(const void *packed, const int64_t *offsets, int64_t n_cli
                     cnt = plan->clips[e].out_off - plan->clips[c].out_off + (long long)plan->P.F * plan->clips[e].T;
                     ++e;
                 }
-                HIP_TRY(hipMemcpyAsync(out + out_offsets[c], (double *)g_out.p + plan->clips[c].out_off,
-                                       (size_t)cnt * 8, hipMemcpyDeviceToHost, g_stream));
+                HIP_TRY(hipMemcpyAsync(out + out_offsets[c], (double *)lane.l->out.p + plan->clips[c].out_off,
+                                       (size_t)cnt * 8, hipMemcpyDeviceToHost, cs()));
                 c = e;
             }
         }
     }
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipStreamSynchronize(cs()));
     return PAA_OK;
 }
 
@@ -1090,7 +1138,8 @@ extern "C" int paa_mid_features_batch_i16(const int16_t *packed, const int64_t *
 static int run_host_spec(const void *signal, int64_t n, int sample_kind, double fs, int window, int step, int mode,
                          double *out) {
     if (!signal || !out) return fail(PAA_ERR_ARG, "null signal / out");
-    std::lock_guard<std::mutex> api_lock(g_api_mu);
+    { const int rc0 = ensure_init(); if (rc0) return rc0; }
+    LaneGuard lane;       // own stream + scratch for this call (see Lane)
     const int64_t off[2] = {0, n};
     paa_plan *plan = nullptr;
     int rc;
@@ -1103,12 +1152,12 @@ static int run_host_spec(const void *signal, int64_t n, int sample_kind, double 
     const size_t esz = sample_kind == 0 ? 2 : 8;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        if ((rc = scratch_reserve(g_in, (size_t)n * esz + 64))) return rc;
-        if ((rc = scratch_reserve(g_out, (size_t)plan->out_doubles * 8))) return rc;
+        if ((rc = scratch_reserve(lane.l->in, (size_t)n * esz + 64))) return rc;
+        if ((rc = scratch_reserve(lane.l->out, (size_t)plan->out_doubles * 8))) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(g_in.p, signal, (size_t)n * esz, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemsetAsync(g_out.p, 0, (size_t)plan->out_doubles * 8, g_stream));   // trailing rows stay 0 (:413-422)
-    if ((rc = paa_plan_execute(plan, g_in.p, (double *)g_out.p))) return rc;
+    HIP_TRY(hipMemcpyAsync(lane.l->in.p, signal, (size_t)n * esz, hipMemcpyHostToDevice, cs()));
+    HIP_TRY(hipMemsetAsync(lane.l->out.p, 0, (size_t)plan->out_doubles * 8, cs()));   // trailing rows stay 0 (:413-422)
+    if ((rc = paa_plan_execute(plan, lane.l->in.p, (double *)lane.l->out.p))) return rc;
     if (mode == 2) {
         // the reference FFTs a truncated last frame when fewer than `window` samples remain (:349-355)
         int64_t filled = 0;
@@ -1120,14 +1169,14 @@ static int run_host_spec(const void *signal, int64_t n, int sample_kind, double 
             if (last_len < window / 2)
                 return fail(PAA_ERR_CHROMA_VALUE, "truncated last chromagram frame shorter than num_fft "
                             "(ValueError in the reference, ShortTermFeatures.py:288)");
-            rc = launch_chroma_tail(plan->P, sample_kind, g_in.p, pos, n, (int)(filled - plan->clips[0].T), plan->d_norms,
-                                    (double *)g_out.p + (long long)plan->clips[0].T * 12, g_stream);
+            rc = launch_chroma_tail(plan->P, sample_kind, lane.l->in.p, pos, n, (int)(filled - plan->clips[0].T), plan->d_norms,
+                                    (double *)lane.l->out.p + (long long)plan->clips[0].T * 12, cs());
             if (rc == -2) return fail(PAA_ERR_UNSUPPORTED, "truncated chromagram tail frame with window %d does not fit LDS", window);
             if (rc) return fail(PAA_ERR_HIP, "chromagram tail launch failed");
         }
     }
-    HIP_TRY(hipMemcpyAsync(out, g_out.p, (size_t)plan->out_doubles * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpyAsync(out, lane.l->out.p, (size_t)plan->out_doubles * 8, hipMemcpyDeviceToHost, cs()));
+    HIP_TRY(hipStreamSynchronize(cs()));
     return PAA_OK;
 }
 
@@ -1156,28 +1205,28 @@ extern "C" int paa_svm_binary_proba_f64(const double *feats, int n_dims, int64_t
     if (!feats || !mean || !scale || !support_vectors || !dual_coef || !prob1) return fail(PAA_ERR_ARG, "null argument");
     if (n_dims < 1 || n_dims > kSvmMaxDims) return fail(PAA_ERR_ARG, "n_dims must be 1..%d", kSvmMaxDims);
     if (n_frames < 1 || n_sv < 1) return fail(PAA_ERR_ARG, "need at least one frame and one support vector");
-    std::lock_guard<std::mutex> api_lock(g_api_mu);
+    LaneGuard lane;       // own stream + scratch for this call (see Lane)
     const size_t fb = (size_t)n_dims * n_frames * 8, sb = (size_t)n_sv * n_dims * 8;
     const size_t small = (size_t)(2 * n_dims + n_sv) * 8 + sb;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        if ((rc = scratch_reserve(g_in, fb + 64))) return rc;
-        if ((rc = scratch_reserve(g_sim_small, small + 64))) return rc;
-        if ((rc = scratch_reserve(g_out, (size_t)n_frames * 8))) return rc;
+        if ((rc = scratch_reserve(lane.l->in, fb + 64))) return rc;
+        if ((rc = scratch_reserve(lane.l->mid, small + 64))) return rc;
+        if ((rc = scratch_reserve(lane.l->out, (size_t)n_frames * 8))) return rc;
     }
-    double *d_small = (double *)g_sim_small.p;
+    double *d_small = (double *)lane.l->mid.p;
     double *d_mean = d_small, *d_scale = d_small + n_dims, *d_coef = d_small + 2 * n_dims, *d_sv = d_coef + n_sv;
-    HIP_TRY(hipMemcpyAsync(g_in.p, feats, fb, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(d_mean, mean, (size_t)n_dims * 8, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(d_scale, scale, (size_t)n_dims * 8, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(d_coef, dual_coef, (size_t)n_sv * 8, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(d_sv, support_vectors, sb, hipMemcpyHostToDevice, g_stream));
-    hipLaunchKernelGGL(svm_binary_proba_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, g_stream,
-                       (const double *)g_in.p, n_dims, (long long)n_frames, (long long)n_frames, d_mean, d_scale, d_sv,
-                       d_coef, n_sv, intercept, gamma, prob_a, prob_b, (double *)g_out.p);
+    HIP_TRY(hipMemcpyAsync(lane.l->in.p, feats, fb, hipMemcpyHostToDevice, cs()));
+    HIP_TRY(hipMemcpyAsync(d_mean, mean, (size_t)n_dims * 8, hipMemcpyHostToDevice, cs()));
+    HIP_TRY(hipMemcpyAsync(d_scale, scale, (size_t)n_dims * 8, hipMemcpyHostToDevice, cs()));
+    HIP_TRY(hipMemcpyAsync(d_coef, dual_coef, (size_t)n_sv * 8, hipMemcpyHostToDevice, cs()));
+    HIP_TRY(hipMemcpyAsync(d_sv, support_vectors, sb, hipMemcpyHostToDevice, cs()));
+    hipLaunchKernelGGL(svm_binary_proba_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, cs(),
+                       (const double *)lane.l->in.p, n_dims, (long long)n_frames, (long long)n_frames, d_mean, d_scale, d_sv,
+                       d_coef, n_sv, intercept, gamma, prob_a, prob_b, (double *)lane.l->out.p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(prob1, g_out.p, (size_t)n_frames * 8, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpyAsync(prob1, lane.l->out.p, (size_t)n_frames * 8, hipMemcpyDeviceToHost, cs()));
+    HIP_TRY(hipStreamSynchronize(cs()));
     return PAA_OK;
 }
 
@@ -1196,7 +1245,7 @@ extern "C" int paa_debug_phase_cycles(uint64_t *out16) {
 #if defined(PAA_F800_TIMING) || defined(PAA_F800_TRACE)
     int rc = ensure_init();
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipStreamSynchronize(cs()));
     unsigned long long host[16];
     HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(f800::g_phase_cycles), sizeof(host)));
     for (int i = 0; i < 16; ++i) out16[i] = host[i];
@@ -1206,13 +1255,22 @@ extern "C" int paa_debug_phase_cycles(uint64_t *out16) {
     return PAA_OK;
 }
 
+// highest number of host-buffer calls that were in flight at the same time since the last query (lanes, see Lane);
+// resets the mark.  Lets a test show that calls from several threads really overlap.
+extern "C" int paa_debug_lane_peak(void) {
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    const int p = g_lanes_peak;
+    g_lanes_peak = g_lanes_active;
+    return p;
+}
+
 // per-wave trace of the last st_fast_800 launch (PAA_F800_TIMING builds): 4 words per run, up to 4096 runs
 extern "C" int paa_debug_wave_trace(uint64_t *out, int max_waves) {
     if (!out || max_waves < 1) return fail(PAA_ERR_ARG, "null");
 #if defined(PAA_F800_TIMING) || defined(PAA_F800_TRACE)
     int rc = ensure_init();
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipStreamSynchronize(cs()));
     const size_t n = (size_t)std::min(max_waves, 4096) * 4 * sizeof(unsigned long long);
     HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(f800::g_wave_trace), n));
     return std::min(max_waves, 4096);

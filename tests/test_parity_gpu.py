@@ -295,22 +295,43 @@ def test_big_window_spectrogram(gpu_lib, capsys):
 
 
 def test_concurrent_python_threads(gpu_lib):
-    """ctypes releases the GIL: host-buffer entry points must be safe to call from several threads."""
+    """ctypes releases the GIL: host-buffer entry points are safe to call from several threads, and the calls really
+    overlap on the device (each runs in its own lane: stream + scratch) instead of queueing behind one mutex."""
     import threading
-    clips = [synth_clip(900 + i, 16000 * (1 + i % 3)) for i in range(6)]
-    expect = [ShortTermFeatures.feature_extraction(c, 16000, 800, 400)[0] for c in clips]
+    clips = [synth_clip(900 + i, 16000 * 60 * (1 + i % 3)) for i in range(6)]
+    expect = [ShortTermFeatures.feature_extraction(c, 16000, 800, 400)[0].copy() for c in clips]
     got = [None] * len(clips)
+    gpu_lib.paa_debug_lane_peak()                       # reset the high-water mark
 
     def work(k):
-        for _ in range(5):
+        for _ in range(8):
             got[k] = ShortTermFeatures.feature_extraction(clips[k], 16000, 800, 400)[0]
     threads = [threading.Thread(target=work, args=(k,)) for k in range(len(clips))]
     for t in threads:
         t.start()
     for t in threads:
         t.join()
+    peak = gpu_lib.paa_debug_lane_peak()
     for e, g_ in zip(expect, got):
         assert np.array_equal(e, g_)
+    assert peak >= 2, "six threads never had two calls in flight at once (peak %d)" % peak
+
+
+def test_result_arrays_are_recycled_only_when_released(gpu_lib):
+    """Large results are views of pooled buffers (_ffi.result_array): a buffer comes back only after the caller dropped
+    every reference, so results a caller still holds never change under it."""
+    x = synth_clip(950, 16000 * 120)
+    a, _ = ShortTermFeatures.feature_extraction(x, 16000, 800, 400)
+    keep = a[:5].copy()
+    view = a[:5]
+    addr = a.__array_interface__["data"][0]
+    del a
+    b, _ = ShortTermFeatures.feature_extraction(synth_clip(951, 16000 * 120), 16000, 800, 400)
+    assert b.__array_interface__["data"][0] != addr          # `view` still points into the first buffer
+    assert np.array_equal(view, keep)
+    del view, b
+    c, _ = ShortTermFeatures.feature_extraction(x, 16000, 800, 400)
+    assert np.array_equal(c[:5], keep)
 
 
 def test_many_clip_batch_properties(gpu_lib):
