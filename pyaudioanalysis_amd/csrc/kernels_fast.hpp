@@ -290,6 +290,84 @@ __device__ unsigned long long g_wave_trace[4096 * 4];
 #define PAA_STEAL_COUNT()
 #endif
 
+// Row store, in whole 64-byte chunks of the row.  The rows of a [F][T] slab are only 8-byte aligned (T is odd in general)
+// and a wave produces four frames per row and iteration; stored as they come, the memory side sees partial-sector writes
+// (measured with rocprofv3 WRITE_SIZE: 2.3x the output bytes; 1.76x with 32-byte aligned groups, because the L2 -- under the
+// pressure of the sample stream -- evicts half-written 64-byte blocks; scripts/microbench/mb3.hip calibrates the counter and
+// shows that 64-byte aligned 64-byte groups cost 1.02x).  So every lane keeps its row's last seven values h[0..6] (frames
+// q0-7 .. q0-1; v[0..3] = the quad's frames q0 .. q0+3) and, once a chunk [g, g+8) with (row + g) 64-byte aligned is complete,
+// stores it as a whole: with a = alignment of frame q0 in doubles, the chunk is the window w[s .. s+7], s = 7 - a, complete
+// with this quad when s <= 3 -- half of the lanes store with every iteration.  Frames outside [lo, hi) belong to another wave
+// (or do not exist): the first chunk of a run and the tail after its last quad fall back to 8-byte stores.
+// (per-lane selects through v_cndmask on a ballot mask: written as `c ? w[j + 2] : w[j]` the optimiser recognises a
+// dynamically indexed array and moves it to scratch memory)
+__device__ __forceinline__ double sel64(unsigned long long take_a, double a, double b) {
+    int lo, hi;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(b)), "v"(__double2loint(a)), "s"(take_a));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(b)), "v"(__double2hiint(a)), "s"(take_a));
+    return __hiloint2double(hi, lo);
+}
+// the part [vlo, vhi) of one 64-byte aligned chunk, in the fewest naturally aligned pieces (32, 16, 8 bytes): a partial
+// store costs one 32-byte write request whatever its size (measured), so a chunk shared by two runs is written in 2..4
+// requests instead of 8
+__device__ __forceinline__ void store_chunk_pieces(double *dst, const double (&o)[8], int vlo, int vhi, int dbg = 0) {
+    if ((dbg & 4) && !(vlo <= 0 && vhi >= 8)) return;     // PAA_KERNEL_DEBUG bit 4: drop partial chunks, bit 8: drop whole ones
+    if ((dbg & 8) && (vlo <= 0 && vhi >= 8)) return;      // (traffic experiments only)
+    typedef double f64x4 __attribute__((ext_vector_type(4), aligned(32)));
+    typedef double f64x2 __attribute__((ext_vector_type(2), aligned(16)));
+    if (vlo <= 0 && vhi >= 8) {                           // the whole chunk: four 16-byte stores back to back
+        __builtin_nontemporal_store(f64x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f64x4 *>(dst));
+        __builtin_nontemporal_store(f64x4{o[4], o[5], o[6], o[7]}, reinterpret_cast<f64x4 *>(dst + 4));
+        return;
+    }
+#pragma unroll
+    for (int b4 = 0; b4 < 8; b4 += 4) {
+        if (vlo <= b4 && vhi >= b4 + 4) {
+            *reinterpret_cast<f64x4 *>(dst + b4) = f64x4{o[b4], o[b4 + 1], o[b4 + 2], o[b4 + 3]};
+        } else {
+#pragma unroll
+            for (int b2 = b4; b2 < b4 + 4; b2 += 2) {
+                if (vlo <= b2 && vhi >= b2 + 2) {
+                    *reinterpret_cast<f64x2 *>(dst + b2) = f64x2{o[b2], o[b2 + 1]};
+                } else {
+                    if (vlo <= b2 && vhi > b2) dst[b2] = o[b2];
+                    if (vlo <= b2 + 1 && vhi > b2 + 1) dst[b2 + 1] = o[b2 + 1];
+                }
+            }
+        }
+    }
+}
+__device__ __forceinline__ void store_row_chunked(double *row, int q0, int lo, int hi, bool last, const double (&h)[7],
+                                                  const double (&v)[4], int dbg) {
+    const double w[11] = {h[0], h[1], h[2], h[3], h[4], h[5], h[6], v[0], v[1], v[2], v[3]};      // w[j] = frame q0 - 7 + j
+    const int s = 7 - (int)(((reinterpret_cast<uintptr_t>(row) >> 3) + (unsigned)q0) & 7);
+    const bool emit = s <= 3;
+    {
+        const unsigned long long m1 = __builtin_amdgcn_ballot_w64((s & 2) != 0), m0 = __builtin_amdgcn_ballot_w64((s & 1) != 0);
+        double x[9], o[8];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) x[j] = sel64(m1, w[j + 2], w[j]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = sel64(m0, x[k + 1], x[k]);
+        const int g = q0 - 7 + s;
+        if (emit) store_chunk_pieces(row + g, o, lo - g, hi - g, dbg);
+    }
+    if (last) {                                           // the values still waiting for their chunk: w[ns ..], ns = 4 .. 11
+        const int ns = emit ? s + 8 : s, g = q0 - 7 + ns, u = ns - 4;
+        const unsigned long long m2 = __builtin_amdgcn_ballot_w64((u & 4) != 0), m1 = __builtin_amdgcn_ballot_w64((u & 2) != 0),
+                                 m0 = __builtin_amdgcn_ballot_w64((u & 1) != 0);
+        double z[7], y[7], o[8];                          // (indices past the window repeat w[10]: never stored, hi - g cuts them)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) z[j] = sel64(m2, w[(j + 8 > 10) ? 10 : j + 8], w[j + 4]);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) y[j] = sel64(m1, z[(j + 2 > 6) ? 6 : j + 2], z[j]);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) o[j] = sel64(m0, y[(j + 1 > 6) ? 6 : j + 1], y[j]);
+        o[7] = o[6];
+        store_chunk_pieces(row + g, o, lo - g, hi - g, dbg);
+    }
+}
+
 // FIXED = 1: the mel / chroma list lengths are the compile-time constants of the usual 16 kHz tables (8, 16, 16, 8,
 // no clamping), which turns the whole feature stage into straight-line code the scheduler can interleave;
 // FIXED = 0: run-time lengths from the layout (other sampling rates).
@@ -444,6 +522,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
     int q0 = r0 >= QUAD ? r0 - QUAD : 0;
     int slot0 = 2;                   // slots of a quad: slot0 .. slot0+3 (mod 5) after the rotation at the loop head; previous = slot0-1
     double vlast = 0.0;              // lane l < 34: feature l of the frame before this quad
+    double hold[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};    // ... and the row's last seven values / deltas, waiting for
+    double holdd[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // their 64-byte chunk (store_row_chunked)
     bool first_quad = true;          // the run's first iteration: the halo quad when r0 >= 4
     int n_done = 0;                  // quads of this run whose FFT stages are complete (pacing)
 
@@ -932,29 +1012,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
             double vq[QUAD];
 #pragma unroll
             for (int s = 0; s < QUAD; ++s) vq[s] = fv[FV_STRIDE * s + lane];
-            if (q0 >= r0 && q0 + QUAD <= t_end) {
-                // the whole quad belongs to this run (the usual case): one 32-byte store per row (the rows are only
-                // 8-byte aligned -- T is odd -- which global_store_dwordx4 does not mind)
-                typedef double f64x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
-                f64x4_a8 row = {vq[0], vq[1], vq[2], vq[3]};
-                *reinterpret_cast<f64x4_a8 *>(&oc[(long long)lane * Tc + q0]) = row;
-                if (DELTAS) {
-                    f64x4_a8 dl = {(q0 == 0) ? 0.0 : vq[0] - vlast, vq[1] - vq[0], vq[2] - vq[1], vq[3] - vq[2]};
-                    *reinterpret_cast<f64x4_a8 *>(&oc[(long long)(kBase + lane) * Tc + q0]) = dl;
-                }
-            } else {
+            const bool last_quad = q0 + QUAD >= t_end;
+            store_row_chunked(oc + (long long)lane * Tc, q0, r0, t_end, last_quad, hold, vq, P.debug);
+            if (DELTAS) {
+                const double dq[QUAD] = {(q0 == 0) ? 0.0 : vq[0] - vlast, vq[1] - vq[0], vq[2] - vq[1], vq[3] - vq[2]};
+                store_row_chunked(oc + (long long)(kBase + lane) * Tc, q0, r0, t_end, last_quad, holdd, dq, P.debug);
 #pragma unroll
-                for (int s = 0; s < QUAD; ++s) {
-                    const int ts = q0 + s;
-                    if (ts >= r0 && ts < t_end) {
-                        oc[(long long)lane * Tc + ts] = vq[s];
-                        if (DELTAS) {
-                            const double pv = (s == 0) ? vlast : vq[s - 1];
-                            oc[(long long)(kBase + lane) * Tc + ts] = (ts == 0) ? 0.0 : vq[s] - pv;
-                        }
-                    }
-                }
+                for (int j = 0; j < 7; ++j) holdd[j] = (j < 3) ? holdd[j + 4] : dq[j - 3];
             }
+#pragma unroll
+            for (int j = 0; j < 7; ++j) hold[j] = (j < 3) ? hold[j + 4] : vq[j - 3];
             vlast = vq[QUAD - 1];
         }
         wsync();
