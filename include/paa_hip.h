@@ -167,7 +167,9 @@ int paa_dev_self_similarity(const double *d_feats, int n_dims, int64_t n_vec, in
 int64_t paa_thumbnail_rows(int64_t n_vec, int m_filter);
 int paa_thumbnail_f64(const double *feats, int n_dims, int64_t n_vec, int m_filter, double band, double limit_1,
                       double limit_2, double *filt, int64_t *pos2);
-/* device buffers in and out; synchronises the library stream before returning pos2             */
+/* device buffers in and out; synchronises the library stream before returning pos2.  d_sim must be symmetric bit for
+ * bit, as paa_dev_self_similarity writes it: the diagonal sums are formed for j >= i only (the cells below the
+ * diagonal are masked, and the minimum over one triangle is the minimum over the matrix)       */
 int paa_dev_thumbnail_filter(const double *d_sim, int64_t n_vec, int m_filter, double band, double limit_1,
                              double limit_2, double *d_filt, int64_t *pos2);
 

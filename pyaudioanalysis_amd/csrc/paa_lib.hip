@@ -712,14 +712,16 @@ extern "C" int paa_dev_self_similarity(const double *d_feats, int n_dims, int64_
                        n_dims, dims_pad, (long long)n_vec, (long long)ld, ldz, d_mean, d_scale, (double *)g_sim_z.p,
                        d_norm);
     const unsigned tiles = (unsigned)(ldz / kSimTile);
-    const size_t lds = (size_t)2 * kSimChunk * kSimPitch * 8;
+    const size_t lds = (size_t)2 * kSimChunk * kSimPitch * 8 + 256 * 8;
     static bool attr_done = false;
     if (!attr_done) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sim_gram_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(sim_gram_kernel, dim3((unsigned)std::min<long long>((long long)tiles * tiles, 2LL * g_num_cu)), dim3(512), lds, cs(), (const double *)g_sim_z.p, dims_pad,
+    const long long n_tri = (long long)tiles * (tiles + 1) / 2;        // tiles on and above the diagonal; the rest are mirrored
+    const dim3 gram_grid((unsigned)std::min<long long>(n_tri, 2LL * g_num_cu));
+    hipLaunchKernelGGL(sim_gram_kernel, gram_grid, dim3(512), lds, cs(), (const double *)g_sim_z.p, dims_pad,
                        (long long)n_vec, ldz, d_norm, d_sim);
     HIP_TRY(hipGetLastError());
     return PAA_OK;
@@ -737,23 +739,24 @@ extern "C" int paa_dev_thumbnail_filter(const double *d_sim, int64_t n_vec, int 
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g_sim_mu);
     const long long lim_lo = (long long)(limit_1 * (double)R), lim_hi = (long long)(limit_2 * (double)R);   // int(), :1157-1160
-    const unsigned gx = (unsigned)((R + kDiagRun - 1 + 255) / 256), gy = (unsigned)((R + kDiagRun - 1) / kDiagRun);
+    // thumb_diag: block (bx, by) = diagonal offsets 256 bx .. of rows kDiagRun by ..; offsets past R - i0 exit at once
+    const unsigned gx = (unsigned)((R + 255) / 256), gy = (unsigned)((R + kDiagRun - 1) / kDiagRun);
     const unsigned mx = (unsigned)((R + 1023) / 1024), my = (unsigned)((R + kMaskRows - 1) / kMaskRows);
-    if (my > 65535u) return fail(PAA_ERR_UNSUPPORTED, "%lld rows: thumbnail matrix too large", R);
-    const long long n_min = (long long)gx * gy, n_cand = (long long)mx * my;
+    if (my > 65535u || gy > 65535u) return fail(PAA_ERR_UNSUPPORTED, "%lld rows: thumbnail matrix too large", R);
+    const long long n_blk = (long long)gx * gy;
     {
         std::lock_guard<std::mutex> lk2(g_mu);
-        if ((rc = scratch_reserve(g_sim_cand, (size_t)(n_min + 2 * n_cand + 4) * 8))) return rc;
+        if ((rc = scratch_reserve(g_sim_cand, (size_t)(3 * n_blk + 4) * 8))) return rc;
     }
-    double *d_min = (double *)g_sim_cand.p, *d_cval = d_min + n_min + 1;
-    long long *d_cidx = (long long *)(d_cval + n_cand), *d_best = d_cidx + n_cand;
-    hipLaunchKernelGGL(thumb_diag_kernel, dim3(gx, gy), dim3(256), 0, cs(), d_sim, (long long)n_vec, m_filter, R,
-                       d_filt, d_min);
-    hipLaunchKernelGGL(thumb_min_kernel, dim3(1), dim3(1024), 0, cs(), (const double *)d_min, n_min, d_min + n_min);
-    hipLaunchKernelGGL(thumb_mask_kernel, dim3(mx, my), dim3(256), 0, cs(), d_filt, R, band, lim_lo, lim_hi,
-                       (const double *)(d_min + n_min), d_cval, d_cidx);
+    double *d_min = (double *)g_sim_cand.p, *d_cval = d_min + n_blk + 1;
+    long long *d_cidx = (long long *)(d_cval + n_blk), *d_best = d_cidx + n_blk;
+    hipLaunchKernelGGL(thumb_diag_kernel, dim3(gx, gy), dim3(256), 0, cs(), d_sim, (long long)n_vec, m_filter, R, band,
+                       lim_lo, lim_hi, d_filt, d_min, d_cval, d_cidx);
+    hipLaunchKernelGGL(thumb_min_kernel, dim3(1), dim3(1024), 0, cs(), (const double *)d_min, n_blk, d_min + n_blk);
+    hipLaunchKernelGGL(thumb_fill_kernel, dim3(mx, my), dim3(256), 0, cs(), d_filt, R, band, lim_lo, lim_hi,
+                       (const double *)(d_min + n_blk));
     hipLaunchKernelGGL(thumb_argmax_kernel, dim3(1), dim3(1024), 0, cs(), (const double *)d_cval,
-                       (const long long *)d_cidx, n_cand, d_best);
+                       (const long long *)d_cidx, n_blk, (const double *)(d_min + n_blk), R, band, lim_lo, lim_hi, d_best);
     HIP_TRY(hipGetLastError());
     long long best = 0;
     HIP_TRY(hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, cs()));
