@@ -557,7 +557,9 @@ __global__ __launch_bounds__(384) void st_reg_kernel(PlanDev P, RegLayout L, con
             const double *prv = slots + ((slot0 + f + Q) % (Q + 1)) * NFP;
             if (P.mode == 1) {            // spectrogram row (ShortTermFeatures.py:422)
                 double *row = oc + (long long)t * NF;
-                for (int k = lane_o; k < NF; k += kWave) row[k] = cur[k];
+                // (write-once stream of 4.4 KB rows that are only 8-byte aligned: non-temporal stores keep the L2 from
+                // writing half-filled lines twice; measured +15 % on float64 input, neutral on int16)
+                for (int k = lane_o; k < NF; k += kWave) __builtin_nontemporal_store(cur[k], row + k);
             } else if (P.mode == 2) {     // chromagram row (:356-359)
                 double p = 0.0;
                 for (int k = lane_o; k < NF; k += kWave) { const double X = cur[k]; p = fma(X, X, p); }
