@@ -5,6 +5,7 @@ Around it, the host-side callers of SURVEY 8f-1/2: beat_extraction (:18-84, a se
 18 short-term rows -- host NumPy) and the directory walkers (:140-309), which read the files on the host
 and push every int16 mono file of one sampling rate through ONE batched GPU call.
 """
+import concurrent.futures
 import glob
 import os
 import time
@@ -168,6 +169,26 @@ def beat_extraction(short_features, window_size, plot=False):
 # ---------------------------------------------------------------------------------------------------------
 # directory walkers (reference :140-309)
 # ---------------------------------------------------------------------------------------------------------
+def _read_for_device(file_path):
+    """(sampling_rate, signal) of one file; int16 stereo stays interleaved (it is reduced to mono on the device),
+    everything else goes through audioBasicIO.stereo_to_mono as in the reference (:182-184)."""
+    sampling_rate, signal = audioBasicIO.read_audio_file(file_path)
+    if sampling_rate > 0 and not (signal.ndim == 2 and signal.shape[1] == 2 and signal.dtype == np.int16):
+        signal = audioBasicIO.stereo_to_mono(signal)
+    return sampling_rate, signal
+
+
+def _read_all(paths):
+    """Decode the files on a few host threads (file I/O and sample conversion release the GIL); results keep the
+    order of `paths`, an exception of a reader surfaces when its result is taken."""
+    if len(paths) < 2:
+        return [(lambda p=p: _read_for_device(p)) for p in paths]
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(paths)))
+    futures = [pool.submit(_read_for_device, p) for p in paths]
+    pool.shutdown(wait=False)
+    return [f.result for f in futures]
+
+
 def _list_audio(folder_path, types):
     files = []
     for pattern in types:
@@ -179,12 +200,20 @@ def mid_and_beat_batch(signals, sampling_rate, mid_window, mid_step, short_windo
                        beat_window_seconds=None):
     """Device-resident batch: int16 clips -> list of (136, M_c) mid-term matrices and, when beat_window_seconds
     is given, an (n_clips, 2) array of (bpm, confidence) from the GPU beat kernel.  The short-term matrices
-    never leave HBM."""
+    never leave HBM.  The clips are either all mono (1-D int16) or all interleaved stereo ((n, 2) int16): stereo
+    clips are uploaded as the exact int32 sums L + R (4 B/sample) and scaled by 2^-16 on the device, which is
+    audioBasicIO.stereo_to_mono (audioBasicIO.py:156-168) followed by the 2^-15 scaling of :568."""
     ratio, step_ratio = _ratios(mid_window, mid_step, short_window, short_step)
     if step_ratio < 1:
         raise ValueError("mid_step / short_step rounds to 0: the reference never terminates")
     window, step = int(short_window), int(short_step)
-    clips = [np.ascontiguousarray(s, dtype=np.int16) for s in signals]
+    stereo = len(signals) > 0 and np.asarray(signals[0]).ndim == 2
+    if any((np.asarray(s).ndim == 2) != stereo for s in signals):
+        raise ValueError("mono and stereo clips cannot share a batch")
+    if stereo:
+        clips = [np.asarray(s)[:, 0].astype(np.int32) + np.asarray(s)[:, 1] for s in signals]
+    else:
+        clips = [np.ascontiguousarray(s, dtype=np.int16) for s in signals]
     lib = _ffi.lib()
     lens = np.array([c.shape[0] for c in clips], dtype=np.int64)
     if np.any(lens < window):
@@ -195,7 +224,7 @@ def mid_and_beat_batch(signals, sampling_rate, mid_window, mid_step, short_windo
     T = (lens - window) // step + 1
     M = -(-T // step_ratio)
     d_in = _ffi.DeviceBuffer.from_host(np.concatenate(clips) if len(clips) > 1 else clips[0])
-    plan = _ffi.Plan(offsets, sampling_rate, window, step, deltas=True, sample_kind=0)
+    plan = _ffi.Plan(offsets, sampling_rate, window, step, deltas=True, sample_kind=2 if stereo else 0)
     d_st = _ffi.DeviceBuffer(plan.out_doubles * 8)
     plan.execute(d_in, d_st)
     n_mid = plan.mid_doubles(step_ratio)
@@ -217,20 +246,22 @@ def mid_and_beat_batch(signals, sampling_rate, mid_window, mid_step, short_windo
 
 
 def _mid_for_files(entries, mid_window, mid_step, short_window, short_step, want_short):
-    """entries: list of (sampling_rate, mono signal).  int16 clips that share a sampling rate go through ONE
-    batched launch; float64 clips (stereo -> mono) take the single-clip float path.  Returns per-entry
+    """entries: list of (sampling_rate, signal).  int16 clips that share a sampling rate and a channel layout (mono,
+    or interleaved stereo as read from the file) go through ONE batched launch each; anything else (float64 signals,
+    more than two channels already reduced to mono) takes the single-clip path.  Returns per-entry
     (mid [136 x M], short [68 x T] or None, names)."""
     out = [None] * len(entries)
     names = _mid_names(ShortTermFeatures._feature_names(True))
     groups = {}
     for idx, (fs, sig) in enumerate(entries):
-        if np.asarray(sig).dtype == np.int16 and np.asarray(sig).ndim == 1:
-            groups.setdefault(fs, []).append(idx)
+        a = np.asarray(sig)
+        if a.dtype == np.int16 and (a.ndim == 1 or (a.ndim == 2 and a.shape[1] == 2)):
+            groups.setdefault((fs, a.ndim), []).append(idx)
         else:
             mid, st, _ = mid_feature_extraction(sig, fs, round(mid_window * fs), round(mid_step * fs),
                                                 round(fs * short_window), round(fs * short_step))
             out[idx] = (mid, st if want_short else None)
-    for fs, members in groups.items():
+    for (fs, _), members in groups.items():
         # want_short here means "the caller needs the beat": computed on the GPU from the resident short-term
         # matrix, returned in place of the matrix as a (bpm, confidence) pair
         mids, beats = mid_and_beat_batch([entries[i][1] for i in members], fs, round(mid_window * fs),
@@ -251,16 +282,16 @@ def directory_feature_extraction(folder_path, mid_window, mid_step, short_window
     wav_file_list = _list_audio(folder_path, ('*.wav', '*.aif', '*.aiff', '*.mp3', '*.au', '*.ogg'))
     kept, entries = [], []
     t_start = time.time()
+    non_empty = [p for p in wav_file_list if os.stat(p).st_size > 0]
+    readers = dict(zip(non_empty, _read_all(non_empty)))
     for i, file_path in enumerate(wav_file_list):
         print("Analyzing file {0:d} of {1:d}: {2:s}".format(i + 1, len(wav_file_list), file_path))
-        if os.stat(file_path).st_size == 0:
+        if file_path not in readers:
             print("   (EMPTY FILE -- SKIPPING)")
             continue
-        sampling_rate, signal = audioBasicIO.read_audio_file(file_path)
+        sampling_rate, signal = readers[file_path]()
         if sampling_rate <= 0:
             continue
-        if not (signal.ndim == 2 and signal.shape[1] == 2 and signal.dtype == np.int16):
-            signal = audioBasicIO.stereo_to_mono(signal)      # int16 stereo is reduced to mono on the device
         if signal.shape[0] < float(sampling_rate) / 5:
             print("  (AUDIO FILE TOO SMALL - SKIPPING)")
             continue
@@ -314,11 +345,11 @@ def directory_feature_extraction_no_avg(folder_path, mid_window, mid_step, short
     RETURNS (X [sum_M x 136], file index of every row, file list)"""
     wav_file_list = _list_audio(folder_path, ('*.wav', '*.aif', '*.aiff', '*.ogg'))
     entries, index = [], []
-    for i, file_path in enumerate(wav_file_list):
-        sampling_rate, signal = audioBasicIO.read_audio_file(file_path)
+    for i, (file_path, reader) in enumerate(zip(wav_file_list, _read_all(wav_file_list))):
+        sampling_rate, signal = reader()
         if sampling_rate <= 0:
             continue
-        entries.append((sampling_rate, audioBasicIO.stereo_to_mono(signal)))
+        entries.append((sampling_rate, signal))
         index.append(i)
     mid_features = np.array([])
     signal_idx = np.array([])

@@ -673,6 +673,8 @@ extern "C" int paa_plan_beat_execute(paa_plan_t *plan, const double *d_st, doubl
     if (max_beat < 1 || max_beat > 4096) return fail(PAA_ERR_UNSUPPORTED, "beat histogram of %d bins", max_beat);
     std::lock_guard<std::mutex> lk(g_mu);
     const size_t lds = (size_t)kBeatRows * (kBeatTile + 1) * 8 + (size_t)kBeatRows * max_beat * 4;
+    if (lds > 160 * 1024)
+        return fail(PAA_ERR_UNSUPPORTED, "beat histogram of %d bins needs %zu bytes of LDS (160 KB per workgroup)", max_beat, lds);
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&beat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(beat_kernel, dim3((unsigned)plan->n_clips), dim3(64), lds, cs(), plan->d_clips, d_st,

@@ -99,3 +99,22 @@ def test_mid_feature_extraction_to_file(gpu_lib, tmp_path):
     assert O.mixed_tolerance_violations(mt, ref_mid)[0] == 0 and O.mixed_tolerance_violations(st, ref_st)[0] == 0
     csv = np.loadtxt(base + "_mt.csv", delimiter=",")
     assert csv.shape == mt.T.shape and np.allclose(csv, mt.T, rtol=1e-12, atol=0)
+
+
+@pytest.mark.gpu
+def test_stereo_batch_equals_single_clips(gpu_lib):
+    """Interleaved int16 stereo clips in one batch (int32 sums L + R, sample kind 2) == the single-clip fused
+    stereo path == the float64 stereo_to_mono signal through the oracle."""
+    from pyaudioanalysis_amd import audioBasicIO
+    from synth import synth_clip
+    clips = [np.stack([synth_clip(300 + k, n), synth_clip(400 + k, n)], axis=1) for k, n in enumerate([32000, 9000, 20000])]
+    with pytest.raises(ValueError):
+        MidTermFeatures.mid_and_beat_batch([clips[0], clips[1][:, 0]], 16000, 16000, 16000, 800, 400)
+    mids, beats = MidTermFeatures.mid_and_beat_batch(clips, 16000, 16000, 16000, 800, 400, beat_window_seconds=0.025)
+    assert beats.shape == (3, 2)
+    for c, m in zip(clips, mids):
+        single, st, _ = MidTermFeatures.mid_feature_extraction(c, 16000, 16000, 16000, 800, 400)
+        assert np.array_equal(m, single)
+        mono = audioBasicIO.stereo_to_mono(c)
+        ref_mid, _, _ = O.mid_feature_extraction(mono, 16000, 16000, 16000, 800, 400)
+        assert O.mixed_tolerance_violations(m, ref_mid)[0] == 0
