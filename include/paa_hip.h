@@ -61,9 +61,11 @@ int  paa_dev_sync(void);
 int  paa_timer_start(void);
 int  paa_timer_stop(float *ms);
 
-/* per-launch HIP-event timing of the feature kernel inside paa_plan_execute (off by default);
- * paa_prof_read returns the accumulated milliseconds / launch count and resets them            */
-int  paa_prof_enable(int on);
+/* HIP-event timing of the feature kernel inside paa_plan_execute (off by default): every_nth = 1 brackets every
+ * launch with an event pair, n > 1 every n-th one (an event pair is an ordering point on the stream, so the
+ * recorder itself slows a stream of back-to-back launches by ~4 % at n = 1), 0 switches it off;
+ * paa_prof_read returns the accumulated milliseconds / number of timed launches and resets them */
+int  paa_prof_enable(int every_nth);
 int  paa_prof_read(double *total_ms, int64_t *launches);
 
 /* ---- shape helpers ----------------------------------------------------------------------- */

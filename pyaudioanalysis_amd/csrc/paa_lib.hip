@@ -125,7 +125,8 @@ static int g_force_generic = 0;
 static int g_f800_waves = 8;          // PAA_F800_WAVES: waves per workgroup of the 800/400 kernel (4 or 8)
 static int g_num_cu = 256;       // multiProcessorCount of the selected device (MI355X: 256)
 // optional per-launch timing of the feature kernel (bench.py's roofline leg)
-static int g_prof = 0;
+static int g_prof = 0;              // 0 = off, n = every n-th feature-kernel launch is bracketed by an event pair
+static long long g_prof_seen = 0;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev;
 static size_t g_prof_used = 0;
 static double g_prof_ms = 0.0;
@@ -562,7 +563,7 @@ extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *
              : plan->sample_kind == 2 ? run_big<int>(plan, d_packed, d_out) : run_big<double>(plan, d_packed, d_out);
     if (plan->n_tiles == 0) return PAA_OK;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
-    if (g_prof) {
+    if (g_prof && (g_prof_seen++ % g_prof) == 0) {
         if (g_prof_used == g_prof_ev.size()) {
             hipEvent_t a, b;
             HIP_TRY(hipEventCreate(&a));
@@ -931,7 +932,8 @@ extern "C" int paa_timer_stop(float *ms) {
 
 extern "C" int paa_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
-    g_prof = on ? 1 : 0;
+    g_prof = on > 0 ? on : 0;
+    g_prof_seen = 0;
     return PAA_OK;
 }
 // folds every recorded launch into (total ms, launches) and resets the recorder
