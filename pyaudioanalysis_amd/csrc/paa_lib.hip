@@ -219,6 +219,36 @@ static int get_tables(double fs, int window, bool need_mel, bool need_chroma, Ta
 // ------------------------------------------------------------------------------------------
 constexpr int kStatChunk = 65536;
 
+// Run length for the one-wave-per-run kernels.  A clip of T frames is cut into k = ceil(T / cap) runs of
+// len = ceil(T / k) frames rounded up to the kernel's quantum (so no clip ends in a short leftover run); a workgroup takes
+// wg_runs consecutive runs and the chip holds num_cu workgroups at a time, so a launch lasts about
+// ceil(workgroups / num_cu) rounds of (longest run + halo) frames.  The cap that minimises that estimate is returned:
+// one 1-hour clip -> 2000 runs of 72 frames (one round); 12 500 clips of 399 frames -> two runs of 200 per clip instead
+// of 244 + 155 (the short run's wave idled for a third of its workgroup's life); 1000 clips of 1199 frames -> 6 x 200.
+static int choose_run_cap(const std::vector<ClipDev> &clips, int quantum, int min_run, int max_run, int halo, int wg_runs,
+                          int num_cu) {
+    std::map<long long, long long> hist;                       // frames per clip -> number of such clips
+    for (const ClipDev &c : clips)
+        if (c.T > 0) ++hist[c.T];
+    if (hist.empty()) return max_run;
+    long long best_cost = -1;
+    int best = max_run;
+    for (int cap = max_run / quantum * quantum; cap >= min_run; cap -= quantum) {
+        long long runs = 0, longest = 0;
+        for (const auto &kv : hist) {
+            const long long k = (kv.first + cap - 1) / cap;
+            const long long len = ((kv.first + k - 1) / k + quantum - 1) / quantum * quantum;
+            runs += kv.second * ((kv.first + len - 1) / len);
+            longest = std::max(longest, len);
+        }
+        const long long wgs = (runs + wg_runs - 1) / wg_runs;
+        const long long rounds = (wgs + num_cu - 1) / num_cu;
+        const long long cost = rounds * (longest + halo);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cap; }     // ties: the longer run (fewer halos)
+    }
+    return best;
+}
+
 struct paa_plan {
     long long n_clips = 0;
     int sample_kind = 0;
@@ -348,7 +378,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         if (rc < 0) return fail(rc, "building the tables of the specialised kernel failed");
         p->fast = rc;
     }
-    int run;
+    int run, run_quantum = 4;
     if (!p->fast && !g_force_generic && tab->fft.even && reg::reg_supported(window)) {
         // windows 2 R1 R2 with coprime primes (config 5: 1102): several frames per wave, prime-factor FFT in registers
         using SH = reg::Shape1102;
@@ -362,21 +392,15 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     }
     if (p->reg) {
         p->lds = (size_t)p->rl.table_bytes + (size_t)p->rl.waves * p->rl.wave_bytes;
-        // about two chip-wide rounds of (CUs x waves per workgroup); runs are multiples of Q frames (halo = one iteration)
-        const long long slots = (long long)g_num_cu * p->rl.waves * 2;
-        const long long per = (total_frames + slots - 1) / slots;
+        // runs are multiples of Q frames (halo = one iteration); see choose_run_cap
         const int q = reg::Shape1102::Q;
-        run = (int)std::min<long long>(32 * q, std::max<long long>(4 * q, (per + q - 1) / q * q));
+        run_quantum = q;
+        run = choose_run_cap(p->clips, q, 4 * q, 32 * q, q, p->rl.waves, g_num_cu);
         p->kernel_name = (mode == 0) ? "st_reg_29x19" : (mode == 1 ? "spectrogram_reg_29x19" : "chromagram_reg_29x19");
     } else if (p->fast) {
-        // one wave per run; size the runs so that the launch is close to a whole number of chip-wide
-        // rounds (256 CUs x resident waves), in multiples of the 4-frame quad, at most fl.run frames
-        const long long slots = (long long)g_num_cu * p->fl.waves_per_cu;
-        const long long per = (total_frames + slots - 1) / slots;
-        const long long rounds = (per + p->fl.run - 1) / p->fl.run;     // fl.run = longest run worth one wave
-        long long r = (per + std::max<long long>(rounds, 1) - 1) / std::max<long long>(rounds, 1);
-        r = ((r + 3) / 4) * 4;
-        run = (int)std::min<long long>(p->fl.run, std::max<long long>(16, r));
+        // one wave per run, in multiples of the 4-frame quad, at most fl.run frames (halo = one quad); see choose_run_cap
+        run_quantum = 4;
+        run = choose_run_cap(p->clips, 4, 16, p->fl.run, 4, p->fl.waves_per_cu, g_num_cu);
         p->lds = p->fl.lds;
         p->kernel_name = p->fl.name;
     } else {
@@ -400,11 +424,17 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     }
     std::vector<Tile> tiles;
     tiles.reserve((size_t)(total_frames / run + n_clips));
-    for (int64_t c = 0; c < n_clips; ++c)
-        for (int t0 = 0; t0 < p->clips[c].T; t0 += run) {
-            Tile tl; tl.clip = (int)c; tl.t0 = t0; tl.cnt = std::min(run, p->clips[c].T - t0); tl.pad = 0;
+    for (int64_t c = 0; c < n_clips; ++c) {
+        const long long T = p->clips[c].T;
+        if (T <= 0) continue;
+        // equal runs per clip: k = ceil(T / run) runs of ceil(T / k) frames, rounded up to the kernel's quantum
+        const long long k = (T + run - 1) / run;
+        const int len = (int)(((T + k - 1) / k + run_quantum - 1) / run_quantum * run_quantum);
+        for (long long t0 = 0; t0 < T; t0 += len) {
+            Tile tl; tl.clip = (int)c; tl.t0 = (int)t0; tl.cnt = (int)std::min<long long>(len, T - t0); tl.pad = 0;
             tiles.push_back(tl);
         }
+    }
     p->n_tiles = (long long)tiles.size();
     if (p->n_tiles > 0x7fffffffLL || n_chunks > 0x7fffffffLL || n_clips > 0x7fffffffLL)
         return fail(PAA_ERR_UNSUPPORTED, "batch too large for one launch (%lld runs, %lld statistics chunks, %lld clips)",
