@@ -220,13 +220,27 @@ __global__ __launch_bounds__(256) void mid_stats_kernel(const ClipDev *__restric
     long long e = b + ratio;
     if (e > T) e = T;
     if (!live) e = b;
-    double s = 0.0;
-    for (long long k = b + i; k < e; k += 16) s += x[k];
-    s = group_sum(s);
+    double s = 0.0, v = 0.0;
     const double n = (double)(e - b);
-    const double mean = s / n;
-    double v = 0.0;
-    for (long long k = b + i; k < e; k += 16) { const double d = x[k] - mean; v = fma(d, d, v); }
+    double mean;
+    if (ratio <= 64) {
+        // the usual shapes (40 or 20 frames per mid-term window): the lane's <= 4 values are loaded once, all at once, and
+        // serve both passes from registers (same operations in the same order as the general loop below)
+        double xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = (b + i + 16 * j < e) ? x[b + i + 16 * j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (b + i + 16 * j < e) s += xv[j];
+        s = group_sum(s);
+        mean = s / n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (b + i + 16 * j < e) { const double d = xv[j] - mean; v = fma(d, d, v); }
+    } else {
+        for (long long k = b + i; k < e; k += 16) s += x[k];
+        s = group_sum(s);
+        mean = s / n;
+        for (long long k = b + i; k < e; k += 16) { const double d = x[k] - mean; v = fma(d, d, v); }
+    }
     v = group_sum(v);
     if (live && i == 0) {
         double *o = mid + mid_off[c];
