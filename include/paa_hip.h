@@ -207,6 +207,11 @@ int paa_debug_lane_peak(void);     /* most host-buffer calls in flight at once s
 int paa_debug_phase_cycles(uint64_t *out16);
 /* radix plan chosen for a window: returns number of passes, fills radices (capacity 32)      */
 int paa_debug_fft_plan(int window, int32_t *radices, int32_t *fft_len);
+/* the run-length choice of paa_plan_create for clips of frames[c] frames (host only): runs are multiples of `quantum`
+ * frames within [min_run, max_run], cost `halo` extra frames each, a workgroup takes wg_runs of them and num_cu
+ * workgroups run at a time.  Returns the cap, the number of runs and the longest run          */
+int paa_debug_run_plan(const int64_t *frames, int64_t n_clips, int quantum, int min_run, int max_run, int halo, int wg_runs,
+                       int num_cu, int32_t *run_cap, int64_t *n_runs, int32_t *longest);
 
 #ifdef __cplusplus
 }

@@ -97,12 +97,16 @@ _SIGNATURES = {
     "paa_debug_wave_trace": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
     "paa_debug_lane_peak": (C.c_int, []),
     "paa_debug_fft_plan": (C.c_int, [C.c_int, c_i32p, c_i32p]),
+    "paa_debug_run_plan": (C.c_int, [c_i64p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p,
+                                     c_i64p, c_i32p]),
 }
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
 
 
 def library_path():
-    return _build.LIB
+    """The in-tree library; PAA_HIP_LIBRARY names another build of the same sources (the sanitizer build of
+    tests/test_sanitizer_cpu.py), which is then loaded as is."""
+    return os.environ.get("PAA_HIP_LIBRARY") or _build.LIB
 
 
 def lib():
@@ -112,7 +116,7 @@ def lib():
         if _lib is not None:
             return _lib
         path = library_path()
-        if _build.is_stale():
+        if path == _build.LIB and _build.is_stale():
             try:
                 _build.hipcc_path()
             except RuntimeError as exc:       # no hipcc on this host: only a prebuilt library can serve

@@ -248,6 +248,11 @@ static int choose_run_cap(const std::vector<ClipDev> &clips, int quantum, int mi
     }
     return best;
 }
+// the runs of one clip of T frames under a cap: k = ceil(T / cap) runs of ceil(T / k) frames, rounded up to the quantum
+static inline int clip_run_length(long long T, int cap, int quantum) {
+    const long long k = (T + cap - 1) / cap;
+    return (int)(((T + k - 1) / k + quantum - 1) / quantum * quantum);
+}
 
 struct paa_plan {
     long long n_clips = 0;
@@ -427,9 +432,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     for (int64_t c = 0; c < n_clips; ++c) {
         const long long T = p->clips[c].T;
         if (T <= 0) continue;
-        // equal runs per clip: k = ceil(T / run) runs of ceil(T / k) frames, rounded up to the kernel's quantum
-        const long long k = (T + run - 1) / run;
-        const int len = (int)(((T + k - 1) / k + run_quantum - 1) / run_quantum * run_quantum);
+        const int len = clip_run_length(T, run, run_quantum);          // equal runs per clip
         for (long long t0 = 0; t0 < T; t0 += len) {
             Tile tl; tl.clip = (int)c; tl.t0 = (int)t0; tl.cnt = (int)std::min<long long>(len, T - t0); tl.pad = 0;
             tiles.push_back(tl);
@@ -1339,6 +1342,25 @@ extern "C" int paa_debug_chroma(double fs, int num_fft, int capacity, int32_t *s
     if (n > capacity) return fail(PAA_ERR_ARG, "capacity %d < %d entries", capacity, n);
     for (int i = 0; i < n; ++i) { src[i] = t.flat_src[i]; weight[i] = t.flat_w[i]; slot[i] = t.flat_slot[i]; }
     return n;
+}
+extern "C" int paa_debug_run_plan(const int64_t *frames, int64_t n_clips, int quantum, int min_run, int max_run, int halo,
+                                  int wg_runs, int num_cu, int32_t *run_cap, int64_t *n_runs, int32_t *longest) {
+    if (!frames || n_clips < 0 || quantum < 1 || min_run < quantum || max_run < min_run || halo < 0 || wg_runs < 1 ||
+        num_cu < 1 || !run_cap || !n_runs || !longest)
+        return fail(PAA_ERR_ARG, "bad argument");
+    std::vector<ClipDev> clips((size_t)n_clips);
+    for (int64_t c = 0; c < n_clips; ++c) { memset(&clips[(size_t)c], 0, sizeof(ClipDev)); clips[(size_t)c].T = (int)frames[c]; }
+    const int cap = choose_run_cap(clips, quantum, min_run, max_run, halo, wg_runs, num_cu);
+    long long runs = 0;
+    int lmax = 0;
+    for (const ClipDev &c : clips) {
+        if (c.T <= 0) continue;
+        const int len = clip_run_length(c.T, cap, quantum);
+        runs += (c.T + len - 1) / len;
+        lmax = std::max(lmax, len);
+    }
+    *run_cap = cap; *n_runs = runs; *longest = lmax;
+    return PAA_OK;
 }
 extern "C" int paa_debug_fft_plan(int window, int32_t *radices, int32_t *fft_len) {
     if (window < 2 || !radices || !fft_len) return fail(PAA_ERR_ARG, "bad argument");

@@ -1,5 +1,6 @@
 """CPU-side checks of the C-ABI library: it loads, exports every symbol of include/paa_hip.h,
 its host tables equal the oracle's, and it refuses to compute without a GPU (no CPU fallback)."""
+import ctypes
 import os
 import re
 
@@ -170,3 +171,31 @@ def test_c_client_links_and_fails_loudly_without_gpu(tmp_path):
         assert run.returncode == 0 and "frames 79" in run.stdout, run.stdout + run.stderr
     else:
         assert run.returncode == 2 and "no HIP device" in run.stdout, run.stdout + run.stderr
+
+
+def _run_plan(frames, quantum=4, min_run=16, max_run=256, halo=4, wg_runs=8, num_cu=256):
+    frames = np.ascontiguousarray(frames, dtype=np.int64)
+    cap, longest, runs = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
+    _ffi.check(_ffi.lib().paa_debug_run_plan(_ffi.as_i64p(frames), len(frames), quantum, min_run, max_run, halo, wg_runs,
+                                             num_cu, ctypes.byref(cap), ctypes.byref(runs), ctypes.byref(longest)))
+    return cap.value, runs.value, longest.value
+
+
+def test_run_length_choice_for_the_baseline_batches():
+    """paa_plan_create's run sizing (host only): equal runs per clip, the cap minimising rounds x (run + halo)."""
+    cap, runs, longest = _run_plan([143999])                      # config 2: one round of 250 workgroups
+    assert (runs, longest) == (2000, 72)
+    cap, runs, longest = _run_plan([399] * 12500)                 # config 4 shard: 4 x 100 per clip, not 244 + 155
+    assert (runs, longest) == (50000, 100)
+    cap, runs, longest = _run_plan([1199] * 1000)                 # config 3: 6 x 200 per clip, not 6 x 196 + 23
+    assert (runs, longest) == (6000, 200)
+    cap, runs, longest = _run_plan([59998], quantum=3, min_run=12, max_run=96, halo=3, wg_runs=6)      # config 5
+    assert longest % 3 == 0 and -(-runs // 6) <= 256
+    rng = np.random.default_rng(4)
+    for _ in range(20):
+        frames = rng.integers(0, 3000, rng.integers(1, 400))
+        cap, runs, longest = _run_plan(frames)
+        assert 16 <= cap <= 256 and cap % 4 == 0 and longest <= cap and longest % 4 == 0
+        live = frames[frames > 0]
+        assert runs >= len(live) and runs >= -(-int(live.sum()) // 256)
+    assert _ffi.lib().paa_debug_run_plan(None, 1, 4, 16, 256, 4, 8, 256, None, None, None) == _ffi.ERR_ARG
