@@ -10,6 +10,8 @@ the tests use torch.distributed with the gloo backend; the feature data itself m
 libpaa_hip.so's paa_comm_gather_f64 (grouped ncclSend/ncclRecv).
 """
 import ctypes
+import hashlib
+import os
 
 import numpy as np
 
@@ -121,16 +123,33 @@ class HipEngine:
     def to_host(self, buf, n_doubles):
         return buf.to_host(np.float64, int(n_doubles))
 
+    def upload(self, flat):
+        """float64 host block (a restart file) -> device buffer"""
+        return _ffi.DeviceBuffer.from_host(np.ascontiguousarray(flat, dtype=np.float64))
+
     def sync(self):
         _ffi.sync()
 
 
-def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank, comm, root=0, engine=None):
+def _shard_key(clips, sampling_rate, window, step, deltas):
+    """Identity of one rank's work for the restart files: parameters, clip lengths and a digest of the samples."""
+    h = hashlib.sha256()
+    h.update(repr((float(sampling_rate), int(window), int(step), bool(deltas), [len(c) for c in clips])).encode())
+    for c in clips:
+        h.update(np.ascontiguousarray(c, dtype=np.int16).tobytes())
+    return h.hexdigest()
+
+
+def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank, comm, root=0, engine=None,
+                    restart_dir=None):
     """Rank-local part of a sharded batch extraction.
 
     clips: the FULL list of int16 clips (every rank sees the list; only its own range is uploaded).
     comm: gather(send, counts, root, recv) / barrier() / close() -- RcclGather on the GPU.
-    engine: extract / alloc / to_host / sync -- HipEngine (default) on the GPU.
+    engine: extract / alloc / to_host / upload / sync -- HipEngine (default) on the GPU.
+    restart_dir: when given, every rank leaves its finished block there (shard_<rank>_of_<world>.npz, keyed by the
+        parameters and a digest of its clips) and a rerun of the same job loads the block instead of extracting it
+        again -- a 100 000-clip job that died in the gather or on another rank restarts without redoing finished shards.
     Returns, on the root, the list of (F, T_c) arrays for all clips (None elsewhere).
     """
     engine = engine or HipEngine()
@@ -144,7 +163,26 @@ def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank
     counts = block_counts(frames, ranges, F)
     a, b = ranges[rank]
     mine = [np.ascontiguousarray(c, dtype=np.int16) for c in clips[a:b]]
-    d_out = engine.extract(mine, sampling_rate, window, step, deltas) if mine else engine.alloc(1)
+    d_out = None
+    shard_file = key = None
+    if restart_dir is not None and mine:
+        os.makedirs(restart_dir, exist_ok=True)
+        shard_file = os.path.join(restart_dir, "shard_%03d_of_%03d.npz" % (rank, world_size))
+        key = _shard_key(mine, sampling_rate, window, step, deltas)
+        if os.path.exists(shard_file):
+            try:
+                with np.load(shard_file, allow_pickle=False) as z:
+                    if str(z["key"]) == key and z["block"].shape == (int(counts[rank]),):
+                        d_out = engine.upload(z["block"])
+            except Exception:                    # an unreadable or foreign file is simply recomputed
+                d_out = None
+    if d_out is None:
+        d_out = engine.extract(mine, sampling_rate, window, step, deltas) if mine else engine.alloc(1)
+        if shard_file is not None:
+            engine.sync()
+            tmp = shard_file + ".tmp.npz"
+            np.savez(tmp, key=np.array(key), block=engine.to_host(d_out, int(counts[rank])))
+            os.replace(tmp, shard_file)
     d_all = engine.alloc(int(counts.sum())) if rank == root else None
     comm.gather(d_out, counts, root, d_all)
     engine.sync()

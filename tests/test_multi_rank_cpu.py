@@ -31,8 +31,13 @@ class _OracleEngine:
 
     def __init__(self, oracle):
         self.O = oracle
+        self.extract_calls = 0
+
+    def upload(self, flat):
+        return _HostBuf(np.array(flat, dtype=np.float64))
 
     def extract(self, clips, sampling_rate, window, step, deltas):
+        self.extract_calls += 1
         return _HostBuf(np.concatenate([self.O.feature_extraction(c, sampling_rate, window, step, deltas)[0].reshape(-1)
                                         for c in clips]))
 
@@ -78,7 +83,7 @@ class _GlooGather:
         pass
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, rdir):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -101,8 +106,23 @@ def _worker(rank, world, port, q):
         # the product's own sharding function, with the communicator and the engine injected
         per_clip = D.extract_sharded(clips, 16000, W, S, True, world, rank, comm, root=0, engine=_OracleEngine(O))
         comm.barrier()
+        # restart files: the first run writes one block per rank, the rerun loads them (no extraction), a changed clip
+        # invalidates only the rank that owns it
+        eng1, eng2, eng3 = _OracleEngine(O), _OracleEngine(O), _OracleEngine(O)
+        first = D.extract_sharded(clips, 16000, W, S, True, world, rank, comm, root=0, engine=eng1, restart_dir=rdir)
+        again = D.extract_sharded(clips, 16000, W, S, True, world, rank, comm, root=0, engine=eng2, restart_dir=rdir)
+        changed = list(clips)
+        changed[0] = synth_clip(12345, lens[0])
+        third = D.extract_sharded(changed, 16000, W, S, True, world, rank, comm, root=0, engine=eng3, restart_dir=rdir)
+        restart_ok = (eng1.extract_calls, eng2.extract_calls) == (1, 0) and eng3.extract_calls == (1 if rank == 0 else 0)
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(restart_ok))
+        comm.barrier()
         if rank == 0:
-            ok = per_clip is not None and len(per_clip) == len(clips)
+            ok = per_clip is not None and len(per_clip) == len(clips) and all(flags)
+            ok &= all(np.array_equal(x, y) and np.array_equal(x, z) for x, y, z in zip(per_clip, first, again))
+            ok &= bool(np.array_equal(third[0], O.feature_extraction(changed[0], 16000, W, S)[0]))
+            ok &= all(np.array_equal(x, y) for x, y in zip(per_clip[1:], third[1:]))
             for c, got in zip(clips, per_clip or []):
                 ref, _ = O.feature_extraction(c, 16000, W, S)
                 ok &= bool(np.array_equal(got, ref))
@@ -113,12 +133,12 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_world_size_2_gather_roundtrip():
+def test_world_size_2_gather_roundtrip(tmp_path):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
     for p in procs:
         p.start()
     status, ranges, counts = q.get(timeout=120)
