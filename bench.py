@@ -28,6 +28,7 @@ import ctypes
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -173,6 +174,7 @@ def main():
     ap.add_argument("--clips", type=int, default=CFG4_TOTAL_CLIPS, help="cfg4: clips in the whole job")
     ap.add_argument("--deltas", type=int, default=0, help="1: 68-row output (reference default), 0: the 34-feature metric")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather to rank 0")
+    ap.add_argument("--comm-timeout", type=int, default=180, help="N>1: seconds allowed for the RCCL rendezvous")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--event-every", type=int, default=4,
                     help="HIP-event pair around every n-th feature-kernel launch of the timed region (roofline.kernel_avg_ms)")
@@ -262,6 +264,7 @@ def main():
 
     gather = world > 1 and not args.no_gather
     gather_note = None
+    comm_hung = False
     d_all = None
     comm = None
     if gather:
@@ -269,14 +272,30 @@ def main():
             obj = [payload]
             dist.broadcast_object_list(obj, src=0)
             return obj[0]
-        try:
-            comm = D.RcclGather(world, rank, bcast)
+        # the communicator is created on a helper thread with a deadline: a rendezvous that never completes (one rank
+        # missing, a fabric problem) must cost the scaling run its gather, not the whole run
+        box = {}
+
+        def init_comm():
+            try:
+                box["comm"] = D.RcclGather(world, rank, bcast)
+            except Exception as exc:
+                box["err"] = exc
+        th = threading.Thread(target=init_comm, daemon=True)
+        th.start()
+        th.join(args.comm_timeout)
+        if th.is_alive():
+            ok = False
+            comm_hung = True
+            gather_note = "RCCL init did not return within %d s on rank %d" % (args.comm_timeout, rank)
+        elif "err" in box:     # keep the scaling run alive, say what happened
+            ok = False
+            gather_note = "RCCL init failed on rank %d: %s" % (rank, box["err"])
+        else:
+            comm = box["comm"]
             if rank == 0:
                 d_all = _ffi.DeviceBuffer(int(counts.sum()) * 8)
             ok = True
-        except Exception as exc:       # keep the scaling run alive, say what happened
-            ok = False
-            gather_note = "RCCL init failed on rank %d: %s" % (rank, exc)
         all_ok = [None] * world
         dist.all_gather_object(all_ok, ok)
         gather = all(all_ok)
@@ -464,6 +483,9 @@ def main():
         comm.close()
     if dist is not None:
         dist.destroy_process_group()
+    if comm_hung:                      # a helper thread is still inside RCCL: do not wait for it at interpreter exit
+        sys.stdout.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -135,9 +135,19 @@ static long long g_prof_n = 0;
 static int comm_wait_buffer_free(const void *d_out);
 static int comm_sync();
 
+// HIP's current device is a per-thread setting (device 0 until hipSetDevice): a host thread other than the one that
+// called paa_init(d) would otherwise allocate on device 0 while the library's streams and tables live on device d.
+static thread_local int tl_device = -1;
 static int ensure_init() {
-    if (g_device >= 0) return PAA_OK;
-    return paa_init(0);
+    if (g_device < 0) {
+        const int rc = paa_init(0);
+        if (rc) return rc;
+    }
+    if (tl_device != g_device) {
+        HIP_TRY(hipSetDevice(g_device));
+        tl_device = g_device;
+    }
+    return PAA_OK;
 }
 
 template <typename T>
@@ -586,6 +596,7 @@ static int run_big(paa_plan *p, const void *d_packed, double *d_out) {
 
 extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *d_out) {
     if (!plan || !d_packed || !d_out) return fail(PAA_ERR_ARG, "null plan / buffer");
+    { const int rc_init = ensure_init(); if (rc_init) return rc_init; }
     std::lock_guard<std::mutex> lk(g_mu);
     int rc = comm_wait_buffer_free(d_out);      // a gather of this buffer may still be in flight
     if (rc) return rc;
@@ -641,6 +652,7 @@ extern "C" int paa_plan_create_mode(const int64_t *offsets, int64_t n_clips, int
 }
 
 extern "C" int paa_plan_destroy(paa_plan_t *plan) {
+    if (g_device >= 0) (void)ensure_init();       // (binds the calling thread to the library's device)
     std::lock_guard<std::mutex> lk(g_mu);
     if (cs()) (void)hipStreamSynchronize(cs());
     plan_free(plan);
@@ -668,6 +680,7 @@ extern "C" int64_t paa_plan_mid_doubles(const paa_plan_t *plan, int64_t mid_step
 extern "C" int paa_plan_mid_execute(paa_plan_t *plan, const double *d_st, int64_t mid_ratio, int64_t mid_step_ratio,
                                     double *d_mid) {
     if (!plan || !d_st || !d_mid) return fail(PAA_ERR_ARG, "null plan / buffer");
+    { const int rc_init = ensure_init(); if (rc_init) return rc_init; }
     if (plan->mode != 0) return fail(PAA_ERR_ARG, "mid-term statistics need a feature plan");
     if (mid_step_ratio < 1)
         return fail(PAA_ERR_ARG, "mid_step / short_step rounds to %lld: the reference loops forever "
@@ -703,6 +716,7 @@ extern "C" int paa_plan_beat_execute(paa_plan_t *plan, const double *d_st, doubl
     if (!plan || !d_st || !d_beat) return fail(PAA_ERR_ARG, "null plan / buffer");
     if (plan->mode != 0) return fail(PAA_ERR_ARG, "beat extraction needs a feature plan");
     if (!(window_size > 0)) return fail(PAA_ERR_ARG, "window_size must be positive");
+    { const int rc_init = ensure_init(); if (rc_init) return rc_init; }
     const int max_beat = (int)nearbyint(2.0 / window_size);          // int(round(2.0 / window_size)), :33
     if (max_beat < 1 || max_beat > 4096) return fail(PAA_ERR_UNSUPPORTED, "beat histogram of %d bins", max_beat);
     std::lock_guard<std::mutex> lk(g_mu);
@@ -875,6 +889,7 @@ extern "C" int paa_init(int device_id) {
         paa_shutdown();
     }
     HIP_TRY(hipSetDevice(device_id));
+    tl_device = device_id;
     HIP_TRY(hipStreamCreateWithFlags(&g_main_stream, hipStreamNonBlocking));
     for (int i = 0; i < kLanes; ++i) HIP_TRY(hipStreamCreateWithFlags(&g_lanes[i].stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&g_ev0));
