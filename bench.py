@@ -118,6 +118,16 @@ def other_configs(ffi, steps=8):
                               {"workload": "12 500 clips x 10 s (64 distinct, tiled), 34 rows: one GPU's share of config 4"})
     plan.destroy()
     del d_in, d_out
+    # ---- the reference's own default shape for classification / segmentation (50 ms / 50 ms: window 800, step 800,
+    # audioTrainTest.py:28-29): 1000 clips x 30 s, 68 rows
+    plan = ffi.Plan(np.arange(1001, dtype=np.int64) * n3, FS, WINDOW, WINDOW, deltas=True)
+    d_in = replicate_on_device(ffi, np.stack([synth_clip(3000 + i, n3, FS) for i in range(8)]), 1000)
+    d_out = ffi.DeviceBuffer(plan.out_doubles * 8)
+    ms = timed(ffi, lambda: plan.execute(d_in, d_out), steps, 2)
+    out["step800_68rows"] = entry(plan.total_frames, ms, 2 * WINDOW + 8 * 68, plan.kernel_name,
+                                  {"workload": "1000 clips x 30 s (8 distinct, tiled), window 800 / step 800, 68 rows"})
+    plan.destroy()
+    del d_in, d_out
     # ---- config 5: 44.1 kHz, window 25 ms / step 10 ms (1102 / 441), 600 s.  Two resident input forms: int16 mono (the
     # accounting of SURVEY 8d: 882 B of input per frame) and the float64 mono array audioBasicIO.stereo_to_mono hands the
     # reference for a stereo file (audioBasicIO.py:167: .5 fractions; 3 528 B of input per frame)

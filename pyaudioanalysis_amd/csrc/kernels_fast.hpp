@@ -86,7 +86,11 @@ struct Geo {
     static constexpr int NCHUNK = RAW_N / CHUNK;                // 50 / 80
     static constexpr int CPF = S / CHUNK;                       // chunks per frame step: 10 / 20
     static constexpr int NPRE = (RAW_N / 8 + 63) / 64;          // 16-byte prefetch registers per lane: 4 / 7
-    static constexpr int RAW_BYTES = (RAW_N + 2 * RAW_PAD) * 2;
+    // samples in front of raw[]: raw[PAD - 1] = the sample before the quad (16 bytes keep raw + PAD vector aligned).
+    // The two-waves-per-SIMD layout of step 800 has no room for it (3200 samples fill the two spectrum slots exactly):
+    // there lane 0 keeps that sample in a register (it owns chunk 0).
+    static constexpr int PAD = (NW == 8 && S == 800) ? 0 : RAW_PAD;
+    static constexpr int RAW_BYTES = (RAW_N + 2 * PAD) * 2;
     // NW = 8 (two waves per SIMD): the per-wave LDS must stay below 17.5 KB, so the transient buffers live inside the
     // spectrum ring: raw[] in two index-adjacent TARGET slots of the quad (dead until the exchange writes them),
     // msp[] / fv[] in the PREVIOUS-spectrum slot (dead once the flux operands are in registers)
@@ -546,6 +550,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
     if (NW == 4) PAA_F800_FETCH(q0)
 
     int16_t before_next = 0;         // lane 0: the sample just before the NEXT quad (saved while raw[] still holds it)
+    int16_t before_reg = 0;          // lane 0: the sample just before THIS quad
     for (;; first_quad = false) {
         // next quad: the halo quad first (frames r0-4 .. r0-1, nothing stored), then quads drawn from the run's word
         if (NW == 8 && STEAL) {
@@ -605,19 +610,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
             // than the exposed load: the partner wave of the SIMD computes meanwhile)
             if (NW != 4) PAA_F800_FETCH(q0)
             if (pre_ok) {
-                int4 *d4 = reinterpret_cast<int4 *>(raw + RAW_PAD);
+                int4 *d4 = reinterpret_cast<int4 *>(raw + G::PAD);
 #pragma unroll
                 for (int r = 0; r < G::NPRE; ++r)
                     if (lane + 64 * r < RAW_N / 8) d4[lane + 64 * r] = pre[r];
             } else {
                 const long long avail = c.n - base;
-                for (int n = lane; n < RAW_N; n += 64) raw[RAW_PAD + n] = (n < avail) ? src[n] : (int16_t)0;
+                for (int n = lane; n < RAW_N; n += 64) raw[G::PAD + n] = (n < avail) ? src[n] : (int16_t)0;
             }
-            if (lane == 0) raw[RAW_PAD - 1] = before;
+            if (G::PAD > 0 && lane == 0) raw[G::PAD - 1] = before;
+            before_reg = before;
             if (NW == 4 && q0 + QUAD < t_end) PAA_F800_FETCH(q0 + QUAD)
         }
         wsync();
-        if (lane == 0) before_next = raw[RAW_PAD + QUAD * S - 1];
+        if (lane == 0) before_next = raw[G::PAD + QUAD * S - 1];
         PAA_TICK(0)
 
         // ---------------- time domain: chunk partials (ShortTermFeatures.py:22-51)
@@ -625,9 +631,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
         // packed 16-bit saturating arithmetic:  s = clamp(sat(x - floor(mu)), lo, 1) * a + c  with (lo, a, c) =
         // (-1, 1, 0) when mu is a whole number (sign 0 exists) and (0, 2, -1) otherwise (x - floor(mu) >= 1 <=> +1).
         for (int ch = spec_only ? NCHUNK : lane; ch < NCHUNK; ch += 64) {
-            const int4 *p4 = reinterpret_cast<const int4 *>(raw + RAW_PAD + CHUNK * ch);
-            // the dword before the chunk holds the previous sample in its upper half
-            s16x2 sp = __builtin_bit_cast(s16x2, reinterpret_cast<const int *>(raw + RAW_PAD + CHUNK * ch)[-1]);
+            const int4 *p4 = reinterpret_cast<const int4 *>(raw + G::PAD + CHUNK * ch);
+            // the dword before the chunk holds the previous sample in its upper half (chunk 0 without a pad: lane 0's register)
+            s16x2 sp;
+            if (G::PAD == 0 && ch == 0) sp = (s16x2){0, before_reg};
+            else sp = __builtin_bit_cast(s16x2, reinterpret_cast<const int *>(raw + G::PAD + CHUNK * ch)[-1]);
             sp = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_elementwise_sub_sat(sp, zc_b), zc_lo), zc_one) * zc_mul + zc_add;
             double sx2 = 0.0;            // sum x^2 (exact: every term is an integer below 2^31, the sum below 2^53)
             int sx = 0;                  // sum x
@@ -667,7 +675,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
         // ---------------- pass 1: radix-25 on z[j + 16 r], z = x[2n] + i x[2n+1] (raw integers, exact in f64)
         double2 v[25];
         {
-            const int *r32 = reinterpret_cast<const int *>(raw + RAW_PAD) + (S / 2) * g + i;
+            const int *r32 = reinterpret_cast<const int *>(raw + G::PAD) + (S / 2) * g + i;
             int w25[25];
 #pragma unroll
             for (int r = 0; r < 25; ++r) w25[r] = r32[16 * r];
@@ -1039,10 +1047,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
 inline int fast_select(int window, int step, int sample_kind, double fs, FastTables &ft, const FftPlan &fft,
                        const MelTable &mel, const ChromaTable &chroma, FastLaunch &fl, int want_waves) {
     if (!(window == 800 && (step == 400 || step == 800) && sample_kind == 0)) return 0;
-    // 8 waves per workgroup (two per SIMD) exist for the 50 %-overlap shape only
-    int nw = (want_waves == 8 && step == 400) ? 8 : 4;
+    int nw = (want_waves == 8) ? 8 : 4;             // 8 waves per workgroup = two per SIMD
     int wave_bytes = (step == 400) ? (nw == 8 ? f800::Geo<400, 8>::WAVE_BYTES : f800::Geo<400, 4>::WAVE_BYTES)
-                                   : f800::Geo<800, 4>::WAVE_BYTES;
+                                   : (nw == 8 ? f800::Geo<800, 8>::WAVE_BYTES : f800::Geo<800, 4>::WAVE_BYTES);
     f800::TabLayout &L = fl.layout;
     auto up4 = [](int n) { return std::max(8, (n + 7) / 8 * 8); };      // lists are unrolled by 8 on the device
     int c0 = 0, c1 = 0, c2 = 0, cc = 0;
@@ -1080,7 +1087,7 @@ inline int fast_select(int window, int step, int sample_kind, double fs, FastTab
     L.f0sq = L.f0 * L.f0;
     if (nw == 8 && (size_t)L.total + (size_t)nw * wave_bytes > 160 * 1024) {      // tables too large: one wave per SIMD
         nw = 4;
-        wave_bytes = f800::Geo<400, 4>::WAVE_BYTES;
+        wave_bytes = (step == 400) ? f800::Geo<400, 4>::WAVE_BYTES : f800::Geo<800, 4>::WAVE_BYTES;
     }
     if ((size_t)L.total + (size_t)nw * wave_bytes > 160 * 1024) return 0;   // generic kernel instead
     if (!ft.d_blob) {
@@ -1118,7 +1125,7 @@ inline int fast_select(int window, int step, int sample_kind, double fs, FastTab
         if (hipMalloc(&ft.d_blob, blob.size()) != hipSuccess) return PAA_ERR_OOM;
         if (hipMemcpy(ft.d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) return PAA_ERR_HIP;
     }
-    fl.name = (step == 400) ? (nw == 8 ? "st_fast_800_w8" : "st_fast_800") : "st_fast_800_s800";
+    fl.name = (step == 400) ? (nw == 8 ? "st_fast_800_w8" : "st_fast_800") : (nw == 8 ? "st_fast_800_s800_w8" : "st_fast_800_s800");
     fl.lds = (size_t)L.total + (size_t)nw * wave_bytes;
     fl.variant = (step == 400) ? 800 : 1600;
     fl.run = 256;       // longest run (frames) given to one wave; the plan shrinks it to fill the chip
@@ -1161,6 +1168,8 @@ inline int fast_launch(const FastLaunch &fl, const PlanDev &P, const FastTables 
     if (fl.variant == 800 && fl.waves_per_cu == 8)
         return fast_launch_step<400, 8>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
     if (fl.variant == 800) return fast_launch_step<400, 4>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+    if (fl.variant == 1600 && fl.waves_per_cu == 8)
+        return fast_launch_step<800, 8>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
     if (fl.variant == 1600) return fast_launch_step<800, 4>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
     return -1;
 }
