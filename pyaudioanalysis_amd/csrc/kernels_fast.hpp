@@ -1,8 +1,9 @@
 // Specialised feature kernel for the headline configuration: int16 PCM, window 800, step 400
-// (50 ms / 25 ms at 16 kHz -- BASELINE configs 1-4).  Any sampling rate (tables are per fs).
+// (50 ms / 25 ms at 16 kHz -- BASELINE configs 1-4) or step 800 (the reference's own 50 ms / 50 ms default).
+// Any sampling rate (tables are per fs).
 //
-// One workgroup = ONE wave = one run of consecutive frames of one clip, processed FOUR frames
-// ("a quad") per iteration:
+// One wave = one run of consecutive frames of one clip (a workgroup is NW = 8 or 4 such waves that share the LDS
+// tables and nothing else), processed FOUR frames ("a quad") per iteration:
 //   stage   : 2000 raw int16 samples (4 frames, 50 % overlap) HBM -> LDS with 16 B/lane loads
 //   time    : 50 lanes x 40-sample chunks: sum y^2 and sign changes (integer compares against the
 //             clip mean); frames / 80-sample entropy blocks are sums of chunk partials
@@ -15,7 +16,8 @@
 //   features: 16 lanes per frame reduce the spectrum (4 frames at once): centroid/spread, entropy,
 //             flux against the previous spectrum (kept in a rotating LDS slot), roll-off scan, sparse
 //             mel -> log10 -> 13x40 DCT, chroma gather; deltas from the previous column in registers
-//   store   : lane = feature row, 4 consecutive frames (32 B) per row
+//   store   : lane = feature row; the row's last seven values wait in registers until a 64-byte aligned chunk of eight
+//             frames is complete, which is stored whole and non-temporally (store_row_chunked)
 // Halo: a run with t0 > 0 first processes the quad t0-4..t0-1 without storing it.
 //
 // Replaces ShortTermFeatures.py:608-682 (+ helpers :22-140, :236-321) for this configuration.
