@@ -92,18 +92,29 @@ def music_thumbnailing(signal, sampling_rate, short_window=1.0, short_step=0.5, 
 # silence removal (reference :672-815)
 # ---------------------------------------------------------------------------------------------------------
 def smooth_moving_avg(signal, window=11):
-    """Moving average with reflected ends (reference :25-37)."""
-    window = int(window)
-    if signal.ndim != 1:
-        raise ValueError("")
-    if signal.size < window:
+    """Box-filter smoothing of a 1-D sequence whose ends are continued by point reflection about the first / last
+    sample (what the reference's helper computes, audioSegmentation.py:25-37): out[i] is the mean of `width`
+    consecutive entries of the extended sequence, the block ending (width - 1) // 2 entries after position i.
+    width = int(window); sequences are returned untouched for width < 3 (:31-32); ValueError for anything that is
+    not one-dimensional or is shorter than the width (:27-30)."""
+    width = int(window)
+    seq = signal
+    if seq.ndim != 1:
+        raise ValueError("smooth_moving_avg needs a one-dimensional sequence, got %d dimensions" % seq.ndim)
+    n = seq.size
+    if n < width:
         raise ValueError("Input vector needs to be bigger than window size.")
-    if window < 3:
+    if width < 3:
         return signal
-    s = np.r_[2 * signal[0] - signal[window - 1::-1], signal, 2 * signal[-1] - signal[-1:-window:-1]]
-    w = np.ones(window, 'd')
-    y = np.convolve(w / w.sum(), s, mode='same')
-    return y[window:-window + 1]
+    # point reflections: `width` entries in front (seq[width-1] .. seq[0] mirrored about seq[0]), width - 1 behind
+    lead = 2.0 * seq[0] - seq[:width][::-1]
+    trail = 2.0 * seq[-1] - seq[n - width + 1:][::-1]
+    extended = np.concatenate((lead, seq, trail))
+    box = np.full(width, 1.0) / float(width)
+    # 'valid' block means m[k] = mean(extended[k : k + width]); out[i] uses the block that ends at extended index
+    # width + i + (width - 1) // 2, i.e. k = i + 1 + (width - 1) // 2  (np.convolve(.., 'same') of the reference, cropped)
+    first = 1 + (width - 1) // 2
+    return np.convolve(extended, box, mode="valid")[first:first + n]
 
 
 def svm_onset_probability(st_feats, mean, std, svm):
@@ -154,60 +165,73 @@ def _train_onset_svm(low_energy, high_energy):
     return svm, scaler.mean_, scaler.scale_
 
 
+def _energy_extremes(st_feats):
+    """Columns (frames) of the short-term matrix that fall into the quietest / loudest tenth by energy (row 1):
+    thresholds are the means of the lowest and of the highest tenth of the sorted energies -- the loudest frame itself
+    left out of the upper mean, as in the reference -- plus 1e-15 (audioSegmentation.py:713-728)."""
+    energy = st_feats[1]
+    ranked = np.sort(energy)
+    tenth = int(ranked.size / 10)
+    quiet_limit = ranked[:tenth].mean() + 1e-15
+    loud_limit = ranked[-tenth:-1].mean() + 1e-15
+    return st_feats[:, energy <= quiet_limit], st_feats[:, energy >= loud_limit]
+
+
+def _onset_threshold(prob, weight):
+    """Weighted mix of the mean of the lowest tenth and the mean of the highest tenth of the smoothed probabilities
+    (audioSegmentation.py:753-759; the low part is scaled before it is averaged, the high part after)."""
+    ranked = np.sort(prob)
+    tenth = int(ranked.size / 10)
+    return ((1 - weight) * ranked[:tenth]).mean() + weight * ranked[-tenth:].mean()
+
+
+def _onset_segments(active, st_step, min_duration=0.2):
+    """Frame indices above the threshold -> [start, end] limits in seconds (audioSegmentation.py:764-791).
+
+    Indices whose neighbours are at most 2 frames apart belong to one segment; the list is cut where np.diff exceeds 2.
+    A segment is kept when it lasts longer than min_duration seconds (:786-790) -- which also removes every one-frame
+    segment, so the reference's habit of never opening a segment at the very last index (:770-771) changes nothing."""
+    active = np.asarray(active)
+    if active.size == 0:
+        return []
+    cuts = np.flatnonzero(np.diff(active) > 2) + 1
+    firsts = active[np.concatenate(([0], cuts))]
+    lasts = active[np.concatenate((cuts - 1, [active.size - 1]))]
+    limits = [[lo * st_step, hi * st_step] for lo, hi in zip(firsts, lasts)]
+    return [seg for seg in limits if seg[1] - seg[0] > min_duration]
+
+
+def _plot_segments(signal, sampling_rate, prob, st_step, seg_limits):
+    # waveform and probability curve with the segment limits marked (:793-811)
+    import matplotlib.pyplot as plt
+    curves = ((np.arange(signal.shape[0]) / float(sampling_rate), signal, 'Signal'),
+              (np.arange(prob.shape[0]) * st_step, prob, 'svm Probability'))
+    for row, (xs, ys, title) in enumerate(curves):
+        plt.subplot(2, 1, row + 1)
+        plt.plot(xs, ys)
+        for lo, hi in seg_limits:
+            plt.axvline(x=lo, color='red')
+            plt.axvline(x=hi, color='red')
+        plt.title(title)
+    plt.show()
+
+
 def silence_removal(signal, sampling_rate, st_win, st_step, smooth_window=0.5, weight=0.5, plot=False):
-    """Event detection (silence removal), reference :672-815.  Returns the list of [start, end] segments in seconds."""
+    """Event detection (silence removal), reference :672-815.  Returns the list of [start, end] segments in seconds.
+
+    signal, sampling_rate: the audio; st_win, st_step: short-term window and step in SECONDS; smooth_window: length of
+    the probability smoothing in seconds; weight in (0, 1): the higher, the stricter (values outside are pulled to
+    0.01 / 0.99, :697-700)."""
     from . import ShortTermFeatures as stf
-    if weight >= 1:
-        weight = 0.99
-    if weight <= 0:
-        weight = 0.01
-    # Step 1: feature extraction (:707-710)
-    signal = audioBasicIO.stereo_to_mono(signal)
-    st_feats, _ = stf.feature_extraction(signal, sampling_rate, st_win * sampling_rate, st_step * sampling_rate)
-    # Step 2: binary SVM of low vs high energy frames (:712-739)
-    st_energy = st_feats[1, :]
-    en = np.sort(st_energy)
-    st_windows_fraction = int(len(en) / 10)
-    low_threshold = np.mean(en[0:st_windows_fraction]) + 1e-15
-    high_threshold = np.mean(en[-st_windows_fraction:-1]) + 1e-15
-    low_energy = st_feats[:, np.where(st_energy <= low_threshold)[0]]
-    high_energy = st_feats[:, np.where(st_energy >= high_threshold)[0]]
-    svm, mean, std = _train_onset_svm(low_energy.T, high_energy.T)
-    # Step 3: onset probability of every frame (:741-751) -- one kernel instead of a predict_proba call per frame
-    prob_on_set = svm_onset_probability(st_feats, mean, std, svm)
-    prob_on_set = smooth_moving_avg(prob_on_set, smooth_window / st_step)
-    # Step 4A: threshold as a weighted average of the top and bottom 10 % (:753-762)
-    prog_on_set_sort = np.sort(prob_on_set)
-    nt = int(prog_on_set_sort.shape[0] / 10)
-    threshold = (np.mean((1 - weight) * prog_on_set_sort[0:nt]) + weight * np.mean(prog_on_set_sort[-nt::]))
-    max_indices = np.where(prob_on_set > threshold)[0]
-    # Step 4B: group frame indices to onset segments (:764-783)
-    index = 0
-    seg_limits = []
-    while index < len(max_indices):
-        cur_cluster = [max_indices[index]]
-        if index == len(max_indices) - 1:
-            break
-        while max_indices[index + 1] - cur_cluster[-1] <= 2:
-            cur_cluster.append(max_indices[index + 1])
-            index += 1
-            if index == len(max_indices) - 1:
-                break
-        index += 1
-        seg_limits.append([cur_cluster[0] * st_step, cur_cluster[-1] * st_step])
-    # Step 5: drop very small segments (:785-791)
-    min_duration = 0.2
-    seg_limits = [s_lim for s_lim in seg_limits if s_lim[1] - s_lim[0] > min_duration]
-    if plot:       # waveform and probability curve with the segment limits marked (:793-811)
-        import matplotlib.pyplot as plt
-        curves = ((np.arange(signal.shape[0]) / float(sampling_rate), signal, 'Signal'),
-                  (np.arange(prob_on_set.shape[0]) * st_step, prob_on_set, 'svm Probability'))
-        for row, (xs, ys, title) in enumerate(curves):
-            plt.subplot(2, 1, row + 1)
-            plt.plot(xs, ys)
-            for lo, hi in seg_limits:
-                plt.axvline(x=lo, color='red')
-                plt.axvline(x=hi, color='red')
-            plt.title(title)
-        plt.show()
+    weight = min(max(weight, 0.01), 0.99) if not 0 < weight < 1 else weight
+    mono = audioBasicIO.stereo_to_mono(signal)
+    st_feats, _ = stf.feature_extraction(mono, sampling_rate, st_win * sampling_rate, st_step * sampling_rate)   # :707-710
+    quiet, loud = _energy_extremes(st_feats)
+    svm, mean, std = _train_onset_svm(quiet.T, loud.T)                                     # :730-739, scikit-learn
+    # onset probability of every frame in one kernel (replaces the predict_proba loop :741-748), then smoothing (:751)
+    prob = smooth_moving_avg(svm_onset_probability(st_feats, mean, std, svm), smooth_window / st_step)
+    active = np.flatnonzero(prob > _onset_threshold(prob, weight))                         # :761
+    seg_limits = _onset_segments(active, st_step)
+    if plot:
+        _plot_segments(mono, sampling_rate, prob, st_step, seg_limits)
     return seg_limits

@@ -41,13 +41,12 @@ struct TabLayout {
     int off_chw, off_chk;                                  // chroma gather list of pitch class i
     int off_dct;                                           // 13 rows padded to 41 doubles
     int off_tw2, off_twp;                                  // double2 [16][13]: W400^(r p) and W800^(p + 25 q) of lane p
-    int off_sync;                                          // NW = 8 pacing / work stealing: SIMD id [8], remaining quads [8],
-                                                           // run index [8] (ints), then {end << 32 | next} [8] (64-bit)
+    int off_sync;                                          // NW = 8 pacing: SIMD id [8], progress in half iterations [8] (ints)
     int melN0, melN1, melN2, chN;                          // list lengths (multiples of 8)
     int mel_clamp;                                         // 1: some padded list reaches past bin 399
     double f0, rf0, r_half_fs, f0sq;                       // fs / 800, its reciprocal, 2 / fs, f0^2 (host-computed: scalar registers)
     int fixed_lists;                                       // 1: lengths are exactly 8/16/16/8 without clamping
-    int pace_mode;                                         // NW = 8: 0 none, 1 equal progress, 2 half an iteration apart
+    int pace_mode;                                         // NW = 8: 0 none, 1 the two waves of a SIMD keep equal progress
     int total;                                             // bytes, multiple of 16
 };
 }  // namespace f800
@@ -72,10 +71,6 @@ constexpr int RAW_PAD = 8;                          // raw[RAW_PAD + i]; raw[RAW
 constexpr int CHUNK = 40;                           // time-domain partials are formed over 40-sample chunks
 constexpr int FV_STRIDE = 34;
 typedef short s16x2 __attribute__((ext_vector_type(2)));
-// Work stealing between the waves of an 8-wave workgroup (see the kernel).  Measured on cfg2 with the light per-wave
-// trace (PAA_F800_TRACE): wave life times are 283..331 us around a median of 298 us -- the spread is between CUs, not
-// inside a workgroup -- so no wave ever finds three quads to steal and the per-quad atomic costs 2 %.  Off.
-constexpr bool STEAL = false;
 constexpr int TW_STRIDE = 13;                       // twiddle tables: one column per ACTIVE pass-2 lane (p = 0..12)
 constexpr int CH_STRIDE = 12;                       // chroma gather lists: one column per pitch class
 
@@ -280,20 +275,16 @@ __device__ unsigned long long g_wave_trace[4096 * 4];      // per wave: realtime
 // light-weight variant: only the per-wave life times (two clock reads and four stores per wave)
 __device__ unsigned long long g_phase_cycles[16];
 __device__ unsigned long long g_wave_trace[4096 * 4];
-#define PAA_T0() const unsigned long long t_rt0_ = __builtin_amdgcn_s_memrealtime(), t_c0_ = __builtin_readcyclecounter(); unsigned long long n_steal_ = 0;
+#define PAA_T0() const unsigned long long t_rt0_ = __builtin_amdgcn_s_memrealtime(), t_c0_ = __builtin_readcyclecounter();
 #define PAA_TICK(idx)
-#define PAA_TEND() if (lane == 0) { atomicAdd(&g_phase_cycles[15], 1ULL); atomicAdd(&g_phase_cycles[14], n_steal_); \
+#define PAA_TEND() if (lane == 0) { atomicAdd(&g_phase_cycles[15], 1ULL); \
     if (tile_id < 4096) { g_wave_trace[4 * tile_id] = t_rt0_; g_wave_trace[4 * tile_id + 1] = __builtin_amdgcn_s_memrealtime(); \
         g_wave_trace[4 * tile_id + 2] = __builtin_readcyclecounter() - t_c0_; \
         g_wave_trace[4 * tile_id + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } }
-#define PAA_STEAL_COUNT() ++n_steal_;
 #else
 #define PAA_T0()
 #define PAA_TICK(idx)
 #define PAA_TEND()
-#endif
-#ifndef PAA_STEAL_COUNT
-#define PAA_STEAL_COUNT()
 #endif
 
 // Row store, in whole 64-byte chunks of the row.  The rows of a [F][T] slab are only 8-byte aligned (T is odd in general)
@@ -413,36 +404,23 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
     // NW = 8: the two waves of a SIMD are paced against each other.  The hardware issues oldest-first, so without pacing
     // the older wave of a pair runs at nearly its single-wave speed, finishes early and leaves the younger one alone on the
     // SIMD for a long tail.  Every iteration a wave publishes how many quads it still has to do and raises its priority
-    // when it is behind its partner (s_setprio outranks age).  pace[0..7] = SIMD id, pace[8..15] = remaining quads.
-    //
-    // Work stealing inside the workgroup (NW = 8): the four SIMDs of a CU do not get equal shares of the LDS, so waves
-    // with equal runs finish up to 2x apart.  Every wave keeps {end << 32 | next} of its run (in frames) in one LDS
-    // word and draws its quads from it with an atomic add; a wave that has run dry halves the largest remainder of
-    // another wave with a compare-and-swap on that word (the victim's next atomic add sees the new end), recomputes
-    // the one-quad halo and continues there.  Which wave computes a frame never changes the frame's bits.
+    // when it is behind its partner (s_setprio outranks age).  pace[0..7] = SIMD id, pace[8..15] = progress.
+    // (Work stealing between the waves of a workgroup and a half-iteration pacing offset were measured and rejected:
+    // scripts/experiments/r02_work_stealing_pace2.diff.)
     volatile int *pace = reinterpret_cast<volatile int *>(smem + L.off_sync);
-    volatile int *wtile = pace + 16;
-    unsigned long long *wstate = reinterpret_cast<unsigned long long *>(smem + L.off_sync + 96);
     int partner = wave;
     if (NW == 8) {
         const int my_simd = (int)((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3u);     // HW_REG_HW_ID[5:4]
         if ((threadIdx.x & 63) == 0) {
             pace[wave] = my_simd;
             pace[8 + wave] = (tile_id < n_tiles) ? 0 : 0x7fffffff;
-            wtile[wave] = (tile_id < n_tiles) ? tile_id : -1;
-            unsigned long long st = 0;
-            if (tile_id < n_tiles) {
-                const Tile t0_ = tiles[tile_id];
-                st = ((unsigned long long)(unsigned)(t0_.t0 + t0_.cnt) << 32) | (unsigned)t0_.t0;
-            }
-            wstate[wave] = st;
         }
         __syncthreads();
 #pragma unroll
         for (int w = 0; w < 8; ++w) partner = (w != wave && pace[w] == my_simd) ? w : partner;
         partner = __builtin_amdgcn_readfirstlane(partner);
     }
-    if (!(NW == 8 && STEAL) && tile_id >= n_tiles) return;
+    if (tile_id >= n_tiles) return;
     using G = Geo<S, NW>;
     constexpr int RAW_N = G::RAW_N, NCHUNK = G::NCHUNK, CPF = G::CPF;
     unsigned char *wbase = smem + L.total + wave * G::WAVE_BYTES;
@@ -457,50 +435,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
 
     const int lane = threadIdx.x & 63;
     int g = lane >> 4, i = lane & 15;          // NW = 8 makes them opaque per iteration (see the loop head)
-    int cur_tile = tile_id;                    // the run this wave works on (its own first, stolen remainders later)
-    int r0 = 0, r_end = 0;                     // frames [r0, r_end) of that run are this wave's to store
-    bool have_work = tile_id < n_tiles;
-    if (have_work) { const Tile t0_ = tiles[tile_id]; r0 = t0_.t0; r_end = t0_.t0 + t0_.cnt; }
     PAA_T0()
-  for (;;) {          // one pass per assignment (NW = 4: exactly one)
-    if (!have_work) {
-        if (NW != 8 || !STEAL) break;
-        // ---- steal: the largest remainder among the other waves of the workgroup, at least 3 quads
-        bool got = false;
-        for (int attempt = 0; attempt < 8 && !got; ++attempt) {
-            int best = -1, best_rem = 2 * QUAD;
-            unsigned long long best_s = 0;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) {
-                const unsigned long long sw = *reinterpret_cast<volatile unsigned long long *>(&wstate[w]);
-                const int rem = (int)(unsigned)(sw >> 32) - (int)(unsigned)sw;
-                if (w != wave && rem > best_rem) { best = w; best_rem = rem; best_s = sw; }
-            }
-            best = __builtin_amdgcn_readfirstlane(best);
-            if (best < 0) break;
-            const int v_next = (int)(unsigned)best_s, v_end = (int)(unsigned)(best_s >> 32);
-            const int rem_quads = (v_end - v_next + QUAD - 1) / QUAD;
-            const int new_end = v_next + QUAD * ((rem_quads + 1) / 2);          // the victim keeps the larger half
-            const unsigned long long want = ((unsigned long long)(unsigned)new_end << 32) | (unsigned)v_next;
-            int ok = 0;
-            if (lane == 0) ok = (atomicCAS(&wstate[best], best_s, want) == best_s) ? 1 : 0;
-            ok = __builtin_amdgcn_readfirstlane(ok);
-            if (ok) {
-                got = true;
-                PAA_STEAL_COUNT()
-                r0 = __builtin_amdgcn_readfirstlane(new_end);
-                r_end = __builtin_amdgcn_readfirstlane(v_end);
-                cur_tile = __builtin_amdgcn_readfirstlane(wtile[best]);
-                if (lane == 0) {
-                    wtile[wave] = cur_tile;
-                    wstate[wave] = ((unsigned long long)(unsigned)r_end << 32) | (unsigned)r0;
-                }
-            }
-        }
-        if (!got) break;
-    }
-    have_work = false;
-    const Tile tl = tiles[cur_tile];
+    const Tile tl = tiles[tile_id];
     const ClipDev c = clips[tl.clip];
     const ClipNorm nm = norms[tl.clip];
     const int16_t *xc = sig + c.sample_off;
@@ -524,7 +460,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
     const s16x2 zc_add = mu_whole ? (s16x2){0, 0} : (s16x2){-1, -1};
     const s16x2 zc_one = {1, 1};
 
-    int t_end = r_end;               // NW = 8: re-read with every quad (a thief may lower it)
+    const int r0 = tl.t0, t_end = tl.t0 + tl.cnt;      // frames [r0, t_end) are this wave's to store
     int q0 = r0 >= QUAD ? r0 - QUAD : 0;
     int slot0 = 2;                   // slots of a quad: slot0 .. slot0+3 (mod 5) after the rotation at the loop head; previous = slot0-1
     double vlast = 0.0;              // lane l < 34: feature l of the frame before this quad
@@ -554,32 +490,21 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
     int16_t before_next = 0;         // lane 0: the sample just before the NEXT quad (saved while raw[] still holds it)
     int16_t before_reg = 0;          // lane 0: the sample just before THIS quad
     for (;; first_quad = false) {
-        // next quad: the halo quad first (frames r0-4 .. r0-1, nothing stored), then quads drawn from the run's word
-        if (NW == 8 && STEAL) {
-            if (!(first_quad && r0 >= QUAD)) {
-                unsigned long long old_ = 0;
-                if (lane == 0) old_ = atomicAdd(&wstate[wave], (unsigned long long)QUAD);
-                q0 = __builtin_amdgcn_readfirstlane((int)(unsigned)old_);
-                t_end = __builtin_amdgcn_readfirstlane((int)(unsigned)(old_ >> 32));
-            }
-        } else if (!first_quad) {
-            q0 += QUAD;
-        }
+        // next quad: the halo quad first (frames r0-4 .. r0-1, nothing stored), then the run's own quads
+        if (!first_quad) q0 += QUAD;
         if (q0 >= t_end) break;
         slot0 = (slot0 + 4) % 5;
         // NW = 8: hide the lane indices from loop-invariant code motion -- the dozens of per-lane LDS addresses the
         // compiler would otherwise keep in registers across the whole iteration cost more than re-deriving them
         if (NW != 4) asm volatile("" : "+v"(g), "+v"(i));
-        // pacing of the two waves of a SIMD: progress is counted in half iterations (loop head, end of the FFT);
-        // mode 1 keeps the pair level, mode 2 keeps the lower-numbered wave one half iteration ahead, so that one
-        // wave's issue-bound FFT stages run beside the other's latency-bound feature stages
+        // pacing of the two waves of a SIMD: progress is counted in half iterations (loop head, end of the FFT) and the
+        // pair is kept level
 #define PAA_F800_PACE(half_)                                                                           \
         if (NW == 8 && L.pace_mode != 0) {                                                             \
             const int mine_ = 2 * n_done + (half_);                                                    \
             if (lane == 0) pace[8 + wave] = mine_;                                                     \
             const int other_ = __builtin_amdgcn_readfirstlane(pace[8 + partner]);                      \
-            const int lead_ = (L.pace_mode == 2) ? ((wave < partner) ? 1 : -1) : 0;                    \
-            const int d_ = mine_ - other_ - lead_;                                                     \
+            const int d_ = mine_ - other_;                                                             \
             if (d_ < 0) __builtin_amdgcn_s_setprio(3);                                                 \
             else if (d_ > 0) __builtin_amdgcn_s_setprio(0);                                            \
             else __builtin_amdgcn_s_setprio(1);                                                        \
@@ -1038,7 +963,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
         PAA_TICK(10)
     }
     if (NW == 8 && lane == 0) pace[8 + wave] = 0x7fffffff;
-  }     // assignments
     PAA_TEND()
 }
 
@@ -1077,11 +1001,11 @@ inline int fast_select(int window, int step, int sample_kind, double fs, FastTab
     L.off_dct = take(13 * 41 * 8);
     L.off_tw2 = take(16 * f800::TW_STRIDE * 16);
     L.off_twp = take(16 * f800::TW_STRIDE * 16);
-    L.off_sync = take(24 * 4 + 8 * 8);
+    L.off_sync = take(16 * 4);
     L.total = off;
     {
-        const char *pm = getenv("PAA_F800_PACE");          // A/B switch of the pacing policy (default 1: 0.314 ms; 0: 0.329, 2: 0.318 on cfg2)
-        L.pace_mode = (pm && pm[0] >= '0' && pm[0] <= '2') ? pm[0] - '0' : 1;
+        const char *pm = getenv("PAA_F800_PACE");          // A/B switch of the pacing (default 1: 0.314 ms; 0: 0.329 on cfg2)
+        L.pace_mode = (pm && pm[0] == '0') ? 0 : 1;
     }
     L.f0 = fs / (2.0 * (double)f800::NF);
     L.rf0 = 1.0 / L.f0;
