@@ -51,6 +51,9 @@ const char *paa_last_error(void);
 int  paa_device_count(void);             /* >= 0, or PAA_ERR_HIP                                   */
 int  paa_init(int device_id);            /* select the device for this process (one process per GPU) */
 void paa_shutdown(void);                 /* free cached tables, scratch and the stream              */
+/* PCI bus id of the selected device ("0000:75:00.0", NUL-terminated): names the physical device whatever
+ * HIP_VISIBLE_DEVICES says; used to refuse two ranks of one RCCL job on one device                  */
+int  paa_device_bus_id(char *out, int capacity);
 int  paa_dev_alloc(size_t bytes, void **out_ptr);
 int  paa_dev_free(void *ptr);
 int  paa_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);   /* synchronous */
@@ -188,6 +191,8 @@ int paa_svm_binary_proba_f64(const double *feats, int n_dims, int64_t n_frames, 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI --------------------------------------- */
 #define PAA_COMM_ID_BYTES 128
 int paa_comm_unique_id(void *id_out /* PAA_COMM_ID_BYTES, rank 0 only */);
+/* one process per GPU: PAA_ERR_COMM when another live rank of the same job (same id) already uses the same physical
+ * device on this node (ncclCommInitRank would hang); multi-node jobs and one-visible-device-per-rank launchers are fine */
 int paa_comm_init(int world_size, int rank, const void *id);
 int paa_comm_destroy(void);
 /* gather variable-sized double blocks to rank `root`: counts[world] doubles per rank (host);

@@ -32,6 +32,7 @@ _SIGNATURES = {
     "paa_device_count": (C.c_int, []),
     "paa_init": (C.c_int, [C.c_int]),
     "paa_shutdown": (None, []),
+    "paa_device_bus_id": (C.c_int, [C.c_char_p, C.c_int]),
     "paa_dev_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "paa_dev_free": (C.c_int, [C.c_void_p]),
     "paa_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -300,40 +301,48 @@ def sync():
 
 # ---- recycled result arrays ------------------------------------------------------------------------------
 # A fresh 39 MB NumPy array (one hour of features) costs ~2 ms of mmap/munmap plus ~1 ms of first-touch page faults during
-# the device-to-host copy -- as much as the copy itself.  Result arrays are therefore views of pooled base buffers; a
-# buffer is handed out again only when NOTHING refers to it any more (every view keeps a reference to its base, so the
-# reference count tells), which keeps the reference's contract: the caller owns what it gets for as long as it keeps it.
+# the device-to-host copy -- as much as the copy itself.  Result arrays >= 1 MB are therefore views of pooled storage.
+# Liveness is tracked explicitly, not through reference counts: every hand-out wraps the storage in a fresh *token* array
+# (np.frombuffer over a memoryview: its base is not an ndarray, so NumPy's base-collapsing stops at the token and every
+# view, slice or reshape the caller derives from the result keeps the TOKEN alive); a weakref.finalize on the token marks
+# the storage idle when the last such view is gone.  The caller owns what it gets for as long as it keeps any view of it,
+# exactly the reference's contract; the arrays are non-owning views (flags.owndata is False, in-place resize is refused).
+import weakref
+
 _POOL_LOCK = threading.Lock()
-_POOL = []
+_POOL = []                      # [storage (uint8 ndarray, owns the memory), idle flag]
 _POOL_MAX_BYTES = 1 << 30
 _POOL_MIN_BYTES = 1 << 20
 
 
+def _retire(entry):
+    entry[1] = True             # (list item assignment: atomic under the GIL; finalizers may run on any thread)
+
+
 def result_array(shape, dtype=np.float64):
-    """Uninitialised C-contiguous array of `shape`, from the pool when a retired buffer fits."""
-    import sys
+    """Uninitialised C-contiguous array of `shape`, from the pool when an idle block fits."""
     n = int(np.prod(shape))
     nbytes = n * np.dtype(dtype).itemsize
     if nbytes < _POOL_MIN_BYTES:
         return np.empty(shape, dtype=dtype)
     with _POOL_LOCK:
         best = None
-        for k in range(len(_POOL)):
-            buf = _POOL[k]
-            # references of a retired buffer: the pool list, `buf`, getrefcount's argument
-            if sys.getrefcount(buf) <= 3 and buf.nbytes >= nbytes and (best is None or buf.nbytes < _POOL[best].nbytes):
-                best = k
-        if best is not None and _POOL[best].nbytes <= 2 * nbytes + (1 << 22):
-            base = _POOL[best]
-        else:
-            base = np.empty(nbytes, dtype=np.uint8)
-            _POOL.append(base)
-            total = sum(b.nbytes for b in _POOL)
+        for entry in _POOL:
+            if entry[1] and entry[0].nbytes >= nbytes and (best is None or entry[0].nbytes < best[0].nbytes):
+                best = entry
+        if best is None or best[0].nbytes > 2 * nbytes + (1 << 22):
+            best = [np.empty(nbytes, dtype=np.uint8), True]
+            _POOL.append(best)
+            total = sum(e[0].nbytes for e in _POOL)
             k = 0
-            while total > _POOL_MAX_BYTES and k < len(_POOL):       # drop retired buffers, oldest first
-                if sys.getrefcount(_POOL[k]) <= 2 and _POOL[k] is not base:
-                    total -= _POOL[k].nbytes
+            while total > _POOL_MAX_BYTES and k < len(_POOL):       # drop idle blocks, oldest first
+                if _POOL[k][1] and _POOL[k] is not best:
+                    total -= _POOL[k][0].nbytes
                     del _POOL[k]
                 else:
                     k += 1
-        return base[:nbytes].view(dtype).reshape(shape)
+        best[1] = False
+        token = np.frombuffer(memoryview(best[0]), dtype=np.uint8)
+        fin = weakref.finalize(token, _retire, best)
+        fin.atexit = False
+        return token[:nbytes].view(dtype).reshape(shape)

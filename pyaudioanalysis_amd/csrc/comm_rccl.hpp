@@ -3,6 +3,12 @@
 // xGMI link; it is issued as one grouped ncclSend/ncclRecv batch on the library stream.
 // librccl.so is opened lazily so that hosts without a GPU can still load libpaa_hip.so.
 #pragma once
+#include <dirent.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <rccl/rccl.h>
 
 namespace {
@@ -28,6 +34,77 @@ hipStream_t g_comm_stream = nullptr;
 hipEvent_t g_ev_ready = nullptr;
 std::map<const void *, hipEvent_t> g_gather_done;
 
+// ---- "one process per GPU" guard ---------------------------------------------------------------------------
+// Two ranks of one communicator on the SAME physical device make ncclCommInitRank wait forever on this stack (measured:
+// no "duplicate GPU" error, a hang).  world_size says nothing about that (multi-node jobs, launchers that pin one visible
+// device per rank), so the check is on the device itself: before RCCL is called every rank drops a marker file
+//   <tmp>/paa_comm_<hash of the unique id>_<PCI bus id>.<rank>     (content: its pid)
+// and refuses to go on when a marker of ANOTHER live rank of the same job sits on the same bus id.  Node-local by
+// construction (that is where two processes can share a device); markers are removed by paa_comm_destroy and ignored when
+// their pid is gone.  Python callers with an all-gather on their control plane check the bus ids of all ranks up front
+// (distributed.RcclGather), which fails on every rank at once; this is the backstop for plain C callers.
+std::string g_comm_marker;
+unsigned long long comm_id_hash(const void *id_bytes, size_t n) {
+    unsigned long long h = 1469598103934665603ULL;                       // FNV-1a
+    for (size_t i = 0; i < n; ++i) { h ^= ((const unsigned char *)id_bytes)[i]; h *= 1099511628211ULL; }
+    return h;
+}
+const char *comm_tmp_dir() {
+    const char *d = getenv("PAA_COMM_MARKER_DIR");
+    if (d && d[0]) return d;
+    d = getenv("TMPDIR");
+    return (d && d[0]) ? d : "/tmp";
+}
+// marker stem of (job, device) and the directory scan: 0 when no other live rank of this job uses the device, the other
+// rank's number + 1 otherwise
+std::string comm_marker_stem(const void *id_bytes, const char *bus_id) {
+    char stem[160];
+    std::string bus(bus_id);
+    for (char &ch : bus) if (ch == ':' || ch == '.' || ch == '/') ch = '-';
+    snprintf(stem, sizeof(stem), "paa_comm_%016llx_%s.", comm_id_hash(id_bytes, sizeof(ncclUniqueId)), bus.c_str());
+    return stem;
+}
+int comm_scan_device(const std::string &stem, int rank) {
+    const std::string dir = comm_tmp_dir();
+    int clash = 0;
+    if (DIR *dp = opendir(dir.c_str())) {
+        while (struct dirent *de = readdir(dp)) {
+            if (strncmp(de->d_name, stem.c_str(), stem.size()) != 0) continue;
+            const int other = atoi(de->d_name + stem.size());
+            if (other == rank) continue;
+            long pid = 0;
+            const std::string path = dir + "/" + de->d_name;
+            if (FILE *f = fopen(path.c_str(), "r")) { if (fscanf(f, "%ld", &pid) != 1) pid = 0; fclose(f); }
+            if (pid > 0 && (kill((pid_t)pid, 0) == 0 || errno == EPERM)) { clash = other + 1; break; }
+            unlink(path.c_str());                                           // left behind by a process that is gone
+        }
+        closedir(dp);
+    }
+    return clash;
+}
+void comm_release_device() {
+    if (!g_comm_marker.empty()) unlink(g_comm_marker.c_str());
+    g_comm_marker.clear();
+}
+
+// drops this rank's marker, looks for others, and looks again after a short pause: ranks that a launcher starts together
+// then ALL see the clash (a rank that arrives much later still fails alone, while the early one waits inside RCCL)
+int comm_claim_device(const void *id_bytes, int rank, const char *bus_id) {
+    const std::string stem = comm_marker_stem(id_bytes, bus_id);
+    g_comm_marker = std::string(comm_tmp_dir()) + "/" + stem + std::to_string(rank);
+    FILE *f = fopen(g_comm_marker.c_str(), "w");
+    if (!f) { g_comm_marker.clear(); return 0; }                         // no writable tmp directory: no check possible
+    fprintf(f, "%ld\n", (long)getpid());
+    fclose(f);
+    static bool at_exit = false;
+    if (!at_exit) { atexit(comm_release_device); at_exit = true; }
+    int clash = comm_scan_device(stem, rank);
+    if (!clash) {
+        usleep(150 * 1000);
+        clash = comm_scan_device(stem, rank);
+    }
+    return clash;
+}
 int rccl_load() {
     if (g_rccl.h) return PAA_OK;
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -76,20 +153,27 @@ extern "C" int paa_comm_init(int world_size, int rank, const void *id_bytes) {
     if (rc) return rc;
     if ((rc = rccl_load())) return rc;
     if (!id_bytes || world_size < 1 || rank < 0 || rank >= world_size) return fail(PAA_ERR_ARG, "bad comm arguments");
-    {
-        // One process per GPU.  Two ranks on ONE device make ncclCommInitRank wait forever on this stack (measured: no
-        // "duplicate GPU" error, a hang), so the case is refused before RCCL is called.  Ranks that are each restricted
-        // to their own single device (HIP_VISIBLE_DEVICES per rank) opt in with PAA_COMM_SHARED_DEVICES=1.
-        int n_dev = 0;
-        const char *opt = getenv("PAA_COMM_SHARED_DEVICES");
-        if (hipGetDeviceCount(&n_dev) == hipSuccess && world_size > n_dev && !(opt && opt[0] == '1'))
-            return fail(PAA_ERR_COMM, "paa_comm_init: %d ranks but only %d visible device(s): one process per GPU "
-                        "(set PAA_COMM_SHARED_DEVICES=1 if every rank sees only its own device)", world_size, n_dev);
-    }
     if (g_comm) paa_comm_destroy();
+    if (world_size > 1) {
+        char bus[64] = "";
+        if (paa_device_bus_id(bus, (int)sizeof(bus)) == PAA_OK) {
+            const int clash = comm_claim_device(id_bytes, rank, bus);
+            if (clash) {
+                // (the marker stays until paa_comm_destroy / process exit: the other rank's second look must still find it)
+                return fail(PAA_ERR_COMM, "paa_comm_init: ranks %d and %d of this job both use the device at PCI %s: one "
+                            "process per GPU (ncclCommInitRank would never return)", rank, clash - 1, bus);
+            }
+        }
+    }
     ncclUniqueId id;
     memcpy(&id, id_bytes, sizeof(id));
-    NCCL_TRY(g_rccl.CommInitRank(&g_comm, world_size, id, rank));
+    {
+        const ncclResult_t r_ = g_rccl.CommInitRank(&g_comm, world_size, id, rank);
+        if (r_ != ncclSuccess) {
+            comm_release_device();
+            return fail(PAA_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(r_));
+        }
+    }
     g_world = world_size;
     g_rank = rank;
     HIP_TRY(hipMalloc((void **)&g_bar, sizeof(int)));
@@ -111,6 +195,7 @@ extern "C" int paa_comm_destroy(void) {
     if (g_ev_ready) { (void)hipEventDestroy(g_ev_ready); g_ev_ready = nullptr; }
     if (g_comm_stream) { (void)hipStreamDestroy(g_comm_stream); g_comm_stream = nullptr; }
     if (g_bar) { (void)hipFree(g_bar); g_bar = nullptr; }
+    comm_release_device();
     g_world = 1;
     g_rank = 0;
     return PAA_OK;

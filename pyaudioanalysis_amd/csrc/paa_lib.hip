@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -74,7 +75,11 @@ struct Scratch {
 
 static std::mutex g_mu;
 static std::mutex g_api_mu;     // the self-similarity entry points share their scratch buffers: one call at a time
-static int g_device = -1;
+static std::atomic<int> g_device{-1};
+// paa_init / paa_shutdown / the implicit first-call initialisation are serialised by this mutex (recursive: a device switch
+// inside paa_init shuts the old device down).  A live lane stream is never overwritten: streams are created only while
+// g_device < 0 and destroyed only by paa_shutdown.
+static std::recursive_mutex g_init_mu;
 static hipStream_t g_main_stream = nullptr;     // plan API, RCCL ordering, everything not running in a lane
 static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 static std::map<std::pair<double, int>, std::unique_ptr<TableSet>> g_tables;
@@ -139,13 +144,18 @@ static int comm_sync();
 // called paa_init(d) would otherwise allocate on device 0 while the library's streams and tables live on device d.
 static thread_local int tl_device = -1;
 static int ensure_init() {
-    if (g_device < 0) {
-        const int rc = paa_init(0);
-        if (rc) return rc;
+    if (g_device.load(std::memory_order_acquire) < 0) {
+        // first call of the process: two threads may arrive here together; the second one finds the device selected
+        std::lock_guard<std::recursive_mutex> lk(g_init_mu);
+        if (g_device.load(std::memory_order_acquire) < 0) {
+            const int rc = paa_init(0);
+            if (rc) return rc;
+        }
     }
-    if (tl_device != g_device) {
-        HIP_TRY(hipSetDevice(g_device));
-        tl_device = g_device;
+    const int dev = g_device.load(std::memory_order_acquire);
+    if (tl_device != dev) {
+        HIP_TRY(hipSetDevice(dev));
+        tl_device = dev;
     }
     return PAA_OK;
 }
@@ -166,6 +176,67 @@ static int scratch_reserve(Scratch &s, size_t bytes) {
     size_t want = bytes + bytes / 8 + 4096;
     HIP_TRY(hipMalloc(&s.p, want));
     s.cap = want;
+    return PAA_OK;
+}
+
+// Plan-owned device arrays (clip descriptors, tiles, statistics partials ...) come from a small cache instead of
+// hipMalloc / hipFree: the host-buffer entry points build and drop a plan per call, and every hipFree is a device-wide
+// synchronisation that would serialise the lanes.  Blocks are rounded up to a power of two (>= 4 KB), kept up to 256 MB.
+struct DevPool {
+    std::mutex mu;
+    std::multimap<size_t, void *> idle;
+    std::map<void *, size_t> size_of;
+    size_t idle_bytes = 0;
+};
+static DevPool g_pool;
+static int pool_alloc(void **out, size_t bytes) {
+    size_t cls = 4096;
+    while (cls < bytes) cls <<= 1;
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        auto it = g_pool.idle.find(cls);
+        if (it != g_pool.idle.end()) {
+            *out = it->second;
+            g_pool.idle.erase(it);
+            g_pool.idle_bytes -= cls;
+            return PAA_OK;
+        }
+    }
+    HIP_TRY(hipMalloc(out, cls));
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    g_pool.size_of[*out] = cls;
+    return PAA_OK;
+}
+static void pool_free(void *p) {
+    if (!p) return;
+    std::unique_lock<std::mutex> lk(g_pool.mu);
+    auto it = g_pool.size_of.find(p);
+    if (it == g_pool.size_of.end()) { lk.unlock(); (void)hipFree(p); return; }
+    if (g_pool.idle_bytes + it->second <= ((size_t)256 << 20)) {
+        g_pool.idle.emplace(it->second, p);
+        g_pool.idle_bytes += it->second;
+        return;
+    }
+    g_pool.size_of.erase(it);
+    lk.unlock();
+    (void)hipFree(p);
+}
+static void pool_release_all() {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    for (auto &kv : g_pool.idle) { g_pool.size_of.erase(kv.second); (void)hipFree(kv.second); }
+    g_pool.idle.clear();
+    g_pool.idle_bytes = 0;
+}
+// upload into a pooled block (plans); asynchronous on the calling thread's stream, ordered before the plan's kernels.
+// The host source must stay valid until the copy has been issued from pageable memory (hipMemcpyAsync stages it).
+template <typename T>
+static int upload_pooled(T **dst, const void *src, size_t count) {
+    pool_free(*dst);
+    *dst = nullptr;
+    if (count == 0) count = 1;
+    int rc = pool_alloc((void **)dst, count * sizeof(T));
+    if (rc) return rc;
+    if (src) HIP_TRY(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
     return PAA_OK;
 }
 
@@ -295,13 +366,23 @@ struct paa_plan {
     std::string kernel_name;
 };
 
-static int g_live_plans = 0;          // plans hold raw pointers into the device's table sets
+static std::atomic<int> g_live_plans{0};          // plans hold raw pointers into the device's table sets (freed outside g_mu too)
 static void plan_free(paa_plan *p) {
     if (!p) return;
     --g_live_plans;
-    (void)hipFree(p->d_clips); (void)hipFree(p->d_norms); (void)hipFree(p->d_tiles); (void)hipFree(p->d_chunks);
-    (void)hipFree(p->d_psum); (void)hipFree(p->d_pmin); (void)hipFree(p->d_pmax); (void)hipFree(p->d_mid_off); (void)hipFree(p->d_gen_blob); (void)hipFree(p->d_big);
+    // (the caller has synchronised the stream the plan ran on: pooled blocks may be handed to the next plan at once)
+    pool_free(p->d_clips); pool_free(p->d_norms); pool_free(p->d_tiles); pool_free(p->d_chunks);
+    pool_free(p->d_psum); pool_free(p->d_pmin); pool_free(p->d_pmax); pool_free(p->d_mid_off); pool_free(p->d_gen_blob);
+    if (p->d_big) (void)hipFree(p->d_big);
     delete p;
+}
+
+// deleter of the per-call plans of the host-buffer entry points: an early error return may leave kernels of this call in
+// flight on the lane's stream, and the plan's pooled blocks go straight to the next plan
+static void plan_free_synced(paa_plan *p) {
+    if (!p) return;
+    if (cs()) (void)hipStreamSynchronize(cs());
+    plan_free(p);
 }
 
 static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, double fs, int window, int step,
@@ -401,7 +482,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         reg::reg_layout(tab->fft, mode == 0 ? &tab->mel : nullptr, mode != 1 ? &tab->chroma : nullptr, F, SH::NFP, SH::Q,
                         p->rl, &blob);
         if ((size_t)p->rl.table_bytes + (size_t)p->rl.wave_bytes <= 160 * 1024) {
-            if ((rc = upload(&p->d_gen_blob, blob.data(), blob.size()))) return rc;
+            if ((rc = upload_pooled(&p->d_gen_blob, blob.data(), blob.size()))) return rc;
             p->reg = 1;
         }
     }
@@ -425,7 +506,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         if (p->lds > 160 * 1024) {
             p->big = 1;                 // no CPU fallback: the same passes run through HBM scratch instead
             p->lds = 0;
-        } else if ((rc = upload(&p->d_gen_blob, blob.data(), blob.size()))) {
+        } else if ((rc = upload_pooled(&p->d_gen_blob, blob.data(), blob.size()))) {
             return rc;
         }
         // one wave per run: about two chip-wide rounds of (256 CUs x waves per workgroup), 8..64 frames per run
@@ -461,14 +542,13 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
             ch.clip = (int)c;
             chunks.push_back(ch);
         }
-    if ((rc = upload(&p->d_clips, p->clips.data(), p->clips.size()))) return rc;
-    if ((rc = upload(&p->d_tiles, tiles.data(), tiles.size()))) return rc;
-    if ((rc = upload(&p->d_chunks, chunks.data(), chunks.size()))) return rc;
-    if ((rc = upload(&p->d_norms, (const void *)nullptr, (size_t)n_clips))) return rc;
+    if ((rc = upload_pooled(&p->d_clips, p->clips.data(), p->clips.size()))) return rc;
+    if ((rc = upload_pooled(&p->d_tiles, tiles.data(), tiles.size()))) return rc;
+    if ((rc = upload_pooled(&p->d_chunks, chunks.data(), chunks.size()))) return rc;
+    if ((rc = upload_pooled(&p->d_norms, (const void *)nullptr, (size_t)n_clips))) return rc;
     const size_t nch = (size_t)std::max<long long>(n_chunks, 1);
-    HIP_TRY(hipMalloc(&p->d_psum, nch * 8));
-    HIP_TRY(hipMalloc(&p->d_pmin, nch * 8));
-    HIP_TRY(hipMalloc(&p->d_pmax, nch * 8));
+    if ((rc = pool_alloc(&p->d_psum, nch * 8)) || (rc = pool_alloc(&p->d_pmin, nch * 8)) ||
+        (rc = pool_alloc(&p->d_pmax, nch * 8))) return rc;
     *out = p.release();
     return PAA_OK;
 }
@@ -652,7 +732,7 @@ extern "C" int paa_plan_create_mode(const int64_t *offsets, int64_t n_clips, int
 }
 
 extern "C" int paa_plan_destroy(paa_plan_t *plan) {
-    if (g_device >= 0) (void)ensure_init();       // (binds the calling thread to the library's device)
+    if (g_device.load() >= 0) (void)ensure_init();       // (binds the calling thread to the library's device)
     std::lock_guard<std::mutex> lk(g_mu);
     if (cs()) (void)hipStreamSynchronize(cs());
     plan_free(plan);
@@ -695,7 +775,7 @@ extern "C" int paa_plan_mid_execute(paa_plan_t *plan, const double *d_st, int64_
             o += 2LL * plan->P.F * paa_num_mid_windows(plan->clips[c].T, mid_step_ratio);
         }
         if (cs()) HIP_TRY(hipStreamSynchronize(cs()));
-        int rc = upload(&plan->d_mid_off, off.data(), off.size());
+        int rc = upload_pooled(&plan->d_mid_off, off.data(), off.size());
         if (rc) return rc;
         plan->mid_off_step = mid_step_ratio;
     }
@@ -874,8 +954,21 @@ extern "C" int paa_device_count(void) {
     return n;
 }
 
+// PCI bus id ("0000:75:00.0") of the selected device: identifies the PHYSICAL device whatever HIP_VISIBLE_DEVICES says
+extern "C" int paa_device_bus_id(char *out, int capacity) {
+    if (!out || capacity < 16) return fail(PAA_ERR_ARG, "bus id buffer too small");
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIP_TRY(hipDeviceGetPCIBusId(out, capacity, g_device.load()));
+    return PAA_OK;
+}
+
 extern "C" int paa_init(int device_id) {
-    if (g_device == device_id && cs()) return PAA_OK;
+    std::lock_guard<std::recursive_mutex> init_lock(g_init_mu);
+    if (g_device == device_id && g_main_stream) {
+        if (tl_device != device_id) { HIP_TRY(hipSetDevice(device_id)); tl_device = device_id; }
+        return PAA_OK;
+    }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n < 1)
@@ -883,18 +976,19 @@ extern "C" int paa_init(int device_id) {
     if (device_id < 0 || device_id >= n) return fail(PAA_ERR_ARG, "device %d out of range (%d devices)", device_id, n);
     if (g_device >= 0 && g_device != device_id) {
         // live plans and caller-owned device buffers point into the current device: switching would leave them dangling
-        if (g_live_plans > 0)
+        if (g_live_plans.load() > 0)
             return fail(PAA_ERR_ARG, "paa_init(%d): %d plan(s) of device %d are still alive; destroy them first",
-                        device_id, g_live_plans, g_device);
+                        device_id, g_live_plans.load(), g_device.load());
         paa_shutdown();
     }
     HIP_TRY(hipSetDevice(device_id));
     tl_device = device_id;
-    HIP_TRY(hipStreamCreateWithFlags(&g_main_stream, hipStreamNonBlocking));
-    for (int i = 0; i < kLanes; ++i) HIP_TRY(hipStreamCreateWithFlags(&g_lanes[i].stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&g_ev0));
-    HIP_TRY(hipEventCreate(&g_ev1));
-    g_device = device_id;
+    // (a failed earlier attempt may have left some of these behind: create only what is missing)
+    if (!g_main_stream) HIP_TRY(hipStreamCreateWithFlags(&g_main_stream, hipStreamNonBlocking));
+    for (int i = 0; i < kLanes; ++i)
+        if (!g_lanes[i].stream) HIP_TRY(hipStreamCreateWithFlags(&g_lanes[i].stream, hipStreamNonBlocking));
+    if (!g_ev0) HIP_TRY(hipEventCreate(&g_ev0));
+    if (!g_ev1) HIP_TRY(hipEventCreate(&g_ev1));
     {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && ncu > 0) g_num_cu = ncu;
@@ -903,15 +997,18 @@ extern "C" int paa_init(int device_id) {
     g_force_generic = (fg && fg[0] == '1') ? 1 : 0;
     const char *fw = getenv("PAA_F800_WAVES");          // 4: one wave per SIMD, 8: two (A/B switch, default 8)
     g_f800_waves = (fw && fw[0] == '4') ? 4 : 8;
+    g_device.store(device_id, std::memory_order_release);      // published last: ensure_init's fast path sees a complete state
     return PAA_OK;
 }
 
 extern "C" void paa_shutdown(void) {
+    std::lock_guard<std::recursive_mutex> init_lock(g_init_mu);
     if (g_device < 0) return;
     (void)paa_comm_destroy();          // communicator, its stream and events
     if (g_main_stream) (void)hipStreamSynchronize(g_main_stream);
     for (auto &kv : g_tables) free_tables(*kv.second);
     g_tables.clear();
+    pool_release_all();
     for (Scratch *s : {&g_sim_z, &g_sim_small, &g_sim_cand, &g_sim_in, &g_sim_out, &g_sim_filt}) { if (s->p) (void)hipFree(s->p); s->p = nullptr; s->cap = 0; }
     for (Lane &ln : g_lanes) {
         if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); ln.stream = nullptr; }
@@ -922,7 +1019,7 @@ extern "C" void paa_shutdown(void) {
     if (g_main_stream) (void)hipStreamDestroy(g_main_stream);
     g_ev0 = g_ev1 = nullptr;
     g_main_stream = nullptr;
-    g_device = -1;
+    g_device.store(-1, std::memory_order_release);
 }
 
 extern "C" int paa_dev_alloc(size_t bytes, void **out_ptr) {
@@ -1058,7 +1155,7 @@ static int run_host_st(const void *packed, const int64_t *offsets, int64_t n_cli
         rc = plan_build(offsets, n_clips, sample_kind, fs, window, step, deltas, 0, &plan);
     }
     if (rc) return rc;
-    std::unique_ptr<paa_plan, void (*)(paa_plan *)> guard(plan, plan_free);
+    std::unique_ptr<paa_plan, void (*)(paa_plan *)> guard(plan, plan_free_synced);
     // sample_kind 2: the host buffer holds interleaved stereo int16 (4 bytes per frame); the device turns it
     // into int32 sums L + R before anything else (fused stereo_to_mono)
     const size_t esz = sample_kind == 0 ? 2 : (sample_kind == 2 ? 4 : 8);
@@ -1203,7 +1300,7 @@ static int run_host_spec(const void *signal, int64_t n, int sample_kind, double 
         rc = plan_build(off, 1, sample_kind, fs, window, step, 0, mode, &plan);
     }
     if (rc) return rc;
-    std::unique_ptr<paa_plan, void (*)(paa_plan *)> guard(plan, plan_free);
+    std::unique_ptr<paa_plan, void (*)(paa_plan *)> guard(plan, plan_free_synced);
     const size_t esz = sample_kind == 0 ? 2 : 8;
     {
         std::lock_guard<std::mutex> lk(g_mu);

@@ -12,6 +12,7 @@ libpaa_hip.so's paa_comm_gather_f64 (grouped ncclSend/ncclRecv).
 import ctypes
 import hashlib
 import os
+import socket
 
 import numpy as np
 
@@ -78,9 +79,23 @@ class RcclGather:
     The interface extract_sharded() needs from a communicator is gather / barrier / close; the CPU tests inject a
     gloo-backed object with the same three methods."""
 
-    def __init__(self, world_size, rank, broadcast_bytes):
-        """broadcast_bytes(payload_or_None) -> payload: broadcast from rank 0 over any control-plane group."""
+    def __init__(self, world_size, rank, broadcast_bytes, exchange_bytes=None):
+        """broadcast_bytes(payload_or_None) -> payload: broadcast from rank 0 over any control-plane group.
+        exchange_bytes(payload) -> [payload of rank 0, 1, ..]: optional all-gather on the same control plane.  With it
+        every rank learns (host, PCI bus id) of all ranks BEFORE RCCL is touched and all of them refuse a job that puts
+        two ranks on one physical device (ncclCommInitRank would hang); without it the library's node-local marker
+        files catch the case (paa_comm_init)."""
         lib = _ffi.lib()
+        if exchange_bytes is not None and int(world_size) > 1:
+            bus = ctypes.create_string_buffer(64)
+            _ffi.check(lib.paa_device_bus_id(bus, 64))
+            me = (socket.gethostname() + "|" + bus.value.decode()).encode()
+            seen = {}
+            for r, who in enumerate(exchange_bytes(me)):
+                if who in seen:
+                    raise _ffi.HipLibraryError("ranks %d and %d both use device %s: one process per GPU"
+                                               % (seen[who], r, bytes(who).decode(errors="replace")))
+                seen[who] = r
         buf = ctypes.create_string_buffer(_ffi.COMM_ID_BYTES)
         if rank == 0:
             _ffi.check(lib.paa_comm_unique_id(buf))
@@ -130,10 +145,24 @@ class HipEngine:
     def sync(self):
         _ffi.sync()
 
+    _build_id = None
 
-def _shard_key(clips, sampling_rate, window, step, deltas):
-    """Identity of one rank's work for the restart files: parameters, clip lengths and a digest of the samples."""
+    def build_id(self):
+        """Digest of the library binary: restart files written by another build of the kernels are not reused."""
+        if HipEngine._build_id is None:
+            h = hashlib.sha256()
+            with open(_ffi.library_path(), "rb") as f:
+                for chunk in iter(lambda: f.read(1 << 20), b""):
+                    h.update(chunk)
+            HipEngine._build_id = h.hexdigest()[:16]
+        return HipEngine._build_id
+
+
+def _shard_key(clips, sampling_rate, window, step, deltas, build_id=""):
+    """Identity of one rank's work for the restart files: the build of the compute engine, the parameters, the clip
+    lengths and a digest of the samples."""
     h = hashlib.sha256()
+    h.update(str(build_id).encode())
     h.update(repr((float(sampling_rate), int(window), int(step), bool(deltas), [len(c) for c in clips])).encode())
     for c in clips:
         h.update(np.ascontiguousarray(c, dtype=np.int16).tobytes())
@@ -168,12 +197,15 @@ def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank
     if restart_dir is not None and mine:
         os.makedirs(restart_dir, exist_ok=True)
         shard_file = os.path.join(restart_dir, "shard_%03d_of_%03d.npz" % (rank, world_size))
-        key = _shard_key(mine, sampling_rate, window, step, deltas)
+        build_id = engine.build_id() if hasattr(engine, "build_id") else ""
+        key = _shard_key(mine, sampling_rate, window, step, deltas, build_id)
         if os.path.exists(shard_file):
             try:
                 with np.load(shard_file, allow_pickle=False) as z:
-                    if str(z["key"]) == key and z["block"].shape == (int(counts[rank]),):
-                        d_out = engine.upload(z["block"])
+                    if str(z["key"]) == key:
+                        block = z["block"]                       # (read once: every access decompresses the member)
+                        if block.shape == (int(counts[rank]),):
+                            d_out = engine.upload(block)
             except Exception:                    # an unreadable or foreign file is simply recomputed
                 d_out = None
     if d_out is None:

@@ -199,3 +199,33 @@ def test_run_length_choice_for_the_baseline_batches():
         live = frames[frames > 0]
         assert runs >= len(live) and runs >= -(-int(live.sum()) // 256)
     assert _ffi.lib().paa_debug_run_plan(None, 1, 4, 16, 256, 4, 8, 256, None, None, None) == _ffi.ERR_ARG
+
+
+def test_result_pool_tracks_liveness_through_views_of_views():
+    """_ffi.result_array hands out views of pooled storage; the storage is idle again only when the LAST view derived
+    from the result is gone -- slices, reshapes and transposes of the result count (no reference-count heuristics)."""
+    import gc
+    from pyaudioanalysis_amd import _ffi
+    shape = (68, 40000)                                     # 21.8 MB: above the pooling threshold
+    a = _ffi.result_array(shape)
+    assert a.shape == shape and a.dtype == np.float64 and a.flags.c_contiguous and a.flags.writeable
+    addr = a.__array_interface__["data"][0]
+    tail = a[34:]                                           # a view of the view
+    flat = a.reshape(-1)[:7]
+    del a
+    gc.collect()
+    b = _ffi.result_array(shape)                            # the first block is still referenced: a second one
+    assert b.__array_interface__["data"][0] != addr
+    tail[:] = 1.0
+    b[:] = 2.0
+    assert float(tail.min()) == 1.0
+    del tail
+    gc.collect()
+    c = _ffi.result_array(shape)                            # `flat` still pins the first block
+    assert c.__array_interface__["data"][0] != addr
+    del flat
+    gc.collect()
+    d = _ffi.result_array(shape)                            # now it is idle and comes back
+    assert d.__array_interface__["data"][0] == addr
+    small = _ffi.result_array((10, 10))
+    assert small.flags.owndata                              # small results are ordinary arrays

@@ -3,8 +3,10 @@
 With >= 2 visible devices: two processes, one per GPU, run distributed.extract_sharded() through RcclGather (grouped
 ncclSend / ncclRecv) and rank 0 checks every clip against the single-GPU result.
 With ONE device (the usual gpurun box): both ranks would have to share device 0, on which ncclCommInitRank never
-returns; paa_comm_init refuses that before calling RCCL.  The test asserts that it fails on both ranks with PAA_ERR_COMM
-and a clear message -- promptly, without a hang or a crash -- and that the library keeps working afterwards."""
+returns.  RcclGather compares the PCI bus ids of all ranks over the control plane before RCCL is touched, so BOTH ranks
+refuse with a clear message -- promptly, without a hang or a crash -- and the library keeps working afterwards.  The
+library's own backstop for callers without a control plane (node-local marker files keyed on job id + bus id,
+paa_comm_init) is exercised by planting the marker of a live "other rank"."""
 import os
 import sys
 
@@ -15,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _rank_main(rank, world, n_dev, comm_id, res_q):
+def _rank_main(rank, world, n_dev, comm_id, res_q, slots, gate):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -30,10 +32,15 @@ def _rank_main(rank, world, n_dev, comm_id, res_q):
         def bcast(payload):          # the parent process created the unique id (it hosts the RCCL bootstrap root)
             return comm_id
 
+        def exchange(payload):       # all-gather over shared memory: slot per rank, then a barrier
+            slots[64 * rank:64 * rank + 64] = payload[:63].ljust(64, b"\0")
+            gate.wait(timeout=60)
+            return [bytes(slots[64 * r:64 * r + 64]).rstrip(b"\0") for r in range(world)]
+
         lens = [4000, 16000, 9000, 800, 5200, 2500, 24000, 1199]
         clips = [synth_clip(4000 + i, n) for i, n in enumerate(lens)]
         try:
-            comm = D.RcclGather(world, rank, bcast)
+            comm = D.RcclGather(world, rank, bcast, exchange)
         except _ffi.HipLibraryError as exc:
             # the library must stay usable after a failed communicator init
             single, _ = ShortTermFeatures.feature_extraction(clips[1], 16000, 800, 400)
@@ -65,7 +72,8 @@ def test_two_ranks_rccl_gather_or_clean_failure(gpu_lib):
     buf = ctypes.create_string_buffer(_ffi.COMM_ID_BYTES)
     _ffi.check(gpu_lib.paa_comm_unique_id(buf))
     comm_id = bytes(buf.raw)
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, n_dev, comm_id, res_q)) for r in range(2)]
+    slots, gate = ctx.Array("c", 2 * 64, lock=False), ctx.Barrier(2)
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, n_dev, comm_id, res_q, slots, gate)) for r in range(2)]
     for p in procs:
         p.start()
     results = {}
@@ -88,3 +96,28 @@ def test_two_ranks_rccl_gather_or_clean_failure(gpu_lib):
             assert "one process per GPU" in msg, msg                            # PAA_ERR_COMM says what is wrong
             assert alive                                                        # single-GPU extraction still works
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
+def test_comm_init_refuses_a_device_another_live_rank_of_the_job_holds(gpu_lib, tmp_path, monkeypatch):
+    """Backstop inside paa_comm_init (no control plane): a marker for this job id and this PCI bus id that names a live
+    process as "rank 1" makes rank 0 fail with PAA_ERR_COMM before RCCL is called; paa_comm_destroy removes rank 0's
+    own marker again."""
+    import ctypes
+    from pyaudioanalysis_amd import _ffi
+    monkeypatch.setenv("PAA_COMM_MARKER_DIR", str(tmp_path))
+    bus = ctypes.create_string_buffer(64)
+    _ffi.check(gpu_lib.paa_device_bus_id(bus, 64))
+    assert bus.value.count(b":") == 2, bus.value                       # "0000:75:00.0"
+    buf = ctypes.create_string_buffer(_ffi.COMM_ID_BYTES)
+    _ffi.check(gpu_lib.paa_comm_unique_id(buf))
+    # FNV-1a of the first sizeof(ncclUniqueId) = 128 bytes, as comm_rccl.hpp names the markers
+    h = 1469598103934665603
+    for byte in buf.raw[:128]:
+        h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    stem = "paa_comm_%016x_%s." % (h, bus.value.decode().replace(":", "-").replace(".", "-"))
+    (tmp_path / (stem + "1")).write_text("%d\n" % os.getpid())         # "rank 1" = this (live) process
+    rc = gpu_lib.paa_comm_init(2, 0, buf)
+    assert rc == _ffi.ERR_COMM, rc
+    assert "one process per GPU" in _ffi.last_error(), _ffi.last_error()
+    gpu_lib.paa_comm_destroy()                                            # removes rank 0's own marker
+    assert sorted(p.name for p in tmp_path.iterdir()) == [stem + "1"]
