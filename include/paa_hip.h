@@ -114,12 +114,27 @@ int paa_spectrogram_f64(const double *signal, int64_t n, double fs, int window, 
  * (:349-355); that frame is evaluated on the device as a direct DFT of its true length.      */
 int paa_chromagram_i16(const int16_t *signal, int64_t n, double fs, int window, int step, double *out);
 int paa_chromagram_f64(const double *signal, int64_t n, double fs, int window, int step, double *out);
+/* interleaved stereo int16 (n frames): audioAnalysis.fileSpectrogramWrapper / fileChromagramWrapper call stereo_to_mono
+ * first (audioAnalysis.py:66-81, audioBasicIO.py:156-168); here the channels are summed on the device (4 B/frame over PCIe
+ * instead of the 8 B of the float64 mono copy)                                                                  */
+int paa_spectrogram_stereo_i16(const int16_t *interleaved, int64_t n, double fs, int window, int step, double *out);
+int paa_chromagram_stereo_i16(const int16_t *interleaved, int64_t n, double fs, int window, int step, double *out);
 
 /* ---- batched many-clip path (what MidTermFeatures.directory_feature_extraction :140-221
  *      does sequentially per file)                                                          */
 int paa_st_features_batch_i16(const int16_t *packed, const int64_t *offsets, int64_t n_clips,
                               double fs, int window, int step, int deltas,
                               double *out, const int64_t *out_offsets);
+/* float64 clips (what stereo_to_mono / np.double() hand the reference for stereo, 8-bit, 32-bit or float files,
+ * audioBasicIO.py:167, ShortTermFeatures.py:567): the same batch, 8 B/sample                 */
+int paa_st_features_batch_f64(const double *packed, const int64_t *offsets, int64_t n_clips,
+                              double fs, int window, int step, int deltas,
+                              double *out, const int64_t *out_offsets);
+int paa_mid_features_batch_f64(const double *packed, const int64_t *offsets, int64_t n_clips,
+                               double fs, int window, int step,
+                               int64_t mid_ratio, int64_t mid_step_ratio,
+                               double *mid_out, const int64_t *mid_out_offsets,
+                               double *st_out, const int64_t *st_out_offsets);
 /* mid_out_offsets index [136][M_c] slabs; st_out / st_out_offsets may be NULL               */
 int paa_mid_features_batch_i16(const int16_t *packed, const int64_t *offsets, int64_t n_clips,
                                double fs, int window, int step,

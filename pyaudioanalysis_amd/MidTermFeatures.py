@@ -66,14 +66,13 @@ def mid_feature_extraction(signal, sampling_rate, mid_window, mid_step, short_wi
 
 def mid_feature_extraction_batch(signals, sampling_rate, mid_window, mid_step, short_window, short_step,
                                  return_short=False):
-    """Many int16 clips in one launch -> list of (136, M_c) arrays (+ list of (68, T_c)), names."""
+    """Many clips in one launch (all int16, or anything else as float64) -> list of (136, M_c) arrays (+ list of
+    (68, T_c)), names."""
     ratio, step_ratio = _ratios(mid_window, mid_step, short_window, short_step)
     if step_ratio < 1:
         raise ValueError("mid_step / short_step rounds to 0: the reference never terminates")
     window, step = int(short_window), int(short_step)
-    clips = [np.ascontiguousarray(s, dtype=np.int16) for s in signals]
-    if not clips:
-        raise ValueError("need at least one clip")
+    clips, as_i16 = ShortTermFeatures._batch_clips(signals)
     short_names = ShortTermFeatures._feature_names(True)
     F = len(short_names)
     lib = _ffi.lib()
@@ -93,8 +92,9 @@ def mid_feature_extraction_batch(signals, sampling_rate, mid_window, mid_step, s
         st_off = np.zeros(len(clips), dtype=np.int64)
         np.cumsum(F * T[:-1], out=st_off[1:])
         st = _ffi.result_array((int(F * T.sum()),))
-    _ffi.check(lib.paa_mid_features_batch_i16(
-        _ffi.as_i16p(packed), _ffi.as_i64p(offsets), len(clips), float(sampling_rate), window, step,
+    fn = lib.paa_mid_features_batch_i16 if as_i16 else lib.paa_mid_features_batch_f64
+    _ffi.check(fn(
+        _ffi.as_i16p(packed) if as_i16 else _ffi.as_f64p(packed), _ffi.as_i64p(offsets), len(clips), float(sampling_rate), window, step,
         ratio, step_ratio, _ffi.as_f64p(mid), _ffi.as_i64p(mid_off),
         _ffi.as_f64p(st) if return_short else None, _ffi.as_i64p(st_off) if return_short else None))
     mids = [mid[int(o):int(o) + 2 * F * int(m)].reshape(2 * F, int(m)) for o, m in zip(mid_off, M)]
@@ -200,8 +200,9 @@ def mid_and_beat_batch(signals, sampling_rate, mid_window, mid_step, short_windo
                        beat_window_seconds=None):
     """Device-resident batch: int16 clips -> list of (136, M_c) mid-term matrices and, when beat_window_seconds
     is given, an (n_clips, 2) array of (bpm, confidence) from the GPU beat kernel.  The short-term matrices
-    never leave HBM.  The clips are either all mono (1-D int16) or all interleaved stereo ((n, 2) int16): stereo
-    clips are uploaded as the exact int32 sums L + R (4 B/sample) and scaled by 2^-16 on the device, which is
+    never leave HBM.  The clips are either all mono (1-D int16), all interleaved stereo ((n, 2) int16) or all float64
+    (1-D: what np.double() / stereo_to_mono make of every other file, ShortTermFeatures.py:567): stereo clips are
+    uploaded as the exact int32 sums L + R (4 B/sample) and scaled by 2^-16 on the device, which is
     audioBasicIO.stereo_to_mono (audioBasicIO.py:156-168) followed by the 2^-15 scaling of :568."""
     ratio, step_ratio = _ratios(mid_window, mid_step, short_window, short_step)
     if step_ratio < 1:
@@ -210,8 +211,13 @@ def mid_and_beat_batch(signals, sampling_rate, mid_window, mid_step, short_windo
     stereo = len(signals) > 0 and np.asarray(signals[0]).ndim == 2
     if any((np.asarray(s).ndim == 2) != stereo for s in signals):
         raise ValueError("mono and stereo clips cannot share a batch")
+    floats = (not stereo) and len(signals) > 0 and np.asarray(signals[0]).dtype != np.int16
+    if (not stereo) and any((np.asarray(s).dtype != np.int16) != floats for s in signals):
+        raise ValueError("int16 and float64 clips cannot share a batch")
     if stereo:
         clips = [np.asarray(s)[:, 0].astype(np.int32) + np.asarray(s)[:, 1] for s in signals]
+    elif floats:
+        clips = [np.ascontiguousarray(np.double(s)) for s in signals]
     else:
         clips = [np.ascontiguousarray(s, dtype=np.int16) for s in signals]
     lib = _ffi.lib()
@@ -224,7 +230,7 @@ def mid_and_beat_batch(signals, sampling_rate, mid_window, mid_step, short_windo
     T = (lens - window) // step + 1
     M = -(-T // step_ratio)
     d_in = _ffi.DeviceBuffer.from_host(np.concatenate(clips) if len(clips) > 1 else clips[0])
-    plan = _ffi.Plan(offsets, sampling_rate, window, step, deltas=True, sample_kind=2 if stereo else 0)
+    plan = _ffi.Plan(offsets, sampling_rate, window, step, deltas=True, sample_kind=2 if stereo else (1 if floats else 0))
     d_st = _ffi.DeviceBuffer(plan.out_doubles * 8)
     plan.execute(d_in, d_st)
     n_mid = plan.mid_doubles(step_ratio)
@@ -246,25 +252,33 @@ def mid_and_beat_batch(signals, sampling_rate, mid_window, mid_step, short_windo
 
 
 def _mid_for_files(entries, mid_window, mid_step, short_window, short_step, want_short):
-    """entries: list of (sampling_rate, signal).  int16 clips that share a sampling rate and a channel layout (mono,
-    or interleaved stereo as read from the file) go through ONE batched launch each; anything else (float64 signals,
-    more than two channels already reduced to mono) takes the single-clip path.  Returns per-entry
-    (mid [136 x M], short [68 x T] or None, names)."""
+    """entries: list of (sampling_rate, signal).  Clips that share a sampling rate and a sample layout go through ONE
+    batched launch each: int16 mono, interleaved int16 stereo as read from the file (summed on the device), and float64
+    -- which is what the reference's stereo_to_mono / np.double() make of every other file (8-bit, 32-bit, float,
+    stereo of those; audioBasicIO.py:156-168, ShortTermFeatures.py:567), so those files no longer take the reference's
+    one-by-one loop (MidTermFeatures.py:167).  Returns per-entry (mid [136 x M], short [68 x T] or None, names)."""
     out = [None] * len(entries)
     names = _mid_names(ShortTermFeatures._feature_names(True))
     groups = {}
+    signals = [None] * len(entries)
     for idx, (fs, sig) in enumerate(entries):
         a = np.asarray(sig)
         if a.dtype == np.int16 and (a.ndim == 1 or (a.ndim == 2 and a.shape[1] == 2)):
-            groups.setdefault((fs, a.ndim), []).append(idx)
-        else:
+            signals[idx] = a
+            groups.setdefault((fs, "i16", a.ndim), []).append(idx)
+            continue
+        mono = np.asarray(audioBasicIO.stereo_to_mono(a))
+        if mono.ndim == 1:
+            signals[idx] = np.double(mono)
+            groups.setdefault((fs, "f64", 1), []).append(idx)
+        else:               # more than two channels: the reference fails on these too; keep its single-clip error path
             mid, st, _ = mid_feature_extraction(sig, fs, round(mid_window * fs), round(mid_step * fs),
                                                 round(fs * short_window), round(fs * short_step))
             out[idx] = (mid, st if want_short else None)
-    for (fs, _), members in groups.items():
+    for (fs, _, _), members in groups.items():
         # want_short here means "the caller needs the beat": computed on the GPU from the resident short-term
         # matrix, returned in place of the matrix as a (bpm, confidence) pair
-        mids, beats = mid_and_beat_batch([entries[i][1] for i in members], fs, round(mid_window * fs),
+        mids, beats = mid_and_beat_batch([signals[i] for i in members], fs, round(mid_window * fs),
                                          round(mid_step * fs), round(fs * short_window), round(fs * short_step),
                                          beat_window_seconds=short_step if want_short else None)
         for k, i in enumerate(members):
@@ -308,7 +322,7 @@ def directory_feature_extraction(folder_path, mid_window, mid_step, short_window
             vec = np.transpose(mid).mean(axis=0)                       # long-term averaging (:199-201)
             if (not np.isnan(vec).any()) and (not np.isinf(vec).any()):
                 if compute_beat:
-                    # int16 files: (bpm, confidence) straight from the GPU beat kernel; float files: host scan
+                    # (bpm, confidence) straight from the GPU beat kernel (a host scan only for the single-clip path)
                     beat, beat_conf = st if isinstance(st, tuple) else beat_extraction(st, short_step)
                     vec = np.append(vec, beat)
                     vec = np.append(vec, beat_conf)

@@ -30,14 +30,14 @@ def _feature_names(deltas=True):
     return names
 
 
-def _mono_only(signal):
-    """spectrogram / chromagram have no fused stereo entry point: an (n, 2) int16 array is reduced to mono on
-    the host exactly like audioBasicIO.stereo_to_mono (float64) and takes the float64 path."""
-    kind, sig = _ffi.classify_signal(signal)
+def _spec_call(lib, stem, kind, sig):
+    """entry point and sample pointer of spectrogram / chromagram for a classified signal: int16 mono, float64, or
+    interleaved stereo int16 (summed on the device: the float64 mono copy of audioBasicIO.stereo_to_mono is never made)"""
+    if kind == 0:
+        return getattr(lib, "paa_%s_i16" % stem), _ffi.as_i16p(sig)
     if kind == 2:
-        sig = np.ascontiguousarray((sig[:, 1] / 2) + (sig[:, 0] / 2))
-        kind = 1
-    return kind, sig
+        return getattr(lib, "paa_%s_stereo_i16" % stem), _ffi.as_i16p(sig)
+    return getattr(lib, "paa_%s_f64" % stem), _ffi.as_f64p(sig)
 
 
 def feature_extraction(signal, sampling_rate, window, step, deltas=True):
@@ -78,16 +78,27 @@ def feature_extraction(signal, sampling_rate, window, step, deltas=True):
     return out, names
 
 
+def _batch_clips(signals):
+    """-> (contiguous 1-D clips of ONE dtype, True for int16 / False for float64)"""
+    arrays = [np.asarray(s) for s in signals]
+    if not arrays:
+        raise ValueError("need at least one clip")
+    if any(a.ndim != 1 for a in arrays):
+        raise ValueError("batched clips must be one-dimensional (reduce stereo with audioBasicIO.stereo_to_mono first)")
+    if all(a.dtype == np.int16 for a in arrays):
+        return [np.ascontiguousarray(a) for a in arrays], True
+    return [np.ascontiguousarray(np.double(a)) for a in arrays], False
+
+
 def feature_extraction_batch(signals, sampling_rate, window, step, deltas=True):
-    """Many clips in one launch: list of 1-D int16 arrays -> list of (F, T_c) arrays + names.
+    """Many clips in one launch: list of 1-D arrays -> list of (F, T_c) arrays + names.  int16 clips travel as int16;
+    if any clip has another dtype the whole batch goes through np.double() like the reference's :567 (8 B/sample).
 
     This is what MidTermFeatures.directory_feature_extraction (:140-221) does one file at a time.
     """
     window = int(window)
     step = int(step)
-    clips = [np.ascontiguousarray(s, dtype=np.int16) for s in signals]
-    if not clips:
-        raise ValueError("need at least one clip")
+    clips, as_i16 = _batch_clips(signals)
     names = _feature_names(deltas)
     lib = _ffi.lib()
     lens = np.array([c.shape[0] for c in clips], dtype=np.int64)
@@ -101,9 +112,9 @@ def feature_extraction_batch(signals, sampling_rate, window, step, deltas=True):
     out_off = np.zeros(len(clips), dtype=np.int64)
     np.cumsum(F * frames[:-1], out=out_off[1:])
     out = _ffi.result_array((int(F * frames.sum()),))
-    _ffi.check(lib.paa_st_features_batch_i16(_ffi.as_i16p(packed), _ffi.as_i64p(offsets), len(clips),
-                                             float(sampling_rate), window, step, 1 if deltas else 0,
-                                             _ffi.as_f64p(out), _ffi.as_i64p(out_off)))
+    fn = lib.paa_st_features_batch_i16 if as_i16 else lib.paa_st_features_batch_f64
+    _ffi.check(fn(_ffi.as_i16p(packed) if as_i16 else _ffi.as_f64p(packed), _ffi.as_i64p(offsets), len(clips),
+                  float(sampling_rate), window, step, 1 if deltas else 0, _ffi.as_f64p(out), _ffi.as_i64p(out_off)))
     res = [out[int(o):int(o) + F * int(t)].reshape(F, int(t)) for o, t in zip(out_off, frames)]
     return res, names
 
@@ -116,15 +127,14 @@ def spectrogram(signal, sampling_rate, window, step, plot=False, show_progress=F
     """
     window = int(window)
     step = int(step)
-    kind, sig = _mono_only(signal)
+    kind, sig = _ffi.classify_signal(signal)
     lib = _ffi.lib()
     num_fft = int(window / 2)
     rows = int(lib.paa_spectrogram_rows(sig.shape[0], window, step, None)) if window >= 1 and step >= 1 else 0
     if rows < 1:
         raise ValueError("negative dimensions are not allowed")     # np.zeros((<=0, num_fft)) at :413
     specgram = _ffi.result_array((rows, num_fft))
-    fn = lib.paa_spectrogram_i16 if kind == 0 else lib.paa_spectrogram_f64
-    ptr = _ffi.as_i16p(sig) if kind == 0 else _ffi.as_f64p(sig)
+    fn, ptr = _spec_call(lib, "spectrogram", kind, sig)
     _ffi.check(fn(ptr, sig.shape[0], float(sampling_rate), window, step, _ffi.as_f64p(specgram)))
     freq_axis = [float((f + 1) * sampling_rate) / (2 * num_fft) for f in range(specgram.shape[1])]
     time_axis = [float(t * step) / sampling_rate for t in range(specgram.shape[0])]
@@ -138,14 +148,13 @@ def chromagram(signal, sampling_rate, window, step, plot=False, show_progress=Fa
     """Chromagram (reference :324-386).  Returns (chromogram [T x 12], time_axis, freq_axis)."""
     window = int(window)
     step = int(step)
-    kind, sig = _mono_only(signal)
+    kind, sig = _ffi.classify_signal(signal)
     lib = _ffi.lib()
     rows = int(lib.paa_chromagram_rows(sig.shape[0], window, step, None)) if window >= 1 and step >= 1 else 0
     if rows < 1:
         raise ValueError("negative dimensions are not allowed")     # np.zeros at :347
     chromogram = np.empty((rows, 12), dtype=np.float64)
-    fn = lib.paa_chromagram_i16 if kind == 0 else lib.paa_chromagram_f64
-    ptr = _ffi.as_i16p(sig) if kind == 0 else _ffi.as_f64p(sig)
+    fn, ptr = _spec_call(lib, "chromagram", kind, sig)
     _ffi.check(fn(ptr, sig.shape[0], float(sampling_rate), window, step, _ffi.as_f64p(chromogram)))
     freq_axis = list(_CHROMA_NAMES)
     time_axis = [(t * step) / sampling_rate for t in range(chromogram.shape[0])]

@@ -60,6 +60,12 @@ _SIGNATURES = {
     "paa_spectrogram_f64": (C.c_int, [c_f64p, C.c_int64, C.c_double, C.c_int, C.c_int, c_f64p]),
     "paa_chromagram_i16": (C.c_int, [c_i16p, C.c_int64, C.c_double, C.c_int, C.c_int, c_f64p]),
     "paa_chromagram_f64": (C.c_int, [c_f64p, C.c_int64, C.c_double, C.c_int, C.c_int, c_f64p]),
+    "paa_spectrogram_stereo_i16": (C.c_int, [c_i16p, C.c_int64, C.c_double, C.c_int, C.c_int, c_f64p]),
+    "paa_chromagram_stereo_i16": (C.c_int, [c_i16p, C.c_int64, C.c_double, C.c_int, C.c_int, c_f64p]),
+    "paa_st_features_batch_f64": (C.c_int, [c_f64p, c_i64p, C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int,
+                                            c_f64p, c_i64p]),
+    "paa_mid_features_batch_f64": (C.c_int, [c_f64p, c_i64p, C.c_int64, C.c_double, C.c_int, C.c_int,
+                                             C.c_int64, C.c_int64, c_f64p, c_i64p, c_f64p, c_i64p]),
     "paa_st_features_batch_i16": (C.c_int, [c_i16p, c_i64p, C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int,
                                             c_f64p, c_i64p]),
     "paa_mid_features_batch_i16": (C.c_int, [c_i16p, c_i64p, C.c_int64, C.c_double, C.c_int, C.c_int,

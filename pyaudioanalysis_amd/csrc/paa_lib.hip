@@ -20,6 +20,7 @@
 #include "../../include/paa_hip.h"
 #include "kernels_aux.hpp"
 #include "kernels_big.hpp"
+#include "kernels_ct.hpp"
 #include "kernels_fast.hpp"
 #include "kernels_generic.hpp"
 #include "kernels_reg.hpp"
@@ -363,6 +364,8 @@ struct paa_plan {
     size_t lds = 0;
     int fast = 0;                    // 1: specialised kernel
     FastLaunch fl;
+    int ct = 0;                      // 1: register-FFT family for windows 2 RA RB (kernels_ct.hpp); table blob in d_gen_blob
+    ct::CtLaunch cl;
     std::string kernel_name;
 };
 
@@ -475,7 +478,16 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         p->fast = rc;
     }
     int run, run_quantum = 4;
-    if (!p->fast && !g_force_generic && tab->fft.even && reg::reg_supported(window)) {
+    int run_halo = 0;                // frames a run with t0 > 0 starts early INSIDE its first iteration (ct kernels)
+    if (!p->fast && !g_force_generic) {
+        std::vector<unsigned char> blob;
+        if (ct::ct_select(window, mode, fs, tab->fft, mode == 0 ? &tab->mel : nullptr, mode != 1 ? &tab->chroma : nullptr,
+                          p->cl, blob)) {
+            if ((rc = upload_pooled(&p->d_gen_blob, blob.data(), blob.size()))) return rc;
+            p->ct = 1;
+        }
+    }
+    if (!p->fast && !p->ct && !g_force_generic && tab->fft.even && reg::reg_supported(window)) {
         // windows 2 R1 R2 with coprime primes (config 5: 1102): several frames per wave, prime-factor FFT in registers
         using SH = reg::Shape1102;
         std::vector<unsigned char> blob;
@@ -486,7 +498,15 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
             p->reg = 1;
         }
     }
-    if (p->reg) {
+    if (p->ct) {
+        // one wave per run, 4 frames per iteration; a run with t0 > 0 starts 1 frame early (2 with deltas) inside its first
+        // iteration, so the first run of a clip gets `run` frames and the others run - halo: every run is whole iterations
+        run_quantum = 4;
+        run_halo = (mode == 0) ? (deltas ? 2 : 1) : 0;
+        run = choose_run_cap(p->clips, 4, 16, 256, 0, p->cl.waves, g_num_cu);
+        p->lds = p->cl.lds;
+        p->kernel_name = p->cl.name;
+    } else if (p->reg) {
         p->lds = (size_t)p->rl.table_bytes + (size_t)p->rl.waves * p->rl.wave_bytes;
         // runs are multiples of Q frames (halo = one iteration); see choose_run_cap
         const int q = reg::Shape1102::Q;
@@ -524,9 +544,11 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         const long long T = p->clips[c].T;
         if (T <= 0) continue;
         const int len = clip_run_length(T, run, run_quantum);          // equal runs per clip
-        for (long long t0 = 0; t0 < T; t0 += len) {
-            Tile tl; tl.clip = (int)c; tl.t0 = (int)t0; tl.cnt = (int)std::min<long long>(len, T - t0); tl.pad = 0;
+        for (long long t0 = 0; t0 < T;) {
+            const long long want = (t0 > 0) ? len - run_halo : len;
+            Tile tl; tl.clip = (int)c; tl.t0 = (int)t0; tl.cnt = (int)std::min<long long>(want, T - t0); tl.pad = 0;
             tiles.push_back(tl);
+            t0 += tl.cnt;
         }
     }
     p->n_tiles = (long long)tiles.size();
@@ -703,6 +725,13 @@ extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *
     if (plan->fast) {
         rc = fast_launch(plan->fl, plan->P, plan->tab->fast, d_packed, plan->d_clips, plan->d_norms, plan->d_tiles,
                          plan->n_tiles, d_out, cs());
+        if (rc) return fail(PAA_ERR_HIP, "launch of %s failed: %s", plan->kernel_name.c_str(),
+                            hipGetErrorString(hipGetLastError()));
+        return PAA_OK;
+    }
+    if (plan->ct) {
+        rc = ct::ct_launch(plan->cl, plan->sample_kind, plan->P, plan->d_gen_blob, d_packed, plan->d_clips, plan->d_norms,
+                           plan->d_tiles, plan->n_tiles, d_out, cs());
         if (rc) return fail(PAA_ERR_HIP, "launch of %s failed: %s", plan->kernel_name.c_str(),
                             hipGetErrorString(hipGetLastError()));
         return PAA_OK;
@@ -1275,6 +1304,19 @@ extern "C" int paa_st_features_batch_i16(const int16_t *packed, const int64_t *o
     if (!out) return fail(PAA_ERR_ARG, "null out");
     return run_host_st(packed, offsets, n_clips, 0, fs, window, step, deltas, out, out_offsets, 0, 0, nullptr, nullptr);
 }
+extern "C" int paa_st_features_batch_f64(const double *packed, const int64_t *offsets, int64_t n_clips, double fs,
+                                         int window, int step, int deltas, double *out, const int64_t *out_offsets) {
+    if (!out) return fail(PAA_ERR_ARG, "null out");
+    return run_host_st(packed, offsets, n_clips, 1, fs, window, step, deltas, out, out_offsets, 0, 0, nullptr, nullptr);
+}
+extern "C" int paa_mid_features_batch_f64(const double *packed, const int64_t *offsets, int64_t n_clips, double fs,
+                                          int window, int step, int64_t mid_ratio, int64_t mid_step_ratio,
+                                          double *mid_out, const int64_t *mid_out_offsets, double *st_out,
+                                          const int64_t *st_out_offsets) {
+    if (!mid_out) return fail(PAA_ERR_ARG, "null mid_out");
+    return run_host_st(packed, offsets, n_clips, 1, fs, window, step, 1, st_out, st_out_offsets, mid_ratio,
+                       mid_step_ratio, mid_out, mid_out_offsets);
+}
 extern "C" int paa_mid_features_batch_i16(const int16_t *packed, const int64_t *offsets, int64_t n_clips, double fs,
                                           int window, int step, int64_t mid_ratio, int64_t mid_step_ratio,
                                           double *mid_out, const int64_t *mid_out_offsets, double *st_out,
@@ -1301,15 +1343,26 @@ static int run_host_spec(const void *signal, int64_t n, int sample_kind, double 
     }
     if (rc) return rc;
     std::unique_ptr<paa_plan, void (*)(paa_plan *)> guard(plan, plan_free_synced);
-    const size_t esz = sample_kind == 0 ? 2 : 8;
+    // sample_kind 2: the host buffer holds interleaved stereo int16 (4 bytes per frame); the device turns it into int32
+    // sums L + R before anything else (fused stereo_to_mono, audioBasicIO.py:156-168)
+    const size_t esz = sample_kind == 0 ? 2 : (sample_kind == 2 ? 4 : 8);
     {
         std::lock_guard<std::mutex> lk(g_mu);
         if ((rc = scratch_reserve(lane.l->in, (size_t)n * esz + 64))) return rc;
+        if (sample_kind == 2 && (rc = scratch_reserve(lane.l->in2, (size_t)n * 4 + 64))) return rc;
         if ((rc = scratch_reserve(lane.l->out, (size_t)plan->out_doubles * 8))) return rc;
     }
     HIP_TRY(hipMemcpyAsync(lane.l->in.p, signal, (size_t)n * esz, hipMemcpyHostToDevice, cs()));
+    const void *d_samples = lane.l->in.p;
+    if (sample_kind == 2) {
+        const unsigned gs = (unsigned)std::min<long long>(4096, (n / 4 + 255) / 256 + 1);
+        hipLaunchKernelGGL(stereo_sum_kernel, dim3(gs), dim3(256), 0, cs(), (const int16_t *)lane.l->in.p, (long long)n,
+                           (int *)lane.l->in2.p);
+        HIP_TRY(hipGetLastError());
+        d_samples = lane.l->in2.p;
+    }
     HIP_TRY(hipMemsetAsync(lane.l->out.p, 0, (size_t)plan->out_doubles * 8, cs()));   // trailing rows stay 0 (:413-422)
-    if ((rc = paa_plan_execute(plan, lane.l->in.p, (double *)lane.l->out.p))) return rc;
+    if ((rc = paa_plan_execute(plan, d_samples, (double *)lane.l->out.p))) return rc;
     if (mode == 2) {
         // the reference FFTs a truncated last frame when fewer than `window` samples remain (:349-355)
         int64_t filled = 0;
@@ -1321,7 +1374,7 @@ static int run_host_spec(const void *signal, int64_t n, int sample_kind, double 
             if (last_len < window / 2)
                 return fail(PAA_ERR_CHROMA_VALUE, "truncated last chromagram frame shorter than num_fft "
                             "(ValueError in the reference, ShortTermFeatures.py:288)");
-            rc = launch_chroma_tail(plan->P, sample_kind, lane.l->in.p, pos, n, (int)(filled - plan->clips[0].T), plan->d_norms,
+            rc = launch_chroma_tail(plan->P, sample_kind, d_samples, pos, n, (int)(filled - plan->clips[0].T), plan->d_norms,
                                     (double *)lane.l->out.p + (long long)plan->clips[0].T * 12, cs());
             if (rc == -2) return fail(PAA_ERR_UNSUPPORTED, "truncated chromagram tail frame with window %d does not fit LDS", window);
             if (rc) return fail(PAA_ERR_HIP, "chromagram tail launch failed");
@@ -1343,6 +1396,12 @@ extern "C" int paa_chromagram_i16(const int16_t *s, int64_t n, double fs, int w,
 }
 extern "C" int paa_chromagram_f64(const double *s, int64_t n, double fs, int w, int st, double *out) {
     return run_host_spec(s, n, 1, fs, w, st, 2, out);
+}
+extern "C" int paa_spectrogram_stereo_i16(const int16_t *lr, int64_t n, double fs, int w, int st, double *out) {
+    return run_host_spec(lr, n, 2, fs, w, st, 1, out);
+}
+extern "C" int paa_chromagram_stereo_i16(const int16_t *lr, int64_t n, double fs, int w, int st, double *out) {
+    return run_host_spec(lr, n, 2, fs, w, st, 2, out);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -104,3 +104,42 @@ def test_config5_spectrogram_chromagram_600s(gpu_lib, cfg5_clip, capsys):
         c = grid.reshape(-1, 12).sum(axis=0)
         ref[m] = c / O.EPS if P.sum() == 0 else c / P.sum()
     assert_parity(np.ascontiguousarray(chroma[pick].T), np.ascontiguousarray(ref.T), "config 5 chromagram rows")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# full-matrix checks at BASELINE sizes against the plain-C oracle (oracle/paa_oracle.c: ~45 k frames/s on one core)
+# ---------------------------------------------------------------------------------------------------------
+def _ill_mask(signal, fs, window, step):
+    from test_ct_kernels_gpu import ill_mask
+    return ill_mask(signal, fs, window, step)
+
+
+@pytest.mark.parametrize("deltas", [False, True], ids=["34rows", "68rows"])
+def test_config2_one_hour_full_matrix(gpu_lib, deltas):
+    """BASELINE config 2 itself: the whole (34 | 68) x 143 999 matrix of the seeded 1-hour clip against the C oracle,
+    contract and tight gate on every entry (ShortTermFeatures.py:608-682)."""
+    import c_oracle
+    x = synth_clip(2, 3600 * FS)
+    F, _ = ShortTermFeatures.feature_extraction(x, FS, 800, 400, deltas)
+    assert F.shape == (68 if deltas else 34, 143999)
+    ref = c_oracle.feature_extraction(x, FS, 800, 400, deltas)
+    assert_parity(F, ref, "config 2 full matrix", ill=_ill_mask(x, FS, 800, 400))
+
+
+def test_config5_full_matrices(gpu_lib, cfg5_clip, capsys):
+    """Config 5: every frame of the 600 s stereo clip's feature matrix, and every row of the spectrogram and chromagram of
+    its first 60 s, against the C oracle."""
+    import c_oracle
+    fs, xs, mono, xn = cfg5_clip
+    W, S = 1102, 441
+    F, _ = ShortTermFeatures.feature_extraction(xs, fs, W, S, deltas=False)
+    ref = c_oracle.feature_extraction(mono, fs, W, S, False)
+    assert_parity(F, ref, "config 5 features, all frames", ill=_ill_mask(mono, fs, W, S))
+    n60 = 60 * fs
+    spec, _, _ = ShortTermFeatures.spectrogram(xs[:n60], fs, W, S)
+    capsys.readouterr()
+    assert_parity(np.ascontiguousarray(spec.T), np.ascontiguousarray(c_oracle.spectrogram(mono[:n60], W, S).T),
+                  "config 5 spectrogram, 60 s, all rows")
+    chroma, _, _ = ShortTermFeatures.chromagram(xs[:n60], fs, W, S)
+    assert_parity(np.ascontiguousarray(chroma.T), np.ascontiguousarray(c_oracle.chromagram(mono[:n60], fs, W, S).T),
+                  "config 5 chromagram, 60 s, all rows")
