@@ -1,4 +1,11 @@
-mkdir -p gpurun_out/r03b
-(timeout 900 python -m pytest tests/test_ct_kernels_gpu.py -m gpu -q -x --no-header -rN 2>&1 | tail -40) > gpurun_out/r03b/ct.log
-(timeout 900 python -m pytest tests -m gpu -q --no-header 2>&1 | tail -40) > gpurun_out/r03b/all.log
-tail -25 gpurun_out/r03b/ct.log; echo ======; tail -25 gpurun_out/r03b/all.log
+#!/bin/bash
+# one GPU pass of a round: the whole -m gpu suite, kernel-resident timing of every non-headline case, optional profiles
+# usage: bash scripts/gpu_round.sh <tag> [profile-case ...]
+tag=${1:-r03}; shift
+out=gpurun_out/$tag; mkdir -p $out
+(timeout 1200 python -m pytest tests -m gpu -q --no-header 2>&1 | tail -60) > $out/tests.log
+for c in reg_features reg_features_stereo reg_spectrogram reg_spectrogram_stereo reg_chromagram ct_640 ct_640_spectrogram ct_800_f64 ct_800_stereo ct_400 ct_320 generic_2400 generic_2205 mid_stats; do
+  timeout 300 python scripts/kernel_loop.py --case $c --launches 50 2>&1 | tail -1
+done > $out/cases.jsonl
+for c in "$@"; do timeout 900 bash scripts/profile_kernel.sh $tag $c > $out/prof_$c.log 2>&1; done
+tail -12 $out/tests.log; cat $out/cases.jsonl | cut -c1-330

@@ -1,0 +1,59 @@
+"""Fold the rocprofv3 (rocpd sqlite) outputs of scripts/profile_kernel.sh into one JSON summary: kernel-trace statistics,
+per-dispatch counters of the case's feature kernel, HBM traffic (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+gfx950, WRITE_SIZE as reported) and its ratio to the algorithmic bytes of SURVEY 8d."""
+import json
+import os
+import sqlite3
+import sys
+
+
+def main(prof_dir, out_path):
+    out = {"source": os.path.basename(prof_dir.rstrip("/"))}
+    line = None
+    for ln in open(os.path.join(prof_dir, "bench_trace.log")):
+        if ln.startswith("{"):
+            line = json.loads(ln)
+    if line is None:
+        raise SystemExit("no result line in %s/bench_trace.log" % prof_dir)
+    out["run_under_trace"] = line
+    stem = line["kernel"].replace("_w8", "")
+    like = {"st_reg_29x19": "%st_reg_kernel%", "spectrogram_reg_29x19": "%st_reg_kernel%", "chromagram_reg_29x19": "%st_reg_kernel%",
+            "st_generic": "%st_generic_kernel%"}.get(stem, "%st_ct_kernel%" if "_ct_" in stem else "%" + stem + "%")
+    if line["case"] == "mid_stats":
+        like = "%mid_stats_kernel%"
+    out["kernel_like"] = like
+    con = sqlite3.connect(os.path.join(prof_dir, "trace", "trace_results.db"))
+    out["kernel_trace_stats"] = [dict(name=r[0][:160], calls=r[1], total_us=r[2], avg_us=r[3], pct=r[4])
+                                 for r in con.execute("select * from top_kernels")][:8]
+    pm = {}
+    for n in sorted(os.listdir(prof_dir)):
+        db = os.path.join(prof_dir, n, "pmc_results.db")
+        if not os.path.exists(db):
+            continue
+        con = sqlite3.connect(db)
+        nd = con.execute("select count(distinct dispatch_id) from pmc_events where name like ?", (like,)).fetchone()[0]
+        for r in con.execute("select counter_name, sum(counter_value) from pmc_events where name like ? group by counter_name", (like,)):
+            pm[r[0]] = {"per_dispatch": r[1] / max(nd, 1), "dispatches": nd}
+    out["pmc"] = pm
+    avg = [k for k in out["kernel_trace_stats"] if like.strip("%") in k["name"]]
+    if avg:
+        out["kernel_avg_us"] = avg[0]["avg_us"]
+        out["achieved_GBps_kernel"] = line["algorithmic_bytes_per_launch"] / (avg[0]["avg_us"] * 1e-6) / 1e9
+        out["hbm_frac"] = out["achieved_GBps_kernel"] / 8000.0
+    if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+        fetch = pm["FETCH_SIZE"]["per_dispatch"] * 1024.0 * 2.0
+        write = pm["WRITE_SIZE"]["per_dispatch"] * 1024.0
+        out["traffic"] = {"fetch_bytes_corrected_x2": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
+                          "algorithmic_bytes_per_launch": line["algorithmic_bytes_per_launch"],
+                          "traffic_over_algorithmic": (fetch + write) / line["algorithmic_bytes_per_launch"]}
+    if "SQ_LDS_BANK_CONFLICT" in pm and "SQ_LDS_IDX_ACTIVE" in pm and pm["SQ_LDS_IDX_ACTIVE"]["per_dispatch"] > 0:
+        out["lds_bank_conflict_ratio"] = pm["SQ_LDS_BANK_CONFLICT"]["per_dispatch"] / pm["SQ_LDS_IDX_ACTIVE"]["per_dispatch"]
+    if "SQ_ACTIVE_INST_VALU" in pm and "SQ_BUSY_CYCLES" in pm and pm["SQ_BUSY_CYCLES"]["per_dispatch"] > 0:
+        # as DESIGN 5: ACTIVE_INST_VALU x 4 / 1024 SIMDs / (BUSY_CYCLES / 32)
+        out["valu_issue_fraction"] = pm["SQ_ACTIVE_INST_VALU"]["per_dispatch"] * 4.0 / 1024.0 / (pm["SQ_BUSY_CYCLES"]["per_dispatch"] / 32.0)
+    json.dump(out, open(out_path, "w"), indent=1)
+    print(json.dumps({k: out[k] for k in out if k not in ("pmc", "kernel_trace_stats")}, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

@@ -30,6 +30,31 @@ def ill_mask(signal, fs, window, step, factor=1e4):
     return out
 
 
+def reference_matrix(mono, fs, window, step, deltas):
+    """The full reference matrix: the plain-C oracle (45 k frames/s) for every frame, except the frames of DIGITAL SILENCE
+    (all samples equal), which come from the NumPy oracle.  On such frames the reference's FFT (pocketfft) returns exact
+    zeros for the non-DC bins and log10(E + eps) of the mel bands resolves that; oracle/paa_oracle.c has its own DFT and
+    leaves 1e-17 there (-99.00180463 instead of -99.00180475 in mfcc_1) -- the NumPy oracle, which runs the same
+    pocketfft as the reference and is pinned to it at 1e-9, is the authority for those frames.  Delta rows are
+    differences of the base rows (:668-680) and are re-formed around the patched frames."""
+    ref = c_oracle.feature_extraction(mono, fs, window, step, deltas)
+    x = np.asarray(mono, dtype=np.float64)
+    frames = np.lib.stride_tricks.sliding_window_view(x, window)[::step]
+    silent = np.flatnonzero(frames.max(axis=1) == frames.min(axis=1))
+    if len(silent):
+        xn = O.normalize_clip(mono)
+        tab = O.Tables(fs, window)
+        spec = lambda t: O.magnitude_spectrum(xn[t * step:t * step + window], tab.nfft)
+        for t in silent:
+            X = spec(t)
+            ref[:34, t] = O.frame_vector(xn[t * step:t * step + window], X, X if t == 0 else spec(t - 1), tab)
+        if deltas:
+            for t in sorted(set(silent) | set(silent + 1)):
+                if t < ref.shape[1]:
+                    ref[34:, t] = 0.0 if t == 0 else ref[:34, t] - ref[:34, t - 1]
+    return ref
+
+
 def make_signal(kind, seed, seconds, fs):
     """kind: 'i16' mono PCM, 'f64' what stereo_to_mono returns for a stereo file (.5 fractions), 'stereo' (n, 2) int16,
     'unit' a float signal in [-1, 1] (not a multiple of anything)"""
@@ -94,7 +119,7 @@ CASES = [
 def test_full_matrix_against_c_oracle(gpu_lib, fs, window, step, kind, seconds, deltas):
     sig, mono = make_signal(kind, 7000 + window + step, seconds, fs)
     F, names = ShortTermFeatures.feature_extraction(sig, fs, window, step, deltas)
-    ref = c_oracle.feature_extraction(mono, fs, window, step, deltas)
+    ref = reference_matrix(mono, fs, window, step, deltas)
     assert F.shape == ref.shape and len(names) == ref.shape[0]
     assert_parity(F, ref, "%s %d/%d @%d" % (kind, window, step, fs), ill=ill_mask(mono, fs, window, step))
     if deltas:
@@ -137,7 +162,7 @@ def test_degenerate_clips_through_the_family(gpu_lib):
         ref, _ = O.feature_extraction(sig, fs, W, S)
         assert_parity(F, ref, label, sig=(sig, fs, W, S))
     z, _ = ShortTermFeatures.feature_extraction(cases["zeros"], fs, W, S, deltas=False)
-    assert abs(z[8, 0] - (-99.00180474843068)) < 1e-9 and np.all(z[9:21] == 0.0)      # 40 log10(eps) / sqrt(40)
+    assert abs(z[8, 0] - 40.0 * np.log10(O.EPS) / np.sqrt(40.0)) < 1e-9 and np.all(np.abs(z[9:21]) < 1e-12)   # mfcc of silence
     with pytest.raises(ValueError):
         ShortTermFeatures.feature_extraction(synth_clip(84, W - 1, fs), fs, W, S)
 
@@ -150,7 +175,7 @@ def test_ragged_batches_and_mid_term_through_the_family(gpu_lib):
     for c, r in zip(clips, res):
         single, _ = ShortTermFeatures.feature_extraction(c, fs, W, S)
         assert np.array_equal(single, r)
-        assert_parity(r, c_oracle.feature_extraction(c, fs, W, S, True), "ragged batch", ill=ill_mask(c, fs, W, S))
+        assert_parity(r, reference_matrix(c, fs, W, S, True), "ragged batch", ill=ill_mask(c, fs, W, S))
     # float64 clips batch too (what the directory walkers do with stereo / non-int16 files)
     fclips = [O.stereo_to_mono(synth_clip(8700 + i, n, fs, stereo=True)) for i, n in enumerate(lens[1:5])]
     fres, _ = ShortTermFeatures.feature_extraction_batch(fclips, fs, 800, 400, deltas=True)
