@@ -38,6 +38,10 @@ namespace ct {
 
 using f800::dft4r;
 using f800::dft5r;
+#if defined(PAA_F800_TIMING) || defined(PAA_F800_TRACE)
+using f800::g_phase_cycles;        // per-phase cycle accounting of diagnostic builds (PAA_T0 / PAA_TICK / PAA_TEND)
+using f800::g_wave_trace;
+#endif
 
 // ---- shapes ---------------------------------------------------------------------------------------------------
 template <int RA_, int RB_>
@@ -239,6 +243,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_ct_kernel(PlanDev P, TabLa
     double hold[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     double holdd[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     int n_done = 0;
+    PAA_T0()
     for (int q0 = (r0 >= HALO) ? r0 - HALO : 0; q0 < t_end; q0 += QUAD) {
         slot0 = (slot0 + 4) % 5;
         if (NW != 4) asm volatile("" : "+v"(g), "+v"(i));
@@ -271,6 +276,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_ct_kernel(PlanDev P, TabLa
                 v[r] = make_double2(fma(x.x, sc, -mean), fma(x.y, sc, -mean));
             }
         }
+#ifdef PAA_F800_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        PAA_TICK(0)
         // ---------------- time domain (ShortTermFeatures.py:22-51) on the same registers
         double e_tot = 0.0, ent_e = 0.0;
         int zc = 0;
@@ -316,9 +325,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_ct_kernel(PlanDev P, TabLa
             const double se = fast_div(mine, e_tot + kEps);
             ent_e = group_sum((i < 10) ? -(se * fast_log2(se + kEps)) : 0.0);
         }
+        PAA_TICK(1)
         // ---------------- pass 1: radix-RA over r
         if (act1) Dft<RA>::template run<(NW != 4)>(v);
         wsync();        // the previous quad's readers of the slots are done
+        PAA_TICK(2)
 
         // exchange through the quad's 4 spectrum slots: real plane, then imaginary plane; element (j, q) at RAP j + q
         double ax[RB], ay[RB], bx[RB], by[RB];
@@ -341,6 +352,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_ct_kernel(PlanDev P, TabLa
             for (int r = 0; r < RB; ++r) { ay[r] = pl[pa + RAP * r]; by[r] = pl[pb + RAP * r]; }
             wsync();
         }
+        PAA_TICK(3)
         // ---------------- pass 2 + real-FFT recombination + magnitude (ShortTermFeatures.py:617-621)
         if (act2) {
             double2 a[RB], b[RB];
@@ -396,6 +408,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_ct_kernel(PlanDev P, TabLa
         wsync();
         ++n_done;
         PAA_CT_PACE(-1)
+        PAA_TICK(4)
 
         if (MODE == 1) {
             // ---------------- spectrogram rows (ShortTermFeatures.py:422): one row at a time with the whole wave
@@ -499,6 +512,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_ct_kernel(PlanDev P, TabLa
             const double sf = fast_div(hi_ - lo_, sP + kEps);
             ent_f = group_sum((i < 10) ? -(sf * fast_log2(sf + kEps)) : 0.0);
         }
+        PAA_TICK(5)
         // centroid, spread, flux (:57-82, :110-124)
         const double r = (mx == 0.0) ? 1.0 / kEps : fast_div(1.0, mx);
         const double den = sX * r + kEps;
@@ -538,6 +552,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_ct_kernel(PlanDev P, TabLa
             }
             first = group_min_i(first);
         }
+        PAA_TICK(6)
         // MFCC (:236-254): per-lane padded mel lists: class 0 = filter i, class 1 = filter 16 + i, class 2 = one half of
         // filter 32 + (i & 7); the halves meet through a row rotation by 8
         double *mg = msp + 40 * g;
@@ -578,6 +593,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_ct_kernel(PlanDev P, TabLa
             const double l2 = fast_log10(acc2 + kEps);
             if (i < 8) mg[32 + i] = l2;
         }
+        PAA_TICK(7)
         // chroma (:277-321): lane i < 12 = pitch class i, padded gather list in ascending slot order
         double chroma = 0.0;
         {
@@ -595,6 +611,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_ct_kernel(PlanDev P, TabLa
             if (i >= 12) chroma = 0.0;
         }
         wsync();
+        PAA_TICK(8)
         double *fg = fv + FV * g;
         if (i < 13) {
             const double *dm = t_dct + 41 * i;        // rows padded to 41 doubles: conflict-free across lanes
@@ -632,6 +649,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_ct_kernel(PlanDev P, TabLa
             if (i == 14) fg[33] = fast_sqrt(var);
         }
         wsync();
+        PAA_TICK(9)
         // ---------------- store: lane = feature row, 4 consecutive frames
         if (lane < kBase) {
             double vq[QUAD];
@@ -650,7 +668,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_ct_kernel(PlanDev P, TabLa
             vlast = vq[QUAD - 1];
         }
         wsync();
+        PAA_TICK(10)
     }
+    PAA_TEND()
 #undef PAA_CT_PACE
     if (NW == 8 && lane == 0) pace[8 + wave] = 0x7fffffff;
 }

@@ -16,7 +16,11 @@ pytestmark = pytest.mark.gpu
 
 
 def ill_mask(signal, fs, window, step, factor=1e4):
-    """paa_oracle.ill_conditioned_mfcc_frames, vectorised over frames (same rule: a numerically empty mel band)."""
+    """paa_oracle.ill_conditioned_mfcc_frames (a numerically empty mel band: the reference's own MFCCs are a function of
+    its FFT's round-off), vectorised over frames.  Frames of digital silence are re-examined one by one through the
+    oracle's own single-frame FFT call: whether pocketfft returns exact zeros for a CONSTANT frame or leaves 1e-17 in the
+    non-DC bins depends on the constant (and its batched transform need not round like its single one); when it leaves
+    something, mfcc_2.. of the reference read 5e-8 instead of 0 and the frame is flagged like any other empty band."""
     x = O.normalize_clip(signal)
     tab = O.Tables(fs, window)
     frames = np.lib.stride_tricks.sliding_window_view(x, window)[::step]
@@ -25,6 +29,10 @@ def ill_mask(signal, fs, window, step, factor=1e4):
         X = np.abs(np.fft.fft(frames[a:a + 4096], axis=1))[:, :tab.nfft] / tab.nfft
         E = X @ tab.mel.T
         mask[a:a + 4096] = np.any((E > 0) & (E < factor * O.EPS), axis=1)
+    raw = np.lib.stride_tricks.sliding_window_view(np.asarray(signal, dtype=np.float64), window)[::step]
+    for t in np.flatnonzero(raw.max(axis=1) == raw.min(axis=1)):
+        E = np.dot(O.magnitude_spectrum(x[t * step:t * step + window], tab.nfft), tab.mel.T)
+        mask[t] = bool(np.any((E > 0) & (E < factor * O.EPS)))
     out = mask.copy()
     out[1:] |= mask[:-1]
     return out
