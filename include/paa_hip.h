@@ -91,8 +91,9 @@ int paa_st_features_f64(const double *signal, int64_t n, double fs, int window, 
                         int deltas, double *out);
 
 /* interleaved stereo int16 (L0 R0 L1 R1 ..., n frames): audioBasicIO.stereo_to_mono (audioBasicIO.py:156-168) is
- * fused on the device as exact int32 sums L + R, so stereo files cost 4 B/sample over PCIe instead of the 8 B of
- * the float64 mono copy the reference makes on the host                                                  */
+ * fused into the kernels' sample loads (L + R summed exactly as it is fetched, scaled by 2^-16): the mono signal is
+ * never materialised; stereo files cost 4 B/sample over PCIe and HBM instead of the 8 B of the float64 mono copy the
+ * reference makes on the host                                                                              */
 int paa_st_features_stereo_i16(const int16_t *interleaved, int64_t n, double fs, int window, int step,
                                int deltas, double *out);
 int paa_mid_features_stereo_i16(const int16_t *interleaved, int64_t n, double fs, int window, int step,
@@ -145,7 +146,9 @@ int paa_mid_features_batch_i16(const int16_t *packed, const int64_t *offsets, in
 /* ---- device-resident plans (bench / pipelines: samples and results stay in HBM) --------- */
 typedef struct paa_plan paa_plan_t;
 /* offsets: n_clips+1 HOST sample offsets into the packed device buffer.  sample_kind 0 = int16,
- * 1 = float64, 2 = int32 stereo sums L + R (scaled by 2^-16).  The plan owns the tables, the tile list and the per-clip statistics.        */
+ * 1 = float64, 2 = interleaved stereo int16 (offsets count stereo frames of 4 bytes; L + R is formed in the kernels'
+ * loads and scaled by 2^-16 = stereo_to_mono followed by :568).  The plan owns the tables, the tile list and the
+ * per-clip statistics.                                                                                      */
 int paa_plan_create(const int64_t *offsets, int64_t n_clips, int sample_kind, double fs,
                     int window, int step, int deltas, paa_plan_t **out_plan);
 /* spectrogram (mode 1) / chromagram (mode 2) rows kept in HBM (ShortTermFeatures.py:389-452, :324-386); mode 0 = features
@@ -213,6 +216,9 @@ int paa_comm_destroy(void);
 /* gather variable-sized double blocks to rank `root`: counts[world] doubles per rank (host);
  * d_recv (root only) receives them back to back in rank order.  Asynchronous on the stream. */
 int paa_comm_gather_f64(const double *d_send, const int64_t *counts, int root, double *d_recv);
+/* the same with explicit placement: rank r's block lands at d_recv + displs[r] (in doubles) on the root, so that a job
+ * cut into chunks can gather chunk k while chunk k+1 is being computed and still end with one rank-major buffer   */
+int paa_comm_gatherv_f64(const double *d_send, const int64_t *counts, const int64_t *displs, int root, double *d_recv);
 int paa_comm_barrier(void);
 
 /* ---- introspection for tests (host tables built by the reference's rules) ----------------- */

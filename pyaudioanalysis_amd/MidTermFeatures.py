@@ -202,8 +202,9 @@ def mid_and_beat_batch(signals, sampling_rate, mid_window, mid_step, short_windo
     is given, an (n_clips, 2) array of (bpm, confidence) from the GPU beat kernel.  The short-term matrices
     never leave HBM.  The clips are either all mono (1-D int16), all interleaved stereo ((n, 2) int16) or all float64
     (1-D: what np.double() / stereo_to_mono make of every other file, ShortTermFeatures.py:567): stereo clips are
-    uploaded as the exact int32 sums L + R (4 B/sample) and scaled by 2^-16 on the device, which is
-    audioBasicIO.stereo_to_mono (audioBasicIO.py:156-168) followed by the 2^-15 scaling of :568."""
+    uploaded interleaved as they come from the file (4 B per stereo frame); the kernels form L + R in their sample
+    loads and scale by 2^-16, which is audioBasicIO.stereo_to_mono (audioBasicIO.py:156-168) followed by the 2^-15
+    scaling of :568 -- no pass over the samples on the host."""
     ratio, step_ratio = _ratios(mid_window, mid_step, short_window, short_step)
     if step_ratio < 1:
         raise ValueError("mid_step / short_step rounds to 0: the reference never terminates")
@@ -215,7 +216,7 @@ def mid_and_beat_batch(signals, sampling_rate, mid_window, mid_step, short_windo
     if (not stereo) and any((np.asarray(s).dtype != np.int16) != floats for s in signals):
         raise ValueError("int16 and float64 clips cannot share a batch")
     if stereo:
-        clips = [np.asarray(s)[:, 0].astype(np.int32) + np.asarray(s)[:, 1] for s in signals]
+        clips = [np.ascontiguousarray(s, dtype=np.int16) for s in signals]        # (n, 2): one stereo frame per row
     elif floats:
         clips = [np.ascontiguousarray(np.double(s)) for s in signals]
     else:
@@ -229,7 +230,7 @@ def mid_and_beat_batch(signals, sampling_rate, mid_window, mid_step, short_windo
     F = 68
     T = (lens - window) // step + 1
     M = -(-T // step_ratio)
-    d_in = _ffi.DeviceBuffer.from_host(np.concatenate(clips) if len(clips) > 1 else clips[0])
+    d_in = _ffi.DeviceBuffer.from_host((np.concatenate(clips) if len(clips) > 1 else clips[0]).reshape(-1))
     plan = _ffi.Plan(offsets, sampling_rate, window, step, deltas=True, sample_kind=2 if stereo else (1 if floats else 0))
     d_st = _ffi.DeviceBuffer(plan.out_doubles * 8)
     plan.execute(d_in, d_st)

@@ -96,6 +96,7 @@ _SIGNATURES = {
     "paa_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
     "paa_comm_destroy": (C.c_int, []),
     "paa_comm_gather_f64": (C.c_int, [C.c_void_p, c_i64p, C.c_int, C.c_void_p]),
+    "paa_comm_gatherv_f64": (C.c_int, [C.c_void_p, c_i64p, c_i64p, C.c_int, C.c_void_p]),
     "paa_comm_barrier": (C.c_int, []),
     "paa_debug_mel_bank": (C.c_int, [C.c_double, C.c_int, c_f64p]),
     "paa_debug_dct": (C.c_int, [c_f64p]),

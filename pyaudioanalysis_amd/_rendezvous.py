@@ -1,0 +1,158 @@
+"""Control plane of a multi-rank job: a star of TCP sockets around rank 0, on the launcher's environment variables
+(RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torchrun, srun wrappers and mpirun shims export them).
+
+It carries only what the data path cannot: the RCCL unique id, per-rank sizes, a barrier and a max over ranks.  Feature
+data never goes through it (that is paa_comm_gather_f64 over xGMI).  The reference has no distributed code; this is
+plumbing for distributed.extract_sharded and bench.py, with no dependency beyond the standard library.
+
+The port: MASTER_PORT itself usually belongs to the launcher (torchrun's agent keeps its store there), so rank 0 binds
+the first free port of MASTER_PORT + 1 .. + 16 and a peer tries those in turn; both sides check a token derived from
+the job's environment, so a foreign listener on one of them is skipped, not joined.
+"""
+import hashlib
+import os
+import pickle
+import socket
+import struct
+import time
+
+_PORT_SPAN = 16
+
+
+def _send(sock, obj):
+    blob = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+    sock.sendall(struct.pack("<Q", len(blob)) + blob)
+
+
+def _recv_exact(sock, n):
+    parts = []
+    while n:
+        chunk = sock.recv(min(n, 1 << 20))
+        if not chunk:
+            raise ConnectionError("control-plane peer closed the connection")
+        parts.append(chunk)
+        n -= len(chunk)
+    return b"".join(parts)
+
+
+def _recv(sock):
+    (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    return pickle.loads(_recv_exact(sock, n))
+
+
+class SocketGroup:
+    """world_size processes; every collective is 'send to rank 0, rank 0 answers' (payloads are a few bytes)."""
+
+    def __init__(self, rank=None, world_size=None, addr=None, port=None, timeout=120.0, job_tag=None):
+        env = os.environ
+        self.rank = int(env.get("RANK", "0")) if rank is None else int(rank)
+        self.world_size = int(env.get("WORLD_SIZE", "1")) if world_size is None else int(world_size)
+        addr = addr or env.get("MASTER_ADDR", "127.0.0.1")
+        port = int(env.get("MASTER_PORT", "29500")) if port is None else int(port)
+        tag = job_tag if job_tag is not None else env.get("TORCHELASTIC_RUN_ID", "")
+        self._token = hashlib.sha256(("paa-rdzv|%s|%d|%d|%s" % (addr, port, self.world_size, tag)).encode()).digest()
+        self._peers = {}          # rank 0: rank -> socket
+        self._root = None         # other ranks: socket to rank 0
+        self._listener = None
+        if self.world_size == 1:
+            return
+        deadline = time.monotonic() + timeout
+        if self.rank == 0:
+            self._serve(addr, port, deadline)
+        else:
+            self._join(addr, port, deadline)
+
+    # ---- connection set-up
+    def _serve(self, addr, port, deadline):
+        last = None
+        for cand in range(port + 1, port + 1 + _PORT_SPAN):
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                srv.bind(("", cand))
+            except OSError as exc:
+                last = exc
+                srv.close()
+                continue
+            srv.listen(self.world_size)
+            self._listener = srv
+            break
+        if self._listener is None:
+            raise OSError("no free control-plane port in %d..%d: %s" % (port + 1, port + _PORT_SPAN, last))
+        while len(self._peers) < self.world_size - 1:
+            left = deadline - time.monotonic()
+            if left <= 0:
+                raise TimeoutError("control plane: %d of %d ranks joined" % (len(self._peers) + 1, self.world_size))
+            self._listener.settimeout(left)
+            try:
+                conn, _ = self._listener.accept()
+            except socket.timeout:
+                continue
+            try:
+                conn.settimeout(5.0)
+                hello = _recv_exact(conn, 32 + 4)
+                peer = struct.unpack("<i", hello[32:])[0]
+                if hello[:32] != self._token or not (0 < peer < self.world_size) or peer in self._peers:
+                    conn.close()
+                    continue
+                conn.sendall(self._token)
+                conn.settimeout(None)
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                self._peers[peer] = conn
+            except (OSError, struct.error):
+                conn.close()
+
+    def _join(self, addr, port, deadline):
+        while time.monotonic() < deadline:
+            for cand in range(port + 1, port + 1 + _PORT_SPAN):
+                try:
+                    s = socket.create_connection((addr, cand), timeout=2.0)
+                except OSError:
+                    continue
+                try:
+                    s.settimeout(5.0)
+                    s.sendall(self._token + struct.pack("<i", self.rank))
+                    if _recv_exact(s, 32) == self._token:
+                        s.settimeout(None)
+                        s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        self._root = s
+                        return
+                except OSError:
+                    pass
+                s.close()
+            time.sleep(0.05)
+        raise TimeoutError("control plane: rank %d could not reach rank 0 at %s:%d+" % (self.rank, addr, port + 1))
+
+    # ---- collectives
+    def all_gather(self, obj):
+        """[obj of rank 0, obj of rank 1, ...] on every rank."""
+        if self.world_size == 1:
+            return [obj]
+        if self.rank == 0:
+            out = [obj] + [None] * (self.world_size - 1)
+            for r, s in self._peers.items():
+                out[r] = _recv(s)
+            for s in self._peers.values():
+                _send(s, out)
+            return out
+        _send(self._root, obj)
+        return _recv(self._root)
+
+    def broadcast(self, obj, src=0):
+        """obj of rank `src` on every rank."""
+        return self.all_gather(obj if self.rank == src else None)[src]
+
+    def barrier(self):
+        self.all_gather(None)
+
+    def all_max(self, value):
+        return max(self.all_gather(value))
+
+    def close(self):
+        for s in list(self._peers.values()) + [self._root, self._listener]:
+            if s is not None:
+                try:
+                    s.close()
+                except OSError:
+                    pass
+        self._peers, self._root, self._listener = {}, None, None

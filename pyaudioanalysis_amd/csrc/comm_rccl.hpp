@@ -201,42 +201,48 @@ extern "C" int paa_comm_destroy(void) {
     return PAA_OK;
 }
 
-extern "C" int paa_comm_gather_f64(const double *d_send, const int64_t *counts, int root, double *d_recv) {
-    if (!counts) return fail(PAA_ERR_ARG, "null counts");
+// rank r's block lands at d_recv + displs[r] (doubles) on the root: a chunked gather can fill the final rank-major
+// layout piece by piece while later chunks are still being computed
+extern "C" int paa_comm_gatherv_f64(const double *d_send, const int64_t *counts, const int64_t *displs, int root,
+                                    double *d_recv) {
+    if (!counts || !displs) return fail(PAA_ERR_ARG, "null counts / displs");
     std::lock_guard<std::mutex> lk(g_mu);      // g_gather_done is shared with paa_plan_execute
     if (!g_comm) {
         if (g_world != 1) return fail(PAA_ERR_COMM, "communicator not initialised");
-        if (d_recv && d_send && d_recv != d_send)
-            HIP_TRY(hipMemcpyAsync(d_recv, d_send, (size_t)counts[0] * 8, hipMemcpyDeviceToDevice, g_main_stream));
+        if (d_recv && d_send && d_recv + displs[0] != d_send && counts[0] > 0)
+            HIP_TRY(hipMemcpyAsync(d_recv + displs[0], d_send, (size_t)counts[0] * 8, hipMemcpyDeviceToDevice, g_main_stream));
         return PAA_OK;
     }
+    if (root < 0 || root >= g_world) return fail(PAA_ERR_ARG, "bad root");
+    if (g_rank == root && !d_recv) return fail(PAA_ERR_ARG, "root needs a receive buffer");
     // order the gather after everything queued so far on the compute stream
     HIP_TRY(hipEventRecord(g_ev_ready, g_main_stream));
     HIP_TRY(hipStreamWaitEvent(g_comm_stream, g_ev_ready, 0));
     NCCL_TRY(g_rccl.GroupStart());
     if (g_rank == root) {
-        long long off = 0;
-        for (int r = 0; r < g_world; ++r) {
+        for (int r = 0; r < g_world; ++r)
             if (r != root && counts[r] > 0)
-                NCCL_TRY(g_rccl.Recv(d_recv + off, (size_t)counts[r], ncclDouble, r, g_comm, g_comm_stream));
-            off += counts[r];
-        }
+                NCCL_TRY(g_rccl.Recv(d_recv + displs[r], (size_t)counts[r], ncclDouble, r, g_comm, g_comm_stream));
     } else if (counts[g_rank] > 0) {
         NCCL_TRY(g_rccl.Send(d_send, (size_t)counts[g_rank], ncclDouble, root, g_comm, g_comm_stream));
     }
     NCCL_TRY(g_rccl.GroupEnd());
-    if (g_rank == root && d_send && counts[root] > 0) {
-        long long off = 0;
-        for (int r = 0; r < root; ++r) off += counts[r];
-        if (d_recv + off != d_send)
-            HIP_TRY(hipMemcpyAsync(d_recv + off, d_send, (size_t)counts[root] * 8, hipMemcpyDeviceToDevice, g_comm_stream));
-    }
+    if (g_rank == root && d_send && counts[root] > 0 && d_recv + displs[root] != d_send)
+        HIP_TRY(hipMemcpyAsync(d_recv + displs[root], d_send, (size_t)counts[root] * 8, hipMemcpyDeviceToDevice, g_comm_stream));
     if (d_send) {       // the next kernel that writes d_send must wait for this gather (see paa_plan_execute)
         hipEvent_t &ev = g_gather_done[d_send];
         if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(ev, g_comm_stream));
     }
     return PAA_OK;
+}
+
+extern "C" int paa_comm_gather_f64(const double *d_send, const int64_t *counts, int root, double *d_recv) {
+    if (!counts) return fail(PAA_ERR_ARG, "null counts");
+    std::vector<int64_t> displs((size_t)std::max(g_world, 1));
+    long long off = 0;
+    for (int r = 0; r < std::max(g_world, 1); ++r) { displs[r] = off; off += counts[r]; }
+    return paa_comm_gatherv_f64(d_send, counts, displs.data(), root, d_recv);
 }
 
 // called by paa_plan_execute before it overwrites d_out

@@ -335,10 +335,15 @@ __device__ __forceinline__ double fast_log10(double x) { return fast_log2(x) * 0
 template <typename T> __device__ __forceinline__ double load_sample(const T *p);
 template <> __device__ __forceinline__ double load_sample<int16_t>(const int16_t *p) { return (double)(*p); }
 template <> __device__ __forceinline__ double load_sample<double>(const double *p) { return *p; }
-// int32 samples are the SUMS L + R of a stereo int16 pair (fused stereo_to_mono, audioBasicIO.py:156-168):
-// mono = L/2 + R/2 exactly, so x / 2^15 = (L + R) / 2^16
-template <> __device__ __forceinline__ double load_sample<int>(const int *p) { return (double)(*p); }
+// stereo16 = one interleaved stereo frame (L, R) of int16 PCM, fetched as one 32-bit word and summed in the load:
+// stereo_to_mono (audioBasicIO.py:156-168) is mono = L/2 + R/2 exactly, so x / 2^15 = (L + R) / 2^16 -- the mono signal
+// never exists in memory
+struct alignas(4) stereo16 { int16_t l, r; };
+__device__ __forceinline__ int stereo_word_sum(int w) { return (int)(short)(w & 0xffff) + (w >> 16); }
+template <> __device__ __forceinline__ double load_sample<stereo16>(const stereo16 *p) {
+    return (double)stereo_word_sum(*reinterpret_cast<const int *>(p));
+}
 template <typename T> __host__ __device__ constexpr double sample_scale() { return 1.0 / 32768.0; }
-template <> __host__ __device__ constexpr double sample_scale<int>() { return 1.0 / 65536.0; }
+template <> __host__ __device__ constexpr double sample_scale<stereo16>() { return 1.0 / 65536.0; }
 
 }  // namespace paa

@@ -67,19 +67,40 @@ __global__ __launch_bounds__(256) void clip_stats_i16_kernel(const int16_t *__re
     }
 }
 
-// int32 samples (stereo sums L + R): same reduction, sums still exact in int64
-__global__ __launch_bounds__(256) void clip_stats_i32_kernel(const int *__restrict__ sig,
-                                                              const StatChunk *__restrict__ chunks,
-                                                              long long *__restrict__ psum,
-                                                              int *__restrict__ pmin, int *__restrict__ pmax) {
+// interleaved stereo int16 (L0 R0 L1 R1 ...; sample index = stereo frame): statistics of the sums L + R, i.e. of
+// 2^16 x what stereo_to_mono + the /2^15 scaling produce (audioBasicIO.py:156-168, ShortTermFeatures.py:568); sums stay
+// exact in int64.  Same shape as the int16 kernel: 16-byte loads (4 stereo frames), four in flight per thread.
+__global__ __launch_bounds__(256) void clip_stats_stereo_kernel(const stereo16 *__restrict__ sig,
+                                                                 const StatChunk *__restrict__ chunks,
+                                                                 long long *__restrict__ psum,
+                                                                 int *__restrict__ pmin, int *__restrict__ pmax) {
     const StatChunk ch = chunks[blockIdx.x];
     const int tid = threadIdx.x;
+    const long long a0 = ch.start, a1 = ch.start + ch.len;
+    long long b0 = (a0 + 3) & ~3LL;
+    if (b0 > a1) b0 = a1;
+    const long long b1 = b0 + ((a1 - b0) & ~3LL);
+    const int *w32 = reinterpret_cast<const int *>(sig);
     long long s = 0;
     int mn = 0x7fffffff, mx = -0x7fffffff - 1;
-    for (long long i = ch.start + tid; i < ch.start + ch.len; i += 256) {
-        const int v = sig[i];
-        s += v; mn = min(mn, v); mx = max(mx, v);
+    for (long long i = a0 + tid; i < b0; i += 256) { const int v = stereo_word_sum(w32[i]); s += v; mn = min(mn, v); mx = max(mx, v); }
+    for (long long i = b1 + tid; i < a1; i += 256) { const int v = stereo_word_sum(w32[i]); s += v; mn = min(mn, v); mx = max(mx, v); }
+    const int4 *body = reinterpret_cast<const int4 *>(w32 + b0);
+    const long long nvec = (b1 - b0) >> 2;
+    int s32 = 0;      // a 64 K-frame chunk: 256 values of |v| < 2^16 per thread -- fits
+    auto fold = [&](const int4 &q) {
+        const int v0 = stereo_word_sum(q.x), v1 = stereo_word_sum(q.y), v2 = stereo_word_sum(q.z), v3 = stereo_word_sum(q.w);
+        s32 += (v0 + v1) + (v2 + v3);
+        mn = min(mn, min(min(v0, v1), min(v2, v3)));
+        mx = max(mx, max(max(v0, v1), max(v2, v3)));
+    };
+    long long i = tid;
+    for (; i + 768 < nvec; i += 1024) {
+        const int4 q0 = body[i], q1 = body[i + 256], q2 = body[i + 512], q3 = body[i + 768];
+        fold(q0); fold(q1); fold(q2); fold(q3);
     }
+    for (; i < nvec; i += 256) fold(body[i]);
+    s += s32;
     __shared__ long long ss[4];
     __shared__ int smn[4], smx[4];
 #pragma unroll
@@ -97,37 +118,34 @@ __global__ __launch_bounds__(256) void clip_stats_i32_kernel(const int *__restri
     }
 }
 
-// interleaved stereo int16 (L0 R0 L1 R1 ...) -> int32 sums L + R: the device half of stereo_to_mono
-// (audioBasicIO.py:156-168); 16 bytes in, 16 bytes out per thread-iteration
-__global__ __launch_bounds__(256) void stereo_sum_kernel(const int16_t *__restrict__ lr, long long n_frames,
-                                                          int *__restrict__ sums) {
-    const long long nvec = n_frames >> 2;
-    const int4 *in4 = reinterpret_cast<const int4 *>(lr);
-    int4 *out4 = reinterpret_cast<int4 *>(sums);
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
-        const int4 q = in4[i];
-        int4 r;
-        r.x = (int)(short)(q.x & 0xffff) + (q.x >> 16);
-        r.y = (int)(short)(q.y & 0xffff) + (q.y >> 16);
-        r.z = (int)(short)(q.z & 0xffff) + (q.z >> 16);
-        r.w = (int)(short)(q.w & 0xffff) + (q.w >> 16);
-        out4[i] = r;
-    }
-    if (blockIdx.x == 0)
-        for (long long i = (nvec << 2) + threadIdx.x; i < n_frames; i += 256) sums[i] = (int)lr[2 * i] + (int)lr[2 * i + 1];
-}
-
+// float64 samples: 16-byte loads, four in flight per thread (one 8-byte load at a time left this pass at ~2 TB/s)
 __global__ __launch_bounds__(256) void clip_stats_f64_kernel(const double *__restrict__ sig,
                                                               const StatChunk *__restrict__ chunks,
                                                               double *__restrict__ psum,
                                                               double *__restrict__ pmin, double *__restrict__ pmax) {
     const StatChunk ch = chunks[blockIdx.x];
     const int tid = threadIdx.x;
-    double s = 0.0, mn = DBL_MAX, mx = -DBL_MAX;
-    for (long long i = ch.start + tid; i < ch.start + ch.len; i += 256) {
-        const double v = sig[i];
-        s += v; mn = fmin(mn, v); mx = fmax(mx, v);
+    const long long a0 = ch.start, a1 = ch.start + ch.len;
+    long long b0 = (a0 + 1) & ~1LL;
+    if (b0 > a1) b0 = a1;
+    const long long b1 = b0 + ((a1 - b0) & ~1LL);
+    double s = 0.0, s2 = 0.0, mn = DBL_MAX, mx = -DBL_MAX;
+    if (tid == 0 && a0 < b0) { const double v = sig[a0]; s += v; mn = fmin(mn, v); mx = fmax(mx, v); }
+    if (tid == 1 && b1 < a1) { const double v = sig[b1]; s += v; mn = fmin(mn, v); mx = fmax(mx, v); }
+    const double2 *body = reinterpret_cast<const double2 *>(sig + b0);
+    const long long nvec = (b1 - b0) >> 1;
+    auto fold = [&](const double2 &q) {
+        s += q.x; s2 += q.y;
+        mn = fmin(mn, fmin(q.x, q.y));
+        mx = fmax(mx, fmax(q.x, q.y));
+    };
+    long long i = tid;
+    for (; i + 768 < nvec; i += 1024) {
+        const double2 q0 = body[i], q1 = body[i + 256], q2 = body[i + 512], q3 = body[i + 768];
+        fold(q0); fold(q1); fold(q2); fold(q3);
     }
+    for (; i < nvec; i += 256) fold(body[i]);
+    s += s2;
     __shared__ double ss[4], smn[4], smx[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

@@ -1,4 +1,4 @@
-// Register-FFT feature kernels for windows W = 2 RA RB, any step, any sample type (int16 / int32 stereo sums / float64),
+// Register-FFT feature kernels for windows W = 2 RA RB, any step, any sample type (int16 / interleaved stereo int16 / float64),
 // features / spectrogram / chromagram: the family behind the shapes the reference's own callers use besides the
 // int16 800/400 headline (kernels_fast.hpp):
 //     W = 800 = 2 x 25 x 16   float64 or stereo input at 50 ms / 16 kHz (audioBasicIO.py:167 hands every stereo file over as
@@ -150,11 +150,11 @@ template <> struct PairLoad<int16_t> {
         return make_double2((double)s.x, (double)s.y);
     }
 };
-template <> struct PairLoad<int> {
+template <> struct PairLoad<stereo16> {      // two stereo frames = 8 bytes, each summed L + R in the load
     typedef int vec __attribute__((ext_vector_type(2), aligned(4)));
-    static __device__ __forceinline__ double2 get(const int *p) {
+    static __device__ __forceinline__ double2 get(const stereo16 *p) {
         const vec s = *reinterpret_cast<const vec *>(p);
-        return make_double2((double)s.x, (double)s.y);
+        return make_double2((double)stereo_word_sum(s.x), (double)stereo_word_sum(s.y));
     }
 };
 template <> struct PairLoad<double> {
@@ -847,12 +847,12 @@ inline int ct_launch_shape(const CtLaunch &cl, const PlanDev &P, const unsigned 
     }
 }
 
-// sample_kind 0: int16, 1: float64, 2: int32 stereo sums
+// sample_kind 0: int16, 1: float64, 2: interleaved stereo int16 (summed in the loads)
 inline int ct_launch(const CtLaunch &cl, int sample_kind, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                      const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
                      hipStream_t stream) {
     if (sample_kind == 0) return ct_launch_shape<int16_t>(cl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
-    if (sample_kind == 2) return ct_launch_shape<int>(cl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+    if (sample_kind == 2) return ct_launch_shape<stereo16>(cl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
     return ct_launch_shape<double>(cl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
 }
 

@@ -1,5 +1,5 @@
 // Register-FFT feature kernel for windows W = 2 R1 R2 with two coprime odd primes (BASELINE config 5: 1102 = 2 x 29 x 19
-// at 44.1 kHz / 25 ms): several frames per wave-iteration, both FFT passes in registers, int16 / int32 (stereo sums) /
+// at 44.1 kHz / 25 ms): several frames per wave-iteration, both FFT passes in registers, int16 / interleaved stereo int16 /
 // float64 samples; also produces spectrogram / chromagram rows (modes 1 / 2).
 //
 // The complex FFT of length Nc = R1 R2 (real-input trick: z[n] = y[2n] + i y[2n+1]) is a PRIME-FACTOR transform: with

@@ -51,15 +51,15 @@ inline int launch_chroma_tail(const PlanDev &P, int sample_kind, const void *d_s
     if (lds > 160 * 1024) return -2;          // spectrum of the tail frame does not fit LDS
     if (lds > 64 * 1024) {
         const void *fn = sample_kind == 0 ? reinterpret_cast<const void *>(&chroma_tail_kernel<int16_t>)
-                       : sample_kind == 2 ? reinterpret_cast<const void *>(&chroma_tail_kernel<int>)
+                       : sample_kind == 2 ? reinterpret_cast<const void *>(&chroma_tail_kernel<stereo16>)
                                           : reinterpret_cast<const void *>(&chroma_tail_kernel<double>);
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
     }
     if (sample_kind == 0)
         hipLaunchKernelGGL(chroma_tail_kernel<int16_t>, dim3(count), dim3(256), lds, stream, P, (const int16_t *)d_sig,
                            pos0, n_total, norms, d_out);
-    else if (sample_kind == 2)        // int32 stereo sums L + R (fused stereo_to_mono)
-        hipLaunchKernelGGL(chroma_tail_kernel<int>, dim3(count), dim3(256), lds, stream, P, (const int *)d_sig,
+    else if (sample_kind == 2)        // interleaved stereo int16, summed in the loads (fused stereo_to_mono)
+        hipLaunchKernelGGL(chroma_tail_kernel<stereo16>, dim3(count), dim3(256), lds, stream, P, (const stereo16 *)d_sig,
                            pos0, n_total, norms, d_out);
     else
         hipLaunchKernelGGL(chroma_tail_kernel<double>, dim3(count), dim3(256), lds, stream, P, (const double *)d_sig,

@@ -89,7 +89,7 @@ static std::map<std::pair<double, int>, std::unique_ptr<TableSet>> g_tables;
 // mutex.  A thread holds a lane for the duration of one call; every launch / copy of that call goes to cs().
 struct Lane {
     hipStream_t stream = nullptr;
-    Scratch in, in2, out, mid;
+    Scratch in, out, mid;
     bool busy = false;
 };
 constexpr int kLanes = 4;
@@ -395,7 +395,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     if (!offsets || n_clips < 1 || !out) return fail(PAA_ERR_ARG, "null offsets / no clips");
     if (window < 2 || step < 1) return fail(PAA_ERR_ARG, "window=%d step=%d: need window >= 2, step >= 1", window, step);
     if (sample_kind < 0 || sample_kind > 2)
-        return fail(PAA_ERR_ARG, "sample_kind must be 0 (int16), 1 (float64) or 2 (int32 stereo sums)");
+        return fail(PAA_ERR_ARG, "sample_kind must be 0 (int16), 1 (float64) or 2 (interleaved stereo int16)");
     if (!(fs > 0)) return fail(PAA_ERR_ARG, "sampling rate must be positive");
     std::unique_ptr<paa_plan, void (*)(paa_plan *)> p(new paa_plan(), plan_free);
     ++g_live_plans;
@@ -582,8 +582,8 @@ static int launch_stats(paa_plan *p, const void *d_packed) {
                                (const int16_t *)d_packed, p->d_chunks, (long long *)p->d_psum, (int *)p->d_pmin,
                                (int *)p->d_pmax);
         else if (p->sample_kind == 2)
-            hipLaunchKernelGGL(clip_stats_i32_kernel, dim3((unsigned)p->n_chunks), dim3(256), 0, cs(),
-                               (const int *)d_packed, p->d_chunks, (long long *)p->d_psum, (int *)p->d_pmin,
+            hipLaunchKernelGGL(clip_stats_stereo_kernel, dim3((unsigned)p->n_chunks), dim3(256), 0, cs(),
+                               (const stereo16 *)d_packed, p->d_chunks, (long long *)p->d_psum, (int *)p->d_pmin,
                                (int *)p->d_pmax);
         else
             hipLaunchKernelGGL(clip_stats_f64_kernel, dim3((unsigned)p->n_chunks), dim3(256), 0, cs(),
@@ -598,7 +598,7 @@ static int launch_stats(paa_plan *p, const void *d_packed) {
     else
         hipLaunchKernelGGL((clip_params_kernel<long long, int>), dim3(gb), dim3(64), 0, cs(), p->d_clips,
                            p->n_clips, (const long long *)p->d_psum, (const int *)p->d_pmin, (const int *)p->d_pmax,
-                           p->sample_kind == 2 ? sample_scale<int>() : sample_scale<int16_t>(), p->P.W, p->d_norms);
+                           p->sample_kind == 2 ? sample_scale<stereo16>() : sample_scale<int16_t>(), p->P.W, p->d_norms);
     HIP_TRY(hipGetLastError());
     return PAA_OK;
 }
@@ -706,7 +706,7 @@ extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *
     if (rc) return rc;
     if (plan->big)
         return plan->sample_kind == 0 ? run_big<int16_t>(plan, d_packed, d_out)
-             : plan->sample_kind == 2 ? run_big<int>(plan, d_packed, d_out) : run_big<double>(plan, d_packed, d_out);
+             : plan->sample_kind == 2 ? run_big<stereo16>(plan, d_packed, d_out) : run_big<double>(plan, d_packed, d_out);
     if (plan->n_tiles == 0) return PAA_OK;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (g_prof && (g_prof_seen++ % g_prof) == 0) {
@@ -738,9 +738,9 @@ extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *
     }
     if (plan->reg)
         return plan->sample_kind == 0 ? launch_reg<int16_t>(plan, d_packed, d_out)
-             : plan->sample_kind == 2 ? launch_reg<int>(plan, d_packed, d_out) : launch_reg<double>(plan, d_packed, d_out);
+             : plan->sample_kind == 2 ? launch_reg<stereo16>(plan, d_packed, d_out) : launch_reg<double>(plan, d_packed, d_out);
     return plan->sample_kind == 0 ? launch_generic<int16_t>(plan, d_packed, d_out)
-         : plan->sample_kind == 2 ? launch_generic<int>(plan, d_packed, d_out)
+         : plan->sample_kind == 2 ? launch_generic<stereo16>(plan, d_packed, d_out)
                                   : launch_generic<double>(plan, d_packed, d_out);
 }
 
@@ -1041,7 +1041,7 @@ extern "C" void paa_shutdown(void) {
     for (Scratch *s : {&g_sim_z, &g_sim_small, &g_sim_cand, &g_sim_in, &g_sim_out, &g_sim_filt}) { if (s->p) (void)hipFree(s->p); s->p = nullptr; s->cap = 0; }
     for (Lane &ln : g_lanes) {
         if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); ln.stream = nullptr; }
-        for (Scratch *s : {&ln.in, &ln.in2, &ln.out, &ln.mid}) { if (s->p) (void)hipFree(s->p); s->p = nullptr; s->cap = 0; }
+        for (Scratch *s : {&ln.in, &ln.out, &ln.mid}) { if (s->p) (void)hipFree(s->p); s->p = nullptr; s->cap = 0; }
     }
     if (g_ev0) (void)hipEventDestroy(g_ev0);
     if (g_ev1) (void)hipEventDestroy(g_ev1);
@@ -1185,8 +1185,8 @@ static int run_host_st(const void *packed, const int64_t *offsets, int64_t n_cli
     }
     if (rc) return rc;
     std::unique_ptr<paa_plan, void (*)(paa_plan *)> guard(plan, plan_free_synced);
-    // sample_kind 2: the host buffer holds interleaved stereo int16 (4 bytes per frame); the device turns it
-    // into int32 sums L + R before anything else (fused stereo_to_mono)
+    // sample_kind 2: the host buffer holds interleaved stereo int16 (4 bytes per frame); the kernels sum L + R in their
+    // loads (fused stereo_to_mono: the mono signal is never materialised)
     const size_t esz = sample_kind == 0 ? 2 : (sample_kind == 2 ? 4 : 8);
     const long long base = offsets[0], n_total = offsets[n_clips] - base;
     // samples are uploaded from offsets[0]; rebase the clip offsets accordingly
@@ -1212,17 +1212,6 @@ static int run_host_st(const void *packed, const int64_t *offsets, int64_t n_cli
     HIP_TRY(hipMemcpyAsync(lane.l->in.p, (const char *)packed + (size_t)base * esz, (size_t)n_total * esz,
                            hipMemcpyHostToDevice, cs()));
     const void *d_samples = lane.l->in.p;
-    if (sample_kind == 2) {
-        {
-            std::lock_guard<std::mutex> lk(g_mu);
-            if ((rc = scratch_reserve(lane.l->in2, (size_t)n_total * 4 + 64))) return rc;
-        }
-        const unsigned gs = (unsigned)std::min<long long>(4096, (n_total / 4 + 255) / 256 + 1);
-        hipLaunchKernelGGL(stereo_sum_kernel, dim3(gs), dim3(256), 0, cs(), (const int16_t *)lane.l->in.p, n_total,
-                           (int *)lane.l->in2.p);
-        HIP_TRY(hipGetLastError());
-        d_samples = lane.l->in2.p;
-    }
     if ((rc = paa_plan_execute(plan, d_samples, (double *)lane.l->out.p))) return rc;
     if (want_mid) {
         const long long md = paa_plan_mid_doubles(plan, mid_step);
@@ -1343,24 +1332,16 @@ static int run_host_spec(const void *signal, int64_t n, int sample_kind, double 
     }
     if (rc) return rc;
     std::unique_ptr<paa_plan, void (*)(paa_plan *)> guard(plan, plan_free_synced);
-    // sample_kind 2: the host buffer holds interleaved stereo int16 (4 bytes per frame); the device turns it into int32
-    // sums L + R before anything else (fused stereo_to_mono, audioBasicIO.py:156-168)
+    // sample_kind 2: the host buffer holds interleaved stereo int16 (4 bytes per frame); the kernels sum L + R in their
+    // loads (fused stereo_to_mono, audioBasicIO.py:156-168)
     const size_t esz = sample_kind == 0 ? 2 : (sample_kind == 2 ? 4 : 8);
     {
         std::lock_guard<std::mutex> lk(g_mu);
         if ((rc = scratch_reserve(lane.l->in, (size_t)n * esz + 64))) return rc;
-        if (sample_kind == 2 && (rc = scratch_reserve(lane.l->in2, (size_t)n * 4 + 64))) return rc;
         if ((rc = scratch_reserve(lane.l->out, (size_t)plan->out_doubles * 8))) return rc;
     }
     HIP_TRY(hipMemcpyAsync(lane.l->in.p, signal, (size_t)n * esz, hipMemcpyHostToDevice, cs()));
     const void *d_samples = lane.l->in.p;
-    if (sample_kind == 2) {
-        const unsigned gs = (unsigned)std::min<long long>(4096, (n / 4 + 255) / 256 + 1);
-        hipLaunchKernelGGL(stereo_sum_kernel, dim3(gs), dim3(256), 0, cs(), (const int16_t *)lane.l->in.p, (long long)n,
-                           (int *)lane.l->in2.p);
-        HIP_TRY(hipGetLastError());
-        d_samples = lane.l->in2.p;
-    }
     HIP_TRY(hipMemsetAsync(lane.l->out.p, 0, (size_t)plan->out_doubles * 8, cs()));   // trailing rows stay 0 (:413-422)
     if ((rc = paa_plan_execute(plan, d_samples, (double *)lane.l->out.p))) return rc;
     if (mode == 2) {

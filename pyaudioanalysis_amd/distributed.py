@@ -5,9 +5,13 @@ Clips are independent units (normalisation is per clip, ShortTermFeatures.py:570
 collective besides that gather.  The reference has no distributed code; this is the batched form of the
 per-file loop in MidTermFeatures.directory_feature_extraction (MidTermFeatures.py:167-201).
 
-The process group used for rendezvous (unique-id broadcast, barriers) is supplied by the caller -- bench.py and
-the tests use torch.distributed with the gloo backend; the feature data itself moves GPU -> GPU through
-libpaa_hip.so's paa_comm_gather_f64 (grouped ncclSend/ncclRecv).
+A rank's range is cut into chunks: while chunk k travels to the root on the communication stream, chunk k+1 is uploaded
+and computed (extract_sharded(chunks=K)); gather="mid" ships the (136, M) mid-term matrices -- what the directory
+walkers consume, 1/40 of the bytes of the short-term matrices -- instead of the (F, T) slabs.
+
+The control plane (unique-id broadcast, barriers) is supplied by the caller -- _rendezvous.SocketGroup (bench.py, the
+standard library only) or any process group with a broadcast (the CPU tests use torch.distributed / gloo); the feature
+data itself moves GPU -> GPU through libpaa_hip.so's paa_comm_gatherv_f64 (grouped ncclSend/ncclRecv).
 """
 import ctypes
 import hashlib
@@ -105,16 +109,38 @@ class RcclGather:
         _ffi.check(lib.paa_comm_init(int(world_size), int(rank), buf))
         self.world_size, self.rank = int(world_size), int(rank)
 
-    def gather(self, d_send, counts, root, d_recv):
+    @classmethod
+    def over(cls, group):
+        """Communicator on a _rendezvous.SocketGroup (or anything with rank / world_size / broadcast / all_gather)."""
+        return cls(group.world_size, group.rank, lambda payload: group.broadcast(payload, 0), group.all_gather)
+
+    def gather(self, d_send, counts, root, d_recv, displs=None):
+        """counts[r] doubles of rank r land at d_recv + displs[r] on the root (back to back in rank order when displs is
+        None).  Asynchronous: queued on the library's communication stream behind the kernels launched so far."""
         counts = np.ascontiguousarray(counts, dtype=np.int64)
+        if displs is None:
+            displs = np.concatenate(([0], np.cumsum(counts)[:-1]))
+        displs = np.ascontiguousarray(displs, dtype=np.int64)
         recv = d_recv.ptr if d_recv is not None else None
-        _ffi.check(_ffi.lib().paa_comm_gather_f64(d_send.ptr, _ffi.as_i64p(counts), int(root), recv))
+        _ffi.check(_ffi.lib().paa_comm_gatherv_f64(d_send.ptr, _ffi.as_i64p(counts), _ffi.as_i64p(displs), int(root), recv))
 
     def barrier(self):
         _ffi.check(_ffi.lib().paa_comm_barrier())
 
     def close(self):
         _ffi.lib().paa_comm_destroy()
+
+
+class _DeviceView:
+    """A range of a DeviceBuffer (keeps the parent alive)."""
+
+    def __init__(self, parent, offset_doubles, n_doubles):
+        self.parent = parent
+        self.ptr = ctypes.c_void_p(parent.ptr.value + 8 * offset_doubles)
+        self.nbytes = 8 * n_doubles
+
+    def to_host(self, dtype, count, offset_bytes=0):
+        return self.parent.to_host(dtype, count, offset_bytes + self.ptr.value - self.parent.ptr.value)
 
 
 class HipEngine:
@@ -132,8 +158,27 @@ class HipEngine:
         d_out._keep = (d_in, plan)          # the launch is asynchronous: inputs live as long as the result
         return d_out
 
+    def extract_mid(self, clips, sampling_rate, window, step, mid_ratio, mid_step_ratio):
+        """int16 clips -> device buffer holding their (136, M_c) mid-term matrices back to back (MidTermFeatures.py:87-127:
+        68 short-term rows, mean and std over mid_ratio frames every mid_step_ratio frames); the short-term matrices
+        stay in HBM and are dropped."""
+        offsets = np.zeros(len(clips) + 1, dtype=np.int64)
+        np.cumsum([len(c) for c in clips], out=offsets[1:])
+        d_in = _ffi.DeviceBuffer.from_host(np.concatenate(clips) if len(clips) > 1 else clips[0])
+        plan = _ffi.Plan(offsets, sampling_rate, window, step, deltas=True, sample_kind=0)
+        d_st = _ffi.DeviceBuffer(max(plan.out_doubles, 1) * 8)
+        plan.execute(d_in, d_st)
+        d_mid = _ffi.DeviceBuffer(max(plan.mid_doubles(mid_step_ratio), 1) * 8)
+        plan.mid_execute(d_st, mid_ratio, mid_step_ratio, d_mid)
+        d_mid._keep = (d_in, d_st, plan)
+        return d_mid
+
     def alloc(self, n_doubles):
         return _ffi.DeviceBuffer(max(int(n_doubles), 1) * 8)
+
+    def view(self, buf, offset_doubles, n_doubles):
+        """The sub-range [offset, offset + n) of a device buffer as something gather() / to_host() accept."""
+        return _DeviceView(buf, int(offset_doubles), int(n_doubles))
 
     def to_host(self, buf, n_doubles):
         return buf.to_host(np.float64, int(n_doubles))
@@ -158,28 +203,38 @@ class HipEngine:
         return HipEngine._build_id
 
 
-def _shard_key(clips, sampling_rate, window, step, deltas, build_id=""):
-    """Identity of one rank's work for the restart files: the build of the compute engine, the parameters, the clip
-    lengths and a digest of the samples."""
+def _shard_key(clips, sampling_rate, window, step, deltas, build_id="", what="short"):
+    """Identity of one rank's work for the restart files: the build of the compute engine, the parameters, what is
+    gathered, the clip lengths and a digest of the samples."""
     h = hashlib.sha256()
     h.update(str(build_id).encode())
-    h.update(repr((float(sampling_rate), int(window), int(step), bool(deltas), [len(c) for c in clips])).encode())
+    h.update(repr((float(sampling_rate), int(window), int(step), bool(deltas), what, [len(c) for c in clips])).encode())
     for c in clips:
         h.update(np.ascontiguousarray(c, dtype=np.int16).tobytes())
     return h.hexdigest()
 
 
+def mid_windows_per_clip(frames, mid_step_ratio):
+    """M_c = ceil(T_c / step ratio): one mid-term window per start 0, r, 2r, .. < T_c (MidTermFeatures.py:116-124)."""
+    return -(-np.asarray(frames, dtype=np.int64) // int(mid_step_ratio))
+
+
 def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank, comm, root=0, engine=None,
-                    restart_dir=None):
+                    restart_dir=None, chunks=1, gather="short", mid_window=None, mid_step=None):
     """Rank-local part of a sharded batch extraction.
 
     clips: the FULL list of int16 clips (every rank sees the list; only its own range is uploaded).
-    comm: gather(send, counts, root, recv) / barrier() / close() -- RcclGather on the GPU.
-    engine: extract / alloc / to_host / upload / sync -- HipEngine (default) on the GPU.
+    comm: gather(send, counts, root, recv, displs) / barrier() / close() -- RcclGather on the GPU.
+    engine: extract / extract_mid / alloc / view / to_host / upload / sync -- HipEngine (default) on the GPU.
+    chunks: every rank cuts its range into this many contiguous pieces (balanced by frames); piece k is gathered on the
+        communication stream while piece k+1 is uploaded and computed, and lands at its final place in the root's buffer.
+    gather: "short" -- the (F, T_c) short-term matrices (F = 68 with deltas, else 34);
+            "mid"   -- the (136, M_c) mid-term matrices of mid_feature_extraction(mid_window, mid_step in samples,
+                       MidTermFeatures.py:87-127) and nothing else: 1/40 of the bytes at 1.0 s / 1.0 s over 50 / 25 ms.
     restart_dir: when given, every rank leaves its finished block there (shard_<rank>_of_<world>.npz, keyed by the
         parameters and a digest of its clips) and a rerun of the same job loads the block instead of extracting it
         again -- a 100 000-clip job that died in the gather or on another rank restarts without redoing finished shards.
-    Returns, on the root, the list of (F, T_c) arrays for all clips (None elsewhere).
+    Returns, on the root, the list of per-clip arrays for all clips (None elsewhere).
     """
     engine = engine or HipEngine()
     window, step = int(window), int(step)
@@ -187,38 +242,75 @@ def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank
     frames = frames_per_clip(lengths, window, step)
     if np.any(frames < 1):
         raise ValueError("need at least one array to concatenate")
+    if gather == "mid":
+        if mid_window is None or mid_step is None:
+            raise ValueError('gather="mid" needs mid_window and mid_step (samples)')
+        mid_ratio = int(round((mid_window - (window - step)) / step))          # MidTermFeatures.py:100-102
+        mid_step_ratio = int(round(mid_step / step))
+        if mid_step_ratio < 1:
+            raise ValueError("mid_step / short_step rounds to 0: the reference never terminates")
+        units, n_rows, what = mid_windows_per_clip(frames, mid_step_ratio), 136, ("mid", mid_ratio, mid_step_ratio)
+    elif gather == "short":
+        units, n_rows, what = frames, (68 if deltas else 34), "short"
+    else:
+        raise ValueError('gather must be "short" or "mid"')
+    chunks = max(1, int(chunks))
     ranges = partition_by_frames(frames, world_size)
-    F = 68 if deltas else 34
-    counts = block_counts(frames, ranges, F)
+    counts = block_counts(units, ranges, n_rows)
+    rank_base = np.concatenate(([0], np.cumsum(counts)[:-1]))
+    # piece k of every rank: clip range, size and place in the root's buffer (every rank can compute all of it)
+    pieces = []                                   # pieces[k][r] = (clip_start, clip_end, count, displ)
+    for r, (ra, rb) in enumerate(ranges):
+        sub = partition_by_frames(frames[ra:rb], chunks) if rb > ra else [(0, 0)] * chunks
+        off = int(rank_base[r])
+        row = []
+        for (sa, sb) in sub:
+            cnt = n_rows * int(units[ra + sa:ra + sb].sum())
+            row.append((ra + sa, ra + sb, cnt, off))
+            off += cnt
+        pieces.append(row)
     a, b = ranges[rank]
     mine = [np.ascontiguousarray(c, dtype=np.int16) for c in clips[a:b]]
-    d_out = None
+    d_block = None                                # a restart file's block, uploaded whole
     shard_file = key = None
     if restart_dir is not None and mine:
         os.makedirs(restart_dir, exist_ok=True)
         shard_file = os.path.join(restart_dir, "shard_%03d_of_%03d.npz" % (rank, world_size))
         build_id = engine.build_id() if hasattr(engine, "build_id") else ""
-        key = _shard_key(mine, sampling_rate, window, step, deltas, build_id)
+        key = _shard_key(mine, sampling_rate, window, step, deltas, build_id, what)
         if os.path.exists(shard_file):
             try:
                 with np.load(shard_file, allow_pickle=False) as z:
                     if str(z["key"]) == key:
                         block = z["block"]                       # (read once: every access decompresses the member)
                         if block.shape == (int(counts[rank]),):
-                            d_out = engine.upload(block)
+                            d_block = engine.upload(block)
             except Exception:                    # an unreadable or foreign file is simply recomputed
-                d_out = None
-    if d_out is None:
-        d_out = engine.extract(mine, sampling_rate, window, step, deltas) if mine else engine.alloc(1)
-        if shard_file is not None:
-            engine.sync()
-            tmp = shard_file + ".tmp.npz"
-            np.savez(tmp, key=np.array(key), block=engine.to_host(d_out, int(counts[rank])))
-            os.replace(tmp, shard_file)
+                d_block = None
     d_all = engine.alloc(int(counts.sum())) if rank == root else None
-    comm.gather(d_out, counts, root, d_all)
+    sent = []                                     # this rank's pieces, kept until the gathers have run
+    for k in range(chunks):
+        ca, cb, cnt, displ = pieces[rank][k]
+        if cnt == 0:
+            d_piece = engine.alloc(1)
+        elif d_block is not None:
+            d_piece = engine.view(d_block, displ - int(rank_base[rank]), cnt)
+        elif gather == "mid":
+            d_piece = engine.extract_mid(mine[ca - a:cb - a], sampling_rate, window, step, mid_ratio, mid_step_ratio)
+        else:
+            d_piece = engine.extract(mine[ca - a:cb - a], sampling_rate, window, step, deltas)
+        sent.append((d_piece, cnt))
+        comm.gather(d_piece, np.array([pieces[r][k][2] for r in range(world_size)], dtype=np.int64), root, d_all,
+                    np.array([pieces[r][k][3] for r in range(world_size)], dtype=np.int64))
+    if shard_file is not None and d_block is None:
+        # written BEFORE waiting for the gathers (to_host is ordered behind the kernels only): a job that dies in the
+        # exchange, or on another rank, still leaves this rank's finished block behind
+        parts = [engine.to_host(d, cnt) for d, cnt in sent if cnt]
+        tmp = shard_file + ".tmp.npz"
+        np.savez(tmp, key=np.array(key), block=np.concatenate(parts) if len(parts) > 1 else parts[0])
+        os.replace(tmp, shard_file)
     engine.sync()
     if rank != root:
         return None
     flat = engine.to_host(d_all, int(counts.sum()))
-    return split_gathered(flat, frames, F)
+    return split_gathered(flat, units, n_rows)

@@ -18,25 +18,8 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 from pyaudioanalysis_amd import _ffi          # noqa: E402
-from synth import synth_clip                  # noqa: E402
 
-# name: (fs, window, step, seconds of one clip, clips, sample kind [0 int16, 1 f64, 2 int32 sums], mode, deltas)
-CASES = {
-    "reg_features": (44100, 1102, 441, 600, 1, 0, 0, 0),
-    "reg_features_stereo": (44100, 1102, 441, 600, 1, 2, 0, 0),
-    "reg_spectrogram": (44100, 1102, 441, 600, 1, 0, 1, 0),
-    "reg_spectrogram_stereo": (44100, 1102, 441, 600, 1, 2, 1, 0),
-    "reg_chromagram": (44100, 1102, 441, 600, 1, 0, 2, 0),
-    "ct_640": (16000, 640, 640, 3600, 1, 0, 0, 0),
-    "ct_640_spectrogram": (16000, 640, 640, 3600, 1, 0, 1, 0),
-    "ct_800_f64": (16000, 800, 400, 3600, 1, 1, 0, 0),
-    "ct_800_stereo": (16000, 800, 400, 3600, 1, 2, 0, 0),
-    "ct_400": (8000, 400, 200, 3600, 2, 0, 0, 0),
-    "ct_320": (16000, 320, 160, 1800, 1, 0, 0, 0),
-    "generic_2400": (48000, 2400, 1200, 1200, 1, 0, 0, 0),
-    "generic_2205": (44100, 2205, 1102, 1200, 1, 0, 0, 0),
-    "mid_stats": (16000, 800, 400, 30, 1000, 0, 0, 1),
-}
+from bench import SHAPES as CASES, shape_input, shape_bytes_per_frame          # noqa: E402
 
 
 def main():
@@ -48,17 +31,7 @@ def main():
     fs, W, S, seconds, clips, kind, mode, deltas = CASES[args.case]
     lib = _ffi.lib()
     _ffi.init(0)
-    base_s = min(seconds, 100)                       # synthesise at most 100 s, tile the rest
-    reps = -(-seconds // base_s)
-    n = base_s * fs
-    if kind == 0:
-        x = np.tile(synth_clip(5, n, fs), reps)
-    else:
-        xs = synth_clip(5, n, fs, stereo=True)
-        x = np.tile((xs[:, 1] / 2) + (xs[:, 0] / 2), reps) if kind == 1 else np.tile(xs[:, 0].astype(np.int32) + xs[:, 1], reps)
-    x = np.ascontiguousarray(np.tile(x, clips))
-    per = len(x) // clips
-    offsets = np.arange(clips + 1, dtype=np.int64) * per
+    x, offsets = shape_input(args.case)
     d_in = _ffi.DeviceBuffer.from_host(x)
     plan = _ffi.Plan(offsets, fs, W, S, deltas=bool(deltas), sample_kind=kind, mode=mode)
     d_out = _ffi.DeviceBuffer(plan.out_doubles * 8)
@@ -78,9 +51,7 @@ def main():
         step()
     ms = ctypes.c_float()
     _ffi.check(lib.paa_timer_stop(ctypes.byref(ms)))
-    in_bytes = {0: 2, 1: 8, 2: 4}[kind] * S
-    out_bytes = 8 * (plan.F if mode != 0 else (68 if deltas else 34))
-    per_frame = in_bytes + out_bytes
+    per_frame = shape_bytes_per_frame(args.case, plan.F if mode != 0 else (68 if deltas else 34))
     res = {"case": args.case, "kernel": plan.kernel_name, "frames": plan.total_frames, "launches": args.launches,
            "ms_per_step": ms.value / args.launches, "frames_per_s": plan.total_frames / (ms.value / args.launches * 1e-3),
            "algorithmic_bytes_per_frame": per_frame, "algorithmic_bytes_per_launch": per_frame * plan.total_frames,

@@ -18,10 +18,11 @@ for case in sys.argv[1:] or ["ct_640", "ct_800_f64", "ct_800_stereo", "ct_400", 
         x = synth_clip(5, n, fs)
     else:
         xs = synth_clip(5, n, fs, stereo=True)
-        x = (xs[:, 1] / 2) + (xs[:, 0] / 2) if kind == 1 else xs[:, 0].astype(np.int32) + xs[:, 1]
-    x = np.ascontiguousarray(np.tile(x, -(-seconds // min(seconds, 100)) * clips))
-    offsets = np.arange(clips + 1, dtype=np.int64) * (len(x) // clips)
-    d_in = _ffi.DeviceBuffer.from_host(x)
+        x = (xs[:, 1] / 2) + (xs[:, 0] / 2) if kind == 1 else xs
+    reps = -(-seconds // min(seconds, 100)) * clips
+    x = np.ascontiguousarray(np.tile(x, reps) if x.ndim == 1 else np.tile(x, (reps, 1)))
+    offsets = np.arange(clips + 1, dtype=np.int64) * (x.shape[0] // clips)
+    d_in = _ffi.DeviceBuffer.from_host(x.reshape(-1))
     plan = _ffi.Plan(offsets, fs, W, S, deltas=bool(deltas), sample_kind=kind, mode=mode)
     d_out = _ffi.DeviceBuffer(plan.out_doubles * 8)
     for _ in range(3): plan.execute(d_in, d_out)

@@ -103,7 +103,7 @@ def test_mid_feature_extraction_to_file(gpu_lib, tmp_path):
 
 @pytest.mark.gpu
 def test_stereo_batch_equals_single_clips(gpu_lib):
-    """Interleaved int16 stereo clips in one batch (int32 sums L + R, sample kind 2) == the single-clip fused
+    """Interleaved int16 stereo clips in one batch (sample kind 2: L + R formed in the kernels' loads) == the single-clip fused
     stereo path == the float64 stereo_to_mono signal through the oracle."""
     from pyaudioanalysis_amd import audioBasicIO
     from synth import synth_clip

@@ -41,8 +41,22 @@ class _OracleEngine:
         return _HostBuf(np.concatenate([self.O.feature_extraction(c, sampling_rate, window, step, deltas)[0].reshape(-1)
                                         for c in clips]))
 
+    def extract_mid(self, clips, sampling_rate, window, step, mid_ratio, mid_step_ratio):
+        self.extract_calls += 1
+        out = []
+        for c in clips:
+            st, _ = self.O.feature_extraction(c, sampling_rate, window, step, True)
+            # the reference's loop (MidTermFeatures.py:116-124) on the frame ratios extract_sharded derived
+            cols = [np.concatenate([st[:, p:p + mid_ratio].mean(axis=1), st[:, p:p + mid_ratio].std(axis=1)])
+                    for p in range(0, st.shape[1], mid_step_ratio)]
+            out.append(np.stack(cols, axis=1).reshape(-1))
+        return _HostBuf(np.concatenate(out))
+
     def alloc(self, n_doubles):
         return _HostBuf(np.zeros(max(int(n_doubles), 1)))
+
+    def view(self, buf, offset_doubles, n_doubles):
+        return _HostBuf(buf.arr[int(offset_doubles):int(offset_doubles) + int(n_doubles)])
 
     def to_host(self, buf, n_doubles):
         return buf.arr[:int(n_doubles)]
@@ -58,17 +72,19 @@ class _GlooGather:
     def __init__(self, dist, torch, world_size, rank):
         self.dist, self.torch, self.world_size, self.rank = dist, torch, world_size, rank
 
-    def gather(self, send, counts, root, recv):
+    def gather(self, send, counts, root, recv, displs=None):
         counts = [int(c) for c in counts]
+        if displs is None:
+            displs = np.concatenate(([0], np.cumsum(counts)[:-1]))
         if self.rank == root:
-            off, reqs, parts = 0, [], {}
+            reqs, parts = [], {}
             for r in range(self.world_size):
+                off = int(displs[r])
                 if r != root and counts[r] > 0:
                     parts[r] = (off, self.torch.empty(counts[r], dtype=self.torch.float64))
                     reqs.append(self.dist.irecv(parts[r][1], src=r))
                 elif r == root:
                     recv.arr[off:off + counts[r]] = send.arr[:counts[r]]
-                off += counts[r]
             for q in reqs:
                 q.wait()
             for r, (o, t) in parts.items():
@@ -115,6 +131,18 @@ def _worker(rank, world, port, q, rdir):
         changed[0] = synth_clip(12345, lens[0])
         third = D.extract_sharded(changed, 16000, W, S, True, world, rank, comm, root=0, engine=eng3, restart_dir=rdir)
         restart_ok = (eng1.extract_calls, eng2.extract_calls) == (1, 0) and eng3.extract_calls == (1 if rank == 0 else 0)
+        # chunked pipeline: 3 pieces per rank, each gathered to its final place; with restart files a rerun sends
+        # slices of the loaded block piece by piece
+        eng4, eng5 = _OracleEngine(O), _OracleEngine(O)
+        rdir3 = os.path.join(rdir, "k3")
+        chunked = D.extract_sharded(clips, 16000, W, S, True, world, rank, comm, root=0, engine=eng4, chunks=3,
+                                    restart_dir=rdir3)
+        chunked_again = D.extract_sharded(clips, 16000, W, S, True, world, rank, comm, root=0, engine=eng5, chunks=3,
+                                          restart_dir=rdir3)
+        restart_ok = restart_ok and eng4.extract_calls >= 2 and eng5.extract_calls == 0
+        # the cheap gather: (136, M) mid-term matrices of 1.0 s / 0.5 s over 50 ms / 25 ms, 2 pieces per rank
+        mids = D.extract_sharded(clips, 16000, W, S, True, world, rank, comm, root=0, engine=_OracleEngine(O), chunks=2,
+                                 gather="mid", mid_window=16000, mid_step=8000)
         flags = [None] * world
         dist.all_gather_object(flags, bool(restart_ok))
         comm.barrier()
@@ -123,6 +151,10 @@ def _worker(rank, world, port, q, rdir):
             ok &= all(np.array_equal(x, y) and np.array_equal(x, z) for x, y, z in zip(per_clip, first, again))
             ok &= bool(np.array_equal(third[0], O.feature_extraction(changed[0], 16000, W, S)[0]))
             ok &= all(np.array_equal(x, y) for x, y in zip(per_clip[1:], third[1:]))
+            ok &= all(np.array_equal(x, y) and np.array_equal(x, z) for x, y, z in zip(per_clip, chunked, chunked_again))
+            for c, got in zip(clips, mids):
+                ref_mid = O.mid_feature_extraction(c, 16000, 16000, 8000, W, S)[0]
+                ok &= bool(got.shape == ref_mid.shape and np.allclose(got, ref_mid, rtol=1e-12, atol=1e-12))
             for c, got in zip(clips, per_clip or []):
                 ref, _ = O.feature_extraction(c, 16000, W, S)
                 ok &= bool(np.array_equal(got, ref))
@@ -169,3 +201,50 @@ def test_partition_properties():
     ranges = D.partition_by_frames(np.full(100000, 399), 8)
     assert [b - a for a, b in ranges] == [12500] * 8
     assert list(D.frames_per_clip([799, 800, 1199, 1200, 160000], 800, 400)) == [0, 1, 1, 2, 399]
+
+
+def _socket_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from pyaudioanalysis_amd._rendezvous import SocketGroup
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    g = SocketGroup(timeout=60)
+    try:
+        got = g.all_gather({"rank": rank, "blob": bytes([rank]) * 1000})
+        ok = [d["rank"] for d in got] == list(range(world)) and all(d["blob"] == bytes([r]) * 1000 for r, d in enumerate(got))
+        ok &= g.broadcast(b"id-%d" % rank, 0) == b"id-0"
+        ok &= g.all_max(10.0 + rank) == 10.0 + world - 1
+        for _ in range(20):
+            g.barrier()
+        q.put((rank, bool(ok)))
+    finally:
+        g.close()
+
+
+def test_socket_control_plane_world_3():
+    """_rendezvous.SocketGroup on the launcher's environment variables: all-gather / broadcast / max / barrier among three
+    processes, with MASTER_PORT itself occupied by a foreign listener (as torchrun's agent store does) and the first
+    candidate port taken by another foreign listener that never answers the handshake."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    foreign = socket.socket()
+    foreign.bind(("127.0.0.1", 0))
+    port = foreign.getsockname()[1]
+    foreign.listen(4)
+    squatter = socket.socket()
+    try:
+        squatter.bind(("", port + 1))
+        squatter.listen(4)
+    except OSError:
+        squatter = None
+    procs = [ctx.Process(target=_socket_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    foreign.close()
+    if squatter is not None:
+        squatter.close()
+    assert got == [(0, True), (1, True), (2, True)]
