@@ -22,6 +22,13 @@ def main(prof_dir, out_path):
     if line["case"] == "mid_stats":
         like = "%mid_stats_kernel%"
     out["kernel_like"] = like
+    if line["case"] == "mid_stats":
+        # the profiled kernel is mid_stats_kernel alone: it reads the (68, T) short-term slabs once and writes (136, M)
+        # (MidTermFeatures.py:110-126; 1000 clips x 1199 frames, mid-term window and step of 40 frames -> M = 30)
+        clips, T, M = 1000, line["frames"] // 1000, -(-(line["frames"] // 1000) // 40)
+        line = dict(line, algorithmic_bytes_per_launch=8 * clips * (68 * T + 136 * M),
+                    algorithmic_bytes_note="mid_stats_kernel only: 8 B x (68 T + 136 M) per clip")
+        out["run_under_trace"] = line
     con = sqlite3.connect(os.path.join(prof_dir, "trace", "trace_results.db"))
     out["kernel_trace_stats"] = [dict(name=r[0][:160], calls=r[1], total_us=r[2], avg_us=r[3], pct=r[4])
                                  for r in con.execute("select * from top_kernels")][:8]
