@@ -1,0 +1,464 @@
+// Mixed-radix feature kernel for every window whose FFT length factors into {2, 3, 5, 7, 11, 13} and that no
+// register-FFT kernel covers (50 ms at 44.1 / 48 kHz = 2205 / 2400 samples, 40 ms at 44.1 / 48 kHz = 1764 / 1920, 1024, ...):
+// any step, int16 / interleaved stereo int16 / float64 samples, features / spectrogram / chromagram.
+//
+// One wave owns a run of consecutive frames, one frame at a time, like the generic kernel -- but the FFT is an IN-PLACE
+// decimation-in-frequency transform (radix 8/4/2/7/11/13/5/3 butterflies held in registers, digit-reversed output read
+// back through a host-built permutation), so a wave needs ONE complex buffer instead of the Stockham ping-pong pair, and
+// the spectrum is written over the dead FFT buffer:
+//
+//     LDS per wave = Nc complex (FFT / current spectrum) + Nf doubles (previous spectrum) + the feature staging,
+//
+// 34 KB instead of 62 KB at window 2400: four waves per CU instead of one.  The two spectra never move: even frames of
+// a run transform in [0, B) and leave their spectrum at the front, odd frames transform in [U, U + B) and leave it at
+// the back, so the previous spectrum always sits in the third the current transform does not touch (B = 16 Nc bytes,
+// U = 8 Nf bytes rounded to 16).
+//
+// Replaces the while loop at ShortTermFeatures.py:608-682 (+ helpers :22-140, :236-321) and the loops of spectrogram
+// (:415-422) / chromagram (:349-359) for those windows; the time-domain and spectral feature stages are the generic
+// kernel's (kernels_generic.hpp).
+#pragma once
+#include <vector>
+
+#include "kernels_ct.hpp"
+#include "kernels_generic.hpp"
+
+namespace paa {
+namespace mix {
+#if defined(PAA_F800_TIMING) || defined(PAA_F800_TRACE)
+using f800::g_phase_cycles;        // per-phase cycle accounting of diagnostic builds (PAA_T0 / PAA_TICK / PAA_TEND)
+using f800::g_wave_trace;
+#endif
+
+constexpr int kMaxPass = 12;
+constexpr int kSlots = 24;          // magnitude pass: result pairs a lane keeps until every lane has read its inputs
+
+struct MixLayout {
+    int off_tw, off_post, off_perm, off_mello, off_melcnt, off_meloff, off_melw, off_dct, off_chstart, off_chsrc, off_chw;
+    int table_bytes;     // multiple of 16
+    int wave_bytes;      // per-wave region, multiple of 16
+    int waves;           // waves per workgroup
+    int tw_global;       // 1: twiddles and post-twiddles stay in global memory (L1/L2 hits), 0: LDS copies
+    int unit_bytes;      // U: one spectrum, rounded to 16 bytes
+    int buf_bytes;       // B: Nc complex
+    int n_pass;
+    int radix[kMaxPass];
+    int span[kMaxPass];            // M of the pass: the block a butterfly lives in (M / radix = element stride)
+    int tws[kMaxPass];             // Nc / M: twiddle W_M^j = tw[j * tws]
+    unsigned magic[kMaxPass];      // floor(2^32 / stride) + 1: b / stride == umulhi(b, magic) for b < 2^16
+};
+
+// ---- prime butterflies: X[q], X[R-q] from the sums / differences of the pairs (x_j, x_{R-j}) -------------------
+template <int R> struct PrimeTab;
+template <> struct PrimeTab<7> {
+    static constexpr double c[7] = {1.00000000000000000000, 0.62348980185873359439, -0.22252093395631433737, -0.90096886790241903498, -0.90096886790241914600, -0.22252093395631458717, 0.62348980185873337234};
+    static constexpr double s[7] = {0.00000000000000000000, 0.78183148246802980363, 0.97492791218182361934, 0.43388373911755823142, -0.43388373911755800938, -0.97492791218182361934, -0.78183148246802991466};
+};
+template <> struct PrimeTab<11> {
+    static constexpr double c[11] = {1.00000000000000000000, 0.84125353283118120551, 0.41541501300188643508, -0.14231483827328500480, -0.65486073394528498959, -0.95949297361449736865, -0.95949297361449747967, -0.65486073394528521163, -0.14231483827328522684, 0.41541501300188604651, 0.84125353283118120551};
+    static constexpr double s[11] = {0.00000000000000000000, 0.54064081745559755543, 0.90963199535451833011, 0.98982144188093279524, 0.75574957435425826890, 0.28173255684142967104, -0.28173255684142939348, -0.75574957435425815788, -0.98982144188093268422, -0.90963199535451855215, -0.54064081745559744441};
+};
+template <> struct PrimeTab<13> {
+    static constexpr double c[13] = {1.00000000000000000000, 0.88545602565320991051, 0.56806474673115592289, 0.12053668025532300601, -0.35460488704253545489, -0.74851074817110119231, -0.97094181742605201180, -0.97094181742605212282, -0.74851074817110130333, -0.35460488704253589898, 0.12053668025532320029, 0.56806474673115481266, 0.88545602565321002153};
+    static constexpr double s[13] = {0.00000000000000000000, 0.46472317204376850652, 0.82298386589365635224, 0.99270887409805397272, 0.93501624268541483342, 0.66312265824079519305, 0.23931566428755768339, -0.23931566428755743359, -0.66312265824079497101, -0.93501624268541472240, -0.99270887409805397272, -0.82298386589365701838, -0.46472317204376839550};
+};
+
+template <int R>
+__device__ __forceinline__ void dft_prime(double2 *v) {
+    constexpr int H = (R - 1) / 2;
+    double2 sm[H], df[H];
+#pragma unroll
+    for (int j = 1; j <= H; ++j) {
+        sm[j - 1] = cadd(v[j], v[R - j]);
+        df[j - 1] = csub(v[j], v[R - j]);
+    }
+    const double2 x0 = v[0];
+    double2 tot = x0;
+#pragma unroll
+    for (int j = 0; j < H; ++j) tot = cadd(tot, sm[j]);
+#pragma unroll
+    for (int q = 1; q <= H; ++q) {
+        double ar = x0.x, ai = x0.y, br = 0.0, bi = 0.0;
+#pragma unroll
+        for (int j = 1; j <= H; ++j) {
+            const double c = PrimeTab<R>::c[(j * q) % R], s = PrimeTab<R>::s[(j * q) % R];
+            ar = fma(c, sm[j - 1].x, ar);
+            ai = fma(c, sm[j - 1].y, ai);
+            br = fma(s, df[j - 1].x, br);
+            bi = fma(s, df[j - 1].y, bi);
+        }
+        // X[q] = A - i B, X[R-q] = A + i B  with A = x0 + sum cos (x_j + x_{R-j}), B = sum sin (x_j - x_{R-j})
+        v[q] = make_double2(ar + bi, ai - br);
+        v[R - q] = make_double2(ar - bi, ai + br);
+    }
+    v[0] = tot;
+}
+
+// radix 8 in natural order: two radix-4 halves, W8 twiddles on the odd half
+__device__ __forceinline__ void dft8_natural(double2 *v) {
+    const double h = 0.70710678118654752440;
+    double2 a[4] = {v[0], v[2], v[4], v[6]}, b[4] = {v[1], v[3], v[5], v[7]};
+    dft4(a);
+    dft4(b);
+    b[1] = make_double2(h * (b[1].x + b[1].y), h * (b[1].y - b[1].x));      // W8   = (h, -h)
+    b[2] = make_double2(b[2].y, -b[2].x);                                   // W8^2 = -i
+    b[3] = make_double2(h * (b[3].y - b[3].x), -h * (b[3].x + b[3].y));     // W8^3 = (-h, -h)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[k] = cadd(a[k], b[k]);
+        v[k + 4] = csub(a[k], b[k]);
+    }
+}
+
+template <int R> struct Bfly { static __device__ __forceinline__ void run(double2 *v) { dft_prime<R>(v); } };
+template <> struct Bfly<2> { static __device__ __forceinline__ void run(double2 *v) { dft2(v); } };
+template <> struct Bfly<3> { static __device__ __forceinline__ void run(double2 *v) { dft3(v); } };
+template <> struct Bfly<4> { static __device__ __forceinline__ void run(double2 *v) { dft4(v); } };
+template <> struct Bfly<5> { static __device__ __forceinline__ void run(double2 *v) { dft5(v); } };
+template <> struct Bfly<8> { static __device__ __forceinline__ void run(double2 *v) { dft8_natural(v); } };
+
+// ---- one in-place DIF pass: butterfly b works on the R elements base + r * stride of its block; output q is multiplied
+// by W_M^(q k) and goes back to base + q * stride.  Butterflies touch disjoint elements: no ordering inside a pass.
+template <int R>
+__device__ __forceinline__ void dif_pass(double2 *buf, int Nc, int M, int tws, unsigned magic,
+                                         const double2 *__restrict__ tw, int lane) {
+    const int stride = M / R, nb = Nc / R;
+#pragma unroll 2
+    for (int b = lane; b < nb; b += kWave) {
+        const int blk = (stride == 1) ? b : (int)__umulhi((unsigned)b, magic);
+        const int k = b - blk * stride;
+        double2 *e = buf + blk * M + k;
+        double2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = e[r * stride];
+        Bfly<R>::run(v);
+        if (stride > 1) {
+            const int t1 = k * tws;
+#pragma unroll
+            for (int q = 1; q < R; ++q) v[q] = cmul(v[q], tw[q * t1]);
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) e[q * stride] = v[q];
+    }
+}
+
+// ---- the whole transform + |X| / num_fft (ShortTermFeatures.py:617-621) ------------------------------------------
+// buf: the frame as packed complex (even windows: z[m] = y[2m] + i y[2m+1]; odd: z[n] = y[n]); cur: where the Nf
+// magnitudes go -- it may overlap buf: every lane holds its results in registers until all inputs have been read.
+__device__ __forceinline__ void fft_passes_inplace(const PlanDev &P, const MixLayout &L, double2 *buf,
+                                                   const double2 *__restrict__ tw, int lane) {
+    const int Nc = P.Nc;
+    for (int p = 0; p < L.n_pass; ++p) {
+        const int M = L.span[p];
+        const unsigned mg = L.magic[p];
+        const int ts = L.tws[p];
+        switch (L.radix[p]) {
+            case 2: dif_pass<2>(buf, Nc, M, ts, mg, tw, lane); break;
+            case 3: dif_pass<3>(buf, Nc, M, ts, mg, tw, lane); break;
+            case 4: dif_pass<4>(buf, Nc, M, ts, mg, tw, lane); break;
+            case 5: dif_pass<5>(buf, Nc, M, ts, mg, tw, lane); break;
+            case 7: dif_pass<7>(buf, Nc, M, ts, mg, tw, lane); break;
+            case 8: dif_pass<8>(buf, Nc, M, ts, mg, tw, lane); break;
+            case 11: dif_pass<11>(buf, Nc, M, ts, mg, tw, lane); break;
+            default: dif_pass<13>(buf, Nc, M, ts, mg, tw, lane); break;
+        }
+        wsync();
+    }
+}
+__device__ __forceinline__ void magnitudes_inplace(const PlanDev &P, const double2 *buf, const double2 *__restrict__ post,
+                                                   const unsigned short *__restrict__ perm, double *cur, int lane) {
+    const int Nc = P.Nc, Nf = P.Nf;
+    const double invNf = 1.0 / (double)Nf;     // X / len(X)  (:621)
+    double r0[kSlots], r1[kSlots];
+    if (P.even) {
+        // bins k and Nc - k come from the same pair: X[k] = E + w^k O, X[Nc-k] = conj(E - w^k O) with
+        // E = (Z[k] + conj Z[Nc-k]) / 2, O = -i (Z[k] - conj Z[Nc-k]) / 2
+        const int npairs = Nc / 2 + 1;
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
+            r0[j] = 0.0; r1[j] = 0.0;
+            if (kWave * j < npairs) {
+                const int k = lane + kWave * j;
+                if (k < npairs) {
+                    const double2 zk = buf[perm[k]];
+                    const double2 zm = buf[perm[k == 0 ? 0 : Nc - k]];
+                    const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+                    const double2 o = make_double2(0.5 * (zk.y + zm.y), 0.5 * (zm.x - zk.x));
+                    const double2 wo = cmul(post[k], o);
+                    const double ar = e.x + wo.x, ai = e.y + wo.y, br = e.x - wo.x, bi = e.y - wo.y;
+                    r0[j] = mag_sqrt(fma(ar, ar, ai * ai)) * invNf;
+                    r1[j] = mag_sqrt(fma(br, br, bi * bi)) * invNf;
+                }
+            }
+        }
+        wsync();
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
+            if (kWave * j < npairs) {
+                const int k = lane + kWave * j;
+                if (k < npairs) {
+                    cur[k] = r0[j];
+                    if (k > 0 && Nc - k != k) cur[Nc - k] = r1[j];
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
+            r0[j] = 0.0; r1[j] = 0.0;
+            if (kWave * j < Nf) {
+                const int k = lane + kWave * j, k2 = k + kWave * kSlots;
+                if (k < Nf) { const double2 z = buf[perm[k]]; r0[j] = mag_sqrt(fma(z.x, z.x, z.y * z.y)) * invNf; }
+                if (k2 < Nf) { const double2 z = buf[perm[k2]]; r1[j] = mag_sqrt(fma(z.x, z.x, z.y * z.y)) * invNf; }
+            }
+        }
+        wsync();
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
+            if (kWave * j < Nf) {
+                const int k = lane + kWave * j, k2 = k + kWave * kSlots;
+                if (k < Nf) cur[k] = r0[j];
+                if (k2 < Nf) cur[k2] = r1[j];
+            }
+        }
+    }
+    wsync();
+}
+
+// load + normalise one frame into buf; even windows fetch two consecutive samples per load (element alignment only)
+template <typename T>
+__device__ __forceinline__ void frame_load_pairs(const PlanDev &P, const T *__restrict__ x, ClipNorm nm, double2 *buf, int lane) {
+    const double sc = sample_scale<T>();
+    if (P.even) {
+        for (int m = lane; m < P.Nc; m += kWave) {
+            const double2 s = ct::PairLoad<T>::get(x + 2 * m);
+            buf[m] = make_double2(fma(s.x, sc, -nm.mean) * nm.inv, fma(s.y, sc, -nm.mean) * nm.inv);
+        }
+    } else {
+        for (int n = lane; n < P.W; n += kWave)
+            buf[n] = make_double2(fma(load_sample<T>(x + n), sc, -nm.mean) * nm.inv, 0.0);
+    }
+    wsync();
+}
+
+// ---- host: radix schedule, permutation, LDS layout + table blob ---------------------------------------------------
+inline bool mix_factor(int n, std::vector<int> &radix) {
+    radix.clear();
+    int twos = 0;
+    while (n % 2 == 0) { ++twos; n /= 2; }
+    std::vector<int> odd;
+    for (int f : {13, 11, 7, 5, 3})
+        while (n % f == 0) { odd.push_back(f); n /= f; }
+    if (n != 1) return false;
+    // big strides first for the power-of-two butterflies, the odd radices (conflict-free at small strides) last
+    while (twos >= 3 && twos != 4) { radix.push_back(8); twos -= 3; }
+    while (twos >= 2) { radix.push_back(4); twos -= 2; }
+    if (twos) radix.push_back(2);
+    for (int f : odd) radix.push_back(f);
+    return (int)radix.size() <= kMaxPass && !radix.empty();
+}
+
+// position that holds Z[k] after the passes: digit q_p of k (least significant first) sits at weight Nc / (R_0 .. R_p)
+inline void mix_permutation(int Nc, const std::vector<int> &radix, std::vector<unsigned short> &perm) {
+    perm.assign((size_t)Nc, 0);
+    for (int k = 0; k < Nc; ++k) {
+        int rest = k, weight = Nc, pos = 0;
+        for (int R : radix) {
+            weight /= R;
+            pos += (rest % R) * weight;
+            rest /= R;
+        }
+        perm[k] = (unsigned short)pos;
+    }
+}
+
+// 0: this window is not for the mixed-radix kernel.  Fills the layout and the host image of the shared table region.
+inline int mix_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable *chroma, int F, MixLayout &L,
+                      std::vector<unsigned char> *blob) {
+    const int Nc = fft.len, Nf = fft.window / 2;
+    if (Nc < 2 || Nc > 60000) return 0;
+    std::vector<int> radix;
+    if (!mix_factor(Nc, radix)) return 0;
+    if (fft.even ? (Nc / 2 + 1 > kWave * kSlots) : (Nf > 2 * kWave * kSlots)) return 0;
+    memset(&L, 0, sizeof(L));
+    L.n_pass = (int)radix.size();
+    int M = Nc;
+    for (int p = 0; p < L.n_pass; ++p) {
+        L.radix[p] = radix[p];
+        L.span[p] = M;
+        const unsigned stride = (unsigned)(M / radix[p]);
+        L.magic[p] = stride > 1 ? (unsigned)((1ULL << 32) / stride) + 1u : 0u;
+        L.tws[p] = Nc / M;
+        M /= radix[p];
+    }
+    L.unit_bytes = (Nf * 8 + 15) / 16 * 16;
+    L.buf_bytes = Nc * 16;
+    const int FF = F > 0 ? F : 1;
+    L.wave_bytes = (L.buf_bytes + L.unit_bytes + kFlush * FF * 8 + 48 * 8 + 40 * 8 + 15) / 16 * 16;
+    const size_t n_melw = mel ? mel->w.size() : 0, n_ch = chroma ? chroma->src.size() : 0;
+    const size_t n_post = fft.even ? (size_t)(Nc / 2 + 1) : 1;
+    auto lay = [&](int tw_global) {
+        int off = 0;
+        auto take = [&off](size_t bytes) { const int o = off; off += (int)((bytes + 15) / 16 * 16); return o; };
+        L.off_tw = take(tw_global ? 16 : (size_t)Nc * 16);
+        L.off_post = take(tw_global ? 16 : n_post * 16);
+        L.off_perm = take((size_t)Nc * 2);
+        L.off_mello = take(40 * 4);
+        L.off_melcnt = take(40 * 4);
+        L.off_meloff = take(40 * 4);
+        L.off_melw = take(std::max<size_t>(n_melw, 1) * 8);
+        L.off_dct = take(13 * 41 * 8);
+        L.off_chstart = take(13 * 4);
+        L.off_chsrc = take(std::max<size_t>(n_ch, 1) * 4);
+        L.off_chw = take(std::max<size_t>(n_ch, 1) * 8);
+        L.table_bytes = off;
+        int waves = 4;
+        while (waves > 0 && (size_t)L.table_bytes + (size_t)waves * L.wave_bytes > 160 * 1024) --waves;
+        return waves;
+    };
+    // the twiddle tables go to LDS unless that costs a wave
+    const int w_lds = lay(0), w_glob = lay(1);
+    L.tw_global = (w_glob > w_lds) ? 1 : 0;
+    L.waves = lay(L.tw_global);
+    if (L.waves < 1) return 0;
+    if (!blob) return 1;
+    blob->assign((size_t)L.table_bytes, 0);
+    unsigned char *b = blob->data();
+    if (!L.tw_global) {
+        memcpy(b + L.off_tw, fft.tw.data(), (size_t)Nc * 16);
+        if (fft.even) memcpy(b + L.off_post, fft.post.data(), n_post * 16);
+    }
+    std::vector<unsigned short> perm;
+    mix_permutation(Nc, radix, perm);
+    memcpy(b + L.off_perm, perm.data(), (size_t)Nc * 2);
+    if (mel && !mel->w.empty()) {
+        memcpy(b + L.off_mello, mel->lo.data(), 40 * 4);
+        memcpy(b + L.off_melcnt, mel->cnt.data(), 40 * 4);
+        memcpy(b + L.off_meloff, mel->off.data(), 40 * 4);
+        memcpy(b + L.off_melw, mel->w.data(), n_melw * 8);
+        double dct[kNumMfcc * kNumMel];
+        build_dct(dct);
+        double *d = reinterpret_cast<double *>(b + L.off_dct);
+        for (int q = 0; q < 13; ++q)
+            for (int n = 0; n < 40; ++n) d[q * 41 + n] = dct[q * 40 + n];
+    }
+    if (chroma && !chroma->src.empty()) {
+        memcpy(b + L.off_chstart, chroma->class_start, 13 * 4);
+        memcpy(b + L.off_chsrc, chroma->src.data(), n_ch * 4);
+        memcpy(b + L.off_chw, chroma->w.data(), n_ch * 8);
+    }
+    return 1;
+}
+
+inline size_t mix_lds_bytes(const MixLayout &L) { return (size_t)L.table_bytes + (size_t)L.waves * L.wave_bytes; }
+
+// TWG = 1: twiddles / post-twiddles are read from global memory (the tables of a 2400-sample window would cost a wave)
+template <typename T, int TWG>
+__global__ __launch_bounds__(256) void st_mix_kernel(PlanDev P, MixLayout L, const unsigned char *__restrict__ blob,
+                                                      const T *__restrict__ sig, const ClipDev *__restrict__ clips,
+                                                      const ClipNorm *__restrict__ norms, const Tile *__restrict__ tiles,
+                                                      int n_tiles, double *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    {
+        const int4 *src4 = reinterpret_cast<const int4 *>(blob);
+        int4 *dst4 = reinterpret_cast<int4 *>(smem);
+        for (int n = threadIdx.x; n < L.table_bytes / 16; n += blockDim.x) dst4[n] = src4[n];
+    }
+    __syncthreads();       // the only workgroup-wide barrier
+    Tabs tb;
+    tb.tw = TWG ? P.tw : reinterpret_cast<const double2 *>(smem + L.off_tw);
+    tb.post = TWG ? P.post : reinterpret_cast<const double2 *>(smem + L.off_post);
+    const unsigned short *perm = reinterpret_cast<const unsigned short *>(smem + L.off_perm);
+    tb.mel_lo = reinterpret_cast<const int *>(smem + L.off_mello);
+    tb.mel_cnt = reinterpret_cast<const int *>(smem + L.off_melcnt);
+    tb.mel_off = reinterpret_cast<const int *>(smem + L.off_meloff);
+    tb.mel_w = reinterpret_cast<const double *>(smem + L.off_melw);
+    tb.dct = reinterpret_cast<const double *>(smem + L.off_dct);
+    tb.dct_stride = 41;
+    tb.ch_start = reinterpret_cast<const int *>(smem + L.off_chstart);
+    tb.ch_src = reinterpret_cast<const int *>(smem + L.off_chsrc);
+    tb.ch_w = reinterpret_cast<const double *>(smem + L.off_chw);
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int tile_id = blockIdx.x * L.waves + wave;
+    if (tile_id >= n_tiles) return;
+    const int Nf = P.Nf, F = P.F > 0 ? P.F : 1;
+    unsigned char *wb = smem + L.table_bytes + wave * L.wave_bytes;
+    double *otile = reinterpret_cast<double *>(wb + L.buf_bytes + L.unit_bytes);
+    double *fv = otile + kFlush * F;
+    double *msp = fv + 48;
+
+    const Tile tl = tiles[tile_id];
+    const ClipDev c = clips[tl.clip];
+    const ClipNorm nm = norms[tl.clip];
+    const T *x0 = sig + c.sample_off + P.frame_origin;
+    const long long Tc = c.T;
+    double *oc = out + c.out_off;
+
+    const int hneed = (P.mode == 0) ? (P.deltas ? 2 : 1) : 0;
+    const int h = min(hneed, tl.t0);
+    double vprev = 0.0;
+    int nslot = 0, tbase = tl.t0, odd = 0;
+    const int tend = tl.t0 + tl.cnt;
+    PAA_T0()
+    for (int t = tl.t0 - h; t < tend; ++t, odd ^= 1) {
+        // even frames of the run: transform at the front, spectrum at the very front, previous spectrum behind the buffer;
+        // odd frames: transform one unit further, spectrum in its last unit, previous spectrum at the very front
+        double2 *buf = reinterpret_cast<double2 *>(wb + (odd ? L.unit_bytes : 0));
+        double *cur = reinterpret_cast<double *>(wb + (odd ? L.buf_bytes : 0));
+        double *prv = reinterpret_cast<double *>(wb + (odd ? 0 : L.buf_bytes));
+        const T *x = x0 + (long long)t * P.S;
+        frame_load_pairs<T>(P, x, nm, buf, lane);
+        PAA_TICK(0)
+        const bool want = (P.mode == 0) && ((t >= tl.t0) || (P.deltas && t == tl.t0 - 1));
+        TimeFeat tf;
+        tf.e_tot = 0.0; tf.ent_e = 0.0; tf.zc = 0;
+        if (want) tf = time_features(P, buf, lane);
+        PAA_TICK(1)
+        fft_passes_inplace(P, L, buf, tb.tw, lane);
+        PAA_TICK(2)
+        magnitudes_inplace(P, buf, tb.post, perm, cur, lane);
+        PAA_TICK(3)
+        if (P.mode == 1) {            // spectrogram row (ShortTermFeatures.py:422)
+            double *row = oc + (long long)t * Nf;
+            for (int k = lane; k < Nf; k += kWave) __builtin_nontemporal_store(cur[k], row + k);
+        } else if (P.mode == 2) {     // chromagram row (:356-359)
+            double p = 0.0;
+            for (int k = lane; k < Nf; k += kWave) { const double X = cur[k]; p = fma(X, X, p); }
+            p = wsum(p);
+            const double ch = chroma_class(tb, cur, p, lane);
+            if (lane < 12) oc[(long long)t * 12 + lane] = ch;
+        } else {
+            if (want) {
+                frame_features(P, tb, tf, cur, (t == 0) ? cur : prv, fv, msp, lane);
+                PAA_TICK(5)
+                const double v = (lane < kBase) ? fv[lane] : 0.0;
+                if (t >= tl.t0) {
+                    if (lane < kBase) {
+                        otile[nslot * F + lane] = v;
+                        if (P.deltas) otile[nslot * F + kBase + lane] = (t == 0) ? 0.0 : v - vprev;
+                    }
+                    ++nslot;
+                }
+                vprev = v;
+            }
+            if (nslot == kFlush || (t == tend - 1 && nslot > 0)) {
+                wsync();
+                // row segments: nslot consecutive frames of feature row f are contiguous in [F][T]
+                for (int idx = lane; idx < F * kFlush; idx += kWave) {
+                    const int f = idx / kFlush, i = idx % kFlush;
+                    if (i < nslot) oc[(long long)f * Tc + tbase + i] = otile[i * F + f];
+                }
+                wsync();
+                tbase += nslot;
+                nslot = 0;
+            }
+        }
+        wsync();
+        PAA_TICK(10)
+    }
+    PAA_TEND()
+}
+
+}  // namespace mix
+}  // namespace paa

@@ -23,6 +23,7 @@
 #include "kernels_ct.hpp"
 #include "kernels_fast.hpp"
 #include "kernels_generic.hpp"
+#include "kernels_mix.hpp"
 #include "kernels_reg.hpp"
 #include "kernels_sim.hpp"
 #include "kernels_svm.hpp"
@@ -364,6 +365,8 @@ struct paa_plan {
     size_t lds = 0;
     int fast = 0;                    // 1: specialised kernel
     FastLaunch fl;
+    int mixk = 0;                    // 1: in-place mixed-radix kernel (kernels_mix.hpp); table blob in d_gen_blob
+    mix::MixLayout ml;
     int ct = 0;                      // 1: register-FFT family for windows 2 RA RB (kernels_ct.hpp); table blob in d_gen_blob
     ct::CtLaunch cl;
     std::string kernel_name;
@@ -498,7 +501,22 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
             p->reg = 1;
         }
     }
-    if (p->ct) {
+    if (!p->fast && !p->ct && !p->reg && !g_force_generic && !getenv("PAA_NO_MIX")) {
+        // FFT lengths made of 2, 3, 5, 7, 11, 13 (50 ms at 44.1 / 48 kHz, 1024, ...): in-place transform, 4 waves per CU
+        std::vector<unsigned char> blob;
+        if (mix::mix_layout(tab->fft, mode == 0 ? &tab->mel : nullptr, mode != 1 ? &tab->chroma : nullptr, F, p->ml, &blob)) {
+            if ((rc = upload_pooled(&p->d_gen_blob, blob.data(), blob.size()))) return rc;
+            p->mixk = 1;
+        }
+    }
+    if (p->mixk) {
+        p->lds = mix::mix_lds_bytes(p->ml);
+        // one wave per run, one frame at a time (halo: 1 frame, 2 with deltas): about two chip-wide rounds, 8..64 frames per run
+        const long long slots = (long long)g_num_cu * p->ml.waves * 2;
+        const long long per = (total_frames + slots - 1) / slots;
+        run = (int)std::min<long long>(64, std::max<long long>(8, (per + 3) / 4 * 4));
+        p->kernel_name = (mode == 0) ? "st_mix" : (mode == 1 ? "spectrogram_mix" : "chromagram_mix");
+    } else if (p->ct) {
         // one wave per run, 4 frames per iteration; a run with t0 > 0 starts 1 frame early (2 with deltas) inside its first
         // iteration, so the first run of a clip gets `run` frames and the others run - halo: every run is whole iterations
         run_quantum = 4;
@@ -616,6 +634,25 @@ static int launch_generic(paa_plan *p, const void *d_packed, double *d_out) {
                        p->d_gen_blob, (const T *)d_packed, p->d_clips, p->d_norms, p->d_tiles, (int)p->n_tiles, d_out);
     HIP_TRY(hipGetLastError());
     return PAA_OK;
+}
+
+template <typename T, int TWG>
+static int launch_mix(paa_plan *p, const void *d_packed, double *d_out) {
+    static size_t attr_set = 0;
+    if (p->lds > attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mix::st_mix_kernel<T, TWG>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(p->lds, 64 * 1024)));
+        attr_set = std::max<size_t>(p->lds, 64 * 1024);
+    }
+    const unsigned grid = (unsigned)((p->n_tiles + p->ml.waves - 1) / p->ml.waves);
+    hipLaunchKernelGGL((mix::st_mix_kernel<T, TWG>), dim3(grid), dim3(64 * p->ml.waves), p->lds, cs(), p->P, p->ml,
+                       p->d_gen_blob, (const T *)d_packed, p->d_clips, p->d_norms, p->d_tiles, (int)p->n_tiles, d_out);
+    HIP_TRY(hipGetLastError());
+    return PAA_OK;
+}
+template <typename T>
+static int launch_mix_any(paa_plan *p, const void *d_packed, double *d_out) {
+    return p->ml.tw_global ? launch_mix<T, 1>(p, d_packed, d_out) : launch_mix<T, 0>(p, d_packed, d_out);
 }
 
 template <typename T>
@@ -739,6 +776,10 @@ extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *
     if (plan->reg)
         return plan->sample_kind == 0 ? launch_reg<int16_t>(plan, d_packed, d_out)
              : plan->sample_kind == 2 ? launch_reg<stereo16>(plan, d_packed, d_out) : launch_reg<double>(plan, d_packed, d_out);
+    if (plan->mixk)
+        return plan->sample_kind == 0 ? launch_mix_any<int16_t>(plan, d_packed, d_out)
+             : plan->sample_kind == 2 ? launch_mix_any<stereo16>(plan, d_packed, d_out)
+                                      : launch_mix_any<double>(plan, d_packed, d_out);
     return plan->sample_kind == 0 ? launch_generic<int16_t>(plan, d_packed, d_out)
          : plan->sample_kind == 2 ? launch_generic<stereo16>(plan, d_packed, d_out)
                                   : launch_generic<double>(plan, d_packed, d_out);

@@ -1,0 +1,108 @@
+"""The in-place mixed-radix kernel (csrc/kernels_mix.hpp: every window whose FFT length factors into 2, 3, 5, 7, 11, 13
+and that no register-FFT kernel covers -- 50 ms at 44.1 / 48 kHz, 40 ms at 44.1 / 48 kHz, 1024, odd windows, ...) against
+the plain-C oracle on every frame, through the C ABI.  -m gpu.  (ShortTermFeatures.py:608-682, :389-452, :324-386)"""
+import numpy as np
+import pytest
+
+import c_oracle
+import paa_oracle as O
+from pyaudioanalysis_amd import ShortTermFeatures, _ffi
+from synth import synth_clip
+from test_ct_kernels_gpu import ill_mask, make_signal, reference_matrix
+from test_parity_gpu import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def test_plans_dispatch_the_mixed_radix_kernel(gpu_lib):
+    def name(fs, w, s, kind=0, mode=0):
+        plan = _ffi.Plan(np.array([0, 20 * fs], dtype=np.int64), fs, w, s, deltas=False, sample_kind=kind, mode=mode)
+        try:
+            return plan.kernel_name
+        finally:
+            plan.destroy()
+    assert name(48000, 2400, 1200) == "st_mix"                 # 50 ms at 48 kHz (audioTrainTest.py:28-29)
+    assert name(44100, 2205, 1102) == "st_mix"                 # 50 ms at 44.1 kHz: odd window, full-length complex FFT
+    assert name(44100, 1764, 1764, mode=1) == "spectrogram_mix"    # the CLI's 40 ms at 44.1 kHz (audioAnalysis.py:71)
+    assert name(48000, 1920, 1920, mode=2) == "chromagram_mix"
+    assert name(16000, 1024, 512, kind=1) == "st_mix"
+    assert name(44100, 1102, 441) == "st_reg_29x19"            # 2 x 19 x 29 keeps its prime-factor kernel
+    assert name(16000, 800, 400) == "st_fast_800_w8"
+    assert name(22050, 1103, 441) == "st_generic"              # 1103 is prime: Stockham passes with an O(R^2) radix
+
+
+CASES = [
+    # fs, window, step, kind, seconds, deltas
+    (48000, 2400, 1200, "i16", 20, True),      # radices 8 4 4 ... 5 5 3, twiddles from global memory
+    (48000, 2400, 2400, "stereo", 15, False),
+    (48000, 2400, 480, "f64", 6, True),
+    (44100, 2205, 1102, "i16", 20, True),      # odd: 2205 = 3 3 5 7 7
+    (44100, 2205, 2205, "f64", 10, False),
+    (44100, 1764, 882, "i16", 15, True),       # 882 = 2 3 3 7 7
+    (48000, 1920, 960, "stereo", 10, True),    # 960 = 8 8 5 3
+    (32000, 1600, 800, "i16", 15, False),      # 50 ms at 32 kHz
+    (16000, 1024, 512, "i16", 20, True),       # 512 = 8 8 8
+    (16000, 512, 256, "f64", 10, True),
+    (22050, 1100, 550, "i16", 10, False),      # 550 = 2 5 5 11
+    (11025, 551, 275, "i16", 20, True),        # 50 ms at 11.025 kHz: odd, 19 x 29 -> stays generic (checked all the same)
+    (16000, 390, 200, "i16", 10, True),        # 195 = 3 5 13
+    (16000, 1001, 500, "unit", 10, False),     # odd: 7 11 13
+    (16000, 256, 128, "i16", 5, True),         # small window: 128 = 8 4 4
+]
+
+
+@pytest.mark.parametrize("fs,window,step,kind,seconds,deltas", CASES,
+                         ids=["%d_%d_%d_%s_%ds_%s" % (c[0], c[1], c[2], c[3], c[4], "d" if c[5] else "n") for c in CASES])
+def test_full_matrix_against_c_oracle(gpu_lib, fs, window, step, kind, seconds, deltas):
+    sig, mono = make_signal(kind, 9000 + window + step, seconds, fs)
+    F, names = ShortTermFeatures.feature_extraction(sig, fs, window, step, deltas)
+    ref = reference_matrix(mono, fs, window, step, deltas)
+    assert F.shape == ref.shape and len(names) == ref.shape[0]
+    assert_parity(F, ref, "%s %d/%d @%d" % (kind, window, step, fs), ill=ill_mask(mono, fs, window, step))
+    if deltas:
+        assert np.array_equal(F[34:, 1:], F[:34, 1:] - F[:34, :-1]) and np.all(F[34:, 0] == 0.0)
+        G, _ = ShortTermFeatures.feature_extraction(sig, fs, window, step, False)
+        assert np.array_equal(G, F[:34])
+
+
+@pytest.mark.parametrize("fs,window,step,kind", [(48000, 2400, 1200, "i16"), (44100, 2205, 1102, "stereo"),
+                                                  (44100, 1764, 1764, "i16"), (48000, 1920, 1920, "f64"),
+                                                  (16000, 1024, 300, "i16")])
+def test_spectrogram_chromagram_full_against_c_oracle(gpu_lib, capsys, fs, window, step, kind):
+    sig, mono = make_signal(kind, 9100 + window, 12.7, fs)
+    spec, t_ax, f_ax = ShortTermFeatures.spectrogram(sig, fs, window, step)
+    capsys.readouterr()
+    ref = c_oracle.spectrogram(mono, window, step)
+    assert spec.shape == ref.shape and len(t_ax) == ref.shape[0] and len(f_ax) == window // 2
+    assert_parity(np.ascontiguousarray(spec.T), np.ascontiguousarray(ref.T), "spectrogram %s %d/%d" % (kind, window, step))
+    chroma, ct_ax, cnames = ShortTermFeatures.chromagram(sig, fs, window, step)
+    cref = c_oracle.chromagram(mono, fs, window, step)
+    assert chroma.shape == cref.shape and cnames == O.CHROMA_NAMES
+    assert_parity(np.ascontiguousarray(chroma.T), np.ascontiguousarray(cref.T), "chromagram %s %d/%d" % (kind, window, step))
+
+
+def test_degenerate_clips_and_ragged_batches(gpu_lib):
+    fs, W, S = 48000, 2400, 1200
+    cases = {
+        "zeros": np.zeros(5 * W, dtype=np.int16),
+        "one_window": synth_clip(91, W, fs),
+        "w_plus_s_minus_1": synth_clip(92, W + S - 1, fs),
+        "dc": np.full(4 * W, 1234, dtype=np.int16),
+        "square": np.tile(np.array([32767, -32768], dtype=np.int16), 3 * W // 2),
+    }
+    x = synth_clip(93, 3 * fs, fs).copy()
+    x[fs:2 * fs] = 0
+    cases["silence_inside"] = x
+    for label, sig in cases.items():
+        F, _ = ShortTermFeatures.feature_extraction(sig, fs, W, S)
+        ref, _ = O.feature_extraction(sig, fs, W, S)
+        assert_parity(F, ref, label, sig=(sig, fs, W, S))
+    with pytest.raises(ValueError):
+        ShortTermFeatures.feature_extraction(synth_clip(94, W - 1, fs), fs, W, S)
+    lens = [W, 50000, 2 * W - 1, 96000, W + S, 7 * W + 3]
+    clips = [synth_clip(9600 + i, n, fs) for i, n in enumerate(lens)]
+    res, _ = ShortTermFeatures.feature_extraction_batch(clips, fs, W, S, deltas=True)
+    for c, r in zip(clips, res):
+        single, _ = ShortTermFeatures.feature_extraction(c, fs, W, S)
+        assert np.array_equal(single, r)
+        assert_parity(r, reference_matrix(c, fs, W, S, True), "ragged batch", ill=ill_mask(c, fs, W, S))
