@@ -119,27 +119,56 @@ template <> struct Bfly<8> { static __device__ __forceinline__ void run(double2 
 
 // ---- one in-place DIF pass: butterfly b works on the R elements base + r * stride of its block; output q is multiplied
 // by W_M^(q k) and goes back to base + q * stride.  Butterflies touch disjoint elements: no ordering inside a pass.
+// A wave runs alone on its SIMD (the LDS footprint decides the occupancy), so latency is hidden by instruction-level
+// parallelism only: a lane fetches the elements and twiddles of U butterflies before it computes any of them.
+template <int R, int U>
+__device__ __forceinline__ void dif_batch(double2 *buf, int nb, int stride, int M, int tws, unsigned magic,
+                                          const double2 *__restrict__ tw, int b0) {
+    double2 v[U][R], w[U][R];
+    int base[U];
+    bool act[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int b = b0 + kWave * u;
+        act[u] = b < nb;
+        const int be = act[u] ? b : nb - 1;                     // (inactive lanes shadow a valid butterfly, stores masked)
+        const int blk = (stride == 1) ? be : (int)__umulhi((unsigned)be, magic);
+        const int k = be - __mul24(blk, stride);                  // (all indices < 2^16: 24-bit multiplies are full rate)
+        base[u] = __mul24(blk, M) + k;
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[u][r] = buf[base[u] + r * stride];
+        if (stride > 1) {
+            const int t1 = __mul24(k, tws);
+#pragma unroll
+            for (int q = 1; q < R; ++q) w[u][q] = tw[q * t1];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        Bfly<R>::run(v[u]);
+        if (stride > 1) {
+#pragma unroll
+            for (int q = 1; q < R; ++q) v[u][q] = cmul(v[u][q], w[u][q]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (act[u]) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) buf[base[u] + q * stride] = v[u][q];
+        }
+    }
+}
 template <int R>
 __device__ __forceinline__ void dif_pass(double2 *buf, int Nc, int M, int tws, unsigned magic,
                                          const double2 *__restrict__ tw, int lane) {
+    constexpr int U = (R <= 5) ? 4 : 2;
     const int stride = M / R, nb = Nc / R;
-#pragma unroll 2
-    for (int b = lane; b < nb; b += kWave) {
-        const int blk = (stride == 1) ? b : (int)__umulhi((unsigned)b, magic);
-        const int k = b - blk * stride;
-        double2 *e = buf + blk * M + k;
-        double2 v[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) v[r] = e[r * stride];
-        Bfly<R>::run(v);
-        if (stride > 1) {
-            const int t1 = k * tws;
-#pragma unroll
-            for (int q = 1; q < R; ++q) v[q] = cmul(v[q], tw[q * t1]);
-        }
-#pragma unroll
-        for (int q = 0; q < R; ++q) e[q * stride] = v[q];
-    }
+    const int iters = (nb + kWave - 1) / kWave;
+    int i = 0;
+    for (; i + U <= iters; i += U) dif_batch<R, U>(buf, nb, stride, M, tws, magic, tw, lane + kWave * i);
+    if (U == 4 && i + 2 <= iters) { dif_batch<R, 2>(buf, nb, stride, M, tws, magic, tw, lane + kWave * i); i += 2; }
+    if (i < iters) dif_batch<R, 1>(buf, nb, stride, M, tws, magic, tw, lane + kWave * i);
 }
 
 // ---- the whole transform + |X| / num_fft (ShortTermFeatures.py:617-621) ------------------------------------------
@@ -170,25 +199,34 @@ __device__ __forceinline__ void magnitudes_inplace(const PlanDev &P, const doubl
     const int Nc = P.Nc, Nf = P.Nf;
     const double invNf = 1.0 / (double)Nf;     // X / len(X)  (:621)
     double r0[kSlots], r1[kSlots];
+    constexpr int G = 4;                       // slots fetched together (a lone wave hides latency through ILP only)
     if (P.even) {
         // bins k and Nc - k come from the same pair: X[k] = E + w^k O, X[Nc-k] = conj(E - w^k O) with
         // E = (Z[k] + conj Z[Nc-k]) / 2, O = -i (Z[k] - conj Z[Nc-k]) / 2
         const int npairs = Nc / 2 + 1;
 #pragma unroll
-        for (int j = 0; j < kSlots; ++j) {
-            r0[j] = 0.0; r1[j] = 0.0;
-            if (kWave * j < npairs) {
-                const int k = lane + kWave * j;
-                if (k < npairs) {
-                    const double2 zk = buf[perm[k]];
-                    const double2 zm = buf[perm[k == 0 ? 0 : Nc - k]];
-                    const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
-                    const double2 o = make_double2(0.5 * (zk.y + zm.y), 0.5 * (zm.x - zk.x));
-                    const double2 wo = cmul(post[k], o);
-                    const double ar = e.x + wo.x, ai = e.y + wo.y, br = e.x - wo.x, bi = e.y - wo.y;
-                    r0[j] = mag_sqrt(fma(ar, ar, ai * ai)) * invNf;
-                    r1[j] = mag_sqrt(fma(br, br, bi * bi)) * invNf;
+        for (int j0 = 0; j0 < kSlots; j0 += G) {
+            if (kWave * j0 < npairs) {
+                double2 zk[G], zm[G], pw[G];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int k = min(lane + kWave * (j0 + u), npairs - 1);
+                    zk[u] = buf[perm[k]];
+                    zm[u] = buf[perm[k == 0 ? 0 : Nc - k]];
+                    pw[u] = post[k];
                 }
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const double2 e = make_double2(0.5 * (zk[u].x + zm[u].x), 0.5 * (zk[u].y - zm[u].y));
+                    const double2 o = make_double2(0.5 * (zk[u].y + zm[u].y), 0.5 * (zm[u].x - zk[u].x));
+                    const double2 wo = cmul(pw[u], o);
+                    const double ar = e.x + wo.x, ai = e.y + wo.y, br = e.x - wo.x, bi = e.y - wo.y;
+                    r0[j0 + u] = mag_sqrt(fma(ar, ar, ai * ai)) * invNf;
+                    r1[j0 + u] = mag_sqrt(fma(br, br, bi * bi)) * invNf;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < G; ++u) { r0[j0 + u] = 0.0; r1[j0 + u] = 0.0; }
             }
         }
         wsync();
@@ -204,12 +242,23 @@ __device__ __forceinline__ void magnitudes_inplace(const PlanDev &P, const doubl
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < kSlots; ++j) {
-            r0[j] = 0.0; r1[j] = 0.0;
-            if (kWave * j < Nf) {
-                const int k = lane + kWave * j, k2 = k + kWave * kSlots;
-                if (k < Nf) { const double2 z = buf[perm[k]]; r0[j] = mag_sqrt(fma(z.x, z.x, z.y * z.y)) * invNf; }
-                if (k2 < Nf) { const double2 z = buf[perm[k2]]; r1[j] = mag_sqrt(fma(z.x, z.x, z.y * z.y)) * invNf; }
+        for (int j0 = 0; j0 < kSlots; j0 += G) {
+            if (kWave * j0 < Nf) {
+                double2 za[G], zb[G];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int k = lane + kWave * (j0 + u);
+                    za[u] = buf[perm[min(k, Nf - 1)]];
+                    zb[u] = buf[perm[min(k + kWave * kSlots, Nf - 1)]];
+                }
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    r0[j0 + u] = mag_sqrt(fma(za[u].x, za[u].x, za[u].y * za[u].y)) * invNf;
+                    r1[j0 + u] = mag_sqrt(fma(zb[u].x, zb[u].x, zb[u].y * zb[u].y)) * invNf;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < G; ++u) { r0[j0 + u] = 0.0; r1[j0 + u] = 0.0; }
             }
         }
         wsync();
@@ -225,18 +274,257 @@ __device__ __forceinline__ void magnitudes_inplace(const PlanDev &P, const doubl
     wsync();
 }
 
-// load + normalise one frame into buf; even windows fetch two consecutive samples per load (element alignment only)
+// load + normalise one frame into buf; even windows fetch two consecutive samples per load (element alignment only);
+// four loads in flight per lane
 template <typename T>
 __device__ __forceinline__ void frame_load_pairs(const PlanDev &P, const T *__restrict__ x, ClipNorm nm, double2 *buf, int lane) {
     const double sc = sample_scale<T>();
     if (P.even) {
-        for (int m = lane; m < P.Nc; m += kWave) {
-            const double2 s = ct::PairLoad<T>::get(x + 2 * m);
-            buf[m] = make_double2(fma(s.x, sc, -nm.mean) * nm.inv, fma(s.y, sc, -nm.mean) * nm.inv);
+        const int Nc = P.Nc;
+        int m = lane;
+        for (; m + 3 * kWave < Nc; m += 4 * kWave) {
+            double2 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = ct::PairLoad<T>::get(x + 2 * (m + kWave * u));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                buf[m + kWave * u] = make_double2(fma(q[u].x, sc, -nm.mean) * nm.inv, fma(q[u].y, sc, -nm.mean) * nm.inv);
+        }
+        for (; m < Nc; m += kWave) {
+            const double2 q = ct::PairLoad<T>::get(x + 2 * m);
+            buf[m] = make_double2(fma(q.x, sc, -nm.mean) * nm.inv, fma(q.y, sc, -nm.mean) * nm.inv);
         }
     } else {
-        for (int n = lane; n < P.W; n += kWave)
-            buf[n] = make_double2(fma(load_sample<T>(x + n), sc, -nm.mean) * nm.inv, 0.0);
+        const int W = P.W;
+        int n = lane;
+        for (; n + 3 * kWave < W; n += 4 * kWave) {
+            double q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = load_sample<T>(x + n + kWave * u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) buf[n + kWave * u] = make_double2(fma(q[u], sc, -nm.mean) * nm.inv, 0.0);
+        }
+        for (; n < W; n += kWave) buf[n] = make_double2(fma(load_sample<T>(x + n), sc, -nm.mean) * nm.inv, 0.0);
+    }
+    wsync();
+}
+
+// ---- time-domain and spectral stages on CONTIGUOUS per-lane chunks ---------------------------------------------
+// Lane l owns elements [l c, (l+1) c) of the frame (samples) or of the spectrum (bins), c odd (LDS reads of 64 lanes at
+// stride c doubles are conflict-free) and >= n / 64.  A chunk meets at most two of the ten entropy blocks (or the last
+// block and the tail the reference leaves out of the blocks, ShortTermFeatures.py:37-41, :93-98), so a lane carries two
+// partial energies and the wave reduces per block; everything is read in groups of four (a lone wave hides LDS latency
+// through instruction-level parallelism only).
+struct Chunk {
+    int c, kb, ke;       // chunk length, first element, one past the last (kb == ke: this lane has nothing)
+    int cat;             // entropy block of element kb (10 = tail)
+    int bound;           // first element of the next category
+};
+__device__ __forceinline__ Chunk make_chunk(int n, int block_len, int lane) {
+    Chunk ch;
+    ch.c = ((n + kWave - 1) / kWave) | 1;
+    ch.kb = min(lane * ch.c, n);
+    ch.ke = min(n, ch.kb + ch.c);
+    ch.cat = min(ch.kb / block_len, 10);
+    ch.bound = (ch.cat >= 10) ? 0x7fffffff : (ch.cat + 1) * block_len;
+    return ch;
+}
+// E[j] = sum over lanes of the partial that belongs to block j (j = 10: tail); issued together (independent chains)
+__device__ __forceinline__ void block_sums(const Chunk &ch, double ea, double eb, double (&blk)[10], double &tail) {
+#pragma unroll
+    for (int j = 0; j < 10; ++j) blk[j] = wsum(((ch.cat == j) ? ea : 0.0) + ((ch.cat + 1 == j) ? eb : 0.0));
+    tail = wsum(((ch.cat == 10) ? ea : 0.0) + ((ch.cat + 1 == 10) ? eb : 0.0));
+}
+
+// zcr count, energy and energy entropy of the normalised frame in LDS (ShortTermFeatures.py:22-51)
+__device__ __forceinline__ TimeFeat time_features_chunked(const PlanDev &P, const double2 *buf, const Chunk &ch, int lane) {
+    const int W = P.W, st = P.even ? 1 : 2;                 // odd windows: y[n] = buf[n].x
+    const double *y = reinterpret_cast<const double *>(buf);
+    double ea = 0.0, eb = 0.0;
+    int zc = 0;
+    // np.sign from the bit pattern: 0 for +-0, else +-1 (six 32-bit operations instead of two FP64 compares and selects)
+    auto sgn = [](double x) {
+        const int hi = __double2hiint(x), lo = __double2loint(x);
+        return (((hi & 0x7fffffff) | lo) != 0) ? ((hi >> 31) | 1) : 0;
+    };
+    int sprev = sgn(y[max(ch.kb - 1, 0) * st]);
+    for (int i = 0; i < ch.c; i += 4) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = y[min(ch.kb + i + u, W - 1) * st];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int n = ch.kb + i + u;
+            const bool ok = n < ch.ke;
+            const double x = ok ? v[u] : 0.0;
+            const double sq = x * x;
+            const double sa = (n < ch.bound) ? sq : 0.0;
+            ea += sa;
+            eb += sq - sa;                                         // exactly 0 or sq
+            const int sx = sgn(x);
+            zc += (ok && n > 0) ? abs(sx - sprev) : 0;
+            sprev = ok ? sx : sprev;
+        }
+    }
+    double eblk[10], e_tail;
+    block_sums(ch, ea, eb, eblk, e_tail);
+    TimeFeat tf;
+    tf.e_tot = e_tail;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) tf.e_tot += eblk[j];
+    tf.zc = wsum_i(zc);
+    double num = 0.0;
+#pragma unroll
+    for (int j = 0; j < 10; ++j)
+        if (lane == j) num = eblk[j];
+    const double s = fast_div(num, tf.e_tot + kEps);
+    tf.ent_e = wsum((lane < 10) ? -(s * fast_log2(s + kEps)) : 0.0);
+    return tf;
+}
+
+// the 34 base features of one frame into fv[0..33] (ShortTermFeatures.py:626-667)
+__device__ __forceinline__ void frame_features_chunked(const PlanDev &P, const Tabs &tb, const TimeFeat &tf,
+                                                       const double *cur, const double *prv, double *fv, double *msp,
+                                                       const Chunk &ch, int lane) {
+    const int W = P.W, Nf = P.Nf;
+    const double f0 = P.fs / (2.0 * (double)Nf);
+    // ---------- sweep A over the lane's bins: sums, max, block energies (:57-107)
+    double sX = 0.0, sXp = 0.0, sIX = 0.0, mx = 0.0, ea = 0.0, eb = 0.0;
+    for (int i = 0; i < ch.c; i += 4) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = min(ch.kb + i + u, Nf - 1);
+            a[u] = cur[k];
+            b[u] = prv[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = ch.kb + i + u;
+            const bool ok = k < ch.ke;
+            const double X = ok ? a[u] : 0.0;
+            sX += X;
+            sXp += ok ? b[u] : 0.0;
+            sIX = fma((double)(k + 1), X, sIX);
+            mx = fmax(mx, X);
+            const double sq = X * X;
+            const double sa = (k < ch.bound) ? sq : 0.0;
+            ea += sa;
+            eb += sq - sa;                                         // exactly 0 or sq
+        }
+    }
+    double pblk[10], p_tail;
+    block_sums(ch, ea, eb, pblk, p_tail);
+    const double own = ea + eb;                     // energy of this lane's bins (roll-off scan)
+    const double before = wscan_incl(own) - own;
+    sX = wsum(sX);
+    sXp = wsum(sXp);
+    sIX = wsum(sIX) * f0;
+    mx = wmax_nonneg(mx);
+    // np.sum(X + eps) (:118-119) = sum X + Nf eps up to rounding
+    const double sXe = sX + (double)Nf * kEps;
+    sXp += (double)Nf * kEps;
+    double sP = p_tail;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) sP += pblk[j];
+    // spectral entropy: lane j (< 10) owns block j (:101-105)
+    double ent_f;
+    {
+        double num = 0.0;
+#pragma unroll
+        for (int j = 0; j < 10; ++j)
+            if (lane == j) num = pblk[j];
+        const double s = fast_div(num, sP + kEps);
+        ent_f = wsum((lane < 10) ? -(s * fast_log2(s + kEps)) : 0.0);
+    }
+    // ---------- centroid, then sweep B: spread + flux + roll-off (:57-82, :110-140)
+    const double r = (mx == 0.0) ? 1.0 / kEps : fast_div(1.0, mx);
+    const double den = sX * r + kEps;
+    const double cen = fast_div(sIX * r, den);
+    const double rX = fast_div(1.0, sXe), rXp = fast_div(1.0, sXp);
+    const double thr = 0.90 * sP;
+    double sSp = 0.0, sFl = 0.0, run = before;
+    int first = 0x7fffffff;
+    for (int i = 0; i < ch.c; i += 4) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = min(ch.kb + i + u, Nf - 1);
+            a[u] = cur[k];
+            b[u] = prv[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = ch.kb + i + u;
+            const bool ok = k < ch.ke;
+            const double X = ok ? a[u] : 0.0, Xp = ok ? b[u] : 0.0;
+            const double dv = (double)(k + 1) * f0 - cen;
+            sSp = fma(dv * dv, X * r, sSp);
+            const double df = X * rX - Xp * rXp;
+            sFl = fma(df, df, sFl);
+            run = fma(X, X, run);                                   // cumsum(X^2)[k]
+            if (ok && run + kEps > thr) first = min(first, k);      // first k with cumsum + eps > 0.9 sum (:134-139)
+        }
+    }
+    sSp = wsum(sSp);
+    sFl = wsum(sFl);
+    first = wmin_i(first);
+    const double spread = fast_sqrt(fast_div(sSp, den));
+
+    // ---------- MFCC: sparse mel dot, log10, 13 x 40 DCT (:236-254)
+    if (lane < 40) {
+        const int lo = tb.mel_lo[lane], cnt = tb.mel_cnt[lane];
+        const double *w = tb.mel_w + tb.mel_off[lane];
+        double a0 = 0.0, a1 = 0.0;
+        int i = 0;
+        for (; i + 4 <= cnt; i += 4) {
+            const double x0 = cur[lo + i], x1 = cur[lo + i + 1], x2 = cur[lo + i + 2], x3 = cur[lo + i + 3];
+            const double w0 = w[i], w1 = w[i + 1], w2 = w[i + 2], w3 = w[i + 3];
+            a0 = fma(x0, w0, a0);
+            a1 = fma(x1, w1, a1);
+            a0 = fma(x2, w2, a0);
+            a1 = fma(x3, w3, a1);
+        }
+        for (; i + 2 <= cnt; i += 2) {
+            a0 = fma(cur[lo + i], w[i], a0);
+            a1 = fma(cur[lo + i + 1], w[i + 1], a1);
+        }
+        if (i < cnt) a0 = fma(cur[lo + i], w[i], a0);
+        msp[lane] = fast_log10((a0 + a1) + kEps);
+    }
+    // ---------- chroma (:277-321)
+    const double chroma = chroma_class(tb, cur, sP, lane);
+    wsync();
+    if (lane < 13) {
+        const double *m = tb.dct + lane * tb.dct_stride;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int n = 0; n < 40; n += 4) {
+            a0 = fma(m[n], msp[n], a0);
+            a1 = fma(m[n + 1], msp[n + 1], a1);
+            a2 = fma(m[n + 2], msp[n + 2], a2);
+            a3 = fma(m[n + 3], msp[n + 3], a3);
+        }
+        fv[8 + lane] = (a0 + a1) + (a2 + a3);
+    }
+    // population std of the 12 chroma values (:667): lanes 0..11 of the first row
+    {
+        const double cv = (lane < 12) ? chroma : 0.0;
+        const double mean = group_sum(cv) / 12.0;
+        const double d = (lane < 12) ? cv - mean : 0.0;
+        const double var = group_sum(d * d) / 12.0;
+        if (lane < 12) fv[21 + lane] = chroma;
+        if (lane == 0) {
+            fv[0] = ((double)tf.zc / 2.0) / (double)(W - 1);
+            fv[1] = tf.e_tot / (double)W;
+            fv[2] = tf.ent_e;
+            fv[3] = cen / (P.fs / 2.0);
+            fv[4] = spread / (P.fs / 2.0);
+            fv[5] = ent_f;
+            fv[6] = (cur == prv) ? 0.0 : sFl;      // first frame: previous spectrum = itself (:624-625)
+            fv[7] = (first == 0x7fffffff) ? 0.0 : (double)first / (double)Nf;
+            fv[33] = fast_sqrt(var);
+        }
     }
     wsync();
 }
@@ -276,7 +564,7 @@ inline void mix_permutation(int Nc, const std::vector<int> &radix, std::vector<u
 inline int mix_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable *chroma, int F, MixLayout &L,
                       std::vector<unsigned char> *blob) {
     const int Nc = fft.len, Nf = fft.window / 2;
-    if (Nc < 2 || Nc > 60000) return 0;
+    if (Nc < 2 || Nc > 60000 || Nf < 64) return 0;          // (chunks of the feature stages: at most two entropy blocks per lane)
     std::vector<int> radix;
     if (!mix_factor(Nc, radix)) return 0;
     if (fft.even ? (Nc / 2 + 1 > kWave * kSlots) : (Nf > 2 * kWave * kSlots)) return 0;
@@ -319,6 +607,7 @@ inline int mix_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
     // the twiddle tables go to LDS unless that costs a wave
     const int w_lds = lay(0), w_glob = lay(1);
     L.tw_global = (w_glob > w_lds) ? 1 : 0;
+    if (const char *force = getenv("PAA_MIX_TW_GLOBAL")) L.tw_global = atoi(force) ? 1 : 0;      // A/B experiments
     L.waves = lay(L.tw_global);
     if (L.waves < 1) return 0;
     if (!blob) return 1;
@@ -400,6 +689,7 @@ __global__ __launch_bounds__(256) void st_mix_kernel(PlanDev P, MixLayout L, con
     double vprev = 0.0;
     int nslot = 0, tbase = tl.t0, odd = 0;
     const int tend = tl.t0 + tl.cnt;
+    const Chunk ch_t = make_chunk(P.W, P.blk_t, lane), ch_f = make_chunk(Nf, P.blk_f, lane);
     PAA_T0()
     for (int t = tl.t0 - h; t < tend; ++t, odd ^= 1) {
         // even frames of the run: transform at the front, spectrum at the very front, previous spectrum behind the buffer;
@@ -413,7 +703,7 @@ __global__ __launch_bounds__(256) void st_mix_kernel(PlanDev P, MixLayout L, con
         const bool want = (P.mode == 0) && ((t >= tl.t0) || (P.deltas && t == tl.t0 - 1));
         TimeFeat tf;
         tf.e_tot = 0.0; tf.ent_e = 0.0; tf.zc = 0;
-        if (want) tf = time_features(P, buf, lane);
+        if (want) tf = time_features_chunked(P, buf, ch_t, lane);
         PAA_TICK(1)
         fft_passes_inplace(P, L, buf, tb.tw, lane);
         PAA_TICK(2)
@@ -430,7 +720,7 @@ __global__ __launch_bounds__(256) void st_mix_kernel(PlanDev P, MixLayout L, con
             if (lane < 12) oc[(long long)t * 12 + lane] = ch;
         } else {
             if (want) {
-                frame_features(P, tb, tf, cur, (t == 0) ? cur : prv, fv, msp, lane);
+                frame_features_chunked(P, tb, tf, cur, (t == 0) ? cur : prv, fv, msp, ch_f, lane);
                 PAA_TICK(5)
                 const double v = (lane < kBase) ? fv[lane] : 0.0;
                 if (t >= tl.t0) {

@@ -88,8 +88,10 @@ def test_degenerate_clips_and_ragged_batches(gpu_lib):
         "one_window": synth_clip(91, W, fs),
         "w_plus_s_minus_1": synth_clip(92, W + S - 1, fs),
         "dc": np.full(4 * W, 1234, dtype=np.int16),
-        "square": np.tile(np.array([32767, -32768], dtype=np.int16), 3 * W // 2),
     }
+    # (no full-scale square wave at fs / 2 here: all of its energy sits in the Nyquist bin the reference drops, and with
+    # radix-3 / radix-5 factors in the transform bins 0 .. Nf-1 hold nothing but the FFT's round-off -- the reference's own
+    # centroid and spread of that frame are functions of pocketfft's rounding; the 2 RA RB family's test keeps the case)
     x = synth_clip(93, 3 * fs, fs).copy()
     x[fs:2 * fs] = 0
     cases["silence_inside"] = x
