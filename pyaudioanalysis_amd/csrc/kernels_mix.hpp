@@ -3,7 +3,7 @@
 // any step, int16 / interleaved stereo int16 / float64 samples, features / spectrogram / chromagram.
 //
 // One wave owns a run of consecutive frames, one frame at a time, like the generic kernel -- but the FFT is an IN-PLACE
-// decimation-in-frequency transform (radix 8/4/2/7/11/13/5/3 butterflies held in registers, digit-reversed output read
+// decimation-in-frequency transform (radix 16/8/4/2/13/11/7/5/3 butterflies held in registers, digit-reversed output read
 // back through a host-built permutation), so a wave needs ONE complex buffer instead of the Stockham ping-pong pair, and
 // the spectrum is written over the dead FFT buffer:
 //
@@ -110,12 +110,20 @@ __device__ __forceinline__ void dft8_natural(double2 *v) {
     }
 }
 
-template <int R> struct Bfly { static __device__ __forceinline__ void run(double2 *v) { dft_prime<R>(v); } };
-template <> struct Bfly<2> { static __device__ __forceinline__ void run(double2 *v) { dft2(v); } };
-template <> struct Bfly<3> { static __device__ __forceinline__ void run(double2 *v) { dft3(v); } };
-template <> struct Bfly<4> { static __device__ __forceinline__ void run(double2 *v) { dft4(v); } };
-template <> struct Bfly<5> { static __device__ __forceinline__ void run(double2 *v) { dft5(v); } };
-template <> struct Bfly<8> { static __device__ __forceinline__ void run(double2 *v) { dft8_natural(v); } };
+// run() transforms v[] in place; X[q] ends at v[pos(q)]
+template <int R> struct Bfly {
+    static __device__ __forceinline__ void run(double2 *v) { dft_prime<R>(v); }
+    static constexpr int pos(int q) { return q; }
+};
+template <> struct Bfly<2> { static __device__ __forceinline__ void run(double2 *v) { dft2(v); } static constexpr int pos(int q) { return q; } };
+template <> struct Bfly<3> { static __device__ __forceinline__ void run(double2 *v) { dft3(v); } static constexpr int pos(int q) { return q; } };
+template <> struct Bfly<4> { static __device__ __forceinline__ void run(double2 *v) { dft4(v); } static constexpr int pos(int q) { return q; } };
+template <> struct Bfly<5> { static __device__ __forceinline__ void run(double2 *v) { dft5(v); } static constexpr int pos(int q) { return q; } };
+template <> struct Bfly<8> { static __device__ __forceinline__ void run(double2 *v) { dft8_natural(v); } static constexpr int pos(int q) { return q; } };
+template <> struct Bfly<16> {          // the 4 x 4 codelet of the 800-sample kernel: X[q] at v[4 (q % 4) + q / 4]
+    static __device__ __forceinline__ void run(double2 *v) { f800::dft16<0>(v); }
+    static constexpr int pos(int q) { return 4 * (q % 4) + q / 4; }
+};
 
 // ---- one in-place DIF pass: butterfly b works on the R elements base + r * stride of its block; output q is multiplied
 // by W_M^(q k) and goes back to base + q * stride.  Butterflies touch disjoint elements: no ordering inside a pass.
@@ -148,21 +156,21 @@ __device__ __forceinline__ void dif_batch(double2 *buf, int nb, int stride, int 
         Bfly<R>::run(v[u]);
         if (stride > 1) {
 #pragma unroll
-            for (int q = 1; q < R; ++q) v[u][q] = cmul(v[u][q], w[u][q]);
+            for (int q = 1; q < R; ++q) v[u][Bfly<R>::pos(q)] = cmul(v[u][Bfly<R>::pos(q)], w[u][q]);
         }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (act[u]) {
 #pragma unroll
-            for (int q = 0; q < R; ++q) buf[base[u] + q * stride] = v[u][q];
+            for (int q = 0; q < R; ++q) buf[base[u] + q * stride] = v[u][Bfly<R>::pos(q)];
         }
     }
 }
 template <int R>
 __device__ __forceinline__ void dif_pass(double2 *buf, int Nc, int M, int tws, unsigned magic,
                                          const double2 *__restrict__ tw, int lane) {
-    constexpr int U = (R <= 5) ? 4 : 2;
+    constexpr int U = (R <= 5) ? 4 : (R <= 13 ? 2 : 1);
     const int stride = M / R, nb = Nc / R;
     const int iters = (nb + kWave - 1) / kWave;
     int i = 0;
@@ -189,7 +197,8 @@ __device__ __forceinline__ void fft_passes_inplace(const PlanDev &P, const MixLa
             case 7: dif_pass<7>(buf, Nc, M, ts, mg, tw, lane); break;
             case 8: dif_pass<8>(buf, Nc, M, ts, mg, tw, lane); break;
             case 11: dif_pass<11>(buf, Nc, M, ts, mg, tw, lane); break;
-            default: dif_pass<13>(buf, Nc, M, ts, mg, tw, lane); break;
+            case 13: dif_pass<13>(buf, Nc, M, ts, mg, tw, lane); break;
+            default: dif_pass<16>(buf, Nc, M, ts, mg, tw, lane); break;
         }
         wsync();
     }
@@ -539,6 +548,7 @@ inline bool mix_factor(int n, std::vector<int> &radix) {
         while (n % f == 0) { odd.push_back(f); n /= f; }
     if (n != 1) return false;
     // big strides first for the power-of-two butterflies, the odd radices (conflict-free at small strides) last
+    while (twos >= 4 && twos != 5 && twos != 6) { radix.push_back(16); twos -= 4; }      // (5 = 8 4, 6 = 8 8)
     while (twos >= 3 && twos != 4) { radix.push_back(8); twos -= 3; }
     while (twos >= 2) { radix.push_back(4); twos -= 2; }
     if (twos) radix.push_back(2);

@@ -144,6 +144,7 @@ struct Shape {
 struct RegLayout {
     int off_post, off_mello, off_melcnt, off_meloff, off_melw, off_dct, off_chstart, off_chsrc, off_chw;
     int table_bytes, wave_bytes, waves;
+    int ring;            // spectrum slots per wave: Q + 1 for the features (the flux needs the previous frame), Q for the rows
 };
 
 // zcr count, energy and energy entropy of one frame read from global memory (ShortTermFeatures.py:22-51)
@@ -381,7 +382,7 @@ __device__ __forceinline__ void frame_features_fixed(const PlanDev &P, const Tab
 }
 
 template <typename SH, typename T>
-__global__ __launch_bounds__(384) void st_reg_kernel(PlanDev P, RegLayout L, const unsigned char *__restrict__ blob,
+__global__ __launch_bounds__(512) void st_reg_kernel(PlanDev P, RegLayout L, const unsigned char *__restrict__ blob,
                                                       const T *__restrict__ sig, const ClipDev *__restrict__ clips,
                                                       const ClipNorm *__restrict__ norms,
                                                       const Tile *__restrict__ tiles, int n_tiles,
@@ -413,8 +414,9 @@ __global__ __launch_bounds__(384) void st_reg_kernel(PlanDev P, RegLayout L, con
     if (tile_id >= n_tiles) return;
     const int F = P.F > 0 ? P.F : 1;
     unsigned char *wb = smem + L.table_bytes + wave * L.wave_bytes;
-    double *slots = reinterpret_cast<double *>(wb);                    // (Q + 1) x NFP doubles
-    double *otile = slots + (Q + 1) * NFP;
+    const int ring = L.ring;
+    double *slots = reinterpret_cast<double *>(wb);                    // ring x NFP doubles
+    double *otile = slots + ring * NFP;
     double *fv = otile + kFlush * F;
     double *msp = fv + 48;
     double *tfs = msp + 40;                                            // Q x 4: time-domain results of the iteration
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(384) void st_reg_kernel(PlanDev P, RegLayout L, con
     int slot0 = 1;                                          // slots of the iteration: slot0 .. slot0+Q-1 (mod Q+1); previous = slot0-1
     double vprev = 0.0;
     int nslot = 0, tbase = tl.t0;
-    for (int tq = halo ? tl.t0 - Q : tl.t0; tq < tend; tq += Q, slot0 = (slot0 + Q) % (Q + 1)) {
+    for (int tq = halo ? tl.t0 - Q : tl.t0; tq < tend; tq += Q, slot0 = (slot0 + Q) % ring) {
         const bool store_it = tq >= tl.t0;
         // lane roles, re-derived every iteration from an opaque copy of the lane index: otherwise the optimiser hoists
         // every lane-dependent address and bin index of the unrolled passes out of the loop and spills them
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(384) void st_reg_kernel(PlanDev P, RegLayout L, con
                 v0 = v[0];
                 prime_fold<R1>(v, s, d);
             }
-            double *pl = slots + ((slot0 + (act_a ? fa : 0)) % (Q + 1)) * NFP;
+            double *pl = slots + ((slot0 + (act_a ? fa : 0)) % ring) * NFP;
             const double2 x0c = prime_dc<R1>(v0, s);
             if (ok) pl[n2] = x0c.x;
             yim[0] = x0c.y;
@@ -500,12 +502,12 @@ __global__ __launch_bounds__(384) void st_reg_kernel(PlanDev P, RegLayout L, con
         // ---------------- exchange: real plane, then imaginary plane
         double2 a[R2], b[R2];
         {
-            const double *pl = slots + ((slot0 + (act_b ? fb : 0)) % (Q + 1)) * NFP;
+            const double *pl = slots + ((slot0 + (act_b ? fb : 0)) % ring) * NFP;
 #pragma unroll
             for (int r = 0; r < R2; ++r) { a[r].x = pl[pcol * R2 + r]; b[r].x = pl[pcolb * R2 + r]; }
             wsync();
             if (act_a && tq + fa < tend) {
-                double *pw = slots + ((slot0 + fa) % (Q + 1)) * NFP;
+                double *pw = slots + ((slot0 + fa) % ring) * NFP;
 #pragma unroll
                 for (int k1 = 0; k1 < R1; ++k1) pw[k1 * R2 + n2] = yim[k1];
             }
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(384) void st_reg_kernel(PlanDev P, RegLayout L, con
         }
         // ---------------- pass B: two radix-R2 DFTs, real-FFT recombination, magnitudes (ShortTermFeatures.py:617-621)
         if (act_b && tq + fb < tend) {
-            double *sp = slots + ((slot0 + fb) % (Q + 1)) * NFP;
+            double *sp = slots + ((slot0 + fb) % ring) * NFP;
             double2 sa[H2], da[H2], sb[H2], db[H2];
             const double2 a0 = a[0], b0 = b[0];
             prime_fold<R2>(a, sa, da);
@@ -553,8 +555,8 @@ __global__ __launch_bounds__(384) void st_reg_kernel(PlanDev P, RegLayout L, con
         for (int f = 0; f < Q; ++f) {
             const int t = tq + f;
             if (t >= tend) break;
-            const double *cur = slots + ((slot0 + f) % (Q + 1)) * NFP;
-            const double *prv = slots + ((slot0 + f + Q) % (Q + 1)) * NFP;
+            const double *cur = slots + ((slot0 + f) % ring) * NFP;
+            const double *prv = slots + ((slot0 + f + Q) % ring) * NFP;
             if (P.mode == 1) {            // spectrogram row (ShortTermFeatures.py:422)
                 double *row = oc + (long long)t * NF;
                 // (write-once stream of 4.4 KB rows that are only 8-byte aligned: non-temporal stores keep the L2 from
@@ -604,8 +606,8 @@ typedef Shape<29, 19, 3> Shape1102;
 
 inline bool reg_supported(int window) { return window == Shape1102::W; }
 
-inline size_t reg_wave_bytes(int nfp, int q, int F) {
-    size_t b = (size_t)(q + 1) * nfp * 8 + (size_t)kFlush * F * 8 + (48 + 40) * 8 + (size_t)q * 4 * 8 + 16 * 8;
+inline size_t reg_wave_bytes(int nfp, int ring, int q, int F) {
+    size_t b = (size_t)ring * nfp * 8 + (size_t)kFlush * F * 8 + (48 + 40) * 8 + (size_t)q * 4 * 8 + 16 * 8;
     return (b + 15) / 16 * 16;
 }
 
@@ -626,8 +628,10 @@ inline void reg_layout(const FftPlan &fft, const MelTable *mel, const ChromaTabl
     L.off_chsrc = take(std::max<size_t>(n_ch, 1) * 4);
     L.off_chw = take(std::max<size_t>(n_ch, 1) * 8);
     L.table_bytes = off;
-    L.wave_bytes = (int)reg_wave_bytes(nfp, q, F > 0 ? F : 1);
-    L.waves = 6;
+    // spectrogram / chromagram rows need no previous spectrum: Q slots, and eight waves (two per SIMD) fit the LDS
+    L.ring = (F > 0) ? q + 1 : q;
+    L.wave_bytes = (int)reg_wave_bytes(nfp, L.ring, q, F > 0 ? F : 1);
+    L.waves = 8;
     while (L.waves > 1 && (size_t)L.table_bytes + (size_t)L.waves * L.wave_bytes > 160 * 1024) --L.waves;
     if (!blob) return;
     blob->assign((size_t)L.table_bytes, 0);

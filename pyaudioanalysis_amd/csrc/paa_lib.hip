@@ -535,6 +535,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         // one wave per run, in multiples of the 4-frame quad, at most fl.run frames (halo = one quad); see choose_run_cap
         run_quantum = 4;
         run = choose_run_cap(p->clips, 4, 16, p->fl.run, 4, p->fl.waves_per_cu, g_num_cu);
+        if (const char *rc_env = getenv("PAA_RUN_CAP")) run = std::max(16, atoi(rc_env) / 4 * 4);      // A/B experiments only
         p->lds = p->fl.lds;
         p->kernel_name = p->fl.name;
     } else {

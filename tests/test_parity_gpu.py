@@ -270,6 +270,20 @@ def test_rccl_gather_world_size_1(gpu_lib):
         for c, r in zip(clips, res):
             single, _ = ShortTermFeatures.feature_extraction(c, 16000, 800, 400)
             assert np.array_equal(single, r)
+        # the chunked pipeline (piece k gathered while piece k+1 computes), restart files written and reloaded (slices of the
+        # uploaded block are sent piece by piece), and the cheap gather of the (136, M) mid-term matrices
+        clips = [synth_clip(520 + i, n) for i, n in enumerate([4000, 16000, 2400, 48000, 9000, 1200, 32000])]
+        import tempfile
+        with tempfile.TemporaryDirectory() as rdir:
+            first = D.extract_sharded(clips, 16000, 800, 400, False, 1, 0, comm, chunks=3, restart_dir=rdir)
+            again = D.extract_sharded(clips, 16000, 800, 400, False, 1, 0, comm, chunks=3, restart_dir=rdir)
+        mids = D.extract_sharded(clips, 16000, 800, 400, True, 1, 0, comm, chunks=2, gather="mid", mid_window=16000,
+                                 mid_step=8000)
+        for c, a, b, m in zip(clips, first, again, mids):
+            single, _ = ShortTermFeatures.feature_extraction(c, 16000, 800, 400, deltas=False)
+            assert np.array_equal(single, a) and np.array_equal(single, b)
+            mid, _, _ = MidTermFeatures.mid_feature_extraction(c, 16000, 16000, 8000, 800, 400)
+            assert np.array_equal(mid, m)
     finally:
         comm.close()
 
