@@ -233,6 +233,10 @@ int paa_debug_lane_peak(void);     /* most host-buffer calls in flight at once s
 int paa_debug_phase_cycles(uint64_t *out16);
 /* radix plan chosen for a window: returns number of passes, fills radices (capacity 32)      */
 int paa_debug_fft_plan(int window, int32_t *radices, int32_t *fft_len);
+/* mixed-radix kernel (csrc/kernels_mix.hpp): radix schedule of its in-place DIF transform and the position that holds
+ * Z[k] afterwards (perm: fft_len entries); returns the number of passes, 0 when the window goes to another kernel   */
+int paa_debug_mix_plan(int window, int32_t *radices, int32_t *fft_len, uint16_t *perm, int perm_capacity,
+                       int32_t *waves, int32_t *tw_global);
 /* the run-length choice of paa_plan_create for clips of frames[c] frames (host only): runs are multiples of `quantum`
  * frames within [min_run, max_run], cost `halo` extra frames each, a workgroup takes wg_runs of them and num_cu
  * workgroups run at a time.  Returns the cap, the number of runs and the longest run          */

@@ -1556,6 +1556,27 @@ extern "C" int paa_debug_run_plan(const int64_t *frames, int64_t n_clips, int qu
     *run_cap = cap; *n_runs = runs; *longest = lmax;
     return PAA_OK;
 }
+// host side of the mixed-radix kernel for a window (no device needed): radix schedule of the in-place DIF transform and the
+// position that holds Z[k] afterwards.  Returns the number of passes, 0 when the window is not for that kernel.
+extern "C" int paa_debug_mix_plan(int window, int32_t *radices, int32_t *fft_len, uint16_t *perm, int perm_capacity,
+                                  int32_t *waves, int32_t *tw_global) {
+    if (window < 2 || !radices || !fft_len) return fail(PAA_ERR_ARG, "bad argument");
+    FftPlan p;
+    build_fft_plan(window, p);
+    *fft_len = p.len;
+    mix::MixLayout L;
+    if (!mix::mix_layout(p, nullptr, nullptr, 34, L, nullptr)) return 0;
+    std::vector<int> radix(L.radix, L.radix + L.n_pass);
+    for (int i = 0; i < L.n_pass; ++i) radices[i] = L.radix[i];
+    if (perm && perm_capacity >= p.len) {
+        std::vector<unsigned short> pm;
+        mix::mix_permutation(p.len, radix, pm);
+        memcpy(perm, pm.data(), (size_t)p.len * 2);
+    }
+    if (waves) *waves = L.waves;
+    if (tw_global) *tw_global = L.tw_global;
+    return L.n_pass;
+}
 extern "C" int paa_debug_fft_plan(int window, int32_t *radices, int32_t *fft_len) {
     if (window < 2 || !radices || !fft_len) return fail(PAA_ERR_ARG, "bad argument");
     FftPlan p;

@@ -230,3 +230,54 @@ def test_result_pool_tracks_liveness_through_views_of_views():
     assert d.__array_interface__["data"][0] == addr
     small = _ffi.result_array((10, 10))
     assert small.flags.owndata                              # small results are ordinary arrays
+
+
+def _dif_in_place(z, radices):
+    """The passes of csrc/kernels_mix.hpp restated in NumPy: in-place decimation in frequency, butterfly over the R elements
+    base + r * stride of a block of M, output q multiplied by W_M^(q k) and written to base + q * stride."""
+    z = np.array(z, dtype=np.complex128)
+    n = len(z)
+    M = n
+    for R in radices:
+        stride = M // R
+        dft = np.exp(-2j * np.pi * np.outer(np.arange(R), np.arange(R)) / R)
+        for blk in range(n // M):
+            for k in range(stride):
+                idx = blk * M + k + stride * np.arange(R)
+                z[idx] = (dft @ z[idx]) * np.exp(-2j * np.pi * np.arange(R) * k / M)
+        M = stride
+    return z
+
+
+@pytest.mark.parametrize("window", [2400, 2205, 1764, 1920, 1600, 1024, 256, 1100, 390, 1001])
+def test_mixed_radix_plan_is_a_valid_transform(window):
+    """Host tables of the mixed-radix kernel (no device): the radix schedule multiplies to the FFT length, uses only the
+    butterflies the kernel has, the permutation is a bijection, and the restated passes + permutation reproduce np.fft.fft."""
+    import ctypes
+    lib = _ffi.lib()
+    rad = np.zeros(16, dtype=np.int32)
+    ln, waves, twg = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    perm = np.zeros(8192, dtype=np.uint16)
+    n_pass = lib.paa_debug_mix_plan(window, rad.ctypes.data_as(_ffi.c_i32p), ctypes.byref(ln),
+                                    perm.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), len(perm), ctypes.byref(waves),
+                                    ctypes.byref(twg))
+    assert n_pass > 0 and 1 <= waves.value <= 4
+    n = ln.value
+    assert n == (window // 2 if window % 2 == 0 else window)
+    radices = [int(r) for r in rad[:n_pass]]
+    assert int(np.prod(radices)) == n and set(radices) <= {2, 3, 4, 5, 7, 8, 11, 13, 16}
+    assert sorted(perm[:n].tolist()) == list(range(n))
+    rng = np.random.default_rng(window)
+    z = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    got = _dif_in_place(z, radices)[perm[:n].astype(np.int64)]
+    ref = np.fft.fft(z)
+    assert np.max(np.abs(got - ref)) < 1e-9 * np.max(np.abs(ref))
+
+
+def test_mixed_radix_plan_declines_other_windows():
+    import ctypes
+    lib = _ffi.lib()
+    rad = np.zeros(16, dtype=np.int32)
+    ln = ctypes.c_int32()
+    for window in (1103, 1102, 58, 2 * 17 * 64):          # prime, 2 x 19 x 29, too small, a factor of 17
+        assert lib.paa_debug_mix_plan(window, rad.ctypes.data_as(_ffi.c_i32p), ctypes.byref(ln), None, 0, None, None) == 0

@@ -47,7 +47,10 @@ CASES = [
     (11025, 551, 275, "i16", 20, True),        # 50 ms at 11.025 kHz: odd, 19 x 29 -> stays generic (checked all the same)
     (16000, 390, 200, "i16", 10, True),        # 195 = 3 5 13
     (16000, 1001, 500, "unit", 10, False),     # odd: 7 11 13
-    (16000, 256, 128, "i16", 5, True),         # small window: 128 = 8 4 4
+    (16000, 256, 128, "i16", 5, True),
+    (96000, 4800, 2400, "i16", 6, True),       # 50 ms at 96 kHz: 2400 complex points, 70 KB per wave (two waves per CU)
+    (44100, 3465, 1000, "f64", 4, False),      # odd and large: 3 3 5 7 11, 73 KB per wave
+    (44100, 6000, 3000, "stereo", 5, False),   # the edge of the magnitude pass's register slots (1501 pairs)         # small window: 128 = 8 4 4
 ]
 
 
