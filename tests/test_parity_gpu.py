@@ -384,6 +384,18 @@ def test_fused_stereo_to_mono(gpu_lib):
     sig2 = (O.stereo_to_mono(xs), 16000, 800, 400)
     assert_parity(st2, ref_st, "fused stereo short", sig=sig2)
     assert_parity(mid, ref_mid, "fused stereo mid", sig=sig2)
+    # the kernels that see stereo samples less often: Stockham passes in LDS (prime window), passes through HBM scratch
+    # (window beyond the LDS envelope), the truncated chromagram tail frame -- L + R formed in their loads as well
+    for fs, W, S, n in ((22050, 1103, 441, 22050 * 2 + 5), (16000, 8000, 4000, 16000 * 3 + 1)):
+        xs = synth_clip(89 + W, n, fs=fs, stereo=True)
+        mono = O.stereo_to_mono(xs)
+        got, _ = ShortTermFeatures.feature_extraction(xs, fs, W, S)
+        ref, _ = O.feature_extraction(mono, fs, W, S)
+        assert_parity(got, ref, "stereo through window %d" % W, sig=(mono, fs, W, S))
+    xs = synth_clip(97, 44100 + 700, fs=44100, stereo=True)         # 700 samples past the last full frame: truncated tail
+    chroma, _, _ = ShortTermFeatures.chromagram(xs, 44100, 1102, 441)
+    chroma_mono, _, _ = ShortTermFeatures.chromagram(O.stereo_to_mono(xs), 44100, 1102, 441)
+    assert chroma.shape == chroma_mono.shape and np.allclose(chroma, chroma_mono, rtol=1e-9, atol=1e-12)
 
 
 def test_c_client_on_gpu(gpu_lib, tmp_path):
