@@ -381,6 +381,246 @@ __device__ __forceinline__ void frame_features_fixed(const PlanDev &P, const Tab
     wsync();
 }
 
+// ---- the same two stages for ALL frames of an iteration at once: 16 lanes per frame (frame f = lane / 16, Q <= 4) ------
+// One frame at a time with the whole wave spends most of its instructions on 64-lane reductions and on stages that use 12,
+// 13 or 40 lanes (profiles/r03d_reg_features_stereo: the time-domain and feature stages were 65 % of the kernel's VALU
+// instructions).  Here lane (f, i) owns a contiguous chunk of its frame -- CT = 69 samples / CB = 35 bins, odd, so the
+// 16 lanes of a frame read LDS conflict-free -- carries two partial block energies (a chunk meets at most two entropy
+// blocks), and every reduction is a 4-step DPP reduction inside the 16-lane row, shared by the Q frames.
+constexpr int kRegFlush = 6;        // frames staged per row segment (a multiple of Q = 3; the LDS budget of six waves)
+
+// four consecutive samples in one load (element alignment only)
+template <typename T> struct QuadLoad;
+template <> struct QuadLoad<int16_t> {
+    typedef short vec __attribute__((ext_vector_type(4), aligned(2)));
+    static __device__ __forceinline__ void get(const int16_t *p, double (&o)[4]) {
+        const vec s = *reinterpret_cast<const vec *>(p);
+        o[0] = (double)s.x; o[1] = (double)s.y; o[2] = (double)s.z; o[3] = (double)s.w;
+    }
+};
+template <> struct QuadLoad<stereo16> {      // four stereo frames = 16 bytes, each summed L + R in the load
+    typedef int vec __attribute__((ext_vector_type(4), aligned(4)));
+    static __device__ __forceinline__ void get(const stereo16 *p, double (&o)[4]) {
+        const vec s = *reinterpret_cast<const vec *>(p);
+        o[0] = (double)stereo_word_sum(s.x); o[1] = (double)stereo_word_sum(s.y);
+        o[2] = (double)stereo_word_sum(s.z); o[3] = (double)stereo_word_sum(s.w);
+    }
+};
+template <> struct QuadLoad<double> {
+    typedef double vec __attribute__((ext_vector_type(2), aligned(8)));
+    static __device__ __forceinline__ void get(const double *p, double (&o)[4]) {
+        const vec a = *reinterpret_cast<const vec *>(p), b = *reinterpret_cast<const vec *>(p + 2);
+        o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+    }
+};
+
+// zcr count, energy, energy entropy (ShortTermFeatures.py:22-51) of frames tq .. tq+Q-1 -> tfs[4 f + {0, 1, 2}]
+template <typename SH, typename T>
+__device__ __forceinline__ void time_features_grouped(const T *__restrict__ x0, long long step, int tq, int tend,
+                                                      const ClipNorm &nm, double *tfs, int lane) {
+    constexpr int W = SH::W, L = W / 10, Q = SH::Q;
+    constexpr int CT = (((W + 15) / 16) + 3) & ~3;                  // samples per lane: whole groups of four
+    static_assert(CT <= L, "a lane's samples may meet at most two entropy blocks");
+    const int f = lane >> 4, i = lane & 15;
+    const int t = (f < Q && tq + f < tend) ? tq + f : tq;           // idle groups shadow a valid frame
+    const T *x = x0 + (long long)t * step;
+    const double sc = sample_scale<T>();
+    const int kb = CT * i;
+    const int cat = min(kb / L, 10);
+    const int bound = (cat >= 10) ? 0x7fffffff : (cat + 1) * L;
+    auto sgn = [](double v) {          // np.sign from the bit pattern: 0 for +-0, else +-1
+        const int hi = __double2hiint(v), lo = __double2loint(v);
+        return (((hi & 0x7fffffff) | lo) != 0) ? ((hi >> 31) | 1) : 0;
+    };
+    double ea = 0.0, eb = 0.0;
+    int zc = 0;
+    int sprev = sgn(fma(load_sample<T>(x + min(max(kb - 1, 0), W - 1)), sc, -nm.mean));
+    constexpr int G = 6;                                            // groups of four samples fetched together
+    static_assert((CT / 4) % G == 0, "whole batches");
+#pragma unroll 1
+    for (int m = 0; m < CT; m += 4 * G) {
+        double raw[G][4];
+#pragma unroll
+        for (int g = 0; g < G; ++g)                                 // (never read past the frame: the last group slides back)
+            QuadLoad<T>::get(x + min(kb + m + 4 * g, W - 4), raw[g]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int n0 = kb + m + 4 * g;
+            const int sh = n0 - min(n0, W - 4);
+            if (sh > 0) {              // one lane, the frame's last group: realign (values past the frame are masked below)
+                double tmp_[4] = {raw[g][0], raw[g][1], raw[g][2], raw[g][3]};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int src = min(u + sh, 3);
+                    raw[g][u] = (src == 1) ? tmp_[1] : (src == 2) ? tmp_[2] : tmp_[3];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int n = n0 + u;
+                const bool ok = n < W;
+                const double d = fma(raw[g][u], sc, -nm.mean);      // (the sign does not need the 1 / peak factor)
+                const double y = ok ? d * nm.inv : 0.0;
+                const double sq = y * y;
+                const double sa = (n < bound) ? sq : 0.0;
+                ea += sa;
+                eb += sq - sa;                                       // exactly 0 or sq
+                const int sx = sgn(d);
+                zc += (ok && n > 0) ? abs(sx - sprev) : 0;
+                sprev = ok ? sx : sprev;
+            }
+        }
+    }
+    double eblk[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) eblk[j] = group_sum(((cat == j) ? ea : 0.0) + ((cat + 1 == j) ? eb : 0.0));
+    double e_tot = group_sum(((cat == 10) ? ea : 0.0) + ((cat + 1 == 10) ? eb : 0.0));
+#pragma unroll
+    for (int j = 0; j < 10; ++j) e_tot += eblk[j];
+    zc = group_sum_i(zc);
+    double num = 0.0;
+#pragma unroll
+    for (int j = 0; j < 10; ++j)
+        if (i == j) num = eblk[j];
+    const double s = fast_div(num, e_tot + kEps);
+    const double ent_e = group_sum((i < 10) ? -(s * fast_log2(s + kEps)) : 0.0);
+    if (i == 0 && f < Q) { tfs[4 * f] = e_tot; tfs[4 * f + 1] = ent_e; tfs[4 * f + 2] = (double)zc; }
+}
+
+// the 34 base features (ShortTermFeatures.py:626-667) of the Q frames in slots (slot0 + f) % ring -> fvq[48 f + 0..33];
+// mspq: Q x 40 doubles, tmpq: Q x 12 doubles, tfs: the time-domain results of the iteration
+template <typename SH>
+__device__ __forceinline__ void frame_features_grouped(const PlanDev &P, const Tabs &tb, const double *slots, int slot0,
+                                                       int ring, int tq, const double *tfs, double *fvq, double *mspq,
+                                                       double *tmpq, int lane) {
+    constexpr int W = SH::W, NF = SH::NF, NFP = SH::NFP, Q = SH::Q, LB = NF / 10;
+    constexpr int CB = ((NF + 15) / 16) | 1;
+    static_assert(CB < LB, "a lane's bins may contain at most one block boundary");
+    const int f = lane >> 4, i = lane & 15;
+    const int fe = (f < Q) ? f : 0;                                 // the idle group shadows frame 0 (nothing is written)
+    const double *cur = slots + ((slot0 + fe) % ring) * NFP;
+    const double *prv = (tq + fe == 0) ? cur : slots + ((slot0 + fe + Q) % ring) * NFP;
+    double *fv = fvq + 48 * fe, *msp = mspq + 40 * fe, *tmp = tmpq + 12 * fe;
+    const double f0 = P.fs / (2.0 * (double)NF);
+    const int kb = CB * i;
+    // sweep A: sums, max, the lane's energy (:57-107)
+    double sX = 0.0, sXp = 0.0, sM = 0.0, mx = 0.0, cs = 0.0;
+#pragma unroll 5
+    for (int m = 0; m < CB; ++m) {
+        const int k = min(kb + m, NF - 1);
+        const bool ok = kb + m < NF;
+        const double a = ok ? cur[k] : 0.0, b = ok ? prv[k] : 0.0;
+        sX += a;
+        sXp += b;
+        sM = fma((double)m, a, sM);
+        mx = fmax(mx, a);
+        cs = fma(a, a, cs);
+    }
+    double sIX = f0 * fma((double)(kb + 1), sX, sM);                   // sum (k + 1) f0 X
+    const double incl = group_scan_incl(cs);
+    const double excl = incl - cs;
+    const double sP = group_max(incl);                                 // total = the (non-decreasing, >= 0) scan's last entry
+    sX = group_sum(sX);
+    sXp = group_sum(sXp);
+    sIX = group_sum(sIX);
+    mx = group_max(mx);
+    // cumulative energy at the block boundaries 0, LB, .. 10 LB: the lane whose chunk holds a boundary writes it
+    {
+        const int jb = (kb + LB - 1) / LB;                             // first boundary at or after the chunk start
+        const int mb = jb * LB - kb;                                   // its offset inside the chunk
+        double part = 0.0, cumb = excl;
+#pragma unroll 5
+        for (int m = 0; m < CB; ++m) {
+            cumb = (m == mb) ? excl + part : cumb;
+            const double a = (kb + m < NF) ? cur[min(kb + m, NF - 1)] : 0.0;
+            part = fma(a, a, part);
+        }
+        if (mb < CB && jb <= 10 && kb < NF && f < Q) tmp[jb] = cumb;
+    }
+    wsync();
+    double ent_f;
+    {
+        const double num = (i < 10) ? tmp[i + 1] - tmp[i] : 0.0;
+        const double s = fast_div(num, sP + kEps);
+        ent_f = group_sum((i < 10) ? -(s * fast_log2(s + kEps)) : 0.0);
+    }
+    const double sXe = sX + (double)NF * kEps;                         // np.sum(X + eps) (:118-119)
+    sXp += (double)NF * kEps;
+    // centroid, spread, flux, roll-off (:57-82, :110-140)
+    const double r = (mx == 0.0) ? 1.0 / kEps : fast_div(1.0, mx);
+    const double den = sX * r + kEps;
+    const double cen = fast_div(sIX * r, den);
+    const double rX = fast_div(1.0, sXe), rXp = fast_div(1.0, sXp);
+    const double thr = 0.90 * sP;
+    double sSp = 0.0, sFl = 0.0, run = excl;
+    int first = 0x7fffffff;
+#pragma unroll 5
+    for (int m = 0; m < CB; ++m) {
+        const int k = min(kb + m, NF - 1);
+        const bool ok = kb + m < NF;
+        const double a = ok ? cur[k] : 0.0, b = ok ? prv[k] : 0.0;
+        const double dv = (double)(kb + m + 1) * f0 - cen;
+        sSp = fma(dv * dv, a * r, sSp);
+        const double df = a * rX - b * rXp;
+        sFl = fma(df, df, sFl);
+        run = fma(a, a, run);
+        first = (first == 0x7fffffff && ok && run + kEps > thr) ? kb + m : first;
+    }
+    sSp = group_sum(sSp);
+    sFl = group_sum(sFl);
+    first = group_min_i(first);
+    const double spread = fast_sqrt(fast_div(sSp, den));
+    // MFCC: sparse mel dot, log10 (:236-251): lane i takes filters i, 16 + i, 32 + i
+#pragma unroll 1
+    for (int fl = i; fl < 40; fl += 16) {
+        const int lo = tb.mel_lo[fl], cnt = tb.mel_cnt[fl];
+        const double *w = tb.mel_w + tb.mel_off[fl];
+        double a0 = 0.0, a1 = 0.0;
+        int n = 0;
+        for (; n + 2 <= cnt; n += 2) {
+            a0 = fma(cur[lo + n], w[n], a0);
+            a1 = fma(cur[lo + n + 1], w[n + 1], a1);
+        }
+        if (n < cnt) a0 = fma(cur[lo + n], w[n], a0);
+        const double lg = fast_log10((a0 + a1) + kEps);
+        if (f < Q) msp[fl] = lg;
+    }
+    const double chroma = chroma_class(tb, cur, sP, i);                // (:277-321): lanes i < 12 of the row
+    wsync();
+    if (i < 13 && f < Q) {                                             // 13 x 40 DCT (:253)
+        const double *mrow = tb.dct + i * tb.dct_stride;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int n = 0; n < 40; n += 4) {
+            a0 = fma(mrow[n], msp[n], a0);
+            a1 = fma(mrow[n + 1], msp[n + 1], a1);
+            a2 = fma(mrow[n + 2], msp[n + 2], a2);
+            a3 = fma(mrow[n + 3], msp[n + 3], a3);
+        }
+        fv[8 + i] = (a0 + a1) + (a2 + a3);
+    }
+    // population std of the 12 chroma values (:667)
+    const double cv = (i < 12) ? chroma : 0.0;
+    const double cmean = group_sum(cv) * (1.0 / 12.0);
+    const double cd = (i < 12) ? cv - cmean : 0.0;
+    const double cvar = group_sum(cd * cd) * (1.0 / 12.0);
+    if (f < Q) {
+        if (i < 12) fv[21 + i] = chroma;
+        if (i == 0) {
+            fv[0] = (tfs[4 * f + 2] / 2.0) / (double)(W - 1);
+            fv[1] = tfs[4 * f] / (double)W;
+            fv[2] = tfs[4 * f + 1];
+            fv[3] = cen / (P.fs / 2.0);
+            fv[4] = spread / (P.fs / 2.0);
+            fv[5] = ent_f;
+            fv[6] = (cur == prv) ? 0.0 : sFl;      // first frame: previous spectrum = itself (:624-625)
+            fv[7] = (first == 0x7fffffff) ? 0.0 : (double)first / (double)NF;
+            fv[33] = fast_sqrt(cvar);
+        }
+    }
+    wsync();
+}
+
 template <typename SH, typename T>
 __global__ __launch_bounds__(512) void st_reg_kernel(PlanDev P, RegLayout L, const unsigned char *__restrict__ blob,
                                                       const T *__restrict__ sig, const ClipDev *__restrict__ clips,
@@ -417,9 +657,10 @@ __global__ __launch_bounds__(512) void st_reg_kernel(PlanDev P, RegLayout L, con
     const int ring = L.ring;
     double *slots = reinterpret_cast<double *>(wb);                    // ring x NFP doubles
     double *otile = slots + ring * NFP;
-    double *fv = otile + kFlush * F;
-    double *msp = fv + 48;
-    double *tfs = msp + 40;                                            // Q x 4: time-domain results of the iteration
+    double *fv = otile + kRegFlush * F;                                // Q x 48: feature vectors of the iteration's frames
+    double *msp = fv + 48 * Q;                                         // Q x 40: log mel energies
+    double *tfs = msp + 40 * Q;                                        // Q x 4: time-domain results of the iteration
+    double *tmpq = tfs + 4 * Q;                                        // Q x 12: cumulative energies at the block boundaries
 
     const Tile tl = tiles[tile_id];
     const ClipDev c = clips[tl.clip];
@@ -446,21 +687,8 @@ __global__ __launch_bounds__(512) void st_reg_kernel(PlanDev P, RegLayout L, con
         const int fb = lane_o / NP, pcol = lane_o - fb * NP;    // pass B: frame fb, column pair (pcol, R1 - pcol)
         const bool act_b = fb < Q;
         const int pcolb = (pcol == 0) ? 0 : R1 - pcol;
-        // ---------------- time-domain features of the iteration's frames (uniform values)
-        // (ONE instance of the stage in a run-time loop over the frames: the iteration's code has to stay inside the
-        //  instruction cache -- unrolled over the frames the kernel ran 40 % slower; results pass through LDS)
-        if (P.mode == 0) {
-#pragma nounroll
-            for (int f = 0; f < Q; ++f) {
-                const int t = tq + f;
-                // with deltas the last halo frame needs its full feature vector (previous column of the first stored frame)
-                const bool want = t < tend && (store_it || (P.deltas && f == Q - 1));
-                if (want && !(P.debug & 1)) {
-                    const TimeFeat tf = time_features_fixed<SH, T>(x0 + (long long)t * P.S, nm, lane_o);
-                    if (lane_o == 0) { tfs[4 * f] = tf.e_tot; tfs[4 * f + 1] = tf.ent_e; tfs[4 * f + 2] = (double)tf.zc; }
-                }
-            }
-        }
+        // ---------------- time-domain features of the iteration's Q frames, 16 lanes per frame (results pass through LDS)
+        if (P.mode == 0 && (store_it || P.deltas) && !(P.debug & 1)) time_features_grouped<SH, T>(x0, P.S, tq, tend, nm, tfs, lane_o);
         // ---------------- pass A: radix-R1 over n1, inputs z[(R2 n1 + R1 n2) mod NC] from global memory
         double yim[R1];
         {
@@ -550,31 +778,17 @@ __global__ __launch_bounds__(512) void st_reg_kernel(PlanDev P, RegLayout L, con
             });
         }
         wsync();
-        // ---------------- per frame: spectrogram row / chromagram row / the 34 features (one code instance, see above)
+        // ---------------- the 34 features of the Q frames at once (16 lanes per frame), then the staging tile
+        if (P.mode == 0) {
+            if ((store_it || P.deltas) && !(P.debug & 2))
+                frame_features_grouped<SH>(P, tb, slots, slot0, ring, tq, tfs, fv, msp, tmpq, lane_o);
 #pragma nounroll
-        for (int f = 0; f < Q; ++f) {
-            const int t = tq + f;
-            if (t >= tend) break;
-            const double *cur = slots + ((slot0 + f) % ring) * NFP;
-            const double *prv = slots + ((slot0 + f + Q) % ring) * NFP;
-            if (P.mode == 1) {            // spectrogram row (ShortTermFeatures.py:422)
-                double *row = oc + (long long)t * NF;
-                // (write-once stream of 4.4 KB rows that are only 8-byte aligned: non-temporal stores keep the L2 from
-                // writing half-filled lines twice; measured +15 % on float64 input, neutral on int16)
-                for (int k = lane_o; k < NF; k += kWave) __builtin_nontemporal_store(cur[k], row + k);
-            } else if (P.mode == 2) {     // chromagram row (:356-359)
-                double p = 0.0;
-                for (int k = lane_o; k < NF; k += kWave) { const double X = cur[k]; p = fma(X, X, p); }
-                p = wsum(p);
-                const double ch = chroma_class(tb, cur, p, lane_o);
-                if (lane_o < 12) oc[(long long)t * 12 + lane_o] = ch;
-            } else {
-                const bool want = store_it || (P.deltas && f == Q - 1);
-                if (want) {
-                    TimeFeat tf;
-                    tf.e_tot = tfs[4 * f]; tf.ent_e = tfs[4 * f + 1]; tf.zc = (int)tfs[4 * f + 2];
-                    if (!(P.debug & 2)) frame_features_fixed<SH>(P, tb, tf, cur, (t == 0) ? cur : prv, fv, msp, tfs + 4 * Q, lane_o);
-                    const double v = (lane_o < kBase) ? fv[lane_o] : 0.0;
+            for (int f = 0; f < Q; ++f) {
+                const int t = tq + f;
+                if (t >= tend) break;
+                // with deltas the last halo frame supplies the previous column of the first stored frame
+                if (store_it || (P.deltas && f == Q - 1)) {
+                    const double v = (lane_o < kBase) ? fv[48 * f + lane_o] : 0.0;
                     if (store_it) {
                         if (lane_o < kBase) {
                             otile[nslot * F + lane_o] = v;
@@ -584,16 +798,36 @@ __global__ __launch_bounds__(512) void st_reg_kernel(PlanDev P, RegLayout L, con
                     }
                     vprev = v;
                 }
-                if (nslot == kFlush || (t == tend - 1 && nslot > 0)) {
+                if (nslot == kRegFlush || (t == tend - 1 && nslot > 0)) {
                     wsync();
                     // row segments: nslot consecutive frames of feature row fr are contiguous in [F][T]
-                    for (int idx = lane_o; idx < F * kFlush; idx += kWave) {
-                        const int fr = idx / kFlush, i = idx % kFlush;
+                    for (int idx = lane_o; idx < F * kRegFlush; idx += kWave) {
+                        const int fr = idx / kRegFlush, i = idx % kRegFlush;
                         if (i < nslot) oc[(long long)fr * Tc + tbase + i] = otile[i * F + fr];
                     }
                     wsync();
                     tbase += nslot;
                     nslot = 0;
+                }
+            }
+        } else {
+            // ---------------- per frame: spectrogram row / chromagram row
+#pragma nounroll
+            for (int f = 0; f < Q; ++f) {
+                const int t = tq + f;
+                if (t >= tend) break;
+                const double *cur = slots + ((slot0 + f) % ring) * NFP;
+                if (P.mode == 1) {            // spectrogram row (ShortTermFeatures.py:422)
+                    double *row = oc + (long long)t * NF;
+                    // (write-once stream of 4.4 KB rows that are only 8-byte aligned: non-temporal stores keep the L2 from
+                    // writing half-filled lines twice; measured +15 % on float64 input, neutral on int16)
+                    for (int k = lane_o; k < NF; k += kWave) __builtin_nontemporal_store(cur[k], row + k);
+                } else {                      // chromagram row (:356-359)
+                    double p = 0.0;
+                    for (int k = lane_o; k < NF; k += kWave) { const double X = cur[k]; p = fma(X, X, p); }
+                    p = wsum(p);
+                    const double ch = chroma_class(tb, cur, p, lane_o);
+                    if (lane_o < 12) oc[(long long)t * 12 + lane_o] = ch;
                 }
             }
         }
@@ -607,7 +841,7 @@ typedef Shape<29, 19, 3> Shape1102;
 inline bool reg_supported(int window) { return window == Shape1102::W; }
 
 inline size_t reg_wave_bytes(int nfp, int ring, int q, int F) {
-    size_t b = (size_t)ring * nfp * 8 + (size_t)kFlush * F * 8 + (48 + 40) * 8 + (size_t)q * 4 * 8 + 16 * 8;
+    size_t b = (size_t)ring * nfp * 8 + (size_t)kRegFlush * F * 8 + (size_t)q * (48 + 40 + 4 + 12) * 8;
     return (b + 15) / 16 * 16;
 }
 
