@@ -414,6 +414,30 @@ template <> struct QuadLoad<double> {
     }
 };
 
+// np.sign(x * sc - mean) per sample.  Integer samples: two integer compares against the clip mean in counts -- for a whole
+// count x, x * sc - mean > 0 <=> x > floor(mu) and < 0 <=> x < ceil(mu) (both tests fail only when x == mu exactly);
+// float samples: from the bit pattern of the difference (0 for +-0, else +-1).
+template <typename T> struct SampleSign {
+    int hi, lo;
+    __device__ __forceinline__ SampleSign(const ClipNorm &nm, double sc) {
+        const double mu = nm.mean / sc;                             // exact: sc is a power of two
+        const double fl = floor(mu);
+        hi = (int)fl;
+        lo = (fl == mu) ? hi : hi + 1;
+    }
+    __device__ __forceinline__ int of(double raw, double) const {
+        const int x = (int)raw;                                     // (the samples are whole numbers)
+        return (int)(x > hi) - (int)(x < lo);
+    }
+};
+template <> struct SampleSign<double> {
+    __device__ __forceinline__ SampleSign(const ClipNorm &, double) {}
+    __device__ __forceinline__ int of(double, double d) const {
+        const int h = __double2hiint(d), l = __double2loint(d);
+        return (((h & 0x7fffffff) | l) != 0) ? ((h >> 31) | 1) : 0;
+    }
+};
+
 // zcr count, energy, energy entropy (ShortTermFeatures.py:22-51) of frames tq .. tq+Q-1 -> tfs[4 f + {0, 1, 2}]
 template <typename SH, typename T>
 __device__ __forceinline__ void time_features_grouped(const T *__restrict__ x0, long long step, int tq, int tend,
@@ -425,16 +449,19 @@ __device__ __forceinline__ void time_features_grouped(const T *__restrict__ x0, 
     const int t = (f < Q && tq + f < tend) ? tq + f : tq;           // idle groups shadow a valid frame
     const T *x = x0 + (long long)t * step;
     const double sc = sample_scale<T>();
+    const SampleSign<T> sign(nm, sc);
     const int kb = CT * i;
     const int cat = min(kb / L, 10);
-    const int bound = (cat >= 10) ? 0x7fffffff : (cat + 1) * L;
-    auto sgn = [](double v) {          // np.sign from the bit pattern: 0 for +-0, else +-1
-        const int hi = __double2hiint(v), lo = __double2loint(v);
-        return (((hi & 0x7fffffff) | lo) != 0) ? ((hi >> 31) | 1) : 0;
-    };
-    double ea = 0.0, eb = 0.0;
+    const int bound = (cat >= 10) ? 0x7fffffff : (cat + 1) * L;    // first sample of the next entropy block
+    // energy: one running sum of d^2 (d = x * sc - mean; the 1 / peak^2 factor is applied to the sums) and its value when
+    // the chunk crosses into the next block
+    double e_all = 0.0, e_snap = 0.0;
     int zc = 0;
-    int sprev = sgn(fma(load_sample<T>(x + min(max(kb - 1, 0), W - 1)), sc, -nm.mean));
+    int sprev;
+    {
+        const double r0 = load_sample<T>(x + min(max(kb - 1, 0), W - 1));
+        sprev = sign.of(r0, fma(r0, sc, -nm.mean));                 // (lane 0: sample 0 against itself counts nothing)
+    }
     constexpr int G = 6;                                            // groups of four samples fetched together
     static_assert((CT / 4) % G == 0, "whole batches");
 #pragma unroll 1
@@ -459,18 +486,19 @@ __device__ __forceinline__ void time_features_grouped(const T *__restrict__ x0, 
             for (int u = 0; u < 4; ++u) {
                 const int n = n0 + u;
                 const bool ok = n < W;
-                const double d = fma(raw[g][u], sc, -nm.mean);      // (the sign does not need the 1 / peak factor)
-                const double y = ok ? d * nm.inv : 0.0;
-                const double sq = y * y;
-                const double sa = (n < bound) ? sq : 0.0;
-                ea += sa;
-                eb += sq - sa;                                       // exactly 0 or sq
-                const int sx = sgn(d);
-                zc += (ok && n > 0) ? abs(sx - sprev) : 0;
-                sprev = ok ? sx : sprev;
+                const double dd = fma(raw[g][u], sc, -nm.mean);
+                const double d = ok ? dd : 0.0;
+                e_snap = (n == bound) ? e_all : e_snap;
+                e_all = fma(d, d, e_all);
+                const int sx = ok ? sign.of(raw[g][u], dd) : sprev;  // past the frame: no change, nothing counted
+                zc += abs(sx - sprev);
+                sprev = sx;
             }
         }
     }
+    const double inv2 = nm.inv * nm.inv;
+    const bool crossed = bound < kb + CT;                           // (samples past the frame add exact zeros: any n works)
+    const double ea = (crossed ? e_snap : e_all) * inv2, eb = (crossed ? e_all - e_snap : 0.0) * inv2;
     double eblk[10];
 #pragma unroll
     for (int j = 0; j < 10; ++j) eblk[j] = group_sum(((cat == j) ? ea : 0.0) + ((cat + 1 == j) ? eb : 0.0));
