@@ -9,9 +9,10 @@ The port: MASTER_PORT itself usually belongs to the launcher (torchrun's agent k
 the first free port of MASTER_PORT + 1 .. + 16 and a peer tries those in turn; both sides check a token derived from
 the job's environment, so a foreign listener on one of them is skipped, not joined.
 """
+import base64
 import hashlib
+import json
 import os
-import pickle
 import socket
 import struct
 import time
@@ -19,8 +20,34 @@ import time
 _PORT_SPAN = 16
 
 
+# Wire format: length-prefixed JSON (never pickle: a peer is another process on the network).  Plain numbers, strings,
+# booleans, None, lists / tuples (tuples come back as lists) and string-keyed dicts pass as they are, bytes as {"__b64__": ..}.
+def _encode(obj):
+    if isinstance(obj, (bytes, bytearray, memoryview)):
+        return {"__b64__": base64.b64encode(bytes(obj)).decode("ascii")}
+    if isinstance(obj, (list, tuple)):
+        return [_encode(v) for v in obj]
+    if isinstance(obj, dict):
+        return {str(k): _encode(v) for k, v in obj.items()}
+    if obj is None or isinstance(obj, (bool, int, float, str)):
+        return obj
+    if hasattr(obj, "item"):                      # NumPy scalars
+        return _encode(obj.item())
+    raise TypeError("control plane carries numbers, strings, bytes, lists and dicts only, not %r" % type(obj))
+
+
+def _decode(obj):
+    if isinstance(obj, dict):
+        if set(obj) == {"__b64__"}:
+            return base64.b64decode(obj["__b64__"])
+        return {k: _decode(v) for k, v in obj.items()}
+    if isinstance(obj, list):
+        return [_decode(v) for v in obj]
+    return obj
+
+
 def _send(sock, obj):
-    blob = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+    blob = json.dumps(_encode(obj), separators=(",", ":")).encode("utf-8")
     sock.sendall(struct.pack("<Q", len(blob)) + blob)
 
 
@@ -37,7 +64,9 @@ def _recv_exact(sock, n):
 
 def _recv(sock):
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
-    return pickle.loads(_recv_exact(sock, n))
+    if n > (64 << 20):
+        raise ConnectionError("control-plane message of %d bytes refused" % n)
+    return _decode(json.loads(_recv_exact(sock, n).decode("utf-8")))
 
 
 class SocketGroup:
@@ -127,14 +156,14 @@ class SocketGroup:
     def all_gather(self, obj):
         """[obj of rank 0, obj of rank 1, ...] on every rank."""
         if self.world_size == 1:
-            return [obj]
+            return [_decode(json.loads(json.dumps(_encode(obj))))]
         if self.rank == 0:
             out = [obj] + [None] * (self.world_size - 1)
             for r, s in self._peers.items():
                 out[r] = _recv(s)
             for s in self._peers.values():
                 _send(s, out)
-            return out
+            return _decode(json.loads(json.dumps(_encode(out))))          # the same value every rank sees
         _send(self._root, obj)
         return _recv(self._root)
 
