@@ -289,3 +289,48 @@ def silence_goldens():
 
 if __name__ == "__main__" and "--silence" in sys.argv:
     silence_goldens()
+
+
+def round3_goldens():
+    """Round 3: outputs of the unmodified reference at the shapes the round-3 kernels own -- 50 ms / 40 ms windows at 44.1 and
+    48 kHz (2205, 2400, 1764, 1920: mixed-radix kernel), 50 ms at 8 and 32 kHz (400: 2 RA RB family, 1600), 1024, and the
+    float64 mono signal audioBasicIO.stereo_to_mono hands over for a stereo file at 800 / 400.  Short clips keep the files
+    small; the seeded synthetic clips are oracle/synth.py's."""
+    from synth import synth_clip
+    ref_st, ref_mt, ref_io = load_reference.load()
+
+    def st_case(name, sig, fs, win, step, deltas=True):
+        F, names = ref_st.feature_extraction(sig, fs, win, step, deltas)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="st", signal=sig, fs=fs, window=win, step=step,
+                            deltas=deltas, features=F, names=np.array(names))
+        print(name, F.shape)
+
+    def spec_case(name, sig, fs, win, step):
+        with contextlib.redirect_stdout(io.StringIO()):
+            S, t_ax, f_ax = ref_st.spectrogram(sig, fs, win, step)
+        C, ct_ax, cf_ax = ref_st.chromagram(sig, fs, win, step)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="spec", signal=sig, fs=fs, window=win, step=step,
+                            specgram=S, spec_time=np.array(t_ax), spec_freq=np.array(f_ax), chromagram=C,
+                            chroma_time=np.array(ct_ax), chroma_names=np.array(cf_ax))
+        print(name, S.shape, C.shape)
+
+    fs, x = wav("pyAudioAnalysis/data/3WORDS.wav", 2.0)                     # 44.1 kHz speech
+    st_case("3words2s_2205_1102", x, fs, 2205, 1102)                          # 50 ms / 25 ms: odd window
+    spec_case("3words2s_spec_1764_1764", x, fs, 1764, 1764)                   # the CLI's 40 ms / 40 ms
+    x48 = synth_clip(4800, 2 * 48000, 48000)
+    st_case("synth48k_2400_1200", x48, 48000, 2400, 1200)
+    spec_case("synth48k_spec_1920_960", x48, 48000, 1920, 960)
+    x8 = synth_clip(800, 3 * 8000, 8000)
+    st_case("synth8k_400_200", x8, 8000, 400, 200)
+    x32 = synth_clip(3200, 2 * 32000, 32000)
+    st_case("synth32k_1600_800_nodelta", x32, 32000, 1600, 800, deltas=False)
+    x16 = synth_clip(1600, 3 * 16000, 16000)
+    st_case("synth16k_1024_512", x16, 16000, 1024, 512)
+    xs = synth_clip(1601, 3 * 16000, 16000, stereo=True)
+    mono = ref_io.stereo_to_mono(xs)                                          # float64, .5 fractions (audioBasicIO.py:167)
+    st_case("synth16k_stereo_to_mono_f64_800_400", mono, 16000, 800, 400)
+    st_case("synth16k_stereo_to_mono_f64_640_640", mono, 16000, 640, 640, deltas=False)
+
+
+if __name__ == "__main__" and "--round3" in sys.argv:
+    round3_goldens()
