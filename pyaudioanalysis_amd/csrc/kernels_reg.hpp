@@ -443,14 +443,16 @@ template <typename SH, typename T>
 __device__ __forceinline__ void time_features_grouped(const T *__restrict__ x0, long long step, int tq, int tend,
                                                       const ClipNorm &nm, double *tfs, int lane) {
     constexpr int W = SH::W, L = W / 10, Q = SH::Q;
-    constexpr int CT = (((W + 15) / 16) + 3) & ~3;                  // samples per lane: whole groups of four
-    static_assert(CT <= L, "a lane's samples may meet at most two entropy blocks");
+    // even split of the frame over the 16 lanes of its row: BASE samples each, the first REM lanes one more -- every lane's
+    // first 4 NG samples are inside the frame (no masks in the main loop), the rest is a short masked epilogue
+    constexpr int BASE = W / 16, REM = W % 16, NG = BASE / 4, EPI = BASE - 4 * NG + (REM ? 1 : 0);
+    static_assert(BASE + 1 <= L, "a lane's samples may meet at most two entropy blocks");
     const int f = lane >> 4, i = lane & 15;
     const int t = (f < Q && tq + f < tend) ? tq + f : tq;           // idle groups shadow a valid frame
     const T *x = x0 + (long long)t * step;
     const double sc = sample_scale<T>();
     const SampleSign<T> sign(nm, sc);
-    const int kb = CT * i;
+    const int kb = BASE * i + min(i, REM), ke = kb + BASE + (i < REM ? 1 : 0);
     const int cat = min(kb / L, 10);
     const int bound = (cat >= 10) ? 0x7fffffff : (cat + 1) * L;    // first sample of the next entropy block
     // energy: one running sum of d^2 (d = x * sc - mean; the 1 / peak^2 factor is applied to the sums) and its value when
@@ -459,45 +461,39 @@ __device__ __forceinline__ void time_features_grouped(const T *__restrict__ x0, 
     int zc = 0;
     int sprev;
     {
-        const double r0 = load_sample<T>(x + min(max(kb - 1, 0), W - 1));
+        const double r0 = load_sample<T>(x + max(kb - 1, 0));
         sprev = sign.of(r0, fma(r0, sc, -nm.mean));                 // (lane 0: sample 0 against itself counts nothing)
     }
-    constexpr int G = 6;                                            // groups of four samples fetched together
-    static_assert((CT / 4) % G == 0, "whole batches");
-#pragma unroll 1
-    for (int m = 0; m < CT; m += 4 * G) {
+    auto one = [&](int n, double raw) {
+        const double d = fma(raw, sc, -nm.mean);
+        e_snap = (n == bound) ? e_all : e_snap;
+        e_all = fma(d, d, e_all);
+        const int sx = sign.of(raw, d);
+        zc += abs(sx - sprev);
+        sprev = sx;
+    };
+    auto batch = [&](auto gc, int g0) {                             // G groups of four samples, fetched together
+        constexpr int G = decltype(gc)::value;
         double raw[G][4];
 #pragma unroll
-        for (int g = 0; g < G; ++g)                                 // (never read past the frame: the last group slides back)
-            QuadLoad<T>::get(x + min(kb + m + 4 * g, W - 4), raw[g]);
+        for (int g = 0; g < G; ++g) QuadLoad<T>::get(x + kb + 4 * (g0 + g), raw[g]);
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int n0 = kb + m + 4 * g;
-            const int sh = n0 - min(n0, W - 4);
-            if (sh > 0) {              // one lane, the frame's last group: realign (values past the frame are masked below)
-                double tmp_[4] = {raw[g][0], raw[g][1], raw[g][2], raw[g][3]};
+        for (int g = 0; g < G; ++g)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int src = min(u + sh, 3);
-                    raw[g][u] = (src == 1) ? tmp_[1] : (src == 2) ? tmp_[2] : tmp_[3];
-                }
-            }
+            for (int u = 0; u < 4; ++u) one(kb + 4 * (g0 + g) + u, raw[g][u]);
+    };
+    constexpr int G = 6;
+    int g0 = 0;
+#pragma unroll 1
+    for (; g0 + G <= NG; g0 += G) batch(std::integral_constant<int, G>{}, g0);
+    if constexpr (NG % G != 0) batch(std::integral_constant<int, NG % G>{}, NG - NG % G);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int n = n0 + u;
-                const bool ok = n < W;
-                const double dd = fma(raw[g][u], sc, -nm.mean);
-                const double d = ok ? dd : 0.0;
-                e_snap = (n == bound) ? e_all : e_snap;
-                e_all = fma(d, d, e_all);
-                const int sx = ok ? sign.of(raw[g][u], dd) : sprev;  // past the frame: no change, nothing counted
-                zc += abs(sx - sprev);
-                sprev = sx;
-            }
-        }
+    for (int u = 0; u < EPI; ++u) {                                 // the lane's last one or two samples
+        const int n = kb + 4 * NG + u;
+        if (n < ke) one(n, load_sample<T>(x + n));
     }
     const double inv2 = nm.inv * nm.inv;
-    const bool crossed = bound < kb + CT;                           // (samples past the frame add exact zeros: any n works)
+    const bool crossed = bound < ke;
     const double ea = (crossed ? e_snap : e_all) * inv2, eb = (crossed ? e_all - e_snap : 0.0) * inv2;
     double eblk[10];
 #pragma unroll
@@ -522,28 +518,31 @@ __device__ __forceinline__ void frame_features_grouped(const PlanDev &P, const T
                                                        int ring, int tq, const double *tfs, double *fvq, double *mspq,
                                                        double *tmpq, int lane) {
     constexpr int W = SH::W, NF = SH::NF, NFP = SH::NFP, Q = SH::Q, LB = NF / 10;
-    constexpr int CB = ((NF + 15) / 16) | 1;
-    static_assert(CB < LB, "a lane's bins may contain at most one block boundary");
     const int f = lane >> 4, i = lane & 15;
     const int fe = (f < Q) ? f : 0;                                 // the idle group shadows frame 0 (nothing is written)
     const double *cur = slots + ((slot0 + fe) % ring) * NFP;
     const double *prv = (tq + fe == 0) ? cur : slots + ((slot0 + fe + Q) % ring) * NFP;
     double *fv = fvq + 48 * fe, *msp = mspq + 40 * fe, *tmp = tmpq + 12 * fe;
     const double f0 = P.fs / (2.0 * (double)NF);
-    const int kb = CB * i;
+    // even split of the bins over the 16 lanes of the row: BASE bins each, the first REM lanes one more: the main loops
+    // run without masks, the extra bin is an epilogue
+    constexpr int BASE = NF / 16, REM = NF % 16;
+    static_assert(BASE + 1 < LB, "a lane's bins may contain at most one block boundary");
+    const int kb = BASE * i + min(i, REM);
+    const bool extra = i < REM;
     // sweep A: sums, max, the lane's energy (:57-107)
     double sX = 0.0, sXp = 0.0, sM = 0.0, mx = 0.0, cs = 0.0;
-#pragma unroll 5
-    for (int m = 0; m < CB; ++m) {
-        const int k = min(kb + m, NF - 1);
-        const bool ok = kb + m < NF;
-        const double a = ok ? cur[k] : 0.0, b = ok ? prv[k] : 0.0;
+    auto sweep_a = [&](int m) {
+        const double a = cur[kb + m], b = prv[kb + m];
         sX += a;
         sXp += b;
         sM = fma((double)m, a, sM);
         mx = fmax(mx, a);
         cs = fma(a, a, cs);
-    }
+    };
+#pragma unroll 2
+    for (int m = 0; m < BASE; ++m) sweep_a(m);
+    if (extra) sweep_a(BASE);
     double sIX = f0 * fma((double)(kb + 1), sX, sM);                   // sum (k + 1) f0 X
     const double incl = group_scan_incl(cs);
     const double excl = incl - cs;
@@ -557,13 +556,15 @@ __device__ __forceinline__ void frame_features_grouped(const PlanDev &P, const T
         const int jb = (kb + LB - 1) / LB;                             // first boundary at or after the chunk start
         const int mb = jb * LB - kb;                                   // its offset inside the chunk
         double part = 0.0, cumb = excl;
-#pragma unroll 5
-        for (int m = 0; m < CB; ++m) {
+        auto bnd = [&](int m) {
             cumb = (m == mb) ? excl + part : cumb;
-            const double a = (kb + m < NF) ? cur[min(kb + m, NF - 1)] : 0.0;
+            const double a = cur[kb + m];
             part = fma(a, a, part);
-        }
-        if (mb < CB && jb <= 10 && kb < NF && f < Q) tmp[jb] = cumb;
+        };
+#pragma unroll 2
+        for (int m = 0; m < BASE; ++m) bnd(m);
+        if (extra) bnd(BASE);
+        if (mb < BASE + (extra ? 1 : 0) && jb <= 10 && f < Q) tmp[jb] = cumb;
     }
     wsync();
     double ent_f;
@@ -582,18 +583,18 @@ __device__ __forceinline__ void frame_features_grouped(const PlanDev &P, const T
     const double thr = 0.90 * sP;
     double sSp = 0.0, sFl = 0.0, run = excl;
     int first = 0x7fffffff;
-#pragma unroll 5
-    for (int m = 0; m < CB; ++m) {
-        const int k = min(kb + m, NF - 1);
-        const bool ok = kb + m < NF;
-        const double a = ok ? cur[k] : 0.0, b = ok ? prv[k] : 0.0;
+    auto sweep_b = [&](int m) {
+        const double a = cur[kb + m], b = prv[kb + m];
         const double dv = (double)(kb + m + 1) * f0 - cen;
         sSp = fma(dv * dv, a * r, sSp);
         const double df = a * rX - b * rXp;
         sFl = fma(df, df, sFl);
         run = fma(a, a, run);
-        first = (first == 0x7fffffff && ok && run + kEps > thr) ? kb + m : first;
-    }
+        first = (first == 0x7fffffff && run + kEps > thr) ? kb + m : first;
+    };
+#pragma unroll 2
+    for (int m = 0; m < BASE; ++m) sweep_b(m);
+    if (extra) sweep_b(BASE);
     sSp = group_sum(sSp);
     sFl = group_sum(sFl);
     first = group_min_i(first);
