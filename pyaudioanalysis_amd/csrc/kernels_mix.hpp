@@ -319,21 +319,23 @@ __device__ __forceinline__ void frame_load_pairs(const PlanDev &P, const T *__re
 }
 
 // ---- time-domain and spectral stages on CONTIGUOUS per-lane chunks ---------------------------------------------
-// Lane l owns elements [l c, (l+1) c) of the frame (samples) or of the spectrum (bins), c odd (LDS reads of 64 lanes at
-// stride c doubles are conflict-free) and >= n / 64.  A chunk meets at most two of the ten entropy blocks (or the last
+// Lane l owns a contiguous run of n / 64 (+ 1) elements of the frame (samples) or of the spectrum (bins).  A chunk meets at most two of the ten entropy blocks (or the last
 // block and the tail the reference leaves out of the blocks, ShortTermFeatures.py:37-41, :93-98), so a lane carries two
 // partial energies and the wave reduces per block; everything is read in groups of four (a lone wave hides LDS latency
 // through instruction-level parallelism only).
 struct Chunk {
-    int c, kb, ke;       // chunk length, first element, one past the last (kb == ke: this lane has nothing)
+    int base, kb, ke;    // elements every lane has (wave-uniform), first element, one past the last (base or base + 1 elements)
     int cat;             // entropy block of element kb (10 = tail)
     int bound;           // first element of the next category
 };
+// even split: n / 64 elements per lane, the first n % 64 lanes one more -- the main loops run over `base` elements without
+// masks, the extra element is an epilogue
 __device__ __forceinline__ Chunk make_chunk(int n, int block_len, int lane) {
     Chunk ch;
-    ch.c = ((n + kWave - 1) / kWave) | 1;
-    ch.kb = min(lane * ch.c, n);
-    ch.ke = min(n, ch.kb + ch.c);
+    const int rem = n % kWave;
+    ch.base = n / kWave;
+    ch.kb = ch.base * lane + min(lane, rem);
+    ch.ke = ch.kb + ch.base + (lane < rem ? 1 : 0);
     ch.cat = min(ch.kb / block_len, 10);
     ch.bound = (ch.cat >= 10) ? 0x7fffffff : (ch.cat + 1) * block_len;
     return ch;
@@ -356,25 +358,25 @@ __device__ __forceinline__ TimeFeat time_features_chunked(const PlanDev &P, cons
         const int hi = __double2hiint(x), lo = __double2loint(x);
         return (((hi & 0x7fffffff) | lo) != 0) ? ((hi >> 31) | 1) : 0;
     };
-    int sprev = sgn(y[max(ch.kb - 1, 0) * st]);
-    for (int i = 0; i < ch.c; i += 4) {
+    int sprev = sgn(y[max(ch.kb - 1, 0) * st]);            // (lane 0: sample 0 against itself counts nothing)
+    auto one = [&](int n, double x) {
+        const double sq = x * x;
+        const double sa = (n < ch.bound) ? sq : 0.0;
+        ea += sa;
+        eb += sq - sa;                                         // exactly 0 or sq
+        const int sx = sgn(x);
+        zc += abs(sx - sprev);
+        sprev = sx;
+    };
+    int i = 0;
+    for (; i + 4 <= ch.base; i += 4) {
         double v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = y[min(ch.kb + i + u, W - 1) * st];
+        for (int u = 0; u < 4; ++u) v[u] = y[(ch.kb + i + u) * st];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int n = ch.kb + i + u;
-            const bool ok = n < ch.ke;
-            const double x = ok ? v[u] : 0.0;
-            const double sq = x * x;
-            const double sa = (n < ch.bound) ? sq : 0.0;
-            ea += sa;
-            eb += sq - sa;                                         // exactly 0 or sq
-            const int sx = sgn(x);
-            zc += (ok && n > 0) ? abs(sx - sprev) : 0;
-            sprev = ok ? sx : sprev;
-        }
+        for (int u = 0; u < 4; ++u) one(ch.kb + i + u, v[u]);
     }
+    for (int n = ch.kb + i; n < ch.ke; ++n) one(n, y[n * st]);
     double eblk[10], e_tail;
     block_sums(ch, ea, eb, eblk, e_tail);
     TimeFeat tf;
@@ -399,28 +401,26 @@ __device__ __forceinline__ void frame_features_chunked(const PlanDev &P, const T
     const double f0 = P.fs / (2.0 * (double)Nf);
     // ---------- sweep A over the lane's bins: sums, max, block energies (:57-107)
     double sX = 0.0, sXp = 0.0, sIX = 0.0, mx = 0.0, ea = 0.0, eb = 0.0;
-    for (int i = 0; i < ch.c; i += 4) {
-        double a[4], b[4];
+    auto sweep_a = [&](int k, double X, double Xp) {
+        sX += X;
+        sXp += Xp;
+        sIX = fma((double)(k + 1), X, sIX);
+        mx = fmax(mx, X);
+        const double sq = X * X;
+        const double sa = (k < ch.bound) ? sq : 0.0;
+        ea += sa;
+        eb += sq - sa;                                         // exactly 0 or sq
+    };
+    {
+        int i = 0;
+        for (; i + 4 <= ch.base; i += 4) {
+            double a[4], b[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = min(ch.kb + i + u, Nf - 1);
-            a[u] = cur[k];
-            b[u] = prv[k];
-        }
+            for (int u = 0; u < 4; ++u) { a[u] = cur[ch.kb + i + u]; b[u] = prv[ch.kb + i + u]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = ch.kb + i + u;
-            const bool ok = k < ch.ke;
-            const double X = ok ? a[u] : 0.0;
-            sX += X;
-            sXp += ok ? b[u] : 0.0;
-            sIX = fma((double)(k + 1), X, sIX);
-            mx = fmax(mx, X);
-            const double sq = X * X;
-            const double sa = (k < ch.bound) ? sq : 0.0;
-            ea += sa;
-            eb += sq - sa;                                         // exactly 0 or sq
+            for (int u = 0; u < 4; ++u) sweep_a(ch.kb + i + u, a[u], b[u]);
         }
+        for (int k = ch.kb + i; k < ch.ke; ++k) sweep_a(k, cur[k], prv[k]);
     }
     double pblk[10], p_tail;
     block_sums(ch, ea, eb, pblk, p_tail);
@@ -454,26 +454,24 @@ __device__ __forceinline__ void frame_features_chunked(const PlanDev &P, const T
     const double thr = 0.90 * sP;
     double sSp = 0.0, sFl = 0.0, run = before;
     int first = 0x7fffffff;
-    for (int i = 0; i < ch.c; i += 4) {
-        double a[4], b[4];
+    auto sweep_b = [&](int k, double X, double Xp) {
+        const double dv = (double)(k + 1) * f0 - cen;
+        sSp = fma(dv * dv, X * r, sSp);
+        const double df = X * rX - Xp * rXp;
+        sFl = fma(df, df, sFl);
+        run = fma(X, X, run);                                   // cumsum(X^2)[k]
+        if (run + kEps > thr) first = min(first, k);            // first k with cumsum + eps > 0.9 sum (:134-139)
+    };
+    {
+        int i = 0;
+        for (; i + 4 <= ch.base; i += 4) {
+            double a[4], b[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = min(ch.kb + i + u, Nf - 1);
-            a[u] = cur[k];
-            b[u] = prv[k];
-        }
+            for (int u = 0; u < 4; ++u) { a[u] = cur[ch.kb + i + u]; b[u] = prv[ch.kb + i + u]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = ch.kb + i + u;
-            const bool ok = k < ch.ke;
-            const double X = ok ? a[u] : 0.0, Xp = ok ? b[u] : 0.0;
-            const double dv = (double)(k + 1) * f0 - cen;
-            sSp = fma(dv * dv, X * r, sSp);
-            const double df = X * rX - Xp * rXp;
-            sFl = fma(df, df, sFl);
-            run = fma(X, X, run);                                   // cumsum(X^2)[k]
-            if (ok && run + kEps > thr) first = min(first, k);      // first k with cumsum + eps > 0.9 sum (:134-139)
+            for (int u = 0; u < 4; ++u) sweep_b(ch.kb + i + u, a[u], b[u]);
         }
+        for (int k = ch.kb + i; k < ch.ke; ++k) sweep_b(k, cur[k], prv[k]);
     }
     sSp = wsum(sSp);
     sFl = wsum(sFl);
