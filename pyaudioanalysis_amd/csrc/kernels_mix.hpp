@@ -347,6 +347,40 @@ __device__ __forceinline__ void block_sums(const Chunk &ch, double ea, double eb
     tail = wsum(((ch.cat == 10) ? ea : 0.0) + ((ch.cat + 1 == 10) ? eb : 0.0));
 }
 
+// wave minimum of non-negative ints on DPP (the generic xor tree goes through ds_bpermute: six dependent LDS round trips)
+__device__ __forceinline__ int wmin_nonneg_i(int v) {
+    v = group_min_i(v);
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x142, 0xA, 0xF, false));      // row_bcast15 into rows 1, 3
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x143, 0xC, 0xF, false));      // row_bcast31 into rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// chroma of one spectrum: lanes 0..11 return their pitch class (ShortTermFeatures.py:285-308); the gather list is walked
+// four entries at a time (index loads, then spectrum and weight loads, then the sums: a lone wave needs the batching)
+__device__ __forceinline__ double chroma_class_batched(const Tabs &tb, const double *spec, double sP, int lane) {
+    double acc = 0.0;
+    if (lane < 12) {
+        const int b = tb.ch_start[lane], e = tb.ch_start[lane + 1];
+        int i = b;
+        for (; i + 4 <= e; i += 4) {
+            int src[4];
+            double x[4], w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) src[u] = tb.ch_src[i + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { x[u] = spec[src[u]]; w[u] = tb.ch_w[i + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += (x[u] * x[u]) * w[u];          // same order as the one-by-one walk
+        }
+        for (; i < e; ++i) {
+            const double x = spec[tb.ch_src[i]];
+            acc += (x * x) * tb.ch_w[i];
+        }
+        acc = (sP == 0.0) ? acc / kEps : fast_div(acc, sP);
+    }
+    return acc;
+}
+
 // zcr count, energy and energy entropy of the normalised frame in LDS (ShortTermFeatures.py:22-51)
 __device__ __forceinline__ TimeFeat time_features_chunked(const PlanDev &P, const double2 *buf, const Chunk &ch, int lane) {
     const int W = P.W, st = P.even ? 1 : 2;                 // odd windows: y[n] = buf[n].x
@@ -475,7 +509,7 @@ __device__ __forceinline__ void frame_features_chunked(const PlanDev &P, const T
     }
     sSp = wsum(sSp);
     sFl = wsum(sFl);
-    first = wmin_i(first);
+    first = wmin_nonneg_i(first);
     const double spread = fast_sqrt(fast_div(sSp, den));
 
     // ---------- MFCC: sparse mel dot, log10, 13 x 40 DCT (:236-254)
@@ -500,7 +534,7 @@ __device__ __forceinline__ void frame_features_chunked(const PlanDev &P, const T
         msp[lane] = fast_log10((a0 + a1) + kEps);
     }
     // ---------- chroma (:277-321)
-    const double chroma = chroma_class(tb, cur, sP, lane);
+    const double chroma = chroma_class_batched(tb, cur, sP, lane);
     wsync();
     if (lane < 13) {
         const double *m = tb.dct + lane * tb.dct_stride;
@@ -712,6 +746,14 @@ __global__ __launch_bounds__(256) void st_mix_kernel(PlanDev P, MixLayout L, con
         TimeFeat tf;
         tf.e_tot = 0.0; tf.ent_e = 0.0; tf.zc = 0;
         if (want) tf = time_features_chunked(P, buf, ch_t, lane);
+        int touched = 0;
+        if (t + 1 < tend) {
+            // pull the next frame's new samples (the S behind this frame's end) towards the L2 / L1 now: their latency then
+            // runs under this frame's transform and feature stage (the values are only "used" at the end of the iteration)
+            const char *nb = reinterpret_cast<const char *>(x + P.W);
+            const int nbytes = P.S * (int)sizeof(T);
+            for (int o = 64 * lane; o + 4 <= nbytes; o += 64 * kWave) touched ^= *reinterpret_cast<const int *>(nb + o);
+        }
         PAA_TICK(1)
         fft_passes_inplace(P, L, buf, tb.tw, lane);
         PAA_TICK(2)
@@ -752,6 +794,7 @@ __global__ __launch_bounds__(256) void st_mix_kernel(PlanDev P, MixLayout L, con
                 nslot = 0;
             }
         }
+        asm volatile("" ::"v"(touched));      // (the prefetch loads retire here at the latest)
         wsync();
         PAA_TICK(10)
     }
