@@ -518,13 +518,12 @@ __device__ __forceinline__ void frame_features_chunked(const PlanDev &P, const T
         const double *w = tb.mel_w + tb.mel_off[lane];
         double a0 = 0.0, a1 = 0.0;
         int i = 0;
-        for (; i + 4 <= cnt; i += 4) {
-            const double x0 = cur[lo + i], x1 = cur[lo + i + 1], x2 = cur[lo + i + 2], x3 = cur[lo + i + 3];
-            const double w0 = w[i], w1 = w[i + 1], w2 = w[i + 2], w3 = w[i + 3];
-            a0 = fma(x0, w0, a0);
-            a1 = fma(x1, w1, a1);
-            a0 = fma(x2, w2, a0);
-            a1 = fma(x3, w3, a1);
+        for (; i + 8 <= cnt; i += 8) {                   // eight bins and weights in flight
+            double xb[8], wb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { xb[u] = cur[lo + i + u]; wb[u] = w[i + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { a0 = fma(xb[u], wb[u], a0); a1 = fma(xb[u + 1], wb[u + 1], a1); }
         }
         for (; i + 2 <= cnt; i += 2) {
             a0 = fma(cur[lo + i], w[i], a0);
