@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "device_common.hpp"
+#include "kernels_ct.hpp"          // PairLoad
 #include "kernels_generic.hpp"
 #include "tables.hpp"
 
@@ -732,8 +733,8 @@ __global__ __launch_bounds__(512) void st_reg_kernel(PlanDev P, RegLayout L, con
                 for (int n1 = 0; n1 < R1; ++n1) {
                     int idx = R2 * n1 + R1 * n2;                    // < 2 NC: one conditional wrap
                     idx = (idx >= NC) ? idx - NC : idx;
-                    const double a = load_sample<T>(xf + 2 * idx), b = load_sample<T>(xf + 2 * idx + 1);
-                    v[n1] = make_double2(fma(a, sc, -nm.mean) * nm.inv, fma(b, sc, -nm.mean) * nm.inv);
+                    const double2 ab = ct::PairLoad<T>::get(xf + 2 * idx);       // one load per complex sample
+                    v[n1] = make_double2(fma(ab.x, sc, -nm.mean) * nm.inv, fma(ab.y, sc, -nm.mean) * nm.inv);
                 }
                 v0 = v[0];
                 prime_fold<R1>(v, s, d);
