@@ -127,7 +127,7 @@ def timed(ffi, fn, steps, warmup):
     return ms.value / steps
 
 
-def other_configs(ffi, steps=8):
+def other_configs(ffi, steps=10):
     """BASELINE configs 3, 4 (one GPU's shard) and 5, kernel-resident, with SURVEY 8d's algorithmic bytes per frame."""
     from synth import synth_clip
     out = {}
@@ -189,7 +189,7 @@ def other_configs(ffi, steps=8):
         d_in = ffi.DeviceBuffer.from_host(x)
         plan = ffi.Plan(offs, fs_, W_, S_, deltas=bool(deltas), sample_kind=kind, mode=mode)
         d_out = ffi.DeviceBuffer(plan.out_doubles * 8)
-        ms = timed(ffi, lambda: plan.execute(d_in, d_out), steps, 2)
+        ms = timed(ffi, lambda: plan.execute(d_in, d_out), 4 * steps, 8)          # (sub-millisecond steps: 40 of them)
         rows = plan.F if mode != 0 else (68 if deltas else 34)
         out[key] = entry(plan.total_frames, ms, shape_bytes_per_frame(name, rows), plan.kernel_name,
                          {"workload": what, "fs": fs_, "window": W_, "step": S_,
