@@ -242,6 +242,9 @@ int paa_debug_mix_plan(int window, int32_t *radices, int32_t *fft_len, uint16_t 
  * workgroups run at a time.  Returns the cap, the number of runs and the longest run          */
 int paa_debug_run_plan(const int64_t *frames, int64_t n_clips, int quantum, int min_run, int max_run, int halo, int wg_runs,
                        int num_cu, int32_t *run_cap, int64_t *n_runs, int32_t *longest);
+/* the same for kernels whose runs after a clip's first are `shrink` frames shorter (halo inside the first iteration) */
+int paa_debug_run_plan_shrink(const int64_t *frames, int64_t n_clips, int quantum, int min_run, int max_run, int shrink,
+                              int wg_runs, int num_cu, int32_t *run_cap, int64_t *n_runs, int32_t *longest);
 
 #ifdef __cplusplus
 }

@@ -108,6 +108,8 @@ _SIGNATURES = {
     "paa_debug_mix_plan": (C.c_int, [C.c_int, c_i32p, c_i32p, C.POINTER(C.c_uint16), C.c_int, c_i32p, c_i32p]),
     "paa_debug_run_plan": (C.c_int, [c_i64p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p,
                                      c_i64p, c_i32p]),
+    "paa_debug_run_plan_shrink": (C.c_int, [c_i64p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p,
+                                     c_i64p, c_i32p]),
 }
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
 

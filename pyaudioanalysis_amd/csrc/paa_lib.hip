@@ -309,7 +309,9 @@ constexpr int kStatChunk = 65536;
 // one 1-hour clip -> 2000 runs of 72 frames (one round); 12 500 clips of 399 frames -> two runs of 200 per clip instead
 // of 244 + 155 (the short run's wave idled for a third of its workgroup's life); 1000 clips of 1199 frames -> 6 x 200.
 static int choose_run_cap(const std::vector<ClipDev> &clips, int quantum, int min_run, int max_run, int halo, int wg_runs,
-                          int num_cu) {
+                          int num_cu, int shrink = 0) {
+    // shrink: frames by which every run but a clip's first is shorter (kernels whose halo rides inside the first iteration:
+    // the tile list gives those runs len - shrink frames, so a clip has more runs than T / len)
     std::map<long long, long long> hist;                       // frames per clip -> number of such clips
     for (const ClipDev &c : clips)
         if (c.T > 0) ++hist[c.T];
@@ -321,7 +323,8 @@ static int choose_run_cap(const std::vector<ClipDev> &clips, int quantum, int mi
         for (const auto &kv : hist) {
             const long long k = (kv.first + cap - 1) / cap;
             const long long len = ((kv.first + k - 1) / k + quantum - 1) / quantum * quantum;
-            runs += kv.second * ((kv.first + len - 1) / len);
+            const long long later = std::max<long long>(len - shrink, 1);
+            runs += kv.second * ((kv.first <= len) ? 1 : 1 + (kv.first - len + later - 1) / later);
             longest = std::max(longest, len);
         }
         const long long wgs = (runs + wg_runs - 1) / wg_runs;
@@ -521,7 +524,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         // iteration, so the first run of a clip gets `run` frames and the others run - halo: every run is whole iterations
         run_quantum = 4;
         run_halo = (mode == 0) ? (deltas ? 2 : 1) : 0;
-        run = choose_run_cap(p->clips, 4, 16, 256, 0, p->cl.waves, g_num_cu);
+        run = choose_run_cap(p->clips, 4, 16, 256, 0, p->cl.waves, g_num_cu, run_halo);
         p->lds = p->cl.lds;
         p->kernel_name = p->cl.name;
     } else if (p->reg) {
@@ -1551,6 +1554,28 @@ extern "C" int paa_debug_run_plan(const int64_t *frames, int64_t n_clips, int qu
         if (c.T <= 0) continue;
         const int len = clip_run_length(c.T, cap, quantum);
         runs += (c.T + len - 1) / len;
+        lmax = std::max(lmax, len);
+    }
+    *run_cap = cap; *n_runs = runs; *longest = lmax;
+    return PAA_OK;
+}
+// the same for the kernels whose halo rides inside a run's first iteration (2 RA RB family): every run of a clip but the
+// first is `shrink` frames shorter, which is what the tile list does -- the run count follows that rule
+extern "C" int paa_debug_run_plan_shrink(const int64_t *frames, int64_t n_clips, int quantum, int min_run, int max_run,
+                                         int shrink, int wg_runs, int num_cu, int32_t *run_cap, int64_t *n_runs,
+                                         int32_t *longest) {
+    if (!frames || n_clips < 0 || quantum < 1 || min_run < quantum || max_run < min_run || shrink < 0 || wg_runs < 1 ||
+        num_cu < 1 || !run_cap || !n_runs || !longest)
+        return fail(PAA_ERR_ARG, "bad argument");
+    std::vector<ClipDev> clips((size_t)n_clips);
+    for (int64_t c = 0; c < n_clips; ++c) { memset(&clips[(size_t)c], 0, sizeof(ClipDev)); clips[(size_t)c].T = (int)frames[c]; }
+    const int cap = choose_run_cap(clips, quantum, min_run, max_run, 0, wg_runs, num_cu, shrink);
+    long long runs = 0;
+    int lmax = 0;
+    for (const ClipDev &c : clips) {
+        if (c.T <= 0) continue;
+        const int len = clip_run_length(c.T, cap, quantum);
+        for (long long t0 = 0; t0 < c.T; ++runs) t0 += (t0 > 0) ? std::max(len - shrink, 1) : len;      // the tile rule
         lmax = std::max(lmax, len);
     }
     *run_cap = cap; *n_runs = runs; *longest = lmax;

@@ -200,6 +200,20 @@ def test_run_length_choice_for_the_baseline_batches():
         live = frames[frames > 0]
         assert runs >= len(live) and runs >= -(-int(live.sum()) // 256)
     assert _ffi.lib().paa_debug_run_plan(None, 1, 4, 16, 256, 4, 8, 256, None, None, None) == _ffi.ERR_ARG
+    # kernels whose halo rides inside the first iteration (runs after a clip's first are 1 or 2 frames shorter): the count
+    # that decides the rounds is the tile list's -- 90 000 frames at 640 / 640 were 2 093 runs = 262 workgroups = two rounds
+    # on 256 CUs when the chooser assumed T / len runs (0.36 ms instead of 0.22 ms)
+    for frames, shrink in (([90000], 1), ([90000], 2), ([179999], 2), ([143999], 1), ([1199] * 1000, 2)):
+        arr = np.ascontiguousarray(frames, dtype=np.int64)
+        cap, longest, runs = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
+        _ffi.check(_ffi.lib().paa_debug_run_plan_shrink(_ffi.as_i64p(arr), len(arr), 4, 16, 256, shrink, 8, 256,
+                                                        ctypes.byref(cap), ctypes.byref(runs), ctypes.byref(longest)))
+        wgs = -(-runs.value // 8)
+        rounds = -(-wgs // 256)
+        ideal_rounds = max(1, -(-int(arr.sum()) // (256 * 8 * 256)))
+        assert rounds == ideal_rounds or len(frames) > 1, (frames[:1], shrink, runs.value, wgs)
+        if len(frames) == 1:
+            assert wgs <= 256 and longest.value <= 256
 
 
 def test_result_pool_tracks_liveness_through_views_of_views():
