@@ -140,15 +140,21 @@ __device__ __forceinline__ void dft4(double2 *v) {
     v[1] = sub_i(t1, t3);
     v[3] = add_i(t1, t3);
 }
+// radix 5 in the form that is EXACTLY zero in its four non-DC outputs for five equal inputs: cos 144 = -1/2 - cos 72, so
+// X[1] = (a0 - t2/2) + c1 (t1 - t2) and X[2] = (a0 - t1/2) - c1 (t1 - t2) (the textbook form leaves a0 * 1e-16).  Frames of
+// digital silence are constant once the clip mean is removed; the reference's FFT (pocketfft: plain sums and differences
+// first) returns exact zeros for their non-DC bins, and log10(E + eps) of an empty mel band resolves 1e-24.
 __device__ __forceinline__ void dft5(double2 *v) {
-    const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+    const double c1 = 0.30901699437494742410;
     const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
-    double2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]);
-    double2 t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
-    double2 m1 = make_double2(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
-    double2 m2 = make_double2(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
-    double2 n1 = make_double2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
-    double2 n2 = make_double2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+    const double2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+    const double2 d = csub(t1, t2);
+    const double2 h1 = make_double2(fma(-0.5, t1.x, v[0].x), fma(-0.5, t1.y, v[0].y));
+    const double2 h2 = make_double2(fma(-0.5, t2.x, v[0].x), fma(-0.5, t2.y, v[0].y));
+    const double2 m1 = make_double2(fma(c1, d.x, h2.x), fma(c1, d.y, h2.y));
+    const double2 m2 = make_double2(fma(-c1, d.x, h1.x), fma(-c1, d.y, h1.y));
+    const double2 n1 = make_double2(fma(s2, t4.x, s1 * t3.x), fma(s2, t4.y, s1 * t3.y));
+    const double2 n2 = make_double2(fma(-s1, t4.x, s2 * t3.x), fma(-s1, t4.y, s2 * t3.y));
     v[0] = make_double2(v[0].x + t1.x + t2.x, v[0].y + t1.y + t2.y);
     v[1] = sub_i(m1, n1);
     v[4] = add_i(m1, n1);

@@ -63,6 +63,11 @@ template <> struct PrimeTab<13> {
     static constexpr double s[13] = {0.00000000000000000000, 0.46472317204376850652, 0.82298386589365635224, 0.99270887409805397272, 0.93501624268541483342, 0.66312265824079519305, 0.23931566428755768339, -0.23931566428755743359, -0.66312265824079497101, -0.93501624268541472240, -0.99270887409805397272, -0.82298386589365701838, -0.46472317204376839550};
 };
 
+// Written so that R EQUAL inputs give exactly zero in every non-DC output (digital silence: see dft5 in
+// device_common.hpp): sum_j cos(2 pi j q / R) over j = 1 .. (R-1)/2 is -1/2 for every q, so the coefficient of the pair
+// the index j*(q) with j* q = H (mod R) -- any fixed pair p would do -- is replaced by -1/2 minus the others:
+//     A_q = (x0 - s_p / 2) + sum_{j != p} cos(2 pi j q / R) (s_j - s_p),     s_j = x_j + x_{R-j}.
+// The differences s_j - s_p are formed once; the B sums (sines of x_j - x_{R-j}) are zero for equal inputs anyway.
 template <int R>
 __device__ __forceinline__ void dft_prime(double2 *v) {
     constexpr int H = (R - 1) / 2;
@@ -76,14 +81,21 @@ __device__ __forceinline__ void dft_prime(double2 *v) {
     double2 tot = x0;
 #pragma unroll
     for (int j = 0; j < H; ++j) tot = cadd(tot, sm[j]);
+    // pivot pair p = H: base = x0 - s_H / 2, rel[j] = s_j - s_H
+    const double2 base = make_double2(fma(-0.5, sm[H - 1].x, x0.x), fma(-0.5, sm[H - 1].y, x0.y));
+    double2 rel[H > 1 ? H - 1 : 1];
+#pragma unroll
+    for (int j = 0; j + 1 < H; ++j) rel[j] = csub(sm[j], sm[H - 1]);
 #pragma unroll
     for (int q = 1; q <= H; ++q) {
-        double ar = x0.x, ai = x0.y, br = 0.0, bi = 0.0;
+        double ar = base.x, ai = base.y, br = 0.0, bi = 0.0;
 #pragma unroll
         for (int j = 1; j <= H; ++j) {
             const double c = PrimeTab<R>::c[(j * q) % R], s = PrimeTab<R>::s[(j * q) % R];
-            ar = fma(c, sm[j - 1].x, ar);
-            ai = fma(c, sm[j - 1].y, ai);
+            if (j < H) {
+                ar = fma(c, rel[j - 1].x, ar);
+                ai = fma(c, rel[j - 1].y, ai);
+            }
             br = fma(s, df[j - 1].x, br);
             bi = fma(s, df[j - 1].y, bi);
         }
