@@ -67,6 +67,7 @@ SHAPES = {
     "ct_800_stereo": (16000, 800, 400, 3600, 1, 2, 0, 0),
     "ct_400": (8000, 400, 200, 3600, 2, 0, 0, 0),                  # 50 ms at 8 kHz (audioTrainTest.py:28-29)
     "ct_320": (16000, 320, 160, 1800, 1, 0, 0, 0),
+    "w1024": (16000, 1024, 512, 3600, 1, 0, 0, 0),                 # a power-of-two window (mixed-radix kernel, lean instance)
     "w2400": (48000, 2400, 1200, 1200, 1, 0, 0, 0),                # 50 ms at 48 kHz
     "w2205": (44100, 2205, 1102, 1200, 1, 0, 0, 0),                # 50 ms at 44.1 kHz (odd window)
     "mid_stats": (16000, 800, 400, 30, 1000, 0, 0, 1),
@@ -208,6 +209,7 @@ def other_configs(ffi, steps=10):
     run_shape("ct_800_f64", "w800_float64", "1 h at 16 kHz, 800 / 400, float64 mono samples (stereo_to_mono's output)")
     run_shape("ct_800_stereo", "w800_stereo", "1 h at 16 kHz, 800 / 400, interleaved stereo int16 samples")
     run_shape("ct_400", "w400_8kHz", "2 x 1 h at 8 kHz, 50 ms / 25 ms (400 / 200)")
+    run_shape("w1024", "w1024_16kHz", "1 h at 16 kHz, window 1024 / step 512 (a power-of-two window: mixed-radix kernel, lean instance)")
     run_shape("w2400", "w2400_48kHz", "20 min at 48 kHz, 50 ms / 25 ms (2400 / 1200)")
     run_shape("w2205", "w2205_44kHz", "20 min at 44.1 kHz, 50 ms / 25 ms (2205 / 1102, odd window)")
     return out

@@ -32,6 +32,7 @@ using f800::g_wave_trace;
 
 constexpr int kMaxPass = 12;
 constexpr int kSlots = 24;          // magnitude pass: result pairs a lane keeps until every lane has read its inputs
+constexpr int kSlotsLean = 12;      // ... in the lean variant (<= 256 registers: two waves per SIMD where the LDS allows it)
 
 struct MixLayout {
     int off_tw, off_post, off_perm, off_mello, off_melcnt, off_meloff, off_melw, off_dct, off_chstart, off_chsrc, off_chw;
@@ -39,6 +40,7 @@ struct MixLayout {
     int wave_bytes;      // per-wave region, multiple of 16
     int waves;           // waves per workgroup
     int tw_global;       // 1: twiddles and post-twiddles stay in global memory (L1/L2 hits), 0: LDS copies
+    int lean;            // 1: the <= 256-register instance with up to eight waves per workgroup (windows whose LDS allows > 4)
     int unit_bytes;      // U: one spectrum, rounded to 16 bytes
     int buf_bytes;       // B: Nc complex
     int n_pass;
@@ -179,10 +181,11 @@ __device__ __forceinline__ void dif_batch(double2 *buf, int nb, int stride, int 
         }
     }
 }
-template <int R>
+template <int R, int LEAN>
 __device__ __forceinline__ void dif_pass(double2 *buf, int Nc, int M, int tws, unsigned magic,
                                          const double2 *__restrict__ tw, int lane) {
-    constexpr int U = (R <= 5) ? 4 : (R <= 13 ? 2 : 1);
+    // butterflies in flight per lane: as many as the register budget of the instance allows
+    constexpr int U = LEAN ? ((R <= 5) ? 2 : 1) : ((R <= 5) ? 4 : (R <= 13 ? 2 : 1));
     const int stride = M / R, nb = Nc / R;
     const int iters = (nb + kWave - 1) / kWave;
     int i = 0;
@@ -194,6 +197,7 @@ __device__ __forceinline__ void dif_pass(double2 *buf, int Nc, int M, int tws, u
 // ---- the whole transform + |X| / num_fft (ShortTermFeatures.py:617-621) ------------------------------------------
 // buf: the frame as packed complex (even windows: z[m] = y[2m] + i y[2m+1]; odd: z[n] = y[n]); cur: where the Nf
 // magnitudes go -- it may overlap buf: every lane holds its results in registers until all inputs have been read.
+template <int LEAN>
 __device__ __forceinline__ void fft_passes_inplace(const PlanDev &P, const MixLayout &L, double2 *buf,
                                                    const double2 *__restrict__ tw, int lane) {
     const int Nc = P.Nc;
@@ -202,21 +206,25 @@ __device__ __forceinline__ void fft_passes_inplace(const PlanDev &P, const MixLa
         const unsigned mg = L.magic[p];
         const int ts = L.tws[p];
         switch (L.radix[p]) {
-            case 2: dif_pass<2>(buf, Nc, M, ts, mg, tw, lane); break;
-            case 3: dif_pass<3>(buf, Nc, M, ts, mg, tw, lane); break;
-            case 4: dif_pass<4>(buf, Nc, M, ts, mg, tw, lane); break;
-            case 5: dif_pass<5>(buf, Nc, M, ts, mg, tw, lane); break;
-            case 7: dif_pass<7>(buf, Nc, M, ts, mg, tw, lane); break;
-            case 8: dif_pass<8>(buf, Nc, M, ts, mg, tw, lane); break;
-            case 11: dif_pass<11>(buf, Nc, M, ts, mg, tw, lane); break;
-            case 13: dif_pass<13>(buf, Nc, M, ts, mg, tw, lane); break;
-            default: dif_pass<16>(buf, Nc, M, ts, mg, tw, lane); break;
+            case 2: dif_pass<2, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
+            case 3: dif_pass<3, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
+            case 4: dif_pass<4, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
+            case 5: dif_pass<5, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
+            case 7: dif_pass<7, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
+            case 8: dif_pass<8, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
+            case 11: dif_pass<11, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
+            case 13: dif_pass<13, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
+            default:                 // radix 16 (the lean instance's schedules stop at radix 8)
+                if constexpr (!LEAN) dif_pass<16, LEAN>(buf, Nc, M, ts, mg, tw, lane);
+                break;
         }
         wsync();
     }
 }
+template <int LEAN>
 __device__ __forceinline__ void magnitudes_inplace(const PlanDev &P, const double2 *buf, const double2 *__restrict__ post,
                                                    const unsigned short *__restrict__ perm, double *cur, int lane) {
+    constexpr int kSlots = LEAN ? kSlotsLean : mix::kSlots;
     const int Nc = P.Nc, Nf = P.Nf;
     const double invNf = 1.0 / (double)Nf;     // X / len(X)  (:621)
     double r0[kSlots], r1[kSlots];
@@ -582,7 +590,7 @@ __device__ __forceinline__ void frame_features_chunked(const PlanDev &P, const T
 }
 
 // ---- host: radix schedule, permutation, LDS layout + table blob ---------------------------------------------------
-inline bool mix_factor(int n, std::vector<int> &radix) {
+inline bool mix_factor(int n, std::vector<int> &radix, bool radix16 = true) {
     radix.clear();
     int twos = 0;
     while (n % 2 == 0) { ++twos; n /= 2; }
@@ -591,7 +599,7 @@ inline bool mix_factor(int n, std::vector<int> &radix) {
         while (n % f == 0) { odd.push_back(f); n /= f; }
     if (n != 1) return false;
     // big strides first for the power-of-two butterflies, the odd radices (conflict-free at small strides) last
-    while (twos >= 4 && twos != 5 && twos != 6) { radix.push_back(16); twos -= 4; }      // (5 = 8 4, 6 = 8 8)
+    while (radix16 && twos >= 4 && twos != 5 && twos != 6) { radix.push_back(16); twos -= 4; }      // (5 = 8 4, 6 = 8 8)
     while (twos >= 3 && twos != 4) { radix.push_back(8); twos -= 3; }
     while (twos >= 2) { radix.push_back(4); twos -= 2; }
     if (twos) radix.push_back(2);
@@ -622,23 +630,26 @@ inline int mix_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
     if (!mix_factor(Nc, radix)) return 0;
     if (fft.even ? (Nc / 2 + 1 > kWave * kSlots) : (Nf > 2 * kWave * kSlots)) return 0;
     memset(&L, 0, sizeof(L));
-    L.n_pass = (int)radix.size();
-    int M = Nc;
-    for (int p = 0; p < L.n_pass; ++p) {
-        L.radix[p] = radix[p];
-        L.span[p] = M;
-        const unsigned stride = (unsigned)(M / radix[p]);
-        L.magic[p] = stride > 1 ? (unsigned)((1ULL << 32) / stride) + 1u : 0u;
-        L.tws[p] = Nc / M;
-        M /= radix[p];
-    }
+    auto set_passes = [&]() {
+        L.n_pass = (int)radix.size();
+        int M = Nc;
+        for (int p = 0; p < L.n_pass; ++p) {
+            L.radix[p] = radix[p];
+            L.span[p] = M;
+            const unsigned stride = (unsigned)(M / radix[p]);
+            L.magic[p] = stride > 1 ? (unsigned)((1ULL << 32) / stride) + 1u : 0u;
+            L.tws[p] = Nc / M;
+            M /= radix[p];
+        }
+    };
+    set_passes();
     L.unit_bytes = (Nf * 8 + 15) / 16 * 16;
     L.buf_bytes = Nc * 16;
     const int FF = F > 0 ? F : 1;
     L.wave_bytes = (L.buf_bytes + L.unit_bytes + kFlush * FF * 8 + 48 * 8 + 40 * 8 + 15) / 16 * 16;
     const size_t n_melw = mel ? mel->w.size() : 0, n_ch = chroma ? chroma->src.size() : 0;
     const size_t n_post = fft.even ? (size_t)(Nc / 2 + 1) : 1;
-    auto lay = [&](int tw_global) {
+    auto lay = [&](int tw_global, int max_waves) {
         int off = 0;
         auto take = [&off](size_t bytes) { const int o = off; off += (int)((bytes + 15) / 16 * 16); return o; };
         L.off_tw = take(tw_global ? 16 : (size_t)Nc * 16);
@@ -653,16 +664,30 @@ inline int mix_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
         L.off_chsrc = take(std::max<size_t>(n_ch, 1) * 4);
         L.off_chw = take(std::max<size_t>(n_ch, 1) * 8);
         L.table_bytes = off;
-        int waves = 4;
+        int waves = max_waves;
         while (waves > 0 && (size_t)L.table_bytes + (size_t)waves * L.wave_bytes > 160 * 1024) --waves;
         return waves;
     };
     // the twiddle tables go to LDS unless that costs a wave
-    const int w_lds = lay(0), w_glob = lay(1);
+    int w_lds = lay(0, 4), w_glob = lay(1, 4);
     L.tw_global = (w_glob > w_lds) ? 1 : 0;
     if (const char *force = getenv("PAA_MIX_TW_GLOBAL")) L.tw_global = atoi(force) ? 1 : 0;      // A/B experiments
-    L.waves = lay(L.tw_global);
+    L.waves = lay(L.tw_global, 4);
     if (L.waves < 1) return 0;
+    // small windows: the LDS has room for more than four waves -- the lean instance (<= 256 registers, fewer butterflies
+    // and magnitude slots in flight per lane) runs six to eight waves per CU, i.e. up to two per SIMD
+    L.lean = 0;
+    const bool lean_fits = fft.even ? (Nc / 2 + 1 <= kWave * kSlotsLean) : (Nf <= 2 * kWave * kSlotsLean);
+    if (lean_fits && !getenv("PAA_MIX_NO_LEAN")) {
+        w_lds = lay(0, 8); w_glob = lay(1, 8);
+        const int g8 = (w_glob > w_lds) ? 1 : 0, w8 = std::max(w_lds, w_glob);
+        if (w8 >= 6) { L.lean = 1; L.tw_global = g8; L.waves = lay(g8, 8); }
+        else L.waves = lay(L.tw_global, 4);
+    }
+    if (L.lean) {                      // (the radix-16 codelet alone needs 128 registers of operands: radix 8 / 4 instead)
+        if (!mix_factor(Nc, radix, false)) return 0;
+        set_passes();
+    }
     if (!blob) return 1;
     blob->assign((size_t)L.table_bytes, 0);
     unsigned char *b = blob->data();
@@ -694,9 +719,10 @@ inline int mix_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
 
 inline size_t mix_lds_bytes(const MixLayout &L) { return (size_t)L.table_bytes + (size_t)L.waves * L.wave_bytes; }
 
-// TWG = 1: twiddles / post-twiddles are read from global memory (the tables of a 2400-sample window would cost a wave)
-template <typename T, int TWG>
-__global__ __launch_bounds__(256) void st_mix_kernel(PlanDev P, MixLayout L, const unsigned char *__restrict__ blob,
+// TWG = 1: twiddles / post-twiddles are read from global memory (the tables of a 2400-sample window would cost a wave);
+// LEAN = 1: up to eight waves per workgroup, <= 256 registers (small windows)
+template <typename T, int TWG, int LEAN>
+__global__ __launch_bounds__(LEAN ? 512 : 256) void st_mix_kernel(PlanDev P, MixLayout L, const unsigned char *__restrict__ blob,
                                                       const T *__restrict__ sig, const ClipDev *__restrict__ clips,
                                                       const ClipNorm *__restrict__ norms, const Tile *__restrict__ tiles,
                                                       int n_tiles, double *__restrict__ out) {
@@ -766,9 +792,9 @@ __global__ __launch_bounds__(256) void st_mix_kernel(PlanDev P, MixLayout L, con
             for (int o = 64 * lane; o + 4 <= nbytes; o += 64 * kWave) touched ^= *reinterpret_cast<const int *>(nb + o);
         }
         PAA_TICK(1)
-        fft_passes_inplace(P, L, buf, tb.tw, lane);
+        fft_passes_inplace<LEAN>(P, L, buf, tb.tw, lane);
         PAA_TICK(2)
-        magnitudes_inplace(P, buf, tb.post, perm, cur, lane);
+        magnitudes_inplace<LEAN>(P, buf, tb.post, perm, cur, lane);
         PAA_TICK(3)
         if (P.mode == 1) {            // spectrogram row (ShortTermFeatures.py:422)
             double *row = oc + (long long)t * Nf;

@@ -640,23 +640,25 @@ static int launch_generic(paa_plan *p, const void *d_packed, double *d_out) {
     return PAA_OK;
 }
 
-template <typename T, int TWG>
+template <typename T, int TWG, int LEAN>
 static int launch_mix(paa_plan *p, const void *d_packed, double *d_out) {
     static size_t attr_set = 0;
     if (p->lds > attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mix::st_mix_kernel<T, TWG>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mix::st_mix_kernel<T, TWG, LEAN>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(p->lds, 64 * 1024)));
         attr_set = std::max<size_t>(p->lds, 64 * 1024);
     }
     const unsigned grid = (unsigned)((p->n_tiles + p->ml.waves - 1) / p->ml.waves);
-    hipLaunchKernelGGL((mix::st_mix_kernel<T, TWG>), dim3(grid), dim3(64 * p->ml.waves), p->lds, cs(), p->P, p->ml,
+    hipLaunchKernelGGL((mix::st_mix_kernel<T, TWG, LEAN>), dim3(grid), dim3(64 * p->ml.waves), p->lds, cs(), p->P, p->ml,
                        p->d_gen_blob, (const T *)d_packed, p->d_clips, p->d_norms, p->d_tiles, (int)p->n_tiles, d_out);
     HIP_TRY(hipGetLastError());
     return PAA_OK;
 }
 template <typename T>
 static int launch_mix_any(paa_plan *p, const void *d_packed, double *d_out) {
-    return p->ml.tw_global ? launch_mix<T, 1>(p, d_packed, d_out) : launch_mix<T, 0>(p, d_packed, d_out);
+    if (p->ml.lean)
+        return p->ml.tw_global ? launch_mix<T, 1, 1>(p, d_packed, d_out) : launch_mix<T, 0, 1>(p, d_packed, d_out);
+    return p->ml.tw_global ? launch_mix<T, 1, 0>(p, d_packed, d_out) : launch_mix<T, 0, 0>(p, d_packed, d_out);
 }
 
 template <typename T>
