@@ -212,8 +212,8 @@ __device__ __forceinline__ void fft_passes_inplace(const PlanDev &P, const MixLa
             case 5: dif_pass<5, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
             case 7: dif_pass<7, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
             case 8: dif_pass<8, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
-            case 11: dif_pass<11, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
-            case 13: dif_pass<13, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
+            case 11: if constexpr (!LEAN) dif_pass<11, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;     // (lean: radix <= 8)
+            case 13: if constexpr (!LEAN) dif_pass<13, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
             default:                 // radix 16 (the lean instance's schedules stop at radix 8)
                 if constexpr (!LEAN) dif_pass<16, LEAN>(buf, Nc, M, ts, mg, tw, lane);
                 break;
@@ -678,7 +678,9 @@ inline int mix_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
     // and magnitude slots in flight per lane) runs six to eight waves per CU, i.e. up to two per SIMD
     L.lean = 0;
     const bool lean_fits = fft.even ? (Nc / 2 + 1 <= kWave * kSlotsLean) : (Nf <= 2 * kWave * kSlotsLean);
-    if (lean_fits && !getenv("PAA_MIX_NO_LEAN")) {
+    bool small_radices = true;         // (the radix-11 / 13 / 16 butterflies need more registers than the lean instance has)
+    for (int r : radix) small_radices &= (r <= 8 || r == 16);
+    if (lean_fits && small_radices && !getenv("PAA_MIX_NO_LEAN")) {
         w_lds = lay(0, 8); w_glob = lay(1, 8);
         const int g8 = (w_glob > w_lds) ? 1 : 0, w8 = std::max(w_lds, w_glob);
         if (w8 >= 6) { L.lean = 1; L.tw_global = g8; L.waves = lay(g8, 8); }
