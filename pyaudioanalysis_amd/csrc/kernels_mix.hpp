@@ -14,9 +14,18 @@
 // the back, so the previous spectrum always sits in the third the current transform does not touch (B = 16 Nc bytes,
 // U = 8 Nf bytes rounded to 16).
 //
+// A wave runs alone on its SIMD at the large windows (the LDS footprint, not the registers, sets the occupancy), so every
+// stage hides latency through instruction-level parallelism: butterflies, magnitudes, sample loads, the mel / chroma
+// gathers and both feature sweeps fetch in groups before they compute; the time-domain and spectral stages work on an
+// even split of the frame over the lanes (contiguous chunks, two block partials per lane, no bounds masks in the main
+// loops); the next frame's new samples are touched before the feature stage.  Windows whose LDS footprint allows more
+// than four waves (up to ~1 700 samples) run a LEAN instance: <= 256 registers, radix <= 8, six to eight waves per CU.
+// The butterflies are written so that R equal inputs give EXACT zeros in the non-DC outputs (dft5 in device_common.hpp,
+// dft_prime below): the spectrum of a digitally silent frame is exact, as the reference's is for these lengths.
+//
 // Replaces the while loop at ShortTermFeatures.py:608-682 (+ helpers :22-140, :236-321) and the loops of spectrogram
-// (:415-422) / chromagram (:349-359) for those windows; the time-domain and spectral feature stages are the generic
-// kernel's (kernels_generic.hpp).
+// (:415-422) / chromagram (:349-359) for those windows; mel / DCT / chroma semantics are the generic kernel's
+// (kernels_generic.hpp: Tabs, chroma_class).
 #pragma once
 #include <vector>
 
