@@ -5,7 +5,10 @@
 // The complex FFT of length Nc = R1 R2 (real-input trick: z[n] = y[2n] + i y[2n+1]) is a PRIME-FACTOR transform: with
 // n = (R2 n1 + R1 n2) mod Nc and k = (c1 k1 + c2 k2) mod Nc (c1 = R2 (R2^-1 mod R1), c2 = R1 (R1^-1 mod R2)) there are
 // no twiddle factors between the passes.  Per iteration a wave handles Q frames:
-//   time    : the time-domain features of each frame, read straight from HBM/L2 with all 64 lanes
+//   time    : the time-domain features of the Q frames at once, 16 lanes per frame: an even split of the frame's samples
+//             over the row (quad loads in batches, no bounds masks in the main loop), np.sign as two integer compares
+//             against the clip mean in counts, one running energy + a snapshot at the entropy-block boundary, 4-step
+//             DPP reductions inside the row
 //   pass A  : lane (frame f, n2 < R2): radix-R1 DFT over n1 of samples fetched (normalised) from global memory; the
 //             O(R^2) prime butterfly uses the cos/sin symmetry (x_j +- x_{R-j}): (R-1)^2 FMAs; outputs leave the lane as
 //             they are produced: real parts into the frame's spectrum slot (used as a plane), imaginary parts are kept
@@ -13,7 +16,8 @@
 //   pass B  : lane (frame f, p <= R1/2): the two radix-R2 DFTs of columns k1 = p and R1 - p, produced output pair by
 //             output pair; Z[k] and Z[Nc-k] = (column R1-p, output R2-q) meet in the lane, so the real-FFT recombination
 //             and |X| happen in registers and each magnitude is written once into the slot
-//   features: per frame with the full wave (the generic kernel's reductions), row segments staged in LDS
+//   features: the Q frames at once, 16 lanes per frame over an even split of the bins (same scheme); row segments staged
+//             in LDS.  Spectrogram / chromagram rows need no previous spectrum: Q slots and eight waves per CU.
 // Halo: a run that starts at t0 > 0 first processes frames t0-Q .. t0-1 without storing them.
 //
 // Replaces the while loop at ShortTermFeatures.py:608-682 and its helpers (:22-140, :236-321), and the loops of
