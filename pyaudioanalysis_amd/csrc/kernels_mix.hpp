@@ -49,6 +49,8 @@ struct MixLayout {
     int wave_bytes;      // per-wave region, multiple of 16
     int waves;           // waves per workgroup
     int tw_global;       // 1: twiddles and post-twiddles stay in global memory (L1/L2 hits), 0: LDS copies
+    int pad_shift;       // FFT buffer skew: element e lives at e + (e >> pad_shift) (5 for lengths that are multiples of 32:
+                         // power-of-two strides would put a butterfly's operands on one bank; 31 = no skew)
     int lean;            // 1: the <= 256-register instance with up to eight waves per workgroup (windows whose LDS allows > 4)
     int unit_bytes;      // U: one spectrum, rounded to 16 bytes
     int buf_bytes;       // B: Nc complex
@@ -58,6 +60,8 @@ struct MixLayout {
     int tws[kMaxPass];             // Nc / M: twiddle W_M^j = tw[j * tws]
     unsigned magic[kMaxPass];      // floor(2^32 / stride) + 1: b / stride == umulhi(b, magic) for b < 2^16
 };
+
+__device__ __forceinline__ int skew(int e, int sh) { return sh < 0 ? e : e + (e >> sh); }      // (sh is a compile-time constant)
 
 // ---- prime butterflies: X[q], X[R-q] from the sums / differences of the pairs (x_j, x_{R-j}) -------------------
 template <int R> struct PrimeTab;
@@ -154,7 +158,7 @@ template <> struct Bfly<16> {          // the 4 x 4 codelet of the 800-sample ke
 // parallelism only: a lane fetches the elements and twiddles of U butterflies before it computes any of them.
 template <int R, int U>
 __device__ __forceinline__ void dif_batch(double2 *buf, int nb, int stride, int M, int tws, unsigned magic,
-                                          const double2 *__restrict__ tw, int b0) {
+                                          const double2 *__restrict__ tw, int b0, int psh) {
     double2 v[U][R], w[U][R];
     int base[U];
     bool act[U];
@@ -167,7 +171,7 @@ __device__ __forceinline__ void dif_batch(double2 *buf, int nb, int stride, int 
         const int k = be - __mul24(blk, stride);                  // (all indices < 2^16: 24-bit multiplies are full rate)
         base[u] = __mul24(blk, M) + k;
 #pragma unroll
-        for (int r = 0; r < R; ++r) v[u][r] = buf[base[u] + r * stride];
+        for (int r = 0; r < R; ++r) v[u][r] = buf[skew(base[u] + r * stride, psh)];
         if (stride > 1) {
             const int t1 = __mul24(k, tws);
 #pragma unroll
@@ -186,21 +190,21 @@ __device__ __forceinline__ void dif_batch(double2 *buf, int nb, int stride, int 
     for (int u = 0; u < U; ++u) {
         if (act[u]) {
 #pragma unroll
-            for (int q = 0; q < R; ++q) buf[base[u] + q * stride] = v[u][Bfly<R>::pos(q)];
+            for (int q = 0; q < R; ++q) buf[skew(base[u] + q * stride, psh)] = v[u][Bfly<R>::pos(q)];
         }
     }
 }
 template <int R, int LEAN>
 __device__ __forceinline__ void dif_pass(double2 *buf, int Nc, int M, int tws, unsigned magic,
-                                         const double2 *__restrict__ tw, int lane) {
+                                         const double2 *__restrict__ tw, int lane, int psh) {
     // butterflies in flight per lane: as many as the register budget of the instance allows
     constexpr int U = LEAN ? ((R <= 5) ? 2 : 1) : ((R <= 5) ? 4 : (R <= 13 ? 2 : 1));
     const int stride = M / R, nb = Nc / R;
     const int iters = (nb + kWave - 1) / kWave;
     int i = 0;
-    for (; i + U <= iters; i += U) dif_batch<R, U>(buf, nb, stride, M, tws, magic, tw, lane + kWave * i);
-    if (U == 4 && i + 2 <= iters) { dif_batch<R, 2>(buf, nb, stride, M, tws, magic, tw, lane + kWave * i); i += 2; }
-    if (i < iters) dif_batch<R, 1>(buf, nb, stride, M, tws, magic, tw, lane + kWave * i);
+    for (; i + U <= iters; i += U) dif_batch<R, U>(buf, nb, stride, M, tws, magic, tw, lane + kWave * i, psh);
+    if (U == 4 && i + 2 <= iters) { dif_batch<R, 2>(buf, nb, stride, M, tws, magic, tw, lane + kWave * i, psh); i += 2; }
+    if (i < iters) dif_batch<R, 1>(buf, nb, stride, M, tws, magic, tw, lane + kWave * i, psh);
 }
 
 // ---- the whole transform + |X| / num_fft (ShortTermFeatures.py:617-621) ------------------------------------------
@@ -209,22 +213,23 @@ __device__ __forceinline__ void dif_pass(double2 *buf, int Nc, int M, int tws, u
 template <int LEAN>
 __device__ __forceinline__ void fft_passes_inplace(const PlanDev &P, const MixLayout &L, double2 *buf,
                                                    const double2 *__restrict__ tw, int lane) {
+    constexpr int PSH = (LEAN == 2) ? 5 : -1;       // instance 2: lean + skewed buffer (lengths that are multiples of 32)
     const int Nc = P.Nc;
     for (int p = 0; p < L.n_pass; ++p) {
         const int M = L.span[p];
         const unsigned mg = L.magic[p];
         const int ts = L.tws[p];
         switch (L.radix[p]) {
-            case 2: dif_pass<2, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
-            case 3: dif_pass<3, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
-            case 4: dif_pass<4, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
-            case 5: dif_pass<5, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
-            case 7: dif_pass<7, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
-            case 8: dif_pass<8, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
-            case 11: if constexpr (!LEAN) dif_pass<11, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;     // (lean: radix <= 8)
-            case 13: if constexpr (!LEAN) dif_pass<13, LEAN>(buf, Nc, M, ts, mg, tw, lane); break;
+            case 2: dif_pass<2, LEAN>(buf, Nc, M, ts, mg, tw, lane, PSH); break;
+            case 3: dif_pass<3, LEAN>(buf, Nc, M, ts, mg, tw, lane, PSH); break;
+            case 4: dif_pass<4, LEAN>(buf, Nc, M, ts, mg, tw, lane, PSH); break;
+            case 5: dif_pass<5, LEAN>(buf, Nc, M, ts, mg, tw, lane, PSH); break;
+            case 7: dif_pass<7, LEAN>(buf, Nc, M, ts, mg, tw, lane, PSH); break;
+            case 8: dif_pass<8, LEAN>(buf, Nc, M, ts, mg, tw, lane, PSH); break;
+            case 11: if constexpr (!LEAN) dif_pass<11, LEAN>(buf, Nc, M, ts, mg, tw, lane, PSH); break;     // (lean: radix <= 8)
+            case 13: if constexpr (!LEAN) dif_pass<13, LEAN>(buf, Nc, M, ts, mg, tw, lane, PSH); break;
             default:                 // radix 16 (the lean instance's schedules stop at radix 8)
-                if constexpr (!LEAN) dif_pass<16, LEAN>(buf, Nc, M, ts, mg, tw, lane);
+                if constexpr (!LEAN) dif_pass<16, LEAN>(buf, Nc, M, ts, mg, tw, lane, PSH);
                 break;
         }
         wsync();
@@ -315,7 +320,8 @@ __device__ __forceinline__ void magnitudes_inplace(const PlanDev &P, const doubl
 // load + normalise one frame into buf; even windows fetch two consecutive samples per load (element alignment only);
 // four loads in flight per lane
 template <typename T>
-__device__ __forceinline__ void frame_load_pairs(const PlanDev &P, const T *__restrict__ x, ClipNorm nm, double2 *buf, int lane) {
+__device__ __forceinline__ void frame_load_pairs(const PlanDev &P, const T *__restrict__ x, ClipNorm nm, double2 *buf, int lane,
+                                                 int psh) {
     const double sc = sample_scale<T>();
     if (P.even) {
         const int Nc = P.Nc;
@@ -326,11 +332,11 @@ __device__ __forceinline__ void frame_load_pairs(const PlanDev &P, const T *__re
             for (int u = 0; u < 4; ++u) q[u] = ct::PairLoad<T>::get(x + 2 * (m + kWave * u));
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                buf[m + kWave * u] = make_double2(fma(q[u].x, sc, -nm.mean) * nm.inv, fma(q[u].y, sc, -nm.mean) * nm.inv);
+                buf[skew(m + kWave * u, psh)] = make_double2(fma(q[u].x, sc, -nm.mean) * nm.inv, fma(q[u].y, sc, -nm.mean) * nm.inv);
         }
         for (; m < Nc; m += kWave) {
             const double2 q = ct::PairLoad<T>::get(x + 2 * m);
-            buf[m] = make_double2(fma(q.x, sc, -nm.mean) * nm.inv, fma(q.y, sc, -nm.mean) * nm.inv);
+            buf[skew(m, psh)] = make_double2(fma(q.x, sc, -nm.mean) * nm.inv, fma(q.y, sc, -nm.mean) * nm.inv);
         }
     } else {
         const int W = P.W;
@@ -340,9 +346,9 @@ __device__ __forceinline__ void frame_load_pairs(const PlanDev &P, const T *__re
 #pragma unroll
             for (int u = 0; u < 4; ++u) q[u] = load_sample<T>(x + n + kWave * u);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) buf[n + kWave * u] = make_double2(fma(q[u], sc, -nm.mean) * nm.inv, 0.0);
+            for (int u = 0; u < 4; ++u) buf[skew(n + kWave * u, psh)] = make_double2(fma(q[u], sc, -nm.mean) * nm.inv, 0.0);
         }
-        for (; n < W; n += kWave) buf[n] = make_double2(fma(load_sample<T>(x + n), sc, -nm.mean) * nm.inv, 0.0);
+        for (; n < W; n += kWave) buf[skew(n, psh)] = make_double2(fma(load_sample<T>(x + n), sc, -nm.mean) * nm.inv, 0.0);
     }
     wsync();
 }
@@ -411,8 +417,12 @@ __device__ __forceinline__ double chroma_class_batched(const Tabs &tb, const dou
 }
 
 // zcr count, energy and energy entropy of the normalised frame in LDS (ShortTermFeatures.py:22-51)
-__device__ __forceinline__ TimeFeat time_features_chunked(const PlanDev &P, const double2 *buf, const Chunk &ch, int lane) {
-    const int W = P.W, st = P.even ? 1 : 2;                 // odd windows: y[n] = buf[n].x
+__device__ __forceinline__ TimeFeat time_features_chunked(const PlanDev &P, const double2 *buf, const Chunk &ch, int lane,
+                                                          int psh) {
+    const int W = P.W, even = P.even;
+    // sample n: even windows pack two per complex slot (slot n / 2, half n & 1), odd windows one (real part); slots skewed
+    auto at = [&](int n) { return even ? 2 * skew(n >> 1, psh) + (n & 1) : 2 * skew(n, psh); };
+    (void)W;
     const double *y = reinterpret_cast<const double *>(buf);
     double ea = 0.0, eb = 0.0;
     int zc = 0;
@@ -421,7 +431,7 @@ __device__ __forceinline__ TimeFeat time_features_chunked(const PlanDev &P, cons
         const int hi = __double2hiint(x), lo = __double2loint(x);
         return (((hi & 0x7fffffff) | lo) != 0) ? ((hi >> 31) | 1) : 0;
     };
-    int sprev = sgn(y[max(ch.kb - 1, 0) * st]);            // (lane 0: sample 0 against itself counts nothing)
+    int sprev = sgn(y[at(max(ch.kb - 1, 0))]);             // (lane 0: sample 0 against itself counts nothing)
     auto one = [&](int n, double x) {
         const double sq = x * x;
         const double sa = (n < ch.bound) ? sq : 0.0;
@@ -435,11 +445,11 @@ __device__ __forceinline__ TimeFeat time_features_chunked(const PlanDev &P, cons
     for (; i + 4 <= ch.base; i += 4) {
         double v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = y[(ch.kb + i + u) * st];
+        for (int u = 0; u < 4; ++u) v[u] = y[at(ch.kb + i + u)];
 #pragma unroll
         for (int u = 0; u < 4; ++u) one(ch.kb + i + u, v[u]);
     }
-    for (int n = ch.kb + i; n < ch.ke; ++n) one(n, y[n * st]);
+    for (int n = ch.kb + i; n < ch.ke; ++n) one(n, y[at(n)]);
     double eblk[10], e_tail;
     block_sums(ch, ea, eb, eblk, e_tail);
     TimeFeat tf;
@@ -653,7 +663,9 @@ inline int mix_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
     };
     set_passes();
     L.unit_bytes = (Nf * 8 + 15) / 16 * 16;
-    L.buf_bytes = Nc * 16;
+    // (the skew is an instance of the kernel: it is decided with the lean instance below; room for it is reserved here)
+    L.pad_shift = (Nc % 32 == 0 && !getenv("PAA_MIX_NO_SKEW")) ? 5 : 31;
+    L.buf_bytes = (Nc + (Nc >> L.pad_shift)) * 16;
     const int FF = F > 0 ? F : 1;
     L.wave_bytes = (L.buf_bytes + L.unit_bytes + kFlush * FF * 8 + 48 * 8 + 40 * 8 + 15) / 16 * 16;
     const size_t n_melw = mel ? mel->w.size() : 0, n_ch = chroma ? chroma->src.size() : 0;
@@ -708,6 +720,8 @@ inline int mix_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
     }
     std::vector<unsigned short> perm;
     mix_permutation(Nc, radix, perm);
+    if (L.lean && L.pad_shift == 5)
+        for (auto &pp : perm) pp = (unsigned short)(pp + (pp >> 5));      // positions in the skewed buffer
     memcpy(b + L.off_perm, perm.data(), (size_t)Nc * 2);
     if (mel && !mel->w.empty()) {
         memcpy(b + L.off_mello, mel->lo.data(), 40 * 4);
@@ -758,6 +772,7 @@ __global__ __launch_bounds__(LEAN ? 512 : 256) void st_mix_kernel(PlanDev P, Mix
     tb.ch_src = reinterpret_cast<const int *>(smem + L.off_chsrc);
     tb.ch_w = reinterpret_cast<const double *>(smem + L.off_chw);
 
+    constexpr int PSH = (LEAN == 2) ? 5 : -1;       // instance 2: lean + skewed FFT buffer
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int tile_id = blockIdx.x * L.waves + wave;
     if (tile_id >= n_tiles) return;
@@ -788,12 +803,12 @@ __global__ __launch_bounds__(LEAN ? 512 : 256) void st_mix_kernel(PlanDev P, Mix
         double *cur = reinterpret_cast<double *>(wb + (odd ? L.buf_bytes : 0));
         double *prv = reinterpret_cast<double *>(wb + (odd ? 0 : L.buf_bytes));
         const T *x = x0 + (long long)t * P.S;
-        frame_load_pairs<T>(P, x, nm, buf, lane);
+        frame_load_pairs<T>(P, x, nm, buf, lane, PSH);
         PAA_TICK(0)
         const bool want = (P.mode == 0) && ((t >= tl.t0) || (P.deltas && t == tl.t0 - 1));
         TimeFeat tf;
         tf.e_tot = 0.0; tf.ent_e = 0.0; tf.zc = 0;
-        if (want) tf = time_features_chunked(P, buf, ch_t, lane);
+        if (want) tf = time_features_chunked(P, buf, ch_t, lane, PSH);
         int touched = 0;
         if (t + 1 < tend) {
             // pull the next frame's new samples (the S behind this frame's end) towards the L2 / L1 now: their latency then

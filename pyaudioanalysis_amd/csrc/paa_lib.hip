@@ -656,6 +656,8 @@ static int launch_mix(paa_plan *p, const void *d_packed, double *d_out) {
 }
 template <typename T>
 static int launch_mix_any(paa_plan *p, const void *d_packed, double *d_out) {
+    if (p->ml.lean && p->ml.pad_shift == 5)
+        return p->ml.tw_global ? launch_mix<T, 1, 2>(p, d_packed, d_out) : launch_mix<T, 0, 2>(p, d_packed, d_out);
     if (p->ml.lean)
         return p->ml.tw_global ? launch_mix<T, 1, 1>(p, d_packed, d_out) : launch_mix<T, 0, 1>(p, d_packed, d_out);
     return p->ml.tw_global ? launch_mix<T, 1, 0>(p, d_packed, d_out) : launch_mix<T, 0, 0>(p, d_packed, d_out);
