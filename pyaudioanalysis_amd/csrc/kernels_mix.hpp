@@ -159,8 +159,12 @@ template <> struct Bfly<16> {          // the 4 x 4 codelet of the 800-sample ke
 template <int R, int U>
 __device__ __forceinline__ void dif_batch(double2 *buf, int nb, int stride, int M, int tws, unsigned magic,
                                           const double2 *__restrict__ tw, int b0, int psh) {
-    double2 v[U][R], w[U][R];
-    int base[U];
+    // radix <= 8: the twiddles are requested together with the operands; the radix-11 / 13 / 16 butterflies keep their
+    // R operands and the codelet's temporaries live, so their twiddles come AFTER the codelet, eight at a time (all of them
+    // up front spilled 19 registers in the instance that reads them from global memory)
+    constexpr bool LATE = R > 8;
+    double2 v[U][R], w[U][LATE ? 1 : R];
+    int base[U], t1[U];
     bool act[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -170,20 +174,33 @@ __device__ __forceinline__ void dif_batch(double2 *buf, int nb, int stride, int 
         const int blk = (stride == 1) ? be : (int)__umulhi((unsigned)be, magic);
         const int k = be - __mul24(blk, stride);                  // (all indices < 2^16: 24-bit multiplies are full rate)
         base[u] = __mul24(blk, M) + k;
+        t1[u] = __mul24(k, tws);
 #pragma unroll
         for (int r = 0; r < R; ++r) v[u][r] = buf[skew(base[u] + r * stride, psh)];
-        if (stride > 1) {
-            const int t1 = __mul24(k, tws);
+        if (!LATE && stride > 1) {
 #pragma unroll
-            for (int q = 1; q < R; ++q) w[u][q] = tw[q * t1];
+            for (int q = 1; q < R; ++q) w[u][LATE ? 0 : q] = tw[q * t1[u]];
         }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         Bfly<R>::run(v[u]);
         if (stride > 1) {
+            if (LATE) {
 #pragma unroll
-            for (int q = 1; q < R; ++q) v[u][Bfly<R>::pos(q)] = cmul(v[u][Bfly<R>::pos(q)], w[u][q]);
+                for (int q0 = 1; q0 < R; q0 += 8) {
+                    double2 wl[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (q0 + j < R) wl[j] = tw[(q0 + j) * t1[u]];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (q0 + j < R) v[u][Bfly<R>::pos(q0 + j)] = cmul(v[u][Bfly<R>::pos(q0 + j)], wl[j]);
+                }
+            } else {
+#pragma unroll
+                for (int q = 1; q < R; ++q) v[u][Bfly<R>::pos(q)] = cmul(v[u][Bfly<R>::pos(q)], w[u][LATE ? 0 : q]);
+            }
         }
     }
 #pragma unroll
