@@ -48,7 +48,23 @@ for seed in range(first, first + n):
         assert_parity(got, ref, "seed %d" % seed, O.ill_conditioned_mfcc_frames(ref_in, fs, window, step))
     except Exception as exc:
         bad.append((seed, kname, fs, window, step, kind, repr(exc)[:160]))
+    if seed % 3 == 0:               # spectrogram / chromagram rows of the same clip (modes 1 / 2 of the same kernels)
+        import contextlib, io
+        try:
+            try:
+                sref = O.spectrogram(ref_in, fs, window, step)[0]
+                cref = O.chromagram(ref_in, fs, window, step)[0]
+            except (ValueError, IndexError):
+                continue
+            with contextlib.redirect_stdout(io.StringIO()):
+                sg = ShortTermFeatures.spectrogram(sig, fs, window, step)[0]
+            cg = ShortTermFeatures.chromagram(sig, fs, window, step)[0]
+            kernels["rows:" + kname] += 1
+            assert_parity(np.ascontiguousarray(sg.T), np.ascontiguousarray(sref.T), "spectrogram seed %d" % seed)
+            assert_parity(np.ascontiguousarray(cg.T), np.ascontiguousarray(cref.T), "chromagram seed %d" % seed)
+        except Exception as exc:
+            bad.append((seed, "rows:" + kname, fs, window, step, kind, repr(exc)[:160]))
 print("kernels:", dict(kernels))
-print("failures:", len(bad))
+print("failures:", len(bad), dict(collections.Counter(b[1] for b in bad)))
 for b in bad[:20]:
     print("  ", b)
