@@ -71,6 +71,7 @@ SHAPES = {
     "w2400": (48000, 2400, 1200, 1200, 1, 0, 0, 0),                # 50 ms at 48 kHz
     "w2205": (44100, 2205, 1102, 1200, 1, 0, 0, 0),                # 50 ms at 44.1 kHz (odd window)
     "mid_stats": (16000, 800, 400, 30, 1000, 0, 0, 1),
+    "big_16000": (16000, 16000, 8000, 600, 1, 0, 0, 0),            # music_thumbnailing's 1 s window (audioSegmentation.py:1137)
 }
 SAMPLE_BYTES = {0: 2, 1: 8, 2: 4}
 
