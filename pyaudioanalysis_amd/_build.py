@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpaa_hip.so")
 SOURCES = ["paa_lib.hip"]
 HEADERS = ["device_common.hpp", "kernels_generic.hpp", "kernels_fast.hpp", "kernels_aux.hpp",
-           "kernels_tail.hpp", "kernels_big.hpp", "kernels_ct.hpp", "kernels_mix.hpp", "kernels_sim.hpp", "kernels_reg.hpp", "kernels_svm.hpp", "comm_rccl.hpp", "tables.hpp", os.path.join("..", "..", "include", "paa_hip.h")]
+           "kernels_tail.hpp", "kernels_big.hpp", "kernels_ct.hpp", "kernels_mix.hpp", "kernels_tri.hpp", "kernels_sim.hpp", "kernels_reg.hpp", "kernels_svm.hpp", "comm_rccl.hpp", "tables.hpp", os.path.join("..", "..", "include", "paa_hip.h")]
 
 
 def hipcc_path():

@@ -805,6 +805,7 @@ inline int ct_select(int window, int mode, double fs, const FftPlan &fft, const 
     return 1;
 }
 
+#ifndef PAA_NO_HOST_LAUNCHERS
 template <typename SH, typename T, int MODE, int DELTAS, int NW>
 inline int ct_launch_one(const CtLaunch &cl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                          const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
@@ -855,6 +856,8 @@ inline int ct_launch(const CtLaunch &cl, int sample_kind, const PlanDev &P, cons
     if (sample_kind == 2) return ct_launch_shape<stereo16>(cl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
     return ct_launch_shape<double>(cl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
 }
+
+#endif  // PAA_NO_HOST_LAUNCHERS
 
 }  // namespace ct
 }  // namespace paa

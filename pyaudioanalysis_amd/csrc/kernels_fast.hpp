@@ -1059,6 +1059,7 @@ inline int fast_select(int window, int step, int sample_kind, double fs, FastTab
     return 1;
 }
 
+#ifndef PAA_NO_HOST_LAUNCHERS      // (development builds of a single kernel family skip the other families' instantiations)
 template <int S, int DELTAS, int FIXED, int NW>
 inline int fast_launch_one(const FastLaunch &fl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                            const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,
@@ -1100,4 +1101,5 @@ inline int fast_launch(const FastLaunch &fl, const PlanDev &P, const FastTables 
     return -1;
 }
 
+#endif  // PAA_NO_HOST_LAUNCHERS
 }  // namespace paa

@@ -1,0 +1,765 @@
+// Three-pass register-FFT feature kernels for the LARGE windows the reference uses by default at 44.1 / 48 kHz
+// (50 ms = 2205 / 2400 samples, audioTrainTest.py:28-29, audioAnalysis.py:46; 40 ms = 1764 / 1920, audioAnalysis.py:71,80):
+// any step, int16 / interleaved stereo int16 / float64 samples, features / spectrogram / chromagram.
+//
+// One wave = one run of consecutive frames of one clip, ONE frame per iteration with all 64 lanes on it.  The frame never
+// sits in LDS as a complex buffer: the transform of length N = R1 R2 R3 runs in registers, and the data moves between the
+// passes through ONE plane of doubles (real parts, then imaginary parts) that is the frame's own spectrum slot:
+//
+//   load    : lane j (< L1 = R2 R3, one or two "jobs" per lane) fetches z[j + L1 r], r < R1, straight from HBM / L2 (per load
+//             instruction the lanes read one contiguous span) and removes the clip mean.  Even windows are packed two real
+//             samples per complex point (N = W / 2, PairLoad); odd windows run a REAL-input transform of length N = W whose
+//             first pass only produces the (R1 + 1) / 2 non-redundant outputs -- half the work of the complex transform the
+//             mixed-radix kernel (kernels_mix.hpp) spends on them
+//   time    : the same registers give energy, the ten entropy-block energies and the sign changes (block membership is
+//             static per register row; the sample before a lane's first one is in the lane below: DPP wave_shr:1)
+//   pass 1  : radix-R1 codelet per job, outputs times W_N^(j q1) (table in global memory: L1 / L2 hits)
+//   exchange: element (j, q1) at plane[q1 P + j]
+//   pass 2  : lane (q1, b): radix-R2 over a of B[R3 a + b][q1], outputs times W_L1^(b q2)
+//   exchange: element (q1, b, q2) at plane[q1 P + q2 R3 + b]
+//   pass 3  : radix-R3 over b for job (q1, q2): Z[q1 + R1 (q2 + R2 k3)].  Packed windows: a lane takes a PAIR of jobs whose
+//             outputs are Z[k] and Z[N - k], so the real-FFT recombination and |X| happen in registers; real-input windows:
+//             |Z[k]| goes to bin k or N - k.  The magnitudes overwrite the plane: it becomes the frame's spectrum.
+//   features: kernels_mix.hpp's spectral stage on the two spectrum slots (current / previous frame alternate)
+//   store   : lane = feature row; a row's values wait in eight registers until a 64-byte aligned chunk is complete, which
+//             is stored whole and non-temporally (kernels_fast.hpp: store_chunk_pieces)
+//
+// Per-wave LDS: two spectrum slots + 0.7 KB (window 2400: 19.9 KB against the 34 KB of the in-place transform), so SEVEN
+// or EIGHT waves share a CU -- two per SIMD -- and every kernel instance stays below 256 registers.
+// The codelets keep the property that R equal inputs give exact zeros in the non-DC outputs (device_common.hpp: dft5), so a
+// digitally silent frame has the exact spectrum [2 |c|, 0, 0, ...] the reference's pocketfft produces.
+//
+// Replaces the while loop at ShortTermFeatures.py:608-682 (+ helpers :22-140, :236-321) and the loops of spectrogram
+// (:415-422) / chromagram (:349-359) for these windows.
+#pragma once
+#include <algorithm>
+#include <vector>
+
+#include "kernels_mix.hpp"
+
+namespace paa {
+namespace tri {
+#if defined(PAA_F800_TIMING) || defined(PAA_F800_TRACE)
+using f800::g_phase_cycles;
+using f800::g_wave_trace;
+#endif
+
+// ---- shapes ---------------------------------------------------------------------------------------------------
+// number of pass-3 lane jobs of a packed shape: unordered pairs {job, partner job}, job (q1, q2) <-> Z[q1 + R1 q2 + ...]
+constexpr int pair_count(int R1, int R2, int R3) {
+    const int N = R1 * R2 * R3;
+    int pairs = 0;
+    for (int q1 = 0; q1 < R1; ++q1)
+        for (int q2 = 0; q2 < R2; ++q2) {
+            const int k = q1 + R1 * q2, m = (N - k) % N;
+            const int p1 = m % R1, p2 = (m / R1) % R2;
+            if (p1 > q1 || (p1 == q1 && p2 >= q2)) ++pairs;         // count each unordered pair once
+        }
+    return pairs;
+}
+
+template <int R1_, int R2_, int R3_, bool PACKED_, int P_, int NW_>
+struct Shape {
+    static constexpr int R1 = R1_, R2 = R2_, R3 = R3_, P = P_, NW = NW_;
+    static constexpr bool PACKED = PACKED_;
+    static constexpr int N = R1 * R2 * R3;                  // transform length
+    static constexpr int W = PACKED ? 2 * N : N, NF = W / 2;
+    static constexpr int L1 = R2 * R3;                      // pass-1 jobs
+    static constexpr int NQ1 = PACKED ? R1 : (R1 + 1) / 2;  // pass-1 outputs that are needed
+    static constexpr int NJ = (L1 + 63) / 64;               // pass-1 jobs per lane
+    static constexpr int J2 = NQ1 * R3;                     // pass-2 jobs (one per lane)
+    static constexpr int NJOB3 = PACKED ? pair_count(R1, R2, R3) : NQ1 * R2;
+    static constexpr int NR3 = (NJOB3 + 63) / 64;           // pass-3 rounds
+    static constexpr int PLANE = NQ1 * P;
+    static constexpr int SLOT = ((PLANE > NF ? PLANE : NF) + 1) & ~1;      // doubles per spectrum slot
+    static constexpr int LT = W / 10, LB = NF / 10;         // entropy blocks (samples / bins)
+    static constexpr int SPL = PACKED ? 2 : 1;              // samples per loaded element
+    static constexpr int WAVE_DOUBLES = 2 * SLOT + 48 + 40; // two slots, fv[48], msp[40]
+    static_assert(P >= L1, "plane rows hold L1 elements");
+    static_assert(J2 <= 64, "one pass-2 job per lane");
+    static_assert(!PACKED || NJ == 1, "packed shapes: one pass-1 job per lane");
+    static_assert(PACKED || (R1 % 2 == 1), "real-input shapes: odd first radix");
+    static_assert(64 * SPL <= LT, "a register row may contain at most one entropy-block boundary");
+    static_assert(NF >= 64 * 10, "spectral chunks: at most two entropy blocks per lane (kernels_mix.hpp)");
+};
+
+// shared (per workgroup) LDS tables + the global tables behind them in the same device blob
+struct TriLayout {
+    int off_tw2;                    // double2 [R2][R3]: W_L1^(b q2)
+    int off_p3;                     // packed: ushort4 [64 NR3]: plane offset of job A, of job B, first bin kA, flags
+    int off_mello, off_melcnt, off_meloff, off_melw, off_dct, off_chstart, off_chsrc, off_chw;
+    int table_bytes;                // LDS part, multiple of 16
+    int off_g_tw1;                  // global part: double2 [NQ1][L1]: W_N^(j q1)
+    int off_g_post;                 // packed: double2 [64 NR3][R3]: W_W^(kA + N3 k3)
+    int total_bytes;
+};
+
+// ---- codelets: run() transforms v[] in place, X[q] ends at v[pos(q)] ------------------------------------------------
+template <int R> struct Cd;
+template <> struct Cd<2> {
+    static __device__ __forceinline__ void run(double2 *v) { dft2(v); }
+    static constexpr int pos(int q) { return q; }
+};
+template <> struct Cd<3> {
+    static __device__ __forceinline__ void run(double2 *v) { dft3(v); }
+    static constexpr int pos(int q) { return q; }
+};
+template <> struct Cd<5> {
+    static __device__ __forceinline__ void run(double2 *v) { dft5(v); }
+    static constexpr int pos(int q) { return q; }
+};
+template <> struct Cd<16> {
+    static __device__ __forceinline__ void run(double2 *v) { ct::Dft<16>::run<1>(v); }
+    static constexpr int pos(int q) { return ct::Dft<16>::pos(q); }
+};
+template <> struct Cd<20> {
+    static __device__ __forceinline__ void run(double2 *v) { ct::Dft<20>::run<1>(v); }
+    static constexpr int pos(int q) { return ct::Dft<20>::pos(q); }
+};
+// 21 = 3 x 7, coprime: prime-factor transform, no twiddles.  Element (n1, n2) sits at v[(7 n1 + 3 n2) % 21] (= natural order);
+// X[q] ends at v[(7 (q % 3) + 3 (q % 7)) % 21].
+template <> struct Cd<21> {
+    static __device__ __forceinline__ void run(double2 *v) {
+#pragma unroll
+        for (int n2 = 0; n2 < 7; ++n2) {
+            double2 t[3] = {v[(3 * n2) % 21], v[(7 + 3 * n2) % 21], v[(14 + 3 * n2) % 21]};
+            dft3(t);
+            v[(3 * n2) % 21] = t[0]; v[(7 + 3 * n2) % 21] = t[1]; v[(14 + 3 * n2) % 21] = t[2];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < 3; ++k1) {
+            double2 t[7];
+#pragma unroll
+            for (int n2 = 0; n2 < 7; ++n2) t[n2] = v[(7 * k1 + 3 * n2) % 21];
+            mix::dft_prime<7>(t);
+#pragma unroll
+            for (int n2 = 0; n2 < 7; ++n2) v[(7 * k1 + 3 * n2) % 21] = t[n2];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    static constexpr int pos(int q) { return (7 * (q % 3) + 3 * (q % 7)) % 21; }
+};
+
+// real-input first pass: x[R] real (natural order) -> a[q] = X[q], q = 0 .. (R - 1) / 2 (the rest are conjugates)
+template <int R> struct RCd;
+// three real inputs: X0 = a + b + c (real), X1 = (a - (b + c) / 2) - i h (b - c); equal inputs give X1 = 0 exactly
+__device__ __forceinline__ void rdft3(double a, double b, double c, double &s0, double2 &x1) {
+    const double h = 0.86602540378443864676;
+    const double t = b + c;
+    s0 = a + t;
+    x1 = make_double2(fma(-0.5, t, a), -(h * (b - c)));
+}
+// seven real inputs -> y[0] (real) .. y[3]; the pivot form of mix::dft_prime (equal inputs: exact zeros in y[1..3])
+__device__ __forceinline__ void rdft7(const double *s, double2 *y) {
+    typedef mix::PrimeTab<7> TB;
+    const double sm1 = s[1] + s[6], sm2 = s[2] + s[5], sm3 = s[3] + s[4];
+    const double df1 = s[1] - s[6], df2 = s[2] - s[5], df3 = s[3] - s[4];
+    const double tot = ((s[0] + sm1) + sm2) + sm3;
+    const double base = fma(-0.5, sm3, s[0]);
+    const double rel1 = sm1 - sm3, rel2 = sm2 - sm3;
+    y[0] = make_double2(tot, 0.0);
+#pragma unroll
+    for (int q = 1; q <= 3; ++q) {
+        double ar = base, br = 0.0;
+        ar = fma(TB::c[(1 * q) % 7], rel1, ar);
+        ar = fma(TB::c[(2 * q) % 7], rel2, ar);
+        br = fma(TB::s[(1 * q) % 7], df1, br);
+        br = fma(TB::s[(2 * q) % 7], df2, br);
+        br = fma(TB::s[(3 * q) % 7], df3, br);
+        y[q] = make_double2(ar, -br);                    // X[q] = A - i B
+    }
+}
+template <> struct RCd<21> {
+    static __device__ __forceinline__ void run(const double *x, double2 *a) {
+        double s0[7];
+        double2 c1[7];
+#pragma unroll
+        for (int n2 = 0; n2 < 7; ++n2) rdft3(x[(3 * n2) % 21], x[(7 + 3 * n2) % 21], x[(14 + 3 * n2) % 21], s0[n2], c1[n2]);
+        __builtin_amdgcn_sched_barrier(0);
+        double2 y0[4];
+        rdft7(s0, y0);                                   // k1 = 0: real radix 7
+        __builtin_amdgcn_sched_barrier(0);
+        mix::dft_prime<7>(c1);                           // k1 = 1: complex radix 7 (k1 = 2 is its conjugate, mirrored)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 11; ++q) {
+            const int k1 = q % 3, k2 = q % 7;
+            if (k1 == 0) a[q] = (k2 <= 3) ? y0[k2] : make_double2(y0[7 - k2].x, -y0[7 - k2].y);
+            else if (k1 == 1) a[q] = c1[k2];
+            else a[q] = make_double2(c1[(7 - k2) % 7].x, -c1[(7 - k2) % 7].y);
+        }
+    }
+};
+
+// lane l receives the value of lane l - 1 (lane 0: `first`)
+__device__ __forceinline__ int wave_shr1(int v, int first) {
+    return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xF, 0xF, false);       // wave_shr:1
+}
+// np.sign from the bit pattern: 0 for +-0, else +-1
+__device__ __forceinline__ int sgn_bits(double x) {
+    const int hi = __double2hiint(x), lo = __double2loint(x);
+    return (((hi & 0x7fffffff) | lo) != 0) ? ((hi >> 31) | 1) : 0;
+}
+
+// a feature row's pending values: h[i] = the frame at position i of the row's current 64-byte chunk
+struct RowChunk {
+    double h[8];
+};
+// frame t of the row starting at `row` (frames [lo, hi) are this wave's): insert, store the chunk when it is complete or
+// the run ends
+__device__ __forceinline__ void row_put(RowChunk &rc, double *row, int t, int lo, int hi, double v) {
+    const int a = (int)(((reinterpret_cast<uintptr_t>(row) >> 3) + (unsigned)t) & 7);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rc.h[i] = (a == i) ? v : rc.h[i];
+    const bool last = (t == hi - 1);
+    if (a == 7 || last) {
+        const int g = t - a;                               // first frame of the chunk
+        f800::store_chunk_pieces(row + g, rc.h, lo - g, (a == 7) ? 8 : a + 1);
+    }
+}
+
+
+// MODE 0: short-term features (DELTAS: 68 rows), 1: spectrogram rows, 2: chromagram rows
+template <typename SH, typename T, int MODE, int DELTAS>
+__global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(PlanDev P, TriLayout L,
+                                                                               const unsigned char *__restrict__ blob,
+                                                                               const T *__restrict__ sig,
+                                                                               const ClipDev *__restrict__ clips,
+                                                                               const ClipNorm *__restrict__ norms,
+                                                                               const Tile *__restrict__ tiles, int n_tiles,
+                                                                               double *__restrict__ out) {
+    constexpr int R1 = SH::R1, R2 = SH::R2, R3 = SH::R3, N = SH::N, W = SH::W, NF = SH::NF, L1 = SH::L1, NQ1 = SH::NQ1;
+    constexpr int NJ = SH::NJ, J2 = SH::J2, NR3 = SH::NR3, PP = SH::P, SLOT = SH::SLOT, LT = SH::LT;
+    constexpr int NW = SH::NW, N3 = R1 * R2;
+    constexpr bool PACKED = SH::PACKED;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    {
+        const int4 *src4 = reinterpret_cast<const int4 *>(blob);
+        int4 *dst4 = reinterpret_cast<int4 *>(smem);
+        for (int n = threadIdx.x; n < L.table_bytes / 16; n += 64 * NW) dst4[n] = src4[n];
+    }
+    __syncthreads();       // the only workgroup-wide barrier
+    Tabs tb;
+    tb.tw = nullptr; tb.post = nullptr;
+    tb.mel_lo = reinterpret_cast<const int *>(smem + L.off_mello);
+    tb.mel_cnt = reinterpret_cast<const int *>(smem + L.off_melcnt);
+    tb.mel_off = reinterpret_cast<const int *>(smem + L.off_meloff);
+    tb.mel_w = reinterpret_cast<const double *>(smem + L.off_melw);
+    tb.dct = reinterpret_cast<const double *>(smem + L.off_dct);
+    tb.dct_stride = 41;
+    tb.ch_start = reinterpret_cast<const int *>(smem + L.off_chstart);
+    tb.ch_src = reinterpret_cast<const int *>(smem + L.off_chsrc);
+    tb.ch_w = reinterpret_cast<const double *>(smem + L.off_chw);
+    const double2 *t_tw2 = reinterpret_cast<const double2 *>(smem + L.off_tw2);
+    const ushort4 *t_p3 = reinterpret_cast<const ushort4 *>(smem + L.off_p3);
+    const double2 *g_tw1 = reinterpret_cast<const double2 *>(blob + L.off_g_tw1);
+    const double2 *g_post = reinterpret_cast<const double2 *>(blob + L.off_g_post);
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile_id = blockIdx.x * NW + wave;
+    if (tile_id >= n_tiles) return;
+    double *slots = reinterpret_cast<double *>(smem + L.table_bytes) + (size_t)wave * SH::WAVE_DOUBLES;
+    double *fv = slots + 2 * SLOT;
+    double *msp = fv + 48;
+
+    const Tile tl = tiles[tile_id];
+    const ClipDev c = clips[tl.clip];
+    const ClipNorm nm = norms[tl.clip];
+    const T *x0 = sig + c.sample_off + P.frame_origin;
+    const long long Tc = c.T;
+    double *oc = out + c.out_off;
+    const double sc = sample_scale<T>();
+    const double mean = nm.mean, inv = nm.inv;
+    const double mscale = (PACKED ? 0.5 : 1.0) * inv / (double)NF;       // X / len(X) (:621); y = d * inv; E, O carry 1/2
+
+    const int hneed = (MODE == 0) ? (DELTAS ? 2 : 1) : 0;
+    const int h = min(hneed, tl.t0);
+    const int tend = tl.t0 + tl.cnt;
+    double vprev = 0.0;
+    int odd = 0;
+    RowChunk rc, rcd;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { rc.h[i] = 0.0; rcd.h[i] = 0.0; }
+    const int lane_id = threadIdx.x & 63;
+    PAA_T0()
+    for (int t = tl.t0 - h; t < tend; ++t, odd ^= 1) {
+        // everything derived from the lane number is recomputed per frame: hoisted out of the loop, the per-lane plane
+        // addresses and table pointers of all passes are some 60 loop-invariant registers (they ended up in scratch)
+        int lane = lane_id;
+        asm volatile("" : "+v"(lane));
+        const mix::Chunk ch_f = mix::make_chunk(NF, P.blk_f, lane);
+        // pass-2 job of this lane: (q1, b); idle lanes shadow the last job (their plane writes are masked)
+        const int m2 = min(lane, J2 - 1);
+        const int q1_2 = m2 / R3, b_2 = m2 - R3 * q1_2;
+        const bool act2 = lane < J2;
+        double *cur = slots + (odd ? SLOT : 0);
+        const double *prv = slots + (odd ? 0 : SLOT);
+        const T *xf = x0 + (long long)t * P.S;
+        const bool want = (MODE == 0) && ((t >= tl.t0) || (DELTAS && t == tl.t0 - 1));
+
+        // ---------------- load, time domain (ShortTermFeatures.py:22-51), pass 1: a[u][q1] = A_j[q1] W_N^(j q1), j = lane + 64 u
+        double2 a[NJ][NQ1];
+        TimeFeat tf;
+        tf.e_tot = 0.0; tf.ent_e = 0.0; tf.zc = 0;
+        {
+            double eb[11];                 // ten entropy blocks + the tail the reference leaves out of them (:37-41)
+#pragma unroll
+            for (int b = 0; b < 11; ++b) eb[b] = 0.0;
+            int zc = 0, carry = 0;
+            // wave totals of the partials (before pass 1: the partials' registers are free for the codelets)
+            auto finish_time = [&]() {
+                if (MODE == 0 && want) {
+                    const double inv2 = inv * inv;         // y = d * inv: energies scale by inv^2
+                    double tot = 0.0;
+#pragma unroll
+                    for (int b = 0; b < 11; ++b) { eb[b] = wsum(eb[b]) * inv2; tot += eb[b]; }
+                    tf.e_tot = tot;
+                    tf.zc = wsum_i(zc);
+                    double num = 0.0;
+#pragma unroll
+                    for (int b = 0; b < 10; ++b) num = (lane == b) ? eb[b] : num;
+                    const double s = fast_div(num, tot + kEps);
+                    tf.ent_e = wsum((lane < 10) ? -(s * fast_log2(s + kEps)) : 0.0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if constexpr (PACKED) {
+                static_assert(LT % 2 == 0, "a sample pair lies in one entropy block");
+                const bool act1 = lane < L1;
+                const int jj = act1 ? lane : L1 - 1;
+                double2 v[R1];
+#pragma unroll
+                for (int r = 0; r < R1; ++r) {
+                    const double2 x = ct::PairLoad<T>::get(xf + 2 * (jj + L1 * r));
+                    v[r] = make_double2(fma(x.x, sc, -mean), fma(x.y, sc, -mean));
+                }
+                PAA_TICK(0)
+                if (MODE == 0) {
+#pragma unroll
+                    for (int r = 0; r < R1; ++r) {
+                        const double d0 = v[r].x, d1 = v[r].y;
+                        const double e = act1 ? fma(d0, d0, d1 * d1) : 0.0;
+                        // samples 2 L1 r + 2 lane, + 1: block jlo for lanes below jth, jlo + 1 from there on (static per row)
+                        const int n0 = 2 * L1 * r;
+                        const int jlo = (n0 / LT < 10) ? n0 / LT : 10;
+                        const int jth = (jlo >= 10) ? 64 : ((jlo + 1) * LT - n0) / 2;
+                        if (jth >= L1) {
+                            eb[jlo] += e;
+                        } else {
+                            eb[jlo] += (lane < jth) ? e : 0.0;
+                            eb[jlo + 1] += (lane >= jth) ? e : 0.0;
+                        }
+                        const int sa = sgn_bits(d0), sb = sgn_bits(d1);
+                        if (r == 0) carry = __builtin_amdgcn_readfirstlane(sa);       // the frame's first sample has no left one
+                        const int left = wave_shr1(sb, carry);
+                        const int dz = abs(sb - sa) + abs(sa - left);
+                        zc += act1 ? dz : 0;
+                        carry = __builtin_amdgcn_readlane(sb, L1 - 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                finish_time();
+                PAA_TICK(1)
+                Cd<R1>::run(v);
+#pragma unroll
+                for (int q0 = 0; q0 < R1; q0 += 4) {
+                    double2 wl[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (q0 + k < R1 && q0 + k > 0) wl[k] = g_tw1[(q0 + k) * L1 + jj];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (q0 + k < R1) a[0][q0 + k] = (q0 + k > 0) ? cmul(v[Cd<R1>::pos(q0 + k)], wl[k]) : v[Cd<R1>::pos(0)];
+                    __builtin_amdgcn_sched_barrier(0);      // (all twiddles requested up front cost 80 registers)
+                }
+            } else {
+                double xr[NJ][R1];
+#pragma unroll
+                for (int u = 0; u < NJ; ++u) {
+                    const int j = lane + 64 * u;
+                    const int jj = (j < L1) ? j : L1 - 1;
+#pragma unroll
+                    for (int r = 0; r < R1; ++r) xr[u][r] = fma(load_sample<T>(xf + jj + L1 * r), sc, -mean);
+                }
+                PAA_TICK(0)
+                if (MODE == 0) {
+#pragma unroll
+                    for (int r = 0; r < R1; ++r)
+#pragma unroll
+                        for (int u = 0; u < NJ; ++u) {
+                            const bool act1 = lane + 64 * u < L1;
+                            const double d = xr[u][r];
+                            const double e = act1 ? d * d : 0.0;
+                            const int n0 = L1 * r + 64 * u;                     // sample of lane 0
+                            const int jlo = (n0 / LT < 10) ? n0 / LT : 10;
+                            const int jth = (jlo >= 10) ? 64 : (jlo + 1) * LT - n0;
+                            if (jth >= 64) {
+                                eb[jlo] += e;
+                            } else {
+                                eb[jlo] += (lane < jth) ? e : 0.0;
+                                eb[jlo + 1] += (lane >= jth) ? e : 0.0;
+                            }
+                            const int s = sgn_bits(d);
+                            if (r == 0 && u == 0) carry = __builtin_amdgcn_readfirstlane(s);
+                            const int left = wave_shr1(s, carry);      // sample n - 1: the lane below / the last lane of the slot before
+                            zc += act1 ? abs(s - left) : 0;
+                            carry = __builtin_amdgcn_readlane(s, (L1 - 1 - 64 * u < 63) ? L1 - 1 - 64 * u : 63);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                }
+                finish_time();
+                PAA_TICK(1)
+#pragma unroll
+                for (int u = 0; u < NJ; ++u) {
+                    const int j = lane + 64 * u;
+                    const int jj = (j < L1) ? j : L1 - 1;
+                    RCd<R1>::run(xr[u], a[u]);
+#pragma unroll
+                    for (int q0 = 1; q0 < NQ1; q0 += 4) {
+                        double2 wl[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (q0 + k < NQ1) wl[k] = g_tw1[(q0 + k) * L1 + jj];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (q0 + k < NQ1) a[u][q0 + k] = cmul(a[u][q0 + k], wl[k]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+        PAA_TICK(2)
+        wsync();               // the previous frame's readers of this slot are done
+
+        // ---------------- exchange 1: element (j, q1) at plane[q1 PP + j]; pass-2 lane (q1, b) reads B[R3 a + b][q1]
+        double2 c2[R2];
+        {
+            double *pl = cur;
+#pragma unroll
+            for (int u = 0; u < NJ; ++u)
+                if (lane + 64 * u < L1) {
+#pragma unroll
+                    for (int q = 0; q < NQ1; ++q) pl[q * PP + lane + 64 * u] = a[u][q].x;
+                }
+            wsync();
+#pragma unroll
+            for (int k = 0; k < R2; ++k) c2[k].x = pl[q1_2 * PP + R3 * k + b_2];
+            wsync();
+#pragma unroll
+            for (int u = 0; u < NJ; ++u)
+                if (lane + 64 * u < L1) {
+#pragma unroll
+                    for (int q = 0; q < NQ1; ++q) pl[q * PP + lane + 64 * u] = a[u][q].y;
+                }
+            wsync();
+#pragma unroll
+            for (int k = 0; k < R2; ++k) c2[k].y = pl[q1_2 * PP + R3 * k + b_2];
+            wsync();
+        }
+        PAA_TICK(3)
+        // ---------------- pass 2: radix R2 over a, outputs times W_L1^(b q2)
+        Cd<R2>::run(c2);
+#pragma unroll
+        for (int q0 = 1; q0 < R2; q0 += 4) {
+            double2 wl[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (q0 + k < R2) wl[k] = t_tw2[(q0 + k) * R3 + b_2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (q0 + k < R2) c2[Cd<R2>::pos(q0 + k)] = cmul(c2[Cd<R2>::pos(q0 + k)], wl[k]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        PAA_TICK(4)
+        // ---------------- exchange 2: element (q1, b, q2) at plane[q1 PP + q2 R3 + b]; pass 3 + |X| / num_fft (:617-621)
+        if constexpr (PACKED) {
+            double2 dA[NR3][R3], dB[NR3][R3];
+            ushort4 pe[NR3];
+#pragma unroll
+            for (int u = 0; u < NR3; ++u) pe[u] = t_p3[lane + 64 * u];
+            double *pl = cur;
+            if (act2) {
+#pragma unroll
+                for (int q = 0; q < R2; ++q) pl[q1_2 * PP + q * R3 + b_2] = c2[Cd<R2>::pos(q)].x;
+            }
+            wsync();
+#pragma unroll
+            for (int u = 0; u < NR3; ++u)
+#pragma unroll
+                for (int b = 0; b < R3; ++b) { dA[u][b].x = pl[pe[u].x + b]; dB[u][b].x = pl[pe[u].y + b]; }
+            wsync();
+            if (act2) {
+#pragma unroll
+                for (int q = 0; q < R2; ++q) pl[q1_2 * PP + q * R3 + b_2] = c2[Cd<R2>::pos(q)].y;
+            }
+            wsync();
+#pragma unroll
+            for (int u = 0; u < NR3; ++u)
+#pragma unroll
+                for (int b = 0; b < R3; ++b) { dA[u][b].y = pl[pe[u].x + b]; dB[u][b].y = pl[pe[u].y + b]; }
+            wsync();
+            PAA_TICK(5)
+#pragma unroll
+            for (int u = 0; u < NR3; ++u) {
+                const int flags = pe[u].w, kA = pe[u].z;
+                const bool act3 = (flags & 1) != 0, self = (flags & 2) != 0, is00 = (flags & 4) != 0;
+                double2 pw[R3];
+#pragma unroll
+                for (int k3 = 0; k3 < R3; ++k3) pw[k3] = g_post[(lane + 64 * u) * R3 + k3];
+                Cd<R3>::run(dA[u]);
+                Cd<R3>::run(dB[u]);
+#pragma unroll
+                for (int k3 = 0; k3 < R3; ++k3) {
+                    const double2 zk = dA[u][Cd<R3>::pos(k3)];
+                    const double2 zb = dB[u][Cd<R3>::pos(R3 - 1 - k3)], z0 = dA[u][Cd<R3>::pos((R3 - k3) % R3)];
+                    const double2 zm = make_double2(is00 ? z0.x : zb.x, is00 ? z0.y : zb.y);
+                    const int k = kA + N3 * k3;
+                    // 2E = Z[k] + conj Z[N-k],  2O = -i (Z[k] - conj Z[N-k]);  X[k] = E + w^k O,  X[N-k] = conj(E - w^k O)
+                    const double2 e = make_double2(zk.x + zm.x, zk.y - zm.y);
+                    const double2 o = make_double2(zk.y + zm.y, zm.x - zk.x);
+                    const double2 wo = cmul(pw[k3], o);
+                    const double xr_ = e.x + wo.x, xi_ = e.y + wo.y, yr_ = e.x - wo.x, yi_ = e.y - wo.y;
+                    const double mk = mag_sqrt(fma(xr_, xr_, xi_ * xi_)) * mscale;
+                    const double mm = mag_sqrt(fma(yr_, yr_, yi_ * yi_)) * mscale;
+                    // a self-paired job meets each of its pairs {k, N - k} twice: the smaller index writes
+                    const bool st1 = act3 && (!self || 2 * k <= N);
+                    const bool st2 = act3 && (k != 0) && (!self || 2 * k < N);
+                    if (st1) cur[k] = mk;
+                    if (st2) cur[N - k] = mm;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            double2 d3[NR3][R3];
+            int q1_3[NR3], q2_3[NR3];
+#pragma unroll
+            for (int u = 0; u < NR3; ++u) {
+                const int m3 = (lane + 64 * u < SH::NJOB3) ? lane + 64 * u : 0;
+                q1_3[u] = m3 / R2;
+                q2_3[u] = m3 - R2 * q1_3[u];
+            }
+            double *pl = cur;
+            if (act2) {
+#pragma unroll
+                for (int q = 0; q < R2; ++q) pl[q1_2 * PP + q * R3 + b_2] = c2[Cd<R2>::pos(q)].x;
+            }
+            wsync();
+#pragma unroll
+            for (int u = 0; u < NR3; ++u)
+#pragma unroll
+                for (int b = 0; b < R3; ++b) d3[u][b].x = pl[q1_3[u] * PP + q2_3[u] * R3 + b];
+            wsync();
+            if (act2) {
+#pragma unroll
+                for (int q = 0; q < R2; ++q) pl[q1_2 * PP + q * R3 + b_2] = c2[Cd<R2>::pos(q)].y;
+            }
+            wsync();
+#pragma unroll
+            for (int u = 0; u < NR3; ++u)
+#pragma unroll
+                for (int b = 0; b < R3; ++b) d3[u][b].y = pl[q1_3[u] * PP + q2_3[u] * R3 + b];
+            wsync();
+            PAA_TICK(5)
+#pragma unroll
+            for (int u = 0; u < NR3; ++u) {
+                const bool act3 = lane + 64 * u < SH::NJOB3;
+                Cd<R3>::run(d3[u]);
+#pragma unroll
+                for (int k3 = 0; k3 < R3; ++k3) {
+                    const double2 z = d3[u][Cd<R3>::pos(k3)];
+                    const double mg = mag_sqrt(fma(z.x, z.x, z.y * z.y)) * mscale;
+                    const int k = q1_3[u] + R1 * (q2_3[u] + R2 * k3);
+                    // bin k, or its mirror N - k (|X[N - k]| = |X[k]| for real input); the jobs with q1 = 0 meet both
+                    if (act3 && k < NF) cur[k] = mg;
+                    else if (act3 && q1_3[u] > 0 && N - k < NF) cur[N - k] = mg;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        wsync();
+        PAA_TICK(6)
+
+        if (MODE == 1) {            // spectrogram row (ShortTermFeatures.py:422)
+            double *row = oc + (long long)t * NF;
+            for (int k = lane; k < NF; k += kWave) __builtin_nontemporal_store(cur[k], row + k);
+        } else if (MODE == 2) {     // chromagram row (:356-359)
+            double p = 0.0;
+            for (int k = lane; k < NF; k += kWave) { const double X = cur[k]; p = fma(X, X, p); }
+            p = wsum(p);
+            const double chv = chroma_class(tb, cur, p, lane);
+            if (lane < 12) oc[(long long)t * 12 + lane] = chv;
+        } else if (want) {
+            mix::frame_features_chunked(P, tb, tf, cur, (t == 0) ? cur : prv, fv, msp, ch_f, lane);
+            PAA_TICK(7)
+            const double v = (lane < kBase) ? fv[lane] : 0.0;
+            if (t >= tl.t0 && lane < kBase) {
+                row_put(rc, oc + (long long)lane * Tc, t, tl.t0, tend, v);
+                if (DELTAS) row_put(rcd, oc + (long long)(kBase + lane) * Tc, t, tl.t0, tend, (t == 0) ? 0.0 : v - vprev);
+            }
+            vprev = v;
+        }
+        wsync();
+        PAA_TICK(10)
+    }
+    {
+        const int lane = lane_id;
+        (void)lane;
+        PAA_TEND()
+    }
+}
+
+// ---- host: shapes, LDS layout + table blob, launch --------------------------------------------------------------------
+typedef Shape<20, 20, 3, true, 60, 7> S2400;        // 50 ms at 48 kHz: 1200 complex points
+typedef Shape<21, 21, 5, false, 105, 7> S2205;      // 50 ms at 44.1 kHz: 2205 real points (odd window)
+
+struct TriLaunch {
+    int shape = -1;                 // 0: 2400, 1: 2205
+    int waves = 0;
+    size_t lds = 0;
+    const char *name = "";
+    TriLayout layout;
+};
+
+inline int tri_shape_of(int window) {
+    switch (window) {
+        case 2400: return 0;
+        case 2205: return 1;
+        default: return -1;
+    }
+}
+
+template <typename SH>
+inline void tri_fill(const MelTable *mel, const ChromaTable *chroma, TriLaunch &tl, std::vector<unsigned char> &blob) {
+    constexpr int R1 = SH::R1, R2 = SH::R2, R3 = SH::R3, N = SH::N, L1 = SH::L1, NQ1 = SH::NQ1, NR3 = SH::NR3;
+    TriLayout &L = tl.layout;
+    memset(&L, 0, sizeof(L));
+    const size_t n_melw = mel ? mel->w.size() : 0, n_ch = chroma ? chroma->src.size() : 0;
+    int off = 0;
+    auto take = [&off](size_t bytes) { const int o = off; off += (int)((bytes + 15) / 16 * 16); return o; };
+    L.off_tw2 = take((size_t)R2 * R3 * 16);
+    L.off_p3 = take(SH::PACKED ? (size_t)64 * NR3 * 8 : 16);
+    L.off_mello = take(40 * 4);
+    L.off_melcnt = take(40 * 4);
+    L.off_meloff = take(40 * 4);
+    L.off_melw = take(std::max<size_t>(n_melw, 1) * 8);
+    L.off_dct = take(13 * 41 * 8);
+    L.off_chstart = take(13 * 4);
+    L.off_chsrc = take(std::max<size_t>(n_ch, 1) * 4);
+    L.off_chw = take(std::max<size_t>(n_ch, 1) * 8);
+    L.table_bytes = off;
+    L.off_g_tw1 = take((size_t)NQ1 * L1 * 16);
+    L.off_g_post = take(SH::PACKED ? (size_t)64 * NR3 * R3 * 16 : 16);
+    L.total_bytes = off;
+    blob.assign((size_t)L.total_bytes, 0);
+    unsigned char *b = blob.data();
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    auto put_w = [&](int o, size_t idx, long long num, long long den) {      // exp(-2 pi i num / den)
+        const long double ang = -two_pi * (long double)(num % den) / (long double)den;
+        double *d = reinterpret_cast<double *>(b + o) + 2 * idx;
+        d[0] = (double)cosl(ang);
+        d[1] = (double)sinl(ang);
+    };
+    for (int q2 = 0; q2 < R2; ++q2)
+        for (int bb = 0; bb < R3; ++bb) put_w(L.off_tw2, (size_t)q2 * R3 + bb, (long long)bb * q2, L1);
+    for (int q1 = 0; q1 < NQ1; ++q1)
+        for (int j = 0; j < L1; ++j) put_w(L.off_g_tw1, (size_t)q1 * L1 + j, (long long)j * q1, N);
+    if (SH::PACKED) {
+        // pass-3 lane jobs: unordered pairs {job A, job B} with Z[N - k] of A's outputs in B (same enumeration as pair_count)
+        unsigned short *pt = reinterpret_cast<unsigned short *>(b + L.off_p3);
+        int p = 0;
+        for (int q1 = 0; q1 < R1; ++q1)
+            for (int q2 = 0; q2 < R2; ++q2) {
+                const int k = q1 + R1 * q2, m = (N - k) % N;
+                const int p1 = m % R1, p2 = (m / R1) % R2;
+                if (!(p1 > q1 || (p1 == q1 && p2 >= q2))) continue;
+                const bool self = (p1 == q1 && p2 == q2);
+                pt[4 * p] = (unsigned short)(q1 * SH::P + q2 * R3);
+                pt[4 * p + 1] = (unsigned short)(p1 * SH::P + p2 * R3);
+                pt[4 * p + 2] = (unsigned short)k;
+                pt[4 * p + 3] = (unsigned short)(1 | (self ? 2 : 0) | ((q1 == 0 && q2 == 0) ? 4 : 0));
+                for (int k3 = 0; k3 < R3; ++k3) put_w(L.off_g_post, (size_t)p * R3 + k3, (long long)k + (long long)R1 * R2 * k3, 2LL * N);
+                ++p;
+            }
+        // idle lanes of the last round: valid plane offsets, nothing stored (flags 0)
+    }
+    if (mel && !mel->w.empty()) {
+        memcpy(b + L.off_mello, mel->lo.data(), 40 * 4);
+        memcpy(b + L.off_melcnt, mel->cnt.data(), 40 * 4);
+        memcpy(b + L.off_meloff, mel->off.data(), 40 * 4);
+        memcpy(b + L.off_melw, mel->w.data(), n_melw * 8);
+        double dct[kNumMfcc * kNumMel];
+        build_dct(dct);
+        double *d = reinterpret_cast<double *>(b + L.off_dct);
+        for (int q = 0; q < 13; ++q)
+            for (int n = 0; n < 40; ++n) d[q * 41 + n] = dct[q * 40 + n];
+    }
+    if (chroma && !chroma->src.empty()) {
+        memcpy(b + L.off_chstart, chroma->class_start, 13 * 4);
+        memcpy(b + L.off_chsrc, chroma->src.data(), n_ch * 4);
+        memcpy(b + L.off_chw, chroma->w.data(), n_ch * 8);
+    }
+    tl.waves = SH::NW;
+    tl.lds = (size_t)L.table_bytes + (size_t)SH::NW * SH::WAVE_DOUBLES * 8;
+}
+
+// returns 1 when a three-pass instance exists for this window (fills tl and the table blob), 0 otherwise
+inline int tri_select(int window, int mode, const MelTable *mel, const ChromaTable *chroma, TriLaunch &tl,
+                      std::vector<unsigned char> &blob) {
+    const int sh = tri_shape_of(window);
+    if (sh < 0) return 0;
+    tl.shape = sh;
+    static const char *names[3][2] = {{"st_tri_20x20x3", "st_tri_r21x21x5"},
+                                      {"spectrogram_tri_20x20x3", "spectrogram_tri_r21x21x5"},
+                                      {"chromagram_tri_20x20x3", "chromagram_tri_r21x21x5"}};
+    tl.name = names[mode][sh];
+    if (sh == 0) tri_fill<S2400>(mel, chroma, tl, blob);
+    else tri_fill<S2205>(mel, chroma, tl, blob);
+    if (tl.lds > 160 * 1024) return 0;
+    return 1;
+}
+
+#ifndef PAA_NO_HOST_LAUNCHERS
+template <typename SH, typename T, int MODE, int DELTAS>
+inline int tri_launch_one(const TriLaunch &tl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
+                          const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
+                          hipStream_t stream) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&st_tri_kernel<SH, T, MODE, DELTAS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl.lds) != hipSuccess) return -1;
+    const unsigned grid = (unsigned)((n_tiles + SH::NW - 1) / SH::NW);
+    hipLaunchKernelGGL((st_tri_kernel<SH, T, MODE, DELTAS>), dim3(grid), dim3(64 * SH::NW), tl.lds, stream, P, tl.layout, blob,
+                       (const T *)d_packed, clips, norms, tiles, (int)n_tiles, d_out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+template <typename SH, typename T>
+inline int tri_launch_mode(const TriLaunch &tl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
+                           const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
+                           hipStream_t stream) {
+    if (P.mode == 1) return tri_launch_one<SH, T, 1, 0>(tl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+    if (P.mode == 2) return tri_launch_one<SH, T, 2, 0>(tl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+    if (P.deltas) return tri_launch_one<SH, T, 0, 1>(tl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+    return tri_launch_one<SH, T, 0, 0>(tl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+}
+template <typename T>
+inline int tri_launch_shape(const TriLaunch &tl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
+                            const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
+                            hipStream_t stream) {
+    switch (tl.shape) {
+        case 0: return tri_launch_mode<S2400, T>(tl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+        case 1: return tri_launch_mode<S2205, T>(tl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+        default: return -1;
+    }
+}
+// sample_kind 0: int16, 1: float64, 2: interleaved stereo int16 (summed in the loads)
+inline int tri_launch(const TriLaunch &tl, int sample_kind, const PlanDev &P, const unsigned char *blob, const void *d_packed,
+                      const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
+                      hipStream_t stream) {
+    if (sample_kind == 0) return tri_launch_shape<int16_t>(tl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+    if (sample_kind == 2) return tri_launch_shape<stereo16>(tl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+    return tri_launch_shape<double>(tl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+}
+
+#endif  // PAA_NO_HOST_LAUNCHERS
+
+}  // namespace tri
+}  // namespace paa

@@ -27,6 +27,7 @@
 #include "kernels_reg.hpp"
 #include "kernels_sim.hpp"
 #include "kernels_svm.hpp"
+#include "kernels_tri.hpp"
 #include "tables.hpp"
 
 using namespace paa;
@@ -372,6 +373,8 @@ struct paa_plan {
     mix::MixLayout ml;
     int ct = 0;                      // 1: register-FFT family for windows 2 RA RB (kernels_ct.hpp); table blob in d_gen_blob
     ct::CtLaunch cl;
+    int tri = 0;                     // 1: three-pass register FFT for the large default windows (kernels_tri.hpp); blob in d_gen_blob
+    tri::TriLaunch trl;
     std::string kernel_name;
 };
 
@@ -504,7 +507,15 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
             p->reg = 1;
         }
     }
-    if (!p->fast && !p->ct && !p->reg && !g_force_generic && !getenv("PAA_NO_MIX")) {
+    if (!p->fast && !p->ct && !p->reg && !g_force_generic) {
+        // the reference's default 50 ms windows at 48 / 44.1 kHz (2400, 2205): three-pass FFT in registers, 7 waves per CU
+        std::vector<unsigned char> blob;
+        if (tri::tri_select(window, mode, mode == 0 ? &tab->mel : nullptr, mode != 1 ? &tab->chroma : nullptr, p->trl, blob)) {
+            if ((rc = upload_pooled(&p->d_gen_blob, blob.data(), blob.size()))) return rc;
+            p->tri = 1;
+        }
+    }
+    if (!p->fast && !p->ct && !p->reg && !p->tri && !g_force_generic && !getenv("PAA_NO_MIX")) {
         // FFT lengths made of 2, 3, 5, 7, 11, 13 (50 ms at 44.1 / 48 kHz, 1024, ...): in-place transform, 4 waves per CU
         std::vector<unsigned char> blob;
         if (mix::mix_layout(tab->fft, mode == 0 ? &tab->mel : nullptr, mode != 1 ? &tab->chroma : nullptr, F, p->ml, &blob)) {
@@ -512,7 +523,13 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
             p->mixk = 1;
         }
     }
-    if (p->mixk) {
+    if (p->tri) {
+        // one wave per run, one frame per iteration; a run with t0 > 0 recomputes 1 frame (2 with deltas) first
+        run_quantum = 1;
+        run = choose_run_cap(p->clips, 1, 8, 96, (mode == 0) ? (deltas ? 2 : 1) : 0, p->trl.waves, g_num_cu);
+        p->lds = p->trl.lds;
+        p->kernel_name = p->trl.name;
+    } else if (p->mixk) {
         p->lds = mix::mix_lds_bytes(p->ml);
         // one wave per run, one frame at a time (halo: 1 frame, 2 with deltas): about two chip-wide rounds, 8..64 frames per run
         const long long slots = (long long)g_num_cu * p->ml.waves * 2;
@@ -777,6 +794,13 @@ extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *
     if (plan->ct) {
         rc = ct::ct_launch(plan->cl, plan->sample_kind, plan->P, plan->d_gen_blob, d_packed, plan->d_clips, plan->d_norms,
                            plan->d_tiles, plan->n_tiles, d_out, cs());
+        if (rc) return fail(PAA_ERR_HIP, "launch of %s failed: %s", plan->kernel_name.c_str(),
+                            hipGetErrorString(hipGetLastError()));
+        return PAA_OK;
+    }
+    if (plan->tri) {
+        rc = tri::tri_launch(plan->trl, plan->sample_kind, plan->P, plan->d_gen_blob, d_packed, plan->d_clips, plan->d_norms,
+                             plan->d_tiles, plan->n_tiles, d_out, cs());
         if (rc) return fail(PAA_ERR_HIP, "launch of %s failed: %s", plan->kernel_name.c_str(),
                             hipGetErrorString(hipGetLastError()));
         return PAA_OK;

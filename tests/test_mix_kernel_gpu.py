@@ -21,8 +21,11 @@ def test_plans_dispatch_the_mixed_radix_kernel(gpu_lib):
             return plan.kernel_name
         finally:
             plan.destroy()
-    assert name(48000, 2400, 1200) == "st_mix"                 # 50 ms at 48 kHz (audioTrainTest.py:28-29)
-    assert name(44100, 2205, 1102) == "st_mix"                 # 50 ms at 44.1 kHz: odd window, full-length complex FFT
+    assert name(48000, 2400, 1200) == "st_tri_20x20x3"         # 50 ms at 48 kHz (audioTrainTest.py:28-29): kernels_tri.hpp
+    assert name(44100, 2205, 1102) == "st_tri_r21x21x5"        # 50 ms at 44.1 kHz: odd window, real-input three-pass FFT
+    assert name(48000, 2400, 1200, mode=1) == "spectrogram_tri_20x20x3"
+    assert name(44100, 2205, 1102, kind=2, mode=2) == "chromagram_tri_r21x21x5"
+    assert name(96000, 4800, 2400) == "st_mix"                 # 50 ms at 96 kHz stays with the in-place transform
     assert name(44100, 1764, 1764, mode=1) == "spectrogram_mix"    # the CLI's 40 ms at 44.1 kHz (audioAnalysis.py:71)
     assert name(48000, 1920, 1920, mode=2) == "chromagram_mix"
     assert name(16000, 1024, 512, kind=1) == "st_mix"
