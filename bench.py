@@ -70,6 +70,12 @@ SHAPES = {
     "w1024": (16000, 1024, 512, 3600, 1, 0, 0, 0),                 # a power-of-two window (mixed-radix kernel, lean instance)
     "w2400": (48000, 2400, 1200, 1200, 1, 0, 0, 0),                # 50 ms at 48 kHz
     "w2205": (44100, 2205, 1102, 1200, 1, 0, 0, 0),                # 50 ms at 44.1 kHz (odd window)
+    "w1764": (44100, 1764, 1764, 1200, 1, 0, 0, 0),                # the CLI's 40 ms at 44.1 kHz (audioAnalysis.py:71,80)
+    "w1920": (48000, 1920, 1920, 1200, 1, 0, 0, 0),                # 40 ms at 48 kHz
+    "w551_11k": (11025, 551, 275, 3600, 1, 0, 0, 0),               # 50 ms at 11.025 kHz (odd: 19 x 29)
+    "w551_22k": (22050, 551, 220, 1800, 1, 0, 0, 0),               # 25 ms at 22.05 kHz
+    "w2400_68": (48000, 2400, 1200, 1200, 1, 0, 0, 1),             # 50 ms at 48 kHz with deltas (what mid-term extraction runs)
+    "w2205_stereo_68": (44100, 2205, 1102, 1200, 1, 2, 0, 1),
     "mid_stats": (16000, 800, 400, 30, 1000, 0, 0, 1),
     "big_16000": (16000, 16000, 8000, 600, 1, 0, 0, 0),            # music_thumbnailing's 1 s window (audioSegmentation.py:1137)
 }

@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "kernels_mix.hpp"
+#include "kernels_reg.hpp"          // PrimeTab
 
 namespace paa {
 namespace tri {
@@ -74,13 +75,16 @@ struct Shape {
     static constexpr int SLOT = ((PLANE > NF ? PLANE : NF) + 1) & ~1;      // doubles per spectrum slot
     static constexpr int LT = W / 10, LB = NF / 10;         // entropy blocks (samples / bins)
     static constexpr int SPL = PACKED ? 2 : 1;              // samples per loaded element
-    static constexpr int WAVE_DOUBLES = 2 * SLOT + 48 + 40; // two slots, fv[48], msp[40]
+    static constexpr int C0 = (NF + 63) / 64;
+    static constexpr int C = (C0 % 2) ? C0 : C0 + 1;        // bins per lane in the feature stage (odd: conflict-free at stride C)
+    static constexpr int WAVE_DOUBLES = 2 * SLOT + 48 + 40 + 12;   // two slots, fv[48], msp[40], bnd[12]
     static_assert(P >= L1, "plane rows hold L1 elements");
     static_assert(J2 <= 64, "one pass-2 job per lane");
     static_assert(!PACKED || NJ == 1, "packed shapes: one pass-1 job per lane");
     static_assert(PACKED || (R1 % 2 == 1), "real-input shapes: odd first radix");
-    static_assert(64 * SPL <= LT, "a register row may contain at most one entropy-block boundary");
-    static_assert(NF >= 64 * 10, "spectral chunks: at most two entropy blocks per lane (kernels_mix.hpp)");
+    static_assert((L1 < 64 ? L1 : 64) * SPL <= LT, "a register row may contain at most one entropy-block boundary");
+    static_assert(C <= LB, "a lane's bins may contain at most one entropy-block boundary");
+    static_assert(R3 > 1 || !PACKED, "two-pass shapes (R3 = 1): real input only (Z[k] and Z[N - k] would sit in different lanes)");
 };
 
 // shared (per workgroup) LDS tables + the global tables behind them in the same device blob
@@ -92,6 +96,7 @@ struct TriLayout {
     int off_g_tw1;                  // global part: double2 [NQ1][L1]: W_N^(j q1)
     int off_g_post;                 // packed: double2 [64 NR3][R3]: W_W^(kA + N3 k3)
     int total_bytes;
+    double f0, rf0, r_half_fs, f0sq;                    // fs / W, its reciprocal, 2 / fs, f0^2 (host-computed: scalar registers)
 };
 
 // ---- codelets: run() transforms v[] in place, X[q] ends at v[pos(q)] ------------------------------------------------
@@ -141,6 +146,80 @@ template <> struct Cd<21> {
     static constexpr int pos(int q) { return (7 * (q % 3) + 3 * (q % 7)) % 21; }
 };
 
+// ---- odd primes: O(R^2) butterflies from the sums / differences of the pairs (x_j, x_{R-j}), in the pivot form of
+// mix::dft_prime (R equal inputs give exact zeros in the non-DC outputs); cos / sin from kernels_reg.hpp's half tables
+template <int R> struct PT {
+    static constexpr int H = (R - 1) / 2;
+    static constexpr double c(int m) { return (m % R == 0) ? 1.0 : reg::PrimeTab<R>::c[((m % R) <= H ? (m % R) : R - (m % R)) - 1]; }
+    static constexpr double s(int m) {
+        return (m % R == 0) ? 0.0 : ((m % R) <= H ? reg::PrimeTab<R>::s[(m % R) - 1] : -reg::PrimeTab<R>::s[R - (m % R) - 1]);
+    }
+};
+template <int R>
+__device__ __forceinline__ void cdft_prime(double2 *v) {          // complex, in place, natural order
+    constexpr int H = (R - 1) / 2;
+    double2 sm[H], df[H];
+#pragma unroll
+    for (int j = 1; j <= H; ++j) { sm[j - 1] = cadd(v[j], v[R - j]); df[j - 1] = csub(v[j], v[R - j]); }
+    const double2 x0 = v[0];
+    double2 tot = x0;
+#pragma unroll
+    for (int j = 0; j < H; ++j) tot = cadd(tot, sm[j]);
+    const double2 base = make_double2(fma(-0.5, sm[H - 1].x, x0.x), fma(-0.5, sm[H - 1].y, x0.y));
+#pragma unroll
+    for (int j = 0; j + 1 < H; ++j) sm[j] = csub(sm[j], sm[H - 1]);      // rel_j = s_j - s_H
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 1; q <= H; ++q) {
+        double ar = base.x, ai = base.y, br = 0.0, bi = 0.0;
+#pragma unroll
+        for (int j = 1; j <= H; ++j) {
+            const double c = PT<R>::c(j * q), sn = PT<R>::s(j * q);
+            if (j < H) { ar = fma(c, sm[j - 1].x, ar); ai = fma(c, sm[j - 1].y, ai); }
+            br = fma(sn, df[j - 1].x, br);
+            bi = fma(sn, df[j - 1].y, bi);
+        }
+        v[q] = make_double2(ar + bi, ai - br);             // X[q] = A - i B, X[R - q] = A + i B
+        v[R - q] = make_double2(ar - bi, ai + br);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    v[0] = tot;
+}
+template <int R>
+__device__ __forceinline__ void rdft_prime(const double *x, double2 *a) {      // real input -> a[q] = X[q], q = 0 .. H
+    constexpr int H = (R - 1) / 2;
+    double sm[H], df[H];
+#pragma unroll
+    for (int j = 1; j <= H; ++j) { sm[j - 1] = x[j] + x[R - j]; df[j - 1] = x[j] - x[R - j]; }
+    double tot = x[0];
+#pragma unroll
+    for (int j = 0; j < H; ++j) tot += sm[j];
+    const double base = fma(-0.5, sm[H - 1], x[0]);
+#pragma unroll
+    for (int j = 0; j + 1 < H; ++j) sm[j] -= sm[H - 1];
+    a[0] = make_double2(tot, 0.0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 1; q <= H; ++q) {
+        double ar = base, br = 0.0;
+#pragma unroll
+        for (int j = 1; j <= H; ++j) {
+            if (j < H) ar = fma(PT<R>::c(j * q), sm[j - 1], ar);
+            br = fma(PT<R>::s(j * q), df[j - 1], br);
+        }
+        a[q] = make_double2(ar, -br);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <> struct Cd<19> {
+    static __device__ __forceinline__ void run(double2 *v) { cdft_prime<19>(v); }
+    static constexpr int pos(int q) { return q; }
+};
+template <> struct Cd<10> {
+    static __device__ __forceinline__ void run(double2 *v) { ct::Dft<10>::run<1>(v); }
+    static constexpr int pos(int q) { return ct::Dft<10>::pos(q); }
+};
+
 // real-input first pass: x[R] real (natural order) -> a[q] = X[q], q = 0 .. (R - 1) / 2 (the rest are conjugates)
 template <int R> struct RCd;
 // three real inputs: X0 = a + b + c (real), X1 = (a - (b + c) / 2) - i h (b - c); equal inputs give X1 = 0 exactly
@@ -170,6 +249,9 @@ __device__ __forceinline__ void rdft7(const double *s, double2 *y) {
         y[q] = make_double2(ar, -br);                    // X[q] = A - i B
     }
 }
+template <> struct RCd<29> {
+    static __device__ __forceinline__ void run(const double *x, double2 *a) { rdft_prime<29>(x, a); }
+};
 template <> struct RCd<21> {
     static __device__ __forceinline__ void run(const double *x, double2 *a) {
         double s0[7];
@@ -220,6 +302,170 @@ __device__ __forceinline__ void row_put(RowChunk &rc, double *row, int t, int lo
 }
 
 
+// ---- the 34 base features of one frame into fv[0..33] (ShortTermFeatures.py:626-667): all 64 lanes on one spectrum,
+// lane i owns bins [C i, C i + C) in registers for both sweeps; spectral-entropy blocks from the cumulative energy at the
+// block boundaries (kernels_ct.hpp's scheme with 64-lane scans)
+template <typename SH>
+__device__ __forceinline__ void tri_features(const TriLayout &L, const Tabs &tb, const TimeFeat &tf, const double *cur,
+                                             const double *prv, bool first_frame, double *fv, double *msp, double *bnd,
+                                             int lane) {
+    constexpr int NF = SH::NF, C = SH::C, LB = SH::LB, W = SH::W;
+    const double f0 = L.f0, rf0 = L.rf0, r_half_fs = L.r_half_fs, f0sq = L.f0sq;
+    const int kb = C * lane;
+    double Xc[C], Xv[C];
+#pragma unroll
+    for (int m = 0; m < C; ++m) {
+        const int k = min(kb + m, NF - 1);
+        const double a = cur[k], b = prv[k];
+        Xc[m] = (kb + m < NF) ? a : 0.0;
+        Xv[m] = (kb + m < NF) ? b : 0.0;
+    }
+    double sXa = 0.0, sXb = 0.0, sMa = 0.0, sMb = 0.0, sVa = 0.0, sVb = 0.0, mx = 0.0, csa = 0.0, csb = 0.0;
+#pragma unroll
+    for (int m = 0; m + 1 < C; m += 2) {
+        const double X0 = Xc[m], X1 = Xc[m + 1];
+        sXa += X0; sXb += X1;
+        sVa += Xv[m]; sVb += Xv[m + 1];
+        sMa = fma((double)m, X0, sMa); sMb = fma((double)(m + 1), X1, sMb);
+        csa = fma(X0, X0, csa); csb = fma(X1, X1, csb);
+        mx = fmax(mx, fmax(X0, X1));
+    }
+    {
+        const double X0 = Xc[C - 1];          // (C is odd)
+        sXa += X0; sVa += Xv[C - 1]; sMa = fma((double)(C - 1), X0, sMa); csa = fma(X0, X0, csa); mx = fmax(mx, X0);
+    }
+    const double cs = csa + csb;
+    const double run_incl = wscan_incl(cs);
+    const double run_excl = run_incl - cs;
+    const double sP = readlane63(run_incl);                  // sum X^2 over all bins
+    const double base_k = (double)(kb + 1);
+    double sX = sXa + sXb;
+    double sIX = f0 * fma(base_k, sX, sMa + sMb);            // sum (k + 1) f0 X
+    double sXp = sVa + sVb;
+    sX = wsum(sX); sXp = wsum(sXp);
+    sIX = wsum(sIX); mx = wmax_nonneg(mx);
+    const double sXe = sX + (double)NF * kEps;               // np.sum(X + eps) (:118-119)
+    sXp += (double)NF * kEps;
+    // spectral entropy (:85-107): cumulative energy at the block boundaries j LB, j = 0 .. 10, written by the lane whose
+    // bins contain the boundary (boundary 10 = the total when the blocks tile the spectrum)
+    {
+        const int jb = (kb + LB - 1) / LB;                   // first boundary at or after the lane's first bin
+        const int mb = jb * LB - kb;
+        double part = 0.0, cumb = run_excl;
+#pragma unroll
+        for (int m = 0; m < C; ++m) {
+            cumb = (m == mb) ? run_excl + part : cumb;
+            part = fma(Xc[m], Xc[m], part);
+        }
+        if (mb < C && jb <= 10 && jb * LB < NF) bnd[jb] = cumb;
+        if (10 * LB == NF && lane == 0) bnd[10] = sP;
+    }
+    wsync();
+    double ent_f;
+    {
+        const int ib = min(lane, 9);
+        const double sf = fast_div(bnd[ib + 1] - bnd[ib], sP + kEps);
+        ent_f = wsum((lane < 10) ? -(sf * fast_log2(sf + kEps)) : 0.0);
+    }
+    // centroid, spread, flux (:57-82, :110-124)
+    const double r = (mx == 0.0) ? 1.0 / kEps : fast_div(1.0, mx);
+    const double den = sX * r + kEps;
+    const double rden = fast_div(1.0, den);
+    const double cen = (sIX * r) * rden;
+    const double rX = fast_div(1.0, sXe), rXp = fast_div(1.0, sXp);
+    const double cb = base_k - cen * rf0;
+    double sSa = 0.0, sSb = 0.0, sFa = 0.0, sFb = 0.0;
+#pragma unroll
+    for (int m = 0; m + 1 < C; m += 2) {
+        const double d0 = cb + (double)m, d1 = cb + (double)(m + 1);
+        sSa = fma(d0 * d0, Xc[m], sSa);
+        sSb = fma(d1 * d1, Xc[m + 1], sSb);
+        const double f0d = Xc[m] * rX - Xv[m] * rXp, f1d = Xc[m + 1] * rX - Xv[m + 1] * rXp;
+        sFa = fma(f0d, f0d, sFa);
+        sFb = fma(f1d, f1d, sFb);
+    }
+    {
+        const double d0 = cb + (double)(C - 1);
+        sSa = fma(d0 * d0, Xc[C - 1], sSa);
+        const double f0d = Xc[C - 1] * rX - Xv[C - 1] * rXp;
+        sFa = fma(f0d, f0d, sFa);
+    }
+    double sSp = (sSa + sSb) * (f0sq * r), sFl = sFa + sFb;
+    sSp = wsum(sSp);
+    sFl = wsum(sFl);
+    const double spread = fast_sqrt(sSp * rden);
+    // roll-off (:127-140): first k with cumsum(X^2)[k] + eps > 0.9 sum(X^2)
+    int first = 0x7fffffff;
+    {
+        const double thr = 0.90 * sP;
+        double run = run_excl;
+#pragma unroll
+        for (int m = 0; m < C; ++m) {
+            run = fma(Xc[m], Xc[m], run);
+            first = (first == 0x7fffffff && kb + m < NF && run + kEps > thr) ? kb + m : first;
+        }
+        first = mix::wmin_nonneg_i(first);
+    }
+    // MFCC (:236-254): lane m < 40 = mel filter m (sparse list), log10, then the 13 x 40 DCT on 52 lanes
+    if (lane < 40) {
+        const int lo = tb.mel_lo[lane], cnt = tb.mel_cnt[lane];
+        const double *w = tb.mel_w + tb.mel_off[lane];
+        double a0 = 0.0, a1 = 0.0;
+        int i = 0;
+        for (; i + 8 <= cnt; i += 8) {                   // eight bins and weights in flight
+            double xb[8], wb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { xb[u] = cur[lo + i + u]; wb[u] = w[i + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { a0 = fma(xb[u], wb[u], a0); a1 = fma(xb[u + 1], wb[u + 1], a1); }
+        }
+        for (; i + 2 <= cnt; i += 2) {
+            a0 = fma(cur[lo + i], w[i], a0);
+            a1 = fma(cur[lo + i + 1], w[i + 1], a1);
+        }
+        if (i < cnt) a0 = fma(cur[lo + i], w[i], a0);
+        msp[lane] = fast_log10((a0 + a1) + kEps);
+    }
+    // chroma (:277-321)
+    const double chroma = mix::chroma_class_batched(tb, cur, sP, lane);
+    wsync();
+    {
+        // lane 4 q + part: ten terms of DCT row q; the four parts meet through two quad permutes
+        const int q = min(lane >> 2, 12), part = lane & 3;
+        const double *dm = tb.dct + q * tb.dct_stride + 10 * part;
+        const double *mv = msp + 10 * part;
+        double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+        for (int n = 0; n < 10; n += 2) {
+            c0 = fma(dm[n], mv[n], c0);
+            c1 = fma(dm[n + 1], mv[n + 1], c1);
+        }
+        double cc = c0 + c1;
+        cc += dpp_mov<PAA_DPP_X1>(cc);
+        cc += dpp_mov<PAA_DPP_X2>(cc);
+        if (lane < 52 && part == 0) fv[8 + q] = cc;
+    }
+    {   // population std of the 12 chroma values (:667): lanes 0..11 of the first row
+        const double cv = (lane < 12) ? chroma : 0.0;
+        const double mean = group_sum(cv) / 12.0;
+        const double d = (lane < 12) ? cv - mean : 0.0;
+        const double var = group_sum(d * d) / 12.0;
+        if (lane < 12) fv[21 + lane] = chroma;
+        if (lane == 0) {
+            fv[0] = ((double)tf.zc * 0.5) * (1.0 / (double)(W - 1));
+            fv[1] = tf.e_tot * (1.0 / (double)W);
+            fv[2] = tf.ent_e;
+            fv[3] = cen * r_half_fs;
+            fv[4] = spread * r_half_fs;
+            fv[5] = ent_f;
+            fv[6] = first_frame ? 0.0 : sFl;      // first frame: previous spectrum = itself (:624-625)
+            fv[7] = (first == 0x7fffffff) ? 0.0 : (double)first * (1.0 / (double)NF);
+            fv[33] = fast_sqrt(var);
+        }
+    }
+    wsync();
+}
+
 // MODE 0: short-term features (DELTAS: 68 rows), 1: spectrogram rows, 2: chromagram rows
 template <typename SH, typename T, int MODE, int DELTAS>
 __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(PlanDev P, TriLayout L,
@@ -262,6 +508,7 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
     double *slots = reinterpret_cast<double *>(smem + L.table_bytes) + (size_t)wave * SH::WAVE_DOUBLES;
     double *fv = slots + 2 * SLOT;
     double *msp = fv + 48;
+    double *bnd = msp + 40;
 
     const Tile tl = tiles[tile_id];
     const ClipDev c = clips[tl.clip];
@@ -270,8 +517,10 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
     const long long Tc = c.T;
     double *oc = out + c.out_off;
     const double sc = sample_scale<T>();
-    const double mean = nm.mean, inv = nm.inv;
-    const double mscale = (PACKED ? 0.5 : 1.0) * inv / (double)NF;       // X / len(X) (:621); y = d * inv; E, O carry 1/2
+    // (wave-uniform: pinned into scalar registers, or they would live in vector registers through the whole loop)
+    const double mean = f800::uni(nm.mean), inv = f800::uni(nm.inv);
+    const double mscale = f800::uni((PACKED ? 0.5 : 1.0) * inv * (1.0 / (double)NF));      // X / len(X) (:621); y = d * inv; E, O carry 1/2
+    const double inv2 = f800::uni(inv * inv);               // energies of y = d * inv
 
     const int hneed = (MODE == 0) ? (DELTAS ? 2 : 1) : 0;
     const int h = min(hneed, tl.t0);
@@ -288,7 +537,6 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
         // addresses and table pointers of all passes are some 60 loop-invariant registers (they ended up in scratch)
         int lane = lane_id;
         asm volatile("" : "+v"(lane));
-        const mix::Chunk ch_f = mix::make_chunk(NF, P.blk_f, lane);
         // pass-2 job of this lane: (q1, b); idle lanes shadow the last job (their plane writes are masked)
         const int m2 = min(lane, J2 - 1);
         const int q1_2 = m2 / R3, b_2 = m2 - R3 * q1_2;
@@ -310,7 +558,6 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
             // wave totals of the partials (before pass 1: the partials' registers are free for the codelets)
             auto finish_time = [&]() {
                 if (MODE == 0 && want) {
-                    const double inv2 = inv * inv;         // y = d * inv: energies scale by inv^2
                     double tot = 0.0;
 #pragma unroll
                     for (int b = 0; b < 11; ++b) { eb[b] = wsum(eb[b]) * inv2; tot += eb[b]; }
@@ -429,6 +676,10 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                 }
             }
         }
+#pragma unroll
+        for (int u = 0; u < NJ; ++u)
+#pragma unroll
+            for (int q = 0; q < NQ1; ++q) asm volatile("" : "+v"(a[u][q].x), "+v"(a[u][q].y));
         PAA_TICK(2)
         wsync();               // the previous frame's readers of this slot are done
 
@@ -461,7 +712,7 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
         // ---------------- pass 2: radix R2 over a, outputs times W_L1^(b q2)
         Cd<R2>::run(c2);
 #pragma unroll
-        for (int q0 = 1; q0 < R2; q0 += 4) {
+        for (int q0 = 1; q0 < (R3 > 1 ? R2 : 0); q0 += 4) {
             double2 wl[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -471,9 +722,23 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                 if (q0 + k < R2) c2[Cd<R2>::pos(q0 + k)] = cmul(c2[Cd<R2>::pos(q0 + k)], wl[k]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // (pinned: the optimiser would sink the imaginary halves of these products into the masked plane store that uses
+        // them, keeping the twiddles and the codelet's outputs alive side by side -- 80 registers)
+#pragma unroll
+        for (int q = 0; q < R2; ++q) asm volatile("" : "+v"(c2[q].x), "+v"(c2[q].y));
         PAA_TICK(4)
         // ---------------- exchange 2: element (q1, b, q2) at plane[q1 PP + q2 R3 + b]; pass 3 + |X| / num_fft (:617-621)
-        if constexpr (PACKED) {
+        if constexpr (R3 == 1) {
+            // two-pass shapes: lane q1 holds Z[q1 + R1 q2] already; bin k or its mirror N - k (real input)
+#pragma unroll
+            for (int q = 0; q < R2; ++q) {
+                const double2 z = c2[Cd<R2>::pos(q)];
+                const double mg = mag_sqrt(fma(z.x, z.x, z.y * z.y)) * mscale;
+                const int k = q1_2 + R1 * q;
+                if (act2 && k < NF) cur[k] = mg;
+                else if (act2 && q1_2 > 0 && N - k < NF) cur[N - k] = mg;
+            }
+        } else if constexpr (PACKED) {
             double2 dA[NR3][R3], dB[NR3][R3];
             ushort4 pe[NR3];
 #pragma unroll
@@ -590,7 +855,7 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
             const double chv = chroma_class(tb, cur, p, lane);
             if (lane < 12) oc[(long long)t * 12 + lane] = chv;
         } else if (want) {
-            mix::frame_features_chunked(P, tb, tf, cur, (t == 0) ? cur : prv, fv, msp, ch_f, lane);
+            tri_features<SH>(L, tb, tf, cur, (t == 0) ? cur : prv, t == 0, fv, msp, bnd, lane);
             PAA_TICK(7)
             const double v = (lane < kBase) ? fv[lane] : 0.0;
             if (t >= tl.t0 && lane < kBase) {
@@ -612,9 +877,14 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
 // ---- host: shapes, LDS layout + table blob, launch --------------------------------------------------------------------
 typedef Shape<20, 20, 3, true, 60, 7> S2400;        // 50 ms at 48 kHz: 1200 complex points
 typedef Shape<21, 21, 5, false, 105, 7> S2205;      // 50 ms at 44.1 kHz: 2205 real points (odd window)
+typedef Shape<21, 21, 2, true, 42, 8> S1764;        // 40 ms at 44.1 kHz (audioAnalysis.py:71,80): 882 complex points
+typedef Shape<20, 16, 3, true, 49, 8> S1920;        // 40 ms at 48 kHz: 960 complex points
+typedef Shape<20, 20, 2, true, 40, 8> S1600;        // 50 ms at 32 kHz: 800 complex points
+typedef Shape<20, 10, 3, true, 30, 8> S1200;        // 50 ms at 24 kHz / 25 ms at 48 kHz: 600 complex points
+typedef Shape<29, 19, 1, false, 19, 8> S551;        // 50 ms at 11.025 kHz / 25 ms at 22.05 kHz: 551 real points, two passes
 
 struct TriLaunch {
-    int shape = -1;                 // 0: 2400, 1: 2205
+    int shape = -1;                 // index into the shape list above
     int waves = 0;
     size_t lds = 0;
     const char *name = "";
@@ -625,12 +895,19 @@ inline int tri_shape_of(int window) {
     switch (window) {
         case 2400: return 0;
         case 2205: return 1;
+        case 1764: return 2;
+        case 1920: return 3;
+        case 1600: return 4;
+        case 1200: return 5;
+        case 551: return 6;
         default: return -1;
     }
 }
+// PAA_TRI_SHAPE(SH) is expanded once per shape, in tri_shape_of's order
+#define PAA_TRI_SHAPES(X) X(0, S2400) X(1, S2205) X(2, S1764) X(3, S1920) X(4, S1600) X(5, S1200) X(6, S551)
 
 template <typename SH>
-inline void tri_fill(const MelTable *mel, const ChromaTable *chroma, TriLaunch &tl, std::vector<unsigned char> &blob) {
+inline void tri_fill(double fs, const MelTable *mel, const ChromaTable *chroma, TriLaunch &tl, std::vector<unsigned char> &blob) {
     constexpr int R1 = SH::R1, R2 = SH::R2, R3 = SH::R3, N = SH::N, L1 = SH::L1, NQ1 = SH::NQ1, NR3 = SH::NR3;
     TriLayout &L = tl.layout;
     memset(&L, 0, sizeof(L));
@@ -651,6 +928,10 @@ inline void tri_fill(const MelTable *mel, const ChromaTable *chroma, TriLaunch &
     L.off_g_tw1 = take((size_t)NQ1 * L1 * 16);
     L.off_g_post = take(SH::PACKED ? (size_t)64 * NR3 * R3 * 16 : 16);
     L.total_bytes = off;
+    L.f0 = fs / (2.0 * (double)SH::NF);
+    L.rf0 = 1.0 / L.f0;
+    L.r_half_fs = 1.0 / (fs / 2.0);
+    L.f0sq = L.f0 * L.f0;
     blob.assign((size_t)L.total_bytes, 0);
     unsigned char *b = blob.data();
     const long double two_pi = 6.283185307179586476925286766559005768L;
@@ -704,17 +985,24 @@ inline void tri_fill(const MelTable *mel, const ChromaTable *chroma, TriLaunch &
 }
 
 // returns 1 when a three-pass instance exists for this window (fills tl and the table blob), 0 otherwise
-inline int tri_select(int window, int mode, const MelTable *mel, const ChromaTable *chroma, TriLaunch &tl,
+inline int tri_select(int window, int mode, double fs, const MelTable *mel, const ChromaTable *chroma, TriLaunch &tl,
                       std::vector<unsigned char> &blob) {
     const int sh = tri_shape_of(window);
     if (sh < 0) return 0;
     tl.shape = sh;
-    static const char *names[3][2] = {{"st_tri_20x20x3", "st_tri_r21x21x5"},
-                                      {"spectrogram_tri_20x20x3", "spectrogram_tri_r21x21x5"},
-                                      {"chromagram_tri_20x20x3", "chromagram_tri_r21x21x5"}};
+    static const char *names[3][7] = {
+        {"st_tri_20x20x3", "st_tri_r21x21x5", "st_tri_21x21x2", "st_tri_20x16x3", "st_tri_20x20x2", "st_tri_20x10x3", "st_tri_r29x19"},
+        {"spectrogram_tri_20x20x3", "spectrogram_tri_r21x21x5", "spectrogram_tri_21x21x2", "spectrogram_tri_20x16x3",
+         "spectrogram_tri_20x20x2", "spectrogram_tri_20x10x3", "spectrogram_tri_r29x19"},
+        {"chromagram_tri_20x20x3", "chromagram_tri_r21x21x5", "chromagram_tri_21x21x2", "chromagram_tri_20x16x3",
+         "chromagram_tri_20x20x2", "chromagram_tri_20x10x3", "chromagram_tri_r29x19"}};
     tl.name = names[mode][sh];
-    if (sh == 0) tri_fill<S2400>(mel, chroma, tl, blob);
-    else tri_fill<S2205>(mel, chroma, tl, blob);
+    switch (sh) {
+#define PAA_TRI_FILL(ID, SH) case ID: tri_fill<SH>(fs, mel, chroma, tl, blob); break;
+        PAA_TRI_SHAPES(PAA_TRI_FILL)
+#undef PAA_TRI_FILL
+        default: return 0;
+    }
     if (tl.lds > 160 * 1024) return 0;
     return 1;
 }
@@ -745,8 +1033,9 @@ inline int tri_launch_shape(const TriLaunch &tl, const PlanDev &P, const unsigne
                             const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
                             hipStream_t stream) {
     switch (tl.shape) {
-        case 0: return tri_launch_mode<S2400, T>(tl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
-        case 1: return tri_launch_mode<S2205, T>(tl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+#define PAA_TRI_GO(ID, SH) case ID: return tri_launch_mode<SH, T>(tl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+        PAA_TRI_SHAPES(PAA_TRI_GO)
+#undef PAA_TRI_GO
         default: return -1;
     }
 }

@@ -510,7 +510,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     if (!p->fast && !p->ct && !p->reg && !g_force_generic) {
         // the reference's default 50 ms windows at 48 / 44.1 kHz (2400, 2205): three-pass FFT in registers, 7 waves per CU
         std::vector<unsigned char> blob;
-        if (tri::tri_select(window, mode, mode == 0 ? &tab->mel : nullptr, mode != 1 ? &tab->chroma : nullptr, p->trl, blob)) {
+        if (tri::tri_select(window, mode, fs, mode == 0 ? &tab->mel : nullptr, mode != 1 ? &tab->chroma : nullptr, p->trl, blob)) {
             if ((rc = upload_pooled(&p->d_gen_blob, blob.data(), blob.size()))) return rc;
             p->tri = 1;
         }

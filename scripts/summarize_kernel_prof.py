@@ -18,7 +18,8 @@ def main(prof_dir, out_path):
     out["run_under_trace"] = line
     stem = line["kernel"].replace("_w8", "")
     like = {"st_reg_29x19": "%st_reg_kernel%", "spectrogram_reg_29x19": "%st_reg_kernel%", "chromagram_reg_29x19": "%st_reg_kernel%",
-            "st_generic": "%st_generic_kernel%"}.get(stem, "%st_ct_kernel%" if "_ct_" in stem else "%" + stem + "%")
+            "st_generic": "%st_generic_kernel%"}.get(stem, "%st_ct_kernel%" if "_ct_" in stem else
+                                                    "%st_tri_kernel%" if "_tri_" in stem else "%" + stem + "%")
     if line["case"] == "mid_stats":
         like = "%mid_stats_kernel%"
     out["kernel_like"] = like

@@ -26,8 +26,14 @@ def test_plans_dispatch_the_mixed_radix_kernel(gpu_lib):
     assert name(48000, 2400, 1200, mode=1) == "spectrogram_tri_20x20x3"
     assert name(44100, 2205, 1102, kind=2, mode=2) == "chromagram_tri_r21x21x5"
     assert name(96000, 4800, 2400) == "st_mix"                 # 50 ms at 96 kHz stays with the in-place transform
-    assert name(44100, 1764, 1764, mode=1) == "spectrogram_mix"    # the CLI's 40 ms at 44.1 kHz (audioAnalysis.py:71)
-    assert name(48000, 1920, 1920, mode=2) == "chromagram_mix"
+    assert name(44100, 1764, 1764, mode=1) == "spectrogram_tri_21x21x2"    # the CLI's 40 ms at 44.1 kHz (audioAnalysis.py:71)
+    assert name(48000, 1920, 1920, mode=2) == "chromagram_tri_20x16x3"
+    assert name(32000, 1600, 800) == "st_tri_20x20x2"          # 50 ms at 32 kHz
+    assert name(24000, 1200, 600) == "st_tri_20x10x3"          # 50 ms at 24 kHz / 25 ms at 48 kHz
+    # 50 ms at 11.025 kHz and 25 ms at 22.05 kHz (audioTrainTest.py:28-29): 551 = 19 x 29, odd -> real-input two-pass FFT
+    assert name(11025, 551, 275) == "st_tri_r29x19"
+    assert name(22050, 551, 220, kind=1) == "st_tri_r29x19"
+    assert name(44100, 1755, 877, mode=1) == "spectrogram_mix"   # other lengths made of 2, 3, 5, 7, 11, 13 stay mixed-radix
     assert name(16000, 1024, 512, kind=1) == "st_mix"
     assert name(44100, 1102, 441) == "st_reg_29x19"            # 2 x 19 x 29 keeps its prime-factor kernel
     assert name(16000, 800, 400) == "st_fast_800_w8"
@@ -47,7 +53,11 @@ CASES = [
     (16000, 1024, 512, "i16", 20, True),       # 512 = 8 8 8
     (16000, 512, 256, "f64", 10, True),
     (22050, 1100, 550, "i16", 10, False),      # 550 = 2 5 5 11
-    (11025, 551, 275, "i16", 20, True),        # 50 ms at 11.025 kHz: odd, 19 x 29 -> stays generic (checked all the same)
+    (11025, 551, 275, "i16", 20, True),        # 50 ms at 11.025 kHz: odd, 19 x 29 -> two-pass real-input kernel (kernels_tri.hpp)
+    (22050, 551, 220, "f64", 15, True),        # 25 ms at 22.05 kHz
+    (22050, 551, 551, "stereo", 15, False),
+    (24000, 1200, 600, "i16", 10, True),       # 600 = 20 x 10 x 3
+    (32000, 1600, 1600, "f64", 10, True),
     (16000, 390, 200, "i16", 10, True),        # 195 = 3 5 13
     (16000, 1001, 500, "unit", 10, False),     # odd: 7 11 13
     (16000, 256, 128, "i16", 5, True),
@@ -73,7 +83,8 @@ def test_full_matrix_against_c_oracle(gpu_lib, fs, window, step, kind, seconds, 
 
 @pytest.mark.parametrize("fs,window,step,kind", [(48000, 2400, 1200, "i16"), (44100, 2205, 1102, "stereo"),
                                                   (44100, 1764, 1764, "i16"), (48000, 1920, 1920, "f64"),
-                                                  (16000, 1024, 300, "i16")])
+                                                  (16000, 1024, 300, "i16"), (11025, 551, 275, "i16"),
+                                                  (32000, 1600, 800, "stereo"), (24000, 1200, 1200, "f64")])
 def test_spectrogram_chromagram_full_against_c_oracle(gpu_lib, capsys, fs, window, step, kind):
     sig, mono = make_signal(kind, 9100 + window, 12.7, fs)
     spec, t_ax, f_ax = ShortTermFeatures.spectrogram(sig, fs, window, step)
