@@ -59,6 +59,10 @@ int  paa_dev_free(void *ptr);
 int  paa_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);   /* synchronous */
 int  paa_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes);    /* queued on the library stream */
 int  paa_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);   /* synchronous */
+/* the same, ordered behind the kernels of the compute stream only -- not behind gathers still queued on the communication
+ * stream.  For buffers that are at most the SOURCE of a gather (distributed.py's restart shards are saved with it while the
+ * exchange may still be waiting for a peer); a gather DESTINATION must be read with paa_memcpy_d2h                    */
+int  paa_memcpy_d2h_compute(void *dst_host, const void *src_dev, size_t bytes);
 int  paa_dev_sync(void);
 /* elapsed GPU milliseconds between two points of the library stream (HIP events) */
 int  paa_timer_start(void);
@@ -233,6 +237,9 @@ int paa_debug_lane_peak(void);     /* most host-buffer calls in flight at once s
 int paa_debug_phase_cycles(uint64_t *out16);
 /* radix plan chosen for a window: returns number of passes, fills radices (capacity 32)      */
 int paa_debug_fft_plan(int window, int32_t *radices, int32_t *fft_len);
+/* file name (inside PAA_COMM_MARKER_DIR / TMPDIR) of the one-process-per-GPU marker that `rank` of the job `unique_id`
+ * drops for the selected device before RCCL is called (comm_rccl.hpp); needs a device                                */
+int paa_debug_comm_marker_name(const void *unique_id, int rank, char *out, int capacity);
 /* mixed-radix kernel (csrc/kernels_mix.hpp): radix schedule of its in-place DIF transform and the position that holds
  * Z[k] afterwards (perm: fft_len entries); returns the number of passes, 0 when the window goes to another kernel   */
 int paa_debug_mix_plan(int window, int32_t *radices, int32_t *fft_len, uint16_t *perm, int perm_capacity,

@@ -37,6 +37,7 @@ _SIGNATURES = {
     "paa_dev_free": (C.c_int, [C.c_void_p]),
     "paa_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "paa_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "paa_memcpy_d2h_compute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "paa_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "paa_dev_sync": (C.c_int, []),
     "paa_timer_start": (C.c_int, []),
@@ -105,6 +106,7 @@ _SIGNATURES = {
     "paa_debug_wave_trace": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
     "paa_debug_lane_peak": (C.c_int, []),
     "paa_debug_fft_plan": (C.c_int, [C.c_int, c_i32p, c_i32p]),
+    "paa_debug_comm_marker_name": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
     "paa_debug_mix_plan": (C.c_int, [C.c_int, c_i32p, c_i32p, C.POINTER(C.c_uint16), C.c_int, c_i32p, c_i32p]),
     "paa_debug_run_plan": (C.c_int, [c_i64p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p,
                                      c_i64p, c_i32p]),
@@ -237,10 +239,12 @@ class DeviceBuffer:
         check(lib().paa_memcpy_h2d(buf.ptr, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
         return buf
 
-    def to_host(self, dtype, count, offset_bytes=0):
+    def to_host(self, dtype, count, offset_bytes=0, wait_comm=True):
+        """wait_comm=False: ordered behind the compute stream only (a buffer that is at most the SOURCE of queued gathers)."""
         out = np.empty(int(count), dtype=dtype)
         src = C.c_void_p(self.ptr.value + int(offset_bytes))
-        check(lib().paa_memcpy_d2h(out.ctypes.data_as(C.c_void_p), src, out.nbytes))
+        fn = lib().paa_memcpy_d2h if wait_comm else lib().paa_memcpy_d2h_compute
+        check(fn(out.ctypes.data_as(C.c_void_p), src, out.nbytes))
         return out
 
     def free(self):

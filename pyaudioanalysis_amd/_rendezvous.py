@@ -8,13 +8,21 @@ plumbing for distributed.extract_sharded and bench.py, with no dependency beyond
 The port: MASTER_PORT itself usually belongs to the launcher (torchrun's agent keeps its store there), so rank 0 binds
 the first free port of MASTER_PORT + 1 .. + 16 and a peer tries those in turn; both sides check a token derived from
 the job's environment, so a foreign listener on one of them is skipped, not joined.
+
+Trust model: the token keeps OTHER JOBS and stray listeners apart; it is not a credential -- address, port, world size and
+run id are guessable.  On a network where hosts outside the job can reach rank 0's ports, export the same PAA_RDZV_SECRET
+on every rank: it is mixed into the token (HMAC-SHA256), and a peer without it cannot claim a rank slot.  Rank 0 listens on
+MASTER_ADDR's interface only when that address is local (loopback for single-node jobs), and every handshake runs on its own
+thread with a 5 s budget, so a half-open connection cannot stall the accept loop.
 """
 import base64
 import hashlib
+import hmac
 import json
 import os
 import socket
 import struct
+import threading
 import time
 
 _PORT_SPAN = 16
@@ -79,7 +87,11 @@ class SocketGroup:
         addr = addr or env.get("MASTER_ADDR", "127.0.0.1")
         port = int(env.get("MASTER_PORT", "29500")) if port is None else int(port)
         tag = job_tag if job_tag is not None else env.get("TORCHELASTIC_RUN_ID", "")
-        self._token = hashlib.sha256(("paa-rdzv|%s|%d|%d|%s" % (addr, port, self.world_size, tag)).encode()).digest()
+        ident = ("paa-rdzv|%s|%d|%d|%s" % (addr, port, self.world_size, tag)).encode()
+        secret = env.get("PAA_RDZV_SECRET", "")
+        self._token = (hmac.new(secret.encode(), ident, hashlib.sha256).digest() if secret
+                       else hashlib.sha256(ident).digest())
+        self._lock = threading.Lock()
         self._peers = {}          # rank 0: rank -> socket
         self._root = None         # other ranks: socket to rank 0
         self._listener = None
@@ -95,41 +107,71 @@ class SocketGroup:
     def _serve(self, addr, port, deadline):
         last = None
         for cand in range(port + 1, port + 1 + _PORT_SPAN):
-            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            try:
-                srv.bind(("", cand))
-            except OSError as exc:
-                last = exc
-                srv.close()
+            srv = None
+            # MASTER_ADDR's own interface when it is an address of this host (127.0.0.1 for single-node jobs: nothing off the
+            # node can connect); all interfaces when it is not bindable here (a name that resolves elsewhere, NAT)
+            for host in (addr, ""):
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    srv.bind((host, cand))
+                    break
+                except OSError as exc:
+                    last = exc
+                    srv.close()
+                    srv = None
+                    if getattr(exc, "errno", None) == 98:          # EADDRINUSE: the port is taken, try the next one
+                        break
+            if srv is None:
                 continue
             srv.listen(self.world_size)
             self._listener = srv
             break
         if self._listener is None:
             raise OSError("no free control-plane port in %d..%d: %s" % (port + 1, port + _PORT_SPAN, last))
-        while len(self._peers) < self.world_size - 1:
-            left = deadline - time.monotonic()
-            if left <= 0:
-                raise TimeoutError("control plane: %d of %d ranks joined" % (len(self._peers) + 1, self.world_size))
-            self._listener.settimeout(left)
-            try:
-                conn, _ = self._listener.accept()
-            except socket.timeout:
-                continue
+
+        claimed = set()
+
+        def handshake(conn):
             try:
                 conn.settimeout(5.0)
                 hello = _recv_exact(conn, 32 + 4)
                 peer = struct.unpack("<i", hello[32:])[0]
-                if hello[:32] != self._token or not (0 < peer < self.world_size) or peer in self._peers:
+                with self._lock:
+                    ok = (hmac.compare_digest(hello[:32], self._token) and 0 < peer < self.world_size
+                          and peer not in claimed)
+                    if ok:
+                        claimed.add(peer)                 # (claimed before the reply: a second claimant is refused)
+                if not ok:
                     conn.close()
-                    continue
-                conn.sendall(self._token)
-                conn.settimeout(None)
-                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                self._peers[peer] = conn
-            except (OSError, struct.error):
+                    return
+                try:
+                    conn.sendall(self._token)
+                    conn.settimeout(None)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    with self._lock:
+                        self._peers[peer] = conn          # (joined: the socket is ready for the collectives)
+                except OSError:
+                    with self._lock:
+                        claimed.discard(peer)
+                    conn.close()
+            except (OSError, struct.error, ConnectionError):
                 conn.close()
+
+        while True:
+            with self._lock:
+                joined = len(self._peers)
+            if joined >= self.world_size - 1:
+                break
+            left = deadline - time.monotonic()
+            if left <= 0:
+                raise TimeoutError("control plane: %d of %d ranks joined" % (joined + 1, self.world_size))
+            self._listener.settimeout(min(left, 0.2))
+            try:
+                conn, _ = self._listener.accept()
+            except socket.timeout:
+                continue
+            threading.Thread(target=handshake, args=(conn,), daemon=True).start()
 
     def _join(self, addr, port, deadline):
         while time.monotonic() < deadline:

@@ -58,10 +58,19 @@ const char *comm_tmp_dir() {
 // marker stem of (job, device) and the directory scan: 0 when no other live rank of this job uses the device, the other
 // rank's number + 1 otherwise
 std::string comm_marker_stem(const void *id_bytes, const char *bus_id) {
-    char stem[160];
+    char stem[256], host[64] = "";
     std::string bus(bus_id);
     for (char &ch : bus) if (ch == ':' || ch == '.' || ch == '/') ch = '-';
-    snprintf(stem, sizeof(stem), "paa_comm_%016llx_%s.", comm_id_hash(id_bytes, sizeof(ncclUniqueId)), bus.c_str());
+    // the host (and the pid namespace: two containers that share /tmp do not see each other's pids) is part of the name:
+    // on a shared TMPDIR the markers of other nodes are other files, never probed with kill() and never unlinked
+    if (gethostname(host, sizeof(host) - 1) != 0) host[0] = 0;
+    host[sizeof(host) - 1] = 0;
+    for (char *c = host; *c; ++c) if (*c == '/' || *c == '.') *c = '-';
+    char pidns[64] = "";
+    const ssize_t nl = readlink("/proc/self/ns/pid", pidns, sizeof(pidns) - 1);
+    pidns[nl > 0 ? nl : 0] = 0;
+    snprintf(stem, sizeof(stem), "paa_comm_%016llx_%s_%08llx_%s.", comm_id_hash(id_bytes, sizeof(ncclUniqueId)), host,
+             comm_id_hash(pidns, strlen(pidns)) & 0xffffffffULL, bus.c_str());
     return stem;
 }
 int comm_scan_device(const std::string &stem, int rank) {
@@ -92,10 +101,14 @@ void comm_release_device() {
 int comm_claim_device(const void *id_bytes, int rank, const char *bus_id) {
     const std::string stem = comm_marker_stem(id_bytes, bus_id);
     g_comm_marker = std::string(comm_tmp_dir()) + "/" + stem + std::to_string(rank);
-    FILE *f = fopen(g_comm_marker.c_str(), "w");
-    if (!f) { g_comm_marker.clear(); return 0; }                         // no writable tmp directory: no check possible
-    fprintf(f, "%ld\n", (long)getpid());
-    fclose(f);
+    // (a world-writable directory: never follow a link someone planted, never truncate a file that is not ours)
+    (void)unlink(g_comm_marker.c_str());                                  // a marker of an earlier run of this very rank
+    const int fd = open(g_comm_marker.c_str(), O_CREAT | O_EXCL | O_NOFOLLOW | O_WRONLY, 0600);
+    if (fd < 0) { g_comm_marker.clear(); return 0; }                     // no writable tmp directory: no check possible
+    char line[32];
+    const int len = snprintf(line, sizeof(line), "%ld\n", (long)getpid());
+    if (write(fd, line, (size_t)len) != len) { close(fd); comm_release_device(); return 0; }
+    close(fd);
     static bool at_exit = false;
     if (!at_exit) { atexit(comm_release_device); at_exit = true; }
     int clash = comm_scan_device(stem, rank);
@@ -145,6 +158,20 @@ extern "C" int paa_comm_unique_id(void *id_out) {
     NCCL_TRY(g_rccl.GetUniqueId(&id));
     memset(id_out, 0, PAA_COMM_ID_BYTES);
     memcpy(id_out, &id, sizeof(id));
+    return PAA_OK;
+}
+
+// file name (inside PAA_COMM_MARKER_DIR / TMPDIR) of the one-process-per-GPU marker of `rank` of the job `id_bytes` on the
+// selected device: tests plant a foreign rank's marker with it instead of re-deriving the naming scheme
+extern "C" int paa_debug_comm_marker_name(const void *id_bytes, int rank, char *out, int capacity) {
+    if (!id_bytes || !out || capacity < 32 || rank < 0) return fail(PAA_ERR_ARG, "bad argument");
+    int rc = ensure_init();
+    if (rc) return rc;
+    char bus[64] = "";
+    if ((rc = paa_device_bus_id(bus, (int)sizeof(bus)))) return rc;
+    const std::string name = comm_marker_stem(id_bytes, bus) + std::to_string(rank);
+    if ((int)name.size() + 1 > capacity) return fail(PAA_ERR_ARG, "capacity %d < %zu", capacity, name.size() + 1);
+    memcpy(out, name.c_str(), name.size() + 1);
     return PAA_OK;
 }
 
@@ -245,7 +272,15 @@ extern "C" int paa_comm_gather_f64(const double *d_send, const int64_t *counts, 
     return paa_comm_gatherv_f64(d_send, counts, displs.data(), root, d_recv);
 }
 
-// called by paa_plan_execute before it overwrites d_out
+// a freed buffer's event goes with it (every chunk piece of extract_sharded is a fresh allocation)
+static void comm_forget_buffer(const void *ptr) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_gather_done.find(ptr);
+    if (it == g_gather_done.end()) return;
+    if (it->second) { (void)hipEventSynchronize(it->second); (void)hipEventDestroy(it->second); }
+    g_gather_done.erase(it);
+}
+// called by the kernels' entry points before they overwrite a caller's buffer (g_mu held)
 static int comm_wait_buffer_free(const void *d_out) {
     auto it = g_gather_done.find(d_out);
     if (it != g_gather_done.end() && it->second) HIP_TRY(hipStreamWaitEvent(g_main_stream, it->second, 0));

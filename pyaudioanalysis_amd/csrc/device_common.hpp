@@ -2,6 +2,7 @@
 // gfx950 only: wavefront = 64 lanes, every workgroup of the feature kernels is ONE wave, so
 // __syncthreads() is an LDS/VMEM wait plus a one-wave barrier.
 #pragma once
+#include <float.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -77,6 +78,13 @@ struct PlanDev {
     int mode;               // 0 features, 1 spectrogram, 2 chromagram
     int frame_origin;       // first frame starts at this sample (0; W for spectrogram/chromagram)
     int debug;              // PAA_KERNEL_DEBUG bit mask (ablation experiments only; 0 in production)
+    // the statistics partials of clip_stats_*: the kernels of the main shapes fold them into ClipNorm themselves, one wave
+    // at a time in their prologue (norms_inline = 1), instead of waiting for clip_params_kernel -- 6 us and a kernel
+    // boundary per step for a one-hour clip
+    const void *st_sum, *st_min, *st_max;
+    double st_scale;        // sample_scale of the plan's sample type
+    int norms_inline;
+    int pad_;
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -351,5 +359,84 @@ template <> __device__ __forceinline__ double load_sample<stereo16>(const stereo
 }
 template <typename T> __host__ __device__ constexpr double sample_scale() { return 1.0 / 32768.0; }
 template <> __host__ __device__ constexpr double sample_scale<stereo16>() { return 1.0 / 65536.0; }
+
+// ---- clip constants from the statistics partials of one clip (ShortTermFeatures.py:14-19, :567-570): the partials are
+// folded lane-strided, then over a fixed xor tree (deterministic: every wave of every kernel gets the same bits); every lane
+// returns the same ClipNorm.  SumT / MmT: long long / int for the integer sample types (exact), double / double for float64.
+template <typename SumT, typename MmT>
+__device__ __forceinline__ ClipNorm clip_norm_wave(const ClipDev &cd, const SumT *__restrict__ psum,
+                                                   const MmT *__restrict__ pmin, const MmT *__restrict__ pmax, double sc,
+                                                   int window, int lane) {
+    SumT s = 0;
+    double mn = DBL_MAX, mx = -DBL_MAX;
+    const SumT *ps = psum + cd.stat_first;
+    const MmT *pn = pmin + cd.stat_first, *px = pmax + cd.stat_first;
+    int i = lane;
+    for (; i + 192 < cd.stat_count; i += 256) {          // four loads of each array in flight (same summation order)
+        SumT a[4];
+        MmT b[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = ps[i + 64 * u]; b[u] = pn[i + 64 * u]; c[u] = px[i + 64 * u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s += a[u]; mn = fmin(mn, (double)b[u]); mx = fmax(mx, (double)c[u]); }
+    }
+    for (; i < cd.stat_count; i += 64) {
+        s += ps[i];
+        mn = fmin(mn, (double)pn[i]);
+        mx = fmax(mx, (double)px[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        mn = fmin(mn, __shfl_xor(mn, o, 64));
+        mx = fmax(mx, __shfl_xor(mx, o, 64));
+    }
+    ClipNorm nm;
+    if (cd.n <= 0) { nm.mean = 0.0; nm.inv = 1.0; }
+    else {
+        nm.mean = ((double)s * sc) / (double)cd.n;
+        const double peak = fmax(fabs(fma(mx, sc, -nm.mean)), fabs(fma(mn, sc, -nm.mean)));
+        nm.inv = 1.0 / (peak + 1e-10);
+    }
+    nm.mu = nm.mean * 32768.0;
+    nm.m_int = (int)fmin(fmax(nearbyint(nm.mu), -40000.0), 40000.0);
+    nm.delta_mu = nm.mu - (double)nm.m_int;
+    nm.inv_sc = nm.inv * (1.0 / 32768.0);
+    nm.y_scale2 = nm.inv_sc * nm.inv_sc;
+    nm.mi = (double)nm.m_int;
+    nm.mag_scale = nm.inv_sc * (0.5 / (double)(window / 2));
+    nm.dc_shift = 2.0 * (double)window * nm.delta_mu;
+    nm.chunk_dmu = 40.0 * nm.delta_mu;
+    const double mu_fl = floor(nm.mu);
+    nm.zb = (int)fmin(fmax(mu_fl, -32768.0), 32767.0);
+    nm.mu_whole = (mu_fl == nm.mu) ? 1 : 0;
+    nm.pad = 0;
+    return nm;
+}
+// wave-uniform values computed with vector instructions, pinned into scalar registers
+__device__ __forceinline__ double uni_f64(double v) {
+    const unsigned long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+// the clip constants of a wave's clip: read (norms_inline = 0) or formed from the partials; wave-uniform either way
+template <typename T>
+__device__ __forceinline__ ClipNorm wave_clip_norm(const PlanDev &P, const ClipDev &cd, const ClipNorm *__restrict__ norms,
+                                                   int clip, int lane) {
+    if (!P.norms_inline) return norms[clip];
+    ClipNorm nm;
+    if constexpr (sizeof(T) == 8)
+        nm = clip_norm_wave<double, double>(cd, (const double *)P.st_sum, (const double *)P.st_min, (const double *)P.st_max,
+                                            P.st_scale, P.W, lane);
+    else
+        nm = clip_norm_wave<long long, int>(cd, (const long long *)P.st_sum, (const int *)P.st_min, (const int *)P.st_max,
+                                            P.st_scale, P.W, lane);
+    nm.mean = uni_f64(nm.mean); nm.inv = uni_f64(nm.inv); nm.mu = uni_f64(nm.mu); nm.delta_mu = uni_f64(nm.delta_mu);
+    nm.inv_sc = uni_f64(nm.inv_sc); nm.y_scale2 = uni_f64(nm.y_scale2); nm.mi = uni_f64(nm.mi);
+    nm.mag_scale = uni_f64(nm.mag_scale); nm.dc_shift = uni_f64(nm.dc_shift); nm.chunk_dmu = uni_f64(nm.chunk_dmu);
+    nm.m_int = __builtin_amdgcn_readfirstlane(nm.m_int); nm.zb = __builtin_amdgcn_readfirstlane(nm.zb);
+    nm.mu_whole = __builtin_amdgcn_readfirstlane(nm.mu_whole);
+    return nm;
+}
 
 }  // namespace paa

@@ -172,40 +172,8 @@ __global__ __launch_bounds__(64) void clip_params_kernel(const ClipDev *__restri
     const long long c = blockIdx.x;
     if (c >= n_clips) return;
     const ClipDev cd = clips[c];
-    SumT s = 0;
-    double mn = DBL_MAX, mx = -DBL_MAX;
-    for (int i = threadIdx.x; i < cd.stat_count; i += 64) {
-        s += psum[cd.stat_first + i];
-        mn = fmin(mn, (double)pmin[cd.stat_first + i]);
-        mx = fmax(mx, (double)pmax[cd.stat_first + i]);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s += __shfl_xor(s, o, 64);
-        mn = fmin(mn, __shfl_xor(mn, o, 64));
-        mx = fmax(mx, __shfl_xor(mx, o, 64));
-    }
+    const ClipNorm nm = clip_norm_wave<SumT, MmT>(cd, psum, pmin, pmax, sc, window, (int)threadIdx.x);
     if (threadIdx.x != 0) return;
-    ClipNorm nm;
-    if (cd.n <= 0) { nm.mean = 0.0; nm.inv = 1.0; }
-    else {
-        nm.mean = ((double)s * sc) / (double)cd.n;
-        const double peak = fmax(fabs(fma(mx, sc, -nm.mean)), fabs(fma(mn, sc, -nm.mean)));
-        nm.inv = 1.0 / (peak + 1e-10);
-    }
-    nm.mu = nm.mean * 32768.0;
-    nm.m_int = (int)fmin(fmax(nearbyint(nm.mu), -40000.0), 40000.0);
-    nm.delta_mu = nm.mu - (double)nm.m_int;
-    nm.inv_sc = nm.inv * (1.0 / 32768.0);
-    nm.y_scale2 = nm.inv_sc * nm.inv_sc;
-    nm.mi = (double)nm.m_int;
-    nm.mag_scale = nm.inv_sc * (0.5 / (double)(window / 2));
-    nm.dc_shift = 2.0 * (double)window * nm.delta_mu;
-    nm.chunk_dmu = 40.0 * nm.delta_mu;
-    const double mu_fl = floor(nm.mu);
-    nm.zb = (int)fmin(fmax(mu_fl, -32768.0), 32767.0);
-    nm.mu_whole = (mu_fl == nm.mu) ? 1 : 0;
-    nm.pad = 0;
     norms[c] = nm;
 }
 

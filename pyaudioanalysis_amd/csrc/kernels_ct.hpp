@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_ct_kernel(PlanDev P, TabLa
     int g = lane >> 4, i = lane & 15;
     const Tile tl = tiles[tile_id];
     const ClipDev c = clips[tl.clip];
-    const ClipNorm nm = norms[tl.clip];
+    const ClipNorm nm = wave_clip_norm<T>(P, c, norms, tl.clip, lane);
     const T *xc = sig + c.sample_off + P.frame_origin;
     const long long Tc = c.T;
     double *oc = out + c.out_off;
@@ -810,11 +810,11 @@ template <typename SH, typename T, int MODE, int DELTAS, int NW>
 inline int ct_launch_one(const CtLaunch &cl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                          const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
                          hipStream_t stream) {
-    static size_t attr_done = 0;
-    if (attr_done < cl.lds) {
+    static LdsAttrCache attr;
+    if (!attr.covers(cl.lds)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&st_ct_kernel<SH, T, MODE, DELTAS, NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)cl.lds) != hipSuccess) return -1;
-        attr_done = cl.lds;
+        attr.set(cl.lds);
     }
     const unsigned grid = (unsigned)((n_tiles + NW - 1) / NW);
     hipLaunchKernelGGL((st_ct_kernel<SH, T, MODE, DELTAS, NW>), dim3(grid), dim3(64 * NW), cl.lds, stream, P, cl.layout, blob,

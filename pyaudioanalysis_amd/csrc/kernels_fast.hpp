@@ -438,7 +438,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
     PAA_T0()
     const Tile tl = tiles[tile_id];
     const ClipDev c = clips[tl.clip];
-    const ClipNorm nm = norms[tl.clip];
+    const ClipNorm nm = wave_clip_norm<int16_t>(P, c, norms, tl.clip, lane);      // (formed from the partials in this prologue)
     const int16_t *xc = sig + c.sample_off;
     const long long Tc = c.T;
     double *oc = out + c.out_off;
@@ -1064,11 +1064,11 @@ template <int S, int DELTAS, int FIXED, int NW>
 inline int fast_launch_one(const FastLaunch &fl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                            const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,
                            double *d_out, hipStream_t stream) {
-    static size_t attr_done = 0;
-    if (attr_done < fl.lds) {
+    static LdsAttrCache attr;
+    if (!attr.covers(fl.lds)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&f800::st_fast_800_kernel<S, DELTAS, FIXED, NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl.lds) != hipSuccess) return -1;
-        attr_done = fl.lds;
+        attr.set(fl.lds);
     }
     const unsigned grid = (unsigned)((n_tiles + NW - 1) / NW);
     hipLaunchKernelGGL((f800::st_fast_800_kernel<S, DELTAS, FIXED, NW>), dim3(grid), dim3(64 * NW), fl.lds, stream,

@@ -512,7 +512,7 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
 
     const Tile tl = tiles[tile_id];
     const ClipDev c = clips[tl.clip];
-    const ClipNorm nm = norms[tl.clip];
+    const ClipNorm nm = wave_clip_norm<T>(P, c, norms, tl.clip, (int)(threadIdx.x & 63));
     const T *x0 = sig + c.sample_off + P.frame_origin;
     const long long Tc = c.T;
     double *oc = out + c.out_off;
@@ -1012,8 +1012,12 @@ template <typename SH, typename T, int MODE, int DELTAS>
 inline int tri_launch_one(const TriLaunch &tl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                           const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
                           hipStream_t stream) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&st_tri_kernel<SH, T, MODE, DELTAS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl.lds) != hipSuccess) return -1;
+    static LdsAttrCache attr;
+    if (!attr.covers(tl.lds)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&st_tri_kernel<SH, T, MODE, DELTAS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl.lds) != hipSuccess) return -1;
+        attr.set(tl.lds);
+    }
     const unsigned grid = (unsigned)((n_tiles + SH::NW - 1) / SH::NW);
     hipLaunchKernelGGL((st_tri_kernel<SH, T, MODE, DELTAS>), dim3(grid), dim3(64 * SH::NW), tl.lds, stream, P, tl.layout, blob,
                        (const T *)d_packed, clips, norms, tiles, (int)n_tiles, d_out);

@@ -141,6 +141,7 @@ static double g_prof_ms = 0.0;
 static long long g_prof_n = 0;
 
 static int comm_wait_buffer_free(const void *d_out);
+static void comm_forget_buffer(const void *ptr);
 static int comm_sync();
 
 // HIP's current device is a per-thread setting (device 0 until hipSetDevice): a host thread other than the one that
@@ -301,7 +302,17 @@ static int get_tables(double fs, int window, bool need_mel, bool need_chroma, Ta
 // ------------------------------------------------------------------------------------------
 // plans
 // ------------------------------------------------------------------------------------------
-constexpr int kStatChunk = 65536;
+constexpr int kStatChunk = 65536;          // samples per statistics workgroup (upper bound, see stat_chunk_for)
+// The statistics pass is an HBM-bound stream with every workgroup resident at once (8 per CU): 879 chunks of a one-hour
+// clip put 4 workgroups on some CUs and 3 on others, and the pass lasts as long as the CUs with 4.  A batch of at least one
+// chunk per CU is therefore cut into a whole multiple of num_cu chunks (1024 x 56 256 samples for the hour).
+static int stat_chunk_for(long long total_samples, int num_cu) {
+    const long long blocks = (total_samples + kStatChunk - 1) / kStatChunk;
+    if (blocks < num_cu) return kStatChunk;
+    const long long want = (blocks + num_cu - 1) / num_cu * num_cu;
+    const long long len = ((total_samples + want - 1) / want + 63) / 64 * 64;      // multiples of 64 samples keep the 16-byte body aligned
+    return (int)std::min<long long>(kStatChunk, std::max<long long>(len, 4096));
+}
 
 // Run length for the one-wave-per-run kernels.  A clip of T frames is cut into k = ceil(T / cap) runs of
 // len = ceil(T / k) frames rounded up to the kernel's quantum (so no clip ends in a short leftover run); a workgroup takes
@@ -350,6 +361,7 @@ struct paa_plan {
     std::vector<long long> alloc_rows;   // modes 1/2: rows the reference allocates per clip
     long long total_frames = 0, out_doubles = 0;
     TableSet *tab = nullptr;
+    int stat_chunk = kStatChunk;     // samples per statistics chunk of this plan
     PlanDev P;
     ClipDev *d_clips = nullptr;
     ClipNorm *d_norms = nullptr;
@@ -422,6 +434,8 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     p->clips.resize(n_clips);
     p->alloc_rows.assign(n_clips, 0);
     long long out_off = 0, total_frames = 0, n_chunks = 0;
+    p->stat_chunk = stat_chunk_for(offsets[n_clips] - offsets[0], g_num_cu);
+    const int kChunk = p->stat_chunk;
     for (int64_t c = 0; c < n_clips; ++c) {
         const long long n = offsets[c + 1] - offsets[c];
         if (n < 0) return fail(PAA_ERR_ARG, "offsets must be non-decreasing (clip %lld)", (long long)c);
@@ -454,7 +468,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         p->alloc_rows[c] = rows;
         cd.T = (int)T;
         cd.stat_first = (int)n_chunks;
-        cd.stat_count = (int)((n + kStatChunk - 1) / kStatChunk);
+        cd.stat_count = (int)((n + kChunk - 1) / kChunk);
         cd.pad = 0;
         n_chunks += cd.stat_count;
         total_frames += T;
@@ -598,8 +612,8 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     chunks.reserve((size_t)n_chunks);
     for (int64_t c = 0; c < n_clips; ++c)
         for (int i = 0; i < p->clips[c].stat_count; ++i) {
-            StatChunk ch; ch.start = p->clips[c].sample_off + (long long)i * kStatChunk;
-            ch.len = (int)std::min<long long>(kStatChunk, p->clips[c].n - (long long)i * kStatChunk);
+            StatChunk ch; ch.start = p->clips[c].sample_off + (long long)i * kChunk;
+            ch.len = (int)std::min<long long>(kChunk, p->clips[c].n - (long long)i * kChunk);
             ch.clip = (int)c;
             chunks.push_back(ch);
         }
@@ -610,6 +624,11 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     const size_t nch = (size_t)std::max<long long>(n_chunks, 1);
     if ((rc = pool_alloc(&p->d_psum, nch * 8)) || (rc = pool_alloc(&p->d_pmin, nch * 8)) ||
         (rc = pool_alloc(&p->d_pmax, nch * 8))) return rc;
+    // the kernels of the main shapes fold the statistics partials into the clip constants themselves; chromagram plans
+    // keep clip_params_kernel (the truncated-tail kernel of the host entry point reads its output)
+    P.st_sum = p->d_psum; P.st_min = p->d_pmin; P.st_max = p->d_pmax;
+    P.st_scale = sample_kind == 1 ? sample_scale<double>() : (sample_kind == 2 ? sample_scale<stereo16>() : sample_scale<int16_t>());
+    P.norms_inline = ((p->fast || p->ct || p->tri) && mode != 2) ? 1 : 0;
     *out = p.release();
     return PAA_OK;
 }
@@ -630,6 +649,10 @@ static int launch_stats(paa_plan *p, const void *d_packed) {
                                (double *)p->d_pmax);
     }
     const unsigned gb = (unsigned)p->n_clips;
+    if (p->P.norms_inline) {
+        HIP_TRY(hipGetLastError());
+        return PAA_OK;
+    }
     if (p->sample_kind == 1)
         hipLaunchKernelGGL((clip_params_kernel<double, double>), dim3(gb), dim3(64), 0, cs(), p->d_clips,
                            p->n_clips, (const double *)p->d_psum, (const double *)p->d_pmin,
@@ -644,11 +667,11 @@ static int launch_stats(paa_plan *p, const void *d_packed) {
 
 template <typename T>
 static int launch_generic(paa_plan *p, const void *d_packed, double *d_out) {
-    static size_t attr_set = 0;
-    if (p->lds > attr_set) {
+    static LdsAttrCache attr;
+    if (!attr.covers(p->lds)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&st_generic_kernel<T>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(p->lds, 64 * 1024)));
-        attr_set = std::max<size_t>(p->lds, 64 * 1024);
+        attr.set(std::max<size_t>(p->lds, 64 * 1024));
     }
     const unsigned grid = (unsigned)((p->n_tiles + p->gl.waves - 1) / p->gl.waves);
     hipLaunchKernelGGL(st_generic_kernel<T>, dim3(grid), dim3(64 * p->gl.waves), p->lds, cs(), p->P, p->gl,
@@ -659,11 +682,11 @@ static int launch_generic(paa_plan *p, const void *d_packed, double *d_out) {
 
 template <typename T, int TWG, int LEAN>
 static int launch_mix(paa_plan *p, const void *d_packed, double *d_out) {
-    static size_t attr_set = 0;
-    if (p->lds > attr_set) {
+    static LdsAttrCache attr;
+    if (!attr.covers(p->lds)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mix::st_mix_kernel<T, TWG, LEAN>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(p->lds, 64 * 1024)));
-        attr_set = std::max<size_t>(p->lds, 64 * 1024);
+        attr.set(std::max<size_t>(p->lds, 64 * 1024));
     }
     const unsigned grid = (unsigned)((p->n_tiles + p->ml.waves - 1) / p->ml.waves);
     hipLaunchKernelGGL((mix::st_mix_kernel<T, TWG, LEAN>), dim3(grid), dim3(64 * p->ml.waves), p->lds, cs(), p->P, p->ml,
@@ -683,11 +706,11 @@ static int launch_mix_any(paa_plan *p, const void *d_packed, double *d_out) {
 template <typename T>
 static int launch_reg(paa_plan *p, const void *d_packed, double *d_out) {
     using SH = reg::Shape1102;
-    static size_t attr_set = 0;
-    if (p->lds > attr_set) {
+    static LdsAttrCache attr;
+    if (!attr.covers(p->lds)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&reg::st_reg_kernel<SH, T>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(p->lds, 64 * 1024)));
-        attr_set = std::max<size_t>(p->lds, 64 * 1024);
+        attr.set(std::max<size_t>(p->lds, 64 * 1024));
     }
     const unsigned grid = (unsigned)((p->n_tiles + p->rl.waves - 1) / p->rl.waves);
     hipLaunchKernelGGL((reg::st_reg_kernel<SH, T>), dim3(grid), dim3(64 * p->rl.waves), p->lds, cs(), p->P, p->rl,
@@ -868,6 +891,7 @@ extern "C" int paa_plan_mid_execute(paa_plan_t *plan, const double *d_st, int64_
         return fail(PAA_ERR_ARG, "mid_step / short_step rounds to %lld: the reference loops forever "
                     "(MidTermFeatures.py:102,124)", (long long)mid_step_ratio);
     std::lock_guard<std::mutex> lk(g_mu);
+    { const int rc_w = comm_wait_buffer_free(d_mid); if (rc_w) return rc_w; }      // a gather of this buffer may still read it
     long long maxM = 0;
     if (plan->mid_off_step != mid_step_ratio) {
         std::vector<long long> off(plan->n_clips);
@@ -902,6 +926,7 @@ extern "C" int paa_plan_beat_execute(paa_plan_t *plan, const double *d_st, doubl
     const int max_beat = (int)nearbyint(2.0 / window_size);          // int(round(2.0 / window_size)), :33
     if (max_beat < 1 || max_beat > 4096) return fail(PAA_ERR_UNSUPPORTED, "beat histogram of %d bins", max_beat);
     std::lock_guard<std::mutex> lk(g_mu);
+    { const int rc_w = comm_wait_buffer_free(d_beat); if (rc_w) return rc_w; }
     const size_t lds = (size_t)kBeatRows * (kBeatTile + 1) * 8 + (size_t)kBeatRows * max_beat * 4;
     if (lds > 160 * 1024)
         return fail(PAA_ERR_UNSUPPORTED, "beat histogram of %d bins needs %zu bytes of LDS (160 KB per workgroup)", max_beat, lds);
@@ -945,11 +970,11 @@ extern "C" int paa_dev_self_similarity(const double *d_feats, int n_dims, int64_
                        d_norm);
     const unsigned tiles = (unsigned)(ldz / kSimTile);
     const size_t lds = (size_t)2 * kSimChunk * kSimPitch * 8 + 256 * 8;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static LdsAttrCache attr;
+    if (!attr.covers(lds)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sim_gram_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        attr.set(lds);
     }
     const long long n_tri = (long long)tiles * (tiles + 1) / 2;        // tiles on and above the diagonal; the rest are mirrored
     const dim3 gram_grid((unsigned)std::min<long long>(n_tri, 2LL * g_num_cu));
@@ -1121,6 +1146,7 @@ extern "C" void paa_shutdown(void) {
     if (g_main_stream) (void)hipStreamDestroy(g_main_stream);
     g_ev0 = g_ev1 = nullptr;
     g_main_stream = nullptr;
+    ++lds_attr_generation();                 // the next device has not seen any hipFuncSetAttribute
     g_device.store(-1, std::memory_order_release);
 }
 
@@ -1132,7 +1158,10 @@ extern "C" int paa_dev_alloc(size_t bytes, void **out_ptr) {
     return PAA_OK;
 }
 extern "C" int paa_dev_free(void *ptr) {
-    if (ptr) HIP_TRY(hipFree(ptr));
+    if (ptr) {
+        comm_forget_buffer(ptr);
+        HIP_TRY(hipFree(ptr));
+    }
     return PAA_OK;
 }
 extern "C" int paa_memcpy_d2d(void *dst, const void *src, size_t bytes) {
@@ -1152,6 +1181,15 @@ extern "C" int paa_memcpy_d2h(void *dst, const void *src, size_t bytes) {
     int rc = ensure_init();
     if (rc) return rc;
     if ((rc = comm_sync())) return rc;       // a gather into src may still run on the communication stream
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, cs()));
+    HIP_TRY(hipStreamSynchronize(cs()));
+    return PAA_OK;
+}
+// the same for a buffer that is only a SOURCE of queued gathers (or not gathered at all): ordered behind the kernels of the
+// compute stream, not behind the communication stream -- a rank whose peer died in the exchange can still save its block
+extern "C" int paa_memcpy_d2h_compute(void *dst, const void *src, size_t bytes) {
+    int rc = ensure_init();
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, cs()));
     HIP_TRY(hipStreamSynchronize(cs()));
     return PAA_OK;
@@ -1269,8 +1307,8 @@ static int run_host_st(const void *packed, const int64_t *offsets, int64_t n_cli
         std::vector<StatChunk> chunks;
         for (int64_t c = 0; c < n_clips; ++c)
             for (int i = 0; i < plan->clips[c].stat_count; ++i) {
-                StatChunk ch; ch.start = plan->clips[c].sample_off + (long long)i * kStatChunk;
-                ch.len = (int)std::min<long long>(kStatChunk, plan->clips[c].n - (long long)i * kStatChunk);
+                StatChunk ch; ch.start = plan->clips[c].sample_off + (long long)i * plan->stat_chunk;
+                ch.len = (int)std::min<long long>(plan->stat_chunk, plan->clips[c].n - (long long)i * plan->stat_chunk);
                 ch.clip = (int)c;
                 chunks.push_back(ch);
             }

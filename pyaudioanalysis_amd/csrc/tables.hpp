@@ -8,6 +8,7 @@
 //                     last writer wins, divisor indexed by slot position)
 //   FFT plan ........ replaces scipy.fftpack.fft at ShortTermFeatures.py:617
 #pragma once
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <vector>
@@ -15,6 +16,19 @@
 #include "../../include/paa_hip.h"
 
 namespace paa {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: the launchers' "already raised to N bytes" caches carry the
+// generation they were filled in, and paa_shutdown starts a new one (a later paa_init may select another device)
+inline std::atomic<int> &lds_attr_generation() {
+    static std::atomic<int> g{0};
+    return g;
+}
+struct LdsAttrCache {
+    size_t bytes = 0;
+    int generation = -1;
+    bool covers(size_t need) const { return generation == lds_attr_generation().load() && bytes >= need; }
+    void set(size_t b) { bytes = b; generation = lds_attr_generation().load(); }
+};
 
 constexpr int kNumMel = 40;
 constexpr int kNumMfcc = 13;

@@ -139,8 +139,8 @@ class _DeviceView:
         self.ptr = ctypes.c_void_p(parent.ptr.value + 8 * offset_doubles)
         self.nbytes = 8 * n_doubles
 
-    def to_host(self, dtype, count, offset_bytes=0):
-        return self.parent.to_host(dtype, count, offset_bytes + self.ptr.value - self.parent.ptr.value)
+    def to_host(self, dtype, count, offset_bytes=0, wait_comm=True):
+        return self.parent.to_host(dtype, count, offset_bytes + self.ptr.value - self.parent.ptr.value, wait_comm)
 
 
 class HipEngine:
@@ -182,6 +182,10 @@ class HipEngine:
 
     def to_host(self, buf, n_doubles):
         return buf.to_host(np.float64, int(n_doubles))
+
+    def to_host_source(self, buf, n_doubles):
+        """A buffer that is at most the SOURCE of queued gathers: the copy waits for the kernels, not for the exchange."""
+        return buf.to_host(np.float64, int(n_doubles), wait_comm=False)
 
     def upload(self, flat):
         """float64 host block (a restart file) -> device buffer"""
@@ -303,9 +307,11 @@ def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank
         comm.gather(d_piece, np.array([pieces[r][k][2] for r in range(world_size)], dtype=np.int64), root, d_all,
                     np.array([pieces[r][k][3] for r in range(world_size)], dtype=np.int64))
     if shard_file is not None and d_block is None:
-        # written BEFORE waiting for the gathers (to_host is ordered behind the kernels only): a job that dies in the
-        # exchange, or on another rank, still leaves this rank's finished block behind
-        parts = [engine.to_host(d, cnt) for d, cnt in sent if cnt]
+        # written BEFORE waiting for the gathers: the pieces are only SOURCES of the queued exchange, so they are copied
+        # with the compute-stream-only variant (paa_memcpy_d2h_compute) -- a job that dies in the exchange, or on another
+        # rank, still leaves this rank's finished block behind (the plain to_host waits for the communication stream)
+        to_host_source = getattr(engine, "to_host_source", engine.to_host)
+        parts = [to_host_source(d, cnt) for d, cnt in sent if cnt]
         tmp = shard_file + ".tmp.npz"
         np.savez(tmp, key=np.array(key), block=np.concatenate(parts) if len(parts) > 1 else parts[0])
         os.replace(tmp, shard_file)

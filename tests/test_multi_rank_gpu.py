@@ -98,26 +98,49 @@ def test_two_ranks_rccl_gather_or_clean_failure(gpu_lib):
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
 
 
-def test_comm_init_refuses_a_device_another_live_rank_of_the_job_holds(gpu_lib, tmp_path, monkeypatch):
-    """Backstop inside paa_comm_init (no control plane): a marker for this job id and this PCI bus id that names a live
-    process as "rank 1" makes rank 0 fail with PAA_ERR_COMM before RCCL is called; paa_comm_destroy removes rank 0's
-    own marker again."""
+def _marker_refusal_child(marker_dir, queue):
+    """Child of the test below (own process: should the guard ever fail, ncclCommInitRank waits for a rank that does not
+    exist -- the parent kills this process instead of hanging the suite)."""
     import ctypes
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["PAA_COMM_MARKER_DIR"] = marker_dir
     from pyaudioanalysis_amd import _ffi
-    monkeypatch.setenv("PAA_COMM_MARKER_DIR", str(tmp_path))
-    bus = ctypes.create_string_buffer(64)
-    _ffi.check(gpu_lib.paa_device_bus_id(bus, 64))
-    assert bus.value.count(b":") == 2, bus.value                       # "0000:75:00.0"
+    lib = _ffi.lib()
+    _ffi.init(0)
     buf = ctypes.create_string_buffer(_ffi.COMM_ID_BYTES)
-    _ffi.check(gpu_lib.paa_comm_unique_id(buf))
-    # FNV-1a of the first sizeof(ncclUniqueId) = 128 bytes, as comm_rccl.hpp names the markers
-    h = 1469598103934665603
-    for byte in buf.raw[:128]:
-        h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
-    stem = "paa_comm_%016x_%s." % (h, bus.value.decode().replace(":", "-").replace(".", "-"))
-    (tmp_path / (stem + "1")).write_text("%d\n" % os.getpid())         # "rank 1" = this (live) process
-    rc = gpu_lib.paa_comm_init(2, 0, buf)
-    assert rc == _ffi.ERR_COMM, rc
-    assert "one process per GPU" in _ffi.last_error(), _ffi.last_error()
-    gpu_lib.paa_comm_destroy()                                            # removes rank 0's own marker
-    assert sorted(p.name for p in tmp_path.iterdir()) == [stem + "1"]
+    _ffi.check(lib.paa_comm_unique_id(buf))
+    name = ctypes.create_string_buffer(256)
+    _ffi.check(lib.paa_debug_comm_marker_name(buf, 1, name, 256))
+    other = name.value.decode()
+    with open(os.path.join(marker_dir, other), "w") as f:          # "rank 1" = the parent of this process: alive
+        f.write("%d\n" % os.getppid())
+    rc = lib.paa_comm_init(2, 0, buf)
+    msg = _ffi.last_error()
+    lib.paa_comm_destroy()                                           # removes rank 0's own marker
+    queue.put((rc, msg, other, sorted(os.listdir(marker_dir))))
+
+
+def test_comm_init_refuses_a_device_another_live_rank_of_the_job_holds(gpu_lib, tmp_path):
+    """Backstop inside paa_comm_init (no control plane): a marker for this job id and this device that names a live
+    process as "rank 1" makes rank 0 fail with PAA_ERR_COMM before RCCL is called; paa_comm_destroy removes rank 0's
+    own marker again.  The marker's name comes from the library (paa_debug_comm_marker_name: host, pid namespace and PCI
+    bus id are part of it)."""
+    import multiprocessing as mp
+    from pyaudioanalysis_amd import _ffi
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_marker_refusal_child, args=(str(tmp_path), q))
+    p.start()
+    p.join(120)
+    if p.is_alive():
+        p.kill()
+        p.join()
+        pytest.fail("paa_comm_init did not refuse the device within 120 s (it is waiting inside ncclCommInitRank)")
+    assert p.exitcode == 0, p.exitcode
+    rc, msg, other, left = q.get(timeout=10)
+    assert rc == _ffi.ERR_COMM, (rc, msg)
+    assert "one process per GPU" in msg, msg
+    assert other.startswith("paa_comm_") and other.endswith(".1")
+    assert left == [other]
