@@ -114,7 +114,7 @@ def main():
     print("total %.2f MB" % (tot / 1e6))
 
 
-if __name__ == "__main__" and not any(a in sys.argv for a in ("--dir", "--thumb", "--wide", "--silence")):
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--dir", "--thumb", "--wide", "--silence", "--round3", "--round4")):
     main()
 
 
@@ -334,3 +334,41 @@ def round3_goldens():
 
 if __name__ == "__main__" and "--round3" in sys.argv:
     round3_goldens()
+
+
+def round4_goldens():
+    """Round 4: outputs of the unmodified reference at the shapes the three-pass register-FFT kernels (csrc/kernels_tri.hpp)
+    took over -- the 50 ms window at 11.025 kHz and the 25 ms window at 22.05 kHz (551 samples, odd: 19 x 29; window and step
+    are passed as the FLOATS the reference's callers compute, 0.050 * fs = 551.25 -> int() = 551), 40 ms at 44.1 kHz as
+    features, 50 ms at 24 kHz."""
+    from synth import synth_clip
+    ref_st, ref_mt, ref_io = load_reference.load()
+
+    def st_case(name, sig, fs, win, step, deltas=True):
+        F, names = ref_st.feature_extraction(sig, fs, win, step, deltas)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="st", signal=sig, fs=fs, window=win, step=step,
+                            deltas=deltas, features=F, names=np.array(names))
+        print(name, F.shape)
+
+    def spec_case(name, sig, fs, win, step):
+        with contextlib.redirect_stdout(io.StringIO()):
+            S, t_ax, f_ax = ref_st.spectrogram(sig, fs, win, step)
+        C, ct_ax, cf_ax = ref_st.chromagram(sig, fs, win, step)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="spec", signal=sig, fs=fs, window=win, step=step,
+                            specgram=S, spec_time=np.array(t_ax), spec_freq=np.array(f_ax), chromagram=C,
+                            chroma_time=np.array(ct_ax), chroma_names=np.array(cf_ax))
+        print(name, S.shape, C.shape)
+
+    x11 = synth_clip(1102, 3 * 11025, 11025)
+    st_case("synth11k_551_275", x11, 11025, 0.050 * 11025, 0.025 * 11025)     # audioTrainTest.py:28-29 at 11.025 kHz
+    spec_case("synth11k_spec_551_275", x11, 11025, 551, 275)
+    x22 = synth_clip(2205, 2 * 22050, 22050)
+    st_case("synth22k_551_220", x22, 22050, 0.025 * 22050, 0.010 * 22050)
+    fs, x = wav("pyAudioAnalysis/data/3WORDS.wav", 2.0)                     # 44.1 kHz speech
+    st_case("3words2s_1764_882", x, fs, 1764, 882)
+    x24 = synth_clip(2400, 2 * 24000, 24000)
+    st_case("synth24k_1200_600_nodelta", x24, 24000, 1200, 600, deltas=False)
+
+
+if __name__ == "__main__" and "--round4" in sys.argv:
+    round4_goldens()

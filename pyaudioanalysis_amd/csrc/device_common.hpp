@@ -12,6 +12,13 @@ constexpr int kWave = 64;
 constexpr int kBase = 34;          // base feature rows (ShortTermFeatures.py:580-585)
 constexpr int kFlush = 8;          // frames staged in LDS before a row-segment store
 constexpr double kEps = 2.220446049250313e-16;   // sys.float_info.epsilon (ShortTermFeatures.py:11)
+// ablation bits of PlanDev::debug (scripts/reg_ablate.py, scripts/write_traffic_ab.sh): compiled in only with
+// -DPAA_EXPERIMENTS; the default build has no code that could skip a stage or drop a store
+#ifdef PAA_EXPERIMENTS
+#define PAA_DEBUG_BIT(word, bit) (((word) & (bit)) != 0)
+#else
+#define PAA_DEBUG_BIT(word, bit) false
+#endif
 
 struct ClipDev {        // one per clip, built on the host
     long long sample_off;   // first sample in the packed buffer

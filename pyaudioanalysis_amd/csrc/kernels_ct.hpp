@@ -734,7 +734,7 @@ inline void ct_fill(const FftPlan &fft, const MelTable *mel, const ChromaTable *
     L.off_sync = take(16 * 4);
     L.total = off;
     {
-        const char *pm = getenv("PAA_F800_PACE");
+        const char *pm = experiment_env("PAA_F800_PACE");
         L.pace = (pm && pm[0] == '0') ? 0 : 1;
     }
     L.f0 = fs / (2.0 * (double)SH::NF);

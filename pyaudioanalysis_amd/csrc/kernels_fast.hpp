@@ -308,8 +308,10 @@ __device__ __forceinline__ double sel64(unsigned long long take_a, double a, dou
 // store costs one 32-byte write request whatever its size (measured), so a chunk shared by two runs is written in 2..4
 // requests instead of 8
 __device__ __forceinline__ void store_chunk_pieces(double *dst, const double (&o)[8], int vlo, int vhi, int dbg = 0) {
-    if ((dbg & 4) && !(vlo <= 0 && vhi >= 8)) return;     // PAA_KERNEL_DEBUG bit 4: drop partial chunks, bit 8: drop whole ones
-    if ((dbg & 8) && (vlo <= 0 && vhi >= 8)) return;      // (traffic experiments only)
+    // (-DPAA_EXPERIMENTS builds only: PAA_KERNEL_DEBUG bit 4 drops partial chunks, bit 8 whole ones -- traffic experiments)
+    if (PAA_DEBUG_BIT(dbg, 4) && !(vlo <= 0 && vhi >= 8)) return;
+    if (PAA_DEBUG_BIT(dbg, 8) && (vlo <= 0 && vhi >= 8)) return;
+    (void)dbg;
     typedef double f64x4 __attribute__((ext_vector_type(4), aligned(32)));
     typedef double f64x2 __attribute__((ext_vector_type(2), aligned(16)));
     if (vlo <= 0 && vhi >= 8) {                           // the whole chunk: four 16-byte stores back to back
@@ -1004,17 +1006,23 @@ inline int fast_select(int window, int step, int sample_kind, double fs, FastTab
     L.off_sync = take(16 * 4);
     L.total = off;
     {
-        const char *pm = getenv("PAA_F800_PACE");          // A/B switch of the pacing (default 1: 0.314 ms; 0: 0.329 on cfg2)
+        const char *pm = experiment_env("PAA_F800_PACE");          // A/B switch of the pacing (default 1: 0.314 ms; 0: 0.329 on cfg2)
         L.pace_mode = (pm && pm[0] == '0') ? 0 : 1;
     }
     L.f0 = fs / (2.0 * (double)f800::NF);
     L.rf0 = 1.0 / L.f0;
     L.r_half_fs = 1.0 / (fs / 2.0);
     L.f0sq = L.f0 * L.f0;
+#ifdef PAA_EXPERIMENTS
     if (nw == 8 && (size_t)L.total + (size_t)nw * wave_bytes > 160 * 1024) {      // tables too large: one wave per SIMD
         nw = 4;
         wave_bytes = (step == 400) ? f800::Geo<400, 4>::WAVE_BYTES : f800::Geo<800, 4>::WAVE_BYTES;
     }
+#else
+    // (very low sampling rates: mel / chroma lists too long for eight waves -- the 2 RA RB family or the mixed-radix kernel
+    // takes the shape; the one-wave-per-SIMD instances exist only in -DPAA_EXPERIMENTS builds)
+    if (nw != 8) return 0;
+#endif
     if ((size_t)L.total + (size_t)nw * wave_bytes > 160 * 1024) return 0;   // generic kernel instead
     if (!ft.d_blob) {
         std::vector<unsigned char> blob((size_t)L.total, 0);
@@ -1094,10 +1102,12 @@ inline int fast_launch(const FastLaunch &fl, const PlanDev &P, const FastTables 
     const unsigned char *blob = reinterpret_cast<const unsigned char *>(ft.d_blob);
     if (fl.variant == 800 && fl.waves_per_cu == 8)
         return fast_launch_step<400, 8>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
-    if (fl.variant == 800) return fast_launch_step<400, 4>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
     if (fl.variant == 1600 && fl.waves_per_cu == 8)
         return fast_launch_step<800, 8>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+#ifdef PAA_EXPERIMENTS      // the one-wave-per-SIMD instances (NW = 4, ~340 registers) are the A/B baseline of scripts/ab_waves.sh
+    if (fl.variant == 800) return fast_launch_step<400, 4>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
     if (fl.variant == 1600) return fast_launch_step<800, 4>(fl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+#endif
     return -1;
 }
 

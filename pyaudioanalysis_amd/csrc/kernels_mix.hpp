@@ -681,7 +681,7 @@ inline int mix_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
     set_passes();
     L.unit_bytes = (Nf * 8 + 15) / 16 * 16;
     // (the skew is an instance of the kernel: it is decided with the lean instance below; room for it is reserved here)
-    L.pad_shift = (Nc % 32 == 0 && !getenv("PAA_MIX_NO_SKEW")) ? 5 : 31;
+    L.pad_shift = (Nc % 32 == 0 && !experiment_env("PAA_MIX_NO_SKEW")) ? 5 : 31;
     L.buf_bytes = (Nc + (Nc >> L.pad_shift)) * 16;
     const int FF = F > 0 ? F : 1;
     L.wave_bytes = (L.buf_bytes + L.unit_bytes + kFlush * FF * 8 + 48 * 8 + 40 * 8 + 15) / 16 * 16;
@@ -709,7 +709,7 @@ inline int mix_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
     // the twiddle tables go to LDS unless that costs a wave
     int w_lds = lay(0, 4), w_glob = lay(1, 4);
     L.tw_global = (w_glob > w_lds) ? 1 : 0;
-    if (const char *force = getenv("PAA_MIX_TW_GLOBAL")) L.tw_global = atoi(force) ? 1 : 0;      // A/B experiments
+    if (const char *force = experiment_env("PAA_MIX_TW_GLOBAL")) L.tw_global = atoi(force) ? 1 : 0;      // A/B experiments
     L.waves = lay(L.tw_global, 4);
     if (L.waves < 1) return 0;
     // small windows: the LDS has room for more than four waves -- the lean instance (<= 256 registers, fewer butterflies
@@ -718,7 +718,7 @@ inline int mix_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
     const bool lean_fits = fft.even ? (Nc / 2 + 1 <= kWave * kSlotsLean) : (Nf <= 2 * kWave * kSlotsLean);
     bool small_radices = true;         // (the radix-11 / 13 / 16 butterflies need more registers than the lean instance has)
     for (int r : radix) small_radices &= (r <= 8 || r == 16);
-    if (lean_fits && small_radices && !getenv("PAA_MIX_NO_LEAN")) {
+    if (lean_fits && small_radices && !experiment_env("PAA_MIX_NO_LEAN")) {
         w_lds = lay(0, 8); w_glob = lay(1, 8);
         const int g8 = (w_glob > w_lds) ? 1 : 0, w8 = std::max(w_lds, w_glob);
         if (w8 >= 6) { L.lean = 1; L.tw_global = g8; L.waves = lay(g8, 8); }

@@ -722,7 +722,7 @@ __global__ __launch_bounds__(512) void st_reg_kernel(PlanDev P, RegLayout L, con
         const bool act_b = fb < Q;
         const int pcolb = (pcol == 0) ? 0 : R1 - pcol;
         // ---------------- time-domain features of the iteration's Q frames, 16 lanes per frame (results pass through LDS)
-        if (P.mode == 0 && (store_it || P.deltas) && !(P.debug & 1)) time_features_grouped<SH, T>(x0, P.S, tq, tend, nm, tfs, lane_o);
+        if (P.mode == 0 && (store_it || P.deltas) && !PAA_DEBUG_BIT(P.debug, 1)) time_features_grouped<SH, T>(x0, P.S, tq, tend, nm, tfs, lane_o);
         // ---------------- pass A: radix-R1 over n1, inputs z[(R2 n1 + R1 n2) mod NC] from global memory
         double yim[R1];
         {
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(512) void st_reg_kernel(PlanDev P, RegLayout L, con
         wsync();
         // ---------------- the 34 features of the Q frames at once (16 lanes per frame), then the staging tile
         if (P.mode == 0) {
-            if ((store_it || P.deltas) && !(P.debug & 2))
+            if ((store_it || P.deltas) && !PAA_DEBUG_BIT(P.debug, 2))
                 frame_features_grouped<SH>(P, tb, slots, slot0, ring, tq, tfs, fv, msp, tmpq, lane_o);
 #pragma nounroll
             for (int f = 0; f < Q; ++f) {

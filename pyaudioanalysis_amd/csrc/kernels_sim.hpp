@@ -156,7 +156,11 @@ __global__ __launch_bounds__(512, 4) void sim_gram_kernel(const double *__restri
             *reinterpret_cast<double2 *>(pb + (prow + 8 * q) * kSimPitch + 2 * pc2) = make_double2(fbx[q], fby[q]);
         }
         // (rnorm is padded to ld entries; kept in LDS so that the epilogue holds no norms in registers)
-        if (k0 == 0 && threadIdx.x < 256) nrm[threadIdx.x] = rnorm[(threadIdx.x < 128 ? i0 : j0 - 128) + threadIdx.x];
+        if (k0 == 0) {
+            int tn = threadIdx.x;                                    // (opaque: rnorm + 8 tid is not kept across the tile loop)
+            asm volatile("" : "+v"(tn));
+            if (tn < 256) nrm[tn] = rnorm[(tn < 128 ? i0 : j0 - 128) + tn];
+        }
         __syncthreads();
         if (k0 + kSimChunk < dims_pad) PAA_SIM_FETCH(k0 + kSimChunk, i0, j0)
         // operand maps of v_mfma_f64_16x16x4_f64: A[m = lane & 15][k = lane >> 4], B[k = lane >> 4][n = lane & 15];
@@ -228,7 +232,10 @@ __global__ __launch_bounds__(512, 4) void sim_gram_kernel(const double *__restri
         }
     }
     if (tile + gridDim.x < n_tri) {               // first chunk of this workgroup's next tile
-        sim_tri_tile(tile + gridDim.x, tiles, ti, tj);
+        // (opaque per tile: hoisted out of the persistent loop, (double)(2 tiles + 1) lived in scratch at the 128-register budget)
+        long long tiles_o = tiles;
+        asm volatile("" : "+s"(tiles_o));
+        sim_tri_tile(tile + gridDim.x, tiles_o, ti, tj);
         PAA_SIM_FETCH(0, ti * kSimTile, tj * kSimTile)
     }
     }   // tile loop

@@ -491,7 +491,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     P.blk_t = window / 10; P.blk_f = Nf / 10;
     P.mode = mode;
     P.frame_origin = (mode == 0) ? 0 : window;
-    { const char *dbg = getenv("PAA_KERNEL_DEBUG"); P.debug = dbg ? atoi(dbg) : 0; }
+    { const char *dbg = experiment_env("PAA_KERNEL_DEBUG"); P.debug = dbg ? atoi(dbg) : 0; }
 
     // ---- kernel choice + tiles
     p->fast = 0;
@@ -529,7 +529,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
             p->tri = 1;
         }
     }
-    if (!p->fast && !p->ct && !p->reg && !p->tri && !g_force_generic && !getenv("PAA_NO_MIX")) {
+    if (!p->fast && !p->ct && !p->reg && !p->tri && !g_force_generic && !experiment_env("PAA_NO_MIX")) {
         // FFT lengths made of 2, 3, 5, 7, 11, 13 (50 ms at 44.1 / 48 kHz, 1024, ...): in-place transform, 4 waves per CU
         std::vector<unsigned char> blob;
         if (mix::mix_layout(tab->fft, mode == 0 ? &tab->mel : nullptr, mode != 1 ? &tab->chroma : nullptr, F, p->ml, &blob)) {
@@ -569,7 +569,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         // one wave per run, in multiples of the 4-frame quad, at most fl.run frames (halo = one quad); see choose_run_cap
         run_quantum = 4;
         run = choose_run_cap(p->clips, 4, 16, p->fl.run, 4, p->fl.waves_per_cu, g_num_cu);
-        if (const char *rc_env = getenv("PAA_RUN_CAP")) run = std::max(16, atoi(rc_env) / 4 * 4);      // A/B experiments only
+        if (const char *rc_env = experiment_env("PAA_RUN_CAP")) run = std::max(16, atoi(rc_env) / 4 * 4);      // A/B experiments only
         p->lds = p->fl.lds;
         p->kernel_name = p->fl.name;
     } else {
@@ -1120,9 +1120,9 @@ extern "C" int paa_init(int device_id) {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && ncu > 0) g_num_cu = ncu;
     }
-    const char *fg = getenv("PAA_HIP_FORCE_GENERIC");
+    const char *fg = experiment_env("PAA_HIP_FORCE_GENERIC");
     g_force_generic = (fg && fg[0] == '1') ? 1 : 0;
-    const char *fw = getenv("PAA_F800_WAVES");          // 4: one wave per SIMD, 8: two (A/B switch, default 8)
+    const char *fw = experiment_env("PAA_F800_WAVES");          // 4: one wave per SIMD, 8: two (A/B switch, default 8)
     g_f800_waves = (fw && fw[0] == '4') ? 4 : 8;
     g_device.store(device_id, std::memory_order_release);      // published last: ensure_init's fast path sees a complete state
     return PAA_OK;

@@ -11,6 +11,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/paa_hip.h"
@@ -29,6 +30,19 @@ struct LdsAttrCache {
     bool covers(size_t need) const { return generation == lds_attr_generation().load() && bytes >= need; }
     void set(size_t b) { bytes = b; generation = lds_attr_generation().load(); }
 };
+
+// Experiment switches of the A/B scripts under scripts/ (PAA_KERNEL_DEBUG, PAA_RUN_CAP, PAA_NO_MIX, PAA_F800_WAVES,
+// PAA_F800_PACE, PAA_MIX_*, PAA_HIP_FORCE_GENERIC) exist only in builds with -DPAA_EXPERIMENTS
+// (PAA_HIPCC_FLAGS=-DPAA_EXPERIMENTS python -m pyaudioanalysis_amd._build): in the default build no environment variable
+// can change which kernel runs or what it stores.
+inline const char *experiment_env(const char *name) {
+#ifdef PAA_EXPERIMENTS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 constexpr int kNumMel = 40;
 constexpr int kNumMfcc = 13;

@@ -299,3 +299,14 @@ def test_mixed_radix_plan_declines_other_windows():
     ln = ctypes.c_int32()
     for window in (1103, 1102, 58, 2 * 17 * 64):          # prime, 2 x 19 x 29, too small, a factor of 17
         assert lib.paa_debug_mix_plan(window, rad.ctypes.data_as(_ffi.c_i32p), ctypes.byref(ln), None, 0, None, None) == 0
+
+
+def test_default_build_has_no_experiment_switches():
+    """The A/B switches of scripts/ (PAA_KERNEL_DEBUG could drop output stores, PAA_RUN_CAP / PAA_NO_MIX / PAA_F800_WAVES
+    change the kernel choice) are compiled in only with -DPAA_EXPERIMENTS: the shipped binary does not even contain their
+    names, so no environment variable can change what the product computes."""
+    from pyaudioanalysis_amd import _ffi
+    blob = open(_ffi.library_path(), "rb").read()
+    for name in (b"PAA_KERNEL_DEBUG", b"PAA_RUN_CAP", b"PAA_NO_MIX", b"PAA_F800_WAVES", b"PAA_F800_PACE", b"PAA_MIX_NO_LEAN",
+                 b"PAA_MIX_TW_GLOBAL", b"PAA_MIX_NO_SKEW", b"PAA_HIP_FORCE_GENERIC"):
+        assert name not in blob, name

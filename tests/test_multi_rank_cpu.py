@@ -248,3 +248,70 @@ def test_socket_control_plane_world_3():
     if squatter is not None:
         squatter.close()
     assert got == [(0, True), (1, True), (2, True)]
+
+
+def test_restart_shard_is_on_disk_while_the_exchange_is_still_blocked(tmp_path):
+    """A rank whose peer died in the exchange never gets out of the communication stream.  Its finished block must be on
+    disk by then: extract_sharded saves the pieces through the engine's compute-stream-only copy (to_host_source ->
+    paa_memcpy_d2h_compute) BEFORE it waits for the gathers; the plain to_host would wait for the exchange (advisor, round 3)."""
+    import threading
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import paa_oracle as O
+    from synth import synth_clip
+    from pyaudioanalysis_amd import distributed as D
+
+    exchange_done = threading.Event()           # never set while the assertions run: the "peer" is dead
+
+    class BlockingEngine(_OracleEngine):
+        def __init__(self):
+            super().__init__(O)
+            self.plain_to_host_calls = 0
+
+        def to_host(self, buf, n_doubles):      # = paa_memcpy_d2h: waits for the communication stream
+            self.plain_to_host_calls += 1
+            exchange_done.wait()
+            return super().to_host(buf, n_doubles)
+
+        def to_host_source(self, buf, n_doubles):      # = paa_memcpy_d2h_compute: kernels only
+            return _OracleEngine.to_host(self, buf, n_doubles)
+
+        def sync(self):                         # = paa_dev_sync: both streams
+            exchange_done.wait()
+
+    class QueuedGather:                         # the gather is only QUEUED (RCCL on its own stream)
+        def gather(self, send, counts, root, recv, displs=None):
+            pass
+
+        def barrier(self):
+            pass
+
+        def close(self):
+            pass
+
+    clips = [synth_clip(700 + i, n) for i, n in enumerate([4000, 2400, 5200])]
+    engine = BlockingEngine()
+    res = {}
+
+    def run():
+        res["out"] = D.extract_sharded(clips, 16000, 800, 400, True, 2, 1, QueuedGather(), root=0, engine=engine,
+                                       restart_dir=str(tmp_path), chunks=2)
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    shard = tmp_path / "shard_001_of_002.npz"
+    for _ in range(600):
+        if shard.exists() or not th.is_alive():
+            break
+        th.join(0.05)
+    assert th.is_alive(), "extract_sharded must still be waiting for the exchange"
+    assert shard.exists(), "the rank's block must be saved before it waits for the exchange"
+    assert engine.plain_to_host_calls == 0
+    with np.load(shard, allow_pickle=False) as z:
+        frames = D.frames_per_clip([len(c) for c in clips], 800, 400)
+        a, b = D.partition_by_frames(frames, 2)[1]
+        want = np.concatenate([O.feature_extraction(c, 16000, 800, 400, True)[0].reshape(-1) for c in clips[a:b]])
+        assert np.array_equal(z["block"], want)
+    exchange_done.set()
+    th.join(30)
+    assert not th.is_alive() and res["out"] is None

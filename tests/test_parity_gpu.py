@@ -423,3 +423,29 @@ def test_random_window_step_sweep(gpu_lib, seed):
     got, _ = ShortTermFeatures.feature_extraction(x, fs, window, step)
     ill = O.ill_conditioned_mfcc_frames(x, fs, window, step)
     assert_parity(got, ref, "fs=%d W=%d S=%d" % (fs, window, step), ill)
+
+
+def test_experiment_switches_change_nothing_in_the_default_build(gpu_lib, monkeypatch):
+    """PAA_KERNEL_DEBUG (bits 4 / 8 used to drop output stores), PAA_RUN_CAP, PAA_NO_MIX, PAA_F800_WAVES ... are read only by
+    -DPAA_EXPERIMENTS builds: with all of them set, plans pick the same kernels and every output bit is the same."""
+    from synth import synth_clip
+    cases = [(16000, 800, 400), (16000, 640, 640), (16000, 1024, 512), (44100, 1102, 441)]
+    clips = {c: synth_clip(77 + i, 3 * c[0], c[0]) for i, c in enumerate(cases)}
+
+    def run():
+        out = {}
+        for (fs, w, s) in cases:
+            plan = _ffi.Plan(np.array([0, 3 * fs], dtype=np.int64), fs, w, s, deltas=True, sample_kind=0)
+            name = plan.kernel_name
+            plan.destroy()
+            F, _ = ShortTermFeatures.feature_extraction(clips[(fs, w, s)], fs, w, s)
+            out[(fs, w, s)] = (name, F)
+        return out
+    before = run()
+    for k, v in {"PAA_KERNEL_DEBUG": "15", "PAA_RUN_CAP": "16", "PAA_NO_MIX": "1", "PAA_F800_WAVES": "4", "PAA_F800_PACE": "0",
+                 "PAA_MIX_NO_LEAN": "1", "PAA_MIX_TW_GLOBAL": "1", "PAA_MIX_NO_SKEW": "1"}.items():
+        monkeypatch.setenv(k, v)
+    after = run()
+    for c in cases:
+        assert before[c][0] == after[c][0], (c, before[c][0], after[c][0])
+        assert np.array_equal(before[c][1], after[c][1]), c
