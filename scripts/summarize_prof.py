@@ -37,7 +37,7 @@ def main(prof_dir, out_path, kernel_like="%st_fast%"):
         write = pm["WRITE_SIZE"]["per_dispatch"] * 1024.0
         traffic = {"kernel": bl["config"]["kernel"], "frames": bl["config"].get("frames_per_step_rank0"),
                    "rows": bl["config"]["rows"], "fetch_bytes_corrected": fetch, "write_bytes": write,
-                   "hbm_bytes_per_launch": fetch + write,
+                   "hbm_bytes_per_launch": fetch + write, "round": os.path.basename(out_path)[:3],
                    "source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 on gfx950)"
                              % os.path.basename(out_path)}
         out["traffic"] = traffic

@@ -144,3 +144,41 @@ def test_comm_init_refuses_a_device_another_live_rank_of_the_job_holds(gpu_lib, 
     assert "one process per GPU" in msg, msg
     assert other.startswith("paa_comm_") and other.endswith(".1")
     assert left == [other]
+
+
+def test_bench_n2_socket_control_plane_without_rccl(gpu_lib, tmp_path):
+    """`bench.py --gpus 2 --no-gather` as the driver launches it (RANK / WORLD_SIZE / MASTER_* in the environment, one
+    process per rank): on this one-GPU box both ranks share device 0, so RCCL stays out (--no-gather) and what runs is the
+    N > 1 code path itself -- partition_by_frames, the socket control plane (barrier, max over ranks), the per-rank plans,
+    the in-line parity check -- ending in one parseable JSON line with n_gpus = 2."""
+    import json
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-gather", "--clips", "2000", "--steps", "5",
+             "--warmup", "2", "--prewarm-seconds", "0", "--no-cpu-baseline"],
+            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=300))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("bench.py --gpus 2 --no-gather did not finish within 300 s")
+    assert all(p.returncode == 0 for p in procs), [(p.returncode, o[1][-800:]) for p, o in zip(procs, outs)]
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]      # rank 0 prints, once
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["clips_in_job"] == 2000 and line["config"]["frames_per_step_job"] == 2000 * 399
+    assert line["config"]["frames_per_step_rank0"] == 1000 * 399
+    assert line["parity_check"]["status"] == "ok", line["parity_check"]
