@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void st_generic_kernel(PlanDev P, GenLayout
 
     const Tile tl = tiles[tile_id];
     const ClipDev c = clips[tl.clip];
-    const ClipNorm nm = norms[tl.clip];
+    const ClipNorm nm = wave_clip_norm<T>(P, c, norms, tl.clip, lane);
     const T *x0 = sig + c.sample_off + P.frame_origin;
     const long long Tc = c.T;
     double *oc = out + c.out_off;

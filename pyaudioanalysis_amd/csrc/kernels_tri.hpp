@@ -882,6 +882,7 @@ typedef Shape<20, 16, 3, true, 49, 8> S1920;        // 40 ms at 48 kHz: 960 comp
 typedef Shape<20, 20, 2, true, 40, 8> S1600;        // 50 ms at 32 kHz: 800 complex points
 typedef Shape<20, 10, 3, true, 30, 8> S1200;        // 50 ms at 24 kHz / 25 ms at 48 kHz: 600 complex points
 typedef Shape<29, 19, 1, false, 19, 8> S551;        // 50 ms at 11.025 kHz / 25 ms at 22.05 kHz: 551 real points, two passes
+typedef Shape<29, 19, 2, false, 38, 8> S1102;       // 25 ms at 44.1 kHz (BASELINE config 5) / 50 ms at 22.05 kHz: 1102 real points
 
 struct TriLaunch {
     int shape = -1;                 // index into the shape list above
@@ -900,11 +901,12 @@ inline int tri_shape_of(int window) {
         case 1600: return 4;
         case 1200: return 5;
         case 551: return 6;
+        case 1102: return 7;
         default: return -1;
     }
 }
 // PAA_TRI_SHAPE(SH) is expanded once per shape, in tri_shape_of's order
-#define PAA_TRI_SHAPES(X) X(0, S2400) X(1, S2205) X(2, S1764) X(3, S1920) X(4, S1600) X(5, S1200) X(6, S551)
+#define PAA_TRI_SHAPES(X) X(0, S2400) X(1, S2205) X(2, S1764) X(3, S1920) X(4, S1600) X(5, S1200) X(6, S551) X(7, S1102)
 
 template <typename SH>
 inline void tri_fill(double fs, const MelTable *mel, const ChromaTable *chroma, TriLaunch &tl, std::vector<unsigned char> &blob) {
@@ -990,12 +992,13 @@ inline int tri_select(int window, int mode, double fs, const MelTable *mel, cons
     const int sh = tri_shape_of(window);
     if (sh < 0) return 0;
     tl.shape = sh;
-    static const char *names[3][7] = {
-        {"st_tri_20x20x3", "st_tri_r21x21x5", "st_tri_21x21x2", "st_tri_20x16x3", "st_tri_20x20x2", "st_tri_20x10x3", "st_tri_r29x19"},
+    static const char *names[3][8] = {
+        {"st_tri_20x20x3", "st_tri_r21x21x5", "st_tri_21x21x2", "st_tri_20x16x3", "st_tri_20x20x2", "st_tri_20x10x3", "st_tri_r29x19",
+         "st_tri_r29x19x2"},
         {"spectrogram_tri_20x20x3", "spectrogram_tri_r21x21x5", "spectrogram_tri_21x21x2", "spectrogram_tri_20x16x3",
-         "spectrogram_tri_20x20x2", "spectrogram_tri_20x10x3", "spectrogram_tri_r29x19"},
+         "spectrogram_tri_20x20x2", "spectrogram_tri_20x10x3", "spectrogram_tri_r29x19", "spectrogram_tri_r29x19x2"},
         {"chromagram_tri_20x20x3", "chromagram_tri_r21x21x5", "chromagram_tri_21x21x2", "chromagram_tri_20x16x3",
-         "chromagram_tri_20x20x2", "chromagram_tri_20x10x3", "chromagram_tri_r29x19"}};
+         "chromagram_tri_20x20x2", "chromagram_tri_20x10x3", "chromagram_tri_r29x19", "chromagram_tri_r29x19x2"}};
     tl.name = names[mode][sh];
     switch (sh) {
 #define PAA_TRI_FILL(ID, SH) case ID: tri_fill<SH>(fs, mel, chroma, tl, blob); break;

@@ -510,7 +510,11 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
             p->ct = 1;
         }
     }
-    if (!p->fast && !p->ct && !g_force_generic && tab->fft.even && reg::reg_supported(window)) {
+    // window 1102 (config 5): spectrogram / chromagram rows stay with the prime-factor kernel (2.8e8 frames/s against 2.3e8);
+    // the FEATURE matrix goes to the three-pass real-input kernel below since round 4 -- same rate (1.28e8 / 1.30e8), but
+    // 64-byte chunked row stores instead of 6-frame row segments (-DPAA_EXPERIMENTS builds: PAA_REG_1102=1 for A/B runs)
+    const bool reg_wanted = reg::reg_supported(window) && (mode != 0 || experiment_env("PAA_REG_1102"));
+    if (!p->fast && !p->ct && !g_force_generic && tab->fft.even && reg_wanted) {
         // windows 2 R1 R2 with coprime primes (config 5: 1102): several frames per wave, prime-factor FFT in registers
         using SH = reg::Shape1102;
         std::vector<unsigned char> blob;
@@ -524,7 +528,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     if (!p->fast && !p->ct && !p->reg && !g_force_generic) {
         // the reference's default 50 ms windows at 48 / 44.1 kHz (2400, 2205): three-pass FFT in registers, 7 waves per CU
         std::vector<unsigned char> blob;
-        if (tri::tri_select(window, mode, fs, mode == 0 ? &tab->mel : nullptr, mode != 1 ? &tab->chroma : nullptr, p->trl, blob)) {
+        if ((window != 1102 || mode == 0) && tri::tri_select(window, mode, fs, mode == 0 ? &tab->mel : nullptr, mode != 1 ? &tab->chroma : nullptr, p->trl, blob)) {
             if ((rc = upload_pooled(&p->d_gen_blob, blob.data(), blob.size()))) return rc;
             p->tri = 1;
         }
@@ -624,11 +628,12 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     const size_t nch = (size_t)std::max<long long>(n_chunks, 1);
     if ((rc = pool_alloc(&p->d_psum, nch * 8)) || (rc = pool_alloc(&p->d_pmin, nch * 8)) ||
         (rc = pool_alloc(&p->d_pmax, nch * 8))) return rc;
-    // the kernels of the main shapes fold the statistics partials into the clip constants themselves; chromagram plans
-    // keep clip_params_kernel (the truncated-tail kernel of the host entry point reads its output)
+    // every one-launch feature kernel folds the statistics partials into the clip constants itself (its waves' prologue);
+    // chromagram plans keep clip_params_kernel (the truncated-tail kernel of the host entry point reads its output), and so
+    // does the big-window path (a chain of small kernels)
     P.st_sum = p->d_psum; P.st_min = p->d_pmin; P.st_max = p->d_pmax;
     P.st_scale = sample_kind == 1 ? sample_scale<double>() : (sample_kind == 2 ? sample_scale<stereo16>() : sample_scale<int16_t>());
-    P.norms_inline = ((p->fast || p->ct || p->tri) && mode != 2) ? 1 : 0;
+    P.norms_inline = (!p->big && mode != 2) ? 1 : 0;
     *out = p.release();
     return PAA_OK;
 }

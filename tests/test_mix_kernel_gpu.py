@@ -35,7 +35,9 @@ def test_plans_dispatch_the_mixed_radix_kernel(gpu_lib):
     assert name(22050, 551, 220, kind=1) == "st_tri_r29x19"
     assert name(44100, 1755, 877, mode=1) == "spectrogram_mix"   # other lengths made of 2, 3, 5, 7, 11, 13 stay mixed-radix
     assert name(16000, 1024, 512, kind=1) == "st_mix"
-    assert name(44100, 1102, 441) == "st_reg_29x19"            # 2 x 19 x 29 keeps its prime-factor kernel
+    assert name(44100, 1102, 441) == "st_tri_r29x19x2"         # config 5's features: real-input 29 x 19 x 2 (kernels_tri.hpp)
+    assert name(44100, 1102, 441, kind=2, mode=1) == "spectrogram_reg_29x19"      # its rows keep the prime-factor kernel
+    assert name(44100, 1102, 441, mode=2) == "chromagram_reg_29x19"
     assert name(16000, 800, 400) == "st_fast_800_w8"
     assert name(22050, 1103, 441) == "st_generic"              # 1103 is prime: Stockham passes with an O(R^2) radix
 
