@@ -572,6 +572,18 @@ def main():
                                            "achieved_tflops": KFLOP_PER_FRAME * 1e3 * frames / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0,
                                            "peak_tflops": FP64_VALU_PEAK_TFLOPS}
         result["roofline"]["fp64_valu"]["frac"] = result["roofline"]["fp64_valu"]["achieved_tflops"] / FP64_VALU_PEAK_TFLOPS
+        # the measured count: SQ_INSTS_VALU of the committed PMC pass x the FP64 share and flop weights of the kernel's ISA
+        # histogram (scripts/fp64_executed.py): wave-instructions x 64 lanes, idle lanes included
+        try:
+            ex = json.load(open(os.path.join(ROOT, "profiles", "%s_fast800_fp64_executed.json" % PROFILE_ROUND)))
+            if plan.kernel_name == "st_fast_800_w8" and F == 34 and ex.get("frames") == int(frames) and k_avg_ms > 0:
+                fv = result["roofline"]["fp64_valu"]
+                fv["issued_kflop_per_frame_measured"] = ex["issued_kflop_per_frame"]
+                fv["issued_tflops"] = ex["issued_fp64_flop_per_launch"] / (k_avg_ms * 1e-3) / 1e12
+                fv["issued_frac"] = fv["issued_tflops"] / FP64_VALU_PEAK_TFLOPS
+                fv["issued_source"] = "profiles/%s_fast800_fp64_executed.json (counter pass of this command x ISA histogram)" % PROFILE_ROUND
+        except Exception:
+            pass
         if args.check:
             import paa_oracle as O
             # the buffer the last step wrote holds clip (k-1) % len(d_inputs); re-run clip 0 into d_out for the check
