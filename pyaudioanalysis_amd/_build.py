@@ -1,14 +1,26 @@
-"""Build libpaa_hip.so in-tree with hipcc for gfx950 (no PyTorch, no JIT cache)."""
+"""Build libpaa_hip.so in-tree with hipcc for gfx950 (no PyTorch, no JIT cache).
+
+The library is several translation units: csrc/paa_lib.hip (host side: state, plans, dispatch, host API, RCCL, debug exports
+-- itself made of the lib_*.hpp units -- plus the small kernels) and one family_*.hip per feature-kernel family, whose
+kernels are instantiated there and nowhere else.  The units compile in parallel and are linked into one shared object."""
+import concurrent.futures
 import os
 import shutil
 import subprocess
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpaa_hip.so")
-SOURCES = ["paa_lib.hip"]
+SOURCES = ["paa_lib.hip", "family_fast.hip", "family_ct.hip", "family_tri_a.hip", "family_tri_b.hip", "family_reg_mix_generic.hip"]
 HEADERS = ["device_common.hpp", "kernels_generic.hpp", "kernels_fast.hpp", "kernels_aux.hpp",
-           "kernels_tail.hpp", "kernels_big.hpp", "kernels_ct.hpp", "kernels_mix.hpp", "kernels_tri.hpp", "kernels_sim.hpp", "kernels_reg.hpp", "kernels_svm.hpp", "comm_rccl.hpp", "tables.hpp", os.path.join("..", "..", "include", "paa_hip.h")]
+           "kernels_tail.hpp", "kernels_big.hpp", "kernels_ct.hpp", "kernels_mix.hpp", "kernels_tri.hpp", "kernels_sim.hpp", "kernels_reg.hpp", "kernels_svm.hpp", "comm_rccl.hpp", "tables.hpp",
+           "family_launch.hpp", "lib_plan.hpp", "lib_dispatch.hpp", "lib_host_api.hpp", "lib_similarity.hpp", "lib_debug.hpp",
+           os.path.join("..", "..", "include", "paa_hip.h")]
+# -disable-machine-licm: the feature kernels' loop bodies are thousands of instructions long; hoisting every FP64 literal
+# and per-lane LDS address out of them creates >100 loop-invariant registers that then spill (AGPR copies at one wave per
+# SIMD, scratch at two).  Re-materialising a literal at its use costs two s_mov / v_mov.
+BASE_FLAGS = ["--offload-arch=gfx950", "-std=c++17", "-fPIC", "-mllvm", "-disable-machine-licm", "-I/opt/rocm/include"]
 
 
 def hipcc_path():
@@ -18,31 +30,48 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (needed to build libpaa_hip.so for gfx950)")
 
 
-def is_stale():
-    if not os.path.exists(LIB):
+def is_stale(lib=None):
+    lib = lib or LIB
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def build_to(lib, extra_flags=(), opt="-O3", verbose=False, jobs=None):
+    """Compile every translation unit (in parallel) and link them into `lib`.  extra_flags go to compile AND link."""
+    hipcc = hipcc_path()
+    extra = list(extra_flags) + os.environ.get("PAA_HIPCC_FLAGS", "").split()
+    jobs = jobs or min(len(SOURCES), os.cpu_count() or 1)
+    with tempfile.TemporaryDirectory(prefix="paa_build_") as tmp:
+        def compile_one(src):
+            obj = os.path.join(tmp, os.path.splitext(src)[0] + ".o")
+            cmd = [hipcc] + BASE_FLAGS + [opt] + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                raise RuntimeError("hipcc failed on %s:\n%s%s" % (src, res.stdout, res.stderr))
+            return obj
+        with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as pool:
+            objs = list(pool.map(compile_one, SOURCES))
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [f for f in extra if f.startswith("-fsanitize") or f == "-g"] \
+            + objs + ["-o", lib + ".tmp", "-ldl"]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("linking %s failed:\n%s%s" % (lib, res.stdout, res.stderr))
+    os.replace(lib + ".tmp", lib)
+    return lib
+
+
 def build(force=False, verbose=False):
-    """Compile csrc/paa_lib.hip -> libpaa_hip.so (gfx950 only).  Returns the library path."""
+    """Build pyaudioanalysis_amd/libpaa_hip.so (gfx950 only) when it is missing or older than its sources.  Returns the path."""
     if not force and not is_stale():
         return LIB
-    # -disable-machine-licm: the feature kernels' loop bodies are thousands of instructions long; hoisting every FP64
-    # literal and per-lane LDS address out of them creates >100 loop-invariant registers that then spill (AGPR copies at
-    # one wave per SIMD, scratch at two).  Re-materialising a literal at its use costs two s_mov / v_mov.
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-mllvm", "-disable-machine-licm",
-           "-I/opt/rocm/include", os.path.join(CSRC, "paa_lib.hip"), "-o", LIB + ".tmp", "-ldl"]
-    cmd += os.environ.get("PAA_HIPCC_FLAGS", "").split()
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    return build_to(LIB, verbose=verbose)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,57 @@
+// Launch entry points of the feature-kernel families.  Every family is its own translation unit (family_<name>.hip: its
+// kernels are instantiated there and nowhere else, so the families compile in parallel); the host side of the library
+// (paa_lib.hip and the lib_*.hpp units it is made of) sees only these functions and the families' host-side layout /
+// selection code.  All of them queue ONE kernel on `stream` and return 0, or -1 when the launch failed (hipGetLastError
+// has the reason).  sample_kind: 0 int16, 1 float64, 2 interleaved stereo int16 (summed in the kernels' loads).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_ct.hpp"
+#include "kernels_fast.hpp"
+#include "kernels_generic.hpp"
+#include "kernels_mix.hpp"
+#include "kernels_reg.hpp"
+#include "kernels_tri.hpp"
+
+namespace paa {
+namespace launch {
+
+// kernels_fast.hpp: window 800, step 400 / 800, int16
+int fast(const FastLaunch &fl, const PlanDev &P, const FastTables &ft, const void *d_packed, const ClipDev *clips,
+         const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out, hipStream_t stream);
+// kernels_ct.hpp: windows 2 RA RB (800, 640, 400, 320)
+int ct(const ct::CtLaunch &cl, int sample_kind, const PlanDev &P, const unsigned char *blob, const void *d_packed,
+       const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out, hipStream_t stream);
+// kernels_tri.hpp: three-pass register FFT (2400, 2205, 1764, 1920, 1600, 1200, 1102 features, 551); two units
+int tri(const tri::TriLaunch &tl, int sample_kind, const PlanDev &P, const unsigned char *blob, const void *d_packed,
+        const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out, hipStream_t stream);
+int tri_part_a(const tri::TriLaunch &tl, int sample_kind, const PlanDev &P, const unsigned char *blob, const void *d_packed,
+               const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
+               hipStream_t stream);
+int tri_part_b(const tri::TriLaunch &tl, int sample_kind, const PlanDev &P, const unsigned char *blob, const void *d_packed,
+               const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
+               hipStream_t stream);
+// kernels_reg.hpp: prime-factor register FFT (window 1102: spectrogram / chromagram rows)
+int reg(const reg::RegLayout &rl, size_t lds, int sample_kind, const PlanDev &P, const unsigned char *blob,
+        const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
+        hipStream_t stream);
+// kernels_mix.hpp: in-place mixed-radix transform (every other length made of 2, 3, 5, 7, 11, 13)
+int mix(const mix::MixLayout &ml, size_t lds, int sample_kind, const PlanDev &P, const unsigned char *blob,
+        const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
+        hipStream_t stream);
+// kernels_generic.hpp: Stockham passes in LDS (what is left)
+int generic(const GenLayout &gl, size_t lds, int sample_kind, const PlanDev &P, const unsigned char *blob,
+            const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,
+            double *d_out, hipStream_t stream);
+
+
+// timing builds (-DPAA_F800_TIMING / _TRACE): per-unit readers of the kernels' phase-cycle counters (kernels_fast.hpp:
+// PAA_PHASE_READER); no-ops otherwise
+int phase_fast(unsigned long long *acc16, unsigned long long *trace, int max_waves);
+int phase_ct(unsigned long long *acc16, unsigned long long *trace, int max_waves);
+int phase_tri_a(unsigned long long *acc16, unsigned long long *trace, int max_waves);
+int phase_tri_b(unsigned long long *acc16, unsigned long long *trace, int max_waves);
+int phase_rmg(unsigned long long *acc16, unsigned long long *trace, int max_waves);
+
+}  // namespace launch
+}  // namespace paa

@@ -805,7 +805,7 @@ inline int ct_select(int window, int mode, double fs, const FftPlan &fft, const 
     return 1;
 }
 
-#ifndef PAA_NO_HOST_LAUNCHERS
+#if !defined(PAA_NO_HOST_LAUNCHERS) || defined(PAA_LAUNCH_CT)      // (kernels are instantiated only in family_ct*.hip)
 template <typename SH, typename T, int MODE, int DELTAS, int NW>
 inline int ct_launch_one(const CtLaunch &cl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                          const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,

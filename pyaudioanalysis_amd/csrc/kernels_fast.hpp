@@ -262,8 +262,10 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 
 // optional per-phase cycle accounting (build with -DPAA_F800_TIMING; read with paa_debug_phase_cycles)
 #ifdef PAA_F800_TIMING
-__device__ unsigned long long g_phase_cycles[16];
-__device__ unsigned long long g_wave_trace[4096 * 4];      // per wave: realtime start / end (100 MHz), cycles, HW_ID | XCC << 32
+// (internal linkage: every translation unit that instantiates kernels -- family_*.hip -- has its own copy; PAA_PHASE_READER
+// below defines the unit's reader and paa_debug_phase_cycles adds the units up)
+static __device__ unsigned long long g_phase_cycles[16];
+static __device__ unsigned long long g_wave_trace[4096 * 4];      // per wave: realtime start / end (100 MHz), cycles, HW_ID | XCC << 32
 #define PAA_T0() unsigned long long t_prev_ = __builtin_readcyclecounter(); unsigned long long t_acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; \
     const unsigned long long t_rt0_ = __builtin_amdgcn_s_memrealtime(), t_c0_ = t_prev_;
 #define PAA_TICK(idx) { const unsigned long long t_now_ = __builtin_readcyclecounter(); t_acc_[idx] += t_now_ - t_prev_; t_prev_ = t_now_; }
@@ -273,8 +275,8 @@ __device__ unsigned long long g_wave_trace[4096 * 4];      // per wave: realtime
         g_wave_trace[4 * tile_id + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } }
 #elif defined(PAA_F800_TRACE)
 // light-weight variant: only the per-wave life times (two clock reads and four stores per wave)
-__device__ unsigned long long g_phase_cycles[16];
-__device__ unsigned long long g_wave_trace[4096 * 4];
+static __device__ unsigned long long g_phase_cycles[16];
+static __device__ unsigned long long g_wave_trace[4096 * 4];
 #define PAA_T0() const unsigned long long t_rt0_ = __builtin_amdgcn_s_memrealtime(), t_c0_ = __builtin_readcyclecounter();
 #define PAA_TICK(idx)
 #define PAA_TEND() if (lane == 0) { atomicAdd(&g_phase_cycles[15], 1ULL); \
@@ -285,6 +287,23 @@ __device__ unsigned long long g_wave_trace[4096 * 4];
 #define PAA_T0()
 #define PAA_TICK(idx)
 #define PAA_TEND()
+#endif
+// reader of this translation unit's phase counters: adds them into acc16[16] and clears them; when trace != nullptr it also
+// copies the per-wave trace of the unit's last launch (4 words per run) and returns the number of runs copied
+#if defined(PAA_F800_TIMING) || defined(PAA_F800_TRACE)
+#define PAA_PHASE_READER(NAME)                                                                                          \
+    int NAME(unsigned long long *acc16, unsigned long long *trace, int max_waves) {                                     \
+        unsigned long long host[16], zero[16] = {0};                                                                    \
+        if (hipMemcpyFromSymbol(host, HIP_SYMBOL(f800::g_phase_cycles), sizeof(host)) != hipSuccess) return -1;          \
+        for (int i = 0; i < 16; ++i) acc16[i] += host[i];                                                               \
+        if (hipMemcpyToSymbol(HIP_SYMBOL(f800::g_phase_cycles), zero, sizeof(zero)) != hipSuccess) return -1;            \
+        if (!trace) return 0;                                                                                           \
+        const int n = max_waves < 4096 ? max_waves : 4096;                                                              \
+        if (hipMemcpyFromSymbol(trace, HIP_SYMBOL(f800::g_wave_trace), (size_t)n * 4 * sizeof(unsigned long long)) != hipSuccess) return -1; \
+        return n;                                                                                                       \
+    }
+#else
+#define PAA_PHASE_READER(NAME) int NAME(unsigned long long *, unsigned long long *, int) { return 0; }
 #endif
 
 // Row store, in whole 64-byte chunks of the row.  The rows of a [F][T] slab are only 8-byte aligned (T is odd in general)
@@ -1067,7 +1086,7 @@ inline int fast_select(int window, int step, int sample_kind, double fs, FastTab
     return 1;
 }
 
-#ifndef PAA_NO_HOST_LAUNCHERS      // (development builds of a single kernel family skip the other families' instantiations)
+#if !defined(PAA_NO_HOST_LAUNCHERS) || defined(PAA_LAUNCH_FAST)      // (kernels are instantiated only in family_fast*.hip)
 template <int S, int DELTAS, int FIXED, int NW>
 inline int fast_launch_one(const FastLaunch &fl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                            const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,

@@ -1010,9 +1010,9 @@ inline int tri_select(int window, int mode, double fs, const MelTable *mel, cons
     return 1;
 }
 
-#ifndef PAA_NO_HOST_LAUNCHERS
+#if !defined(PAA_NO_HOST_LAUNCHERS) || defined(PAA_LAUNCH_TRI)      // (kernels are instantiated only in family_tri*.hip)
 template <typename SH, typename T, int MODE, int DELTAS>
-inline int tri_launch_one(const TriLaunch &tl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
+static inline int tri_launch_one(const TriLaunch &tl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                           const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
                           hipStream_t stream) {
     static LdsAttrCache attr;
@@ -1027,7 +1027,7 @@ inline int tri_launch_one(const TriLaunch &tl, const PlanDev &P, const unsigned 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 template <typename SH, typename T>
-inline int tri_launch_mode(const TriLaunch &tl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
+static inline int tri_launch_mode(const TriLaunch &tl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                            const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
                            hipStream_t stream) {
     if (P.mode == 1) return tri_launch_one<SH, T, 1, 0>(tl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
@@ -1035,19 +1035,24 @@ inline int tri_launch_mode(const TriLaunch &tl, const PlanDev &P, const unsigned
     if (P.deltas) return tri_launch_one<SH, T, 0, 1>(tl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
     return tri_launch_one<SH, T, 0, 0>(tl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
 }
+// (internal linkage: the two units that instantiate these launchers name different shapes in PAA_TRI_SHAPES_HERE)
 template <typename T>
-inline int tri_launch_shape(const TriLaunch &tl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
+static inline int tri_launch_shape(const TriLaunch &tl, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                             const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
                             hipStream_t stream) {
+    // (the shapes are spread over two translation units: PAA_TRI_SHAPES_HERE names the ones this unit instantiates)
+#ifndef PAA_TRI_SHAPES_HERE
+#define PAA_TRI_SHAPES_HERE(X) PAA_TRI_SHAPES(X)
+#endif
     switch (tl.shape) {
 #define PAA_TRI_GO(ID, SH) case ID: return tri_launch_mode<SH, T>(tl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
-        PAA_TRI_SHAPES(PAA_TRI_GO)
+        PAA_TRI_SHAPES_HERE(PAA_TRI_GO)
 #undef PAA_TRI_GO
         default: return -1;
     }
 }
 // sample_kind 0: int16, 1: float64, 2: interleaved stereo int16 (summed in the loads)
-inline int tri_launch(const TriLaunch &tl, int sample_kind, const PlanDev &P, const unsigned char *blob, const void *d_packed,
+static inline int tri_launch(const TriLaunch &tl, int sample_kind, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                       const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
                       hipStream_t stream) {
     if (sample_kind == 0) return tri_launch_shape<int16_t>(tl, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);

@@ -1,0 +1,144 @@
+// Introspection for the tests (paa_debug_*): tables, FFT plans, run-length choices, lane overlap, phase cycles of the timing
+// builds.  One of the units paa_lib.hip is made of.
+#pragma once
+// ------------------------------------------------------------------------------------------
+// introspection for tests
+// ------------------------------------------------------------------------------------------
+// per-phase cycle totals of st_fast_800 (only in builds with -DPAA_F800_TIMING; zeros otherwise); resets them
+extern "C" int paa_debug_phase_cycles(uint64_t *out16) {
+    if (!out16) return fail(PAA_ERR_ARG, "null");
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+#if defined(PAA_F800_TIMING) || defined(PAA_F800_TRACE)
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(cs()));
+    unsigned long long acc[16] = {0};
+    // every translation unit with kernels keeps its own counters (family_*.hip)
+    if (launch::phase_fast(acc, nullptr, 0) < 0 || launch::phase_ct(acc, nullptr, 0) < 0 || launch::phase_tri_a(acc, nullptr, 0) < 0 ||
+        launch::phase_tri_b(acc, nullptr, 0) < 0 || launch::phase_rmg(acc, nullptr, 0) < 0)
+        return fail(PAA_ERR_HIP, "reading the phase counters failed");
+    for (int i = 0; i < 16; ++i) out16[i] = acc[i];
+#endif
+    return PAA_OK;
+}
+
+// highest number of host-buffer calls that were in flight at the same time since the last query (lanes, see Lane);
+// resets the mark.  Lets a test show that calls from several threads really overlap.
+extern "C" int paa_debug_lane_peak(void) {
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    const int p = g_lanes_peak;
+    g_lanes_peak = g_lanes_active;
+    return p;
+}
+
+// per-wave trace of the last st_fast_800 launch (PAA_F800_TIMING builds): 4 words per run, up to 4096 runs
+extern "C" int paa_debug_wave_trace(uint64_t *out, int max_waves) {
+    if (!out || max_waves < 1) return fail(PAA_ERR_ARG, "null");
+#if defined(PAA_F800_TIMING) || defined(PAA_F800_TRACE)
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(cs()));
+    unsigned long long acc[16] = {0};
+    const int n = launch::phase_fast(acc, reinterpret_cast<unsigned long long *>(out), max_waves);      // (also clears that unit's counters)
+    if (n < 0) return fail(PAA_ERR_HIP, "reading the wave trace failed");
+    return n;
+#else
+    return 0;
+#endif
+}
+
+extern "C" int paa_debug_mel_bank(double fs, int num_fft, double *out_dense) {
+    if (!out_dense || num_fft < 1) return fail(PAA_ERR_ARG, "bad argument");
+    MelTable t;
+    int rc = build_mel(fs, num_fft, t);
+    if (rc) return fail(rc, "mel filter bank indexes bin >= num_fft");
+    std::fill(out_dense, out_dense + (size_t)kNumMel * num_fft, 0.0);
+    for (int m = 0; m < kNumMel; ++m)
+        for (int i = 0; i < t.cnt[m]; ++i) out_dense[(size_t)m * num_fft + t.lo[m] + i] = t.w[t.off[m] + i];
+    return PAA_OK;
+}
+extern "C" int paa_debug_dct(double *out_13x40) {
+    if (!out_13x40) return fail(PAA_ERR_ARG, "null");
+    build_dct(out_13x40);
+    return PAA_OK;
+}
+extern "C" int paa_debug_chroma(double fs, int num_fft, int capacity, int32_t *src, double *weight, int32_t *slot) {
+    ChromaTable t;
+    int rc = build_chroma(fs, num_fft, t);
+    if (rc) return fail(rc, "chroma table error");
+    const int n = (int)t.flat_src.size();
+    if (n > capacity) return fail(PAA_ERR_ARG, "capacity %d < %d entries", capacity, n);
+    for (int i = 0; i < n; ++i) { src[i] = t.flat_src[i]; weight[i] = t.flat_w[i]; slot[i] = t.flat_slot[i]; }
+    return n;
+}
+extern "C" int paa_debug_run_plan(const int64_t *frames, int64_t n_clips, int quantum, int min_run, int max_run, int halo,
+                                  int wg_runs, int num_cu, int32_t *run_cap, int64_t *n_runs, int32_t *longest) {
+    if (!frames || n_clips < 0 || quantum < 1 || min_run < quantum || max_run < min_run || halo < 0 || wg_runs < 1 ||
+        num_cu < 1 || !run_cap || !n_runs || !longest)
+        return fail(PAA_ERR_ARG, "bad argument");
+    std::vector<ClipDev> clips((size_t)n_clips);
+    for (int64_t c = 0; c < n_clips; ++c) { memset(&clips[(size_t)c], 0, sizeof(ClipDev)); clips[(size_t)c].T = (int)frames[c]; }
+    const int cap = choose_run_cap(clips, quantum, min_run, max_run, halo, wg_runs, num_cu);
+    long long runs = 0;
+    int lmax = 0;
+    for (const ClipDev &c : clips) {
+        if (c.T <= 0) continue;
+        const int len = clip_run_length(c.T, cap, quantum);
+        runs += (c.T + len - 1) / len;
+        lmax = std::max(lmax, len);
+    }
+    *run_cap = cap; *n_runs = runs; *longest = lmax;
+    return PAA_OK;
+}
+// the same for the kernels whose halo rides inside a run's first iteration (2 RA RB family): every run of a clip but the
+// first is `shrink` frames shorter, which is what the tile list does -- the run count follows that rule
+extern "C" int paa_debug_run_plan_shrink(const int64_t *frames, int64_t n_clips, int quantum, int min_run, int max_run,
+                                         int shrink, int wg_runs, int num_cu, int32_t *run_cap, int64_t *n_runs,
+                                         int32_t *longest) {
+    if (!frames || n_clips < 0 || quantum < 1 || min_run < quantum || max_run < min_run || shrink < 0 || wg_runs < 1 ||
+        num_cu < 1 || !run_cap || !n_runs || !longest)
+        return fail(PAA_ERR_ARG, "bad argument");
+    std::vector<ClipDev> clips((size_t)n_clips);
+    for (int64_t c = 0; c < n_clips; ++c) { memset(&clips[(size_t)c], 0, sizeof(ClipDev)); clips[(size_t)c].T = (int)frames[c]; }
+    const int cap = choose_run_cap(clips, quantum, min_run, max_run, 0, wg_runs, num_cu, shrink);
+    long long runs = 0;
+    int lmax = 0;
+    for (const ClipDev &c : clips) {
+        if (c.T <= 0) continue;
+        const int len = clip_run_length(c.T, cap, quantum);
+        for (long long t0 = 0; t0 < c.T; ++runs) t0 += (t0 > 0) ? std::max(len - shrink, 1) : len;      // the tile rule
+        lmax = std::max(lmax, len);
+    }
+    *run_cap = cap; *n_runs = runs; *longest = lmax;
+    return PAA_OK;
+}
+// host side of the mixed-radix kernel for a window (no device needed): radix schedule of the in-place DIF transform and the
+// position that holds Z[k] afterwards.  Returns the number of passes, 0 when the window is not for that kernel.
+extern "C" int paa_debug_mix_plan(int window, int32_t *radices, int32_t *fft_len, uint16_t *perm, int perm_capacity,
+                                  int32_t *waves, int32_t *tw_global) {
+    if (window < 2 || !radices || !fft_len) return fail(PAA_ERR_ARG, "bad argument");
+    FftPlan p;
+    build_fft_plan(window, p);
+    *fft_len = p.len;
+    mix::MixLayout L;
+    if (!mix::mix_layout(p, nullptr, nullptr, 34, L, nullptr)) return 0;
+    std::vector<int> radix(L.radix, L.radix + L.n_pass);
+    for (int i = 0; i < L.n_pass; ++i) radices[i] = L.radix[i];
+    if (perm && perm_capacity >= p.len) {
+        std::vector<unsigned short> pm;
+        mix::mix_permutation(p.len, radix, pm);
+        memcpy(perm, pm.data(), (size_t)p.len * 2);
+    }
+    if (waves) *waves = L.waves;
+    if (tw_global) *tw_global = L.tw_global;
+    return L.n_pass;
+}
+extern "C" int paa_debug_fft_plan(int window, int32_t *radices, int32_t *fft_len) {
+    if (window < 2 || !radices || !fft_len) return fail(PAA_ERR_ARG, "bad argument");
+    FftPlan p;
+    build_fft_plan(window, p);
+    *fft_len = p.len;
+    const int n = (int)p.radix.size();
+    for (int i = 0; i < n && i < 32; ++i) radices[i] = p.radix[i];
+    return n;
+}

@@ -1,0 +1,191 @@
+// Kernel choice of a plan: one table entry per feature-kernel family -- does it take this (window, step, sample type, mode)?
+// how long are its runs? how is it launched? -- walked in order by plan_build; the first family that accepts owns the plan.
+// Adding a family = one more entry (and its family_<name>.hip).  Included by paa_lib.hip after the plan structure.
+#pragma once
+
+struct FamilyCtx {
+    paa_plan *p;
+    TableSet *tab;
+    double fs;
+    int window, step, deltas, mode, sample_kind, F;
+    long long total_frames;
+    const MelTable *mel() const { return mode == 0 ? &tab->mel : nullptr; }
+    const ChromaTable *chroma() const { return mode != 1 ? &tab->chroma : nullptr; }
+};
+// how the tile list cuts a clip: runs of `run` frames in multiples of `quantum`; a run with t0 > 0 is halo_inside frames
+// shorter (kernels whose look-back frames ride inside the run's first iteration)
+struct RunRule {
+    int run = 64, quantum = 4, halo_inside = 0;
+};
+struct Family {
+    const char *id;
+    // 1: takes the shape (layout + tables are in the plan, kernel_name and lds set), 0: declines, < 0: error code
+    int (*select)(FamilyCtx &c);
+    void (*run_rule)(FamilyCtx &c, RunRule &r);
+    int (*launch)(paa_plan *p, const void *d_packed, double *d_out, const Tile *tiles, long long n_tiles, hipStream_t stream);
+};
+
+static int upload_blob(paa_plan *p, const std::vector<unsigned char> &blob) {
+    return upload_pooled(&p->d_gen_blob, blob.data(), blob.size());
+}
+// the usual rule of the one-frame-per-iteration kernels: about two chip-wide rounds, 8 .. 64 frames per run
+static int two_round_run(long long total_frames, int waves) {
+    const long long slots = (long long)g_num_cu * waves * 2;
+    const long long per = (total_frames + slots - 1) / slots;
+    return (int)std::min<long long>(64, std::max<long long>(8, (per + 3) / 4 * 4));
+}
+
+// ---- kernels_fast.hpp: int16, window 800, step 400 / 800, features only
+static int fam_fast_select(FamilyCtx &c) {
+    if (c.mode != 0 || g_force_generic) return 0;
+    const int rc = fast_select(c.window, c.step, c.sample_kind, c.fs, c.tab->fast, c.tab->fft, c.tab->mel, c.tab->chroma, c.p->fl,
+                               g_f800_waves);
+    if (rc < 0) return fail(rc, "building the tables of the specialised kernel failed");
+    if (rc) { c.p->fast = 1; c.p->lds = c.p->fl.lds; c.p->kernel_name = c.p->fl.name; }
+    return rc;
+}
+static void fam_fast_rule(FamilyCtx &c, RunRule &r) {
+    // one wave per run, in multiples of the 4-frame quad, at most fl.run frames (halo = one quad); see choose_run_cap
+    r.quantum = 4;
+    r.run = choose_run_cap(c.p->clips, 4, 16, c.p->fl.run, 4, c.p->fl.waves_per_cu, g_num_cu);
+    if (const char *rc_env = experiment_env("PAA_RUN_CAP")) r.run = std::max(16, atoi(rc_env) / 4 * 4);      // A/B experiments only
+}
+static int fam_fast_launch(paa_plan *p, const void *d_packed, double *d_out, const Tile *tiles, long long n, hipStream_t s) {
+    return launch::fast(p->fl, p->P, p->tab->fast, d_packed, p->d_clips, p->d_norms, tiles, n, d_out, s);
+}
+
+// ---- kernels_ct.hpp: windows 2 RA RB (800, 640, 400, 320), any step / sample type / mode
+static int fam_ct_select(FamilyCtx &c) {
+    if (g_force_generic) return 0;
+    std::vector<unsigned char> blob;
+    if (!ct::ct_select(c.window, c.mode, c.fs, c.tab->fft, c.mel(), c.chroma(), c.p->cl, blob)) return 0;
+    const int rc = upload_blob(c.p, blob);
+    if (rc) return rc;
+    c.p->ct = 1; c.p->lds = c.p->cl.lds; c.p->kernel_name = c.p->cl.name;
+    return 1;
+}
+static void fam_ct_rule(FamilyCtx &c, RunRule &r) {
+    // one wave per run, 4 frames per iteration; a run with t0 > 0 starts 1 frame early (2 with deltas) inside its first
+    // iteration, so the first run of a clip gets `run` frames and the others run - halo: every run is whole iterations
+    r.quantum = 4;
+    r.halo_inside = (c.mode == 0) ? (c.deltas ? 2 : 1) : 0;
+    r.run = choose_run_cap(c.p->clips, 4, 16, 256, 0, c.p->cl.waves, g_num_cu, r.halo_inside);
+}
+static int fam_ct_launch(paa_plan *p, const void *d_packed, double *d_out, const Tile *tiles, long long n, hipStream_t s) {
+    return launch::ct(p->cl, p->sample_kind, p->P, p->d_gen_blob, d_packed, p->d_clips, p->d_norms, tiles, n, d_out, s);
+}
+
+// ---- kernels_reg.hpp: prime-factor register FFT, window 1102 (config 5): spectrogram / chromagram rows (2.8e8 frames/s
+// against 2.3e8 of the three-pass kernel); the FEATURE matrix goes to kernels_tri.hpp since round 4 -- same rate
+// (1.28e8 / 1.30e8) but 64-byte chunked row stores instead of 6-frame row segments (-DPAA_EXPERIMENTS builds:
+// PAA_REG_1102=1 puts it back for A/B runs)
+static int fam_reg_select(FamilyCtx &c) {
+    if (g_force_generic || !c.tab->fft.even || !reg::reg_supported(c.window)) return 0;
+    if (c.mode == 0 && !experiment_env("PAA_REG_1102")) return 0;
+    using SH = reg::Shape1102;
+    std::vector<unsigned char> blob;
+    reg::reg_layout(c.tab->fft, c.mel(), c.chroma(), c.F, SH::NFP, SH::Q, c.p->rl, &blob);
+    if ((size_t)c.p->rl.table_bytes + (size_t)c.p->rl.wave_bytes > 160 * 1024) return 0;
+    const int rc = upload_blob(c.p, blob);
+    if (rc) return rc;
+    c.p->reg = 1;
+    c.p->lds = (size_t)c.p->rl.table_bytes + (size_t)c.p->rl.waves * c.p->rl.wave_bytes;
+    c.p->kernel_name = (c.mode == 0) ? "st_reg_29x19" : (c.mode == 1 ? "spectrogram_reg_29x19" : "chromagram_reg_29x19");
+    return 1;
+}
+static void fam_reg_rule(FamilyCtx &c, RunRule &r) {
+    const int q = reg::Shape1102::Q;          // runs are multiples of Q frames (halo = one iteration); see choose_run_cap
+    r.quantum = q;
+    r.run = choose_run_cap(c.p->clips, q, 4 * q, 32 * q, q, c.p->rl.waves, g_num_cu);
+}
+static int fam_reg_launch(paa_plan *p, const void *d_packed, double *d_out, const Tile *tiles, long long n, hipStream_t s) {
+    return launch::reg(p->rl, p->lds, p->sample_kind, p->P, p->d_gen_blob, d_packed, p->d_clips, p->d_norms, tiles, n, d_out, s);
+}
+
+// ---- kernels_tri.hpp: three-pass register FFT -- the reference's default 50 ms windows at 48 / 44.1 kHz (2400, 2205), the
+// 40 ms ones (1920, 1764), 1600, 1200, config 5's feature matrix (1102) and the odd 551 (50 ms at 11.025 kHz)
+static int fam_tri_select(FamilyCtx &c) {
+    if (g_force_generic || (c.window == 1102 && c.mode != 0)) return 0;
+    std::vector<unsigned char> blob;
+    if (!tri::tri_select(c.window, c.mode, c.fs, c.mel(), c.chroma(), c.p->trl, blob)) return 0;
+    const int rc = upload_blob(c.p, blob);
+    if (rc) return rc;
+    c.p->tri = 1; c.p->lds = c.p->trl.lds; c.p->kernel_name = c.p->trl.name;
+    return 1;
+}
+static void fam_tri_rule(FamilyCtx &c, RunRule &r) {
+    // one wave per run, one frame per iteration; a run with t0 > 0 recomputes 1 frame (2 with deltas) first
+    r.quantum = 1;
+    r.run = choose_run_cap(c.p->clips, 1, 8, 96, (c.mode == 0) ? (c.deltas ? 2 : 1) : 0, c.p->trl.waves, g_num_cu);
+}
+static int fam_tri_launch(paa_plan *p, const void *d_packed, double *d_out, const Tile *tiles, long long n, hipStream_t s) {
+    return launch::tri(p->trl, p->sample_kind, p->P, p->d_gen_blob, d_packed, p->d_clips, p->d_norms, tiles, n, d_out, s);
+}
+
+// ---- kernels_mix.hpp: in-place mixed-radix transform for every other length made of 2, 3, 5, 7, 11, 13
+static int fam_mix_select(FamilyCtx &c) {
+    if (g_force_generic || experiment_env("PAA_NO_MIX")) return 0;
+    std::vector<unsigned char> blob;
+    if (!mix::mix_layout(c.tab->fft, c.mel(), c.chroma(), c.F, c.p->ml, &blob)) return 0;
+    const int rc = upload_blob(c.p, blob);
+    if (rc) return rc;
+    c.p->mixk = 1;
+    c.p->lds = mix::mix_lds_bytes(c.p->ml);
+    c.p->kernel_name = (c.mode == 0) ? "st_mix" : (c.mode == 1 ? "spectrogram_mix" : "chromagram_mix");
+    return 1;
+}
+static void fam_mix_rule(FamilyCtx &c, RunRule &r) {
+    // one wave per run, one frame at a time (halo: 1 frame, 2 with deltas)
+    r.quantum = 4;
+    r.run = two_round_run(c.total_frames, c.p->ml.waves);
+}
+static int fam_mix_launch(paa_plan *p, const void *d_packed, double *d_out, const Tile *tiles, long long n, hipStream_t s) {
+    return launch::mix(p->ml, p->lds, p->sample_kind, p->P, p->d_gen_blob, d_packed, p->d_clips, p->d_norms, tiles, n, d_out, s);
+}
+
+// ---- kernels_generic.hpp: Stockham passes in LDS (lengths with a prime factor above 13, tiny windows); windows beyond the
+// LDS envelope take the same passes through HBM scratch (kernels_big.hpp: plan->big, no CPU fallback)
+static int fam_generic_select(FamilyCtx &c) {
+    std::vector<unsigned char> blob;
+    generic_layout(c.tab->fft, c.mel(), c.chroma(), c.F, c.p->gl, &blob);
+    c.p->lds = generic_lds_bytes(c.p->gl);
+    if (c.p->lds > 160 * 1024) {
+        c.p->big = 1;
+        c.p->lds = 0;
+    } else {
+        const int rc = upload_blob(c.p, blob);
+        if (rc) return rc;
+    }
+    c.p->kernel_name = c.p->big ? "big_window_hbm_passes"
+                                : (c.mode == 0) ? "st_generic" : (c.mode == 1 ? "spectrogram_generic" : "chromagram_generic");
+    return 1;
+}
+static void fam_generic_rule(FamilyCtx &c, RunRule &r) {
+    r.quantum = 4;
+    r.run = two_round_run(c.total_frames, c.p->gl.waves);
+}
+static int fam_generic_launch(paa_plan *p, const void *d_packed, double *d_out, const Tile *tiles, long long n, hipStream_t s) {
+    return launch::generic(p->gl, p->lds, p->sample_kind, p->P, p->d_gen_blob, d_packed, p->d_clips, p->d_norms, tiles, n, d_out, s);
+}
+
+static const Family kFamilies[] = {
+    {"fast", fam_fast_select, fam_fast_rule, fam_fast_launch},
+    {"ct", fam_ct_select, fam_ct_rule, fam_ct_launch},
+    {"reg", fam_reg_select, fam_reg_rule, fam_reg_launch},
+    {"tri", fam_tri_select, fam_tri_rule, fam_tri_launch},
+    {"mix", fam_mix_select, fam_mix_rule, fam_mix_launch},
+    {"generic", fam_generic_select, fam_generic_rule, fam_generic_launch},
+};
+constexpr int kNumFamilies = (int)(sizeof(kFamilies) / sizeof(kFamilies[0]));
+
+static int choose_family(FamilyCtx &c, RunRule &rr) {
+    for (int i = 0; i < kNumFamilies; ++i) {
+        const int rc = kFamilies[i].select(c);
+        if (rc < 0) return rc;
+        if (rc == 0) continue;
+        c.p->family = i;
+        kFamilies[i].run_rule(c, rr);
+        return PAA_OK;
+    }
+    return fail(PAA_ERR_UNSUPPORTED, "no kernel family takes window %d", c.window);
+}

@@ -1,0 +1,473 @@
+// Plans: clip descriptors, statistics chunks, run lengths and tile lists, the kernel choice (lib_dispatch.hpp) and the
+// device-resident plan API (paa_plan_create / _execute / _mid_execute / _beat_execute ...).  One of the units paa_lib.hip is
+// made of (included there, after the library state; not a translation unit of its own).
+#pragma once
+// ------------------------------------------------------------------------------------------
+// plans
+// ------------------------------------------------------------------------------------------
+constexpr int kStatChunk = 65536;          // samples per statistics workgroup (upper bound, see stat_chunk_for)
+// The statistics pass is an HBM-bound stream with every workgroup resident at once (8 per CU): 879 chunks of a one-hour
+// clip put 4 workgroups on some CUs and 3 on others, and the pass lasts as long as the CUs with 4.  A batch of at least one
+// chunk per CU is therefore cut into a whole multiple of num_cu chunks (1024 x 56 256 samples for the hour).
+static int stat_chunk_for(long long total_samples, int num_cu) {
+    const long long blocks = (total_samples + kStatChunk - 1) / kStatChunk;
+    if (blocks < num_cu) return kStatChunk;
+    const long long want = (blocks + num_cu - 1) / num_cu * num_cu;
+    const long long len = ((total_samples + want - 1) / want + 63) / 64 * 64;      // multiples of 64 samples keep the 16-byte body aligned
+    return (int)std::min<long long>(kStatChunk, std::max<long long>(len, 4096));
+}
+
+// Run length for the one-wave-per-run kernels.  A clip of T frames is cut into k = ceil(T / cap) runs of
+// len = ceil(T / k) frames rounded up to the kernel's quantum (so no clip ends in a short leftover run); a workgroup takes
+// wg_runs consecutive runs and the chip holds num_cu workgroups at a time, so a launch lasts about
+// ceil(workgroups / num_cu) rounds of (longest run + halo) frames.  The cap that minimises that estimate is returned:
+// one 1-hour clip -> 2000 runs of 72 frames (one round); 12 500 clips of 399 frames -> two runs of 200 per clip instead
+// of 244 + 155 (the short run's wave idled for a third of its workgroup's life); 1000 clips of 1199 frames -> 6 x 200.
+static int choose_run_cap(const std::vector<ClipDev> &clips, int quantum, int min_run, int max_run, int halo, int wg_runs,
+                          int num_cu, int shrink = 0) {
+    // shrink: frames by which every run but a clip's first is shorter (kernels whose halo rides inside the first iteration:
+    // the tile list gives those runs len - shrink frames, so a clip has more runs than T / len)
+    std::map<long long, long long> hist;                       // frames per clip -> number of such clips
+    for (const ClipDev &c : clips)
+        if (c.T > 0) ++hist[c.T];
+    if (hist.empty()) return max_run;
+    long long best_cost = -1;
+    int best = max_run;
+    for (int cap = max_run / quantum * quantum; cap >= min_run; cap -= quantum) {
+        long long runs = 0, longest = 0;
+        for (const auto &kv : hist) {
+            const long long k = (kv.first + cap - 1) / cap;
+            const long long len = ((kv.first + k - 1) / k + quantum - 1) / quantum * quantum;
+            const long long later = std::max<long long>(len - shrink, 1);
+            runs += kv.second * ((kv.first <= len) ? 1 : 1 + (kv.first - len + later - 1) / later);
+            longest = std::max(longest, len);
+        }
+        const long long wgs = (runs + wg_runs - 1) / wg_runs;
+        const long long rounds = (wgs + num_cu - 1) / num_cu;
+        const long long cost = rounds * (longest + halo);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cap; }     // ties: the longer run (fewer halos)
+    }
+    return best;
+}
+// the runs of one clip of T frames under a cap: k = ceil(T / cap) runs of ceil(T / k) frames, rounded up to the quantum
+static inline int clip_run_length(long long T, int cap, int quantum) {
+    const long long k = (T + cap - 1) / cap;
+    return (int)(((T + k - 1) / k + quantum - 1) / quantum * quantum);
+}
+
+struct paa_plan {
+    long long n_clips = 0;
+    int sample_kind = 0;
+    int mode = 0;                   // 0 features, 1 spectrogram, 2 chromagram
+    int row_width = 0;              // doubles per frame of the slab in modes 1/2
+    std::vector<ClipDev> clips;
+    std::vector<long long> alloc_rows;   // modes 1/2: rows the reference allocates per clip
+    long long total_frames = 0, out_doubles = 0;
+    TableSet *tab = nullptr;
+    int stat_chunk = kStatChunk;     // samples per statistics chunk of this plan
+    PlanDev P;
+    ClipDev *d_clips = nullptr;
+    ClipNorm *d_norms = nullptr;
+    Tile *d_tiles = nullptr;
+    StatChunk *d_chunks = nullptr;
+    void *d_psum = nullptr, *d_pmin = nullptr, *d_pmax = nullptr;
+    long long *d_mid_off = nullptr;
+    GenLayout gl;                    // generic kernel: LDS layout + table blob
+    reg::RegLayout rl;               // register-FFT kernel (windows 2 R1 R2): LDS layout, blob in d_gen_blob
+    int reg = 0;
+    unsigned char *d_gen_blob = nullptr;
+    int big = 0;                     // window beyond the LDS envelope: Stockham passes through HBM scratch
+    void *d_big = nullptr;
+    size_t big_bytes = 0;
+    long long mid_off_step = -1;
+    long long n_tiles = 0, n_chunks = 0;
+    size_t lds = 0;
+    int fast = 0;                    // 1: specialised kernel
+    FastLaunch fl;
+    int mixk = 0;                    // 1: in-place mixed-radix kernel (kernels_mix.hpp); table blob in d_gen_blob
+    mix::MixLayout ml;
+    int ct = 0;                      // 1: register-FFT family for windows 2 RA RB (kernels_ct.hpp); table blob in d_gen_blob
+    ct::CtLaunch cl;
+    int tri = 0;                     // 1: three-pass register FFT for the large default windows (kernels_tri.hpp); blob in d_gen_blob
+    tri::TriLaunch trl;
+    int family = -1;                 // index into kFamilies (lib_dispatch.hpp); -1: the big-window path
+    std::string kernel_name;
+};
+
+static std::atomic<int> g_live_plans{0};          // plans hold raw pointers into the device's table sets (freed outside g_mu too)
+static void plan_free(paa_plan *p) {
+    if (!p) return;
+    --g_live_plans;
+    // (the caller has synchronised the stream the plan ran on: pooled blocks may be handed to the next plan at once)
+    pool_free(p->d_clips); pool_free(p->d_norms); pool_free(p->d_tiles); pool_free(p->d_chunks);
+    pool_free(p->d_psum); pool_free(p->d_pmin); pool_free(p->d_pmax); pool_free(p->d_mid_off); pool_free(p->d_gen_blob);
+    if (p->d_big) (void)hipFree(p->d_big);
+    delete p;
+}
+
+// deleter of the per-call plans of the host-buffer entry points: an early error return may leave kernels of this call in
+// flight on the lane's stream, and the plan's pooled blocks go straight to the next plan
+static void plan_free_synced(paa_plan *p) {
+    if (!p) return;
+    if (cs()) (void)hipStreamSynchronize(cs());
+    plan_free(p);
+}
+
+#include "lib_dispatch.hpp"
+
+static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, double fs, int window, int step,
+                      int deltas, int mode, paa_plan **out) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!offsets || n_clips < 1 || !out) return fail(PAA_ERR_ARG, "null offsets / no clips");
+    if (window < 2 || step < 1) return fail(PAA_ERR_ARG, "window=%d step=%d: need window >= 2, step >= 1", window, step);
+    if (sample_kind < 0 || sample_kind > 2)
+        return fail(PAA_ERR_ARG, "sample_kind must be 0 (int16), 1 (float64) or 2 (interleaved stereo int16)");
+    if (!(fs > 0)) return fail(PAA_ERR_ARG, "sampling rate must be positive");
+    std::unique_ptr<paa_plan, void (*)(paa_plan *)> p(new paa_plan(), plan_free);
+    ++g_live_plans;
+    p->n_clips = n_clips;
+    p->sample_kind = sample_kind;
+    p->mode = mode;
+    TableSet *tab = nullptr;
+    if ((rc = get_tables(fs, window, mode == 0, mode != 1, &tab))) return rc;
+    p->tab = tab;
+    const int Nf = window / 2;
+    const int F = (mode == 0) ? kBase * (deltas ? 2 : 1) : 0;
+    p->row_width = (mode == 1) ? Nf : (mode == 2 ? 12 : 0);
+
+    // ---- clips
+    p->clips.resize(n_clips);
+    p->alloc_rows.assign(n_clips, 0);
+    long long out_off = 0, total_frames = 0, n_chunks = 0;
+    p->stat_chunk = stat_chunk_for(offsets[n_clips] - offsets[0], g_num_cu);
+    const int kChunk = p->stat_chunk;
+    for (int64_t c = 0; c < n_clips; ++c) {
+        const long long n = offsets[c + 1] - offsets[c];
+        if (n < 0) return fail(PAA_ERR_ARG, "offsets must be non-decreasing (clip %lld)", (long long)c);
+        ClipDev &cd = p->clips[c];
+        cd.sample_off = offsets[c];
+        cd.n = n;
+        cd.out_off = out_off;
+        long long T = 0, rows = 0;
+        if (mode == 0) {
+            T = paa_num_frames(n, window, step);
+            if (T < 1)
+                return fail(PAA_ERR_TOO_SHORT, "need at least one array to concatenate (clip %lld has %lld samples, "
+                            "window %d)", (long long)c, n, window);
+            rows = T;
+            out_off += (long long)F * T;
+        } else {
+            int64_t filled = 0;
+            rows = (mode == 1) ? paa_spectrogram_rows(n, window, step, &filled)
+                               : paa_chromagram_rows(n, window, step, &filled);
+            if (rows < 1)
+                return fail(PAA_ERR_TOO_SHORT, "signal too short for window %d / step %d (clip %lld, %lld samples)",
+                            window, step, (long long)c, n);
+            // full-length frames only; a truncated chromagram tail frame is added by the caller
+            long long full = 0;
+            for (long long pos = window; pos + window <= n && full < filled; pos += step) ++full;
+            T = full;
+            out_off += rows * p->row_width;
+        }
+        if (T > 0x7fffffffLL) return fail(PAA_ERR_ARG, "clip %lld has too many frames", (long long)c);
+        p->alloc_rows[c] = rows;
+        cd.T = (int)T;
+        cd.stat_first = (int)n_chunks;
+        cd.stat_count = (int)((n + kChunk - 1) / kChunk);
+        cd.pad = 0;
+        n_chunks += cd.stat_count;
+        total_frames += T;
+    }
+    p->total_frames = total_frames;
+    p->out_doubles = out_off;
+    p->n_chunks = n_chunks;
+
+    // ---- device plan
+    PlanDev &P = p->P;
+    memset(&P, 0, sizeof(P));
+    P.W = window; P.S = step; P.Nf = Nf; P.Nc = tab->fft.len; P.even = tab->fft.even;
+    P.n_pass = (int)tab->fft.radix.size();
+    if (P.n_pass > 24) return fail(PAA_ERR_UNSUPPORTED, "window %d needs more than 24 FFT passes", window);
+    for (int i = 0; i < P.n_pass; ++i) P.radix[i] = tab->fft.radix[i];
+    P.tw = tab->d_tw; P.post = tab->d_post;
+    P.mel_lo = tab->d_mel_lo; P.mel_cnt = tab->d_mel_cnt; P.mel_off = tab->d_mel_off; P.mel_w = tab->d_mel_w;
+    P.dct = tab->d_dct; P.ch_start = tab->d_ch_start; P.ch_src = tab->d_ch_src; P.ch_w = tab->d_ch_w;
+    P.fs = fs; P.deltas = deltas ? 1 : 0; P.F = F;
+    P.blk_t = window / 10; P.blk_f = Nf / 10;
+    P.mode = mode;
+    P.frame_origin = (mode == 0) ? 0 : window;
+    { const char *dbg = experiment_env("PAA_KERNEL_DEBUG"); P.debug = dbg ? atoi(dbg) : 0; }
+
+    // ---- kernel choice + tiles: the first family of kFamilies (lib_dispatch.hpp) that takes the shape; its run rule
+    FamilyCtx fc{p.get(), tab, fs, window, step, deltas, mode, sample_kind, F, total_frames};
+    RunRule rr;
+    rc = choose_family(fc, rr);
+    if (rc) return rc;
+    const int run = rr.run, run_quantum = rr.quantum, run_halo = rr.halo_inside;
+    std::vector<Tile> tiles;
+    tiles.reserve((size_t)(total_frames / run + n_clips));
+    for (int64_t c = 0; c < n_clips; ++c) {
+        const long long T = p->clips[c].T;
+        if (T <= 0) continue;
+        const int len = clip_run_length(T, run, run_quantum);          // equal runs per clip
+        for (long long t0 = 0; t0 < T;) {
+            const long long want = (t0 > 0) ? len - run_halo : len;
+            Tile tl; tl.clip = (int)c; tl.t0 = (int)t0; tl.cnt = (int)std::min<long long>(want, T - t0); tl.pad = 0;
+            tiles.push_back(tl);
+            t0 += tl.cnt;
+        }
+    }
+    p->n_tiles = (long long)tiles.size();
+    if (p->n_tiles > 0x7fffffffLL || n_chunks > 0x7fffffffLL || n_clips > 0x7fffffffLL)
+        return fail(PAA_ERR_UNSUPPORTED, "batch too large for one launch (%lld runs, %lld statistics chunks, %lld clips)",
+                    p->n_tiles, n_chunks, (long long)n_clips);
+    std::vector<StatChunk> chunks;
+    chunks.reserve((size_t)n_chunks);
+    for (int64_t c = 0; c < n_clips; ++c)
+        for (int i = 0; i < p->clips[c].stat_count; ++i) {
+            StatChunk ch; ch.start = p->clips[c].sample_off + (long long)i * kChunk;
+            ch.len = (int)std::min<long long>(kChunk, p->clips[c].n - (long long)i * kChunk);
+            ch.clip = (int)c;
+            chunks.push_back(ch);
+        }
+    if ((rc = upload_pooled(&p->d_clips, p->clips.data(), p->clips.size()))) return rc;
+    if ((rc = upload_pooled(&p->d_tiles, tiles.data(), tiles.size()))) return rc;
+    if ((rc = upload_pooled(&p->d_chunks, chunks.data(), chunks.size()))) return rc;
+    if ((rc = upload_pooled(&p->d_norms, (const void *)nullptr, (size_t)n_clips))) return rc;
+    const size_t nch = (size_t)std::max<long long>(n_chunks, 1);
+    if ((rc = pool_alloc(&p->d_psum, nch * 8)) || (rc = pool_alloc(&p->d_pmin, nch * 8)) ||
+        (rc = pool_alloc(&p->d_pmax, nch * 8))) return rc;
+    // every one-launch feature kernel folds the statistics partials into the clip constants itself (its waves' prologue);
+    // chromagram plans keep clip_params_kernel (the truncated-tail kernel of the host entry point reads its output), and so
+    // does the big-window path (a chain of small kernels)
+    P.st_sum = p->d_psum; P.st_min = p->d_pmin; P.st_max = p->d_pmax;
+    P.st_scale = sample_kind == 1 ? sample_scale<double>() : (sample_kind == 2 ? sample_scale<stereo16>() : sample_scale<int16_t>());
+    P.norms_inline = (!p->big && mode != 2) ? 1 : 0;
+    *out = p.release();
+    return PAA_OK;
+}
+
+static int launch_stats(paa_plan *p, const void *d_packed) {
+    if (p->n_chunks > 0) {
+        if (p->sample_kind == 0)
+            hipLaunchKernelGGL(clip_stats_i16_kernel, dim3((unsigned)p->n_chunks), dim3(256), 0, cs(),
+                               (const int16_t *)d_packed, p->d_chunks, (long long *)p->d_psum, (int *)p->d_pmin,
+                               (int *)p->d_pmax);
+        else if (p->sample_kind == 2)
+            hipLaunchKernelGGL(clip_stats_stereo_kernel, dim3((unsigned)p->n_chunks), dim3(256), 0, cs(),
+                               (const stereo16 *)d_packed, p->d_chunks, (long long *)p->d_psum, (int *)p->d_pmin,
+                               (int *)p->d_pmax);
+        else
+            hipLaunchKernelGGL(clip_stats_f64_kernel, dim3((unsigned)p->n_chunks), dim3(256), 0, cs(),
+                               (const double *)d_packed, p->d_chunks, (double *)p->d_psum, (double *)p->d_pmin,
+                               (double *)p->d_pmax);
+    }
+    const unsigned gb = (unsigned)p->n_clips;
+    if (p->P.norms_inline) {
+        HIP_TRY(hipGetLastError());
+        return PAA_OK;
+    }
+    if (p->sample_kind == 1)
+        hipLaunchKernelGGL((clip_params_kernel<double, double>), dim3(gb), dim3(64), 0, cs(), p->d_clips,
+                           p->n_clips, (const double *)p->d_psum, (const double *)p->d_pmin,
+                           (const double *)p->d_pmax, sample_scale<double>(), p->P.W, p->d_norms);
+    else
+        hipLaunchKernelGGL((clip_params_kernel<long long, int>), dim3(gb), dim3(64), 0, cs(), p->d_clips,
+                           p->n_clips, (const long long *)p->d_psum, (const int *)p->d_pmin, (const int *)p->d_pmax,
+                           p->sample_kind == 2 ? sample_scale<stereo16>() : sample_scale<int16_t>(), p->P.W, p->d_norms);
+    HIP_TRY(hipGetLastError());
+    return PAA_OK;
+}
+
+// windows beyond the LDS envelope: chunked Stockham passes through HBM scratch (kernels_big.hpp)
+template <typename T>
+static int run_big(paa_plan *p, const void *d_packed, double *d_out) {
+    const PlanDev &P = p->P;
+    const long long Nc = P.Nc, Nf = P.Nf;
+    const size_t per_frame = (size_t)Nc * 32 + (size_t)Nf * 8 + 24;
+    long long maxT = 0;
+    for (auto &cd : p->clips) maxT = std::max<long long>(maxT, cd.T);
+    long long C = (long long)std::max<size_t>(1, ((size_t)1 << 30) / per_frame);
+    C = std::min<long long>(std::min<long long>(C, 65535), std::max<long long>(maxT, 1));
+    const size_t need = (size_t)C * Nc * 32 + (size_t)(C + 1) * Nf * 8 + (size_t)C * 24 + 256;
+    if (need > p->big_bytes) {
+        if (p->d_big) { HIP_TRY(hipStreamSynchronize(cs())); (void)hipFree(p->d_big); p->d_big = nullptr; }
+        HIP_TRY(hipMalloc(&p->d_big, need));
+        p->big_bytes = need;
+    }
+    double2 *bufA = reinterpret_cast<double2 *>(p->d_big);
+    double2 *bufB = bufA + C * Nc;
+    double *spec = reinterpret_cast<double *>(bufB + C * Nc);
+    double *tfeat = spec + (C + 1) * Nf;
+    const unsigned gx = (unsigned)std::min<long long>(64, (std::max<long long>(Nc, P.W) + 255) / 256);
+    for (long long c = 0; c < p->n_clips; ++c) {
+        const ClipDev &cd = p->clips[c];
+        const T *x0 = (const T *)d_packed + cd.sample_off + P.frame_origin;
+        double *oc = d_out + cd.out_off;
+        long long prev_n = 0;
+        for (long long t0 = 0; t0 < cd.T; t0 += C) {
+            const long long n = std::min<long long>(C, cd.T - t0);
+            if (t0 > 0 && P.mode != 1)       // carry the last spectrum of the previous chunk into row 0
+                HIP_TRY(hipMemcpyAsync(spec, spec + prev_n * Nf, (size_t)Nf * 8, hipMemcpyDeviceToDevice, cs()));
+            hipLaunchKernelGGL(big_load_kernel<T>, dim3(gx, (unsigned)n), dim3(256), 0, cs(), P, x0, t0, ClipNorm(),
+                               p->d_norms, (int)c, bufA);
+            if (P.mode == 0)
+                hipLaunchKernelGGL(big_time_kernel, dim3((unsigned)n), dim3(64), 0, cs(), P, bufA, tfeat);
+            double2 *src = bufA, *dst = bufB;
+            int Ns = 1;
+            for (int q = 0; q < P.n_pass; ++q) {
+                hipLaunchKernelGGL(big_pass_kernel, dim3(gx, (unsigned)n), dim3(256), 0, cs(), (int)Nc, P.radix[q], Ns,
+                                   P.tw, src, dst);
+                Ns *= P.radix[q];
+                std::swap(src, dst);
+            }
+            if (P.mode == 1) {
+                hipLaunchKernelGGL(big_post_kernel, dim3(gx, (unsigned)n), dim3(256), 0, cs(), P, src, oc, t0);
+            } else {
+                hipLaunchKernelGGL(big_post_kernel, dim3(gx, (unsigned)n), dim3(256), 0, cs(), P, src, spec, 1LL);
+                hipLaunchKernelGGL(big_feat_kernel, dim3((unsigned)n), dim3(64), 0, cs(), P, spec, tfeat, t0,
+                                   (long long)cd.T, oc);
+            }
+            HIP_TRY(hipGetLastError());
+            prev_n = n;
+        }
+        if (P.mode == 0 && P.deltas) {
+            const long long items = (long long)kBase * cd.T;
+            hipLaunchKernelGGL(big_delta_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, cs(),
+                               (long long)cd.T, oc);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return PAA_OK;
+}
+
+extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *d_out) {
+    if (!plan || !d_packed || !d_out) return fail(PAA_ERR_ARG, "null plan / buffer");
+    { const int rc_init = ensure_init(); if (rc_init) return rc_init; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = comm_wait_buffer_free(d_out);      // a gather of this buffer may still be in flight
+    if (rc) return rc;
+    rc = launch_stats(plan, d_packed);
+    if (rc) return rc;
+    if (plan->big)
+        return plan->sample_kind == 0 ? run_big<int16_t>(plan, d_packed, d_out)
+             : plan->sample_kind == 2 ? run_big<stereo16>(plan, d_packed, d_out) : run_big<double>(plan, d_packed, d_out);
+    if (plan->n_tiles == 0) return PAA_OK;
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    if (g_prof && (g_prof_seen++ % g_prof) == 0) {
+        if (g_prof_used == g_prof_ev.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            g_prof_ev.emplace_back(a, b);
+        }
+        pe0 = g_prof_ev[g_prof_used].first;
+        pe1 = g_prof_ev[g_prof_used].second;
+        ++g_prof_used;
+        HIP_TRY(hipEventRecord(pe0, cs()));
+    }
+    struct StopEv { hipEvent_t e; ~StopEv() { if (e) (void)hipEventRecord(e, cs()); } } stop_ev{pe1};
+    if (plan->family < 0) return fail(PAA_ERR_UNSUPPORTED, "plan without a kernel family");
+    rc = kFamilies[plan->family].launch(plan, d_packed, d_out, plan->d_tiles, plan->n_tiles, cs());
+    if (rc) return fail(PAA_ERR_HIP, "launch of %s failed: %s", plan->kernel_name.c_str(), hipGetErrorString(hipGetLastError()));
+    return PAA_OK;
+}
+
+extern "C" int paa_plan_create(const int64_t *offsets, int64_t n_clips, int sample_kind, double fs, int window,
+                               int step, int deltas, paa_plan_t **out_plan) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return plan_build(offsets, n_clips, sample_kind, fs, window, step, deltas, 0, out_plan);
+}
+
+// device-resident plan of the spectrogram (mode 1, :389-452) / chromagram (mode 2, :324-386) rows of one or more clips:
+// full-length frames only, row t of a clip at out + out_offset(clip) + t * row_width (Nf or 12 doubles); rows the reference
+// allocates but never fills, and the truncated chromagram tail frame, are the host entry points' business
+extern "C" int paa_plan_create_mode(const int64_t *offsets, int64_t n_clips, int sample_kind, double fs, int window,
+                                    int step, int mode, paa_plan_t **out_plan) {
+    if (mode < 0 || mode > 2) return fail(PAA_ERR_ARG, "mode must be 0 (features), 1 (spectrogram) or 2 (chromagram)");
+    std::lock_guard<std::mutex> lk(g_mu);
+    return plan_build(offsets, n_clips, sample_kind, fs, window, step, 0, mode, out_plan);
+}
+
+extern "C" int paa_plan_destroy(paa_plan_t *plan) {
+    if (g_device.load() >= 0) (void)ensure_init();       // (binds the calling thread to the library's device)
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (cs()) (void)hipStreamSynchronize(cs());
+    plan_free(plan);
+    return PAA_OK;
+}
+
+extern "C" int64_t paa_plan_total_frames(const paa_plan_t *plan) { return plan ? plan->total_frames : 0; }
+extern "C" int64_t paa_plan_out_doubles(const paa_plan_t *plan) { return plan ? plan->out_doubles : 0; }
+extern "C" const char *paa_plan_kernel_name(const paa_plan_t *plan) { return plan ? plan->kernel_name.c_str() : ""; }
+
+extern "C" int paa_plan_out_offsets(const paa_plan_t *plan, int64_t *out_offsets) {
+    if (!plan || !out_offsets) return fail(PAA_ERR_ARG, "null plan / buffer");
+    for (long long c = 0; c < plan->n_clips; ++c) out_offsets[c] = plan->clips[c].out_off;
+    return PAA_OK;
+}
+
+extern "C" int64_t paa_plan_mid_doubles(const paa_plan_t *plan, int64_t mid_step_ratio) {
+    if (!plan || mid_step_ratio < 1) return 0;
+    long long tot = 0;
+    for (long long c = 0; c < plan->n_clips; ++c)
+        tot += 2LL * plan->P.F * paa_num_mid_windows(plan->clips[c].T, mid_step_ratio);
+    return tot;
+}
+
+extern "C" int paa_plan_mid_execute(paa_plan_t *plan, const double *d_st, int64_t mid_ratio, int64_t mid_step_ratio,
+                                    double *d_mid) {
+    if (!plan || !d_st || !d_mid) return fail(PAA_ERR_ARG, "null plan / buffer");
+    { const int rc_init = ensure_init(); if (rc_init) return rc_init; }
+    if (plan->mode != 0) return fail(PAA_ERR_ARG, "mid-term statistics need a feature plan");
+    if (mid_step_ratio < 1)
+        return fail(PAA_ERR_ARG, "mid_step / short_step rounds to %lld: the reference loops forever "
+                    "(MidTermFeatures.py:102,124)", (long long)mid_step_ratio);
+    std::lock_guard<std::mutex> lk(g_mu);
+    { const int rc_w = comm_wait_buffer_free(d_mid); if (rc_w) return rc_w; }      // a gather of this buffer may still read it
+    long long maxM = 0;
+    if (plan->mid_off_step != mid_step_ratio) {
+        std::vector<long long> off(plan->n_clips);
+        long long o = 0;
+        for (long long c = 0; c < plan->n_clips; ++c) {
+            off[c] = o;
+            o += 2LL * plan->P.F * paa_num_mid_windows(plan->clips[c].T, mid_step_ratio);
+        }
+        if (cs()) HIP_TRY(hipStreamSynchronize(cs()));
+        int rc = upload_pooled(&plan->d_mid_off, off.data(), off.size());
+        if (rc) return rc;
+        plan->mid_off_step = mid_step_ratio;
+    }
+    for (long long c = 0; c < plan->n_clips; ++c)
+        maxM = std::max<long long>(maxM, paa_num_mid_windows(plan->clips[c].T, mid_step_ratio));
+    const long long items = (long long)plan->P.F * maxM;
+    const int bpc = (int)((items + 15) / 16);          // 16 (row, window) items per 256-thread block
+    const long long grid = plan->n_clips * bpc;
+    if (grid > 0x7fffffffLL) return fail(PAA_ERR_UNSUPPORTED, "mid-term grid too large");
+    hipLaunchKernelGGL(mid_stats_kernel, dim3((unsigned)grid), dim3(256), 0, cs(), plan->d_clips, plan->d_mid_off,
+                       d_st, plan->P.F, (long long)mid_ratio, (long long)mid_step_ratio, bpc, d_mid);
+    HIP_TRY(hipGetLastError());
+    return PAA_OK;
+}
+
+// beat rate of every clip of an executed plan (deltas on or off: rows 0..18 are used)
+extern "C" int paa_plan_beat_execute(paa_plan_t *plan, const double *d_st, double window_size, double *d_beat) {
+    if (!plan || !d_st || !d_beat) return fail(PAA_ERR_ARG, "null plan / buffer");
+    if (plan->mode != 0) return fail(PAA_ERR_ARG, "beat extraction needs a feature plan");
+    if (!(window_size > 0)) return fail(PAA_ERR_ARG, "window_size must be positive");
+    { const int rc_init = ensure_init(); if (rc_init) return rc_init; }
+    const int max_beat = (int)nearbyint(2.0 / window_size);          // int(round(2.0 / window_size)), :33
+    if (max_beat < 1 || max_beat > 4096) return fail(PAA_ERR_UNSUPPORTED, "beat histogram of %d bins", max_beat);
+    std::lock_guard<std::mutex> lk(g_mu);
+    { const int rc_w = comm_wait_buffer_free(d_beat); if (rc_w) return rc_w; }
+    const size_t lds = (size_t)kBeatRows * (kBeatTile + 1) * 8 + (size_t)kBeatRows * max_beat * 4;
+    if (lds > 160 * 1024)
+        return fail(PAA_ERR_UNSUPPORTED, "beat histogram of %d bins needs %zu bytes of LDS (160 KB per workgroup)", max_beat, lds);
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&beat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(beat_kernel, dim3((unsigned)plan->n_clips), dim3(64), lds, cs(), plan->d_clips, d_st,
+                       window_size, max_beat, d_beat);
+    HIP_TRY(hipGetLastError());
+    return PAA_OK;
+}

@@ -36,11 +36,12 @@ def test_cpu_side_abi_tests_pass_under_asan_and_ubsan(tmp_path):
     if rt is None:
         pytest.skip("no ASan runtime next to hipcc's clang")
     lib = str(tmp_path / "libpaa_hip_asan.so")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-shared", "-fPIC", "-fno-omit-frame-pointer",
-           "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-mllvm", "-disable-machine-licm", "-I/opt/rocm/include",
-           os.path.join(_build.CSRC, "paa_lib.hip"), "-o", lib, "-ldl"]
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    assert res.returncode == 0, res.stderr[-4000:]
+    # every translation unit of the library (csrc/paa_lib.hip + the family_*.hip units) with the host sanitizers on
+    try:
+        _build.build_to(lib, extra_flags=["-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-gpu-sanitize"],
+                        opt="-O1")
+    except RuntimeError as exc:
+        pytest.fail(str(exc)[-4000:])
     env = dict(os.environ)
     env.update({"LD_PRELOAD": rt, "PAA_HIP_LIBRARY": lib,
                 "ASAN_OPTIONS": "detect_leaks=0:abort_on_error=1",            # (the interpreter itself "leaks")
