@@ -77,7 +77,10 @@ struct Shape {
     static constexpr int SPL = PACKED ? 2 : 1;              // samples per loaded element
     static constexpr int C0 = (NF + 63) / 64;
     static constexpr int C = (C0 % 2) ? C0 : C0 + 1;        // bins per lane in the feature stage (odd: conflict-free at stride C)
-    static constexpr int WAVE_DOUBLES = 2 * SLOT + 48 + 40 + 12;   // two slots, fv[48], msp[40], bnd[12]
+    // the time-domain partials are summed through an LDS transpose of 11 x 64 doubles: inside the frame's spectrum slot (free
+    // at that point) when it is large enough, in a scratch of its own for the small windows
+    static constexpr int TSCR = (SLOT >= 11 * 64) ? 0 : 11 * 64;
+    static constexpr int WAVE_DOUBLES = 2 * SLOT + 48 + 40 + 12 + TSCR;   // two slots, fv[48], msp[40], bnd[12], scratch
     static_assert(P >= L1, "plane rows hold L1 elements");
     static_assert(J2 <= 64, "one pass-2 job per lane");
     static_assert(!PACKED || NJ == 1, "packed shapes: one pass-1 job per lane");
@@ -554,20 +557,31 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
             double eb[11];                 // ten entropy blocks + the tail the reference leaves out of them (:37-41)
 #pragma unroll
             for (int b = 0; b < 11; ++b) eb[b] = 0.0;
-            int zc = 0, carry = 0;
-            // wave totals of the partials (before pass 1: the partials' registers are free for the codelets)
+            int zcv = 0, carry = 0;        // per-lane sign-change count, the sign carried from the slot before
+            // wave totals of the partials (before pass 1: the partials' registers are free for the codelets).  The eleven block
+            // sums go through LDS transposed -- lane l writes its partials at [b][l], lane 4 b + p adds 16 of block b's values,
+            // two quad permutes join the four parts -- 70 instructions instead of eleven 20-instruction wave reductions; the
+            // slot is free here (it becomes the exchange plane after pass 1)
             auto finish_time = [&]() {
                 if (MODE == 0 && want) {
-                    double tot = 0.0;
+                    double *sc11 = (SH::TSCR > 0) ? bnd + 12 : cur;      // [11][64]
+                    wsync();                                  // (the previous frame's readers of this slot are done)
 #pragma unroll
-                    for (int b = 0; b < 11; ++b) { eb[b] = wsum(eb[b]) * inv2; tot += eb[b]; }
+                    for (int b = 0; b < 11; ++b) sc11[64 * b + lane] = eb[b];
+                    wsync();
+                    const int bq = min(lane >> 2, 10), part = lane & 3;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc += sc11[64 * bq + 16 * part + i];
+                    acc += dpp_mov<PAA_DPP_X1>(acc);
+                    acc += dpp_mov<PAA_DPP_X2>(acc);
+                    acc = (lane < 44) ? acc * inv2 : 0.0;     // lanes 4 b .. 4 b + 3: energy of block b (b = 10: the tail)
+                    const double tot = wsum((part == 0) ? acc : 0.0);
                     tf.e_tot = tot;
-                    tf.zc = wsum_i(zc);
-                    double num = 0.0;
-#pragma unroll
-                    for (int b = 0; b < 10; ++b) num = (lane == b) ? eb[b] : num;
-                    const double s = fast_div(num, tot + kEps);
-                    tf.ent_e = wsum((lane < 10) ? -(s * fast_log2(s + kEps)) : 0.0);
+                    tf.zc = wsum_i(zcv);
+                    const double s = fast_div(acc, tot + kEps);
+                    tf.ent_e = wsum((lane < 40 && part == 0) ? -(s * fast_log2(s + kEps)) : 0.0);
+                    wsync();
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
@@ -601,7 +615,7 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                         if (r == 0) carry = __builtin_amdgcn_readfirstlane(sa);       // the frame's first sample has no left one
                         const int left = wave_shr1(sb, carry);
                         const int dz = abs(sb - sa) + abs(sa - left);
-                        zc += act1 ? dz : 0;
+                        zcv += act1 ? dz : 0;
                         carry = __builtin_amdgcn_readlane(sb, L1 - 1);
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -647,11 +661,11 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                                 eb[jlo] += (lane < jth) ? e : 0.0;
                                 eb[jlo + 1] += (lane >= jth) ? e : 0.0;
                             }
-                            const int s = sgn_bits(d);
-                            if (r == 0 && u == 0) carry = __builtin_amdgcn_readfirstlane(s);
-                            const int left = wave_shr1(s, carry);      // sample n - 1: the lane below / the last lane of the slot before
-                            zc += act1 ? abs(s - left) : 0;
-                            carry = __builtin_amdgcn_readlane(s, (L1 - 1 - 64 * u < 63) ? L1 - 1 - 64 * u : 63);
+                            const int sg = sgn_bits(d);
+                            if (r == 0 && u == 0) carry = __builtin_amdgcn_readfirstlane(sg);
+                            const int left = wave_shr1(sg, carry);      // sample n - 1: the lane below / the last lane of the slot before
+                            zcv += act1 ? abs(sg - left) : 0;
+                            carry = __builtin_amdgcn_readlane(sg, (L1 - 1 - 64 * u < 63) ? L1 - 1 - 64 * u : 63);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                 }
