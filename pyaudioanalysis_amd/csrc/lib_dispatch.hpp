@@ -9,6 +9,9 @@ struct FamilyCtx {
     double fs;
     int window, step, deltas, mode, sample_kind, F;
     long long total_frames;
+    int ranges;          // >= 1: the plan will be launched in this many consecutive tile ranges (host pipeline): runs are cut as if
+                         // the chip had `ranges` times its CUs, so that every range still fills it in one round
+    int num_cu() const { return g_num_cu * (ranges > 1 ? ranges : 1); }
     const MelTable *mel() const { return mode == 0 ? &tab->mel : nullptr; }
     const ChromaTable *chroma() const { return mode != 1 ? &tab->chroma : nullptr; }
 };
@@ -29,8 +32,8 @@ static int upload_blob(paa_plan *p, const std::vector<unsigned char> &blob) {
     return upload_pooled(&p->d_gen_blob, blob.data(), blob.size());
 }
 // the usual rule of the one-frame-per-iteration kernels: about two chip-wide rounds, 8 .. 64 frames per run
-static int two_round_run(long long total_frames, int waves) {
-    const long long slots = (long long)g_num_cu * waves * 2;
+static int two_round_run(long long total_frames, int waves, int num_cu) {
+    const long long slots = (long long)num_cu * waves * 2;
     const long long per = (total_frames + slots - 1) / slots;
     return (int)std::min<long long>(64, std::max<long long>(8, (per + 3) / 4 * 4));
 }
@@ -47,7 +50,7 @@ static int fam_fast_select(FamilyCtx &c) {
 static void fam_fast_rule(FamilyCtx &c, RunRule &r) {
     // one wave per run, in multiples of the 4-frame quad, at most fl.run frames (halo = one quad); see choose_run_cap
     r.quantum = 4;
-    r.run = choose_run_cap(c.p->clips, 4, 16, c.p->fl.run, 4, c.p->fl.waves_per_cu, g_num_cu);
+    r.run = choose_run_cap(c.p->clips, 4, 16, c.p->fl.run, 4, c.p->fl.waves_per_cu, c.num_cu());
     if (const char *rc_env = experiment_env("PAA_RUN_CAP")) r.run = std::max(16, atoi(rc_env) / 4 * 4);      // A/B experiments only
 }
 static int fam_fast_launch(paa_plan *p, const void *d_packed, double *d_out, const Tile *tiles, long long n, hipStream_t s) {
@@ -69,7 +72,7 @@ static void fam_ct_rule(FamilyCtx &c, RunRule &r) {
     // iteration, so the first run of a clip gets `run` frames and the others run - halo: every run is whole iterations
     r.quantum = 4;
     r.halo_inside = (c.mode == 0) ? (c.deltas ? 2 : 1) : 0;
-    r.run = choose_run_cap(c.p->clips, 4, 16, 256, 0, c.p->cl.waves, g_num_cu, r.halo_inside);
+    r.run = choose_run_cap(c.p->clips, 4, 16, 256, 0, c.p->cl.waves, c.num_cu(), r.halo_inside);
 }
 static int fam_ct_launch(paa_plan *p, const void *d_packed, double *d_out, const Tile *tiles, long long n, hipStream_t s) {
     return launch::ct(p->cl, p->sample_kind, p->P, p->d_gen_blob, d_packed, p->d_clips, p->d_norms, tiles, n, d_out, s);
@@ -96,7 +99,7 @@ static int fam_reg_select(FamilyCtx &c) {
 static void fam_reg_rule(FamilyCtx &c, RunRule &r) {
     const int q = reg::Shape1102::Q;          // runs are multiples of Q frames (halo = one iteration); see choose_run_cap
     r.quantum = q;
-    r.run = choose_run_cap(c.p->clips, q, 4 * q, 32 * q, q, c.p->rl.waves, g_num_cu);
+    r.run = choose_run_cap(c.p->clips, q, 4 * q, 32 * q, q, c.p->rl.waves, c.num_cu());
 }
 static int fam_reg_launch(paa_plan *p, const void *d_packed, double *d_out, const Tile *tiles, long long n, hipStream_t s) {
     return launch::reg(p->rl, p->lds, p->sample_kind, p->P, p->d_gen_blob, d_packed, p->d_clips, p->d_norms, tiles, n, d_out, s);
@@ -116,7 +119,7 @@ static int fam_tri_select(FamilyCtx &c) {
 static void fam_tri_rule(FamilyCtx &c, RunRule &r) {
     // one wave per run, one frame per iteration; a run with t0 > 0 recomputes 1 frame (2 with deltas) first
     r.quantum = 1;
-    r.run = choose_run_cap(c.p->clips, 1, 8, 96, (c.mode == 0) ? (c.deltas ? 2 : 1) : 0, c.p->trl.waves, g_num_cu);
+    r.run = choose_run_cap(c.p->clips, 1, 8, 96, (c.mode == 0) ? (c.deltas ? 2 : 1) : 0, c.p->trl.waves, c.num_cu());
 }
 static int fam_tri_launch(paa_plan *p, const void *d_packed, double *d_out, const Tile *tiles, long long n, hipStream_t s) {
     return launch::tri(p->trl, p->sample_kind, p->P, p->d_gen_blob, d_packed, p->d_clips, p->d_norms, tiles, n, d_out, s);
@@ -137,7 +140,7 @@ static int fam_mix_select(FamilyCtx &c) {
 static void fam_mix_rule(FamilyCtx &c, RunRule &r) {
     // one wave per run, one frame at a time (halo: 1 frame, 2 with deltas)
     r.quantum = 4;
-    r.run = two_round_run(c.total_frames, c.p->ml.waves);
+    r.run = two_round_run(c.total_frames, c.p->ml.waves, c.num_cu());
 }
 static int fam_mix_launch(paa_plan *p, const void *d_packed, double *d_out, const Tile *tiles, long long n, hipStream_t s) {
     return launch::mix(p->ml, p->lds, p->sample_kind, p->P, p->d_gen_blob, d_packed, p->d_clips, p->d_norms, tiles, n, d_out, s);
@@ -162,7 +165,7 @@ static int fam_generic_select(FamilyCtx &c) {
 }
 static void fam_generic_rule(FamilyCtx &c, RunRule &r) {
     r.quantum = 4;
-    r.run = two_round_run(c.total_frames, c.p->gl.waves);
+    r.run = two_round_run(c.total_frames, c.p->gl.waves, c.num_cu());
 }
 static int fam_generic_launch(paa_plan *p, const void *d_packed, double *d_out, const Tile *tiles, long long n, hipStream_t s) {
     return launch::generic(p->gl, p->lds, p->sample_kind, p->P, p->d_gen_blob, d_packed, p->d_clips, p->d_norms, tiles, n, d_out, s);
@@ -178,13 +181,63 @@ static const Family kFamilies[] = {
 };
 constexpr int kNumFamilies = (int)(sizeof(kFamilies) / sizeof(kFamilies[0]));
 
+// what a select() left in the plan, kept with the table set of (fs, window): the next plan of the same (mode, rows) copies
+// it back instead of rebuilding the layout and uploading the table blob again
+struct FamilyChoice {
+    int family = -1;
+    int fast = 0, ct = 0, reg = 0, tri = 0, mixk = 0, big = 0;
+    FastLaunch fl;
+    ct::CtLaunch cl;
+    reg::RegLayout rl;
+    tri::TriLaunch trl;
+    mix::MixLayout ml;
+    GenLayout gl;
+    size_t lds = 0;
+    std::string kernel_name;
+    unsigned char *d_blob = nullptr;       // owned here (pool_free in free_family_choices)
+};
+static void free_family_choices(TableSet &t) {
+    for (auto &kv : t.choices)
+        if (kv.second && kv.second->d_blob) pool_free(kv.second->d_blob);
+    t.choices.clear();
+}
+
 static int choose_family(FamilyCtx &c, RunRule &rr) {
+    paa_plan *p = c.p;
+    // the fast family looks at (step, sample type) too; nobody else does
+    const int fast_key = (c.mode == 0 && c.window == 800 && c.sample_kind == 0 && (c.step == 400 || c.step == 800)) ? c.step : 0;
+    const auto key = std::make_tuple(c.mode, c.F, fast_key);
+#ifndef PAA_EXPERIMENTS          // (experiment switches change the choice from plan to plan: no cache in those builds)
+    auto it = c.tab->choices.find(key);
+    if (it != c.tab->choices.end() && !g_force_generic) {
+        const FamilyChoice &fc = *it->second;
+        p->family = fc.family;
+        p->fast = fc.fast; p->ct = fc.ct; p->reg = fc.reg; p->tri = fc.tri; p->mixk = fc.mixk; p->big = fc.big;
+        p->fl = fc.fl; p->cl = fc.cl; p->rl = fc.rl; p->trl = fc.trl; p->ml = fc.ml; p->gl = fc.gl;
+        p->lds = fc.lds; p->kernel_name = fc.kernel_name;
+        p->d_gen_blob = fc.d_blob; p->blob_cached = true;
+        kFamilies[p->family].run_rule(c, rr);
+        return PAA_OK;
+    }
+#endif
     for (int i = 0; i < kNumFamilies; ++i) {
         const int rc = kFamilies[i].select(c);
         if (rc < 0) return rc;
         if (rc == 0) continue;
-        c.p->family = i;
+        p->family = i;
         kFamilies[i].run_rule(c, rr);
+#ifndef PAA_EXPERIMENTS
+        if (!g_force_generic) {
+            auto fc = std::make_shared<FamilyChoice>();
+            fc->family = i;
+            fc->fast = p->fast; fc->ct = p->ct; fc->reg = p->reg; fc->tri = p->tri; fc->mixk = p->mixk; fc->big = p->big;
+            fc->fl = p->fl; fc->cl = p->cl; fc->rl = p->rl; fc->trl = p->trl; fc->ml = p->ml; fc->gl = p->gl;
+            fc->lds = p->lds; fc->kernel_name = p->kernel_name;
+            fc->d_blob = p->d_gen_blob;            // ownership moves to the table set
+            p->blob_cached = true;
+            c.tab->choices[key] = fc;
+        }
+#endif
         return PAA_OK;
     }
     return fail(PAA_ERR_UNSUPPORTED, "no kernel family takes window %d", c.window);

@@ -5,6 +5,8 @@
 // ------------------------------------------------------------------------------------------
 // host-buffer entry points
 // ------------------------------------------------------------------------------------------
+constexpr long long kRangedMinFrames = 65536;       // a range must still fill the chip: four ranges of >= 16 k frames
+
 static int run_host_st(const void *packed, const int64_t *offsets, int64_t n_clips, int sample_kind, double fs,
                        int window, int step, int deltas, double *out, const int64_t *out_offsets,
                        int64_t mid_ratio, int64_t mid_step, double *mid_out, const int64_t *mid_out_offsets) {
@@ -18,9 +20,14 @@ static int run_host_st(const void *packed, const int64_t *offsets, int64_t n_cli
                     "(MidTermFeatures.py:102,124)", (long long)mid_step);
     paa_plan *plan = nullptr;
     int rc;
+    // One long clip, whole matrix wanted: the frames are computed in kCopyRanges consecutive tile ranges and range k is copied
+    // back (a 2-D copy of its columns) while range k + 1 computes -- the copy-back (0.71 ms for an hour at 34 rows) hides
+    // the kernels instead of following them.  The clip-global normalisation still pins upload -> statistics -> first range.
+    const long long frames_1 = (n_clips == 1) ? paa_num_frames(offsets[1] - offsets[0], window, step) : 0;
+    const bool ranged = n_clips == 1 && out && !out_offsets && !want_mid && frames_1 >= kRangedMinFrames;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        rc = plan_build(offsets, n_clips, sample_kind, fs, window, step, deltas, 0, &plan);
+        rc = plan_build(offsets, n_clips, sample_kind, fs, window, step, deltas, 0, &plan, ranged ? kCopyRanges : 1);
     }
     if (rc) return rc;
     std::unique_ptr<paa_plan, void (*)(paa_plan *)> guard(plan, plan_free_synced);
@@ -51,6 +58,44 @@ static int run_host_st(const void *packed, const int64_t *offsets, int64_t n_cli
     HIP_TRY(hipMemcpyAsync(lane.l->in.p, (const char *)packed + (size_t)base * esz, (size_t)n_total * esz,
                            hipMemcpyHostToDevice, cs()));
     const void *d_samples = lane.l->in.p;
+    if (ranged && plan->family >= 0 && !plan->big && !plan->tiles_host.empty()) {
+        double *d_out = (double *)lane.l->out.p;
+        const long long T = plan->clips[0].T;
+        const int F = plan->P.F;
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            if ((rc = launch_stats(plan, d_samples))) return rc;
+        }
+        // tile ranges at (about) equal frame counts; tiles are in frame order
+        long long first = 0;
+        long long t_begin[kCopyRanges + 1];
+        int used = 0;
+        for (int r = 0; r < kCopyRanges && first < plan->n_tiles; ++r) {
+            const long long t_target = (r == kCopyRanges - 1) ? T : T * (r + 1) / kCopyRanges;
+            long long last = first;
+            while (last < plan->n_tiles && (long long)plan->tiles_host[(size_t)last].t0 < t_target) ++last;
+            if (last == first) continue;
+            t_begin[used] = plan->tiles_host[(size_t)first].t0;
+            {
+                std::lock_guard<std::mutex> lk(g_mu);
+                rc = kFamilies[plan->family].launch(plan, d_samples, d_out, plan->d_tiles + first, last - first, cs());
+            }
+            if (rc) return fail(PAA_ERR_HIP, "launch of %s failed: %s", plan->kernel_name.c_str(), hipGetErrorString(hipGetLastError()));
+            HIP_TRY(hipEventRecord(lane.l->range_done[used], cs()));
+            first = last;
+            ++used;
+        }
+        t_begin[used] = T;
+        for (int r = 0; r < used; ++r) {
+            const long long a = t_begin[r], b = t_begin[r + 1];
+            HIP_TRY(hipStreamWaitEvent(lane.l->copy_stream, lane.l->range_done[r], 0));
+            HIP_TRY(hipMemcpy2DAsync(out + a, (size_t)T * 8, d_out + a, (size_t)T * 8, (size_t)(b - a) * 8, (size_t)F,
+                                     hipMemcpyDeviceToHost, lane.l->copy_stream));
+        }
+        HIP_TRY(hipStreamSynchronize(lane.l->copy_stream));
+        HIP_TRY(hipStreamSynchronize(cs()));
+        return PAA_OK;
+    }
     if ((rc = paa_plan_execute(plan, d_samples, (double *)lane.l->out.p))) return rc;
     if (want_mid) {
         const long long md = paa_plan_mid_doubles(plan, mid_step);

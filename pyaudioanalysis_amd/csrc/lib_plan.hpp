@@ -76,6 +76,8 @@ struct paa_plan {
     reg::RegLayout rl;               // register-FFT kernel (windows 2 R1 R2): LDS layout, blob in d_gen_blob
     int reg = 0;
     unsigned char *d_gen_blob = nullptr;
+    bool blob_cached = false;        // d_gen_blob belongs to the table set's FamilyChoice (not freed with the plan)
+    void *d_block = nullptr;         // the plan's one device block: d_clips, d_tiles, d_chunks, d_norms, d_psum / pmin / pmax point into it
     int big = 0;                     // window beyond the LDS envelope: Stockham passes through HBM scratch
     void *d_big = nullptr;
     size_t big_bytes = 0;
@@ -91,6 +93,7 @@ struct paa_plan {
     int tri = 0;                     // 1: three-pass register FFT for the large default windows (kernels_tri.hpp); blob in d_gen_blob
     tri::TriLaunch trl;
     int family = -1;                 // index into kFamilies (lib_dispatch.hpp); -1: the big-window path
+    std::vector<Tile> tiles_host;    // host copy of the tile list (plans built for a ranged launch only)
     std::string kernel_name;
 };
 
@@ -99,8 +102,9 @@ static void plan_free(paa_plan *p) {
     if (!p) return;
     --g_live_plans;
     // (the caller has synchronised the stream the plan ran on: pooled blocks may be handed to the next plan at once)
-    pool_free(p->d_clips); pool_free(p->d_norms); pool_free(p->d_tiles); pool_free(p->d_chunks);
-    pool_free(p->d_psum); pool_free(p->d_pmin); pool_free(p->d_pmax); pool_free(p->d_mid_off); pool_free(p->d_gen_blob);
+    pool_free(p->d_block);          // clips, tiles, statistics chunks / partials, clip constants: one pooled block
+    pool_free(p->d_mid_off);
+    if (!p->blob_cached) pool_free(p->d_gen_blob);
     if (p->d_big) (void)hipFree(p->d_big);
     delete p;
 }
@@ -115,8 +119,9 @@ static void plan_free_synced(paa_plan *p) {
 
 #include "lib_dispatch.hpp"
 
+// ranges > 1: the caller will launch the plan's tiles in that many consecutive groups (run_host_st's copy-back pipeline)
 static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, double fs, int window, int step,
-                      int deltas, int mode, paa_plan **out) {
+                      int deltas, int mode, paa_plan **out, int ranges = 1) {
     int rc = ensure_init();
     if (rc) return rc;
     if (!offsets || n_clips < 1 || !out) return fail(PAA_ERR_ARG, "null offsets / no clips");
@@ -200,7 +205,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     { const char *dbg = experiment_env("PAA_KERNEL_DEBUG"); P.debug = dbg ? atoi(dbg) : 0; }
 
     // ---- kernel choice + tiles: the first family of kFamilies (lib_dispatch.hpp) that takes the shape; its run rule
-    FamilyCtx fc{p.get(), tab, fs, window, step, deltas, mode, sample_kind, F, total_frames};
+    FamilyCtx fc{p.get(), tab, fs, window, step, deltas, mode, sample_kind, F, total_frames, ranges};
     RunRule rr;
     rc = choose_family(fc, rr);
     if (rc) return rc;
@@ -219,6 +224,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         }
     }
     p->n_tiles = (long long)tiles.size();
+    if (ranges > 1) p->tiles_host = tiles;          // (the host pipeline cuts the list at frame boundaries)
     if (p->n_tiles > 0x7fffffffLL || n_chunks > 0x7fffffffLL || n_clips > 0x7fffffffLL)
         return fail(PAA_ERR_UNSUPPORTED, "batch too large for one launch (%lld runs, %lld statistics chunks, %lld clips)",
                     p->n_tiles, n_chunks, (long long)n_clips);
@@ -231,13 +237,29 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
             ch.clip = (int)c;
             chunks.push_back(ch);
         }
-    if ((rc = upload_pooled(&p->d_clips, p->clips.data(), p->clips.size()))) return rc;
-    if ((rc = upload_pooled(&p->d_tiles, tiles.data(), tiles.size()))) return rc;
-    if ((rc = upload_pooled(&p->d_chunks, chunks.data(), chunks.size()))) return rc;
-    if ((rc = upload_pooled(&p->d_norms, (const void *)nullptr, (size_t)n_clips))) return rc;
-    const size_t nch = (size_t)std::max<long long>(n_chunks, 1);
-    if ((rc = pool_alloc(&p->d_psum, nch * 8)) || (rc = pool_alloc(&p->d_pmin, nch * 8)) ||
-        (rc = pool_alloc(&p->d_pmax, nch * 8))) return rc;
+    // ONE pooled device block and ONE upload per plan (the host-buffer entry points build a plan per call):
+    //   [clip descriptors | tiles | statistics chunks] (uploaded) [clip constants | partial sums | minima | maxima]
+    {
+        const size_t nch = (size_t)std::max<long long>(n_chunks, 1);
+        auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+        const size_t o_clips = 0, o_tiles = o_clips + up(p->clips.size() * sizeof(ClipDev));
+        const size_t o_chunks = o_tiles + up(std::max<size_t>(tiles.size(), 1) * sizeof(Tile));
+        const size_t o_norms = o_chunks + up(std::max<size_t>(chunks.size(), 1) * sizeof(StatChunk));
+        const size_t o_sum = o_norms + up((size_t)n_clips * sizeof(ClipNorm));
+        const size_t o_min = o_sum + up(nch * 8), o_max = o_min + up(nch * 8), total = o_max + up(nch * 8);
+        if ((rc = pool_alloc(&p->d_block, total))) return rc;
+        std::vector<unsigned char> stage(o_norms, 0);
+        memcpy(stage.data() + o_clips, p->clips.data(), p->clips.size() * sizeof(ClipDev));
+        if (!tiles.empty()) memcpy(stage.data() + o_tiles, tiles.data(), tiles.size() * sizeof(Tile));
+        if (!chunks.empty()) memcpy(stage.data() + o_chunks, chunks.data(), chunks.size() * sizeof(StatChunk));
+        HIP_TRY(hipMemcpy(p->d_block, stage.data(), o_norms, hipMemcpyHostToDevice));
+        unsigned char *b = reinterpret_cast<unsigned char *>(p->d_block);
+        p->d_clips = reinterpret_cast<ClipDev *>(b + o_clips);
+        p->d_tiles = reinterpret_cast<Tile *>(b + o_tiles);
+        p->d_chunks = reinterpret_cast<StatChunk *>(b + o_chunks);
+        p->d_norms = reinterpret_cast<ClipNorm *>(b + o_norms);
+        p->d_psum = b + o_sum; p->d_pmin = b + o_min; p->d_pmax = b + o_max;
+    }
     // every one-launch feature kernel folds the statistics partials into the clip constants itself (its waves' prologue);
     // chromagram plans keep clip_params_kernel (the truncated-tail kernel of the host entry point reads its output), and so
     // does the big-window path (a chain of small kernels)

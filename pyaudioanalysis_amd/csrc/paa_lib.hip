@@ -14,6 +14,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -67,6 +68,9 @@ struct TableSet {
     int *d_ch_start = nullptr, *d_ch_src = nullptr;
     double *d_ch_w = nullptr;
     FastTables fast;        // extra tables of the specialised kernels (may be empty)
+    // kernel choice per (mode, rows, fast-kernel step): the family that took the shape, its layout and its table blob on the
+    // device -- a host-buffer call builds a plan per call and must not rebuild / re-upload 20-40 KB of tables each time
+    std::map<std::tuple<int, int, int>, std::shared_ptr<struct FamilyChoice>> choices;
 };
 
 struct Scratch {
@@ -87,8 +91,11 @@ static std::map<std::pair<double, int>, std::unique_ptr<TableSet>> g_tables;
 // Host-buffer entry points (NumPy in -> NumPy out) run in LANES: each lane has its own stream and scratch buffers, so
 // calls from several host threads overlap on the device and on both PCIe directions instead of queueing behind one
 // mutex.  A thread holds a lane for the duration of one call; every launch / copy of that call goes to cs().
+constexpr int kCopyRanges = 4;        // frame ranges of one long clip: range k is copied back while range k + 1 computes
 struct Lane {
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;        // D2H of finished frame ranges (run_host_st)
+    hipEvent_t range_done[kCopyRanges] = {nullptr, nullptr, nullptr, nullptr};
     Scratch in, out, mid;
     bool busy = false;
 };
@@ -242,7 +249,9 @@ static int upload_pooled(T **dst, const void *src, size_t count) {
     return PAA_OK;
 }
 
+static void free_family_choices(TableSet &t);      // (lib_dispatch.hpp)
 static void free_tables(TableSet &t) {
+    free_family_choices(t);
     (void)hipFree(t.d_tw); (void)hipFree(t.d_post); (void)hipFree(t.d_mel_lo); (void)hipFree(t.d_mel_cnt);
     (void)hipFree(t.d_mel_off); (void)hipFree(t.d_mel_w); (void)hipFree(t.d_dct); (void)hipFree(t.d_ch_start);
     (void)hipFree(t.d_ch_src); (void)hipFree(t.d_ch_w);
@@ -344,8 +353,12 @@ extern "C" int paa_init(int device_id) {
     tl_device = device_id;
     // (a failed earlier attempt may have left some of these behind: create only what is missing)
     if (!g_main_stream) HIP_TRY(hipStreamCreateWithFlags(&g_main_stream, hipStreamNonBlocking));
-    for (int i = 0; i < kLanes; ++i)
+    for (int i = 0; i < kLanes; ++i) {
         if (!g_lanes[i].stream) HIP_TRY(hipStreamCreateWithFlags(&g_lanes[i].stream, hipStreamNonBlocking));
+        if (!g_lanes[i].copy_stream) HIP_TRY(hipStreamCreateWithFlags(&g_lanes[i].copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < kCopyRanges; ++k)
+            if (!g_lanes[i].range_done[k]) HIP_TRY(hipEventCreateWithFlags(&g_lanes[i].range_done[k], hipEventDisableTiming));
+    }
     if (!g_ev0) HIP_TRY(hipEventCreate(&g_ev0));
     if (!g_ev1) HIP_TRY(hipEventCreate(&g_ev1));
     {
@@ -371,6 +384,8 @@ extern "C" void paa_shutdown(void) {
     for (Scratch *s : {&g_sim_z, &g_sim_small, &g_sim_cand, &g_sim_in, &g_sim_out, &g_sim_filt}) { if (s->p) (void)hipFree(s->p); s->p = nullptr; s->cap = 0; }
     for (Lane &ln : g_lanes) {
         if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); ln.stream = nullptr; }
+        if (ln.copy_stream) { (void)hipStreamSynchronize(ln.copy_stream); (void)hipStreamDestroy(ln.copy_stream); ln.copy_stream = nullptr; }
+        for (hipEvent_t &ev : ln.range_done) { if (ev) (void)hipEventDestroy(ev); ev = nullptr; }
         for (Scratch *s : {&ln.in, &ln.out, &ln.mid}) { if (s->p) (void)hipFree(s->p); s->p = nullptr; s->cap = 0; }
     }
     if (g_ev0) (void)hipEventDestroy(g_ev0);
