@@ -33,6 +33,7 @@
 // (:415-422) / chromagram (:349-359) for these windows.
 #pragma once
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "kernels_mix.hpp"
@@ -72,11 +73,14 @@ struct Shape {
     static constexpr int NJOB3 = PACKED ? pair_count(R1, R2, R3) : NQ1 * R2;
     static constexpr int NR3 = (NJOB3 + 63) / 64;           // pass-3 rounds
     static constexpr int PLANE = NQ1 * P;
-    static constexpr int SLOT = ((PLANE > NF ? PLANE : NF) + 1) & ~1;      // doubles per spectrum slot
-    static constexpr int LT = W / 10, LB = NF / 10;         // entropy blocks (samples / bins)
-    static constexpr int SPL = PACKED ? 2 : 1;              // samples per loaded element
     static constexpr int C0 = (NF + 63) / 64;
     static constexpr int C = (C0 % 2) ? C0 : C0 + 1;        // bins per lane in the feature stage (odd: conflict-free at stride C)
+    // doubles per spectrum slot: the exchange plane, and 64 lanes x C bins for the feature stage -- the bins past NF are kept
+    // at zero (re-zeroed after every transform where the plane reaches into them), so the sweeps need no bounds masks
+    static constexpr int SLOT0 = (PLANE > NF ? PLANE : NF) > 64 * C ? (PLANE > NF ? PLANE : NF) : 64 * C;
+    static constexpr int SLOT = (SLOT0 + 1) & ~1;
+    static constexpr int LT = W / 10, LB = NF / 10;         // entropy blocks (samples / bins)
+    static constexpr int SPL = PACKED ? 2 : 1;              // samples per loaded element
     // the time-domain partials are summed through an LDS transpose of 11 x 64 doubles: inside the frame's spectrum slot (free
     // at that point) when it is large enough, in a scratch of its own for the small windows
     static constexpr int TSCR = (SLOT >= 11 * 64) ? 0 : 11 * 64;
@@ -317,12 +321,7 @@ __device__ __forceinline__ void tri_features(const TriLayout &L, const Tabs &tb,
     const int kb = C * lane;
     double Xc[C], Xv[C];
 #pragma unroll
-    for (int m = 0; m < C; ++m) {
-        const int k = min(kb + m, NF - 1);
-        const double a = cur[k], b = prv[k];
-        Xc[m] = (kb + m < NF) ? a : 0.0;
-        Xv[m] = (kb + m < NF) ? b : 0.0;
-    }
+    for (int m = 0; m < C; ++m) { Xc[m] = cur[kb + m]; Xv[m] = prv[kb + m]; }       // (bins past NF are zeros: see Shape::SLOT)
     double sXa = 0.0, sXb = 0.0, sMa = 0.0, sMb = 0.0, sVa = 0.0, sVb = 0.0, mx = 0.0, csa = 0.0, csb = 0.0;
 #pragma unroll
     for (int m = 0; m + 1 < C; m += 2) {
@@ -405,7 +404,9 @@ __device__ __forceinline__ void tri_features(const TriLayout &L, const Tabs &tb,
 #pragma unroll
         for (int m = 0; m < C; ++m) {
             run = fma(Xc[m], Xc[m], run);
-            first = (first == 0x7fffffff && kb + m < NF && run + kEps > thr) ? kb + m : first;
+            // (a bin below NF always qualifies -- the last one reaches the total, bin 0 does when the total is 0 -- so the zero
+            // bins past NF never decide)
+            first = (first == 0x7fffffff && run + kEps > thr) ? kb + m : first;
         }
         first = mix::wmin_nonneg_i(first);
     }
@@ -590,11 +591,29 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                 const bool act1 = lane < L1;
                 const int jj = act1 ? lane : L1 - 1;
                 double2 v[R1];
+                // int16 PCM: the raw pair words are kept for the sign changes (packed 16-bit arithmetic, below)
+                constexpr bool RAW16 = std::is_same<T, int16_t>::value;
+                int wr[RAW16 ? R1 : 1];
 #pragma unroll
                 for (int r = 0; r < R1; ++r) {
-                    const double2 x = ct::PairLoad<T>::get(xf + 2 * (jj + L1 * r));
-                    v[r] = make_double2(fma(x.x, sc, -mean), fma(x.y, sc, -mean));
+                    if constexpr (RAW16) {
+                        typedef int w32 __attribute__((aligned(2)));
+                        wr[r] = *reinterpret_cast<const w32 *>(xf + 2 * (jj + L1 * r));
+                        v[r] = make_double2(fma((double)(short)(wr[r] & 0xffff), sc, -mean), fma((double)(wr[r] >> 16), sc, -mean));
+                    } else {
+                        const double2 x = ct::PairLoad<T>::get(xf + 2 * (jj + L1 * r));
+                        v[r] = make_double2(fma(x.x, sc, -mean), fma(x.y, sc, -mean));
+                    }
                 }
+                // sign(x / 2^15 - mean) of an int16 sample = sign(x - mu), mu = mean 2^15, decided in packed saturating 16-bit
+                // arithmetic (kernels_fast.hpp): s = clamp(sat(x - floor(mu)), lo, 1) * a + c with (lo, a, c) = (-1, 1, 0) when mu
+                // is a whole number (a sample can sit on the mean: sign 0) and (0, 2, -1) otherwise
+                typedef f800::s16x2 s16x2;
+                const short zb_ = (short)nm.zb, lo_ = nm.mu_whole ? (short)-1 : (short)0, mul_ = nm.mu_whole ? (short)1 : (short)2,
+                            add_ = nm.mu_whole ? (short)0 : (short)-1;
+                const s16x2 zc_b = {zb_, zb_}, zc_lo = {lo_, lo_}, zc_one = {1, 1}, zc_mul = {mul_, mul_}, zc_add = {add_, add_};
+                s16x2 zacc = {0, 0};
+                unsigned carryw = 0;
                 PAA_TICK(0)
                 if (MODE == 0) {
 #pragma unroll
@@ -611,15 +630,29 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                             eb[jlo] += (lane < jth) ? e : 0.0;
                             eb[jlo + 1] += (lane >= jth) ? e : 0.0;
                         }
-                        const int sa = sgn_bits(d0), sb = sgn_bits(d1);
-                        if (r == 0) carry = __builtin_amdgcn_readfirstlane(sa);       // the frame's first sample has no left one
-                        const int left = wave_shr1(sb, carry);
-                        const int dz = abs(sb - sa) + abs(sa - left);
-                        zcv += act1 ? dz : 0;
-                        carry = __builtin_amdgcn_readlane(sb, L1 - 1);
+                        if constexpr (RAW16) {
+                            // both samples of the pair at once: {s_even, s_odd} against {s of the sample before the pair, s_even}
+                            const s16x2 cur2 = __builtin_bit_cast(s16x2, wr[r]);
+                            const s16x2 sg = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_elementwise_sub_sat(cur2, zc_b), zc_lo), zc_one) * zc_mul + zc_add;
+                            const unsigned sgw = __builtin_bit_cast(unsigned, sg);
+                            if (r == 0) carryw = (unsigned)__builtin_amdgcn_readfirstlane((int)sgw) << 16;      // the first sample has no left one
+                            const unsigned leftw = (unsigned)wave_shr1((int)sgw, (int)carryw);         // the lane below (lane 0: the row above)
+                            const s16x2 sh = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(sgw, leftw, 16));
+                            const s16x2 df = sg - sh;
+                            zacc += __builtin_elementwise_max(df, -df);
+                            carryw = (unsigned)__builtin_amdgcn_readlane((int)sgw, L1 - 1);
+                        } else {
+                            const int sa = sgn_bits(d0), sb = sgn_bits(d1);
+                            if (r == 0) carry = __builtin_amdgcn_readfirstlane(sa);       // the frame's first sample has no left one
+                            const int left = wave_shr1(sb, carry);
+                            const int dz = abs(sb - sa) + abs(sa - left);
+                            zcv += act1 ? dz : 0;
+                            carry = __builtin_amdgcn_readlane(sb, L1 - 1);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                if (RAW16) zcv = act1 ? (int)zacc.x + (int)zacc.y : 0;
                 finish_time();
                 PAA_TICK(1)
                 Cd<R1>::run(v);
@@ -855,6 +888,10 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+        // bins NF .. 64 C of the slot are zeros for the feature sweeps (the exchange planes may have written there)
+        if (MODE == 0) {
+            for (int k = NF + lane; k < 64 * SH::C; k += kWave) cur[k] = 0.0;
         }
         wsync();
         PAA_TICK(6)

@@ -150,37 +150,29 @@ def test_config5_full_matrices(gpu_lib, cfg5_clip, capsys):
                   "config 5 chromagram, 60 s, all rows")
 
 
-@pytest.mark.parametrize("deltas", [False, True], ids=["34rows", "68rows"])
-def test_ranged_host_call_equals_the_single_launch_bit_for_bit(gpu_lib, deltas):
-    """A long clip handed to the host-buffer API is computed in four consecutive frame ranges whose columns are copied back
-    while the next range computes (csrc/lib_host_api.hpp: run_host_st, shorter runs per wave).  Every bit must equal the
-    device-resident plan's single launch over the same clip (ShortTermFeatures.py:608-682 is the same arithmetic per frame
-    whatever the tiling)."""
-    import ctypes
-    x = synth_clip(2, 3600 * FS)
-    F, _ = ShortTermFeatures.feature_extraction(x, FS, 800, 400, deltas)            # >= 65 536 frames: the ranged path
+def _plan_matrix(x, deltas, shape):
     plan = _ffi.Plan(np.array([0, len(x)], dtype=np.int64), FS, 800, 400, deltas=deltas, sample_kind=0)
     try:
         d_in = _ffi.DeviceBuffer.from_host(x)
         d_out = _ffi.DeviceBuffer(plan.out_doubles * 8)
         plan.execute(d_in, d_out)
         _ffi.sync()
-        G = d_out.to_host(np.float64, plan.out_doubles).reshape(F.shape)
+        return d_out.to_host(np.float64, plan.out_doubles).reshape(shape)
     finally:
         plan.destroy()
-    assert np.array_equal(F, G)
-    # a clip just below the threshold takes the one-launch path: same bits as its prefix of the long clip's plan? no --
-    # normalisation is clip-global; just make sure both sides of the threshold agree with their own plans
-    y = x[:65535 * 400 + 800 - 400]                                                    # 65 535 frames: not ranged
-    Fy, _ = ShortTermFeatures.feature_extraction(y, FS, 800, 400, deltas)
-    plan = _ffi.Plan(np.array([0, len(y)], dtype=np.int64), FS, 800, 400, deltas=deltas, sample_kind=0)
-    try:
-        d_in = _ffi.DeviceBuffer.from_host(y)
-        d_out = _ffi.DeviceBuffer(plan.out_doubles * 8)
-        plan.execute(d_in, d_out)
-        _ffi.sync()
-        Gy = d_out.to_host(np.float64, plan.out_doubles).reshape(Fy.shape)
-    finally:
-        plan.destroy()
-    assert Fy.shape[1] == 65534 or Fy.shape[1] == 65535
-    assert np.array_equal(Fy, Gy)
+
+
+def test_ranged_host_call_equals_the_single_launch_bit_for_bit(gpu_lib):
+    """A long clip handed to the host-buffer API is computed in four consecutive frame ranges whose columns are copied back
+    while the next range computes (csrc/lib_host_api.hpp: run_host_st, shorter runs per wave).  Every bit must equal the
+    device-resident plan's single launch over the same clip (ShortTermFeatures.py:608-682 is the same arithmetic per frame
+    whatever the tiling), with and without deltas, and on both sides of the 65 536-frame threshold."""
+    x = synth_clip(2, 1700 * FS)                                                        # 67 999 frames: the ranged path
+    for deltas in (False, True):
+        F, _ = ShortTermFeatures.feature_extraction(x, FS, 800, 400, deltas)
+        assert F.shape[1] == 67999
+        assert np.array_equal(F, _plan_matrix(x, deltas, F.shape))
+    y = x[:65535 * 400 + 400]                                                           # 65 535 frames: one launch
+    Fy, _ = ShortTermFeatures.feature_extraction(y, FS, 800, 400, True)
+    assert Fy.shape[1] == 65535
+    assert np.array_equal(Fy, _plan_matrix(y, True, Fy.shape))
