@@ -81,9 +81,9 @@ struct Shape {
     static constexpr int SLOT = (SLOT0 + 1) & ~1;
     static constexpr int LT = W / 10, LB = NF / 10;         // entropy blocks (samples / bins)
     static constexpr int SPL = PACKED ? 2 : 1;              // samples per loaded element
-    // the time-domain partials are summed through an LDS transpose of 11 x 64 doubles: inside the frame's spectrum slot (free
+    // the time-domain partials are summed through an LDS transpose of 11 x 65 doubles: inside the frame's spectrum slot (free
     // at that point) when it is large enough, in a scratch of its own for the small windows
-    static constexpr int TSCR = (SLOT >= 11 * 64) ? 0 : 11 * 64;
+    static constexpr int TSCR = (SLOT >= 11 * 65) ? 0 : 11 * 65;
     static constexpr int WAVE_DOUBLES = 2 * SLOT + 48 + 40 + 12 + TSCR;   // two slots, fv[48], msp[40], bnd[12], scratch
     static_assert(P >= L1, "plane rows hold L1 elements");
     static_assert(J2 <= 64, "one pass-2 job per lane");
@@ -92,12 +92,13 @@ struct Shape {
     static_assert((L1 < 64 ? L1 : 64) * SPL <= LT, "a register row may contain at most one entropy-block boundary");
     static_assert(C <= LB, "a lane's bins may contain at most one entropy-block boundary");
     static_assert(R3 > 1 || !PACKED, "two-pass shapes (R3 = 1): real input only (Z[k] and Z[N - k] would sit in different lanes)");
+    static_assert(R3 <= 4 || !PACKED, "packed shapes: the pass-3 store flags hold four outputs per job");
 };
 
 // shared (per workgroup) LDS tables + the global tables behind them in the same device blob
 struct TriLayout {
     int off_tw2;                    // double2 [R2][R3]: W_L1^(b q2)
-    int off_p3;                     // packed: ushort4 [64 NR3]: plane offset of job A, of job B, first bin kA, flags
+    int off_p3;                     // packed: ushort4 [64 NR3]: plane offset of job A, of job B, first bin kA, store flags
     int off_mello, off_melcnt, off_meloff, off_melw, off_dct, off_chstart, off_chsrc, off_chw;
     int table_bytes;                // LDS part, multiple of 16
     int off_g_tw1;                  // global part: double2 [NQ1][L1]: W_N^(j q1)
@@ -565,15 +566,21 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
             // slot is free here (it becomes the exchange plane after pass 1)
             auto finish_time = [&]() {
                 if (MODE == 0 && want) {
-                    double *sc11 = (SH::TSCR > 0) ? bnd + 12 : cur;      // [11][64]
+                    double *sc11 = (SH::TSCR > 0) ? bnd + 12 : cur;      // [11][65]
                     wsync();                                  // (the previous frame's readers of this slot are done)
+                    // row stride 65 and part p starting 8 (p >> 1) elements into its sixteen: at every step the 32 lanes of a read
+                    // group (eight blocks x four parts) touch 32 different banks
 #pragma unroll
-                    for (int b = 0; b < 11; ++b) sc11[64 * b + lane] = eb[b];
+                    for (int b = 0; b < 11; ++b) sc11[65 * b + lane] = eb[b];
                     wsync();
                     const int bq = min(lane >> 2, 10), part = lane & 3;
+                    const double *rowp = sc11 + 65 * bq + 16 * part;
+                    const double *half_a = rowp + 8 * (part >> 1), *half_b = rowp + 8 * ((part >> 1) ^ 1);
                     double acc = 0.0;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) acc += sc11[64 * bq + 16 * part + i];
+                    for (int i = 0; i < 8; ++i) acc += half_a[i];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc += half_b[i];
                     acc += dpp_mov<PAA_DPP_X1>(acc);
                     acc += dpp_mov<PAA_DPP_X2>(acc);
                     acc = (lane < 44) ? acc * inv2 : 0.0;     // lanes 4 b .. 4 b + 3: energy of block b (b = 10: the tail)
@@ -814,8 +821,10 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
             PAA_TICK(5)
 #pragma unroll
             for (int u = 0; u < NR3; ++u) {
+                // flags (host table): bit 0 the (0, 0) job, bits 1 + k3 "store X[k]", bits 5 + k3 "store X[N - k]" (a self-paired job
+                // meets each of its pairs {k, N - k} twice: only the smaller index writes; idle lanes of the last round: 0)
                 const int flags = pe[u].w, kA = pe[u].z;
-                const bool act3 = (flags & 1) != 0, self = (flags & 2) != 0, is00 = (flags & 4) != 0;
+                const bool is00 = (flags & 1) != 0;
                 double2 pw[R3];
 #pragma unroll
                 for (int k3 = 0; k3 < R3; ++k3) pw[k3] = g_post[(lane + 64 * u) * R3 + k3];
@@ -834,11 +843,8 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                     const double xr_ = e.x + wo.x, xi_ = e.y + wo.y, yr_ = e.x - wo.x, yi_ = e.y - wo.y;
                     const double mk = mag_sqrt(fma(xr_, xr_, xi_ * xi_)) * mscale;
                     const double mm = mag_sqrt(fma(yr_, yr_, yi_ * yi_)) * mscale;
-                    // a self-paired job meets each of its pairs {k, N - k} twice: the smaller index writes
-                    const bool st1 = act3 && (!self || 2 * k <= N);
-                    const bool st2 = act3 && (k != 0) && (!self || 2 * k < N);
-                    if (st1) cur[k] = mk;
-                    if (st2) cur[N - k] = mm;
+                    if (flags & (2 << k3)) cur[k] = mk;
+                    if (flags & (32 << k3)) cur[N - k] = mm;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1011,7 +1017,13 @@ inline void tri_fill(double fs, const MelTable *mel, const ChromaTable *chroma, 
                 pt[4 * p] = (unsigned short)(q1 * SH::P + q2 * R3);
                 pt[4 * p + 1] = (unsigned short)(p1 * SH::P + p2 * R3);
                 pt[4 * p + 2] = (unsigned short)k;
-                pt[4 * p + 3] = (unsigned short)(1 | (self ? 2 : 0) | ((q1 == 0 && q2 == 0) ? 4 : 0));
+                unsigned fl = (q1 == 0 && q2 == 0) ? 1u : 0u;
+                for (int k3 = 0; k3 < R3; ++k3) {
+                    const int kk = k + R1 * R2 * k3;
+                    if (!self || 2 * kk <= N) fl |= 2u << k3;                       // X[k]
+                    if (kk != 0 && (!self || 2 * kk < N)) fl |= 32u << k3;          // X[N - k]
+                }
+                pt[4 * p + 3] = (unsigned short)fl;
                 for (int k3 = 0; k3 < R3; ++k3) put_w(L.off_g_post, (size_t)p * R3 + k3, (long long)k + (long long)R1 * R2 * k3, 2LL * N);
                 ++p;
             }

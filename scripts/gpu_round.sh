@@ -1,11 +1,13 @@
 #!/bin/bash
-# one GPU pass of a round: the whole -m gpu suite, kernel-resident timing of every non-headline case, optional profiles
+# one GPU pass of a round: the whole -m gpu suite, the default bench line, the headline profile (scripts/profile.sh) and the
+# counter passes of the named non-headline cases
 # usage: bash scripts/gpu_round.sh <tag> [profile-case ...]
-tag=${1:-r03}; shift
+tag=${1:-r04}; shift
 out=gpurun_out/$tag; mkdir -p $out
-(timeout 1200 python -m pytest tests -m gpu -q --no-header 2>&1 | tail -60) > $out/tests.log
-for c in reg_features reg_features_stereo reg_spectrogram reg_spectrogram_stereo reg_chromagram reg_chromagram_stereo w1024 ct_640 ct_640_spectrogram ct_800_f64 ct_800_stereo ct_400 ct_320 w2400 w2205 mid_stats; do
-  timeout 300 python scripts/kernel_loop.py --case $c --launches 50 2>&1 | tail -1
-done > $out/cases.jsonl
-for c in "$@"; do timeout 900 bash scripts/profile_kernel.sh $tag $c > $out/prof_$c.log 2>&1; done
-tail -12 $out/tests.log; cat $out/cases.jsonl | cut -c1-330
+if [ -z "$PAA_SKIP_TESTS" ]; then (timeout 900 python -m pytest tests -m gpu -q --no-header --durations=6 2>&1 | tail -16) > $out/tests.log; fi
+timeout 900 python bench.py > $out/bench.json 2> $out/bench.err
+timeout 900 bash scripts/profile.sh $tag > $out/profile.log 2>&1
+python scripts/summarize_prof.py gpurun_out/prof_$tag gpurun_out/${tag}_fast800_w8_summary.json > $out/summarize.log 2>&1
+rm -rf gpurun_out/prof_$tag/trace gpurun_out/prof_$tag/pmc1 gpurun_out/prof_$tag/pmc2 gpurun_out/prof_$tag/pmc3 gpurun_out/prof_$tag/pmc4      # (gpurun brings back at most 64 MiB)
+for c in "$@"; do timeout 600 bash scripts/profile_kernel.sh $tag $c > $out/prof_$c.log 2>&1; done
+tail -12 $out/tests.log

@@ -13,3 +13,5 @@ rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_V
 rocprofv3 --pmc FETCH_SIZE -d $out/pmc3 -o pmc -- python scripts/kernel_loop.py --case $case --launches 4 --warmup 1 > $out/bench_pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $out/pmc4 -o pmc -- python scripts/kernel_loop.py --case $case --launches 4 --warmup 1 > $out/bench_pmc4.log 2>&1
 python scripts/summarize_kernel_prof.py $out $GRAFT_REPO_ROOT/gpurun_out/${tag}_${case}_summary.json
+# (the raw rocpd databases are tens of MB per case and gpurun brings back at most 64 MiB: keep the summary and the logs)
+rm -rf $out/trace $out/pmc1 $out/pmc2 $out/pmc3 $out/pmc4
