@@ -142,3 +142,30 @@ extern "C" int paa_debug_fft_plan(int window, int32_t *radices, int32_t *fft_len
     for (int i = 0; i < n && i < 32; ++i) radices[i] = p.radix[i];
     return n;
 }
+
+// host side of the three-pass register-FFT kernels for a window (no device needed): the shape (R1, R2, R3, packed, plane row
+// pitch P, waves per workgroup, pass-3 lane jobs, LDS bytes) into shape8, and the whole table blob (LDS part followed by the
+// global part) with the offsets of its tables into offsets6 = {tw2, p3, g_tw1, g_post, table_bytes, total_bytes}.
+// Returns the blob size (0: the window goes to another kernel; blob may be null to query the size).
+extern "C" int paa_debug_tri_plan(int window, double fs, int32_t *shape8, int32_t *offsets6, unsigned char *blob, int capacity) {
+    if (window < 2 || !shape8 || !offsets6) return fail(PAA_ERR_ARG, "bad argument");
+    tri::TriLaunch tl;
+    std::vector<unsigned char> b;
+    if (!tri::tri_select(window, 1, fs, nullptr, nullptr, tl, b)) return 0;
+    switch (tl.shape) {
+#define PAA_TRI_DESCRIBE(ID, SH)                                                                               \
+        case ID: shape8[0] = tri::SH::R1; shape8[1] = tri::SH::R2; shape8[2] = tri::SH::R3; shape8[3] = tri::SH::PACKED ? 1 : 0;    \
+                 shape8[4] = tri::SH::P; shape8[5] = tri::SH::NW; shape8[6] = tri::SH::NJOB3; shape8[7] = (int32_t)tl.lds; break;
+        PAA_TRI_SHAPES(PAA_TRI_DESCRIBE)
+#undef PAA_TRI_DESCRIBE
+        default: return 0;
+    }
+    const tri::TriLayout &L = tl.layout;
+    offsets6[0] = L.off_tw2; offsets6[1] = L.off_p3; offsets6[2] = L.off_g_tw1; offsets6[3] = L.off_g_post;
+    offsets6[4] = L.table_bytes; offsets6[5] = L.total_bytes;
+    if (blob) {
+        if (capacity < (int)b.size()) return fail(PAA_ERR_ARG, "capacity %d < %zu", capacity, b.size());
+        memcpy(blob, b.data(), b.size());
+    }
+    return (int)b.size();
+}

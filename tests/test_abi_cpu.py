@@ -310,3 +310,81 @@ def test_default_build_has_no_experiment_switches():
     for name in (b"PAA_KERNEL_DEBUG", b"PAA_RUN_CAP", b"PAA_NO_MIX", b"PAA_F800_WAVES", b"PAA_F800_PACE", b"PAA_MIX_NO_LEAN",
                  b"PAA_MIX_TW_GLOBAL", b"PAA_MIX_NO_SKEW", b"PAA_HIP_FORCE_GENERIC"):
         assert name not in blob, name
+
+
+@pytest.mark.parametrize("window", [2400, 2205, 1764, 1920, 1600, 1200, 1102, 551])
+def test_three_pass_tables_reproduce_the_fft(window):
+    """Host tables of csrc/kernels_tri.hpp (no device): the three passes restated in NumPy FROM THE LIBRARY'S OWN TABLES --
+    pass-1 twiddles W_N^(j q1), pass-2 twiddles W_L1^(b q2), for packed (even) windows the pass-3 job pairs with their plane
+    offsets, first bins, store flags and post-twiddles -- give |fft(frame)|[0:W/2] / (W/2), every bin written exactly once
+    (ShortTermFeatures.py:617-621).  The kernel executes exactly this index algebra in registers."""
+    import ctypes
+    lib = _ffi.lib()
+    shape = np.zeros(8, dtype=np.int32)
+    off = np.zeros(6, dtype=np.int32)
+    size = lib.paa_debug_tri_plan(window, 44100.0, shape.ctypes.data_as(_ffi.c_i32p), off.ctypes.data_as(_ffi.c_i32p), None, 0)
+    assert size > 0
+    blob = np.zeros(size, dtype=np.uint8)
+    assert lib.paa_debug_tri_plan(window, 44100.0, shape.ctypes.data_as(_ffi.c_i32p), off.ctypes.data_as(_ffi.c_i32p),
+                                  blob.ctypes.data_as(ctypes.c_void_p), size) == size
+    R1, R2, R3, packed, P, NW, njob3, lds = (int(v) for v in shape)
+    N = R1 * R2 * R3
+    assert N == (window // 2 if packed else window) and (packed == 1) == (window % 2 == 0 and window != 1102)
+    L1, NQ1, NF = R2 * R3, (R1 if packed else (R1 + 1) // 2), window // 2
+    assert P >= L1 and NQ1 * R3 <= 64 and lds <= 160 * 1024 and 7 <= NW <= 8
+    cplx = lambda o, n: blob[o:o + 16 * n].view(np.float64).reshape(n, 2) @ np.array([1.0, 1j])
+    tw2 = cplx(off[0], R2 * R3).reshape(R2, R3)
+    tw1 = cplx(off[2], NQ1 * L1).reshape(NQ1, L1)
+    rng = np.random.default_rng(window)
+    y = rng.standard_normal(window)
+    z = (y[0::2] + 1j * y[1::2]) if packed else y.astype(complex)
+    plane = np.zeros(NQ1 * P, dtype=complex)
+    for j in range(L1):                                         # pass 1 + exchange 1: element (j, q1) at plane[q1 P + j]
+        plane[np.arange(NQ1) * P + j] = np.fft.fft(z[j + L1 * np.arange(R1)])[:NQ1] * tw1[:, j]
+    plane2 = np.zeros(NQ1 * P, dtype=complex)
+    for q1 in range(NQ1):                                       # pass 2 + exchange 2: (q1, b, q2) at plane[q1 P + q2 R3 + b]
+        for b in range(R3):
+            c = np.fft.fft(plane[q1 * P + R3 * np.arange(R2) + b]) * tw2[:, b]
+            plane2[q1 * P + np.arange(R2) * R3 + b] = c
+    X = np.full(NF, np.nan)
+    hits = np.zeros(NF, dtype=int)
+    if R3 == 1:                                                 # two passes: lane q1 holds Z[q1 + R1 q2]
+        assert not packed
+        for q1 in range(NQ1):
+            for q2 in range(R2):
+                k = q1 + R1 * q2
+                if k < NF:
+                    X[k] = abs(plane2[q1 * P + q2]); hits[k] += 1
+                elif q1 > 0 and N - k < NF:
+                    X[N - k] = abs(plane2[q1 * P + q2]); hits[N - k] += 1
+    elif packed:
+        p3 = blob[off[1]:off[1] + 8 * 64 * ((njob3 + 63) // 64)].view(np.uint16).reshape(-1, 4)
+        post = cplx(off[3], 64 * ((njob3 + 63) // 64) * R3).reshape(-1, R3)
+        assert np.all(p3[njob3:, 3] == 0)                       # idle lanes of the last round store nothing
+        for p in range(njob3):
+            offA, offB, kA, flags = (int(v) for v in p3[p])
+            zA, zB = np.fft.fft(plane2[offA:offA + R3]), np.fft.fft(plane2[offB:offB + R3])
+            for k3 in range(R3):
+                k = kA + R1 * R2 * k3
+                zk = zA[k3]
+                zm = zA[(R3 - k3) % R3] if (flags & 1) else zB[R3 - 1 - k3]
+                e, o = 0.5 * (zk + np.conj(zm)), -0.5j * (zk - np.conj(zm))
+                assert abs(post[p, k3] - np.exp(-1j * np.pi * k / N)) < 1e-15
+                if flags & (2 << k3):
+                    X[k] = abs(e + post[p, k3] * o); hits[k] += 1
+                if flags & (32 << k3):
+                    X[N - k] = abs(e - post[p, k3] * o); hits[N - k] += 1
+    else:
+        assert njob3 == NQ1 * R2
+        for m3 in range(njob3):
+            q1, q2 = divmod(m3, R2)
+            zz = np.fft.fft(plane2[q1 * P + q2 * R3 + np.arange(R3)])
+            for k3 in range(R3):
+                k = q1 + R1 * (q2 + R2 * k3)
+                if k < NF:
+                    X[k] = abs(zz[k3]); hits[k] += 1
+                elif q1 > 0 and N - k < NF:
+                    X[N - k] = abs(zz[k3]); hits[N - k] += 1
+    assert np.all(hits == 1), np.flatnonzero(hits != 1)[:8]
+    ref = np.abs(np.fft.fft(y))[:NF]
+    assert np.max(np.abs(X - ref)) < 1e-10 * np.max(ref)
