@@ -100,6 +100,7 @@ struct TriLayout {
     int off_tw2;                    // double2 [R2][R3]: W_L1^(b q2)
     int off_p3;                     // packed: ushort4 [64 NR3]: plane offset of job A, of job B, first bin kA, store flags
     int off_mello, off_melcnt, off_meloff, off_melw, off_dct, off_chstart, off_chsrc, off_chw;
+    int off_sync;                   // pacing of the two waves of a SIMD: SIMD id [8], progress in half frames [8] (ints)
     int table_bytes;                // LDS part, multiple of 16
     int off_g_tw1;                  // global part: double2 [NQ1][L1]: W_N^(j q1)
     int off_g_post;                 // packed: double2 [64 NR3][R3]: W_W^(kA + N3 k3)
@@ -509,7 +510,37 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tile_id = blockIdx.x * NW + wave;
+    // the two waves of a SIMD are paced against each other (kernels_fast.hpp: the hardware issues oldest-first, so unpaced the
+    // older wave runs ahead and the younger one ends alone on the SIMD): a wave publishes its progress twice per frame and
+    // raises its priority when it is behind its partner.  pace[0..7] = SIMD id, pace[8..15] = progress.
+    volatile int *pace = reinterpret_cast<volatile int *>(smem + L.off_sync);
+    int partner = wave;
+    {
+        const int my_simd = (int)((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3u);     // HW_REG_HW_ID[5:4]
+        if ((threadIdx.x & 63) == 0) {
+            pace[wave] = my_simd;
+            pace[8 + wave] = (tile_id < n_tiles) ? 0 : 0x7fffffff;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NW; ++w) partner = (w != wave && pace[w] == my_simd) ? w : partner;
+        partner = __builtin_amdgcn_readfirstlane(partner);
+    }
     if (tile_id >= n_tiles) return;
+    int n_done = 0;
+#ifndef PAA_TRI_PACING
+#define PAA_TRI_PACING 1
+#endif
+#define PAA_TRI_PACE(half_)                                                                            \
+    if (PAA_TRI_PACING) {                                                                              \
+        const int mine_ = 2 * n_done + (half_);                                                        \
+        if (lane == 0) pace[8 + wave] = mine_;                                                         \
+        const int other_ = __builtin_amdgcn_readfirstlane(pace[8 + partner]);                          \
+        const int d_ = mine_ - other_;                                                                 \
+        if (d_ < 0) __builtin_amdgcn_s_setprio(3);                                                     \
+        else if (d_ > 0) __builtin_amdgcn_s_setprio(0);                                                \
+        else __builtin_amdgcn_s_setprio(1);                                                            \
+    }
     double *slots = reinterpret_cast<double *>(smem + L.table_bytes) + (size_t)wave * SH::WAVE_DOUBLES;
     double *fv = slots + 2 * SLOT;
     double *msp = fv + 48;
@@ -542,6 +573,7 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
         // addresses and table pointers of all passes are some 60 loop-invariant registers (they ended up in scratch)
         int lane = lane_id;
         asm volatile("" : "+v"(lane));
+        PAA_TRI_PACE(0)
         // pass-2 job of this lane: (q1, b); idle lanes shadow the last job (their plane writes are masked)
         const int m2 = min(lane, J2 - 1);
         const int q1_2 = m2 / R3, b_2 = m2 - R3 * q1_2;
@@ -900,6 +932,7 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
             for (int k = NF + lane; k < 64 * SH::C; k += kWave) cur[k] = 0.0;
         }
         wsync();
+        PAA_TRI_PACE(1)
         PAA_TICK(6)
 
         if (MODE == 1) {            // spectrogram row (ShortTermFeatures.py:422)
@@ -922,8 +955,11 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
             vprev = v;
         }
         wsync();
+        ++n_done;
         PAA_TICK(10)
     }
+#undef PAA_TRI_PACE
+    if (lane_id == 0) pace[8 + wave] = 0x7fffffff;
     {
         const int lane = lane_id;
         (void)lane;
@@ -983,6 +1019,7 @@ inline void tri_fill(double fs, const MelTable *mel, const ChromaTable *chroma, 
     L.off_chstart = take(13 * 4);
     L.off_chsrc = take(std::max<size_t>(n_ch, 1) * 4);
     L.off_chw = take(std::max<size_t>(n_ch, 1) * 8);
+    L.off_sync = take(16 * 4);
     L.table_bytes = off;
     L.off_g_tw1 = take((size_t)NQ1 * L1 * 16);
     L.off_g_post = take(SH::PACKED ? (size_t)64 * NR3 * R3 * 16 : 16);
