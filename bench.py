@@ -66,6 +66,7 @@ SHAPES = {
     "reg_chromagram_stereo": (44100, 1102, 441, 600, 1, 2, 2, 0),
     "ct_640": (16000, 640, 640, 3600, 1, 0, 0, 0),                 # the CLI's 40 ms windows (audioAnalysis.py:71,80)
     "ct_640_spectrogram": (16000, 640, 640, 3600, 1, 0, 1, 0),
+    "ct_640_chromagram": (16000, 640, 640, 3600, 1, 0, 2, 0),
     "ct_800_f64": (16000, 800, 400, 3600, 1, 1, 0, 0),             # what stereo_to_mono hands on (audioBasicIO.py:167)
     "ct_800_stereo": (16000, 800, 400, 3600, 1, 2, 0, 0),
     "ct_400": (8000, 400, 200, 3600, 2, 0, 0, 0),                  # 50 ms at 8 kHz (audioTrainTest.py:28-29)
@@ -216,6 +217,7 @@ def other_configs(ffi, steps=10):
     # ---- the shapes of the reference's other callers
     run_shape("ct_640", "w640_step640", "1 h at 16 kHz, 40 ms / 40 ms (the CLI's spectrogram / chromagram window), features")
     run_shape("ct_640_spectrogram", "w640_spectrogram", "1 h at 16 kHz, 40 ms / 40 ms, spectrogram rows")
+    run_shape("ct_640_chromagram", "w640_chromagram", "1 h at 16 kHz, 40 ms / 40 ms, chromagram rows")
     run_shape("ct_800_f64", "w800_float64", "1 h at 16 kHz, 800 / 400, float64 mono samples (stereo_to_mono's output)")
     run_shape("ct_800_stereo", "w800_stereo", "1 h at 16 kHz, 800 / 400, interleaved stereo int16 samples")
     run_shape("ct_400", "w400_8kHz", "2 x 1 h at 8 kHz, 50 ms / 25 ms (400 / 200)")
