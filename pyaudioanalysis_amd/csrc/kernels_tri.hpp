@@ -287,11 +287,27 @@ template <> struct RCd<21> {
 __device__ __forceinline__ int wave_shr1(int v, int first) {
     return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xF, 0xF, false);       // wave_shr:1
 }
-// np.sign from the bit pattern: 0 for +-0, else +-1
-__device__ __forceinline__ int sgn_bits(double x) {
-    const int hi = __double2hiint(x), lo = __double2loint(x);
-    return (((hi & 0x7fffffff) | lo) != 0) ? ((hi >> 31) | 1) : 0;
+// Sign codes: only sums of |s_n - s_{n-1}| are ever used, so a sample's sign is kept as a small non-negative code whose
+// differences are the sign differences (up to the factor `sh` applied once to the wave total).
+// Integer samples (int16 PCM, or L + R of a stereo frame): sign(x sc - mean) = sign(x - mean / sc), decided in integer
+// arithmetic: code = clamp(x - (zb - 1), lo, 2) with zb = floor(mean / sc); lo = 0 when mean / sc is a whole number (a sample
+// can sit on the mean: codes 0 / 1 / 2 = signs -1 / 0 / +1), lo = 1 otherwise (codes 1 / 2, differences count double: sh = 1)
+// -- two instructions per sample
+struct SignRule {
+    int zb1, lo, sh;       // wave-uniform
+};
+__device__ __forceinline__ int sgn1(int x, const SignRule &q) {
+    int t;
+    asm("v_med3_i32 %0, %1, %2, 2" : "=v"(t) : "v"(x - q.zb1), "v"(q.lo));
+    return t;
 }
+__device__ __forceinline__ int sgn1(double d) { return ((d > 0.0) ? 2 : 1) - ((d < 0.0) ? 1 : 0); }      // float64 samples: sign + 1
+// acc += |a - b| for a, b >= 0
+__device__ __forceinline__ void sad_acc(int &acc, int a, int b) { asm("v_sad_u32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b)); }
+template <typename T> __device__ __forceinline__ int load_int(const T *p);
+template <> __device__ __forceinline__ int load_int<int16_t>(const int16_t *p) { return (int)(*p); }
+template <> __device__ __forceinline__ int load_int<stereo16>(const stereo16 *p) { return stereo_word_sum(*reinterpret_cast<const int *>(p)); }
+template <> __device__ __forceinline__ int load_int<double>(const double *) { return 0; }
 
 // a feature row's pending values: h[i] = the frame at position i of the row's current 64-byte chunk
 struct RowChunk {
@@ -557,6 +573,17 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
     const double mean = f800::uni(nm.mean), inv = f800::uni(nm.inv);
     const double mscale = f800::uni((PACKED ? 0.5 : 1.0) * inv * (1.0 / (double)NF));      // X / len(X) (:621); y = d * inv; E, O carry 1/2
     const double inv2 = f800::uni(inv * inv);               // energies of y = d * inv
+    constexpr bool INT_T = !std::is_same<T, double>::value;
+    SignRule sr = {0, 0, 0};
+    if (INT_T && MODE == 0) {
+        const double thr = nm.mean * (1.0 / sample_scale<T>());        // exact: a power of two
+        const double fl = floor(thr);
+        const bool whole = (fl == thr);
+        sr.zb1 = (int)fl - 1;
+        sr.lo = whole ? 0 : 1;
+        sr.sh = __builtin_amdgcn_readfirstlane(whole ? 0 : 1);
+        asm volatile("" : "+v"(sr.zb1), "+v"(sr.lo));        // (opaque: x - zb1 stays ONE subtraction)
+    }
 
     const int hneed = (MODE == 0) ? (DELTAS ? 2 : 1) : 0;
     const int h = min(hneed, tl.t0);
@@ -618,7 +645,8 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                     acc = (lane < 44) ? acc * inv2 : 0.0;     // lanes 4 b .. 4 b + 3: energy of block b (b = 10: the tail)
                     const double tot = wsum((part == 0) ? acc : 0.0);
                     tf.e_tot = tot;
-                    tf.zc = wsum_i(zcv);
+                    // (integer sign codes of a clip whose mean is not a whole count are 1 / 2: their differences count double)
+                    tf.zc = wsum_i(zcv) << ((INT_T && !(PACKED && std::is_same<T, int16_t>::value)) ? sr.sh : 0);
                     const double s = fast_div(acc, tot + kEps);
                     tf.ent_e = wsum((lane < 40 && part == 0) ? -(s * fast_log2(s + kEps)) : 0.0);
                     wsync();
@@ -632,16 +660,26 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                 double2 v[R1];
                 // int16 PCM: the raw pair words are kept for the sign changes (packed 16-bit arithmetic, below)
                 constexpr bool RAW16 = std::is_same<T, int16_t>::value;
+                constexpr bool ST16 = std::is_same<T, stereo16>::value;
                 int wr[RAW16 ? R1 : 1];
+                int w0[ST16 ? R1 : 1], w1[ST16 ? R1 : 1];     // stereo: the two raw frames of a pair (summed L + R row by row, below)
+                // idle lanes shadow the last job with scale and mean 0: their samples are exact zeros (no energy, nothing to mask)
+                const double scl = act1 ? sc : 0.0, meanl = act1 ? mean : 0.0;
 #pragma unroll
                 for (int r = 0; r < R1; ++r) {
                     if constexpr (RAW16) {
                         typedef int w32 __attribute__((aligned(2)));
                         wr[r] = *reinterpret_cast<const w32 *>(xf + 2 * (jj + L1 * r));
-                        v[r] = make_double2(fma((double)(short)(wr[r] & 0xffff), sc, -mean), fma((double)(wr[r] >> 16), sc, -mean));
+                        v[r] = make_double2(fma((double)(short)(wr[r] & 0xffff), scl, -meanl), fma((double)(wr[r] >> 16), scl, -meanl));
+                    } else if constexpr (ST16) {
+                        typedef int vec2 __attribute__((ext_vector_type(2), aligned(4)));
+                        const vec2 s2 = *reinterpret_cast<const vec2 *>(xf + 2 * (jj + L1 * r));
+                        w0[r] = s2.x; w1[r] = s2.y;
+                        if (MODE != 0)
+                            v[r] = make_double2(fma((double)stereo_word_sum(w0[r]), scl, -meanl), fma((double)stereo_word_sum(w1[r]), scl, -meanl));
                     } else {
                         const double2 x = ct::PairLoad<T>::get(xf + 2 * (jj + L1 * r));
-                        v[r] = make_double2(fma(x.x, sc, -mean), fma(x.y, sc, -mean));
+                        v[r] = make_double2(fma(x.x, scl, -meanl), fma(x.y, scl, -meanl));
                     }
                 }
                 // sign(x / 2^15 - mean) of an int16 sample = sign(x - mu), mu = mean 2^15, decided in packed saturating 16-bit
@@ -657,8 +695,13 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                 if (MODE == 0) {
 #pragma unroll
                     for (int r = 0; r < R1; ++r) {
+                        int x0 = 0, x1 = 0;
+                        if constexpr (ST16) {
+                            x0 = stereo_word_sum(w0[r]); x1 = stereo_word_sum(w1[r]);
+                            v[r] = make_double2(fma((double)x0, scl, -meanl), fma((double)x1, scl, -meanl));
+                        }
                         const double d0 = v[r].x, d1 = v[r].y;
-                        const double e = act1 ? fma(d0, d0, d1 * d1) : 0.0;
+                        const double e = fma(d0, d0, d1 * d1);
                         // samples 2 L1 r + 2 lane, + 1: block jlo for lanes below jth, jlo + 1 from there on (static per row)
                         const int n0 = 2 * L1 * r;
                         const int jlo = (n0 / LT < 10) ? n0 / LT : 10;
@@ -681,17 +724,17 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                             zacc += __builtin_elementwise_max(df, -df);
                             carryw = (unsigned)__builtin_amdgcn_readlane((int)sgw, L1 - 1);
                         } else {
-                            const int sa = sgn_bits(d0), sb = sgn_bits(d1);
+                            const int sa = ST16 ? sgn1(x0, sr) : sgn1(d0), sb = ST16 ? sgn1(x1, sr) : sgn1(d1);
                             if (r == 0) carry = __builtin_amdgcn_readfirstlane(sa);       // the frame's first sample has no left one
                             const int left = wave_shr1(sb, carry);
-                            const int dz = abs(sb - sa) + abs(sa - left);
-                            zcv += act1 ? dz : 0;
+                            sad_acc(zcv, sb, sa);
+                            sad_acc(zcv, sa, left);
                             carry = __builtin_amdgcn_readlane(sb, L1 - 1);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                if (RAW16) zcv = act1 ? (int)zacc.x + (int)zacc.y : 0;
+                zcv = act1 ? (RAW16 ? (int)zacc.x + (int)zacc.y : zcv) : 0;
                 finish_time();
                 PAA_TICK(1)
                 Cd<R1>::run(v);
@@ -708,22 +751,36 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                 }
             } else {
                 double xr[NJ][R1];
+                int xi[INT_T ? NJ : 1][INT_T ? R1 : 1];        // integer samples (stereo: L + R), converted row by row below
+                double scl[NJ], meanl[NJ];                     // idle lanes shadow the last job with scale and mean 0: exact zeros
 #pragma unroll
                 for (int u = 0; u < NJ; ++u) {
                     const int j = lane + 64 * u;
                     const int jj = (j < L1) ? j : L1 - 1;
+                    scl[u] = (j < L1) ? sc : 0.0;
+                    meanl[u] = (j < L1) ? mean : 0.0;
 #pragma unroll
-                    for (int r = 0; r < R1; ++r) xr[u][r] = fma(load_sample<T>(xf + jj + L1 * r), sc, -mean);
+                    for (int r = 0; r < R1; ++r) {
+                        if constexpr (INT_T) {
+                            xi[u][r] = load_int<T>(xf + jj + L1 * r);
+                            if (MODE != 0) xr[u][r] = fma((double)xi[u][r], scl[u], -meanl[u]);
+                        } else {
+                            xr[u][r] = fma(load_sample<T>(xf + jj + L1 * r), scl[u], -meanl[u]);
+                        }
+                    }
                 }
                 PAA_TICK(0)
                 if (MODE == 0) {
+                    int zcu[NJ];
+#pragma unroll
+                    for (int u = 0; u < NJ; ++u) zcu[u] = 0;
 #pragma unroll
                     for (int r = 0; r < R1; ++r)
 #pragma unroll
                         for (int u = 0; u < NJ; ++u) {
-                            const bool act1 = lane + 64 * u < L1;
+                            if constexpr (INT_T) xr[u][r] = fma((double)xi[u][r], scl[u], -meanl[u]);
                             const double d = xr[u][r];
-                            const double e = act1 ? d * d : 0.0;
+                            const double e = d * d;
                             const int n0 = L1 * r + 64 * u;                     // sample of lane 0
                             const int jlo = (n0 / LT < 10) ? n0 / LT : 10;
                             const int jth = (jlo >= 10) ? 64 : (jlo + 1) * LT - n0;
@@ -733,13 +790,17 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                                 eb[jlo] += (lane < jth) ? e : 0.0;
                                 eb[jlo + 1] += (lane >= jth) ? e : 0.0;
                             }
-                            const int sg = sgn_bits(d);
+                            int sg;
+                            if constexpr (INT_T) sg = sgn1(xi[u][r], sr);
+                            else sg = sgn1(d);
                             if (r == 0 && u == 0) carry = __builtin_amdgcn_readfirstlane(sg);
                             const int left = wave_shr1(sg, carry);      // sample n - 1: the lane below / the last lane of the slot before
-                            zcv += act1 ? abs(sg - left) : 0;
+                            sad_acc(zcu[u], sg, left);
                             carry = __builtin_amdgcn_readlane(sg, (L1 - 1 - 64 * u < 63) ? L1 - 1 - 64 * u : 63);
                             __builtin_amdgcn_sched_barrier(0);
                         }
+#pragma unroll
+                    for (int u = 0; u < NJ; ++u) zcv += (lane + 64 * u < L1) ? zcu[u] : 0;
                 }
                 finish_time();
                 PAA_TICK(1)

@@ -127,3 +127,35 @@ def test_degenerate_clips_and_ragged_batches(gpu_lib):
         single, _ = ShortTermFeatures.feature_extraction(c, fs, W, S)
         assert np.array_equal(single, r)
         assert_parity(r, reference_matrix(c, fs, W, S, True), "ragged batch", ill=ill_mask(c, fs, W, S))
+
+
+@pytest.mark.parametrize("fs,window,step,kind", [(44100, 2205, 1102, "i16"), (44100, 1102, 441, "stereo"), (44100, 1102, 441, "i16"),
+                                                  (48000, 2400, 1200, "stereo"), (48000, 2400, 1200, "i16"),
+                                                  (11025, 551, 275, "stereo"), (44100, 1764, 882, "f64"), (16000, 800, 400, "i16"),
+                                                  (16000, 640, 320, "stereo")])
+def test_samples_that_sit_on_a_whole_number_mean(gpu_lib, fs, window, step, kind):
+    """The kernels decide sign(x / 2^15 - mean) of integer PCM in integer arithmetic (x against floor(mean 2^15), with a
+    separate rule when the clip mean is a whole count: then samples can sit exactly ON the mean and np.sign gives 0,
+    ShortTermFeatures.py:22-26).  A mirrored clip (a, -a) + c has the whole-number mean c and every fifth sample on it; the
+    zero-crossing row is discrete -- assert_parity's tight gate counts any flip."""
+    rng = np.random.default_rng(window + step)
+    n = 6 * fs // 2
+    def mirrored(c, amp):
+        a = rng.integers(-amp, amp + 1, n)
+        a[rng.random(n) < 0.2] = 0
+        return np.concatenate([a, -a]) + c
+    if kind == "i16":
+        sig = mirrored(-7, 3000).astype(np.int16)
+        mono = sig
+    else:
+        left, right = mirrored(40, 2500), mirrored(-27, 2500)       # L + R has the whole-number mean 13; mono mean 6.5
+        sig = np.stack([left, right], axis=1).astype(np.int16)
+        mono = O.stereo_to_mono(sig)
+        if kind == "f64":
+            sig = mono
+    assert float(np.mean(np.double(mono) * (2.0 if kind != "i16" else 1.0))) in (-7.0, 13.0)
+    F, _ = ShortTermFeatures.feature_extraction(sig, fs, window, step, False)
+    ref = reference_matrix(mono, fs, window, step, False)
+    assert_parity(F, ref, "whole mean %s %d/%d" % (kind, window, step), ill=ill_mask(mono, fs, window, step))
+    counts = lambda row: np.rint(row * 2.0 * (window - 1))        # zcr = sum |diff(sign)| / 2 / (W - 1): whole numbers
+    assert np.array_equal(counts(F[0]), counts(ref[0])) and np.abs(F[0] * 2.0 * (window - 1) - counts(F[0])).max() < 1e-6
