@@ -367,6 +367,37 @@ template <> __device__ __forceinline__ double load_sample<stereo16>(const stereo
 template <typename T> __host__ __device__ constexpr double sample_scale() { return 1.0 / 32768.0; }
 template <> __host__ __device__ constexpr double sample_scale<stereo16>() { return 1.0 / 65536.0; }
 
+// Sign codes: only sums of |s_n - s_{n-1}| are ever used, so a sample's sign is kept as a small non-negative code whose
+// differences are the sign differences (up to the factor `sh` applied once to the wave total).
+// Integer samples (int16 PCM, or L + R of a stereo frame): sign(x sc - mean) = sign(x - mean / sc), decided in integer
+// arithmetic: code = clamp(x - (zb - 1), lo, 2) with zb = floor(mean / sc); lo = 0 when mean / sc is a whole number (a sample
+// can sit on the mean: codes 0 / 1 / 2 = signs -1 / 0 / +1), lo = 1 otherwise (codes 1 / 2, differences count double: sh = 1)
+// -- two instructions per sample
+struct SignRule {
+    int zb1, lo, sh;       // wave-uniform
+};
+__device__ __forceinline__ int sgn1(int x, const SignRule &q) {
+    int t;
+    asm("v_med3_i32 %0, %1, %2, 2" : "=v"(t) : "v"(x - q.zb1), "v"(q.lo));
+    return t;
+}
+__device__ __forceinline__ int sgn1(double d) { return ((d > 0.0) ? 2 : 1) - ((d < 0.0) ? 1 : 0); }      // float64 samples: sign + 1
+// acc += |a - b| for a, b >= 0
+__device__ __forceinline__ void sad_acc(int &acc, int a, int b) { asm("v_sad_u32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b)); }
+// the rule of a clip for integer sample type T (mean = the clip mean of x sc; exact: sc is a power of two)
+template <typename T>
+__device__ __forceinline__ SignRule sign_rule(double mean) {
+    const double thr = mean * (1.0 / sample_scale<T>());
+    const double fl = floor(thr);
+    const bool whole = (fl == thr);
+    SignRule q;
+    q.zb1 = (int)fl - 1;
+    q.lo = whole ? 0 : 1;
+    q.sh = __builtin_amdgcn_readfirstlane(whole ? 0 : 1);
+    asm volatile("" : "+v"(q.zb1), "+v"(q.lo));        // (opaque: x - zb1 stays ONE subtraction)
+    return q;
+}
+
 // ---- clip constants from the statistics partials of one clip (ShortTermFeatures.py:14-19, :567-570): the partials are
 // folded lane-strided, then over a fixed xor tree (deterministic: every wave of every kernel gets the same bits); every lane
 // returns the same ClipNorm.  SumT / MmT: long long / int for the integer sample types (exact), double / double for float64.

@@ -27,6 +27,7 @@
 // chromagram (:349-359), for these windows.
 #pragma once
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "device_common.hpp"
@@ -165,7 +166,31 @@ template <> struct PairLoad<double> {
     }
 };
 
-__device__ __forceinline__ int sgn_i(double v) { return (int)(v > 0.0) - (int)(v < 0.0); }
+// the same pair as integers (int16 PCM: the two halves of one word; stereo: L + R of two frames); float64 has none
+template <typename T> struct PairRaw;
+template <> struct PairRaw<int16_t> {
+    int w;
+    static __device__ __forceinline__ PairRaw get(const int16_t *p) {
+        typedef int w32 __attribute__((aligned(2)));
+        PairRaw r; r.w = *reinterpret_cast<const w32 *>(p); return r;
+    }
+    __device__ __forceinline__ int x0() const { return (int)(short)(w & 0xffff); }
+    __device__ __forceinline__ int x1() const { return w >> 16; }
+};
+template <> struct PairRaw<stereo16> {
+    int a, b;
+    static __device__ __forceinline__ PairRaw get(const stereo16 *p) {
+        const PairLoad<stereo16>::vec s = *reinterpret_cast<const PairLoad<stereo16>::vec *>(p);
+        PairRaw r; r.a = s.x; r.b = s.y; return r;
+    }
+    __device__ __forceinline__ int x0() const { return stereo_word_sum(a); }
+    __device__ __forceinline__ int x1() const { return stereo_word_sum(b); }
+};
+template <> struct PairRaw<double> {
+    static __device__ __forceinline__ PairRaw get(const double *) { return PairRaw(); }
+    __device__ __forceinline__ int x0() const { return 0; }
+    __device__ __forceinline__ int x1() const { return 0; }
+};
 
 // MODE 0: short-term features (DELTAS: 68 rows), 1: spectrogram rows, 2: chromagram rows.
 // NW = waves per workgroup (8: two per SIMD, paced like the 800/400 kernel).
@@ -236,6 +261,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_ct_kernel(PlanDev P, TabLa
     const double mean = nm.mean, inv = nm.inv;
     const double mscale = 0.5 * inv / (double)NF;         // E and O carry 1/2; X / len(X) (:621); y = d * inv
     const double f0 = L.f0, rf0 = L.rf0, r_half_fs = L.r_half_fs, f0sq = L.f0sq;
+    constexpr bool INT_T = !std::is_same<T, double>::value;
+    SignRule sr = {0, 0, 0};
+    if (INT_T && MODE == 0) sr = sign_rule<T>(nm.mean);
 
     const int r0 = tl.t0, t_end = tl.t0 + tl.cnt;         // frames [r0, t_end) are this wave's to store
     int slot0 = 2;                   // slots of a quad: slot0 .. slot0+3 (mod 5) after the rotation at the loop head; previous = slot0-1
@@ -267,13 +295,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_ct_kernel(PlanDev P, TabLa
 
         // ---------------- load: z[j + RB r] of frame t, mean removed (frames past the clip's last repeat it: never stored)
         double2 v[RA];
+        PairRaw<T> raw[(INT_T && MODE == 0) ? RA : 1];       // integer samples: converted row by row in the time-domain stage
+        // idle lanes (RB = 8) re-read lane 0's samples with scale and mean 0: exact zeros, no energy, nothing to mask
+        const double scl = act1 ? sc : 0.0, meanl = act1 ? mean : 0.0;
         {
             const long long tt = (t < Tc) ? t : Tc - 1;
             const T *xf = xc + tt * (long long)S + 2 * (act1 ? i : 0);
 #pragma unroll
             for (int r = 0; r < RA; ++r) {
-                const double2 x = PairLoad<T>::get(xf + 2 * RB * r);
-                v[r] = make_double2(fma(x.x, sc, -mean), fma(x.y, sc, -mean));
+                if constexpr (INT_T && MODE == 0) {
+                    raw[r] = PairRaw<T>::get(xf + 2 * RB * r);
+                } else {
+                    const double2 x = PairLoad<T>::get(xf + 2 * RB * r);
+                    v[r] = make_double2(fma(x.x, scl, -meanl), fma(x.y, scl, -meanl));
+                }
             }
         }
 #ifdef PAA_F800_TIMING
@@ -290,32 +325,44 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_ct_kernel(PlanDev P, TabLa
             int prev_b = 0;
 #pragma unroll
             for (int r = 0; r < RA; ++r) {
+                int x0 = 0, x1 = 0;
+                if constexpr (INT_T) {
+                    x0 = raw[r].x0(); x1 = raw[r].x1();
+                    v[r] = make_double2(fma((double)x0, scl, -meanl), fma((double)x1, scl, -meanl));
+                }
                 const double d0 = v[r].x, d1 = v[r].y;
                 const double e = fma(d0, d0, d1 * d1);
                 // samples 2 RB r + 2 i, + 1: block jlo for lanes below jth, jlo + 1 from there on (static per row)
                 const int jlo = (2 * RB * r) / LT;
                 const int jth = ((jlo + 1) * LT - 2 * RB * r) / 2;
                 if (jth >= RB) {
-                    eb[jlo] += act1 ? e : 0.0;
+                    eb[jlo] += e;
                 } else {
                     eb[jlo] += (i < jth) ? e : 0.0;
-                    eb[(jlo + 1 < 10) ? jlo + 1 : 9] += (i >= jth && act1) ? e : 0.0;
+                    eb[(jlo + 1 < 10) ? jlo + 1 : 9] += (i >= jth) ? e : 0.0;
                 }
-                const int sa = sgn_i(d0), sb = sgn_i(d1);
-                // sign of the sample before the pair: the lane below; lane 0 takes the last active lane of the previous row
+                // sign codes (device_common.hpp): only |differences| are summed
+                int sa, sb;
+                if constexpr (INT_T) { sa = sgn1(x0, sr); sb = sgn1(x1, sr); }
+                else { sa = sgn1(d0); sb = sgn1(d1); }
+                // the sample before the pair: the lane below; lane 0 takes the last active lane of the previous row (the frame's first
+                // sample has no left one: it meets itself)
                 const int from_left = __builtin_amdgcn_update_dpp(0, sb, 0x111, 0xF, 0xF, true);                  // row_shr:1
-                const int from_prev = (RB == 16) ? __builtin_amdgcn_update_dpp(0, prev_b, PAA_DPP_RM, 0xF, 0xF, true)
-                                                 : __builtin_amdgcn_update_dpp(0, prev_b, PAA_DPP_HM, 0xF, 0xF, true);
-                const int left = (i == 0) ? from_prev : from_left;
-                int dz = abs(sb - sa);
-                if (r == 0) dz += (i == 0) ? 0 : abs(sa - left);
-                else dz += abs(sa - left);
-                zc += act1 ? dz : 0;
+                int left;
+                if (r == 0) {
+                    left = (i == 0) ? sa : from_left;
+                } else {
+                    const int from_prev = (RB == 16) ? __builtin_amdgcn_update_dpp(0, prev_b, PAA_DPP_RM, 0xF, 0xF, true)
+                                                     : __builtin_amdgcn_update_dpp(0, prev_b, PAA_DPP_HM, 0xF, 0xF, true);
+                    left = (i == 0) ? from_prev : from_left;
+                }
+                sad_acc(zc, sb, sa);
+                sad_acc(zc, sa, left);
                 prev_b = sb;
             }
 #pragma unroll
             for (int b = 0; b < 10; ++b) eb[b] = group_sum(eb[b]);
-            zc = group_sum_i(zc);
+            zc = group_sum_i(act1 ? zc : 0) << (INT_T ? sr.sh : 0);      // (integer codes 1 / 2: differences count double)
             const double inv2 = inv * inv;
 #pragma unroll
             for (int b = 0; b < 10; ++b) { eb[b] *= inv2; e_tot += eb[b]; }

@@ -287,23 +287,6 @@ template <> struct RCd<21> {
 __device__ __forceinline__ int wave_shr1(int v, int first) {
     return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xF, 0xF, false);       // wave_shr:1
 }
-// Sign codes: only sums of |s_n - s_{n-1}| are ever used, so a sample's sign is kept as a small non-negative code whose
-// differences are the sign differences (up to the factor `sh` applied once to the wave total).
-// Integer samples (int16 PCM, or L + R of a stereo frame): sign(x sc - mean) = sign(x - mean / sc), decided in integer
-// arithmetic: code = clamp(x - (zb - 1), lo, 2) with zb = floor(mean / sc); lo = 0 when mean / sc is a whole number (a sample
-// can sit on the mean: codes 0 / 1 / 2 = signs -1 / 0 / +1), lo = 1 otherwise (codes 1 / 2, differences count double: sh = 1)
-// -- two instructions per sample
-struct SignRule {
-    int zb1, lo, sh;       // wave-uniform
-};
-__device__ __forceinline__ int sgn1(int x, const SignRule &q) {
-    int t;
-    asm("v_med3_i32 %0, %1, %2, 2" : "=v"(t) : "v"(x - q.zb1), "v"(q.lo));
-    return t;
-}
-__device__ __forceinline__ int sgn1(double d) { return ((d > 0.0) ? 2 : 1) - ((d < 0.0) ? 1 : 0); }      // float64 samples: sign + 1
-// acc += |a - b| for a, b >= 0
-__device__ __forceinline__ void sad_acc(int &acc, int a, int b) { asm("v_sad_u32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b)); }
 template <typename T> __device__ __forceinline__ int load_int(const T *p);
 template <> __device__ __forceinline__ int load_int<int16_t>(const int16_t *p) { return (int)(*p); }
 template <> __device__ __forceinline__ int load_int<stereo16>(const stereo16 *p) { return stereo_word_sum(*reinterpret_cast<const int *>(p)); }
@@ -575,15 +558,7 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
     const double inv2 = f800::uni(inv * inv);               // energies of y = d * inv
     constexpr bool INT_T = !std::is_same<T, double>::value;
     SignRule sr = {0, 0, 0};
-    if (INT_T && MODE == 0) {
-        const double thr = nm.mean * (1.0 / sample_scale<T>());        // exact: a power of two
-        const double fl = floor(thr);
-        const bool whole = (fl == thr);
-        sr.zb1 = (int)fl - 1;
-        sr.lo = whole ? 0 : 1;
-        sr.sh = __builtin_amdgcn_readfirstlane(whole ? 0 : 1);
-        asm volatile("" : "+v"(sr.zb1), "+v"(sr.lo));        // (opaque: x - zb1 stays ONE subtraction)
-    }
+    if (INT_T && MODE == 0) sr = sign_rule<T>(nm.mean);
 
     const int hneed = (MODE == 0) ? (DELTAS ? 2 : 1) : 0;
     const int h = min(hneed, tl.t0);
