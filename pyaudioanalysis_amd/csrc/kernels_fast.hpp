@@ -473,13 +473,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
     const double mag_scale = nm.mag_scale;                                       // 0.5: E and O carry a factor 1/2
     const double dc_shift = nm.dc_shift;
     // sign(x/2^15 - mean) = sign(x - mu) in packed 16-bit integers (mu lies inside the int16 range: it is a mean of int16)
+    // as non-negative sign CODES (device_common.hpp: only |differences| are summed): code = clamp(sat(x - (zb - 1)), lo, 2),
+    // lo = 0 when mu is a whole number (codes 0 / 1 / 2 = signs -1 / 0 / +1), 1 otherwise (codes 1 / 2: differences count
+    // double, applied once per frame); |code - code'| of both halves is ONE v_sad_u16
     const bool mu_whole = nm.mu_whole != 0;
-    const short zb_ = (short)nm.zb;
-    const s16x2 zc_b = {zb_, zb_};
-    const s16x2 zc_lo = mu_whole ? (s16x2){-1, -1} : (s16x2){0, 0};
-    const s16x2 zc_mul = mu_whole ? (s16x2){1, 1} : (s16x2){2, 2};
-    const s16x2 zc_add = mu_whole ? (s16x2){0, 0} : (s16x2){-1, -1};
+    const short zb1_ = (short)max(nm.zb - 1, -32768);       // (zb = -32768: every sample equals the mean, every code is equal)
+    const s16x2 zc_b = {zb1_, zb1_};
+    const s16x2 zc_lo = mu_whole ? (s16x2){0, 0} : (s16x2){1, 1};
+    const s16x2 zc_two = {2, 2};
     const s16x2 zc_one = {1, 1};
+    const int zc_shift = mu_whole ? 0 : 1;
 
     const int r0 = tl.t0, t_end = tl.t0 + tl.cnt;      // frames [r0, t_end) are this wave's to store
     int q0 = r0 >= QUAD ? r0 - QUAD : 0;
@@ -584,11 +587,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
             s16x2 sp;
             if (G::PAD == 0 && ch == 0) sp = (s16x2){0, before_reg};
             else sp = __builtin_bit_cast(s16x2, reinterpret_cast<const int *>(raw + G::PAD + CHUNK * ch)[-1]);
-            sp = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_elementwise_sub_sat(sp, zc_b), zc_lo), zc_one) * zc_mul + zc_add;
+            sp = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_elementwise_sub_sat(sp, zc_b), zc_lo), zc_two);
             double sx2 = 0.0;            // sum x^2 (exact: every term is an integer below 2^31, the sum below 2^53)
             int sx = 0;                  // sum x
-            s16x2 zacc = {0, 0};
-            int zfirst = 0;
+            int zacc = 0, zfirst = 0;
 #pragma unroll
             for (int v4 = 0; v4 < CHUNK / 8; ++v4) {
                 const int4 q = p4[v4];
@@ -596,13 +598,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     const s16x2 cur = __builtin_bit_cast(s16x2, w[h]);
-                    const s16x2 sg = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_elementwise_sub_sat(cur, zc_b), zc_lo), zc_one) * zc_mul + zc_add;
-                    // (sign of the sample before the pair, sign of its first sample)
-                    const s16x2 sh = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(__builtin_bit_cast(unsigned, sg), __builtin_bit_cast(unsigned, sp), 16));
-                    const s16x2 df = sg - sh;
-                    const s16x2 ad = __builtin_elementwise_max(df, -df);
-                    if (v4 == 0 && h == 0) zfirst = ad.x;
-                    zacc += ad;
+                    const s16x2 sg = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_elementwise_sub_sat(cur, zc_b), zc_lo), zc_two);
+                    // (code of the sample before the pair, code of its first sample)
+                    const unsigned sgw = __builtin_bit_cast(unsigned, sg);
+                    const unsigned shw = __builtin_amdgcn_alignbit(sgw, __builtin_bit_cast(unsigned, sp), 16);
+                    if (v4 == 0 && h == 0) zfirst = abs((int)(sgw & 0xffffu) - (int)(shw & 0xffffu));
+                    asm("v_sad_u16 %0, %1, %2, %0" : "+v"(zacc) : "v"(sgw), "v"(shw));
                     sp = sg;
                     sx2 += (double)(unsigned)__builtin_amdgcn_sdot2(cur, cur, 0, false);     // 2^31 for (-32768, -32768)
                     sx = __builtin_amdgcn_sdot2(cur, zc_one, sx, false);
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
             const int s1 = sx - CHUNK * m_int;
             const double e = y_scale2 * fma(delta_mu, fma(-2.0, (double)s1, nm.chunk_dmu), e2);
             cE[ch] = e;
-            cZ[ch] = (int)zacc.x + (int)zacc.y;
+            cZ[ch] = zacc;
             cF[ch] = zfirst;
         }
 
@@ -811,7 +812,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
         }
         // zero crossings: 20 chunks of the frame minus the pair that straddles the frame start (:22-26)
         int zc = cZ[CPF * g + i] + ((i < 4) ? cZ[CPF * g + 16 + i] : 0) - ((i == 0) ? cF[CPF * g] : 0);
-        zc = group_sum_i(zc);
+        zc = group_sum_i(zc) << zc_shift;
 
         PAA_TICK(5)
         // centroid, spread, flux (:57-82, :110-124)

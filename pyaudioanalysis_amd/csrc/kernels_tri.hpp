@@ -559,6 +559,8 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
     constexpr bool INT_T = !std::is_same<T, double>::value;
     SignRule sr = {0, 0, 0};
     if (INT_T && MODE == 0) sr = sign_rule<T>(nm.mean);
+    // (the packed int16 path of the even windows forms its codes from nm.zb / nm.mu_whole: the same rule in 16-bit arithmetic)
+    const int zc_shift = !INT_T ? 0 : (PACKED && std::is_same<T, int16_t>::value) ? (nm.mu_whole ? 0 : 1) : sr.sh;
 
     const int hneed = (MODE == 0) ? (DELTAS ? 2 : 1) : 0;
     const int h = min(hneed, tl.t0);
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                     const double tot = wsum((part == 0) ? acc : 0.0);
                     tf.e_tot = tot;
                     // (integer sign codes of a clip whose mean is not a whole count are 1 / 2: their differences count double)
-                    tf.zc = wsum_i(zcv) << ((INT_T && !(PACKED && std::is_same<T, int16_t>::value)) ? sr.sh : 0);
+                    tf.zc = wsum_i(zcv) << zc_shift;
                     const double s = fast_div(acc, tot + kEps);
                     tf.ent_e = wsum((lane < 40 && part == 0) ? -(s * fast_log2(s + kEps)) : 0.0);
                     wsync();
@@ -657,14 +659,13 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                         v[r] = make_double2(fma(x.x, scl, -meanl), fma(x.y, scl, -meanl));
                     }
                 }
-                // sign(x / 2^15 - mean) of an int16 sample = sign(x - mu), mu = mean 2^15, decided in packed saturating 16-bit
-                // arithmetic (kernels_fast.hpp): s = clamp(sat(x - floor(mu)), lo, 1) * a + c with (lo, a, c) = (-1, 1, 0) when mu
-                // is a whole number (a sample can sit on the mean: sign 0) and (0, 2, -1) otherwise
+                // sign(x / 2^15 - mean) of an int16 sample = sign(x - mu), mu = mean 2^15, as the sign CODE of device_common.hpp in
+                // packed saturating 16-bit arithmetic (kernels_fast.hpp): code = clamp(sat(x - (floor(mu) - 1)), lo, 2), lo = 0 when
+                // mu is a whole number (a sample can sit on the mean), 1 otherwise (differences count double: the shift at the end)
                 typedef f800::s16x2 s16x2;
-                const short zb_ = (short)nm.zb, lo_ = nm.mu_whole ? (short)-1 : (short)0, mul_ = nm.mu_whole ? (short)1 : (short)2,
-                            add_ = nm.mu_whole ? (short)0 : (short)-1;
-                const s16x2 zc_b = {zb_, zb_}, zc_lo = {lo_, lo_}, zc_one = {1, 1}, zc_mul = {mul_, mul_}, zc_add = {add_, add_};
-                s16x2 zacc = {0, 0};
+                const short zb1_ = (short)max(nm.zb - 1, -32768), lo_ = nm.mu_whole ? (short)0 : (short)1;
+                const s16x2 zc_b = {zb1_, zb1_}, zc_lo = {lo_, lo_}, zc_two = {2, 2};
+                int zacc = 0;
                 unsigned carryw = 0;
                 PAA_TICK(0)
                 if (MODE == 0) {
@@ -690,13 +691,12 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                         if constexpr (RAW16) {
                             // both samples of the pair at once: {s_even, s_odd} against {s of the sample before the pair, s_even}
                             const s16x2 cur2 = __builtin_bit_cast(s16x2, wr[r]);
-                            const s16x2 sg = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_elementwise_sub_sat(cur2, zc_b), zc_lo), zc_one) * zc_mul + zc_add;
+                            const s16x2 sg = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_elementwise_sub_sat(cur2, zc_b), zc_lo), zc_two);
                             const unsigned sgw = __builtin_bit_cast(unsigned, sg);
                             if (r == 0) carryw = (unsigned)__builtin_amdgcn_readfirstlane((int)sgw) << 16;      // the first sample has no left one
                             const unsigned leftw = (unsigned)wave_shr1((int)sgw, (int)carryw);         // the lane below (lane 0: the row above)
-                            const s16x2 sh = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(sgw, leftw, 16));
-                            const s16x2 df = sg - sh;
-                            zacc += __builtin_elementwise_max(df, -df);
+                            const unsigned shw = __builtin_amdgcn_alignbit(sgw, leftw, 16);
+                            asm("v_sad_u16 %0, %1, %2, %0" : "+v"(zacc) : "v"(sgw), "v"(shw));      // both halves' |code - code'|
                             carryw = (unsigned)__builtin_amdgcn_readlane((int)sgw, L1 - 1);
                         } else {
                             const int sa = ST16 ? sgn1(x0, sr) : sgn1(d0), sb = ST16 ? sgn1(x1, sr) : sgn1(d1);
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                zcv = act1 ? (RAW16 ? (int)zacc.x + (int)zacc.y : zcv) : 0;
+                zcv = act1 ? (RAW16 ? zacc : zcv) : 0;
                 finish_time();
                 PAA_TICK(1)
                 Cd<R1>::run(v);
