@@ -77,7 +77,9 @@ struct Shape {
     static constexpr int C = (C0 % 2) ? C0 : C0 + 1;        // bins per lane in the feature stage (odd: conflict-free at stride C)
     // doubles per spectrum slot: the exchange plane, and 64 lanes x C bins for the feature stage -- the bins past NF are kept
     // at zero (re-zeroed after every transform where the plane reaches into them), so the sweeps need no bounds masks
-    static constexpr int SLOT0 = (PLANE > NF ? PLANE : NF) > 64 * C ? (PLANE > NF ? PLANE : NF) : 64 * C;
+    // (+ one double at index NF, where the last pass parks the results that no bin takes)
+    static constexpr int NFD = NF + 1;
+    static constexpr int SLOT0 = (PLANE > NFD ? PLANE : NFD) > 64 * C ? (PLANE > NFD ? PLANE : NFD) : 64 * C;
     static constexpr int SLOT = (SLOT0 + 1) & ~1;
     static constexpr int LT = W / 10, LB = NF / 10;         // entropy blocks (samples / bins)
     static constexpr int SPL = PACKED ? 2 : 1;              // samples per loaded element
@@ -92,13 +94,17 @@ struct Shape {
     static_assert((L1 < 64 ? L1 : 64) * SPL <= LT, "a register row may contain at most one entropy-block boundary");
     static_assert(C <= LB, "a lane's bins may contain at most one entropy-block boundary");
     static_assert(R3 > 1 || !PACKED, "two-pass shapes (R3 = 1): real input only (Z[k] and Z[N - k] would sit in different lanes)");
-    static_assert(R3 <= 4 || !PACKED, "packed shapes: the pass-3 store flags hold four outputs per job");
+    static_assert(R3 <= 3 || !PACKED, "packed shapes: a pass-3 table entry holds the store offsets of three outputs per job");
+    static_assert(SLOT * 8 < 65536, "pass-3 table entries are 16-bit byte offsets into the slot");
 };
 
 // shared (per workgroup) LDS tables + the global tables behind them in the same device blob
 struct TriLayout {
     int off_tw2;                    // double2 [R2][R3]: W_L1^(b q2)
-    int off_p3;                     // packed: ushort4 [64 NR3]: plane offset of job A, of job B, first bin kA, store flags
+    int off_p3;                     // 8 x ushort [64 NR3], BYTE offsets into the slot.  Packed: plane elements of job A, of job B, then per
+                                    // output k3 where |X[k]| and |X[N - k]| go (8 NF = "nowhere": a parking double).  Real input, three
+                                    // passes: plane elements of the job, then where its R3 (<= 5) magnitudes go.  Two passes (R3 = 1):
+                                    // ushort [R2][64]: where lane q1's magnitude q2 goes
     int off_mello, off_melcnt, off_meloff, off_melw, off_dct, off_chstart, off_chsrc, off_chw;
     int off_sync;                   // pacing of the two waves of a SIMD: SIMD id [8], progress in half frames [8] (ints)
     int table_bytes;                // LDS part, multiple of 16
@@ -503,7 +509,7 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
     tb.ch_src = reinterpret_cast<const int *>(smem + L.off_chsrc);
     tb.ch_w = reinterpret_cast<const double *>(smem + L.off_chw);
     const double2 *t_tw2 = reinterpret_cast<const double2 *>(smem + L.off_tw2);
-    const ushort4 *t_p3 = reinterpret_cast<const ushort4 *>(smem + L.off_p3);
+    const uint4 *t_p3 = reinterpret_cast<const uint4 *>(smem + L.off_p3);
     const double2 *g_tw1 = reinterpret_cast<const double2 *>(blob + L.off_g_tw1);
     const double2 *g_post = reinterpret_cast<const double2 *>(blob + L.off_g_post);
 
@@ -851,30 +857,38 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
         PAA_TICK(4)
         // ---------------- exchange 2: element (q1, b, q2) at plane[q1 PP + q2 R3 + b]; pass 3 + |X| / num_fft (:617-621)
         if constexpr (R3 == 1) {
-            // two-pass shapes: lane q1 holds Z[q1 + R1 q2] already; bin k or its mirror N - k (real input)
+            // two-pass shapes: lane q1 holds Z[q1 + R1 q2] already; bin k or its mirror N - k (real input) -- the host table says
+            // where (idle lanes and the results no bin takes: the parking double at index NF); no predicates around the stores
+            const unsigned short *t_st = reinterpret_cast<const unsigned short *>(t_p3);
+            unsigned char *plb = reinterpret_cast<unsigned char *>(cur);
+            unsigned so[R2];
+#pragma unroll
+            for (int q = 0; q < R2; ++q) so[q] = t_st[q * 64 + lane];
 #pragma unroll
             for (int q = 0; q < R2; ++q) {
                 const double2 z = c2[Cd<R2>::pos(q)];
                 const double mg = mag_sqrt(fma(z.x, z.x, z.y * z.y)) * mscale;
-                const int k = q1_2 + R1 * q;
-                if (act2 && k < NF) cur[k] = mg;
-                else if (act2 && q1_2 > 0 && N - k < NF) cur[N - k] = mg;
+                *reinterpret_cast<double *>(plb + so[q]) = mg;
             }
         } else if constexpr (PACKED) {
             double2 dA[NR3][R3], dB[NR3][R3];
-            ushort4 pe[NR3];
+            uint4 pe[NR3];
 #pragma unroll
             for (int u = 0; u < NR3; ++u) pe[u] = t_p3[lane + 64 * u];
             double *pl = cur;
+            unsigned char *plb = reinterpret_cast<unsigned char *>(cur);
             if (act2) {
 #pragma unroll
                 for (int q = 0; q < R2; ++q) pl[q1_2 * PP + q * R3 + b_2] = c2[Cd<R2>::pos(q)].x;
             }
             wsync();
 #pragma unroll
-            for (int u = 0; u < NR3; ++u)
+            for (int u = 0; u < NR3; ++u) {
+                const double *pa = reinterpret_cast<const double *>(plb + (pe[u].x & 0xffffu));
+                const double *pb = reinterpret_cast<const double *>(plb + (pe[u].x >> 16));
 #pragma unroll
-                for (int b = 0; b < R3; ++b) { dA[u][b].x = pl[pe[u].x + b]; dB[u][b].x = pl[pe[u].y + b]; }
+                for (int b = 0; b < R3; ++b) { dA[u][b].x = pa[b]; dB[u][b].x = pb[b]; }
+            }
             wsync();
             if (act2) {
 #pragma unroll
@@ -882,17 +896,20 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
             }
             wsync();
 #pragma unroll
-            for (int u = 0; u < NR3; ++u)
+            for (int u = 0; u < NR3; ++u) {
+                const double *pa = reinterpret_cast<const double *>(plb + (pe[u].x & 0xffffu));
+                const double *pb = reinterpret_cast<const double *>(plb + (pe[u].x >> 16));
 #pragma unroll
-                for (int b = 0; b < R3; ++b) { dA[u][b].y = pl[pe[u].x + b]; dB[u][b].y = pl[pe[u].y + b]; }
+                for (int b = 0; b < R3; ++b) { dA[u][b].y = pa[b]; dB[u][b].y = pb[b]; }
+            }
             wsync();
             PAA_TICK(5)
 #pragma unroll
             for (int u = 0; u < NR3; ++u) {
-                // flags (host table): bit 0 the (0, 0) job, bits 1 + k3 "store X[k]", bits 5 + k3 "store X[N - k]" (a self-paired job
-                // meets each of its pairs {k, N - k} twice: only the smaller index writes; idle lanes of the last round: 0)
-                const int flags = pe[u].w, kA = pe[u].z;
-                const bool is00 = (flags & 1) != 0;
+                // host table: where each result goes (a self-paired job meets each of its pairs {k, N - k} twice: only the smaller
+                // index is a bin, the other copy -- like everything idle lanes of the last round compute -- is parked at index NF);
+                // no predicates, no branches around the stores.  Job 0 (lane 0 of round 0) is (q1, q2) = (0, 0): its partner is itself
+                const unsigned st[3] = {pe[u].y, pe[u].z, pe[u].w};
                 double2 pw[R3];
 #pragma unroll
                 for (int k3 = 0; k3 < R3; ++k3) pw[k3] = g_post[(lane + 64 * u) * R3 + k3];
@@ -901,9 +918,11 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
 #pragma unroll
                 for (int k3 = 0; k3 < R3; ++k3) {
                     const double2 zk = dA[u][Cd<R3>::pos(k3)];
-                    const double2 zb = dB[u][Cd<R3>::pos(R3 - 1 - k3)], z0 = dA[u][Cd<R3>::pos((R3 - k3) % R3)];
-                    const double2 zm = make_double2(is00 ? z0.x : zb.x, is00 ? z0.y : zb.y);
-                    const int k = kA + N3 * k3;
+                    double2 zm = dB[u][Cd<R3>::pos(R3 - 1 - k3)];
+                    if (u == 0) {
+                        const double2 z0 = dA[u][Cd<R3>::pos((R3 - k3) % R3)];
+                        zm = make_double2((lane == 0) ? z0.x : zm.x, (lane == 0) ? z0.y : zm.y);
+                    }
                     // 2E = Z[k] + conj Z[N-k],  2O = -i (Z[k] - conj Z[N-k]);  X[k] = E + w^k O,  X[N-k] = conj(E - w^k O)
                     const double2 e = make_double2(zk.x + zm.x, zk.y - zm.y);
                     const double2 o = make_double2(zk.y + zm.y, zm.x - zk.x);
@@ -911,30 +930,29 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                     const double xr_ = e.x + wo.x, xi_ = e.y + wo.y, yr_ = e.x - wo.x, yi_ = e.y - wo.y;
                     const double mk = mag_sqrt(fma(xr_, xr_, xi_ * xi_)) * mscale;
                     const double mm = mag_sqrt(fma(yr_, yr_, yi_ * yi_)) * mscale;
-                    if (flags & (2 << k3)) cur[k] = mk;
-                    if (flags & (32 << k3)) cur[N - k] = mm;
+                    *reinterpret_cast<double *>(plb + (st[k3] & 0xffffu)) = mk;
+                    *reinterpret_cast<double *>(plb + (st[k3] >> 16)) = mm;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             double2 d3[NR3][R3];
-            int q1_3[NR3], q2_3[NR3];
+            uint4 pe[NR3];           // host table: byte offsets of the job's plane elements and of its R3 magnitudes' bins
 #pragma unroll
-            for (int u = 0; u < NR3; ++u) {
-                const int m3 = (lane + 64 * u < SH::NJOB3) ? lane + 64 * u : 0;
-                q1_3[u] = m3 / R2;
-                q2_3[u] = m3 - R2 * q1_3[u];
-            }
+            for (int u = 0; u < NR3; ++u) pe[u] = t_p3[lane + 64 * u];
             double *pl = cur;
+            unsigned char *plb = reinterpret_cast<unsigned char *>(cur);
             if (act2) {
 #pragma unroll
                 for (int q = 0; q < R2; ++q) pl[q1_2 * PP + q * R3 + b_2] = c2[Cd<R2>::pos(q)].x;
             }
             wsync();
 #pragma unroll
-            for (int u = 0; u < NR3; ++u)
+            for (int u = 0; u < NR3; ++u) {
+                const double *pa = reinterpret_cast<const double *>(plb + (pe[u].x & 0xffffu));
 #pragma unroll
-                for (int b = 0; b < R3; ++b) d3[u][b].x = pl[q1_3[u] * PP + q2_3[u] * R3 + b];
+                for (int b = 0; b < R3; ++b) d3[u][b].x = pa[b];
+            }
             wsync();
             if (act2) {
 #pragma unroll
@@ -942,23 +960,24 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
             }
             wsync();
 #pragma unroll
-            for (int u = 0; u < NR3; ++u)
+            for (int u = 0; u < NR3; ++u) {
+                const double *pa = reinterpret_cast<const double *>(plb + (pe[u].x & 0xffffu));
 #pragma unroll
-                for (int b = 0; b < R3; ++b) d3[u][b].y = pl[q1_3[u] * PP + q2_3[u] * R3 + b];
+                for (int b = 0; b < R3; ++b) d3[u][b].y = pa[b];
+            }
             wsync();
             PAA_TICK(5)
 #pragma unroll
             for (int u = 0; u < NR3; ++u) {
-                const bool act3 = lane + 64 * u < SH::NJOB3;
+                const unsigned w4[4] = {pe[u].x, pe[u].y, pe[u].z, pe[u].w};
                 Cd<R3>::run(d3[u]);
 #pragma unroll
                 for (int k3 = 0; k3 < R3; ++k3) {
                     const double2 z = d3[u][Cd<R3>::pos(k3)];
                     const double mg = mag_sqrt(fma(z.x, z.x, z.y * z.y)) * mscale;
-                    const int k = q1_3[u] + R1 * (q2_3[u] + R2 * k3);
-                    // bin k, or its mirror N - k (|X[N - k]| = |X[k]| for real input); the jobs with q1 = 0 meet both
-                    if (act3 && k < NF) cur[k] = mg;
-                    else if (act3 && q1_3[u] > 0 && N - k < NF) cur[N - k] = mg;
+                    // bin k, or its mirror N - k (|X[N - k]| = |X[k]| for real input), or the parking double: entry 1 + k3
+                    const unsigned wd = w4[(1 + k3) / 2];
+                    *reinterpret_cast<double *>(plb + (((1 + k3) & 1) ? (wd >> 16) : (wd & 0xffffu))) = mg;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1046,7 +1065,7 @@ inline void tri_fill(double fs, const MelTable *mel, const ChromaTable *chroma, 
     int off = 0;
     auto take = [&off](size_t bytes) { const int o = off; off += (int)((bytes + 15) / 16 * 16); return o; };
     L.off_tw2 = take((size_t)R2 * R3 * 16);
-    L.off_p3 = take(SH::PACKED ? (size_t)64 * NR3 * 8 : 16);
+    L.off_p3 = take(R3 == 1 ? (size_t)R2 * 64 * 2 : (size_t)64 * NR3 * 16);
     L.off_mello = take(40 * 4);
     L.off_melcnt = take(40 * 4);
     L.off_meloff = take(40 * 4);
@@ -1087,20 +1106,40 @@ inline void tri_fill(double fs, const MelTable *mel, const ChromaTable *chroma, 
                 const int p1 = m % R1, p2 = (m / R1) % R2;
                 if (!(p1 > q1 || (p1 == q1 && p2 >= q2))) continue;
                 const bool self = (p1 == q1 && p2 == q2);
-                pt[4 * p] = (unsigned short)(q1 * SH::P + q2 * R3);
-                pt[4 * p + 1] = (unsigned short)(p1 * SH::P + p2 * R3);
-                pt[4 * p + 2] = (unsigned short)k;
-                unsigned fl = (q1 == 0 && q2 == 0) ? 1u : 0u;
-                for (int k3 = 0; k3 < R3; ++k3) {
+                pt[8 * p] = (unsigned short)(8 * (q1 * SH::P + q2 * R3));
+                pt[8 * p + 1] = (unsigned short)(8 * (p1 * SH::P + p2 * R3));
+                for (int k3 = 0; k3 < 3; ++k3) {
                     const int kk = k + R1 * R2 * k3;
-                    if (!self || 2 * kk <= N) fl |= 2u << k3;                       // X[k]
-                    if (kk != 0 && (!self || 2 * kk < N)) fl |= 32u << k3;          // X[N - k]
+                    const bool put_k = k3 < R3 && (!self || 2 * kk <= N);                    // X[k]
+                    const bool put_m = k3 < R3 && kk != 0 && (!self || 2 * kk < N);          // X[N - k]
+                    pt[8 * p + 2 + 2 * k3] = (unsigned short)(8 * (put_k ? kk : SH::NF));
+                    pt[8 * p + 3 + 2 * k3] = (unsigned short)(8 * (put_m ? N - kk : SH::NF));
                 }
-                pt[4 * p + 3] = (unsigned short)fl;
                 for (int k3 = 0; k3 < R3; ++k3) put_w(L.off_g_post, (size_t)p * R3 + k3, (long long)k + (long long)R1 * R2 * k3, 2LL * N);
                 ++p;
             }
-        // idle lanes of the last round: valid plane offsets, nothing stored (flags 0)
+        // idle lanes of the last round: valid plane offsets (0), every result parked
+        for (; p < 64 * NR3; ++p)
+            for (int k3 = 0; k3 < 3; ++k3) pt[8 * p + 2 + 2 * k3] = pt[8 * p + 3 + 2 * k3] = (unsigned short)(8 * SH::NF);
+    }
+    if (!SH::PACKED) {
+        // real input: |Z[k]| goes to bin k, or to its mirror N - k, or nowhere (the parking double at index NF)
+        constexpr int NF = SH::NF;
+        auto where = [&](int q1, int k) { return 8 * ((k < NF) ? k : (q1 > 0 && N - k < NF) ? N - k : NF); };
+        unsigned short *pt = reinterpret_cast<unsigned short *>(b + L.off_p3);
+        if (R3 == 1) {
+            for (int q2 = 0; q2 < R2; ++q2)
+                for (int lane = 0; lane < 64; ++lane)
+                    pt[q2 * 64 + lane] = (unsigned short)(lane < NQ1 ? where(lane, lane + R1 * q2) : 8 * NF);
+        } else {
+            for (int m3 = 0; m3 < 64 * NR3; ++m3) {
+                const int q1 = m3 / R2, q2 = m3 % R2;
+                const bool act = m3 < SH::NJOB3;
+                pt[8 * m3] = (unsigned short)(act ? 8 * (q1 * SH::P + q2 * R3) : 0);
+                for (int k3 = 0; k3 < 7; ++k3)
+                    pt[8 * m3 + 1 + k3] = (unsigned short)((act && k3 < R3) ? where(q1, q1 + R1 * (q2 + R2 * k3)) : 8 * NF);
+            }
+        }
     }
     if (mel && !mel->w.empty()) {
         memcpy(b + L.off_mello, mel->lo.data(), 40 * 4);

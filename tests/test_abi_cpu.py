@@ -316,7 +316,7 @@ def test_default_build_has_no_experiment_switches():
 def test_three_pass_tables_reproduce_the_fft(window):
     """Host tables of csrc/kernels_tri.hpp (no device): the three passes restated in NumPy FROM THE LIBRARY'S OWN TABLES --
     pass-1 twiddles W_N^(j q1), pass-2 twiddles W_L1^(b q2), for packed (even) windows the pass-3 job pairs with their plane
-    offsets, first bins, store flags and post-twiddles -- give |fft(frame)|[0:W/2] / (W/2), every bin written exactly once
+    offsets, store offsets and post-twiddles -- give |fft(frame)|[0:W/2] / (W/2), every bin written exactly once
     (ShortTermFeatures.py:617-621).  The kernel executes exactly this index algebra in registers."""
     import ctypes
     lib = _ffi.lib()
@@ -350,41 +350,51 @@ def test_three_pass_tables_reproduce_the_fft(window):
     hits = np.zeros(NF, dtype=int)
     if R3 == 1:                                                 # two passes: lane q1 holds Z[q1 + R1 q2]
         assert not packed
+        where = blob[off[1]:off[1] + 2 * 64 * R2].view(np.uint16).reshape(R2, 64)      # byte offset of lane q1's magnitude q2
+        assert np.all(where % 8 == 0) and np.all(where[:, NQ1:] == 8 * NF)              # idle lanes: the parking double
         for q1 in range(NQ1):
             for q2 in range(R2):
-                k = q1 + R1 * q2
+                k = int(where[q2, q1]) // 8
+                assert k <= NF and k in (q1 + R1 * q2, N - q1 - R1 * q2, NF)
                 if k < NF:
                     X[k] = abs(plane2[q1 * P + q2]); hits[k] += 1
-                elif q1 > 0 and N - k < NF:
-                    X[N - k] = abs(plane2[q1 * P + q2]); hits[N - k] += 1
     elif packed:
-        p3 = blob[off[1]:off[1] + 8 * 64 * ((njob3 + 63) // 64)].view(np.uint16).reshape(-1, 4)
+        # entries of 8 x uint16, BYTE offsets into the frame's slot: plane elements of job A, of job B, then per output k3 where
+        # |X[k]| and |X[N - k]| go; 8 NF = the parking double (a result no bin takes)
+        p3 = blob[off[1]:off[1] + 16 * 64 * ((njob3 + 63) // 64)].view(np.uint16).reshape(-1, 8)
         post = cplx(off[3], 64 * ((njob3 + 63) // 64) * R3).reshape(-1, R3)
-        assert np.all(p3[njob3:, 3] == 0)                       # idle lanes of the last round store nothing
+        assert np.all(p3 % 8 == 0) and np.all(p3[njob3:, 2:] == 8 * NF) and np.all(p3[:, 2 + 2 * R3:] == 8 * NF)
+        p3 = p3 // 8
         for p in range(njob3):
-            offA, offB, kA, flags = (int(v) for v in p3[p])
+            offA, offB = int(p3[p, 0]), int(p3[p, 1])
             zA, zB = np.fft.fft(plane2[offA:offA + R3]), np.fft.fft(plane2[offB:offB + R3])
             for k3 in range(R3):
-                k = kA + R1 * R2 * k3
                 zk = zA[k3]
-                zm = zA[(R3 - k3) % R3] if (flags & 1) else zB[R3 - 1 - k3]
+                zm = zA[(R3 - k3) % R3] if p == 0 else zB[R3 - 1 - k3]          # job 0 is (q1, q2) = (0, 0): its own partner
                 e, o = 0.5 * (zk + np.conj(zm)), -0.5j * (zk - np.conj(zm))
-                assert abs(post[p, k3] - np.exp(-1j * np.pi * k / N)) < 1e-15
-                if flags & (2 << k3):
-                    X[k] = abs(e + post[p, k3] * o); hits[k] += 1
-                if flags & (32 << k3):
-                    X[N - k] = abs(e - post[p, k3] * o); hits[N - k] += 1
+                ka, kb = int(p3[p, 2 + 2 * k3]), int(p3[p, 3 + 2 * k3])
+                assert ka <= NF and kb <= NF and (ka == NF or kb == NF or ka + kb == N)
+                if ka < NF:
+                    assert abs(post[p, k3] - np.exp(-1j * np.pi * ka / N)) < 1e-15
+                    X[ka] = abs(e + post[p, k3] * o); hits[ka] += 1
+                if kb < NF:
+                    assert abs(post[p, k3] - np.exp(-1j * np.pi * (N - kb) / N)) < 1e-15
+                    X[kb] = abs(e - post[p, k3] * o); hits[kb] += 1
     else:
         assert njob3 == NQ1 * R2
+        # entries of 8 x uint16 byte offsets: the job's plane elements, then where its R3 magnitudes go (8 NF: nowhere)
+        p3 = blob[off[1]:off[1] + 16 * 64 * ((njob3 + 63) // 64)].view(np.uint16).reshape(-1, 8)
+        assert np.all(p3 % 8 == 0) and np.all(p3[njob3:, 1:] == 8 * NF) and np.all(p3[:, 1 + R3:] == 8 * NF)
+        p3 = p3 // 8
         for m3 in range(njob3):
             q1, q2 = divmod(m3, R2)
-            zz = np.fft.fft(plane2[q1 * P + q2 * R3 + np.arange(R3)])
+            assert p3[m3, 0] == q1 * P + q2 * R3
+            zz = np.fft.fft(plane2[int(p3[m3, 0]) + np.arange(R3)])
             for k3 in range(R3):
-                k = q1 + R1 * (q2 + R2 * k3)
-                if k < NF:
-                    X[k] = abs(zz[k3]); hits[k] += 1
-                elif q1 > 0 and N - k < NF:
-                    X[N - k] = abs(zz[k3]); hits[N - k] += 1
+                k, dst = q1 + R1 * (q2 + R2 * k3), int(p3[m3, 1 + k3])
+                assert dst in (k, N - k, NF)
+                if dst < NF:
+                    X[dst] = abs(zz[k3]); hits[dst] += 1
     assert np.all(hits == 1), np.flatnonzero(hits != 1)[:8]
     ref = np.abs(np.fft.fft(y))[:NF]
     assert np.max(np.abs(X - ref)) < 1e-10 * np.max(ref)
