@@ -539,15 +539,21 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_ct_kernel(PlanDev P, TabLa
         sXp += (double)NF * kEps;
         // spectral entropy (:85-107): cumulative energy at the block boundaries j LB, j = 0 .. 9, written by the lane whose
         // bins contain the boundary; boundary 10 is the total
+        // -- and the roll-off (:127-140: first k with cumsum(X^2)[k] + eps > 0.9 sum(X^2)) from the same running energy: it
+        // never decreases, so the first bin that qualifies is the number of bins that do not (the last bin below NF always
+        // qualifies, bin 0 does when the total is 0: the zero bins past NF never decide)
         double *bg = bnd + 12 * g;
+        int below = 0;
         {
             const int jb = (kb + LB - 1) / LB;                   // first boundary at or after the lane's first bin
             const int mb = jb * LB - kb;
-            double part = 0.0, cumb = run_excl;
+            const double thr = 0.90 * sP;
+            double run = run_excl, cumb = run_excl;
 #pragma unroll
             for (int m = 0; m < C; ++m) {
-                cumb = (m == mb) ? run_excl + part : cumb;
-                part = fma(Xc[m], Xc[m], part);
+                cumb = (m == mb) ? run : cumb;
+                run = fma(Xc[m], Xc[m], run);
+                below += (run + kEps > thr) ? 0 : 1;
             }
             if (mb < C && jb < 10 && kb < NF) bg[jb] = cumb;
         }
@@ -587,18 +593,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_ct_kernel(PlanDev P, TabLa
         sSp = group_sum(sSp);
         sFl = group_sum(sFl);
         const double spread = fast_sqrt(sSp * rden);
-        // roll-off (:127-140): first k with cumsum(X^2)[k] + eps > 0.9 sum(X^2)
-        int first = 0x7fffffff;
-        {
-            const double thr = 0.90 * sP;
-            double run = run_excl;
-#pragma unroll
-            for (int m = 0; m < C; ++m) {
-                run = fma(Xc[m], Xc[m], run);
-                first = (first == 0x7fffffff && kb + m < NF && run + kEps > thr) ? kb + m : first;
-            }
-            first = group_min_i(first);
-        }
+        const int first = group_min_i((below < C) ? kb + below : 0x7fffffff);
         PAA_TICK(6)
         // MFCC (:236-254): per-lane padded mel lists: class 0 = filter i, class 1 = filter 16 + i, class 2 = one half of
         // filter 32 + (i & 7); the halves meet through a row rotation by 8

@@ -844,18 +844,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
         sFl = group_sum(sFl);
         const double spread = fast_sqrt(sSp * rden);
 
-        // roll-off (:127-140): first k with cumsum(X^2)[k] + eps > 0.9 sum(X^2); branch-free per lane
-        int first = 0x7fffffff;
+        // roll-off (:127-140): first k with cumsum(X^2)[k] + eps > 0.9 sum(X^2).  The running energy never decreases, so the
+        // first bin that qualifies is the number of bins that do not (one compare and one add-with-carry per bin)
+        int below = 0;
         {
             const double thr = 0.90 * sP;
             double run = run_incl - cs;
 #pragma unroll
             for (int m = 0; m < 25; ++m) {
                 run = fma(Xc[m], Xc[m], run);
-                first = (first == 0x7fffffff && run + kEps > thr) ? 25 * i + m : first;
+                below += (run + kEps > thr) ? 0 : 1;
             }
-            first = group_min_i(first);
         }
+        const int first = group_min_i((below < 25) ? 25 * i + below : 0x7fffffff);
 
         PAA_TICK(6)
         // MFCC (:236-254): per-lane padded mel lists (host-built): class 0 = filter i, class 1 = filter 16+i,

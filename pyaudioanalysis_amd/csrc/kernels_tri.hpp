@@ -357,14 +357,20 @@ __device__ __forceinline__ void tri_features(const TriLayout &L, const Tabs &tb,
     sXp += (double)NF * kEps;
     // spectral entropy (:85-107): cumulative energy at the block boundaries j LB, j = 0 .. 10, written by the lane whose
     // bins contain the boundary (boundary 10 = the total when the blocks tile the spectrum)
+    // -- and the roll-off (:127-140: first k with cumsum(X^2)[k] + eps > 0.9 sum(X^2)) from the same running energy: it never
+    // decreases, so the first bin that qualifies is the number of bins that do not (a bin below NF always qualifies -- the
+    // last one reaches the total, bin 0 does when the total is 0 -- so the zero bins past NF never decide)
+    int below = 0;
     {
         const int jb = (kb + LB - 1) / LB;                   // first boundary at or after the lane's first bin
         const int mb = jb * LB - kb;
-        double part = 0.0, cumb = run_excl;
+        const double thr = 0.90 * sP;
+        double run = run_excl, cumb = run_excl;
 #pragma unroll
         for (int m = 0; m < C; ++m) {
-            cumb = (m == mb) ? run_excl + part : cumb;
-            part = fma(Xc[m], Xc[m], part);
+            cumb = (m == mb) ? run : cumb;
+            run = fma(Xc[m], Xc[m], run);
+            below += (run + kEps > thr) ? 0 : 1;
         }
         if (mb < C && jb <= 10 && jb * LB < NF) bnd[jb] = cumb;
         if (10 * LB == NF && lane == 0) bnd[10] = sP;
@@ -403,20 +409,7 @@ __device__ __forceinline__ void tri_features(const TriLayout &L, const Tabs &tb,
     sSp = wsum(sSp);
     sFl = wsum(sFl);
     const double spread = fast_sqrt(sSp * rden);
-    // roll-off (:127-140): first k with cumsum(X^2)[k] + eps > 0.9 sum(X^2)
-    int first = 0x7fffffff;
-    {
-        const double thr = 0.90 * sP;
-        double run = run_excl;
-#pragma unroll
-        for (int m = 0; m < C; ++m) {
-            run = fma(Xc[m], Xc[m], run);
-            // (a bin below NF always qualifies -- the last one reaches the total, bin 0 does when the total is 0 -- so the zero
-            // bins past NF never decide)
-            first = (first == 0x7fffffff && run + kEps > thr) ? kb + m : first;
-        }
-        first = mix::wmin_nonneg_i(first);
-    }
+    const int first = mix::wmin_nonneg_i((below < C) ? kb + below : 0x7fffffff);
     // MFCC (:236-254): lane m < 40 = mel filter m (sparse list), log10, then the 13 x 40 DCT on 52 lanes
     if (lane < 40) {
         const int lo = tb.mel_lo[lane], cnt = tb.mel_cnt[lane];
@@ -648,20 +641,21 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                 int w0[ST16 ? R1 : 1], w1[ST16 ? R1 : 1];     // stereo: the two raw frames of a pair (summed L + R row by row, below)
                 // idle lanes shadow the last job with scale and mean 0: their samples are exact zeros (no energy, nothing to mask)
                 const double scl = act1 ? sc : 0.0, meanl = act1 ? mean : 0.0;
+                const T *xb = xf + 2 * jj;       // (one address per lane: the rows are immediate offsets of the loads)
 #pragma unroll
                 for (int r = 0; r < R1; ++r) {
                     if constexpr (RAW16) {
                         typedef int w32 __attribute__((aligned(2)));
-                        wr[r] = *reinterpret_cast<const w32 *>(xf + 2 * (jj + L1 * r));
+                        wr[r] = *reinterpret_cast<const w32 *>(xb + 2 * L1 * r);
                         v[r] = make_double2(fma((double)(short)(wr[r] & 0xffff), scl, -meanl), fma((double)(wr[r] >> 16), scl, -meanl));
                     } else if constexpr (ST16) {
                         typedef int vec2 __attribute__((ext_vector_type(2), aligned(4)));
-                        const vec2 s2 = *reinterpret_cast<const vec2 *>(xf + 2 * (jj + L1 * r));
+                        const vec2 s2 = *reinterpret_cast<const vec2 *>(xb + 2 * L1 * r);
                         w0[r] = s2.x; w1[r] = s2.y;
                         if (MODE != 0)
                             v[r] = make_double2(fma((double)stereo_word_sum(w0[r]), scl, -meanl), fma((double)stereo_word_sum(w1[r]), scl, -meanl));
                     } else {
-                        const double2 x = ct::PairLoad<T>::get(xf + 2 * (jj + L1 * r));
+                        const double2 x = ct::PairLoad<T>::get(xb + 2 * L1 * r);
                         v[r] = make_double2(fma(x.x, scl, -meanl), fma(x.y, scl, -meanl));
                     }
                 }
@@ -740,13 +734,14 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                     const int jj = (j < L1) ? j : L1 - 1;
                     scl[u] = (j < L1) ? sc : 0.0;
                     meanl[u] = (j < L1) ? mean : 0.0;
+                    const T *xb = xf + jj;       // (one address per lane: the rows are immediate offsets of the loads)
 #pragma unroll
                     for (int r = 0; r < R1; ++r) {
                         if constexpr (INT_T) {
-                            xi[u][r] = load_int<T>(xf + jj + L1 * r);
+                            xi[u][r] = load_int<T>(xb + L1 * r);
                             if (MODE != 0) xr[u][r] = fma((double)xi[u][r], scl[u], -meanl[u]);
                         } else {
-                            xr[u][r] = fma(load_sample<T>(xf + jj + L1 * r), scl[u], -meanl[u]);
+                            xr[u][r] = fma(load_sample<T>(xb + L1 * r), scl[u], -meanl[u]);
                         }
                     }
                 }
