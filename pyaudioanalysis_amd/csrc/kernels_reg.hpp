@@ -148,6 +148,8 @@ struct Shape {
 // LDS layout: shared tables, then per wave: (Q + 1) spectrum slots, the output staging tile, fv / msp
 struct RegLayout {
     int off_post, off_mello, off_melcnt, off_meloff, off_melw, off_dct, off_chstart, off_chsrc, off_chw;
+    int off_bins;        // ushort2 [R2][16]: byte offsets of bin k and of its mirror NC - k (8 NF: nowhere, the slot's padding double)
+                         // of pass-B lane pcol's output e (e = 0: q = 0, 2 j - 1: q = j, 2 j: q = R2 - j)
     int table_bytes, wave_bytes, waves;
     int ring;            // spectrum slots per wave: Q + 1 for the features (the flux needs the previous frame), Q for the rows
 };
@@ -673,6 +675,7 @@ __global__ __launch_bounds__(512) void st_reg_kernel(PlanDev P, RegLayout L, con
     Tabs tb;
     tb.tw = nullptr;
     tb.post = reinterpret_cast<const double2 *>(smem + L.off_post);
+    const unsigned char *tb_bins = smem + L.off_bins;
     tb.mel_lo = reinterpret_cast<const int *>(smem + L.off_mello);
     tb.mel_cnt = reinterpret_cast<const int *>(smem + L.off_melcnt);
     tb.mel_off = reinterpret_cast<const int *>(smem + L.off_meloff);
@@ -733,11 +736,14 @@ __global__ __launch_bounds__(512) void st_reg_kernel(PlanDev P, RegLayout L, con
             {
                 double2 v[R1];
                 const T *xf = x0 + (long long)(ok ? ta : tq) * P.S;
+                // index R2 n1 + R1 n2 (< 2 NC: one conditional wrap) as ONE of two per-lane addresses + a compile-time offset: the
+                // wrap happens from a compile-time threshold of n2 on
+                const T *p_lo = xf + 2 * R1 * n2, *p_hi = p_lo - 2 * NC;
 #pragma unroll
                 for (int n1 = 0; n1 < R1; ++n1) {
-                    int idx = R2 * n1 + R1 * n2;                    // < 2 NC: one conditional wrap
-                    idx = (idx >= NC) ? idx - NC : idx;
-                    const double2 ab = ct::PairLoad<T>::get(xf + 2 * idx);       // one load per complex sample
+                    const int wrap_from = (NC - R2 * n1 + R1 - 1) / R1;          // n2 >= wrap_from: R2 n1 + R1 n2 >= NC
+                    const T *pp = (n2 >= wrap_from) ? p_hi : p_lo;
+                    const double2 ab = ct::PairLoad<T>::get(pp + 2 * R2 * n1);   // one load per complex sample
                     v[n1] = make_double2(fma(ab.x, sc, -nm.mean) * nm.inv, fma(ab.y, sc, -nm.mean) * nm.inv);
                 }
                 v0 = v[0];
@@ -786,28 +792,31 @@ __global__ __launch_bounds__(512) void st_reg_kernel(PlanDev P, RegLayout L, con
             prime_fold<R2>(a, sa, da);
             prime_fold<R2>(b, sb, db);
             const double mscale = 0.5 / (double)NF;            // E and O carry 1/2; X / len(X) (:621)
-            // bin of (column p, output q): k = (C1 p + C2 q) mod NC; its partner NC - k is (column R1 - p, output R2 - q)
-            const int k_p0 = (SH::C1 * pcol) % NC;
-            auto bins = [&](int k, const double2 &zk, const double2 &zm) {
+            // bin of (column p, output q): k = (C1 p + C2 q) mod NC; its partner NC - k is (column R1 - p, output R2 - q).  Where
+            // the two magnitudes of an output go comes from the host table (byte offsets; the mirror of bin 0 -- the Nyquist bin the
+            // reference drops -- goes to the slot's padding double): no index arithmetic, no predicates around the stores
+            const unsigned *t_bins = reinterpret_cast<const unsigned *>(tb_bins) + pcol;
+            unsigned char *spb = reinterpret_cast<unsigned char *>(sp);
+            const unsigned char *postb = reinterpret_cast<const unsigned char *>(tb.post);
+            auto bins = [&](unsigned ent, const double2 &zk, const double2 &zm) {
                 // 2E = Z[k] + conj Z[NC-k], 2O = -i (Z[k] - conj Z[NC-k]); X[k] = E + w^k O, |X[NC-k]| = |E - w^k O|
+                const unsigned ok_ = ent & 0xffffu, om_ = ent >> 16;
                 const double2 e = make_double2(zk.x + zm.x, zk.y - zm.y);
                 const double2 o = make_double2(zk.y + zm.y, zm.x - zk.x);
-                const double2 t = cmul(tb.post[k], o);
+                const double2 t = cmul(*reinterpret_cast<const double2 *>(postb + 2 * ok_), o);
                 const double xr = e.x + t.x, xi = e.y + t.y, yr = e.x - t.x, yi = e.y - t.y;
-                sp[k] = mag_sqrt(fma(xr, xr, xi * xi)) * mscale;
-                if (k != 0) sp[NC - k] = mag_sqrt(fma(yr, yr, yi * yi)) * mscale;
+                *reinterpret_cast<double *>(spb + ok_) = mag_sqrt(fma(xr, xr, xi * xi)) * mscale;
+                *reinterpret_cast<double *>(spb + om_) = mag_sqrt(fma(yr, yr, yi * yi)) * mscale;
             };
-            bins(k_p0, prime_dc<R2>(a0, sa), prime_dc<R2>(b0, sb));
-            int k_up = k_p0, k_dn = k_p0;
+            bins(t_bins[0], prime_dc<R2>(a0, sa), prime_dc<R2>(b0, sb));
             for_pairs<R2, 1>([&](auto qc) {
                 constexpr int QK = decltype(qc)::value;
                 double2 xa, xar, xb, xbr;
+                const unsigned e_up = t_bins[16 * (2 * QK - 1)], e_dn = t_bins[16 * (2 * QK)];
                 prime_pair<R2, QK>(a0, sa, da, xa, xar);
                 prime_pair<R2, QK>(b0, sb, db, xb, xbr);
-                k_up += SH::C2; k_up = (k_up >= NC) ? k_up - NC : k_up;          // k(p, q)
-                k_dn -= SH::C2; k_dn = (k_dn < 0) ? k_dn + NC : k_dn;            // k(p, R2 - q)
-                bins(k_up, xa, xbr);          // Z[k(p,q)] with Z[NC - k] = column R1-p, output R2-q
-                bins(k_dn, xar, xb);          // Z[k(p,R2-q)] with column R1-p, output q
+                bins(e_up, xa, xbr);          // Z[k(p,q)] with Z[NC - k] = column R1-p, output R2-q
+                bins(e_dn, xar, xb);          // Z[k(p,R2-q)] with column R1-p, output q
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -880,8 +889,11 @@ inline size_t reg_wave_bytes(int nfp, int ring, int q, int F) {
 }
 
 // fills the layout and the host image of the shared table region (no Stockham twiddles: prime-factor transform)
-inline void reg_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable *chroma, int F, int nfp, int q,
-                       RegLayout &L, std::vector<unsigned char> *blob) {
+template <typename SH>
+inline void reg_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable *chroma, int F, RegLayout &L,
+                       std::vector<unsigned char> *blob) {
+    constexpr int nfp = SH::NFP, q = SH::Q;
+    static_assert(SH::NP <= 16 && 8 * SH::NFP < 65536 && SH::NFP > SH::NF, "bin table: 16 lanes per frame, 16-bit byte offsets, a padding double");
     int off = 0;
     auto take = [&off](size_t bytes) { const int o = off; off += (int)((bytes + 15) / 16 * 16); return o; };
     const int Nc = fft.len;
@@ -895,6 +907,7 @@ inline void reg_layout(const FftPlan &fft, const MelTable *mel, const ChromaTabl
     L.off_chstart = take(13 * 4);
     L.off_chsrc = take(std::max<size_t>(n_ch, 1) * 4);
     L.off_chw = take(std::max<size_t>(n_ch, 1) * 8);
+    L.off_bins = take((size_t)SH::R2 * 16 * 4);
     L.table_bytes = off;
     // spectrogram / chromagram rows need no previous spectrum: Q slots, and eight waves (two per SIMD) fit the LDS
     L.ring = (F > 0) ? q + 1 : q;
@@ -905,6 +918,17 @@ inline void reg_layout(const FftPlan &fft, const MelTable *mel, const ChromaTabl
     blob->assign((size_t)L.table_bytes, 0);
     unsigned char *b = blob->data();
     memcpy(b + L.off_post, fft.post.data(), (size_t)Nc * 16);
+    {
+        unsigned short *bt = reinterpret_cast<unsigned short *>(b + L.off_bins);
+        for (int e = 0; e < SH::R2; ++e) {
+            const int qq = (e == 0) ? 0 : (e % 2 ? (e + 1) / 2 : SH::R2 - e / 2);
+            for (int pc = 0; pc < 16; ++pc) {
+                const int k = (SH::C1 * std::min(pc, SH::NP - 1) + SH::C2 * qq) % SH::NC;
+                bt[2 * (16 * e + pc)] = (unsigned short)(8 * k);
+                bt[2 * (16 * e + pc) + 1] = (unsigned short)(8 * (k != 0 ? SH::NC - k : SH::NF));
+            }
+        }
+    }
     if (mel && !mel->w.empty()) {
         memcpy(b + L.off_mello, mel->lo.data(), 40 * 4);
         memcpy(b + L.off_melcnt, mel->cnt.data(), 40 * 4);

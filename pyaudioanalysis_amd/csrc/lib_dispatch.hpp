@@ -87,7 +87,7 @@ static int fam_reg_select(FamilyCtx &c) {
     if (c.mode == 0 && !experiment_env("PAA_REG_1102")) return 0;
     using SH = reg::Shape1102;
     std::vector<unsigned char> blob;
-    reg::reg_layout(c.tab->fft, c.mel(), c.chroma(), c.F, SH::NFP, SH::Q, c.p->rl, &blob);
+    reg::reg_layout<SH>(c.tab->fft, c.mel(), c.chroma(), c.F, c.p->rl, &blob);
     if ((size_t)c.p->rl.table_bytes + (size_t)c.p->rl.wave_bytes > 160 * 1024) return 0;
     const int rc = upload_blob(c.p, blob);
     if (rc) return rc;

@@ -5,7 +5,7 @@ lane-operations whether the lanes carry useful data or not, so two numbers come 
     issued  = SQ_INSTS_VALU x f64 share x mean flop weight x 64      (what the FP64 pipes were asked to do)
     useful  = the same x the active-lane share of the stages (estimated from the stage structure, stated below)
 usage (build container): python scripts/fp64_executed.py profiles/r04_fast800_w8_summary.json  ->  profiles/r04_fast800_fp64_executed.json
-(compiles csrc/paa_lib.hip with -save-temps into /tmp to get the listing of st_fast_800_kernel<400,0,1,8>)."""
+(compiles csrc/family_fast.hip with -save-temps into /tmp to get the listing of st_fast_800_kernel<400,0,1,8>)."""
 import collections
 import json
 import os
@@ -42,10 +42,10 @@ def loop_body(lines, key):
 def main(summary_path, out_path):
     summ = json.load(open(summary_path))
     with tempfile.TemporaryDirectory() as d:
-        src = os.path.join(ROOT, "pyaudioanalysis_amd", "csrc", "paa_lib.hip")
+        src = os.path.join(ROOT, "pyaudioanalysis_amd", "csrc", "family_fast.hip")
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-disable-machine-licm", "-I/opt/rocm/include",
                         "-c", src, "-o", os.path.join(d, "x.o"), "-save-temps"], cwd=d, check=True, capture_output=True)
-        lines = open(os.path.join(d, "paa_lib-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
+        lines = open(os.path.join(d, "family_fast-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
     body = loop_body(lines, "st_fast_800_kernelILi400ELi0ELi1ELi8E")
     ops = collections.Counter()
     for l in body:
