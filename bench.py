@@ -292,6 +292,9 @@ def main():
 
     group = None                        # control plane: TCP sockets on the launcher's environment (no torch)
     if world > 1:
+        # several processes that touch GPUs on this driver stack need dmabuf IPC (RCCL's peer mappings fail with
+        # "hipIpcGetMemHandle: invalid argument" in the legacy mode); must be in place before the HIP runtime loads
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         from pyaudioanalysis_amd._rendezvous import SocketGroup
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         group = SocketGroup(rank=rank, world_size=world, timeout=max(60.0, float(args.comm_timeout)))

@@ -246,14 +246,20 @@ extern "C" int paa_comm_gatherv_f64(const double *d_send, const int64_t *counts,
     HIP_TRY(hipEventRecord(g_ev_ready, g_main_stream));
     HIP_TRY(hipStreamWaitEvent(g_comm_stream, g_ev_ready, 0));
     NCCL_TRY(g_rccl.GroupStart());
+    // a call that fails inside the group must not leave the group open (every later RCCL call of this thread would
+    // be swallowed by it): remember the first error, close the group, then report
+    ncclResult_t in_group = ncclSuccess;
     if (g_rank == root) {
-        for (int r = 0; r < g_world; ++r)
+        for (int r = 0; r < g_world && in_group == ncclSuccess; ++r)
             if (r != root && counts[r] > 0)
-                NCCL_TRY(g_rccl.Recv(d_recv + displs[r], (size_t)counts[r], ncclDouble, r, g_comm, g_comm_stream));
+                in_group = g_rccl.Recv(d_recv + displs[r], (size_t)counts[r], ncclDouble, r, g_comm, g_comm_stream);
     } else if (counts[g_rank] > 0) {
-        NCCL_TRY(g_rccl.Send(d_send, (size_t)counts[g_rank], ncclDouble, root, g_comm, g_comm_stream));
+        if (!d_send) in_group = ncclInvalidArgument;
+        else in_group = g_rccl.Send(d_send, (size_t)counts[g_rank], ncclDouble, root, g_comm, g_comm_stream);
     }
-    NCCL_TRY(g_rccl.GroupEnd());
+    const ncclResult_t at_end = g_rccl.GroupEnd();
+    if (in_group != ncclSuccess) return fail(PAA_ERR_COMM, "ncclSend / ncclRecv of the gather: %s", g_rccl.GetErrorString(in_group));
+    if (at_end != ncclSuccess) return fail(PAA_ERR_COMM, "ncclGroupEnd of the gather: %s", g_rccl.GetErrorString(at_end));
     if (g_rank == root && d_send && counts[root] > 0 && d_recv + displs[root] != d_send)
         HIP_TRY(hipMemcpyAsync(d_recv + displs[root], d_send, (size_t)counts[root] * 8, hipMemcpyDeviceToDevice, g_comm_stream));
     if (d_send) {       // the next kernel that writes d_send must wait for this gather (see paa_plan_execute)

@@ -321,6 +321,8 @@ def test_shipped_kernels_hold_their_register_budget():
     mixed-radix kernel (TWG = 2: reserved, 12-20 bytes) and AGPRs only in its full instance (TWG = 0, one wave per SIMD:
     windows like 4800 / 6000) -- VERDICT r03, items 1 and 8."""
     import importlib.util
+    if os.environ.get("PAA_HIP_LIBRARY"):
+        pytest.skip("about the shipped binary, not the build under test (sanitizer / experiment builds)")
     spec = importlib.util.spec_from_file_location("resource_usage", os.path.join(ROOT, "scripts", "resource_usage.py"))
     ru = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ru)
@@ -349,6 +351,26 @@ def test_shipped_kernels_hold_their_register_budget():
     for r in rows:                                 # the tracked record is the shipped build's (same compiler, same flags)
         t = table[r["kernel"]]
         assert (t["vgpr"], t["agpr"], t["scratch_bytes_per_lane"]) == (r["vgpr"], r["agpr"], r["scratch_bytes_per_lane"]), (t, r)
+
+
+def test_device_code_is_the_validated_one():
+    """The machine code of every gfx950 code object in the shipped library equals the record of the build whose GPU test
+    run, bench line and rocprofv3 passes are the round's evidence (profiles/r04_device_code.json, scripts/device_code_hash.py;
+    two builds of one source tree give the same .text / .rodata bytes).  Whoever changes a kernel re-runs the GPU pass
+    (scripts/gpu_round.sh writes the new record) -- a host-side or documentation commit cannot move the device code unnoticed."""
+    import importlib.util
+    import json
+    if os.environ.get("PAA_HIP_LIBRARY"):
+        pytest.skip("about the shipped binary, not the build under test (sanitizer / experiment builds)")
+    spec = importlib.util.spec_from_file_location("device_code_hash", os.path.join(ROOT, "scripts", "device_code_hash.py"))
+    dch = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dch)
+    have = dch.device_code(_ffi.library_path())
+    want = json.load(open(os.path.join(ROOT, "profiles", "r04_device_code.json")))["code_objects"]
+    assert [(u["first_kernel"], u["kernels"]) for u in have] == [(w["first_kernel"], w["kernels"]) for w in want]
+    for u, w in zip(have, want):
+        assert (u["text_sha256"], u["rodata_sha256"]) == (w["text_sha256"], w["rodata_sha256"]), \
+            "device code of the unit with %s differs from the GPU-validated record" % u["first_kernel"]
 
 
 @pytest.mark.parametrize("window", [2400, 2205, 1764, 1920, 1600, 1200, 1102, 551])
