@@ -10,8 +10,13 @@ x = synth_clip(2, 3600 * 16000)
 d_in = _ffi.DeviceBuffer.from_host(x)
 plan = _ffi.Plan(np.array([0, len(x)], dtype=np.int64), 16000, 800, 400, deltas=False)
 d_out = _ffi.DeviceBuffer(plan.out_doubles * 8)
-for _ in range(3): plan.execute(d_in, d_out)
-_ffi.sync()
+import time
+# a fresh box idles at a low engine clock: run the plan for a fixed wall time first (PAA_PHASE_PREWARM seconds, default 0.5),
+# so that the clock the wave trace reports below is the sustained one
+t_pre = time.perf_counter()
+while time.perf_counter() - t_pre < float(os.environ.get("PAA_PHASE_PREWARM", "0.5")):
+    for _ in range(20): plan.execute(d_in, d_out)
+    _ffi.sync()
 buf = (ctypes.c_uint64 * 16)()
 lib.paa_debug_phase_cycles(buf)
 for _ in range(5): plan.execute(d_in, d_out)
