@@ -589,6 +589,22 @@ def main():
                 fv["issued_source"] = "profiles/%s_fast800_fp64_executed.json (counter pass of this command x ISA histogram)" % PROFILE_ROUND
         except Exception:
             pass
+        # the data sheet's FP64 peak needs 2.4 GHz; the clock this kernel sustains was read from its waves' own cycle counters
+        # (profiles/<round>_fast800_clock.json): the same fractions against the peak at THAT clock, beside the ones above
+        try:
+            ck = json.load(open(os.path.join(ROOT, "profiles", "%s_fast800_clock.json" % PROFILE_ROUND)))
+            ghz = float(ck["sustained_clock_ghz"])
+            if plan.kernel_name == ck.get("kernel") and 0.5 < ghz <= float(ck.get("data_sheet_clock_ghz", 2.4)):
+                fv = result["roofline"]["fp64_valu"]
+                peak_at = FP64_VALU_PEAK_TFLOPS * ghz / float(ck.get("data_sheet_clock_ghz", 2.4))
+                fv["sustained_clock_ghz"] = ghz
+                fv["peak_tflops_at_sustained_clock"] = peak_at
+                fv["frac_at_sustained_clock"] = fv["achieved_tflops"] / peak_at
+                if "issued_tflops" in fv:
+                    fv["issued_frac_at_sustained_clock"] = fv["issued_tflops"] / peak_at
+                fv["clock_source"] = "not measured in this run: " + str(ck.get("source"))
+        except Exception:
+            pass
         if args.check:
             import paa_oracle as O
             # the buffer the last step wrote holds clip (k-1) % len(d_inputs); re-run clip 0 into d_out for the check

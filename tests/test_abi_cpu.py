@@ -373,6 +373,33 @@ def test_device_code_is_the_validated_one():
             "device code of the unit with %s differs from the GPU-validated record" % u["first_kernel"]
 
 
+def test_profile_records_the_bench_line_quotes_are_this_rounds():
+    """bench.py does not measure HBM traffic, the executed FP64 count or the sustained clock itself: it quotes the committed
+    records of this round's profiling passes and says so in the line.  The records exist, belong to bench.PROFILE_ROUND and
+    to the headline kernel / workload, carry the keys the line reads, and are consistent with each other (the FP64 fraction
+    at the sustained clock follows from the two files it is computed from)."""
+    import json
+    import bench
+    rnd = bench.PROFILE_ROUND
+    prof = os.path.join(ROOT, "profiles")
+    traffic = json.load(open(os.path.join(prof, "latest_traffic.json")))
+    assert traffic["round"] == rnd and traffic["kernel"] == "st_fast_800_w8" and traffic["rows"] == 34
+    assert traffic["frames"] == (3600 * bench.FS - bench.WINDOW) // bench.STEP + 1
+    algorithmic = (2 * bench.STEP + 8 * 34) * traffic["frames"]
+    assert 1.0 <= traffic["hbm_bytes_per_launch"] / algorithmic <= 1.10          # SURVEY 8d: traffic within 1.1x of the algorithmic bytes
+    assert os.path.exists(os.path.join(prof, traffic["source"].split(" ")[0]))
+    ex = json.load(open(os.path.join(prof, "%s_fast800_fp64_executed.json" % rnd)))
+    assert ex["frames"] == traffic["frames"] and ex["issued_fp64_flop_per_launch"] > 0
+    assert abs(ex["issued_kflop_per_frame"] * 1e3 * ex["frames"] - ex["issued_fp64_flop_per_launch"]) < 1e-6 * ex["issued_fp64_flop_per_launch"]
+    ck = json.load(open(os.path.join(prof, "%s_fast800_clock.json" % rnd)))
+    assert ck["kernel"] == "st_fast_800_w8" and 1.0 < ck["sustained_clock_ghz"] <= ck["data_sheet_clock_ghz"] == 2.4
+    assert os.path.exists(os.path.join(ROOT, ck["source"]))
+    # the clock is the waves' own cycles over their own life times
+    assert abs(ck["wave_cycles_median"] / (ck["wave_life_us_median"] * 1e3) - ck["sustained_clock_ghz"]) < 0.02
+    peak_at = bench.FP64_VALU_PEAK_TFLOPS * ck["sustained_clock_ghz"] / ck["data_sheet_clock_ghz"]
+    assert 0.25 < ex["issued_tflops"] / peak_at < 0.45
+
+
 @pytest.mark.parametrize("window", [2400, 2205, 1764, 1920, 1600, 1200, 1102, 551])
 def test_three_pass_tables_reproduce_the_fft(window):
     """Host tables of csrc/kernels_tri.hpp (no device): the three passes restated in NumPy FROM THE LIBRARY'S OWN TABLES --
