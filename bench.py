@@ -594,7 +594,7 @@ def main():
         try:
             ck = json.load(open(os.path.join(ROOT, "profiles", "%s_fast800_clock.json" % PROFILE_ROUND)))
             ghz = float(ck["sustained_clock_ghz"])
-            if plan.kernel_name == ck.get("kernel") and 0.5 < ghz <= float(ck.get("data_sheet_clock_ghz", 2.4)):
+            if plan.kernel_name == ck.get("kernel") and ck.get("frames") == int(frames) and 0.5 < ghz <= float(ck.get("data_sheet_clock_ghz", 2.4)):
                 fv = result["roofline"]["fp64_valu"]
                 peak_at = FP64_VALU_PEAK_TFLOPS * ghz / float(ck.get("data_sheet_clock_ghz", 2.4))
                 fv["sustained_clock_ghz"] = ghz

@@ -392,7 +392,7 @@ def test_profile_records_the_bench_line_quotes_are_this_rounds():
     assert ex["frames"] == traffic["frames"] and ex["issued_fp64_flop_per_launch"] > 0
     assert abs(ex["issued_kflop_per_frame"] * 1e3 * ex["frames"] - ex["issued_fp64_flop_per_launch"]) < 1e-6 * ex["issued_fp64_flop_per_launch"]
     ck = json.load(open(os.path.join(prof, "%s_fast800_clock.json" % rnd)))
-    assert ck["kernel"] == "st_fast_800_w8" and 1.0 < ck["sustained_clock_ghz"] <= ck["data_sheet_clock_ghz"] == 2.4
+    assert ck["kernel"] == "st_fast_800_w8" and ck["frames"] == traffic["frames"] and 1.0 < ck["sustained_clock_ghz"] <= ck["data_sheet_clock_ghz"] == 2.4
     assert os.path.exists(os.path.join(ROOT, ck["source"]))
     # the clock is the waves' own cycles over their own life times
     assert abs(ck["wave_cycles_median"] / (ck["wave_life_us_median"] * 1e3) - ck["sustained_clock_ghz"]) < 0.02
