@@ -49,7 +49,7 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6          # datasheet; informational only
 KFLOP_PER_FRAME = 45.0                # ~35-55 kflop of FP64 per 800/400 frame
 CFG4_TOTAL_CLIPS = 100000
-PROFILE_ROUND = "r04"                 # profiles/latest_traffic.json must come from this round's PMC pass of the headline
+PROFILE_ROUND = "r05"                 # profiles/latest_traffic.json must come from this round's PMC pass of the headline
                                       # kernel (scripts/profile.sh r04): an older file is reported, flagged traffic_stale
 XGMI_LINK_GBS = 76.8                  # one xGMI link, one direction (7 links into the root at N = 8)
 
@@ -255,6 +255,76 @@ def host_to_host(ffi, clip):
     return res
 
 
+def visible_devices():
+    """HIP devices this host shows, counted in a throw-away child (the launcher itself never loads the HIP runtime)."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); from pyaudioanalysis_amd import _ffi; _ffi.lib(); "
+            "print('DEVICES', _ffi.device_count())" % ROOT)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    for ln in res.stdout.splitlines():
+        if ln.startswith("DEVICES "):
+            return int(ln.split()[1])
+    raise SystemExit("bench.py: cannot count the HIP devices (libpaa_hip.so missing / not loadable?):\n%s%s" % (res.stdout, res.stderr))
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher's environment: spawn the N ranks here -- one process per GPU, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torchrun would, rank r on device r -- and wait for them; rank
+    0 prints the one JSON line on the stdout it inherits.  Fewer than N devices: a job with the RCCL gather cannot run (two
+    ranks on one device never leave ncclCommInitRank) and is refused HERE, loudly, with a non-zero exit -- the line never claims
+    GPUs that did not run; with --no-gather the ranks may share devices (what the one-GPU test box exercises: partitioning,
+    control plane, per-rank plans), and the line says which device every rank used (config.devices)."""
+    import socket
+    import subprocess
+    n = args.gpus
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    have = visible_devices()
+    if have < 1:
+        sys.stderr.write("bench.py: no HIP device visible (this bench has no CPU path)\n")
+        return 2
+    if have < n and not args.no_gather:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d HIP device(s) visible: the %d-rank job with the RCCL gather needs one "
+                         "device per rank; not running a smaller job under that name (use --no-gather to time the ranks' "
+                         "compute on shared devices)\n" % (n, have, n))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PAA_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n" % (r, code))
+                    for q in pending:
+                        procs[q].terminate()
+            time.sleep(0.1)
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+    return rc
+
+
+def compact(entry):
+    """[frames/s, ms per step, fraction of the HBM peak, kernel] of a config.others entry, four significant digits"""
+    def r4(v):
+        return float("%.4g" % v)
+    return [r4(entry["frames_per_s"]), r4(entry["ms_per_step"]), r4(entry["hbm_frac"]), entry["kernel"]]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,11 +353,16 @@ def main():
                          "first ~0.2 s of load; reported in the line)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # bare `python bench.py --gpus N`: no launcher exported RANK / WORLD_SIZE -- this process becomes the launcher
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the line would claim GPUs that did not run" % (args.gpus, world))
     workload = args.workload or ("cfg2" if world == 1 else "cfg4")
 
     group = None                        # control plane: TCP sockets on the launcher's environment (no torch)
@@ -315,6 +390,9 @@ def main():
     if _ffi.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     _ffi.init(local_rank % _ffi.device_count())
+    bus = ctypes.create_string_buffer(64)
+    _ffi.check(lib.paa_device_bus_id(bus, 64))
+    devices = group.all_gather(bus.value.decode()) if group else [bus.value.decode()]      # PCI bus id of every rank's device
 
     # ------------------------------------------------------------------ workload
     host_clip = None                    # rank 0 keeps what the spot check and the CPU baseline need
@@ -348,7 +426,11 @@ def main():
         scaling = "strong"
         job_clips = args.clips
 
-    plan = _ffi.Plan(offsets, FS, WINDOW, STEP, deltas=bool(args.deltas), sample_kind=0)
+    # N > 1 with the gather and 68 rows: every rank computes and ships the 34 BASE rows, rank 0 re-forms rows 34..67 on its device
+    # (paa_dev_expand_deltas: exact differences of consecutive columns, bit-identical to the 68-row kernel) -- half the bytes
+    # on the xGMI links into the root
+    ship_base = world > 1 and not args.no_gather and bool(args.deltas)
+    plan = _ffi.Plan(offsets, FS, WINDOW, STEP, deltas=bool(args.deltas) and not ship_base, sample_kind=0)
     F = plan.F
     frames = plan.total_frames
     d_out = _ffi.DeviceBuffer(plan.out_doubles * 8)
@@ -392,6 +474,21 @@ def main():
                 d_all = _ffi.DeviceBuffer(int(counts.sum()) * 8)
             ok = True
         gather = all(group.all_gather(ok))
+        if ship_base and not gather:         # no exchange after all: the ranks produce their 68 rows themselves
+            ship_base = False
+            plan.destroy()
+            plan = _ffi.Plan(offsets, FS, WINDOW, STEP, deltas=True, sample_kind=0)
+            F = plan.F
+            d_out = _ffi.DeviceBuffer(plan.out_doubles * 8)
+            d_out2 = _ffi.DeviceBuffer(plan.out_doubles * 8)
+    d_full = frames_job = None
+    if ship_base and rank == 0:
+        # frames of every clip of the job in rank order (contiguous clip ranges): the layout of the gathered base rows
+        per_clip = (10 * FS - WINDOW) // STEP + 1 if workload == "cfg4" else int(frames)
+        n_job = int(job_clips)
+        frames_job = np.full(n_job, per_clip, dtype=np.int64)
+        assert int(frames_job.sum()) * 34 == int(counts.sum())
+        d_full = _ffi.DeviceBuffer(2 * int(counts.sum()) * 8)
 
     bufs = [d_out, d_out2]
     state = {"k": 0}
@@ -404,6 +501,8 @@ def main():
         if gather:
             # runs on the library's communication stream; the next write of `buf` waits for it
             comm.gather(buf, counts, 0, d_all)
+            if d_full is not None:       # root: delta rows of the whole job, queued behind the gather on the communication stream
+                _ffi.check(lib.paa_dev_expand_deltas(d_all.ptr, _ffi.as_i64p(frames_job), len(frames_job), d_full.ptr))
 
     def device_sync():
         _ffi.sync()                      # both library streams (compute + communication): everything this process queued
@@ -514,8 +613,13 @@ def main():
             "dtype": "f64", "data": "synthetic (oracle/synth.py; SURVEY 8d seeds)",
             "config": {"workload": desc, "frames_per_step_job": int(total_frames),
                        "frames_per_step_rank0": int(frames), "clips_in_job": int(job_clips),
-                       "window": WINDOW, "step": STEP, "rows": F, "kernel": plan.kernel_name,
+                       "window": WINDOW, "step": STEP, "rows": 68 if args.deltas else 34, "kernel": plan.kernel_name,
+                       "rows_computed_per_rank": F,
                        "input_buffers_rotated": len(d_inputs),
+                       "devices": devices, "distinct_devices": len(set(devices)),
+                       "rccl_ranks": (world if comm is not None and gather else None),
+                       "launched_by": ("bench.py itself (no launcher environment)" if os.environ.get("PAA_BENCH_SELF_LAUNCHED")
+                                       else ("launcher environment (RANK / WORLD_SIZE)" if world > 1 else "single process")),
                        "multi_gpu": ("contiguous clip ranges per rank (partition_by_frames), RCCL gather of the slabs to "
                                      "rank 0 overlapped with the next step" if (gather and workload == "cfg4") else
                                      "one clip per rank, RCCL gather to rank 0" if gather else
@@ -528,6 +632,9 @@ def main():
                          "note": "path is FP64 VALU/LDS bound (about 40 flop/B); HBM fraction is reported as the "
                                  "metric asks, see DESIGN.md"},
         }
+        if ship_base:
+            result["config"]["gather_rows"] = ("34 base rows per frame travel; rank 0 re-forms rows 34..67 on its device "
+                                               "(paa_dev_expand_deltas) inside the timed region")
         if gather_note:
             result["config"]["gather_note"] = gather_note
         if value_no_gather is not None:
@@ -683,6 +790,20 @@ def main():
             result["cpu_baseline"] = cb
         elif not args.no_cpu_baseline:
             result["cpu_baseline"] = None
+        # every BASELINE configuration once more, compact and LAST in the line (what a truncated tail of the line keeps):
+        # name -> [frames/s, ms per step, fraction of the HBM peak (SURVEY 8d's algorithmic bytes), kernel]
+        configs = {workload + ("_job" if world > 1 else ""): [float("%.4g" % result["value"]), float("%.4g" % result["ms_per_step"]),
+                                                              float("%.4g" % result["roofline"]["frac"]), plan.kernel_name]}
+        others = result["config"].get("others") or {}
+        for key, e in others.items():
+            if isinstance(e, dict) and "frames_per_s" in e:
+                configs[key] = compact(e)
+        for key in ("cfg3", "cfg4_shard", "cfg5_features", "cfg5_spectrogram", "cfg5_chromagram"):
+            if key in configs:             # flat scalars beside the nested record
+                result["config"][key + "_frames_per_s"] = configs[key][0]
+                result["config"][key + "_hbm_frac"] = configs[key][2]
+        result["configs_columns"] = ["frames_per_s", "ms_per_step", "hbm_frac", "kernel"]
+        result["configs"] = configs
         print(json.dumps(result))
         sys.stdout.flush()
     if comm is not None:

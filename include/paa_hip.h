@@ -174,8 +174,18 @@ int paa_plan_mid_execute(paa_plan_t *plan, const double *d_st, int64_t mid_ratio
 /* MidTermFeatures.beat_extraction (MidTermFeatures.py:18-84) for every clip of an executed plan:
  * d_beat receives [n_clips][2] = (bpm, confidence); window_size = short-term step in seconds          */
 int paa_plan_beat_execute(paa_plan_t *plan, const double *d_st, double window_size, double *d_beat);
+/* the same for ONE short-term matrix in host memory (the reference's own signature, MidTermFeatures.py:18): feats is
+ * [n_rows][n_frames] feature-major (n_rows >= 19: rows 0..18 are read, :30-31); bpm_ratio receives (bpm, confidence) */
+int paa_beat_extraction_f64(const double *feats, int n_rows, int64_t n_frames, double window_size, double *bpm_ratio);
 /* name of the feature kernel the plan dispatches ("st_fast_800", "st_generic", ...)          */
 const char *paa_plan_kernel_name(const paa_plan_t *plan);
+
+/* delta rows re-formed on the device (ShortTermFeatures.py:668-680): d_base holds the [34][T_c] base-feature slabs of
+ * n_clips clips back to back (frames[c] = T_c, HOST array), d_out receives their [68][T_c] slabs back to back -- rows
+ * 34..67 are the differences of consecutive columns, column 0 zeros, bit-identical to what a 68-row plan stores.  A sharded
+ * job gathers the 34 base rows over xGMI and the root completes the matrices (half the bytes on the links).  Asynchronous:
+ * queued behind the gathers on the communication stream when a communicator exists, else on the library stream          */
+int paa_dev_expand_deltas(const double *d_base, const int64_t *frames, int64_t n_clips, double *d_out);
 
 /* ---- self-similarity matrix / music thumbnailing ----------------------------- */
 /* audioSegmentation.self_similarity_matrix (audioSegmentation.py:40-55): rows standardised like scikit-learn's

@@ -433,6 +433,55 @@ def music_thumbnailing(signal, sampling_rate, short_window=1.0, short_step=0.5, 
     return short_step * i1, short_step * i2, short_step * j1, short_step * j2, filt
 
 
+# ---- beat extraction (MidTermFeatures.py:18-84 + utilities.peakdet, utilities.py:33-102): checker of the GPU beat_kernel ----
+def _peak_positions(v, delta):
+    """Positions of the maxima of Billauer's peakdet (utilities.py:33-102): a maximum is recorded once the signal has dropped
+    by more than delta below the running maximum, a minimum once it rose by more than delta above the running minimum."""
+    peaks = []
+    lo, hi = np.inf, -np.inf
+    hi_pos = 0
+    seek_max = True
+    for k in range(len(v)):
+        cur = v[k]
+        if cur > hi:
+            hi, hi_pos = cur, k
+        if cur < lo:
+            lo = cur
+        if seek_max:
+            if cur < hi - delta:
+                peaks.append(hi_pos)
+                lo = cur
+                seek_max = False
+        elif cur > lo + delta:
+            hi, hi_pos = cur, k
+            seek_max = True
+    return peaks
+
+
+def beat_extraction(short_features, window_size):
+    """(bpm, confidence) of a short-term matrix, restating MidTermFeatures.py:18-84 (pinned on tests/golden/directory_small.npz)."""
+    rows = [0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18]      # :30-31
+    max_beat_time = int(round(2.0 / window_size))
+    hist_all = np.zeros((max_beat_time,))
+    n_frames = short_features.shape[1]
+    edges = np.arange(0.5, max_beat_time + 1.5)
+    for r in rows:
+        v = np.asarray(short_features[r, :])
+        with np.errstate(invalid="ignore"):
+            thr = 2.0 * (np.abs(v[0:-1] - v[1::])).mean() if n_frames > 1 else np.nan   # :37-38 (mean of nothing: NaN)
+        if thr <= 0:
+            thr = 0.0000000000000001
+        pos = _peak_positions(v, thr)
+        gaps = [pos[j + 1] - pos[j] for j in range(len(pos) - 1)]
+        counts, _ = np.histogram(gaps, edges)
+        hist_all += counts.astype(float) / n_frames
+    centers = (edges[0:-1] + edges[1::]) / 2.0
+    best = np.argmax(hist_all)
+    bpm = (60 / (centers * window_size))[best]
+    ratio = hist_all[best] / (hist_all.sum() + 0.00000001)                       # MidTermFeatures.py:13 eps
+    return bpm, ratio
+
+
 def ill_conditioned_mfcc_frames(signal, sampling_rate, window, step, factor=1e4):
     """Frames whose MFCCs the reference itself computes from FFT round-off.
 

@@ -1,9 +1,10 @@
 """Drop-in for pyAudioAnalysis.MidTermFeatures (reference: pyAudioAnalysis/MidTermFeatures.py).
 
 mid_feature_extraction (:87-127) and its batched many-clip form run on the GPU (HIP only, no CPU path).
-Around it, the host-side callers of SURVEY 8f-1/2: beat_extraction (:18-84, a sequential peak detector over
-18 short-term rows -- host NumPy) and the directory walkers (:140-309), which read the files on the host
-and push every int16 mono file of one sampling rate through ONE batched GPU call.
+Around it, the callers of SURVEY 8f-1/2: beat_extraction (:18-84, a sequential peak detector over 18 short-term rows:
+one wave of the GPU's beat_kernel, for a single matrix as for the batched walkers) and the directory walkers
+(:140-309), which read the files on the host and push every int16 mono file of one sampling rate through ONE batched
+GPU call.
 """
 import concurrent.futures
 import glob
@@ -107,63 +108,29 @@ def mid_feature_extraction_batch(signals, sampling_rate, mid_window, mid_step, s
 # ---------------------------------------------------------------------------------------------------------
 # beat extraction (reference :18-84 + utilities.peakdet, utilities.py:33-102)
 # ---------------------------------------------------------------------------------------------------------
-def _peak_positions(v, delta):
-    """Positions of the maxima of Billauer's peakdet: a maximum is recorded once the signal has dropped by more
-    than delta below the running maximum, a minimum once it rose by more than delta above the running minimum."""
-    peaks = []
-    lo, hi = np.inf, -np.inf
-    hi_pos = 0
-    seek_max = True
-    for k in range(len(v)):
-        cur = v[k]
-        if cur > hi:
-            hi, hi_pos = cur, k
-        if cur < lo:
-            lo = cur
-        if seek_max:
-            if cur < hi - delta:
-                peaks.append(hi_pos)
-                lo = cur
-                seek_max = False
-        elif cur > lo + delta:
-            hi, hi_pos = cur, k
-            seek_max = True
-    return peaks
-
-
 def beat_extraction(short_features, window_size, plot=False):
-    """Estimate of the beat rate of a musical signal (reference :18-84).
+    """Estimate of the beat rate of a musical signal (reference :18-84): per row of the 18 short-term rows (:30-31) a
+    threshold of twice the mean absolute difference, Billauer's peak detector (utilities.py:33-102), a histogram of the
+    gaps between successive maxima; the rows' histograms / T are summed, arg-max -> (bpm, confidence).
+
+    Runs on the GPU (beat_kernel through paa_beat_extraction_f64: one wave, lane r scans row r) -- the same kernel the
+    batched directory walkers run on matrices that never leave HBM.  `plot` is accepted and ignored (the reference opens
+    a matplotlib window with the histogram).
 
     ARGUMENTS: short_features (n_feats x numOfShortTermWindows), window_size = short-term step in seconds
     RETURNS:   bpm (beats per minute), ratio (confidence)
     """
-    rows = [0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18]      # :30-31
-    max_beat_time = int(round(2.0 / window_size))
-    hist_all = np.zeros((max_beat_time,))
-    n_frames = short_features.shape[1]
-    edges = np.arange(0.5, max_beat_time + 1.5)
-    for r in rows:
-        v = np.asarray(short_features[r, :])
-        thr = 2.0 * (np.abs(v[0:-1] - v[1::])).mean()                            # :37-38
-        if thr <= 0:
-            thr = 0.0000000000000001
-        pos = _peak_positions(v, thr)
-        gaps = [pos[j + 1] - pos[j] for j in range(len(pos) - 1)]
-        counts, _ = np.histogram(gaps, edges)
-        hist_all += counts.astype(float) / n_frames
-    centers = (edges[0:-1] + edges[1::]) / 2.0
-    best = np.argmax(hist_all)
-    bpms = 60 / (centers * window_size)
-    bpm = bpms[best]
-    ratio = hist_all[best] / (hist_all.sum() + eps)
-    if plot:
-        import matplotlib.pyplot as plt
-        keep = bpms < 500
-        plt.plot(bpms[keep], hist_all[keep], 'k')
-        plt.xlabel('Beats per minute')
-        plt.ylabel('Freq Count')
-        plt.show(block=True)
-    return bpm, ratio
+    feats = np.ascontiguousarray(short_features, dtype=np.float64)
+    if feats.ndim != 2:
+        raise ValueError("short_features must be a (n_feats, n_frames) matrix")
+    if feats.shape[0] < 19:
+        raise IndexError("index 18 is out of bounds for axis 0 with size %d" % feats.shape[0])      # :31 reads row 18
+    if feats.shape[1] < 1:
+        raise ValueError("short_features has no frames")
+    out = np.empty(2, dtype=np.float64)
+    _ffi.check(_ffi.lib().paa_beat_extraction_f64(_ffi.as_f64p(feats), feats.shape[0], feats.shape[1],
+                                                  float(window_size), _ffi.as_f64p(out)))
+    return out[0], out[1]
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -84,6 +84,8 @@ _SIGNATURES = {
     "paa_plan_mid_execute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "paa_plan_beat_execute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
     "paa_plan_kernel_name": (C.c_char_p, [C.c_void_p]),
+    "paa_beat_extraction_f64": (C.c_int, [c_f64p, C.c_int, C.c_int64, C.c_double, c_f64p]),
+    "paa_dev_expand_deltas": (C.c_int, [C.c_void_p, c_i64p, C.c_int64, C.c_void_p]),
     "paa_self_similarity_f64": (C.c_int, [c_f64p, C.c_int, C.c_int64, c_f64p]),
     "paa_dev_self_similarity": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
     "paa_thumbnail_rows": (C.c_int64, [C.c_int64, C.c_int]),

@@ -12,10 +12,12 @@ the job's environment, so a foreign listener on one of them is skipped, not join
 Trust model: the token keeps OTHER JOBS and stray listeners apart; it is not a credential -- address, port, world size and
 run id are guessable.  On a network where hosts outside the job can reach rank 0's ports, export the same PAA_RDZV_SECRET
 on every rank: it is mixed into the token (HMAC-SHA256), and a peer without it cannot claim a rank slot.  Rank 0 listens on
-MASTER_ADDR's interface only when that address is local (loopback for single-node jobs), and every handshake runs on its own
-thread with a 5 s budget, so a half-open connection cannot stall the accept loop.
+loopback only when MASTER_ADDR is a loopback literal (single-node jobs), on MASTER_ADDR's own interface when that is a
+non-loopback address of this host, and on all interfaces otherwise (_bind_hosts); every handshake runs on its own thread
+with a 5 s budget, so a half-open connection cannot stall the accept loop.
 """
 import base64
+import errno
 import hashlib
 import hmac
 import json
@@ -104,13 +106,36 @@ class SocketGroup:
             self._join(addr, port, deadline)
 
     # ---- connection set-up
+    @staticmethod
+    def _bind_hosts(addr):
+        """Interfaces rank 0 tries to listen on, in order.  MASTER_ADDR given as a loopback LITERAL (127.x.y.z, localhost)
+        declares a single-node job: every peer connects to that same literal, so loopback is enough and nothing off the node
+        can connect.  A NAME that merely resolves to loopback here (Debian / Ubuntu map the host's own name to 127.0.1.1 in
+        /etc/hosts) says nothing about where the peers are -- remote ranks resolve it to the real interface -- so all
+        interfaces are bound, as for a name that resolves elsewhere (NAT).  A non-loopback address of this host is bound
+        itself, with all interfaces as the fallback when it turns out not to be bindable here."""
+        literal = addr.strip().lower()
+        try:
+            packed = socket.inet_aton(literal)
+            is_literal_ip = literal.count(".") == 3
+        except OSError:
+            packed, is_literal_ip = None, False
+        if literal == "localhost" or (is_literal_ip and packed[0] == 127):
+            return ["127.0.0.1" if literal == "localhost" else literal]
+        try:
+            resolved = socket.gethostbyname(addr)
+        except OSError:
+            return [""]
+        if resolved.startswith("127."):
+            return [""]
+        return [resolved, ""]
+
     def _serve(self, addr, port, deadline):
         last = None
+        hosts = self._bind_hosts(addr)
         for cand in range(port + 1, port + 1 + _PORT_SPAN):
             srv = None
-            # MASTER_ADDR's own interface when it is an address of this host (127.0.0.1 for single-node jobs: nothing off the
-            # node can connect); all interfaces when it is not bindable here (a name that resolves elsewhere, NAT)
-            for host in (addr, ""):
+            for host in hosts:
                 srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
                 srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
                 try:
@@ -120,7 +145,7 @@ class SocketGroup:
                     last = exc
                     srv.close()
                     srv = None
-                    if getattr(exc, "errno", None) == 98:          # EADDRINUSE: the port is taken, try the next one
+                    if getattr(exc, "errno", None) == errno.EADDRINUSE:          # the port is taken, try the next one
                         break
             if srv is None:
                 continue

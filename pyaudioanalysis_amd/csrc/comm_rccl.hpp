@@ -79,12 +79,16 @@ int comm_scan_device(const std::string &stem, int rank) {
     if (DIR *dp = opendir(dir.c_str())) {
         while (struct dirent *de = readdir(dp)) {
             if (strncmp(de->d_name, stem.c_str(), stem.size()) != 0) continue;
+            if (strstr(de->d_name + stem.size(), ".tmp.")) continue;       // another rank's marker in the making (see comm_claim_device)
             const int other = atoi(de->d_name + stem.size());
             if (other == rank) continue;
             long pid = 0;
             const std::string path = dir + "/" + de->d_name;
             if (FILE *f = fopen(path.c_str(), "r")) { if (fscanf(f, "%ld", &pid) != 1) pid = 0; fclose(f); }
-            if (pid > 0 && (kill((pid_t)pid, 0) == 0 || errno == EPERM)) { clash = other + 1; break; }
+            // markers appear complete (link() of a finished temp file), so an empty or unparsable one is not ours to judge:
+            // it is neither a clash nor unlinked (unlinking a live rank's marker would hide the clash the guard exists for)
+            if (pid <= 0) continue;
+            if (kill((pid_t)pid, 0) == 0 || errno == EPERM) { clash = other + 1; break; }
             unlink(path.c_str());                                           // left behind by a process that is gone
         }
         closedir(dp);
@@ -103,12 +107,19 @@ int comm_claim_device(const void *id_bytes, int rank, const char *bus_id) {
     g_comm_marker = std::string(comm_tmp_dir()) + "/" + stem + std::to_string(rank);
     // (a world-writable directory: never follow a link someone planted, never truncate a file that is not ours)
     (void)unlink(g_comm_marker.c_str());                                  // a marker of an earlier run of this very rank
-    const int fd = open(g_comm_marker.c_str(), O_CREAT | O_EXCL | O_NOFOLLOW | O_WRONLY, 0600);
+    // the pid is written to a private temp name first and the finished file is link()ed to the marker name: a concurrent
+    // scan on another rank never reads a half-written marker (it would take pid 0 for "stale" -- advisor, round 4)
+    const std::string tmp = g_comm_marker + ".tmp." + std::to_string((long)getpid());
+    (void)unlink(tmp.c_str());
+    const int fd = open(tmp.c_str(), O_CREAT | O_EXCL | O_NOFOLLOW | O_WRONLY, 0600);
     if (fd < 0) { g_comm_marker.clear(); return 0; }                     // no writable tmp directory: no check possible
     char line[32];
     const int len = snprintf(line, sizeof(line), "%ld\n", (long)getpid());
-    if (write(fd, line, (size_t)len) != len) { close(fd); comm_release_device(); return 0; }
+    const bool written = write(fd, line, (size_t)len) == len;
     close(fd);
+    const bool linked = written && link(tmp.c_str(), g_comm_marker.c_str()) == 0;
+    (void)unlink(tmp.c_str());
+    if (!linked) { g_comm_marker.clear(); return 0; }
     static bool at_exit = false;
     if (!at_exit) { atexit(comm_release_device); at_exit = true; }
     int clash = comm_scan_device(stem, rank);
@@ -278,13 +289,38 @@ extern "C" int paa_comm_gather_f64(const double *d_send, const int64_t *counts, 
     return paa_comm_gatherv_f64(d_send, counts, displs.data(), root, d_recv);
 }
 
-// a freed buffer's event goes with it (every chunk piece of extract_sharded is a fresh allocation)
+// a freed buffer's events go with it (every chunk piece of extract_sharded is a fresh allocation; views into an allocation
+// -- restart-file pieces at an offset -- are keyed by their own address, so every key inside the allocation goes).  The
+// events are taken out of the map under g_mu and waited for WITHOUT it: a gather that waits for a slow or dead peer must not
+// stall every other thread's plan_build / plan_execute / gather behind the lock (advisor, round 4).
 static void comm_forget_buffer(const void *ptr) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_gather_done.find(ptr);
-    if (it == g_gather_done.end()) return;
-    if (it->second) { (void)hipEventSynchronize(it->second); (void)hipEventDestroy(it->second); }
-    g_gather_done.erase(it);
+    std::vector<hipEvent_t> gone;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_gather_done.empty()) return;
+        const char *lo = static_cast<const char *>(ptr), *hi = lo + 1;
+        void *base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange(&base, &size, const_cast<void *>(ptr)) == hipSuccess && base == ptr && size > 0) hi = lo + size;
+        else (void)hipGetLastError();
+        for (auto it = g_gather_done.begin(); it != g_gather_done.end();) {
+            const char *k = static_cast<const char *>(it->first);
+            if (k >= lo && k < hi) {
+                if (it->second) gone.push_back(it->second);
+                it = g_gather_done.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
+    for (hipEvent_t ev : gone) { (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); }
+}
+static hipStream_t comm_stream_or_null() { return g_comm ? g_comm_stream : nullptr; }
+// work queued on `s` (the communication stream) starts after everything queued so far on the compute stream (g_mu held)
+static int comm_order_after_compute(hipStream_t s) {
+    HIP_TRY(hipEventRecord(g_ev_ready, g_main_stream));
+    HIP_TRY(hipStreamWaitEvent(s, g_ev_ready, 0));
+    return PAA_OK;
 }
 // called by the kernels' entry points before they overwrite a caller's buffer (g_mu held)
 static int comm_wait_buffer_free(const void *d_out) {

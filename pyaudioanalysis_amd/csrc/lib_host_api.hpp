@@ -62,6 +62,9 @@ static int run_host_st(const void *packed, const int64_t *offsets, int64_t n_cli
         double *d_out = (double *)lane.l->out.p;
         const long long T = plan->clips[0].T;
         const int F = plan->P.F;
+        // every exit path -- an error return in the middle of the loops included -- waits for the copies already queued on the
+        // lane's copy stream: they write into the CALLER's buffer (plan_free_synced only waits for the compute stream)
+        struct CopyStreamGuard { hipStream_t s; ~CopyStreamGuard() { if (s) (void)hipStreamSynchronize(s); } } copy_guard{lane.l->copy_stream};
         {
             std::lock_guard<std::mutex> lk(g_mu);
             if ((rc = launch_stats(plan, d_samples))) return rc;
@@ -78,6 +81,8 @@ static int run_host_st(const void *packed, const int64_t *offsets, int64_t n_cli
             t_begin[used] = plan->tiles_host[(size_t)first].t0;
             {
                 std::lock_guard<std::mutex> lk(g_mu);
+                ProfScope prof_scope;          // (paa_prof_read counts the ranged launches like any other)
+                if ((rc = prof_scope.begin())) return rc;
                 rc = kFamilies[plan->family].launch(plan, d_samples, d_out, plan->d_tiles + first, last - first, cs());
             }
             if (rc) return fail(PAA_ERR_HIP, "launch of %s failed: %s", plan->kernel_name.c_str(), hipGetErrorString(hipGetLastError()));
@@ -302,6 +307,44 @@ extern "C" int paa_svm_binary_proba_f64(const double *feats, int n_dims, int64_t
                        d_coef, n_sv, intercept, gamma, prob_a, prob_b, (double *)lane.l->out.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(prob1, lane.l->out.p, (size_t)n_frames * 8, hipMemcpyDeviceToHost, cs()));
+    HIP_TRY(hipStreamSynchronize(cs()));
+    return PAA_OK;
+}
+
+// MidTermFeatures.beat_extraction (MidTermFeatures.py:18-84 + utilities.peakdet) of ONE short-term matrix in host memory:
+// feats [n_rows][n_frames] (rows 0..18 are read, :30-31), window_size = short-term step in seconds; bpm_ratio receives
+// (bpm, confidence).  The same beat_kernel the batched directory walkers run on matrices that never leave HBM.
+extern "C" int paa_beat_extraction_f64(const double *feats, int n_rows, int64_t n_frames, double window_size, double *bpm_ratio) {
+    if (!feats || !bpm_ratio) return fail(PAA_ERR_ARG, "null buffer");
+    if (n_rows < 19) return fail(PAA_ERR_ARG, "beat extraction reads short-term rows 0..18: %d rows given", n_rows);
+    if (n_frames < 1 || n_frames > 0x7fffffffLL) return fail(PAA_ERR_ARG, "n_frames=%lld", (long long)n_frames);
+    if (!(window_size > 0)) return fail(PAA_ERR_ARG, "window_size must be positive");
+    { const int rc0 = ensure_init(); if (rc0) return rc0; }
+    const int max_beat = (int)nearbyint(2.0 / window_size);          // int(round(2.0 / window_size)), :33
+    if (max_beat < 1 || max_beat > 4096) return fail(PAA_ERR_UNSUPPORTED, "beat histogram of %d bins", max_beat);
+    const size_t lds = (size_t)kBeatRows * (kBeatTile + 1) * 8 + (size_t)kBeatRows * max_beat * 4;
+    if (lds > 160 * 1024)
+        return fail(PAA_ERR_UNSUPPORTED, "beat histogram of %d bins needs %zu bytes of LDS (160 KB per workgroup)", max_beat, lds);
+    LaneGuard lane;
+    const size_t rows_bytes = (size_t)19 * (size_t)n_frames * 8;      // rows 0..18 are contiguous at the head of the matrix
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if ((rc = scratch_reserve(lane.l->in, rows_bytes))) return rc;
+        if ((rc = scratch_reserve(lane.l->mid, 256))) return rc;
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&beat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    ClipDev cd;
+    memset(&cd, 0, sizeof(cd));
+    cd.T = (int)n_frames;
+    unsigned char *small = reinterpret_cast<unsigned char *>(lane.l->mid.p);          // [ClipDev | pad | 2 doubles]
+    HIP_TRY(hipMemcpyAsync(lane.l->in.p, feats, rows_bytes, hipMemcpyHostToDevice, cs()));
+    HIP_TRY(hipMemcpyAsync(small, &cd, sizeof(cd), hipMemcpyHostToDevice, cs()));
+    hipLaunchKernelGGL(beat_kernel, dim3(1), dim3(64), lds, cs(), reinterpret_cast<const ClipDev *>(small),
+                       (const double *)lane.l->in.p, window_size, max_beat, reinterpret_cast<double *>(small + 128));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(bpm_ratio, small + 128, 16, hipMemcpyDeviceToHost, cs()));
     HIP_TRY(hipStreamSynchronize(cs()));
     return PAA_OK;
 }

@@ -364,6 +364,27 @@ static int run_big(paa_plan *p, const void *d_packed, double *d_out) {
     return PAA_OK;
 }
 
+// paa_prof_enable(n): every n-th feature-kernel launch is bracketed by an event pair on the calling thread's stream (g_mu held
+// by the caller); the closing event is recorded when the scope ends, i.e. right behind the launch
+struct ProfScope {
+    hipEvent_t stop = nullptr;
+    int begin() {
+        if (!(g_prof && (g_prof_seen++ % g_prof) == 0)) return PAA_OK;
+        if (g_prof_used == g_prof_ev.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            g_prof_ev.emplace_back(a, b);
+        }
+        const hipEvent_t start = g_prof_ev[g_prof_used].first;
+        stop = g_prof_ev[g_prof_used].second;
+        ++g_prof_used;
+        HIP_TRY(hipEventRecord(start, cs()));
+        return PAA_OK;
+    }
+    ~ProfScope() { if (stop) (void)hipEventRecord(stop, cs()); }
+};
+
 extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *d_out) {
     if (!plan || !d_packed || !d_out) return fail(PAA_ERR_ARG, "null plan / buffer");
     { const int rc_init = ensure_init(); if (rc_init) return rc_init; }
@@ -376,20 +397,8 @@ extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *
         return plan->sample_kind == 0 ? run_big<int16_t>(plan, d_packed, d_out)
              : plan->sample_kind == 2 ? run_big<stereo16>(plan, d_packed, d_out) : run_big<double>(plan, d_packed, d_out);
     if (plan->n_tiles == 0) return PAA_OK;
-    hipEvent_t pe0 = nullptr, pe1 = nullptr;
-    if (g_prof && (g_prof_seen++ % g_prof) == 0) {
-        if (g_prof_used == g_prof_ev.size()) {
-            hipEvent_t a, b;
-            HIP_TRY(hipEventCreate(&a));
-            HIP_TRY(hipEventCreate(&b));
-            g_prof_ev.emplace_back(a, b);
-        }
-        pe0 = g_prof_ev[g_prof_used].first;
-        pe1 = g_prof_ev[g_prof_used].second;
-        ++g_prof_used;
-        HIP_TRY(hipEventRecord(pe0, cs()));
-    }
-    struct StopEv { hipEvent_t e; ~StopEv() { if (e) (void)hipEventRecord(e, cs()); } } stop_ev{pe1};
+    ProfScope prof_scope;
+    { const int rc_p = prof_scope.begin(); if (rc_p) return rc_p; }
     if (plan->family < 0) return fail(PAA_ERR_UNSUPPORTED, "plan without a kernel family");
     rc = kFamilies[plan->family].launch(plan, d_packed, d_out, plan->d_tiles, plan->n_tiles, cs());
     if (rc) return fail(PAA_ERR_HIP, "launch of %s failed: %s", plan->kernel_name.c_str(), hipGetErrorString(hipGetLastError()));
@@ -490,6 +499,57 @@ extern "C" int paa_plan_beat_execute(paa_plan_t *plan, const double *d_st, doubl
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&beat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(beat_kernel, dim3((unsigned)plan->n_clips), dim3(64), lds, cs(), plan->d_clips, d_st,
                        window_size, max_beat, d_beat);
+    HIP_TRY(hipGetLastError());
+    return PAA_OK;
+}
+
+// [34][T_c] base slabs of n_clips clips, back to back -> [68][T_c] slabs back to back (delta rows re-formed on the device;
+// bit-identical to what a 68-row plan stores).  Queued behind everything on the communication stream when a communicator
+// exists (the slabs usually arrive through paa_comm_gatherv_f64), else on the library stream.  The tile list of the last
+// frames[] is kept (a sharded job expands the same batch shape step after step).
+struct DeltaPlanCache {
+    std::vector<int64_t> frames;
+    DeltaTile *d_tiles = nullptr;
+    long long n_tiles = 0;
+};
+static DeltaPlanCache g_delta_cache;
+static hipStream_t comm_stream_or_null();
+static int comm_order_after_compute(hipStream_t s);
+extern "C" int paa_dev_expand_deltas(const double *d_base, const int64_t *frames, int64_t n_clips, double *d_out) {
+    if (!d_base || !frames || !d_out || n_clips < 1) return fail(PAA_ERR_ARG, "null buffer / no clips");
+    if (d_base == d_out) return fail(PAA_ERR_ARG, "in-place expansion is not possible (rows move)");
+    { const int rc_init = ensure_init(); if (rc_init) return rc_init; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeltaPlanCache &dc = g_delta_cache;
+    if ((int64_t)dc.frames.size() != n_clips || memcmp(dc.frames.data(), frames, (size_t)n_clips * 8) != 0) {
+        constexpr int kTile = 2048;
+        std::vector<DeltaTile> tiles;
+        long long tot = 0;
+        for (int64_t c = 0; c < n_clips; ++c) {
+            const long long T = frames[c];
+            if (T < 0 || T > 0x7fffffffLL) return fail(PAA_ERR_ARG, "clip %lld: %lld frames", (long long)c, T);
+            for (long long t0 = 0; t0 < T; t0 += kTile) {
+                DeltaTile tl;
+                tl.base_off = (long long)kBase * tot; tl.out_off = 2LL * kBase * tot;
+                tl.T = (int)T; tl.t0 = (int)t0; tl.cnt = (int)std::min<long long>(kTile, T - t0); tl.pad = 0;
+                tiles.push_back(tl);
+            }
+            tot += T;
+        }
+        if (tiles.size() > 0x7fffffffULL) return fail(PAA_ERR_UNSUPPORTED, "too many tiles");
+        // (a launch that still reads the old list may be in flight on either stream)
+        if (cs()) HIP_TRY(hipStreamSynchronize(cs()));
+        { const int rc_s = comm_sync(); if (rc_s) return rc_s; }
+        const int rc = upload_pooled(&dc.d_tiles, tiles.data(), tiles.size());
+        if (rc) return rc;
+        dc.n_tiles = (long long)tiles.size();
+        dc.frames.assign(frames, frames + n_clips);
+    }
+    if (dc.n_tiles == 0) return PAA_OK;
+    hipStream_t s = comm_stream_or_null();
+    if (s) { const int rc_o = comm_order_after_compute(s); if (rc_o) return rc_o; }
+    else s = cs();
+    hipLaunchKernelGGL(expand_deltas_kernel, dim3((unsigned)dc.n_tiles), dim3(256), 0, s, dc.d_tiles, d_base, d_out);
     HIP_TRY(hipGetLastError());
     return PAA_OK;
 }

@@ -176,6 +176,12 @@ class HipEngine:
     def alloc(self, n_doubles):
         return _ffi.DeviceBuffer(max(int(n_doubles), 1) * 8)
 
+    def expand_deltas(self, d_base, frames, d_out):
+        """[34][T_c] base slabs back to back -> [68][T_c] slabs back to back (paa_dev_expand_deltas: the delta rows of
+        ShortTermFeatures.py:668-680 re-formed on the device, bit-identical to a 68-row plan's; queued behind the gathers)."""
+        frames = np.ascontiguousarray(frames, dtype=np.int64)
+        _ffi.check(_ffi.lib().paa_dev_expand_deltas(d_base.ptr, _ffi.as_i64p(frames), len(frames), d_out.ptr))
+
     def view(self, buf, offset_doubles, n_doubles):
         """The sub-range [offset, offset + n) of a device buffer as something gather() / to_host() accept."""
         return _DeviceView(buf, int(offset_doubles), int(n_doubles))
@@ -232,7 +238,8 @@ def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank
     engine: extract / extract_mid / alloc / view / to_host / upload / sync -- HipEngine (default) on the GPU.
     chunks: every rank cuts its range into this many contiguous pieces (balanced by frames); piece k is gathered on the
         communication stream while piece k+1 is uploaded and computed, and lands at its final place in the root's buffer.
-    gather: "short" -- the (F, T_c) short-term matrices (F = 68 with deltas, else 34);
+    gather: "short" -- the (F, T_c) short-term matrices (F = 68 with deltas, else 34); with deltas only the 34 base rows
+                       travel and the root re-forms the delta rows on its device (bit-identical, half the link bytes);
             "mid"   -- the (136, M_c) mid-term matrices of mid_feature_extraction(mid_window, mid_step in samples,
                        MidTermFeatures.py:87-127) and nothing else: 1/40 of the bytes at 1.0 s / 1.0 s over 50 / 25 ms.
     restart_dir: when given, every rank leaves its finished block there (shard_<rank>_of_<world>.npz, keyed by the
@@ -241,6 +248,7 @@ def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank
     Returns, on the root, the list of per-clip arrays for all clips (None elsewhere).
     """
     engine = engine or HipEngine()
+    base_only = False
     window, step = int(window), int(step)
     lengths = [len(c) for c in clips]
     frames = frames_per_clip(lengths, window, step)
@@ -255,7 +263,12 @@ def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank
             raise ValueError("mid_step / short_step rounds to 0: the reference never terminates")
         units, n_rows, what = mid_windows_per_clip(frames, mid_step_ratio), 136, ("mid", mid_ratio, mid_step_ratio)
     elif gather == "short":
-        units, n_rows, what = frames, (68 if deltas else 34), "short"
+        # with deltas the ranks compute and ship the 34 BASE rows only: rows 34..67 are exact differences of consecutive columns
+        # of rows 0..33 (ShortTermFeatures.py:668-680), so the root re-forms them on its device (engine.expand_deltas) -- half the
+        # bytes on the xGMI links, and the peers run the cheaper 34-row kernel.  An engine without expand_deltas ships all 68.
+        base_only = bool(deltas) and hasattr(engine, "expand_deltas")
+        units, n_rows = frames, (34 if (base_only or not deltas) else 68)
+        what = ("short", "base34") if base_only else "short"
     else:
         raise ValueError('gather must be "short" or "mid"')
     chunks = max(1, int(chunks))
@@ -302,7 +315,7 @@ def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank
         elif gather == "mid":
             d_piece = engine.extract_mid(mine[ca - a:cb - a], sampling_rate, window, step, mid_ratio, mid_step_ratio)
         else:
-            d_piece = engine.extract(mine[ca - a:cb - a], sampling_rate, window, step, deltas)
+            d_piece = engine.extract(mine[ca - a:cb - a], sampling_rate, window, step, bool(deltas) and not base_only)
         sent.append((d_piece, cnt))
         comm.gather(d_piece, np.array([pieces[r][k][2] for r in range(world_size)], dtype=np.int64), root, d_all,
                     np.array([pieces[r][k][3] for r in range(world_size)], dtype=np.int64))
@@ -315,8 +328,14 @@ def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank
         tmp = shard_file + ".tmp.npz"
         np.savez(tmp, key=np.array(key), block=np.concatenate(parts) if len(parts) > 1 else parts[0])
         os.replace(tmp, shard_file)
+    if rank == root and base_only:
+        d_full = engine.alloc(2 * int(counts.sum()))
+        engine.expand_deltas(d_all, frames, d_full)          # on the device, behind the gathers
+        d_all, n_rows, total = d_full, 68, 2 * int(counts.sum())
+    else:
+        total = int(counts.sum())
     engine.sync()
     if rank != root:
         return None
-    flat = engine.to_host(d_all, int(counts.sum()))
+    flat = engine.to_host(d_all, total)
     return split_gathered(flat, units, n_rows)

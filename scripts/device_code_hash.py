@@ -6,8 +6,8 @@ the hashes identify the DEVICE code a GPU run validated: a change that touches o
 code behind a switch that is off by default, must leave them as they are.
 
     python scripts/device_code_hash.py                                   # print
-    python scripts/device_code_hash.py --write profiles/r04_device_code.json --note "pytest -m gpu green at <commit>"
-    python scripts/device_code_hash.py --check profiles/r04_device_code.json
+    python scripts/device_code_hash.py --write profiles/r05_device_code.json --note "pytest -m gpu green at <commit>"
+    python scripts/device_code_hash.py --check profiles/r05_device_code.json
 
 scripts/gpu_round.sh records them after a green `pytest -m gpu`; tests/test_abi_cpu.py::test_device_code_is_the_validated_one
 compares the shipped binary with the record.
@@ -62,6 +62,20 @@ def kernels_in(image):
                 yield {"symbol": k[".name"]}
 
 
+def compiler_id():
+    """What built the library here: the machine code (and the register counts) are a function of the hipcc / LLVM version
+    and of PAA_HIPCC_FLAGS, so the records carry it and the tests that compare against them skip on another compiler."""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    try:
+        out = subprocess.run([hipcc, "--version"], capture_output=True, text=True, timeout=60).stdout.splitlines()
+    except Exception:
+        return None
+    keep = [ln.strip() for ln in out if ln.startswith("HIP version") or "clang version" in ln]
+    return " | ".join(keep + ["PAA_HIPCC_FLAGS=" + os.environ.get("PAA_HIPCC_FLAGS", "")]) if keep else None
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--lib", default=ru.LIB)
@@ -73,7 +87,8 @@ def main():
     if args.write:
         with open(args.write, "w") as f:
             json.dump({"what": "machine code of the gfx950 code objects inside pyaudioanalysis_amd/libpaa_hip.so "
-                               "(scripts/device_code_hash.py)", "note": args.note, "code_objects": units}, f, indent=1)
+                               "(scripts/device_code_hash.py)", "note": args.note, "compiler": compiler_id(),
+                       "code_objects": units}, f, indent=1)
             f.write("\n")
     for u in units:
         print("%8d  %s  %s  %3d kernels  %s" % (u["text_bytes"], u["text_sha256"][:16], u["rodata_sha256"][:8], u["kernels"],

@@ -8,7 +8,7 @@ registers, private segment (scratch) bytes per lane, static LDS bytes, and the w
 and decides their occupancy separately -- DESIGN 4).
 
     python scripts/resource_usage.py                      # table on stdout
-    python scripts/resource_usage.py --json profiles/r04_resource_usage.json
+    python scripts/resource_usage.py --json profiles/r05_resource_usage.json
 
 tests/test_abi_cpu.py::test_shipped_kernels_hold_their_register_budget asserts the claims DESIGN makes on these numbers.
 """
@@ -124,6 +124,17 @@ def kernels_of(path):
     return rows
 
 
+def compiler_id():
+    """hipcc / LLVM version + PAA_HIPCC_FLAGS of this host (the register counts are a function of them)"""
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    try:
+        out = subprocess.run([hipcc, "--version"], capture_output=True, text=True, timeout=60).stdout.splitlines()
+    except Exception:
+        return None
+    keep = [ln.strip() for ln in out if ln.startswith("HIP version") or "clang version" in ln]
+    return " | ".join(keep + ["PAA_HIPCC_FLAGS=" + os.environ.get("PAA_HIPCC_FLAGS", "")]) if keep else None
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--lib", default=LIB)
@@ -137,6 +148,7 @@ def main():
             "library_bytes": os.path.getsize(args.lib),
             "source": "NT_AMDGPU_METADATA notes of the gfx950 code objects inside the shipped library (scripts/resource_usage.py)",
             "kernels": len(rows),
+            "compiler": compiler_id(),
             "kernels_with_scratch": sorted(r["kernel"] for r in rows if r["scratch_bytes_per_lane"]),
             "kernels_with_agprs": sorted(r["kernel"] for r in rows if r["agpr"]),
             "kernels_with_vgpr_spills": sorted(r["kernel"] for r in rows if r["vgpr_spill"]),

@@ -15,7 +15,7 @@ from test_parity_gpu import assert_parity
 pytestmark = pytest.mark.gpu
 
 
-from checks import ill_mask, reference_matrix          # noqa: E402,F401  (shared with bench.py's --check leg)
+from checks import ill_info, reference_matrix          # noqa: E402,F401  (shared with bench.py's --check leg)
 
 
 def make_signal(kind, seed, seconds, fs):
@@ -84,7 +84,7 @@ def test_full_matrix_against_c_oracle(gpu_lib, fs, window, step, kind, seconds, 
     F, names = ShortTermFeatures.feature_extraction(sig, fs, window, step, deltas)
     ref = reference_matrix(mono, fs, window, step, deltas)
     assert F.shape == ref.shape and len(names) == ref.shape[0]
-    assert_parity(F, ref, "%s %d/%d @%d" % (kind, window, step, fs), ill=ill_mask(mono, fs, window, step))
+    assert_parity(F, ref, "%s %d/%d @%d" % (kind, window, step, fs), ill=ill_info(mono, fs, window, step))
     if deltas:
         assert np.array_equal(F[34:, 1:], F[:34, 1:] - F[:34, :-1]) and np.all(F[34:, 0] == 0.0)
         G, _ = ShortTermFeatures.feature_extraction(sig, fs, window, step, False)
@@ -138,7 +138,7 @@ def test_ragged_batches_and_mid_term_through_the_family(gpu_lib):
     for c, r in zip(clips, res):
         single, _ = ShortTermFeatures.feature_extraction(c, fs, W, S)
         assert np.array_equal(single, r)
-        assert_parity(r, reference_matrix(c, fs, W, S, True), "ragged batch", ill=ill_mask(c, fs, W, S))
+        assert_parity(r, reference_matrix(c, fs, W, S, True), "ragged batch", ill=ill_info(c, fs, W, S))
     # float64 clips batch too (what the directory walkers do with stereo / non-int16 files)
     fclips = [O.stereo_to_mono(synth_clip(8700 + i, n, fs, stereo=True)) for i, n in enumerate(lens[1:5])]
     fres, _ = ShortTermFeatures.feature_extraction_batch(fclips, fs, 800, 400, deltas=True)

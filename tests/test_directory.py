@@ -1,4 +1,4 @@
-"""beat extraction (host) and the directory walkers (host I/O + batched GPU mid-term path),
+"""beat extraction (GPU beat_kernel; the host restatement is the oracle's) and the directory walkers (host I/O + batched GPU mid-term path),
 against outputs of the unmodified reference stored in tests/golden/directory_small.npz."""
 import os
 
@@ -16,16 +16,37 @@ def _golden():
         return {k: z[k] for k in z.files}
 
 
-def test_beat_extraction_matches_reference_on_oracle_features():
-    """CPU: the short-term matrix comes from the oracle (pinned to the reference), so this isolates beat_extraction."""
+def test_oracle_beat_extraction_matches_reference():
+    """CPU: the checker's restatement of beat_extraction (oracle/paa_oracle.py) on oracle features (pinned to the reference)
+    against the values the unmodified reference returned (golden)."""
     g = _golden()
     x = g["beat_signal"]
     st, _ = O.feature_extraction(x, 16000, 800, 800)
-    bpm, ratio = MidTermFeatures.beat_extraction(st, 0.05)
-    assert np.allclose([bpm, ratio], g["beat_050"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(O.beat_extraction(st, 0.05), g["beat_050"], rtol=1e-9, atol=1e-12)
     st, _ = O.feature_extraction(x, 16000, 800, 400)
-    bpm, ratio = MidTermFeatures.beat_extraction(st, 0.025)
-    assert np.allclose([bpm, ratio], g["beat_025"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(O.beat_extraction(st, 0.025), g["beat_025"], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_gpu_beat_kernel_matches_reference_values(gpu_lib):
+    """beat_kernel DIRECTLY against the unmodified reference: the golden holds what
+    MidTermFeatures.beat_extraction of the reference returned for this signal at 50 ms / 50 ms and 50 ms / 25 ms; both the
+    public beat_extraction() (one matrix: paa_beat_extraction_f64) and the batched walkers' path (paa_plan_beat_execute on
+    matrices that stay in HBM) must reproduce them -- from GPU short-term features and from the oracle's."""
+    from pyaudioanalysis_amd import ShortTermFeatures
+    g = _golden()
+    x = g["beat_signal"]
+    for ws, step, key in ((0.05, 800, "beat_050"), (0.025, 400, "beat_025")):
+        st, _ = ShortTermFeatures.feature_extraction(x, 16000, 800, step)
+        assert np.allclose(MidTermFeatures.beat_extraction(st, ws), g[key], rtol=1e-9, atol=1e-12)
+        st_ref, _ = O.feature_extraction(x, 16000, 800, step)
+        assert np.allclose(MidTermFeatures.beat_extraction(st_ref, ws), g[key], rtol=1e-9, atol=1e-12)
+        _, beats = MidTermFeatures.mid_and_beat_batch([x, x[:len(x) // 2]], 16000, 16000, 16000, 800, step,
+                                                      beat_window_seconds=ws)
+        assert np.allclose(beats[0], g[key], rtol=1e-9, atol=1e-12)
+    # the reference's failure modes of the public function
+    with pytest.raises(IndexError):
+        MidTermFeatures.beat_extraction(np.zeros((18, 50)), 0.05)
 
 
 def _write_dir(g, d):
@@ -72,8 +93,9 @@ def test_directory_feature_extraction_matches_reference(gpu_lib, tmp_path, capsy
 
 
 @pytest.mark.gpu
-def test_gpu_beat_kernel_equals_host_beat_extraction(gpu_lib):
-    """The beat kernel (one wave per clip) against the host restatement on the same GPU short-term features."""
+def test_gpu_beat_kernel_equals_oracle_beat_extraction(gpu_lib):
+    """The beat kernel (one wave per clip, batched and single-matrix entry points) against the checker's restatement
+    (oracle/paa_oracle.py, pinned to the reference) on the same GPU short-term features: long, short and one-frame clips."""
     from pyaudioanalysis_amd import ShortTermFeatures
     from synth import synth_clip
     clips = [synth_clip(60 + k, n) for k, n in enumerate([160000, 48000, 16000, 800, 20000])]
@@ -81,8 +103,9 @@ def test_gpu_beat_kernel_equals_host_beat_extraction(gpu_lib):
         mids, beats = MidTermFeatures.mid_and_beat_batch(clips, 16000, 16000, 16000, 800, step, beat_window_seconds=ws)
         for c, b in zip(clips, beats):
             st, _ = ShortTermFeatures.feature_extraction(c, 16000, 800, step)
-            bpm, ratio = MidTermFeatures.beat_extraction(st, ws)
+            bpm, ratio = O.beat_extraction(st, ws)
             assert np.allclose(b, [bpm, ratio], rtol=1e-9, atol=1e-12), (ws, len(c), b, bpm, ratio)
+            assert np.allclose(MidTermFeatures.beat_extraction(st, ws), [bpm, ratio], rtol=1e-9, atol=1e-12)
 
 
 @pytest.mark.gpu

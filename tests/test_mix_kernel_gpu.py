@@ -8,7 +8,7 @@ import c_oracle
 import paa_oracle as O
 from pyaudioanalysis_amd import ShortTermFeatures, _ffi
 from synth import synth_clip
-from test_ct_kernels_gpu import ill_mask, make_signal, reference_matrix
+from test_ct_kernels_gpu import ill_info, make_signal, reference_matrix
 from test_parity_gpu import assert_parity
 
 pytestmark = pytest.mark.gpu
@@ -76,7 +76,7 @@ def test_full_matrix_against_c_oracle(gpu_lib, fs, window, step, kind, seconds, 
     F, names = ShortTermFeatures.feature_extraction(sig, fs, window, step, deltas)
     ref = reference_matrix(mono, fs, window, step, deltas)
     assert F.shape == ref.shape and len(names) == ref.shape[0]
-    assert_parity(F, ref, "%s %d/%d @%d" % (kind, window, step, fs), ill=ill_mask(mono, fs, window, step))
+    assert_parity(F, ref, "%s %d/%d @%d" % (kind, window, step, fs), ill=ill_info(mono, fs, window, step))
     if deltas:
         assert np.array_equal(F[34:, 1:], F[:34, 1:] - F[:34, :-1]) and np.all(F[34:, 0] == 0.0)
         G, _ = ShortTermFeatures.feature_extraction(sig, fs, window, step, False)
@@ -126,7 +126,7 @@ def test_degenerate_clips_and_ragged_batches(gpu_lib):
     for c, r in zip(clips, res):
         single, _ = ShortTermFeatures.feature_extraction(c, fs, W, S)
         assert np.array_equal(single, r)
-        assert_parity(r, reference_matrix(c, fs, W, S, True), "ragged batch", ill=ill_mask(c, fs, W, S))
+        assert_parity(r, reference_matrix(c, fs, W, S, True), "ragged batch", ill=ill_info(c, fs, W, S))
 
 
 @pytest.mark.parametrize("fs,window,step,kind", [(44100, 2205, 1102, "i16"), (44100, 1102, 441, "stereo"), (44100, 1102, 441, "i16"),
@@ -156,6 +156,6 @@ def test_samples_that_sit_on_a_whole_number_mean(gpu_lib, fs, window, step, kind
     assert float(np.mean(np.double(mono) * (2.0 if kind != "i16" else 1.0))) in (-7.0, 13.0)
     F, _ = ShortTermFeatures.feature_extraction(sig, fs, window, step, False)
     ref = reference_matrix(mono, fs, window, step, False)
-    assert_parity(F, ref, "whole mean %s %d/%d" % (kind, window, step), ill=ill_mask(mono, fs, window, step))
+    assert_parity(F, ref, "whole mean %s %d/%d" % (kind, window, step), ill=ill_info(mono, fs, window, step))
     counts = lambda row: np.rint(row * 2.0 * (window - 1))        # zcr = sum |diff(sign)| / 2 / (W - 1): whole numbers
     assert np.array_equal(counts(F[0]), counts(ref[0])) and np.abs(F[0] * 2.0 * (window - 1) - counts(F[0])).max() < 1e-6

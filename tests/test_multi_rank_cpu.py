@@ -55,6 +55,20 @@ class _OracleEngine:
     def alloc(self, n_doubles):
         return _HostBuf(np.zeros(max(int(n_doubles), 1)))
 
+    def expand_deltas(self, d_base, frames, d_out):
+        """what paa_dev_expand_deltas does on the GPU: [34][T] base slabs -> [68][T] slabs, delta column 0 = zeros"""
+        self.expand_calls = getattr(self, "expand_calls", 0) + 1
+        pos_b = pos_o = 0
+        for t in np.asarray(frames, dtype=np.int64):
+            t = int(t)
+            b = d_base.arr[pos_b:pos_b + 34 * t].reshape(34, t)
+            o = d_out.arr[pos_o:pos_o + 68 * t].reshape(68, t)
+            o[:34] = b
+            o[34:, 0] = 0.0
+            o[34:, 1:] = b[:, 1:] - b[:, :-1]
+            pos_b += 34 * t
+            pos_o += 68 * t
+
     def view(self, buf, offset_doubles, n_doubles):
         return _HostBuf(buf.arr[int(offset_doubles):int(offset_doubles) + int(n_doubles)])
 
@@ -114,7 +128,7 @@ def _worker(rank, world, port, q, rdir):
     try:
         lens = [4000, 1600, 9000, 800, 5200, 2500, 7000]
         clips = [synth_clip(900 + i, n) for i, n in enumerate(lens)]
-        W, S, F = 800, 400, 68
+        W, S, F = 800, 400, 34          # rows on the wire: with deltas the ranks ship the 34 base rows, the root re-forms the rest
         frames = D.frames_per_clip(lens, W, S)
         ranges = D.partition_by_frames(frames, world)
         counts = D.block_counts(frames, ranges, F)
@@ -179,7 +193,7 @@ def test_world_size_2_gather_roundtrip(tmp_path):
         assert p.exitcode == 0
     assert status == "ok"
     assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == 7
-    assert sum(counts) == 68 * int(sum((n - 800) // 400 + 1 for n in [4000, 1600, 9000, 800, 5200, 2500, 7000]))
+    assert sum(counts) == 34 * int(sum((n - 800) // 400 + 1 for n in [4000, 1600, 9000, 800, 5200, 2500, 7000]))
 
 
 def test_partition_properties():
@@ -250,6 +264,27 @@ def test_socket_control_plane_world_3():
     assert got == [(0, True), (1, True), (2, True)]
 
 
+def test_rank0_listener_interfaces(monkeypatch):
+    """Where rank 0 of the control plane listens (advisor, round 4): a loopback LITERAL means a single-node job and binds
+    loopback only; the host's own NAME resolving to loopback (Debian's 127.0.1.1 line in /etc/hosts) must NOT pin the listener to
+    loopback -- remote ranks resolve that name to the real interface -- so all interfaces are bound; a routable address is
+    tried itself first, all interfaces after it; an unresolvable name binds all interfaces."""
+    from pyaudioanalysis_amd import _rendezvous as R
+    hosts = R.SocketGroup._bind_hosts
+    assert hosts("127.0.0.1") == ["127.0.0.1"]
+    assert hosts("127.0.1.1") == ["127.0.1.1"]
+    assert hosts("localhost") == ["127.0.0.1"]
+    monkeypatch.setattr(R.socket, "gethostbyname", lambda name: {"node7": "127.0.1.1", "node8": "10.1.2.3"}.get(name, name))
+    assert hosts("node7") == [""]
+    assert hosts("node8") == ["10.1.2.3", ""]
+    assert hosts("10.1.2.3") == ["10.1.2.3", ""]
+
+    def boom(name):
+        raise OSError("no such host")
+    monkeypatch.setattr(R.socket, "gethostbyname", boom)
+    assert hosts("elsewhere.example") == [""]
+
+
 def test_restart_shard_is_on_disk_while_the_exchange_is_still_blocked(tmp_path):
     """A rank whose peer died in the exchange never gets out of the communication stream.  Its finished block must be on
     disk by then: extract_sharded saves the pieces through the engine's compute-stream-only copy (to_host_source ->
@@ -310,7 +345,8 @@ def test_restart_shard_is_on_disk_while_the_exchange_is_still_blocked(tmp_path):
     with np.load(shard, allow_pickle=False) as z:
         frames = D.frames_per_clip([len(c) for c in clips], 800, 400)
         a, b = D.partition_by_frames(frames, 2)[1]
-        want = np.concatenate([O.feature_extraction(c, 16000, 800, 400, True)[0].reshape(-1) for c in clips[a:b]])
+        # (with deltas the rank ships -- and saves -- its 34 base rows; the root re-forms rows 34..67)
+        want = np.concatenate([O.feature_extraction(c, 16000, 800, 400, False)[0].reshape(-1) for c in clips[a:b]])
         assert np.array_equal(z["block"], want)
     exchange_done.set()
     th.join(30)

@@ -182,3 +182,53 @@ def test_bench_n2_socket_control_plane_without_rccl(gpu_lib, tmp_path):
     assert line["config"]["clips_in_job"] == 2000 and line["config"]["frames_per_step_job"] == 2000 * 399
     assert line["config"]["frames_per_step_rank0"] == 1000 * 399
     assert line["parity_check"]["status"] == "ok", line["parity_check"]
+
+
+def _run_bare_bench(extra, timeout=420):
+    """`python bench.py --gpus 2 ...` with NO launcher environment (RANK / WORLD_SIZE / MASTER_* removed): bench.py must spawn its
+    own ranks.  -> (returncode, stdout, stderr)"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--clips", "2000", "--steps", "5", "--warmup", "2",
+           "--prewarm-seconds", "0", "--no-cpu-baseline"] + extra
+    try:
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        pytest.fail("bare bench.py --gpus 2 %s did not finish within %d s" % (" ".join(extra), timeout))
+    return res.returncode, res.stdout, res.stderr
+
+
+def test_bare_bench_gpus_2_launches_its_own_ranks(gpu_lib):
+    """`python bench.py --gpus 2 --no-gather` as the driver runs N = 1 (no RANK / WORLD_SIZE in the
+    environment) becomes a two-rank run by itself and says so: n_gpus = 2, one JSON line, the device of every rank in
+    config.devices, config.rccl_ranks = null (no exchange asked for), the compact `configs` object last in the line."""
+    import json
+    rc, out, err = _run_bare_bench(["--no-gather"])
+    assert rc == 0, err[-1500:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-1500:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["frames_per_step_job"] == 2000 * 399 and line["config"]["frames_per_step_rank0"] == 1000 * 399
+    assert len(line["config"]["devices"]) == 2 and line["config"]["rccl_ranks"] is None
+    assert "bench.py itself" in line["config"]["launched_by"]
+    assert line["parity_check"]["status"] == "ok", line["parity_check"]
+    assert list(line)[-1] == "configs" and "cfg4_job" in line["configs"]
+
+
+def test_bare_bench_gpus_2_with_the_gather_runs_rccl_or_refuses_loudly(gpu_lib):
+    """The same with the RCCL gather.  Two devices: a real two-rank job (config.rccl_ranks = 2, two distinct devices).  One
+    device (the usual test box): refused before any rank starts -- non-zero exit, a message that names the device count, and NO
+    JSON line (never `n_gpus: 1` under a `--gpus 2` command)."""
+    import json
+    from pyaudioanalysis_amd import _ffi
+    rc, out, err = _run_bare_bench([])
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if _ffi.device_count() >= 2:
+        assert rc == 0, err[-1500:]
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["config"]["distinct_devices"] == 2
+        assert line["parity_check"]["status"] == "ok"
+    else:
+        assert rc != 0 and not lines, (rc, out[-800:])
+        assert "--gpus 2" in err and "1 HIP device(s) visible" in err, err[-800:]

@@ -110,8 +110,8 @@ def test_config5_spectrogram_chromagram_600s(gpu_lib, cfg5_clip, capsys):
 # full-matrix checks at BASELINE sizes against the plain-C oracle (oracle/paa_oracle.c: ~45 k frames/s on one core)
 # ---------------------------------------------------------------------------------------------------------
 def _ill_mask(signal, fs, window, step):
-    from test_ct_kernels_gpu import ill_mask
-    return ill_mask(signal, fs, window, step)
+    from test_ct_kernels_gpu import ill_info
+    return ill_info(signal, fs, window, step)
 
 
 def _reference_matrix(mono, fs, window, step, deltas):

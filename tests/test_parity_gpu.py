@@ -8,7 +8,10 @@ Two gates, both applied by assert_parity():
   |d| <= 1e-9*|ref| + 1e-10*scale(row) + 1e-12, where a delta row inherits the scale of its base row (a delta is a
   difference of two base values, so its error lives on the base row's scale) and the 13 MFCC rows share one scale.
   Two documented exceptions, both places where the REFERENCE's own value is a function of round-off:
-  (i) MFCC rows of the frames paa_oracle.ill_conditioned_mfcc_frames flags (log10 of an empty mel band);
+  (i) MFCC rows of the frames paa_oracle.ill_conditioned_mfcc_frames flags (log10 of an empty mel band) -- a BOUNDED
+  exception: the flagged frames are the digitally silent ones (whose MFCCs are then held to the analytic vector at 1e-9,
+  checks.silent_mfcc) plus at most 1e-3 of the frames (checks.IllInfo.budget_ok; a test built on an ill-conditioned input
+  states its own allowance);
   (ii) spectral spread (:80) is the square root of a cancelling sum: on digitally silent frames the reference itself
   returns sqrt(round-off ~1e-17) ~ 3e-9 (oracle/paa_oracle.c differs from it by as much), so rows 4 / 38 get
   1e-7*scale.
@@ -72,15 +75,37 @@ def tight_violations(got, ref, ill=None):
     return int(bad.sum()), bad
 
 
-def assert_parity(got, ref, what="", ill=None, tight=True, sig=None):
-    """sig = (signal, fs, window, step): derive the ill-conditioned-frame mask from the input.
-    ill: optional bool mask of frames whose MFCCs are round-off-determined in the reference itself
+def _exact_zero_kernel(fs, window, step):
+    """True when the kernel family that takes this window keeps the exact-zero property of DESIGN section 2 (a digitally silent
+    frame's spectrum is exactly [2|c|, 0, 0, ...]): every family but the Stockham kernels (st_generic, the big-window passes)."""
+    plan = _ffi.Plan(np.array([0, 4 * int(window) + 4 * int(step)], dtype=np.int64), fs, int(window), int(step), deltas=False)
+    name = plan.kernel_name
+    plan.destroy()
+    return not ("generic" in name or "big" in name)
+
+
+def assert_parity(got, ref, what="", ill=None, tight=True, sig=None, max_other_share=1e-3, max_other_abs=0):
+    """sig = (signal, fs, window, step): derive the ill-conditioned-frame information from the input (checks.ill_info).
+    ill: a checks.IllInfo, or a plain bool mask of frames whose MFCCs are round-off-determined in the reference itself
     (paa_oracle.ill_conditioned_mfcc_frames); there the MFCC rows get 1e-5 of the group scale (contract) and are
-    exempt from the tight gate."""
+    exempt from the tight gate.  That exception is BOUNDED: with an IllInfo, flagged frames that are not
+    explained by digital silence may be at most max(max_other_abs, max_other_share x frames) -- tests whose input is built
+    to be ill-conditioned say so -- and the MFCC rows of the digitally silent frames themselves are held to the analytic
+    vector (checks.silent_mfcc) at 1e-9 on every kernel that produces exact zeros for them."""
     assert got.shape == ref.shape, (got.shape, ref.shape)
     assert got.dtype == np.float64 and got.flags["C_CONTIGUOUS"]
     if ill is None and sig is not None:
-        ill = O.ill_conditioned_mfcc_frames(*sig)
+        ill = checks.ill_info(*sig)
+    info = ill if isinstance(ill, checks.IllInfo) else None
+    if info is not None:
+        ill = info.mask
+        if ref.ndim == 2 and ref.shape[0] in (34, 68) and ref.shape[1] == len(info.mask):
+            assert info.budget_ok(max_other_share, max_other_abs), \
+                "%s: the 1e-5 MFCC exception would cover %s (allowed: %g of the frames / %d)" % (
+                    what, info.counts(), max_other_share, max_other_abs)
+            if info.silent.any() and (sig is None or _exact_zero_kernel(*sig[1:4])):
+                nsil = checks.silent_mfcc_violations(got, info)
+                assert nsil == 0, "%s: %d MFCC entries of digitally silent frames differ from the analytic value" % (what, nsil)
     nbad, bad = checks.contract_violations(got, ref, ill)
     if nbad:
         idx = np.argwhere(bad)[:8]
@@ -100,8 +125,10 @@ def test_short_term_golden(gpu_lib, path):
     g = load_golden(path)
     F, names = ShortTermFeatures.feature_extraction(g["signal"], g["fs"], g["window"], g["step"], g["deltas"])
     assert names == [str(s) for s in g["names"]]
-    ill = O.ill_conditioned_mfcc_frames(g["signal"], g["fs"], g["window"], g["step"])
-    assert_parity(F, g["features"], golden_id(path), ill)
+    mono = O.stereo_to_mono(g["signal"]) if g["signal"].ndim == 2 else g["signal"]
+    # quarter_tone_with_zeros is BUILT to be ill-conditioned (a tone exactly on an FFT bin: every other band holds round-off only)
+    share = 1.0 if golden_id(path) == "quarter_tone_with_zeros" else 1e-3
+    assert_parity(F, g["features"], golden_id(path), sig=(mono, g["fs"], g["window"], g["step"]), max_other_share=share)
 
 
 @pytest.mark.parametrize("path", golden_files("mid"), ids=golden_id)
@@ -238,13 +265,17 @@ def test_size_independent_properties_at_scale(gpu_lib, minutes):
     # SAME normalisation constants -> use the oracle on a few frame ranges with the clip-global constants
     xn = O.normalize_clip(x)
     tab = O.Tables(fs, W)
+    # (the contract exactly as assert_parity applies it: the row term is 1e-6 of the ROW's scale over the whole clip -- the 13 MFCC
+    # rows share one -- not of the one column that is compared here)
+    scale = np.max(np.abs(F[:34]), axis=1)
+    scale[O.MFCC_ROWS] = scale[O.MFCC_ROWS].max()
     for t in (0, 1, 31, 32, 33, 5000, T - 1):
         fr = xn[t * S:t * S + W]
         X = O.magnitude_spectrum(fr, tab.nfft)
         Xp = X if t == 0 else O.magnitude_spectrum(xn[(t - 1) * S:(t - 1) * S + W], tab.nfft)
         v = O.frame_vector(fr, X, Xp, tab)
-        nbad, _ = O.mixed_tolerance_violations(F[:34, t:t + 1], v[:, None], REL, ROW * 10, 1e-8)
-        assert nbad == 0, "frame %d" % t
+        bad = np.abs(F[:34, t] - v) > REL * np.abs(v) + ROW * scale + FLOOR
+        assert not bad.any(), "frame %d rows %s" % (t, np.flatnonzero(bad))
     # periodicity: the clip is 10 repeats of a 60 s block and 60 s is a multiple of the step, so
     # frames one period apart see identical samples and identical clip constants
     per = 60 * fs // S
@@ -280,6 +311,37 @@ def test_rccl_gather_world_size_1(gpu_lib):
             assert np.array_equal(mid, m)
     finally:
         comm.close()
+
+
+def test_delta_rows_reformed_on_the_device_equal_the_68_row_plan(gpu_lib):
+    """paa_dev_expand_deltas: [34][T_c] base slabs -> [68][T_c] slabs, bit for bit what a 68-row plan stores (what lets a
+    sharded job ship the 34 base rows only, ShortTermFeatures.py:668-680) -- clips of 1 frame, of a few frames, of more than one
+    2048-frame tile, two window families; and a second call with another batch shape (the cached tile list is rebuilt)."""
+    from pyaudioanalysis_amd import _ffi
+    for fs, W, S, lens in ((16000, 800, 400, [800, 1200, 16000, 400 * 5000 + 800, 2400]), (44100, 2205, 1102, [2205, 44100 * 3])):
+        clips = [synth_clip(8100 + i, n, fs) for i, n in enumerate(lens)]
+        offs = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+        d_in = _ffi.DeviceBuffer.from_host(np.concatenate(clips))
+        p34 = _ffi.Plan(offs, fs, W, S, deltas=False)
+        p68 = _ffi.Plan(offs, fs, W, S, deltas=True)
+        d34 = _ffi.DeviceBuffer(p34.out_doubles * 8)
+        d68 = _ffi.DeviceBuffer(p68.out_doubles * 8)
+        d_exp = _ffi.DeviceBuffer(p68.out_doubles * 8)
+        p34.execute(d_in, d34)
+        p68.execute(d_in, d68)
+        frames = np.array([(n - W) // S + 1 for n in lens], dtype=np.int64)
+        _ffi.check(gpu_lib.paa_dev_expand_deltas(d34.ptr, _ffi.as_i64p(frames), len(frames), d_exp.ptr))
+        _ffi.sync()
+        want = d68.to_host(np.float64, p68.out_doubles)
+        got = d_exp.to_host(np.float64, p68.out_doubles)
+        assert np.array_equal(got, want)
+        pos = 0
+        for t in frames:
+            slab = got[pos:pos + 68 * int(t)].reshape(68, int(t))
+            assert np.all(slab[34:, 0] == 0.0) and np.array_equal(slab[34:, 1:], slab[:34, 1:] - slab[:34, :-1])
+            pos += 68 * int(t)
+        p34.destroy()
+        p68.destroy()
 
 
 @pytest.mark.parametrize("fs,window,step,seconds", [
@@ -443,8 +505,7 @@ def test_random_window_step_sweep(gpu_lib, seed):
             ShortTermFeatures.feature_extraction(x, fs, window, step)
         return
     got, _ = ShortTermFeatures.feature_extraction(x, fs, window, step)
-    ill = O.ill_conditioned_mfcc_frames(x, fs, window, step)
-    assert_parity(got, ref, "fs=%d W=%d S=%d" % (fs, window, step), ill)
+    assert_parity(got, ref, "fs=%d W=%d S=%d" % (fs, window, step), sig=(x, fs, window, step))
 
 
 def test_experiment_switches_change_nothing_in_the_default_build(gpu_lib, monkeypatch):
