@@ -71,7 +71,11 @@ SHAPES = {
     "ct_800_stereo": (16000, 800, 400, 3600, 1, 2, 0, 0),
     "ct_400": (8000, 400, 200, 3600, 2, 0, 0, 0),                  # 50 ms at 8 kHz (audioTrainTest.py:28-29)
     "ct_320": (16000, 320, 160, 1800, 1, 0, 0, 0),
-    "w1024": (16000, 1024, 512, 3600, 1, 0, 0, 0),                 # a power-of-two window (mixed-radix kernel, lean instance)
+    "w1024": (16000, 1024, 512, 3600, 1, 0, 0, 0),                 # power-of-two windows: three-pass register FFT 8 x 8 x 8 ...
+    "w2048": (44100, 2048, 1024, 1200, 1, 0, 0, 0),                # ... 16 x 16 x 4
+    "w512": (16000, 512, 256, 3600, 1, 0, 0, 0),                   # ... 4 x 8 x 8
+    "w1024_68": (16000, 1024, 512, 3600, 1, 0, 0, 1),
+    "w1024_spectrogram": (16000, 1024, 512, 3600, 1, 0, 1, 0),
     "w2400": (48000, 2400, 1200, 1200, 1, 0, 0, 0),                # 50 ms at 48 kHz
     "w2205": (44100, 2205, 1102, 1200, 1, 0, 0, 0),                # 50 ms at 44.1 kHz (odd window)
     "w1764": (44100, 1764, 1764, 1200, 1, 0, 0, 0),                # the CLI's 40 ms at 44.1 kHz (audioAnalysis.py:71,80)
@@ -221,7 +225,11 @@ def other_configs(ffi, steps=10):
     run_shape("ct_800_f64", "w800_float64", "1 h at 16 kHz, 800 / 400, float64 mono samples (stereo_to_mono's output)")
     run_shape("ct_800_stereo", "w800_stereo", "1 h at 16 kHz, 800 / 400, interleaved stereo int16 samples")
     run_shape("ct_400", "w400_8kHz", "2 x 1 h at 8 kHz, 50 ms / 25 ms (400 / 200)")
-    run_shape("w1024", "w1024_16kHz", "1 h at 16 kHz, window 1024 / step 512 (a power-of-two window: mixed-radix kernel, lean instance)")
+    run_shape("w1024", "w1024_16kHz", "1 h at 16 kHz, window 1024 / step 512 (power of two: three-pass register FFT 8 x 8 x 8)")
+    run_shape("w1024_68", "w1024_16kHz_68rows", "1 h at 16 kHz, 1024 / 512, 68 rows")
+    run_shape("w1024_spectrogram", "w1024_spectrogram", "1 h at 16 kHz, 1024 / 512, spectrogram rows")
+    run_shape("w2048", "w2048_44kHz", "20 min at 44.1 kHz, window 2048 / step 1024 (16 x 16 x 4)")
+    run_shape("w512", "w512_16kHz", "1 h at 16 kHz, window 512 / step 256 (4 x 8 x 8; entropy blocks of 51 samples)")
     run_shape("w2400", "w2400_48kHz", "20 min at 48 kHz, 50 ms / 25 ms (2400 / 1200)")
     run_shape("w2205", "w2205_44kHz", "20 min at 44.1 kHz, 50 ms / 25 ms (2205 / 1102, odd window)")
     run_shape("w2400_68", "w2400_48kHz_68rows", "20 min at 48 kHz, 2400 / 1200, 68 rows (what mid-term extraction runs)")

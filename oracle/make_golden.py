@@ -114,7 +114,7 @@ def main():
     print("total %.2f MB" % (tot / 1e6))
 
 
-if __name__ == "__main__" and not any(a in sys.argv for a in ("--dir", "--thumb", "--wide", "--silence", "--round3", "--round4")):
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--dir", "--thumb", "--wide", "--silence", "--round3", "--round4", "--round5")):
     main()
 
 
@@ -372,3 +372,55 @@ def round4_goldens():
 
 if __name__ == "__main__" and "--round4" in sys.argv:
     round4_goldens()
+
+
+def round5_goldens():
+    """Round 5: outputs of the unmodified reference at the power-of-two windows the three-pass register-FFT kernels took over
+    (csrc/kernels_tri.hpp: 1024 = 2 x 8 x 8 x 8 had a golden already, synth16k_1024_512) -- 512 / 256 (entropy blocks of 51
+    samples: odd, a sample pair straddles block boundaries; the reference's mid-term path too) and 2048 / 1024 on the 44.1 kHz
+    speech of the reference's data folder and on a seeded clip, plus their spectrogram / chromagram -- and at the big windows
+    music_thumbnailing uses by default (audioSegmentation.py:1137: 1.0 s / 0.5 s) on a seeded 16 kHz clip and at 44.1 kHz."""
+    from synth import synth_clip
+    ref_st, ref_mt, ref_io = load_reference.load()
+
+    def st_case(name, sig, fs, win, step, deltas=True):
+        F, names = ref_st.feature_extraction(sig, fs, win, step, deltas)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="st", signal=sig, fs=fs, window=win, step=step,
+                            deltas=deltas, features=F, names=np.array(names))
+        print(name, F.shape)
+
+    def mid_case(name, sig, fs, mw, ms, sw, ss):
+        mid, st, names = ref_mt.mid_feature_extraction(sig, fs, mw, ms, sw, ss)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="mid", signal=sig, fs=fs, mid_window=mw, mid_step=ms,
+                            window=sw, step=ss, mid=mid, features=st, names=np.array(names))
+        print(name, mid.shape, st.shape)
+
+    def spec_case(name, sig, fs, win, step):
+        with contextlib.redirect_stdout(io.StringIO()):
+            S, t_ax, f_ax = ref_st.spectrogram(sig, fs, win, step)
+        C, ct_ax, cf_ax = ref_st.chromagram(sig, fs, win, step)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="spec", signal=sig, fs=fs, window=win, step=step,
+                            specgram=S, spec_time=np.array(t_ax), spec_freq=np.array(f_ax), chromagram=C,
+                            chroma_time=np.array(ct_ax), chroma_names=np.array(cf_ax))
+        print(name, S.shape, C.shape)
+
+    x16 = synth_clip(512, 2 * 16000, 16000)
+    st_case("synth16k_512_256", x16, 16000, 512, 256)
+    mid_case("synth16k_mid_512_256", x16, 16000, 16000, 8000, 512, 256)
+    spec_case("synth16k_spec_512_256", x16, 16000, 512, 256)
+    fs, x = wav("pyAudioAnalysis/data/3WORDS.wav", 2.0)                     # 44.1 kHz speech
+    st_case("3words2s_2048_1024", x, fs, 2048, 1024)
+    x44 = synth_clip(2048, 2 * 44100, 44100)
+    st_case("synth44k_2048_1024_nodelta", x44, 44100, 2048, 1024, deltas=False)
+    spec_case("synth44k_spec_2048_1024", x44, 44100, 2048, 1024)
+    fs, x = wav("pyAudioAnalysis/data/doremi.wav", 2.5)                      # 16 kHz
+    st_case("doremi_1024_256", x, fs, 1024, 256)
+    # music_thumbnailing's default short-term window (audioSegmentation.py:1137): 1 s / 0.5 s
+    x1s = synth_clip(16000, 12 * 16000, 16000)
+    st_case("synth16k_16000_8000", x1s, 16000, 16000, 8000)
+    x1s44 = synth_clip(44100, 6 * 44100, 44100)
+    st_case("synth44k_44100_22050_nodelta", x1s44, 44100, 44100, 22050, deltas=False)
+
+
+if __name__ == "__main__" and "--round5" in sys.argv:
+    round5_goldens()

@@ -22,13 +22,16 @@ int fast(const FastLaunch &fl, const PlanDev &P, const FastTables &ft, const voi
 // kernels_ct.hpp: windows 2 RA RB (800, 640, 400, 320)
 int ct(const ct::CtLaunch &cl, int sample_kind, const PlanDev &P, const unsigned char *blob, const void *d_packed,
        const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out, hipStream_t stream);
-// kernels_tri.hpp: three-pass register FFT (2400, 2205, 1764, 1920, 1600, 1200, 1102 features, 551); two units
+// kernels_tri.hpp: three-pass register FFT (2400, 2205, 1764, 1920, 1600, 1200, 1102 features, 551; 1024, 2048, 512); three units
 int tri(const tri::TriLaunch &tl, int sample_kind, const PlanDev &P, const unsigned char *blob, const void *d_packed,
         const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out, hipStream_t stream);
 int tri_part_a(const tri::TriLaunch &tl, int sample_kind, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
                hipStream_t stream);
 int tri_part_b(const tri::TriLaunch &tl, int sample_kind, const PlanDev &P, const unsigned char *blob, const void *d_packed,
+               const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
+               hipStream_t stream);
+int tri_part_c(const tri::TriLaunch &tl, int sample_kind, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
                hipStream_t stream);
 // kernels_reg.hpp: prime-factor register FFT (window 1102: spectrogram / chromagram rows)
@@ -51,6 +54,7 @@ int phase_fast(unsigned long long *acc16, unsigned long long *trace, int max_wav
 int phase_ct(unsigned long long *acc16, unsigned long long *trace, int max_waves);
 int phase_tri_a(unsigned long long *acc16, unsigned long long *trace, int max_waves);
 int phase_tri_b(unsigned long long *acc16, unsigned long long *trace, int max_waves);
+int phase_tri_c(unsigned long long *acc16, unsigned long long *trace, int max_waves);
 int phase_rmg(unsigned long long *acc16, unsigned long long *trace, int max_waves);
 
 }  // namespace launch

@@ -19,6 +19,7 @@ int tri_part_a(const tri::TriLaunch &tl, int sample_kind, const PlanDev &P, cons
 int tri(const tri::TriLaunch &tl, int sample_kind, const PlanDev &P, const unsigned char *blob, const void *d_packed,
         const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out, hipStream_t stream) {
     const bool here = tl.shape == 0 || tl.shape == 1 || tl.shape == 7;
+    if (tl.shape >= 8) return tri_part_c(tl, sample_kind, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
     return here ? tri_part_a(tl, sample_kind, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream)
                 : tri_part_b(tl, sample_kind, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
 }

@@ -91,18 +91,20 @@ struct Shape {
     static_assert(J2 <= 64, "one pass-2 job per lane");
     static_assert(!PACKED || NJ == 1, "packed shapes: one pass-1 job per lane");
     static_assert(PACKED || (R1 % 2 == 1), "real-input shapes: odd first radix");
-    static_assert((L1 < 64 ? L1 : 64) * SPL <= LT, "a register row may contain at most one entropy-block boundary");
+    // packed shapes: a pass-3 table entry is PE x 8 ushorts = {plane offset of job A, of job B, (bin of X[k], bin of X[N - k]) x R3}
+    static constexpr int PE = PACKED ? (2 + 2 * R3 + 7) / 8 : 1;
+    static_assert(PACKED || (L1 < 64 ? L1 : 64) * SPL <= LT, "real-input shapes: a register row may contain at most one entropy-block boundary");
     static_assert(C <= LB, "a lane's bins may contain at most one entropy-block boundary");
     static_assert(R3 > 1 || !PACKED, "two-pass shapes (R3 = 1): real input only (Z[k] and Z[N - k] would sit in different lanes)");
-    static_assert(R3 <= 3 || !PACKED, "packed shapes: a pass-3 table entry holds the store offsets of three outputs per job");
+    static_assert(R3 <= 8, "pass 3 has codelets up to radix 8");
     static_assert(SLOT * 8 < 65536, "pass-3 table entries are 16-bit byte offsets into the slot");
 };
 
 // shared (per workgroup) LDS tables + the global tables behind them in the same device blob
 struct TriLayout {
     int off_tw2;                    // double2 [R2][R3]: W_L1^(b q2)
-    int off_p3;                     // 8 x ushort [64 NR3], BYTE offsets into the slot.  Packed: plane elements of job A, of job B, then per
-                                    // output k3 where |X[k]| and |X[N - k]| go (8 NF = "nowhere": a parking double).  Real input, three
+    int off_p3;                     // PE x 8 ushorts [64 NR3], BYTE offsets into the slot.  Packed: plane elements of job A, of job B, then per
+                                    // output k3 < R3 where |X[k]| and |X[N - k]| go (8 NF = "nowhere": a parking double).  Real input, three
                                     // passes: plane elements of the job, then where its R3 (<= 5) magnitudes go.  Two passes (R3 = 1):
                                     // ushort [R2][64]: where lane q1's magnitude q2 goes
     int off_mello, off_melcnt, off_meloff, off_melw, off_dct, off_chstart, off_chsrc, off_chw;
@@ -127,6 +129,14 @@ template <> struct Cd<3> {
 template <> struct Cd<5> {
     static __device__ __forceinline__ void run(double2 *v) { dft5(v); }
     static constexpr int pos(int q) { return q; }
+};
+template <> struct Cd<4> {
+    static __device__ __forceinline__ void run(double2 *v) { ct::dft4r(v[0], v[1], v[2], v[3]); }
+    static constexpr int pos(int q) { return q; }
+};
+template <> struct Cd<8> {
+    static __device__ __forceinline__ void run(double2 *v) { ct::Dft<8>::run<1>(v); }
+    static constexpr int pos(int q) { return ct::Dft<8>::pos(q); }
 };
 template <> struct Cd<16> {
     static __device__ __forceinline__ void run(double2 *v) { ct::Dft<16>::run<1>(v); }
@@ -630,7 +640,6 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                 __builtin_amdgcn_sched_barrier(0);
             };
             if constexpr (PACKED) {
-                static_assert(LT % 2 == 0, "a sample pair lies in one entropy block");
                 const bool act1 = lane < L1;
                 const int jj = act1 ? lane : L1 - 1;
                 double2 v[R1];
@@ -678,15 +687,26 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                         }
                         const double d0 = v[r].x, d1 = v[r].y;
                         const double e = fma(d0, d0, d1 * d1);
-                        // samples 2 L1 r + 2 lane, + 1: block jlo for lanes below jth, jlo + 1 from there on (static per row)
-                        const int n0 = 2 * L1 * r;
-                        const int jlo = (n0 / LT < 10) ? n0 / LT : 10;
-                        const int jth = (jlo >= 10) ? 64 : ((jlo + 1) * LT - n0) / 2;
-                        if (jth >= L1) {
-                            eb[jlo] += e;
-                        } else {
-                            eb[jlo] += (lane < jth) ? e : 0.0;
-                            eb[jlo + 1] += (lane >= jth) ? e : 0.0;
+                        // the row holds samples [n0, n0 + 2 L1), lane p the pair (n0 + 2 p, + 1); block(n) = min(n / LT, 10) (10: the tail
+                        // the reference leaves out of the blocks).  Everything below is static per register row: a row inside one block
+                        // is a plain add, a block boundary at an even sample splits the LANES, one at an odd sample (LT odd: power-of-two
+                        // windows such as 512) also splits the pair of the lane it falls into
+                        const int n0 = 2 * L1 * r, n1 = n0 + 2 * L1;
+                        const int jfirst = (n0 / LT < 10) ? n0 / LT : 10, jlast = ((n1 - 1) / LT < 10) ? (n1 - 1) / LT : 10;
+#pragma unroll
+                        for (int jb = 0; jb < 11; ++jb) {
+                            if (jb < jfirst || jb > jlast) continue;
+                            const int lo_s = ((jb * LT > n0) ? jb * LT : n0) - n0;                               // first sample of block jb in the row
+                            const int hi_s = ((jb < 10 && (jb + 1) * LT < n1) ? (jb + 1) * LT : n1) - n0;        // one past its last
+                            if (lo_s == 0 && hi_s == 2 * L1) {
+                                eb[jb] += e;
+                            } else if (lo_s % 2 == 0 && hi_s % 2 == 0) {
+                                eb[jb] += (lane >= lo_s / 2 && lane < hi_s / 2) ? e : 0.0;
+                            } else {
+                                const int s_even = 2 * lane, s_odd = 2 * lane + 1;
+                                const double part0 = (s_even >= lo_s && s_even < hi_s) ? d0 * d0 : 0.0;
+                                eb[jb] += (s_odd >= lo_s && s_odd < hi_s) ? fma(d1, d1, part0) : part0;
+                            }
                         }
                         if constexpr (RAW16) {
                             // both samples of the pair at once: {s_even, s_odd} against {s of the sample before the pair, s_even}
@@ -866,10 +886,17 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                 *reinterpret_cast<double *>(plb + so[q]) = mg;
             }
         } else if constexpr (PACKED) {
+            constexpr int PE = SH::PE;
             double2 dA[NR3][R3], dB[NR3][R3];
-            uint4 pe[NR3];
+            // host table, PE x 8 ushorts per lane job: byte offsets {plane elements of job A, of job B, (|X[k]|, |X[N - k]|) x R3}
+            unsigned pw32[NR3][4 * PE];
 #pragma unroll
-            for (int u = 0; u < NR3; ++u) pe[u] = t_p3[lane + 64 * u];
+            for (int u = 0; u < NR3; ++u)
+#pragma unroll
+                for (int i = 0; i < PE; ++i) {
+                    const uint4 q4 = t_p3[(lane + 64 * u) * PE + i];
+                    pw32[u][4 * i] = q4.x; pw32[u][4 * i + 1] = q4.y; pw32[u][4 * i + 2] = q4.z; pw32[u][4 * i + 3] = q4.w;
+                }
             double *pl = cur;
             unsigned char *plb = reinterpret_cast<unsigned char *>(cur);
             if (act2) {
@@ -879,8 +906,8 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
             wsync();
 #pragma unroll
             for (int u = 0; u < NR3; ++u) {
-                const double *pa = reinterpret_cast<const double *>(plb + (pe[u].x & 0xffffu));
-                const double *pb = reinterpret_cast<const double *>(plb + (pe[u].x >> 16));
+                const double *pa = reinterpret_cast<const double *>(plb + (pw32[u][0] & 0xffffu));
+                const double *pb = reinterpret_cast<const double *>(plb + (pw32[u][0] >> 16));
 #pragma unroll
                 for (int b = 0; b < R3; ++b) { dA[u][b].x = pa[b]; dB[u][b].x = pb[b]; }
             }
@@ -892,8 +919,8 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
             wsync();
 #pragma unroll
             for (int u = 0; u < NR3; ++u) {
-                const double *pa = reinterpret_cast<const double *>(plb + (pe[u].x & 0xffffu));
-                const double *pb = reinterpret_cast<const double *>(plb + (pe[u].x >> 16));
+                const double *pa = reinterpret_cast<const double *>(plb + (pw32[u][0] & 0xffffu));
+                const double *pb = reinterpret_cast<const double *>(plb + (pw32[u][0] >> 16));
 #pragma unroll
                 for (int b = 0; b < R3; ++b) { dA[u][b].y = pa[b]; dB[u][b].y = pb[b]; }
             }
@@ -904,7 +931,6 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                 // host table: where each result goes (a self-paired job meets each of its pairs {k, N - k} twice: only the smaller
                 // index is a bin, the other copy -- like everything idle lanes of the last round compute -- is parked at index NF);
                 // no predicates, no branches around the stores.  Job 0 (lane 0 of round 0) is (q1, q2) = (0, 0): its partner is itself
-                const unsigned st[3] = {pe[u].y, pe[u].z, pe[u].w};
                 double2 pw[R3];
 #pragma unroll
                 for (int k3 = 0; k3 < R3; ++k3) pw[k3] = g_post[(lane + 64 * u) * R3 + k3];
@@ -925,8 +951,9 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                     const double xr_ = e.x + wo.x, xi_ = e.y + wo.y, yr_ = e.x - wo.x, yi_ = e.y - wo.y;
                     const double mk = mag_sqrt(fma(xr_, xr_, xi_ * xi_)) * mscale;
                     const double mm = mag_sqrt(fma(yr_, yr_, yi_ * yi_)) * mscale;
-                    *reinterpret_cast<double *>(plb + (st[k3] & 0xffffu)) = mk;
-                    *reinterpret_cast<double *>(plb + (st[k3] >> 16)) = mm;
+                    const unsigned st = pw32[u][1 + k3];
+                    *reinterpret_cast<double *>(plb + (st & 0xffffu)) = mk;
+                    *reinterpret_cast<double *>(plb + (st >> 16)) = mm;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1026,6 +1053,13 @@ typedef Shape<20, 20, 2, true, 40, 8> S1600;        // 50 ms at 32 kHz: 800 comp
 typedef Shape<20, 10, 3, true, 30, 8> S1200;        // 50 ms at 24 kHz / 25 ms at 48 kHz: 600 complex points
 typedef Shape<29, 19, 1, false, 19, 8> S551;        // 50 ms at 11.025 kHz / 25 ms at 22.05 kHz: 551 real points, two passes
 typedef Shape<29, 19, 2, false, 38, 8> S1102;       // 25 ms at 44.1 kHz (BASELINE config 5) / 50 ms at 22.05 kHz: 1102 real points
+// power-of-two windows (what callers outside the reference's 50 ms default pass most often, ShortTermFeatures.py:563-564 takes any
+// window): every pass on all 64 lanes where the factorisation allows it.  Plane row pitches from scripts/dev/tri_model.py's LDS
+// model (ds_write_b64: 16-lane groups mod 16 doubles, ds_read_b64: 32-lane groups mod 32): P = 69 makes both exchanges of the
+// radix-8 shapes cost 176 LDS cycles per plane against 112 conflict-free (P = 64: 312), P = 68 is the best pitch of 16 x 16 x 4
+typedef Shape<8, 8, 8, true, 69, 8> S1024;          // 512 complex points: 64 x radix 8, three times
+typedef Shape<16, 16, 4, true, 68, 7> S2048;        // 1024 complex points
+typedef Shape<4, 8, 8, true, 69, 8> S512;           // 256 complex points (odd entropy blocks: 51 samples)
 
 struct TriLaunch {
     int shape = -1;                 // index into the shape list above
@@ -1045,11 +1079,15 @@ inline int tri_shape_of(int window) {
         case 1200: return 5;
         case 551: return 6;
         case 1102: return 7;
+        case 1024: return 8;
+        case 2048: return 9;
+        case 512: return 10;
         default: return -1;
     }
 }
 // PAA_TRI_SHAPE(SH) is expanded once per shape, in tri_shape_of's order
-#define PAA_TRI_SHAPES(X) X(0, S2400) X(1, S2205) X(2, S1764) X(3, S1920) X(4, S1600) X(5, S1200) X(6, S551) X(7, S1102)
+#define PAA_TRI_SHAPES(X) X(0, S2400) X(1, S2205) X(2, S1764) X(3, S1920) X(4, S1600) X(5, S1200) X(6, S551) X(7, S1102) \
+    X(8, S1024) X(9, S2048) X(10, S512)
 
 template <typename SH>
 inline void tri_fill(double fs, const MelTable *mel, const ChromaTable *chroma, TriLaunch &tl, std::vector<unsigned char> &blob) {
@@ -1060,7 +1098,7 @@ inline void tri_fill(double fs, const MelTable *mel, const ChromaTable *chroma, 
     int off = 0;
     auto take = [&off](size_t bytes) { const int o = off; off += (int)((bytes + 15) / 16 * 16); return o; };
     L.off_tw2 = take((size_t)R2 * R3 * 16);
-    L.off_p3 = take(R3 == 1 ? (size_t)R2 * 64 * 2 : (size_t)64 * NR3 * 16);
+    L.off_p3 = take(R3 == 1 ? (size_t)R2 * 64 * 2 : (size_t)64 * NR3 * 16 * SH::PE);
     L.off_mello = take(40 * 4);
     L.off_melcnt = take(40 * 4);
     L.off_meloff = take(40 * 4);
@@ -1094,6 +1132,7 @@ inline void tri_fill(double fs, const MelTable *mel, const ChromaTable *chroma, 
     if (SH::PACKED) {
         // pass-3 lane jobs: unordered pairs {job A, job B} with Z[N - k] of A's outputs in B (same enumeration as pair_count)
         unsigned short *pt = reinterpret_cast<unsigned short *>(b + L.off_p3);
+        constexpr int E = 8 * SH::PE, NK = (E - 2) / 2;            // ushorts per entry, (bin, mirror bin) slots of an entry
         int p = 0;
         for (int q1 = 0; q1 < R1; ++q1)
             for (int q2 = 0; q2 < R2; ++q2) {
@@ -1101,21 +1140,21 @@ inline void tri_fill(double fs, const MelTable *mel, const ChromaTable *chroma, 
                 const int p1 = m % R1, p2 = (m / R1) % R2;
                 if (!(p1 > q1 || (p1 == q1 && p2 >= q2))) continue;
                 const bool self = (p1 == q1 && p2 == q2);
-                pt[8 * p] = (unsigned short)(8 * (q1 * SH::P + q2 * R3));
-                pt[8 * p + 1] = (unsigned short)(8 * (p1 * SH::P + p2 * R3));
-                for (int k3 = 0; k3 < 3; ++k3) {
+                pt[E * p] = (unsigned short)(8 * (q1 * SH::P + q2 * R3));
+                pt[E * p + 1] = (unsigned short)(8 * (p1 * SH::P + p2 * R3));
+                for (int k3 = 0; k3 < NK; ++k3) {
                     const int kk = k + R1 * R2 * k3;
                     const bool put_k = k3 < R3 && (!self || 2 * kk <= N);                    // X[k]
                     const bool put_m = k3 < R3 && kk != 0 && (!self || 2 * kk < N);          // X[N - k]
-                    pt[8 * p + 2 + 2 * k3] = (unsigned short)(8 * (put_k ? kk : SH::NF));
-                    pt[8 * p + 3 + 2 * k3] = (unsigned short)(8 * (put_m ? N - kk : SH::NF));
+                    pt[E * p + 2 + 2 * k3] = (unsigned short)(8 * (put_k ? kk : SH::NF));
+                    pt[E * p + 3 + 2 * k3] = (unsigned short)(8 * (put_m ? N - kk : SH::NF));
                 }
                 for (int k3 = 0; k3 < R3; ++k3) put_w(L.off_g_post, (size_t)p * R3 + k3, (long long)k + (long long)R1 * R2 * k3, 2LL * N);
                 ++p;
             }
         // idle lanes of the last round: valid plane offsets (0), every result parked
         for (; p < 64 * NR3; ++p)
-            for (int k3 = 0; k3 < 3; ++k3) pt[8 * p + 2 + 2 * k3] = pt[8 * p + 3 + 2 * k3] = (unsigned short)(8 * SH::NF);
+            for (int k3 = 0; k3 < NK; ++k3) pt[E * p + 2 + 2 * k3] = pt[E * p + 3 + 2 * k3] = (unsigned short)(8 * SH::NF);
     }
     if (!SH::PACKED) {
         // real input: |Z[k]| goes to bin k, or to its mirror N - k, or nowhere (the parking double at index NF)
@@ -1162,13 +1201,15 @@ inline int tri_select(int window, int mode, double fs, const MelTable *mel, cons
     const int sh = tri_shape_of(window);
     if (sh < 0) return 0;
     tl.shape = sh;
-    static const char *names[3][8] = {
+    static const char *names[3][11] = {
         {"st_tri_20x20x3", "st_tri_r21x21x5", "st_tri_21x21x2", "st_tri_20x16x3", "st_tri_20x20x2", "st_tri_20x10x3", "st_tri_r29x19",
-         "st_tri_r29x19x2"},
+         "st_tri_r29x19x2", "st_tri_8x8x8", "st_tri_16x16x4", "st_tri_4x8x8"},
         {"spectrogram_tri_20x20x3", "spectrogram_tri_r21x21x5", "spectrogram_tri_21x21x2", "spectrogram_tri_20x16x3",
-         "spectrogram_tri_20x20x2", "spectrogram_tri_20x10x3", "spectrogram_tri_r29x19", "spectrogram_tri_r29x19x2"},
+         "spectrogram_tri_20x20x2", "spectrogram_tri_20x10x3", "spectrogram_tri_r29x19", "spectrogram_tri_r29x19x2",
+         "spectrogram_tri_8x8x8", "spectrogram_tri_16x16x4", "spectrogram_tri_4x8x8"},
         {"chromagram_tri_20x20x3", "chromagram_tri_r21x21x5", "chromagram_tri_21x21x2", "chromagram_tri_20x16x3",
-         "chromagram_tri_20x20x2", "chromagram_tri_20x10x3", "chromagram_tri_r29x19", "chromagram_tri_r29x19x2"}};
+         "chromagram_tri_20x20x2", "chromagram_tri_20x10x3", "chromagram_tri_r29x19", "chromagram_tri_r29x19x2",
+         "chromagram_tri_8x8x8", "chromagram_tri_16x16x4", "chromagram_tri_4x8x8"}};
     tl.name = names[mode][sh];
     switch (sh) {
 #define PAA_TRI_FILL(ID, SH) case ID: tri_fill<SH>(fs, mel, chroma, tl, blob); break;

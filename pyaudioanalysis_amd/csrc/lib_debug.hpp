@@ -15,7 +15,7 @@ extern "C" int paa_debug_phase_cycles(uint64_t *out16) {
     unsigned long long acc[16] = {0};
     // every translation unit with kernels keeps its own counters (family_*.hip)
     if (launch::phase_fast(acc, nullptr, 0) < 0 || launch::phase_ct(acc, nullptr, 0) < 0 || launch::phase_tri_a(acc, nullptr, 0) < 0 ||
-        launch::phase_tri_b(acc, nullptr, 0) < 0 || launch::phase_rmg(acc, nullptr, 0) < 0)
+        launch::phase_tri_b(acc, nullptr, 0) < 0 || launch::phase_tri_c(acc, nullptr, 0) < 0 || launch::phase_rmg(acc, nullptr, 0) < 0)
         return fail(PAA_ERR_HIP, "reading the phase counters failed");
     for (int i = 0; i < 16; ++i) out16[i] = acc[i];
 #endif

@@ -410,7 +410,7 @@ def test_profile_records_the_bench_line_quotes_are_this_rounds():
     assert 0.25 < ex["issued_tflops"] / peak_at < 0.45
 
 
-@pytest.mark.parametrize("window", [2400, 2205, 1764, 1920, 1600, 1200, 1102, 551])
+@pytest.mark.parametrize("window", [2400, 2205, 1764, 1920, 1600, 1200, 1102, 551, 1024, 2048, 512])
 def test_three_pass_tables_reproduce_the_fft(window):
     """Host tables of csrc/kernels_tri.hpp (no device): the three passes restated in NumPy FROM THE LIBRARY'S OWN TABLES --
     pass-1 twiddles W_N^(j q1), pass-2 twiddles W_L1^(b q2), for packed (even) windows the pass-3 job pairs with their plane
@@ -428,6 +428,7 @@ def test_three_pass_tables_reproduce_the_fft(window):
     R1, R2, R3, packed, P, NW, njob3, lds = (int(v) for v in shape)
     N = R1 * R2 * R3
     assert N == (window // 2 if packed else window) and (packed == 1) == (window % 2 == 0 and window != 1102)
+    assert R3 <= 8
     L1, NQ1, NF = R2 * R3, (R1 if packed else (R1 + 1) // 2), window // 2
     assert P >= L1 and NQ1 * R3 <= 64 and lds <= 160 * 1024 and 7 <= NW <= 8
     cplx = lambda o, n: blob[o:o + 16 * n].view(np.float64).reshape(n, 2) @ np.array([1.0, 1j])
@@ -457,9 +458,11 @@ def test_three_pass_tables_reproduce_the_fft(window):
                 if k < NF:
                     X[k] = abs(plane2[q1 * P + q2]); hits[k] += 1
     elif packed:
-        # entries of 8 x uint16, BYTE offsets into the frame's slot: plane elements of job A, of job B, then per output k3 where
-        # |X[k]| and |X[N - k]| go; 8 NF = the parking double (a result no bin takes)
-        p3 = blob[off[1]:off[1] + 16 * 64 * ((njob3 + 63) // 64)].view(np.uint16).reshape(-1, 8)
+        # entries of PE x 8 uint16 (PE = ceil((2 + 2 R3) / 8): one 16-byte word for R3 <= 3, two for radix 4, three for radix 8),
+        # BYTE offsets into the frame's slot: plane elements of job A, of job B, then per output k3 where |X[k]| and |X[N - k]| go;
+        # 8 NF = the parking double (a result no bin takes)
+        E = 8 * ((2 + 2 * R3 + 7) // 8)
+        p3 = blob[off[1]:off[1] + 2 * E * 64 * ((njob3 + 63) // 64)].view(np.uint16).reshape(-1, E)
         post = cplx(off[3], 64 * ((njob3 + 63) // 64) * R3).reshape(-1, R3)
         assert np.all(p3 % 8 == 0) and np.all(p3[njob3:, 2:] == 8 * NF) and np.all(p3[:, 2 + 2 * R3:] == 8 * NF)
         p3 = p3 // 8

@@ -34,7 +34,14 @@ def test_plans_dispatch_the_mixed_radix_kernel(gpu_lib):
     assert name(11025, 551, 275) == "st_tri_r29x19"
     assert name(22050, 551, 220, kind=1) == "st_tri_r29x19"
     assert name(44100, 1755, 877, mode=1) == "spectrogram_mix"   # other lengths made of 2, 3, 5, 7, 11, 13 stay mixed-radix
-    assert name(16000, 1024, 512, kind=1) == "st_mix"
+    # power-of-two windows: three-pass register FFT since round 5 (8 x 8 x 8, 16 x 16 x 4, 4 x 8 x 8); 256 and 4096 stay mixed-radix
+    assert name(16000, 1024, 512, kind=1) == "st_tri_8x8x8"
+    assert name(44100, 2048, 1024) == "st_tri_16x16x4"
+    assert name(16000, 512, 256, kind=2) == "st_tri_4x8x8"
+    assert name(16000, 1024, 512, mode=1) == "spectrogram_tri_8x8x8"
+    assert name(44100, 2048, 512, mode=2) == "chromagram_tri_16x16x4"
+    assert name(16000, 256, 128) == "st_mix"
+    assert name(44100, 4096, 2048) == "st_mix"
     assert name(44100, 1102, 441) == "st_tri_r29x19x2"         # config 5's features: real-input 29 x 19 x 2 (kernels_tri.hpp)
     assert name(44100, 1102, 441, kind=2, mode=1) == "spectrogram_reg_29x19"      # its rows keep the prime-factor kernel
     assert name(44100, 1102, 441, mode=2) == "chromagram_reg_29x19"
@@ -52,8 +59,15 @@ CASES = [
     (44100, 1764, 882, "i16", 15, True),       # 882 = 2 3 3 7 7
     (48000, 1920, 960, "stereo", 10, True),    # 960 = 8 8 5 3
     (32000, 1600, 800, "i16", 15, False),      # 50 ms at 32 kHz
-    (16000, 1024, 512, "i16", 20, True),       # 512 = 8 8 8
-    (16000, 512, 256, "f64", 10, True),
+    (16000, 1024, 512, "i16", 20, True),       # 512 = 8 x 8 x 8: three-pass register FFT (round 5)
+    (16000, 1024, 1024, "stereo", 20, False),
+    (16000, 1024, 333, "f64", 12, True),
+    (16000, 512, 256, "f64", 10, True),        # 256 = 4 x 8 x 8; entropy blocks of 51 samples (a pair straddles the boundary)
+    (16000, 512, 256, "i16", 20, True),
+    (8000, 512, 512, "stereo", 20, False),
+    (44100, 2048, 1024, "i16", 20, True),      # 1024 = 16 x 16 x 4
+    (44100, 2048, 441, "f64", 8, False),
+    (48000, 2048, 2048, "stereo", 15, True),
     (22050, 1100, 550, "i16", 10, False),      # 550 = 2 5 5 11
     (11025, 551, 275, "i16", 20, True),        # 50 ms at 11.025 kHz: odd, 19 x 29 -> two-pass real-input kernel (kernels_tri.hpp)
     (22050, 551, 220, "f64", 15, True),        # 25 ms at 22.05 kHz
@@ -86,7 +100,8 @@ def test_full_matrix_against_c_oracle(gpu_lib, fs, window, step, kind, seconds, 
 @pytest.mark.parametrize("fs,window,step,kind", [(48000, 2400, 1200, "i16"), (44100, 2205, 1102, "stereo"),
                                                   (44100, 1764, 1764, "i16"), (48000, 1920, 1920, "f64"),
                                                   (16000, 1024, 300, "i16"), (11025, 551, 275, "i16"),
-                                                  (32000, 1600, 800, "stereo"), (24000, 1200, 1200, "f64")])
+                                                  (32000, 1600, 800, "stereo"), (24000, 1200, 1200, "f64"),
+                                                  (44100, 2048, 1024, "stereo"), (16000, 512, 256, "i16"), (16000, 1024, 512, "f64")])
 def test_spectrogram_chromagram_full_against_c_oracle(gpu_lib, capsys, fs, window, step, kind):
     sig, mono = make_signal(kind, 9100 + window, 12.7, fs)
     spec, t_ax, f_ax = ShortTermFeatures.spectrogram(sig, fs, window, step)
@@ -132,7 +147,8 @@ def test_degenerate_clips_and_ragged_batches(gpu_lib):
 @pytest.mark.parametrize("fs,window,step,kind", [(44100, 2205, 1102, "i16"), (44100, 1102, 441, "stereo"), (44100, 1102, 441, "i16"),
                                                   (48000, 2400, 1200, "stereo"), (48000, 2400, 1200, "i16"),
                                                   (11025, 551, 275, "stereo"), (44100, 1764, 882, "f64"), (16000, 800, 400, "i16"),
-                                                  (16000, 640, 320, "stereo")])
+                                                  (16000, 640, 320, "stereo"), (16000, 1024, 512, "i16"), (16000, 512, 256, "stereo"),
+                                                  (44100, 2048, 1024, "i16")])
 def test_samples_that_sit_on_a_whole_number_mean(gpu_lib, fs, window, step, kind):
     """The kernels decide sign(x / 2^15 - mean) of integer PCM in integer arithmetic (x against floor(mean 2^15), with a
     separate rule when the clip mean is a whole count: then samples can sit exactly ON the mean and np.sign gives 0,
