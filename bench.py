@@ -86,6 +86,10 @@ SHAPES = {
     "w2205_stereo_68": (44100, 2205, 1102, 1200, 1, 2, 0, 1),
     "mid_stats": (16000, 800, 400, 30, 1000, 0, 0, 1),
     "big_16000": (16000, 16000, 8000, 600, 1, 0, 0, 0),            # music_thumbnailing's 1 s window (audioSegmentation.py:1137)
+    "big_16000_1h": (16000, 16000, 8000, 3600, 1, 0, 0, 0),        # ... on the one-hour clip (7 199 frames: 28 per CU)
+    "big_16000_68": (16000, 16000, 8000, 600, 1, 0, 0, 1),         # ... with deltas, as music_thumbnailing calls it
+    "big_8000_batch": (16000, 8000, 4000, 30, 200, 0, 0, 0),       # 0.5 s windows, 200 clips x 30 s in one plan
+    "big_44100": (44100, 44100, 22050, 300, 1, 0, 0, 0),           # 1 s at 44.1 kHz: 22 050 complex points do not fit the LDS
 }
 SAMPLE_BYTES = {0: 2, 1: 8, 2: 4}
 
@@ -239,7 +243,11 @@ def other_configs(ffi, steps=10):
     run_shape("w551_11k", "w551_11kHz", "1 h at 11.025 kHz, 50 ms / 25 ms (551 / 275, odd window 19 x 29)")
     run_shape("w551_22k", "w551_22kHz", "30 min at 22.05 kHz, 25 ms / 10 ms (551 / 220)")
     # the window of music_thumbnailing (audioSegmentation.py:1137: 1 s / 0.5 s): beyond the LDS envelope, passes through HBM
-    run_shape("big_16000", "w16000_16kHz", "10 min at 16 kHz, 1 s / 0.5 s (16000 / 8000): the big-window path", launches=5)
+    run_shape("big_16000", "w16000_16kHz", "10 min at 16 kHz, 1 s / 0.5 s (16000 / 8000): one workgroup per frame, transform in LDS", launches=20)
+    run_shape("big_16000_1h", "w16000_16kHz_1h", "1 h at 16 kHz, 16000 / 8000", launches=10)
+    run_shape("big_16000_68", "w16000_16kHz_68rows", "10 min at 16 kHz, 16000 / 8000, 68 rows", launches=20)
+    run_shape("big_8000_batch", "w8000_batch", "200 clips x 30 s at 16 kHz, 8000 / 4000, one plan", launches=20)
+    run_shape("big_44100", "w44100_44kHz", "5 min at 44.1 kHz, 1 s / 0.5 s (44100 / 22050): Stockham passes through HBM scratch", launches=3)
     return out
 
 

@@ -25,6 +25,7 @@ def ill_mask(signal, fs, window, step, factor=1e4):
     oracle's own single-frame FFT call: whether pocketfft returns exact zeros for a CONSTANT frame or leaves 1e-17 in the
     non-DC bins depends on the constant (and its batched transform need not round like its single one); when it leaves
     something, mfcc_2.. of the reference read 5e-8 instead of 0 and the frame is flagged like any other empty band."""
+    window, step = int(window), int(step)          # (the reference's callers pass floats: 0.050 * fs; :563-564 truncates)
     x = O.normalize_clip(signal)
     tab = O.Tables(fs, window)
     frames = np.lib.stride_tricks.sliding_window_view(x, window)[::step]

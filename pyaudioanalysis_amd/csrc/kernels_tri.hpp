@@ -79,12 +79,15 @@ struct Shape {
     // at zero (re-zeroed after every transform where the plane reaches into them), so the sweeps need no bounds masks
     // (+ one double at index NF, where the last pass parks the results that no bin takes)
     static constexpr int NFD = NF + 1;
-    static constexpr int SLOT0 = (PLANE > NFD ? PLANE : NFD) > 64 * C ? (PLANE > NFD ? PLANE : NFD) : 64 * C;
+    static constexpr int SLOT00 = (PLANE > NFD ? PLANE : NFD) > 64 * C ? (PLANE > NFD ? PLANE : NFD) : 64 * C;
+    // the time-domain partials are summed through an LDS transpose of 11 x 65 doubles inside the frame's spectrum slot (free at
+    // that point); a slot that is only a little smaller is padded to that size (both slots: 2 x the padding) when that is cheaper
+    // than a scratch of its own -- 1024-sample windows: 12.3 instead of 15.7 KB per wave = ten waves per CU instead of eight
+    static constexpr int SLOT0 = (SLOT00 < 11 * 65 && 2 * (11 * 65 - SLOT00) < 11 * 65) ? 11 * 65 : SLOT00;
     static constexpr int SLOT = (SLOT0 + 1) & ~1;
     static constexpr int LT = W / 10, LB = NF / 10;         // entropy blocks (samples / bins)
     static constexpr int SPL = PACKED ? 2 : 1;              // samples per loaded element
-    // the time-domain partials are summed through an LDS transpose of 11 x 65 doubles: inside the frame's spectrum slot (free
-    // at that point) when it is large enough, in a scratch of its own for the small windows
+    // ... in a scratch of its own for the small windows
     static constexpr int TSCR = (SLOT >= 11 * 65) ? 0 : 11 * 65;
     static constexpr int WAVE_DOUBLES = 2 * SLOT + 48 + 40 + 12 + TSCR;   // two slots, fv[48], msp[40], bnd[12], scratch
     static_assert(P >= L1, "plane rows hold L1 elements");
@@ -108,7 +111,7 @@ struct TriLayout {
                                     // passes: plane elements of the job, then where its R3 (<= 5) magnitudes go.  Two passes (R3 = 1):
                                     // ushort [R2][64]: where lane q1's magnitude q2 goes
     int off_mello, off_melcnt, off_meloff, off_melw, off_dct, off_chstart, off_chsrc, off_chw;
-    int off_sync;                   // pacing of the two waves of a SIMD: SIMD id [8], progress in half frames [8] (ints)
+    int off_sync;                   // pacing of the waves of a SIMD: SIMD id [16], progress in half frames [16] (ints)
     int table_bytes;                // LDS part, multiple of 16
     int off_g_tw1;                  // global part: double2 [NQ1][L1]: W_N^(j q1)
     int off_g_post;                 // packed: double2 [64 NR3][R3]: W_W^(kA + N3 k3)
@@ -520,14 +523,15 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
     const int tile_id = blockIdx.x * NW + wave;
     // the two waves of a SIMD are paced against each other (kernels_fast.hpp: the hardware issues oldest-first, so unpaced the
     // older wave runs ahead and the younger one ends alone on the SIMD): a wave publishes its progress twice per frame and
-    // raises its priority when it is behind its partner.  pace[0..7] = SIMD id, pace[8..15] = progress.
+    // raises its priority when it is behind its partner.  pace[0..15] = SIMD id, pace[16..31] = progress (up to 16 waves per
+    // workgroup; with three waves on a SIMD a wave paces itself against one of the other two).
     volatile int *pace = reinterpret_cast<volatile int *>(smem + L.off_sync);
     int partner = wave;
     {
         const int my_simd = (int)((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3u);     // HW_REG_HW_ID[5:4]
         if ((threadIdx.x & 63) == 0) {
             pace[wave] = my_simd;
-            pace[8 + wave] = (tile_id < n_tiles) ? 0 : 0x7fffffff;
+            pace[16 + wave] = (tile_id < n_tiles) ? 0 : 0x7fffffff;
         }
         __syncthreads();
 #pragma unroll
@@ -542,8 +546,8 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
 #define PAA_TRI_PACE(half_)                                                                            \
     if (PAA_TRI_PACING) {                                                                              \
         const int mine_ = 2 * n_done + (half_);                                                        \
-        if (lane == 0) pace[8 + wave] = mine_;                                                         \
-        const int other_ = __builtin_amdgcn_readfirstlane(pace[8 + partner]);                          \
+        if (lane == 0) pace[16 + wave] = mine_;                                                         \
+        const int other_ = __builtin_amdgcn_readfirstlane(pace[16 + partner]);                          \
         const int d_ = mine_ - other_;                                                                 \
         if (d_ < 0) __builtin_amdgcn_s_setprio(3);                                                     \
         else if (d_ > 0) __builtin_amdgcn_s_setprio(0);                                                \
@@ -1036,7 +1040,7 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
         PAA_TICK(10)
     }
 #undef PAA_TRI_PACE
-    if (lane_id == 0) pace[8 + wave] = 0x7fffffff;
+    if (lane_id == 0) pace[16 + wave] = 0x7fffffff;
     {
         const int lane = lane_id;
         (void)lane;
@@ -1057,9 +1061,12 @@ typedef Shape<29, 19, 2, false, 38, 8> S1102;       // 25 ms at 44.1 kHz (BASELI
 // window): every pass on all 64 lanes where the factorisation allows it.  Plane row pitches from scripts/dev/tri_model.py's LDS
 // model (ds_write_b64: 16-lane groups mod 16 doubles, ds_read_b64: 32-lane groups mod 32): P = 69 makes both exchanges of the
 // radix-8 shapes cost 176 LDS cycles per plane against 112 conflict-free (P = 64: 312), P = 68 is the best pitch of 16 x 16 x 4
-typedef Shape<8, 8, 8, true, 69, 8> S1024;          // 512 complex points: 64 x radix 8, three times
+#ifndef PAA_NW_1024
+#define PAA_NW_1024 11              // (A/B builds of scripts/rounds/r05: 8 / 10 / 11 waves per workgroup)
+#endif
+typedef Shape<8, 8, 8, true, 69, PAA_NW_1024> S1024;          // 512 complex points: 64 x radix 8, three times
 typedef Shape<16, 16, 4, true, 68, 7> S2048;        // 1024 complex points
-typedef Shape<4, 8, 8, true, 69, 8> S512;           // 256 complex points (odd entropy blocks: 51 samples)
+typedef Shape<4, 8, 8, true, 69, 12> S512;           // 256 complex points (odd entropy blocks: 51 samples)
 
 struct TriLaunch {
     int shape = -1;                 // index into the shape list above
@@ -1107,7 +1114,7 @@ inline void tri_fill(double fs, const MelTable *mel, const ChromaTable *chroma, 
     L.off_chstart = take(13 * 4);
     L.off_chsrc = take(std::max<size_t>(n_ch, 1) * 4);
     L.off_chw = take(std::max<size_t>(n_ch, 1) * 8);
-    L.off_sync = take(16 * 4);
+    L.off_sync = take(32 * 4);
     L.table_bytes = off;
     L.off_g_tw1 = take((size_t)NQ1 * L1 * 16);
     L.off_g_post = take(SH::PACKED ? (size_t)64 * NR3 * R3 * 16 : 16);

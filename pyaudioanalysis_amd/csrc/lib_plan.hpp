@@ -78,9 +78,16 @@ struct paa_plan {
     unsigned char *d_gen_blob = nullptr;
     bool blob_cached = false;        // d_gen_blob belongs to the table set's FamilyChoice (not freed with the plan)
     void *d_block = nullptr;         // the plan's one device block: d_clips, d_tiles, d_chunks, d_norms, d_psum / pmin / pmax point into it
-    int big = 0;                     // window beyond the LDS envelope: Stockham passes through HBM scratch
+    int big = 0;                     // window beyond the LDS envelope of the one-wave-per-frame kernels
     void *d_big = nullptr;
     size_t big_bytes = 0;
+    int wg = 0;                      // ... whose transform still fits ONE WORKGROUP's LDS (kernels_wg.hpp); else HBM passes (kernels_big.hpp)
+    wg::WgLayout wl;
+    std::vector<wg::FrameRef> wg_frames;              // every frame of the plan, chunk after chunk (a chunk's rows fit the scratch)
+    std::vector<std::pair<long long, long long>> wg_chunks;     // [first, last) into wg_frames
+    wg::FrameRef *d_wg_frames = nullptr;
+    unsigned short *d_wg_perm = nullptr;
+    long long wg_rows = 0;           // spectrum rows of the largest chunk
     long long mid_off_step = -1;
     long long n_tiles = 0, n_chunks = 0;
     size_t lds = 0;
@@ -104,6 +111,8 @@ static void plan_free(paa_plan *p) {
     // (the caller has synchronised the stream the plan ran on: pooled blocks may be handed to the next plan at once)
     pool_free(p->d_block);          // clips, tiles, statistics chunks / partials, clip constants: one pooled block
     pool_free(p->d_mid_off);
+    pool_free(p->d_wg_frames);
+    pool_free(p->d_wg_perm);
     if (!p->blob_cached) pool_free(p->d_gen_blob);
     if (p->d_big) (void)hipFree(p->d_big);
     delete p;
@@ -260,6 +269,36 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         p->d_norms = reinterpret_cast<ClipNorm *>(b + o_norms);
         p->d_psum = b + o_sum; p->d_pmin = b + o_min; p->d_pmax = b + o_max;
     }
+    // windows beyond the one-wave kernels whose transform fits one workgroup's LDS: the frame list of kernels_wg.hpp
+    if (p->big) {
+        std::vector<unsigned short> perm;
+        if (wg::wg_layout(tab->fft, p->wl, perm)) {
+            // spectrum scratch: one row of Nf doubles per frame of a chunk, at most 1 GiB; a chunk that starts inside a clip
+            // begins with that clip's previous frame once more (halo: only its spectrum row is wanted)
+            const long long cap = std::max<long long>(2, ((long long)1 << 30) / ((long long)Nf * 8));
+            long long first = 0;
+            for (int64_t c = 0; c < n_clips; ++c)
+                for (long long t = 0; t < p->clips[c].T; ++t) {
+                    long long in_chunk = (long long)p->wg_frames.size() - first;
+                    if (in_chunk >= cap) {
+                        p->wg_chunks.emplace_back(first, (long long)p->wg_frames.size());
+                        first = (long long)p->wg_frames.size();
+                        in_chunk = 0;
+                        if (t > 0 && mode != 1) p->wg_frames.push_back(wg::FrameRef{(int)c, (int)(t - 1), 0, 1});
+                    }
+                    p->wg_frames.push_back(wg::FrameRef{(int)c, (int)t, (int)((long long)p->wg_frames.size() - first), 0});
+                }
+            if ((long long)p->wg_frames.size() > first) p->wg_chunks.emplace_back(first, (long long)p->wg_frames.size());
+            for (auto &ch : p->wg_chunks) {
+                p->wg_rows = std::max(p->wg_rows, ch.second - ch.first);
+                for (long long i = ch.first; i < ch.second; ++i) p->wg_frames[(size_t)i].row = (int)(i - ch.first);
+            }
+            if ((rc = upload_pooled(&p->d_wg_frames, p->wg_frames.data(), std::max<size_t>(p->wg_frames.size(), 1)))) return rc;
+            if ((rc = upload_pooled(&p->d_wg_perm, perm.data(), perm.size()))) return rc;
+            p->wg = 1;
+            p->kernel_name = (mode == 0) ? "st_wg_lds_fft" : (mode == 1 ? "spectrogram_wg_lds_fft" : "chromagram_wg_lds_fft");
+        }
+    }
     // every one-launch feature kernel folds the statistics partials into the clip constants itself (its waves' prologue);
     // chromagram plans keep clip_params_kernel (the truncated-tail kernel of the host entry point reads its output), and so
     // does the big-window path (a chain of small kernels)
@@ -385,6 +424,49 @@ struct ProfScope {
     ~ProfScope() { if (stop) (void)hipEventRecord(stop, cs()); }
 };
 
+// windows beyond the one-wave kernels whose transform fits one workgroup's LDS (kernels_wg.hpp): per chunk of frames one
+// launch for the spectra of ALL its frames and one for their features, then one for the delta rows of all clips
+template <typename T>
+static int run_wg(paa_plan *p, const void *d_packed, double *d_out) {
+    const PlanDev &P = p->P;
+    const size_t need = (size_t)p->wg_rows * ((size_t)P.Nf * 8 + 24) + 256;
+    if (need > p->big_bytes) {
+        if (p->d_big) { HIP_TRY(hipStreamSynchronize(cs())); (void)hipFree(p->d_big); p->d_big = nullptr; p->big_bytes = 0; }
+        HIP_TRY(hipMalloc(&p->d_big, need));
+        p->big_bytes = need;
+    }
+    double *spec = reinterpret_cast<double *>(p->d_big);
+    double *tfeat = spec + (size_t)p->wg_rows * P.Nf;
+    static LdsAttrCache attr;
+    if (!attr.covers((size_t)p->wl.lds_bytes)) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wg::wg_spectrum_kernel<T>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, p->wl.lds_bytes));
+        attr.set((size_t)p->wl.lds_bytes);
+    }
+    for (const auto &ch : p->wg_chunks) {
+        const unsigned n = (unsigned)(ch.second - ch.first);
+        const wg::FrameRef *fr = p->d_wg_frames + ch.first;
+        ProfScope prof_scope;          // (bench.py's event pairs bracket the spectrum kernel: the dominant one of this path)
+        { const int rc_p = prof_scope.begin(); if (rc_p) return rc_p; }
+        hipLaunchKernelGGL(wg::wg_spectrum_kernel<T>, dim3(n), dim3(wg::kThreads), (size_t)p->wl.lds_bytes, cs(), P, p->wl,
+                           p->d_wg_perm, (const T *)d_packed, p->d_clips, p->d_norms, fr, spec, tfeat, d_out);
+        if (prof_scope.stop) { (void)hipEventRecord(prof_scope.stop, cs()); prof_scope.stop = nullptr; }
+        if (P.mode != 1)
+            hipLaunchKernelGGL(wg::wg_feat_kernel, dim3(n), dim3(wg::kFeatThreads), 0, cs(), P, fr, p->d_clips, spec, tfeat, d_out);
+        HIP_TRY(hipGetLastError());
+    }
+    if (P.mode == 0 && P.deltas) {
+        long long maxT = 0;
+        for (auto &cd : p->clips) maxT = std::max<long long>(maxT, cd.T);
+        const long long gx = ((long long)kBase * maxT + 255) / 256;
+        if (gx > 0x7fffffffLL || p->n_clips > 65535)
+            return fail(PAA_ERR_UNSUPPORTED, "delta grid too large (%lld clips)", (long long)p->n_clips);
+        hipLaunchKernelGGL(wg::wg_delta_kernel, dim3((unsigned)gx, (unsigned)p->n_clips), dim3(256), 0, cs(), p->d_clips, d_out);
+        HIP_TRY(hipGetLastError());
+    }
+    return PAA_OK;
+}
+
 extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *d_out) {
     if (!plan || !d_packed || !d_out) return fail(PAA_ERR_ARG, "null plan / buffer");
     { const int rc_init = ensure_init(); if (rc_init) return rc_init; }
@@ -393,6 +475,9 @@ extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *
     if (rc) return rc;
     rc = launch_stats(plan, d_packed);
     if (rc) return rc;
+    if (plan->wg)
+        return plan->sample_kind == 0 ? run_wg<int16_t>(plan, d_packed, d_out)
+             : plan->sample_kind == 2 ? run_wg<stereo16>(plan, d_packed, d_out) : run_wg<double>(plan, d_packed, d_out);
     if (plan->big)
         return plan->sample_kind == 0 ? run_big<int16_t>(plan, d_packed, d_out)
              : plan->sample_kind == 2 ? run_big<stereo16>(plan, d_packed, d_out) : run_big<double>(plan, d_packed, d_out);

@@ -25,6 +25,7 @@
 #include "family_launch.hpp"
 #include "kernels_aux.hpp"
 #include "kernels_big.hpp"
+#include "kernels_wg.hpp"
 #include "kernels_sim.hpp"
 #include "kernels_svm.hpp"
 #include "tables.hpp"

@@ -430,7 +430,7 @@ def test_three_pass_tables_reproduce_the_fft(window):
     assert N == (window // 2 if packed else window) and (packed == 1) == (window % 2 == 0 and window != 1102)
     assert R3 <= 8
     L1, NQ1, NF = R2 * R3, (R1 if packed else (R1 + 1) // 2), window // 2
-    assert P >= L1 and NQ1 * R3 <= 64 and lds <= 160 * 1024 and 7 <= NW <= 8
+    assert P >= L1 and NQ1 * R3 <= 64 and lds <= 160 * 1024 and 7 <= NW <= 12
     cplx = lambda o, n: blob[o:o + 16 * n].view(np.float64).reshape(n, 2) @ np.array([1.0, 1j])
     tw2 = cplx(off[0], R2 * R3).reshape(R2, R3)
     tw1 = cplx(off[2], NQ1 * L1).reshape(NQ1, L1)

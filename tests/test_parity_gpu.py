@@ -268,7 +268,7 @@ def test_size_independent_properties_at_scale(gpu_lib, minutes):
     # (the contract exactly as assert_parity applies it: the row term is 1e-6 of the ROW's scale over the whole clip -- the 13 MFCC
     # rows share one -- not of the one column that is compared here)
     scale = np.max(np.abs(F[:34]), axis=1)
-    scale[O.MFCC_ROWS] = scale[O.MFCC_ROWS].max()
+    scale[list(O.MFCC_ROWS)] = scale[list(O.MFCC_ROWS)].max()
     for t in (0, 1, 31, 32, 33, 5000, T - 1):
         fr = xn[t * S:t * S + W]
         X = O.magnitude_spectrum(fr, tab.nfft)
@@ -344,10 +344,69 @@ def test_delta_rows_reformed_on_the_device_equal_the_68_row_plan(gpu_lib):
         p68.destroy()
 
 
+def test_big_window_kernel_choice(gpu_lib):
+    """Windows beyond the one-wave kernels: the transform runs in ONE WORKGROUP's LDS when it fits (kernels_wg.hpp: up to 10 000
+    complex points made of 2, 3, 5, 7, 11, 13), otherwise through HBM scratch (kernels_big.hpp).  No window falls back to the CPU."""
+    def name(fs, w, s, mode=0):
+        plan = _ffi.Plan(np.array([0, 4 * w], dtype=np.int64), fs, w, s, deltas=False, mode=mode)
+        try:
+            return plan.kernel_name
+        finally:
+            plan.destroy()
+    assert name(16000, 16000, 8000) == "st_wg_lds_fft"                 # music_thumbnailing's 1 s window (audioSegmentation.py:1137)
+    assert name(16000, 8000, 4000, mode=1) == "spectrogram_wg_lds_fft"
+    assert name(16000, 8000, 4000, mode=2) == "chromagram_wg_lds_fft"
+    assert name(16000, 9009, 4500) == "st_wg_lds_fft"                  # odd: 9009 = 7 x 9 x 11 x 13 real points, 144 KB of LDS
+    assert name(44100, 44100, 22050) == "big_window_hbm_passes"        # 22 050 complex points: 353 KB
+    assert name(16000, 9001, 4500) == "big_window_hbm_passes"          # prime
+
+
+@pytest.mark.parametrize("kind,fs,window,step,seconds,deltas", [
+    ("i16", 16000, 16000, 8000, 12.0, True),     # the music_thumbnailing shape, 23 frames
+    ("stereo", 16000, 8000, 4000, 9.0, True),    # interleaved stereo samples summed in the loads
+    ("f64", 22050, 11000, 5000, 6.0, False),     # 5500 complex points = 4 x 5 x 5 x 5 x 11, float64 samples
+    ("f64", 8000, 8000, 8000, 9.0, False),       # 1 s at 8 kHz, float64 samples
+    ("i16", 16000, 9009, 3000, 4.0, True),       # odd window: real points, radices 13 11 7 3 3
+    ("i16", 16000, 20000, 10000, 6.0, False),    # the edge of the LDS: 10 000 complex points = 160 000 bytes
+])
+def test_workgroup_lds_kernel_full_matrix(gpu_lib, kind, fs, window, step, seconds, deltas):
+    """kernels_wg.hpp against the NumPy oracle, every frame and row, every sample type (contract + tight gate)."""
+    from test_ct_kernels_gpu import make_signal
+    sig, mono = make_signal(kind, 7000 + window, seconds, fs)
+    ref, _ = O.feature_extraction(mono, fs, window, step, deltas)
+    got, _ = ShortTermFeatures.feature_extraction(sig, fs, window, step, deltas)
+    assert_parity(got, ref, "%s %d/%d@%d" % (kind, window, step, fs), sig=(mono, fs, window, step))
+    if deltas:
+        assert np.array_equal(got[34:, 1:], got[:34, 1:] - got[:34, :-1]) and np.all(got[34:, 0] == 0.0)
+
+
+def test_workgroup_lds_kernel_batches_and_rows(gpu_lib, capsys):
+    """A ragged batch through one plan (frames of all clips in one launch) equals the single-clip calls bit for bit; the
+    spectrogram / chromagram rows of a big window against the oracle (incl. the chromagram's truncated tail frame)."""
+    fs, W, S = 16000, 8000, 4000
+    lens = [W, 3 * W + 17, 2 * W - 1, 40000, W + S]
+    clips = [synth_clip(6100 + i, n, fs) for i, n in enumerate(lens)]
+    res, _ = ShortTermFeatures.feature_extraction_batch(clips, fs, W, S, deltas=True)
+    for c, r in zip(clips, res):
+        single, _ = ShortTermFeatures.feature_extraction(c, fs, W, S)
+        assert np.array_equal(single, r)
+        ref, _ = O.feature_extraction(c, fs, W, S)
+        assert_parity(r, ref, "ragged big-window batch", sig=(c, fs, W, S))
+    x = synth_clip(6200, 7 * fs + 123, fs)
+    spec, t_ax, f_ax = ShortTermFeatures.spectrogram(x, fs, W, S)
+    capsys.readouterr()
+    ref_s, _, _ = O.spectrogram(x, fs, W, S)
+    assert_parity(np.ascontiguousarray(spec.T), np.ascontiguousarray(ref_s.T), "big-window spectrogram")
+    chroma, _, _ = ShortTermFeatures.chromagram(x, fs, W, S)
+    ref_c, _, _ = O.chromagram(x, fs, W, S)
+    assert_parity(np.ascontiguousarray(chroma.T), np.ascontiguousarray(ref_c.T), "big-window chromagram")
+
+
 @pytest.mark.parametrize("fs,window,step,seconds", [
-    (16000, 8000, 4000, 6.0),       # 0.5 s window: beyond the LDS envelope -> Stockham passes through HBM scratch
+    (16000, 8000, 4000, 6.0),       # 0.5 s window: beyond the one-wave kernels -> one workgroup per frame (kernels_wg.hpp)
     (16000, 16000, 16000, 8.0),     # 1 s / 1 s, the music_thumbnailing shape (audioSegmentation.py:1137)
-    (16000, 9001, 4500, 3.0),       # odd prime window: one O(N^2) pass
+    (16000, 9001, 4500, 3.0),       # odd prime window: Stockham passes through HBM scratch, one O(N^2) pass
+    (44100, 44100, 22050, 3.0),     # 1 s at 44.1 kHz: 22 050 complex points do not fit the LDS -> HBM passes
 ])
 def test_big_windows_match_oracle(gpu_lib, fs, window, step, seconds):
     x = synth_clip(700 + window, int(seconds * fs), fs=fs)
