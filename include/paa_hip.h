@@ -250,7 +250,7 @@ int paa_debug_fft_plan(int window, int32_t *radices, int32_t *fft_len);
 /* file name (inside PAA_COMM_MARKER_DIR / TMPDIR) of the one-process-per-GPU marker that `rank` of the job `unique_id`
  * drops for the selected device before RCCL is called (comm_rccl.hpp); needs a device                                */
 int paa_debug_comm_marker_name(const void *unique_id, int rank, char *out, int capacity);
-/* three-pass register-FFT kernels (csrc/kernels_tri.hpp), host only: shape8 = {R1, R2, R3, packed, plane row pitch P, waves per
+/* three-pass register-FFT kernels (csrc/kernels_tri.hpp), host only: shape8 = {R1, R2, R3, packed | group pitch of the second exchange << 8, plane row pitch P, waves per
  * workgroup, pass-3 lane jobs, LDS bytes}, offsets6 = byte offsets {tw2, p3, g_tw1, g_post, table_bytes, total_bytes} into the
  * table blob (spectrogram mode: no mel / chroma lists), which is copied to `blob` when that is not NULL.  Returns the blob
  * size, 0 when the window goes to another kernel                                                                     */

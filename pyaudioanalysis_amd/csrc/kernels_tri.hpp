@@ -60,9 +60,12 @@ constexpr int pair_count(int R1, int R2, int R3) {
     return pairs;
 }
 
-template <int R1_, int R2_, int R3_, bool PACKED_, int P_, int NW_>
+template <int R1_, int R2_, int R3_, bool PACKED_, int P_, int NW_, int R3P_ = R3_>
 struct Shape {
     static constexpr int R1 = R1_, R2 = R2_, R3 = R3_, P = P_, NW = NW_;
+    // second exchange: element (q1, b, q2) sits at plane[q1 P + q2 R3P + b]; R3P = R3 + 1 for the radix-8 last pass (the jobs of a
+    // pass-3 read group then hit 32 different bank pairs: q2 R3 = 8 q2 repeats every four jobs)
+    static constexpr int R3P = R3P_;
     static constexpr bool PACKED = PACKED_;
     static constexpr int N = R1 * R2 * R3;                  // transform length
     static constexpr int W = PACKED ? 2 * N : N, NF = W / 2;
@@ -90,7 +93,7 @@ struct Shape {
     // ... in a scratch of its own for the small windows
     static constexpr int TSCR = (SLOT >= 11 * 65) ? 0 : 11 * 65;
     static constexpr int WAVE_DOUBLES = 2 * SLOT + 48 + 40 + 12 + TSCR;   // two slots, fv[48], msp[40], bnd[12], scratch
-    static_assert(P >= L1, "plane rows hold L1 elements");
+    static_assert(P >= L1 && P >= (R2 - 1) * R3P + R3 && R3P >= R3, "plane rows hold L1 elements (first exchange) and R2 groups of R3 (second)");
     static_assert(J2 <= 64, "one pass-2 job per lane");
     static_assert(!PACKED || NJ == 1, "packed shapes: one pass-1 job per lane");
     static_assert(PACKED || (R1 % 2 == 1), "real-input shapes: odd first radix");
@@ -905,7 +908,7 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
             unsigned char *plb = reinterpret_cast<unsigned char *>(cur);
             if (act2) {
 #pragma unroll
-                for (int q = 0; q < R2; ++q) pl[q1_2 * PP + q * R3 + b_2] = c2[Cd<R2>::pos(q)].x;
+                for (int q = 0; q < R2; ++q) pl[q1_2 * PP + q * SH::R3P + b_2] = c2[Cd<R2>::pos(q)].x;
             }
             wsync();
 #pragma unroll
@@ -918,7 +921,7 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
             wsync();
             if (act2) {
 #pragma unroll
-                for (int q = 0; q < R2; ++q) pl[q1_2 * PP + q * R3 + b_2] = c2[Cd<R2>::pos(q)].y;
+                for (int q = 0; q < R2; ++q) pl[q1_2 * PP + q * SH::R3P + b_2] = c2[Cd<R2>::pos(q)].y;
             }
             wsync();
 #pragma unroll
@@ -970,7 +973,7 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
             unsigned char *plb = reinterpret_cast<unsigned char *>(cur);
             if (act2) {
 #pragma unroll
-                for (int q = 0; q < R2; ++q) pl[q1_2 * PP + q * R3 + b_2] = c2[Cd<R2>::pos(q)].x;
+                for (int q = 0; q < R2; ++q) pl[q1_2 * PP + q * SH::R3P + b_2] = c2[Cd<R2>::pos(q)].x;
             }
             wsync();
 #pragma unroll
@@ -982,7 +985,7 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
             wsync();
             if (act2) {
 #pragma unroll
-                for (int q = 0; q < R2; ++q) pl[q1_2 * PP + q * R3 + b_2] = c2[Cd<R2>::pos(q)].y;
+                for (int q = 0; q < R2; ++q) pl[q1_2 * PP + q * SH::R3P + b_2] = c2[Cd<R2>::pos(q)].y;
             }
             wsync();
 #pragma unroll
@@ -1059,14 +1062,15 @@ typedef Shape<29, 19, 1, false, 19, 8> S551;        // 50 ms at 11.025 kHz / 25 
 typedef Shape<29, 19, 2, false, 38, 8> S1102;       // 25 ms at 44.1 kHz (BASELINE config 5) / 50 ms at 22.05 kHz: 1102 real points
 // power-of-two windows (what callers outside the reference's 50 ms default pass most often, ShortTermFeatures.py:563-564 takes any
 // window): every pass on all 64 lanes where the factorisation allows it.  Plane row pitches from scripts/dev/tri_model.py's LDS
-// model (ds_write_b64: 16-lane groups mod 16 doubles, ds_read_b64: 32-lane groups mod 32): P = 69 makes both exchanges of the
-// radix-8 shapes cost 176 LDS cycles per plane against 112 conflict-free (P = 64: 312), P = 68 is the best pitch of 16 x 16 x 4
+// model (ds_write_b64: 16-lane groups mod 16 doubles, ds_read_b64: 32-lane groups mod 32): the radix-8 shapes use row pitch 72
+// and group pitch 9 in the second exchange -- the two exchanges then cost 48 + 80 LDS cycles per plane against 48 + 64 conflict-free
+// (row pitch 64, group pitch 8: 312; 69 / 8, the first version: 176, measured conflict ratio 0.36); P = 68 is the best pitch of 16 x 16 x 4
 #ifndef PAA_NW_1024
 #define PAA_NW_1024 11              // (A/B builds of scripts/rounds/r05: 8 / 10 / 11 waves per workgroup)
 #endif
-typedef Shape<8, 8, 8, true, 69, PAA_NW_1024> S1024;          // 512 complex points: 64 x radix 8, three times
+typedef Shape<8, 8, 8, true, 72, PAA_NW_1024, 9> S1024;          // 512 complex points: 64 x radix 8, three times
 typedef Shape<16, 16, 4, true, 68, 7> S2048;        // 1024 complex points
-typedef Shape<4, 8, 8, true, 69, 12> S512;           // 256 complex points (odd entropy blocks: 51 samples)
+typedef Shape<4, 8, 8, true, 72, 12, 9> S512;           // 256 complex points (odd entropy blocks: 51 samples)
 
 struct TriLaunch {
     int shape = -1;                 // index into the shape list above
@@ -1147,8 +1151,8 @@ inline void tri_fill(double fs, const MelTable *mel, const ChromaTable *chroma, 
                 const int p1 = m % R1, p2 = (m / R1) % R2;
                 if (!(p1 > q1 || (p1 == q1 && p2 >= q2))) continue;
                 const bool self = (p1 == q1 && p2 == q2);
-                pt[E * p] = (unsigned short)(8 * (q1 * SH::P + q2 * R3));
-                pt[E * p + 1] = (unsigned short)(8 * (p1 * SH::P + p2 * R3));
+                pt[E * p] = (unsigned short)(8 * (q1 * SH::P + q2 * SH::R3P));
+                pt[E * p + 1] = (unsigned short)(8 * (p1 * SH::P + p2 * SH::R3P));
                 for (int k3 = 0; k3 < NK; ++k3) {
                     const int kk = k + R1 * R2 * k3;
                     const bool put_k = k3 < R3 && (!self || 2 * kk <= N);                    // X[k]
@@ -1176,7 +1180,7 @@ inline void tri_fill(double fs, const MelTable *mel, const ChromaTable *chroma, 
             for (int m3 = 0; m3 < 64 * NR3; ++m3) {
                 const int q1 = m3 / R2, q2 = m3 % R2;
                 const bool act = m3 < SH::NJOB3;
-                pt[8 * m3] = (unsigned short)(act ? 8 * (q1 * SH::P + q2 * R3) : 0);
+                pt[8 * m3] = (unsigned short)(act ? 8 * (q1 * SH::P + q2 * SH::R3P) : 0);
                 for (int k3 = 0; k3 < 7; ++k3)
                     pt[8 * m3 + 1 + k3] = (unsigned short)((act && k3 < R3) ? where(q1, q1 + R1 * (q2 + R2 * k3)) : 8 * NF);
             }

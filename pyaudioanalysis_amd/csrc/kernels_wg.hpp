@@ -6,11 +6,11 @@
 //                       10 000 complex points, i.e. windows up to 20 000 samples even / 10 000 odd); zero-crossing count,
 //                       energy and the ten entropy-block energies straight from that buffer (every wave a contiguous eighth of
 //                       the frame); the in-place decimation-in-frequency passes of kernels_mix.hpp (radix 16 / 8 / 4 / 2 / 13 /
-//                       11 / 7 / 5 / 3 butterflies in registers, one __syncthreads per pass, twiddles from the L2-resident
-//                       table); real-FFT recombination + |X| / num_fft read through the digit-reversal permutation and written
+//                       11 / 7 / 5 / 3 butterflies in registers, two per lane in flight, one __syncthreads per pass, twiddles as the
+//                       product of two LDS-resident factors W^(128 h) W^l -- no global load inside a pass); real-FFT recombination + |X| / num_fft read through the digit-reversal permutation and written
 //                       ONCE to the frame's spectrum row in HBM (for spectrogram plans: straight into the output)
-//   wg_feat_kernel      256 threads, one frame: the 34 features from the frame's and the previous frame's spectrum rows
-//                       (L2 / HBM), every sweep spread over the workgroup (block energies per block range, mel filters and
+//   wg_feat_kernel      512 threads, one frame: the frame's and the previous frame's spectrum rows are staged in LDS (all loads in
+//                       flight at once), then the 34 features with every sweep spread over the workgroup (block energies per block range, mel filters and
 //                       chroma classes one wave at a time with all 64 lanes on the filter's bins)
 //   wg_delta_kernel     rows 34..67 of every clip
 //
@@ -26,14 +26,19 @@ namespace wg {
 
 constexpr int kThreads = 512;           // spectrum kernel: eight waves, two per SIMD (256 registers each: radix-16 / 13 butterflies fit)
 constexpr int kWaves = kThreads / 64;
-constexpr int kFeatThreads = 256;
+constexpr int kFeatThreads = 512;
 constexpr int kFeatWaves = kFeatThreads / 64;
+constexpr int kTwLo = 128;              // two-level twiddles: W^m = W^(128 (m >> 7)) W^(m & 127), both factors in LDS
 
 struct WgLayout {
     int n_pass;
     int radix[mix::kMaxPass], span[mix::kMaxPass], tws[mix::kMaxPass];
     unsigned magic[mix::kMaxPass];
-    int lds_bytes;
+    int off_red, off_twlo, off_twhi, off_perm;      // byte offsets into the LDS behind the Nc x 16 transform buffer
+    int n_twhi;
+    int perm_lds;                   // 1: the digit-reversal permutation fits the LDS beside the buffer
+    int lds_bytes;                  // spectrum kernel
+    int feat_lds_bytes;             // feature kernel: the frame's and the previous frame's spectrum rows + 1 KB
 };
 // one frame of the launch: its clip, its index in the clip, the row of the spectrum scratch it writes, and whether it is only
 // there to provide the previous spectrum of the next one (a chunk that starts inside a clip)
@@ -41,24 +46,75 @@ struct FrameRef {
     int clip, t, row, halo;
 };
 
+struct Tw2 {
+    const double2 *lo, *hi;
+    __device__ __forceinline__ double2 get(int m) const { return cmul(hi[m >> 7], lo[m & (kTwLo - 1)]); }
+};
+
+// U butterflies of one in-place DIF pass per lane (kernels_mix.hpp's dif_batch with the twiddles from the two LDS tables):
+// butterfly b works on the R elements base + r * stride of its block; output q is multiplied by W_M^(q k) and goes back to
+// base + q * stride.  Butterflies touch disjoint elements: no ordering inside a pass.
+template <int R, int U>
+__device__ __forceinline__ void wg_dif_batch(double2 *buf, int nb, int stride, int M, int tws, unsigned magic, const Tw2 &tw, int b0) {
+    double2 v[U][R];
+    int base[U], t1[U];
+    bool act[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int b = b0 + kThreads * u;
+        act[u] = b < nb;
+        const int be = act[u] ? b : nb - 1;                     // (lanes past the end shadow a valid butterfly, stores masked)
+        const int blk = (stride == 1) ? be : (int)__umulhi((unsigned)be, magic);
+        const int k = be - __mul24(blk, stride);
+        base[u] = __mul24(blk, M) + k;
+        t1[u] = __mul24(k, tws);
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[u][r] = buf[base[u] + r * stride];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        mix::Bfly<R>::run(v[u]);
+        if (stride > 1) {
+#pragma unroll
+            for (int q0 = 1; q0 < R; q0 += 4) {
+                double2 wl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (q0 + j < R) wl[j] = tw.get((q0 + j) * t1[u]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (q0 + j < R) v[u][mix::Bfly<R>::pos(q0 + j)] = cmul(v[u][mix::Bfly<R>::pos(q0 + j)], wl[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (act[u]) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) buf[base[u] + q * stride] = v[u][mix::Bfly<R>::pos(q)];
+        }
+    }
+}
 template <int R>
-__device__ __forceinline__ void wg_dif_pass(double2 *buf, int Nc, int M, int tws, unsigned magic, const double2 *__restrict__ tw,
-                                            int tid) {
+__device__ __forceinline__ void wg_dif_pass(double2 *buf, int Nc, int M, int tws, unsigned magic, const Tw2 &tw, int tid) {
+    constexpr int U = (R <= 8) ? 2 : 1;          // two butterflies in flight per lane where the registers allow it
     const int stride = M / R, nb = Nc / R;
-    // (wave-uniform trip count: a wave whose first butterfly exists runs the batch, lanes past the end shadow a valid one)
-    for (int b0 = tid; (b0 & ~63) < nb; b0 += kThreads) mix::dif_batch<R, 1>(buf, nb, stride, M, tws, magic, tw, b0, -1);
+    // (wave-uniform trip count: a wave whose first butterfly exists runs the batch)
+    for (int b0 = tid; (b0 & ~63) < nb; b0 += U * kThreads) wg_dif_batch<R, U>(buf, nb, stride, M, tws, magic, tw, b0);
 }
 
-// MODE-independent: P.mode decides where the row goes and whether the time-domain features are formed
+// P.mode decides where the row goes and whether the time-domain features are formed
 template <typename T>
-__global__ __launch_bounds__(kThreads) void wg_spectrum_kernel(PlanDev P, WgLayout L, const unsigned short *__restrict__ perm,
+__global__ __launch_bounds__(kThreads) void wg_spectrum_kernel(PlanDev P, WgLayout L, const unsigned short *__restrict__ perm_g,
                                                                const T *__restrict__ sig, const ClipDev *__restrict__ clips,
                                                                const ClipNorm *__restrict__ norms,
                                                                const FrameRef *__restrict__ frames, double *__restrict__ spec,
                                                                double *__restrict__ tfeat, double *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double2 *buf = reinterpret_cast<double2 *>(smem);
-    double *red = reinterpret_cast<double *>(smem + (size_t)P.Nc * 16);        // [kWaves][5]
+    double *red = reinterpret_cast<double *>(smem + L.off_red);        // [kWaves][5]
+    double2 *twlo = reinterpret_cast<double2 *>(smem + L.off_twlo), *twhi = reinterpret_cast<double2 *>(smem + L.off_twhi);
+    unsigned short *perm_l = reinterpret_cast<unsigned short *>(smem + L.off_perm);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const FrameRef fr = frames[blockIdx.x];
     const ClipDev c = clips[fr.clip];
@@ -66,11 +122,23 @@ __global__ __launch_bounds__(kThreads) void wg_spectrum_kernel(PlanDev P, WgLayo
     const T *x = sig + c.sample_off + P.frame_origin + (long long)fr.t * P.S;
     const int W = P.W, Nc = P.Nc, Nf = P.Nf;
     const double sc = sample_scale<T>();
+    // ---- tables: the two twiddle factors (and the permutation when it fits)
+    if (tid < kTwLo) twlo[tid] = P.tw[tid < Nc ? tid : 0];
+    if (tid >= 256 && tid - 256 < L.n_twhi) twhi[tid - 256] = P.tw[(tid - 256) * kTwLo];
+    if (L.perm_lds) {
+        const unsigned *src = reinterpret_cast<const unsigned *>(perm_g);
+        unsigned *dst = reinterpret_cast<unsigned *>(perm_l);
+        for (int i = tid; i < (Nc + 1) / 2; i += kThreads) dst[i] = src[i];
+    }
     // ---- load: y = (x / 2^15 - mean) / (max|.| + 1e-10) (ShortTermFeatures.py:567-570); even windows packed two samples per point
     if (P.even) {
-        double *y = reinterpret_cast<double *>(buf);
-        for (int n = tid; n < W; n += kThreads) y[n] = fma(load_sample<T>(x + n), sc, -nm.mean) * nm.inv;
+#pragma unroll 4
+        for (int p = tid; p < Nc; p += kThreads) {
+            const double2 xx = ct::PairLoad<T>::get(x + 2 * p);
+            buf[p] = make_double2(fma(xx.x, sc, -nm.mean) * nm.inv, fma(xx.y, sc, -nm.mean) * nm.inv);
+        }
     } else {
+#pragma unroll 4
         for (int n = tid; n < W; n += kThreads) buf[n] = make_double2(fma(load_sample<T>(x + n), sc, -nm.mean) * nm.inv, 0.0);
     }
     __syncthreads();
@@ -86,16 +154,15 @@ __global__ __launch_bounds__(kThreads) void wg_spectrum_kernel(PlanDev P, WgLayo
         const int bnd1 = (b0 < 10) ? (b0 + 1) * LT : 0x7fffffff, bnd2 = (b0 + 1 < 10) ? (b0 + 2) * LT : 0x7fffffff;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
         int zc = 0;
+#pragma unroll 4
         for (int n = n0 + lane; n < n1; n += 64) {
             const double v = y[n * st];
+            const double u = y[max(n - 1, 0) * st];          // (n = 0 meets itself: no sign change)
             const double e = v * v;
             a0 += (n < bnd1) ? e : 0.0;
             a1 += (n >= bnd1 && n < bnd2) ? e : 0.0;
             a2 += (n >= bnd2) ? e : 0.0;
-            if (n > 0) {
-                const double u = y[(n - 1) * st];
-                zc += abs(((v > 0.0) - (v < 0.0)) - ((u > 0.0) - (u < 0.0)));
-            }
+            zc += abs(((v > 0.0) - (v < 0.0)) - ((u > 0.0) - (u < 0.0)));
         }
         a0 = wsum(a0); a1 = wsum(a1); a2 = wsum(a2);
         zc = wsum_i(zc);
@@ -121,42 +188,59 @@ __global__ __launch_bounds__(kThreads) void wg_spectrum_kernel(PlanDev P, WgLayo
             tfp[0] = e_tot; tfp[1] = ent; tfp[2] = zct;
         }
     }
-    // ---- in-place DIF passes (kernels_mix.hpp's butterflies, one per lane and iteration; two waves per SIMD hide the latency)
+    // ---- in-place DIF passes (kernels_mix.hpp's butterflies; two waves per SIMD and two butterflies per lane hide the latency)
+    const Tw2 tw = {twlo, twhi};
     for (int p = 0; p < L.n_pass; ++p) {
         const int M = L.span[p], ts = L.tws[p];
         const unsigned mg = L.magic[p];
         switch (L.radix[p]) {
-            case 2: wg_dif_pass<2>(buf, Nc, M, ts, mg, P.tw, tid); break;
-            case 3: wg_dif_pass<3>(buf, Nc, M, ts, mg, P.tw, tid); break;
-            case 4: wg_dif_pass<4>(buf, Nc, M, ts, mg, P.tw, tid); break;
-            case 5: wg_dif_pass<5>(buf, Nc, M, ts, mg, P.tw, tid); break;
-            case 7: wg_dif_pass<7>(buf, Nc, M, ts, mg, P.tw, tid); break;
-            case 8: wg_dif_pass<8>(buf, Nc, M, ts, mg, P.tw, tid); break;
-            case 11: wg_dif_pass<11>(buf, Nc, M, ts, mg, P.tw, tid); break;
-            case 13: wg_dif_pass<13>(buf, Nc, M, ts, mg, P.tw, tid); break;
-            default: wg_dif_pass<16>(buf, Nc, M, ts, mg, P.tw, tid); break;
+            case 2: wg_dif_pass<2>(buf, Nc, M, ts, mg, tw, tid); break;
+            case 3: wg_dif_pass<3>(buf, Nc, M, ts, mg, tw, tid); break;
+            case 4: wg_dif_pass<4>(buf, Nc, M, ts, mg, tw, tid); break;
+            case 5: wg_dif_pass<5>(buf, Nc, M, ts, mg, tw, tid); break;
+            case 7: wg_dif_pass<7>(buf, Nc, M, ts, mg, tw, tid); break;
+            case 8: wg_dif_pass<8>(buf, Nc, M, ts, mg, tw, tid); break;
+            case 11: wg_dif_pass<11>(buf, Nc, M, ts, mg, tw, tid); break;
+            case 13: wg_dif_pass<13>(buf, Nc, M, ts, mg, tw, tid); break;
+            default: wg_dif_pass<16>(buf, Nc, M, ts, mg, tw, tid); break;
         }
         __syncthreads();
     }
     // ---- |X| / num_fft (:617-621) through the digit-reversal permutation, written once to the frame's row
     double *row = (P.mode == 1) ? out + c.out_off + (long long)fr.t * Nf : spec + (long long)fr.row * Nf;
     const double invNf = 1.0 / (double)Nf;
+    const unsigned short *perm = L.perm_lds ? perm_l : perm_g;
     if (P.even) {
         // bins k and Nc - k from one pair: X[k] = E + w^k O, X[Nc - k] = conj(E - w^k O), E = (Z[k] + conj Z[Nc - k]) / 2,
-        // O = -i (Z[k] - conj Z[Nc - k]) / 2
+        // O = -i (Z[k] - conj Z[Nc - k]) / 2; four pairs in flight per lane
         const int npairs = Nc / 2 + 1;
-        for (int k = tid; k < npairs; k += kThreads) {
-            const double2 zk = buf[perm[k]];
-            const double2 zm = buf[perm[k == 0 ? 0 : Nc - k]];
-            const double2 pw = P.post[k];
-            const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
-            const double2 o = make_double2(0.5 * (zk.y + zm.y), 0.5 * (zm.x - zk.x));
-            const double2 wo = cmul(pw, o);
-            const double ar = e.x + wo.x, ai = e.y + wo.y, br = e.x - wo.x, bi = e.y - wo.y;
-            row[k] = mag_sqrt(fma(ar, ar, ai * ai)) * invNf;
-            if (k > 0 && Nc - k != k) row[Nc - k] = mag_sqrt(fma(br, br, bi * bi)) * invNf;
+        for (int k0 = tid; (k0 & ~63) < npairs; k0 += 4 * kThreads) {
+            int kk[4], pa[4], pb[4];
+            double2 pw[4], zk[4], zm[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                kk[u] = min(k0 + u * kThreads, npairs - 1);
+                pw[u] = P.post[kk[u]];
+                pa[u] = L.perm_lds ? perm_l[kk[u]] : perm_g[kk[u]];
+                pb[u] = L.perm_lds ? perm_l[kk[u] == 0 ? 0 : Nc - kk[u]] : perm_g[kk[u] == 0 ? 0 : Nc - kk[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { zk[u] = buf[pa[u]]; zm[u] = buf[pb[u]]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = kk[u];
+                const double2 e = make_double2(0.5 * (zk[u].x + zm[u].x), 0.5 * (zk[u].y - zm[u].y));
+                const double2 o = make_double2(0.5 * (zk[u].y + zm[u].y), 0.5 * (zm[u].x - zk[u].x));
+                const double2 wo = cmul(pw[u], o);
+                const double ar = e.x + wo.x, ai = e.y + wo.y, br = e.x - wo.x, bi = e.y - wo.y;
+                if (k0 + u * kThreads < npairs) {
+                    row[k] = mag_sqrt(fma(ar, ar, ai * ai)) * invNf;
+                    if (k > 0 && Nc - k != k) row[Nc - k] = mag_sqrt(fma(br, br, bi * bi)) * invNf;
+                }
+            }
         }
     } else {
+#pragma unroll 4
         for (int k = tid; k < Nf; k += kThreads) {
             const double2 z = buf[perm[k]];
             row[k] = mag_sqrt(fma(z.x, z.x, z.y * z.y)) * invNf;
@@ -164,33 +248,49 @@ __global__ __launch_bounds__(kThreads) void wg_spectrum_kernel(PlanDev P, WgLayo
     }
 }
 
-// sum / max over the workgroup: every wave's total through LDS (slots [4]); all threads return the same bits
-__device__ __forceinline__ double bsum4(double v, double *slot, int lane, int wave) {
+// sum over the workgroup: every wave's total through LDS (slot[kFeatWaves]); all threads return the same bits
+__device__ __forceinline__ double bsum8(double v, double *slot, int lane, int wave) {
     v = wsum(v);
     if (lane == 0) slot[wave] = v;
     __syncthreads();
-    const double r = (slot[0] + slot[1]) + (slot[2] + slot[3]);
+    const double r = ((slot[0] + slot[1]) + (slot[2] + slot[3])) + ((slot[4] + slot[5]) + (slot[6] + slot[7]));
     __syncthreads();
     return r;
 }
 
-// the 34 features (or the 12 chromagram values) of one frame from its spectrum row and the previous frame's
+// the 34 features (or the 12 chromagram values) of one frame from its spectrum row and the previous frame's: both rows are
+// staged in LDS first (16 independent loads per lane and row), every sweep then runs from there
 __global__ __launch_bounds__(kFeatThreads) void wg_feat_kernel(PlanDev P, const FrameRef *__restrict__ frames,
                                                               const ClipDev *__restrict__ clips, const double *__restrict__ spec,
                                                               const double *__restrict__ tfeat, double *__restrict__ out) {
-    __shared__ double fv[48], msp[40], red[kFeatWaves * 16], slot[kFeatWaves];
-    __shared__ int redi[kFeatWaves];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const FrameRef fr = frames[blockIdx.x];
     if (fr.halo) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const ClipDev c = clips[fr.clip];
     const int Nf = P.Nf, W = P.W;
-    const double *cur = spec + (long long)fr.row * Nf;
-    const double *prv = (fr.t == 0) ? cur : cur - Nf;      // frames are laid out in clip order: the previous frame is the previous row
+    double *cur = reinterpret_cast<double *>(smem);
+    double *prv = cur + Nf;
+    double *fv = prv + Nf;               // [48]
+    double *msp = fv + 48;               // [40]
+    double *red = msp + 40;              // [kFeatWaves][16]
+    double *slot = red + kFeatWaves * 16;      // [kFeatWaves]
+    int *redi = reinterpret_cast<int *>(slot + kFeatWaves);
+    {
+        const double *gc = spec + (long long)fr.row * Nf;
+        const double *gp = (fr.t == 0) ? gc : gc - Nf;      // frames are laid out in clip order: the previous frame is the previous row
+#pragma unroll 8
+        for (int k = tid; k < Nf; k += kFeatThreads) cur[k] = gc[k];
+        if (P.mode == 0) {
+#pragma unroll 8
+            for (int k = tid; k < Nf; k += kFeatThreads) prv[k] = gp[k];
+        }
+    }
+    __syncthreads();
     double *oc = out + c.out_off;
     const long long Tc = c.T;
     const Tabs tb = tabs_global(P);
-    // ---- sweep A (:57-107): sums, maximum, the ten block energies + the tail, block range by block range (coalesced)
+    // ---- sweep A (:57-107): sums, maximum, the ten block energies + the tail, block range by block range
     const int LB = P.blk_f;
     double part[15];          // 0..9 blocks, 10 tail, 11 sum X, 12 sum X_prev, 13 sum (k + 1) X, 14 max
 #pragma unroll
@@ -218,8 +318,18 @@ __global__ __launch_bounds__(kFeatThreads) void wg_feat_kernel(PlanDev P, const 
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 14; ++i) part[i] = (red[i] + red[16 + i]) + (red[32 + i] + red[48 + i]);
-    part[14] = fmax(fmax(red[14], red[16 + 14]), fmax(red[32 + 14], red[48 + 14]));
+    for (int i = 0; i < 14; ++i) {
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < kFeatWaves; ++w) a += red[16 * w + i];
+        part[i] = a;
+    }
+    {
+        double m = 0.0;
+#pragma unroll
+        for (int w = 0; w < kFeatWaves; ++w) m = fmax(m, red[16 * w + 14]);
+        part[14] = m;
+    }
     __syncthreads();
     double sP = part[10];
 #pragma unroll
@@ -253,6 +363,7 @@ __global__ __launch_bounds__(kFeatThreads) void wg_feat_kernel(PlanDev P, const 
     const double cen = fast_div(sIX * r, den);
     const double rX = fast_div(1.0, sXe), rXp = fast_div(1.0, sXp);
     double sSp = 0.0, sFl = 0.0;
+#pragma unroll 4
     for (int k = tid; k < Nf; k += kFeatThreads) {
         const double X = cur[k];
         const double dv = (double)(k + 1) * f0 - cen;
@@ -260,15 +371,16 @@ __global__ __launch_bounds__(kFeatThreads) void wg_feat_kernel(PlanDev P, const 
         const double df = X * rX - prv[k] * rXp;
         sFl = fma(df, df, sFl);
     }
-    sSp = bsum4(sSp, slot, lane, wave);
-    sFl = bsum4(sFl, slot, lane, wave);
+    sSp = bsum8(sSp, slot, lane, wave);
+    sFl = bsum8(sFl, slot, lane, wave);
     const double spread = fast_sqrt(fast_div(sSp, den));
-    // ---- roll-off (:127-140): first k with cumsum(X^2)[k] + eps > 0.9 sum(X^2); contiguous chunks, workgroup-wide scan
+    // ---- roll-off (:127-140): first k with cumsum(X^2)[k] + eps > 0.9 sum(X^2); contiguous chunks of ODD length (a lane's
+    // chunk starts an odd number of doubles after its neighbour's: no LDS bank is hit twice), workgroup-wide scan
     int first = 0x7fffffff;
     {
         const double thr = 0.90 * sP;
-        const int cch = (Nf + kFeatThreads - 1) / kFeatThreads;
-        const int kb = tid * cch, ke = min(Nf, kb + cch);
+        const int cch = ((Nf + kFeatThreads - 1) / kFeatThreads) | 1;
+        const int kb = min(tid * cch, Nf), ke = min(Nf, kb + cch);
         double cs = 0.0;
         for (int k = kb; k < ke; ++k) { const double X = cur[k]; cs = fma(X, X, cs); }
         const double incl = wscan_incl(cs);
@@ -285,13 +397,16 @@ __global__ __launch_bounds__(kFeatThreads) void wg_feat_kernel(PlanDev P, const 
         first = wmin_i(first);
         if (lane == 0) redi[wave] = first;
         __syncthreads();
-        first = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+        first = redi[0];
+#pragma unroll
+        for (int w = 1; w < kFeatWaves; ++w) first = min(first, redi[w]);
     }
     // ---- MFCC (:236-254): filter by filter, one wave per filter, all lanes on the filter's bins
     for (int m = wave; m < 40; m += kFeatWaves) {
         const int lo = tb.mel_lo[m], cnt = tb.mel_cnt[m];
         const double *wv = tb.mel_w + tb.mel_off[m];
         double a = 0.0;
+#pragma unroll 4
         for (int i = lane; i < cnt; i += 64) a = fma(cur[lo + i], wv[i], a);
         a = wsum(a);
         if (lane == 0) msp[m] = fast_log10(a + kEps);
@@ -300,6 +415,7 @@ __global__ __launch_bounds__(kFeatThreads) void wg_feat_kernel(PlanDev P, const 
     for (int cls = wave; cls < 12; cls += kFeatWaves) {
         const int b = tb.ch_start[cls], e = tb.ch_start[cls + 1];
         double acc = 0.0;
+#pragma unroll 4
         for (int i = b + lane; i < e; i += 64) { const double xv = cur[tb.ch_src[i]]; acc = fma(xv * xv, tb.ch_w[i], acc); }
         acc = wsum(acc);
         if (lane == 0) fv[21 + cls] = (sP == 0.0) ? acc / kEps : fast_div(acc, sP);
@@ -352,12 +468,26 @@ __global__ __launch_bounds__(256) void wg_delta_kernel(const ClipDev *__restrict
 // ---- host: does the window fit, radix schedule, permutation ----------------------------------------------------------------
 // 1: the transform of this window runs in one workgroup's LDS (fills L and perm); 0: it does not (kernels_big.hpp keeps it)
 inline int wg_layout(const FftPlan &fft, WgLayout &L, std::vector<unsigned short> &perm) {
-    const int Nc = fft.len;
-    const size_t lds = (size_t)Nc * 16 + (size_t)kWaves * 5 * 8;
-    if (Nc < 64 || Nc > 65535 || lds > 160 * 1024) return 0;
+    const int Nc = fft.len, Nf = fft.window / 2;
+    if (Nc < 256 || Nc > 65535) return 0;
     std::vector<int> radix;
     if (!mix::mix_factor(Nc, radix)) return 0;
     memset(&L, 0, sizeof(L));
+    auto up16 = [](size_t b) { return (b + 15) / 16 * 16; };
+    size_t off = up16((size_t)Nc * 16);
+    L.off_red = (int)off; off += up16((size_t)kWaves * 5 * 8);
+    L.off_twlo = (int)off; off += (size_t)kTwLo * 16;
+    L.n_twhi = (Nc + kTwLo - 1) / kTwLo;
+    if (L.n_twhi > kThreads - 256) return 0;
+    L.off_twhi = (int)off; off += (size_t)L.n_twhi * 16;
+    L.off_perm = (int)off;
+    L.perm_lds = (off + up16((size_t)Nc * 2 + 4) <= 160 * 1024) ? 1 : 0;
+    if (L.perm_lds) off += up16((size_t)Nc * 2 + 4);
+    if (off > 160 * 1024) return 0;
+    L.lds_bytes = (int)off;
+    const size_t feat = up16((size_t)Nf * 16 + (48 + 40 + kFeatWaves * 16 + kFeatWaves) * 8 + kFeatWaves * 4);
+    if (feat > 160 * 1024) return 0;
+    L.feat_lds_bytes = (int)feat;
     L.n_pass = (int)radix.size();
     int M = Nc;
     for (int p = 0; p < L.n_pass; ++p) {
@@ -368,8 +498,8 @@ inline int wg_layout(const FftPlan &fft, WgLayout &L, std::vector<unsigned short
         L.tws[p] = Nc / M;
         M /= radix[p];
     }
-    L.lds_bytes = (int)lds;
     mix::mix_permutation(Nc, radix, perm);
+    perm.push_back(0);          // (the LDS copy moves whole 32-bit words)
     return 1;
 }
 

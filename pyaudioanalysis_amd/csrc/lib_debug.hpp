@@ -154,7 +154,7 @@ extern "C" int paa_debug_tri_plan(int window, double fs, int32_t *shape8, int32_
     if (!tri::tri_select(window, 1, fs, nullptr, nullptr, tl, b)) return 0;
     switch (tl.shape) {
 #define PAA_TRI_DESCRIBE(ID, SH)                                                                               \
-        case ID: shape8[0] = tri::SH::R1; shape8[1] = tri::SH::R2; shape8[2] = tri::SH::R3; shape8[3] = tri::SH::PACKED ? 1 : 0;    \
+        case ID: shape8[0] = tri::SH::R1; shape8[1] = tri::SH::R2; shape8[2] = tri::SH::R3; shape8[3] = (tri::SH::PACKED ? 1 : 0) | (tri::SH::R3P << 8);    \
                  shape8[4] = tri::SH::P; shape8[5] = tri::SH::NW; shape8[6] = tri::SH::NJOB3; shape8[7] = (int32_t)tl.lds; break;
         PAA_TRI_SHAPES(PAA_TRI_DESCRIBE)
 #undef PAA_TRI_DESCRIBE

@@ -443,6 +443,12 @@ static int run_wg(paa_plan *p, const void *d_packed, double *d_out) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, p->wl.lds_bytes));
         attr.set((size_t)p->wl.lds_bytes);
     }
+    static LdsAttrCache attr_feat;
+    if (!attr_feat.covers((size_t)p->wl.feat_lds_bytes)) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wg::wg_feat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    p->wl.feat_lds_bytes));
+        attr_feat.set((size_t)p->wl.feat_lds_bytes);
+    }
     for (const auto &ch : p->wg_chunks) {
         const unsigned n = (unsigned)(ch.second - ch.first);
         const wg::FrameRef *fr = p->d_wg_frames + ch.first;
@@ -452,7 +458,8 @@ static int run_wg(paa_plan *p, const void *d_packed, double *d_out) {
                            p->d_wg_perm, (const T *)d_packed, p->d_clips, p->d_norms, fr, spec, tfeat, d_out);
         if (prof_scope.stop) { (void)hipEventRecord(prof_scope.stop, cs()); prof_scope.stop = nullptr; }
         if (P.mode != 1)
-            hipLaunchKernelGGL(wg::wg_feat_kernel, dim3(n), dim3(wg::kFeatThreads), 0, cs(), P, fr, p->d_clips, spec, tfeat, d_out);
+            hipLaunchKernelGGL(wg::wg_feat_kernel, dim3(n), dim3(wg::kFeatThreads), (size_t)p->wl.feat_lds_bytes, cs(), P, fr,
+                               p->d_clips, spec, tfeat, d_out);
         HIP_TRY(hipGetLastError());
     }
     if (P.mode == 0 && P.deltas) {

@@ -426,6 +426,8 @@ def test_three_pass_tables_reproduce_the_fft(window):
     assert lib.paa_debug_tri_plan(window, 44100.0, shape.ctypes.data_as(_ffi.c_i32p), off.ctypes.data_as(_ffi.c_i32p),
                                   blob.ctypes.data_as(ctypes.c_void_p), size) == size
     R1, R2, R3, packed, P, NW, njob3, lds = (int(v) for v in shape)
+    packed, R3P = packed & 1, packed >> 8          # second exchange: element (q1, b, q2) at plane[q1 P + q2 R3P + b]
+    assert R3P >= R3 and P >= (R2 - 1) * R3P + R3
     N = R1 * R2 * R3
     assert N == (window // 2 if packed else window) and (packed == 1) == (window % 2 == 0 and window != 1102)
     assert R3 <= 8
@@ -441,10 +443,10 @@ def test_three_pass_tables_reproduce_the_fft(window):
     for j in range(L1):                                         # pass 1 + exchange 1: element (j, q1) at plane[q1 P + j]
         plane[np.arange(NQ1) * P + j] = np.fft.fft(z[j + L1 * np.arange(R1)])[:NQ1] * tw1[:, j]
     plane2 = np.zeros(NQ1 * P, dtype=complex)
-    for q1 in range(NQ1):                                       # pass 2 + exchange 2: (q1, b, q2) at plane[q1 P + q2 R3 + b]
+    for q1 in range(NQ1):                                       # pass 2 + exchange 2: (q1, b, q2) at plane[q1 P + q2 R3P + b]
         for b in range(R3):
             c = np.fft.fft(plane[q1 * P + R3 * np.arange(R2) + b]) * tw2[:, b]
-            plane2[q1 * P + np.arange(R2) * R3 + b] = c
+            plane2[q1 * P + np.arange(R2) * R3P + b] = c
     X = np.full(NF, np.nan)
     hits = np.zeros(NF, dtype=int)
     if R3 == 1:                                                 # two passes: lane q1 holds Z[q1 + R1 q2]
@@ -489,7 +491,7 @@ def test_three_pass_tables_reproduce_the_fft(window):
         p3 = p3 // 8
         for m3 in range(njob3):
             q1, q2 = divmod(m3, R2)
-            assert p3[m3, 0] == q1 * P + q2 * R3
+            assert p3[m3, 0] == q1 * P + q2 * R3P
             zz = np.fft.fft(plane2[int(p3[m3, 0]) + np.arange(R3)])
             for k3 in range(R3):
                 k, dst = q1 + R1 * (q2 + R2 * k3), int(p3[m3, 1 + k3])
