@@ -9,8 +9,8 @@
 //                       11 / 7 / 5 / 3 butterflies in registers, two per lane in flight, one __syncthreads per pass, twiddles as the
 //                       product of two LDS-resident factors W^(128 h) W^l -- no global load inside a pass); real-FFT recombination + |X| / num_fft read through the digit-reversal permutation and written
 //                       ONCE to the frame's spectrum row in HBM (for spectrogram plans: straight into the output)
-//   wg_feat_kernel      512 threads, one frame: the frame's and the previous frame's spectrum rows are staged in LDS (all loads in
-//                       flight at once), then the 34 features with every sweep spread over the workgroup (block energies per block range, mel filters and
+//   wg_feat_kernel      512 threads, one frame: the frame's spectrum row is staged in LDS (all loads in flight at once; the previous
+//                       frame's row is swept from L2), then the 34 features with every sweep spread over the workgroup (block energies per block range, mel filters and
 //                       chroma classes one wave at a time with all 64 lanes on the filter's bins)
 //   wg_delta_kernel     rows 34..67 of every clip
 //
@@ -24,21 +24,33 @@
 namespace paa {
 namespace wg {
 
-constexpr int kThreads = 512;           // spectrum kernel: eight waves, two per SIMD (256 registers each: radix-16 / 13 butterflies fit)
-constexpr int kWaves = kThreads / 64;
+// spectrum kernel: NT = 768 threads (twelve waves, three per SIMD, 121 registers) when every radix of the schedule is <= 8,
+// NT = 512 (two per SIMD, 175 registers: the radix-16 / 13 / 11 butterflies fit) otherwise; 1024 threads spilled 31 registers
+// at the 128 the hardware then allows and was no faster (scripts/rounds/r05/gpu_r05g.sh: 0.2022 / 0.2004 / 0.2082 ms per 1 199
+// frames at 1024 / 768 / 512 threads)
 constexpr int kFeatThreads = 512;
 constexpr int kFeatWaves = kFeatThreads / 64;
+#ifndef PAA_WG_ABLATE
+#define PAA_WG_ABLATE 0            // timing builds of scripts/rounds/r05 only: bit mask of phases that are skipped
+#endif
+constexpr int kAblate = PAA_WG_ABLATE;
 constexpr int kTwLo = 128;              // two-level twiddles: W^m = W^(128 (m >> 7)) W^(m & 127), both factors in LDS
 
 struct WgLayout {
     int n_pass;
     int radix[mix::kMaxPass], span[mix::kMaxPass], tws[mix::kMaxPass];
     unsigned magic[mix::kMaxPass];
-    int off_red, off_twlo, off_twhi, off_perm;      // byte offsets into the LDS behind the Nc x 16 transform buffer
+    int top;                        // elements per top-level block of the first pass (Nc / radix[0]); the LDS buffer holds one PAD
+                                    // element after each: element e sits at e + e / top -- the digit-reversed reads of the magnitude
+                                    // pass walk the top-level digit first, and top x 16 bytes is a multiple of the 256 bytes of one
+                                    // bank sweep for the usual lengths (8000 = 8 x 1000: every lane of a read on two bank groups)
+    unsigned magic_top;             // ceil(2^32 / top): e / top for e < 2^16
+    int off_red, off_twlo, off_twhi, off_perm;      // byte offsets into the LDS behind the transform buffer
     int n_twhi;
     int perm_lds;                   // 1: the digit-reversal permutation fits the LDS beside the buffer
+    int threads;                    // spectrum kernel: 768 when every radix is <= 8, else 512
     int lds_bytes;                  // spectrum kernel
-    int feat_lds_bytes;             // feature kernel: the frame's and the previous frame's spectrum rows + 1 KB
+    int feat_lds_bytes;             // feature kernel: the frame's spectrum row + 2 KB
 };
 // one frame of the launch: its clip, its index in the clip, the row of the spectrum scratch it writes, and whether it is only
 // there to provide the previous spectrum of the next one (a chunk that starts inside a clip)
@@ -51,78 +63,91 @@ struct Tw2 {
     __device__ __forceinline__ double2 get(int m) const { return cmul(hi[m >> 7], lo[m & (kTwLo - 1)]); }
 };
 
-// U butterflies of one in-place DIF pass per lane (kernels_mix.hpp's dif_batch with the twiddles from the two LDS tables):
-// butterfly b works on the R elements base + r * stride of its block; output q is multiplied by W_M^(q k) and goes back to
-// base + q * stride.  Butterflies touch disjoint elements: no ordering inside a pass.
-template <int R, int U>
-__device__ __forceinline__ void wg_dif_batch(double2 *buf, int nb, int stride, int M, int tws, unsigned magic, const Tw2 &tw, int b0) {
+__device__ __forceinline__ double2 csqr(double2 a) { return make_double2(fma(a.x, a.x, -a.y * a.y), 2.0 * (a.x * a.y)); }
+
+// U butterflies of one in-place DIF pass per lane (kernels_mix.hpp's dif_batch): butterfly b works on the R elements
+// base + r * stride of its block; output q is multiplied by W_M^(q k) and goes back to base + q * stride.  Butterflies touch
+// disjoint elements: no ordering inside a pass.  The twiddles of a butterfly are the powers of ONE table value W^(k tws) (the
+// product of the two LDS factors), formed by squaring / multiplying (depth log2 R: a few ulp, far inside the gates) -- the R - 1
+// table look-ups they replace were the larger half of a pass's instructions.  LDS addresses follow the padded layout (WgLayout::top).
+template <int R, int U, bool FIRST, int NT>
+__device__ __forceinline__ void wg_dif_batch(double2 *buf, int nb, int stride, int M, int tws, unsigned magic, unsigned magic_top,
+                                             const Tw2 &tw, int b0) {
     double2 v[U][R];
     int base[U], t1[U];
     bool act[U];
+    const int lstride = FIRST ? stride + 1 : stride;           // first pass: element r of a butterfly lies in top-level block r
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int b = b0 + kThreads * u;
+        const int b = b0 + NT * u;
         act[u] = b < nb;
         const int be = act[u] ? b : nb - 1;                     // (lanes past the end shadow a valid butterfly, stores masked)
         const int blk = (stride == 1) ? be : (int)__umulhi((unsigned)be, magic);
         const int k = be - __mul24(blk, stride);
-        base[u] = __mul24(blk, M) + k;
+        const int e0 = __mul24(blk, M) + k;
+        base[u] = FIRST ? e0 : e0 + (int)__umulhi((unsigned)e0, magic_top);      // (later passes: a butterfly stays inside one block)
         t1[u] = __mul24(k, tws);
 #pragma unroll
-        for (int r = 0; r < R; ++r) v[u][r] = buf[base[u] + r * stride];
+        for (int r = 0; r < R; ++r) v[u][r] = buf[base[u] + r * lstride];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         mix::Bfly<R>::run(v[u]);
         if (stride > 1) {
+            double2 wq[R];
+            wq[1] = tw.get(t1[u]);
 #pragma unroll
-            for (int q0 = 1; q0 < R; q0 += 4) {
-                double2 wl[4];
+            for (int q = 2; q < R; ++q) wq[q] = (q % 2 == 0) ? csqr(wq[q / 2]) : cmul(wq[q / 2], wq[q - q / 2]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (q0 + j < R) wl[j] = tw.get((q0 + j) * t1[u]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (q0 + j < R) v[u][mix::Bfly<R>::pos(q0 + j)] = cmul(v[u][mix::Bfly<R>::pos(q0 + j)], wl[j]);
-            }
+            for (int q = 1; q < R; ++q) v[u][mix::Bfly<R>::pos(q)] = cmul(v[u][mix::Bfly<R>::pos(q)], wq[q]);
         }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (act[u]) {
 #pragma unroll
-            for (int q = 0; q < R; ++q) buf[base[u] + q * stride] = v[u][mix::Bfly<R>::pos(q)];
+            for (int q = 0; q < R; ++q) buf[base[u] + q * lstride] = v[u][mix::Bfly<R>::pos(q)];
         }
     }
 }
-template <int R>
-__device__ __forceinline__ void wg_dif_pass(double2 *buf, int Nc, int M, int tws, unsigned magic, const Tw2 &tw, int tid) {
-    constexpr int U = (R <= 8) ? 2 : 1;          // two butterflies in flight per lane where the registers allow it
+template <int R, int NT>
+__device__ __forceinline__ void wg_dif_pass(double2 *buf, int Nc, int M, int tws, unsigned magic, unsigned magic_top, bool first,
+                                            const Tw2 &tw, int tid) {
+    constexpr int U = (NT <= 768 && R <= (NT == 512 ? 8 : 5)) ? 2 : 1;          // two butterflies in flight per lane where the registers allow it
     const int stride = M / R, nb = Nc / R;
     // (wave-uniform trip count: a wave whose first butterfly exists runs the batch)
-    for (int b0 = tid; (b0 & ~63) < nb; b0 += U * kThreads) wg_dif_batch<R, U>(buf, nb, stride, M, tws, magic, tw, b0);
+    if (first) {
+        for (int b0 = tid; (b0 & ~63) < nb; b0 += U * NT) wg_dif_batch<R, U, true, NT>(buf, nb, stride, M, tws, magic, magic_top, tw, b0);
+    } else {
+        for (int b0 = tid; (b0 & ~63) < nb; b0 += U * NT) wg_dif_batch<R, U, false, NT>(buf, nb, stride, M, tws, magic, magic_top, tw, b0);
+    }
 }
 
-// P.mode decides where the row goes and whether the time-domain features are formed
-template <typename T>
-__global__ __launch_bounds__(kThreads) void wg_spectrum_kernel(PlanDev P, WgLayout L, const unsigned short *__restrict__ perm_g,
-                                                               const T *__restrict__ sig, const ClipDev *__restrict__ clips,
-                                                               const ClipNorm *__restrict__ norms,
-                                                               const FrameRef *__restrict__ frames, double *__restrict__ spec,
-                                                               double *__restrict__ tfeat, double *__restrict__ out) {
+// lane l receives the value of lane l - 1 (lane 0: `first`)
+__device__ __forceinline__ int wg_shr1(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xF, 0xF, false); }
+
+// P.mode decides where the row goes and whether the time-domain features are formed.  PERSISTENT: the transform buffer takes
+// the CU's LDS, so one workgroup lives on a CU and nothing overlaps the latency chain at the head of a frame (frame record ->
+// clip record -> first samples: four dependent trips to L2 / HBM) -- a workgroup therefore walks frames blockIdx.x,
+// + gridDim.x, ..., loads the tables once, and fetches the next frame's records and touches its samples while it still
+// computes the magnitudes of the current one
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void wg_spectrum_kernel(PlanDev P, WgLayout L, const unsigned short *__restrict__ perm_g,
+                                                         const T *__restrict__ sig, const ClipDev *__restrict__ clips,
+                                                         const ClipNorm *__restrict__ norms,
+                                                         const FrameRef *__restrict__ frames, int n_frames,
+                                                         double *__restrict__ spec, double *__restrict__ tfeat,
+                                                         double *__restrict__ out) {
+    constexpr int kThreads = NT, kWaves = NT / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double2 *buf = reinterpret_cast<double2 *>(smem);
     double *red = reinterpret_cast<double *>(smem + L.off_red);        // [kWaves][5]
     double2 *twlo = reinterpret_cast<double2 *>(smem + L.off_twlo), *twhi = reinterpret_cast<double2 *>(smem + L.off_twhi);
     unsigned short *perm_l = reinterpret_cast<unsigned short *>(smem + L.off_perm);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const FrameRef fr = frames[blockIdx.x];
-    const ClipDev c = clips[fr.clip];
-    const ClipNorm nm = norms[fr.clip];
-    const T *x = sig + c.sample_off + P.frame_origin + (long long)fr.t * P.S;
     const int W = P.W, Nc = P.Nc, Nf = P.Nf;
     const double sc = sample_scale<T>();
-    // ---- tables: the two twiddle factors (and the permutation when it fits)
+    // ---- tables, once per workgroup: the two twiddle factors (and the permutation when it fits)
     if (tid < kTwLo) twlo[tid] = P.tw[tid < Nc ? tid : 0];
     if (tid >= 256 && tid - 256 < L.n_twhi) twhi[tid - 256] = P.tw[(tid - 256) * kTwLo];
     if (L.perm_lds) {
@@ -130,43 +155,84 @@ __global__ __launch_bounds__(kThreads) void wg_spectrum_kernel(PlanDev P, WgLayo
         unsigned *dst = reinterpret_cast<unsigned *>(perm_l);
         for (int i = tid; i < (Nc + 1) / 2; i += kThreads) dst[i] = src[i];
     }
-    // ---- load: y = (x / 2^15 - mean) / (max|.| + 1e-10) (ShortTermFeatures.py:567-570); even windows packed two samples per point
-    if (P.even) {
+    if ((int)blockIdx.x >= n_frames) return;
+    // (only the fields that are used travel from frame to frame: whole records kept live across the loop went to scratch)
+    struct Cur { long long x_off, out_off; double mean, inv; int t, row, halo, pad; };
+    auto fetch = [&](int f) {
+        const FrameRef r = frames[f];
+        const ClipDev cd = clips[r.clip];
+        const ClipNorm n_ = norms[r.clip];
+        Cur q;
+        q.x_off = cd.sample_off + P.frame_origin + (long long)r.t * P.S;
+        q.out_off = cd.out_off; q.mean = n_.mean; q.inv = n_.inv; q.t = r.t; q.row = r.row; q.halo = r.halo; q.pad = 0;
+        return q;
+    };
+    Cur cu = fetch(blockIdx.x);
+    for (int fidx = blockIdx.x; fidx < n_frames; fidx += gridDim.x) {
+    const T *x = sig + cu.x_off;
+    struct { int t, row, halo; } fr = {cu.t, cu.row, cu.halo};
+    struct { double mean, inv; } nm = {cu.mean, cu.inv};
+    struct { long long out_off; } c = {cu.out_off};
+    // ---- load: y = (x / 2^15 - mean) / (max|.| + 1e-10) (ShortTermFeatures.py:567-570); even windows packed two samples per point;
+    // element e of the sequence sits at buf[e + e / top]
+    const unsigned mtop = L.magic_top;
+    if (kAblate & 1) {
+        for (int p = tid; p < Nc; p += kThreads) buf[p + (int)__umulhi((unsigned)p, mtop)] = make_double2(1e-3 * (double)(p & 7), 1e-3);
+    } else if (P.even) {
 #pragma unroll 4
         for (int p = tid; p < Nc; p += kThreads) {
             const double2 xx = ct::PairLoad<T>::get(x + 2 * p);
-            buf[p] = make_double2(fma(xx.x, sc, -nm.mean) * nm.inv, fma(xx.y, sc, -nm.mean) * nm.inv);
+            buf[p + (int)__umulhi((unsigned)p, mtop)] = make_double2(fma(xx.x, sc, -nm.mean) * nm.inv, fma(xx.y, sc, -nm.mean) * nm.inv);
         }
     } else {
 #pragma unroll 4
-        for (int n = tid; n < W; n += kThreads) buf[n] = make_double2(fma(load_sample<T>(x + n), sc, -nm.mean) * nm.inv, 0.0);
+        for (int n = tid; n < W; n += kThreads)
+            buf[n + (int)__umulhi((unsigned)n, mtop)] = make_double2(fma(load_sample<T>(x + n), sc, -nm.mean) * nm.inv, 0.0);
     }
     __syncthreads();
-    // ---- time domain (:22-51): wave w owns samples [w per, (w + 1) per); per <= 1.25 blocks, so a wave meets at most three of
-    // the ten entropy blocks (or the tail the reference leaves out of them, block "10")
-    if (P.mode == 0 && !fr.halo) {
-        const int st = P.even ? 1 : 2;
-        const double *y = reinterpret_cast<const double *>(buf);
+    // ---- time domain (:22-51): wave w owns the elements [w per, (w + 1) per) of the sequence (sample pairs for even windows); its
+    // samples meet at most three of the ten entropy blocks (or the tail the reference leaves out of them, block "10"): the energy
+    // of the first, of the last and of all of them are summed, the middle one is the rest.  Sign codes are formed once per
+    // sample; the left neighbour comes from the lane below (lane 0: the previous iteration's lane 63, or the element before the range)
+    if (P.mode == 0 && !fr.halo && !(kAblate & 2)) {
         const int LT = P.blk_t;
-        const int per = (W + kWaves - 1) / kWaves;
-        const int n0 = wave * per, n1 = min(W, n0 + per);
-        const int b0 = min(n0 / LT, 10);
+        const int spe = P.even ? 2 : 1;                       // samples per element
+        const int per = (Nc + kWaves - 1) / kWaves;
+        const int p0 = wave * per, p1 = min(Nc, p0 + per);
+        const int b0 = min((p0 * spe) / LT, 10);
         const int bnd1 = (b0 < 10) ? (b0 + 1) * LT : 0x7fffffff, bnd2 = (b0 + 1 < 10) ? (b0 + 2) * LT : 0x7fffffff;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        double aA = 0.0, aC = 0.0, aT = 0.0;
         int zc = 0;
-#pragma unroll 4
-        for (int n = n0 + lane; n < n1; n += 64) {
-            const double v = y[n * st];
-            const double u = y[max(n - 1, 0) * st];          // (n = 0 meets itself: no sign change)
-            const double e = v * v;
-            a0 += (n < bnd1) ? e : 0.0;
-            a1 += (n >= bnd1 && n < bnd2) ? e : 0.0;
-            a2 += (n >= bnd2) ? e : 0.0;
-            zc += abs(((v > 0.0) - (v < 0.0)) - ((u > 0.0) - (u < 0.0)));
+        int carry = 0;            // sign code of the sample before this iteration's first one
+        bool have_left = false;
+        if (p0 > 0 && p0 < p1) {
+            const double2 zl = buf[(p0 - 1) + (int)__umulhi((unsigned)(p0 - 1), mtop)];
+            const double vl = P.even ? zl.y : zl.x;
+            carry = (vl > 0.0) - (vl < 0.0);
+            have_left = true;
         }
-        a0 = wsum(a0); a1 = wsum(a1); a2 = wsum(a2);
+        for (int pb = p0; pb < p1; pb += 64) {
+            const int p = pb + lane;
+            const bool in = p < p1;
+            const int pe = in ? p : p1 - 1;
+            const double2 z = buf[pe + (int)__umulhi((unsigned)pe, mtop)];
+            const double v0 = in ? z.x : 0.0, v1 = (in && P.even) ? z.y : 0.0;
+            const int n = pe * spe;
+            const double e0 = v0 * v0, e1 = v1 * v1;
+            aT += e0 + e1;
+            aA += ((n < bnd1) ? e0 : 0.0) + ((n + 1 < bnd1) ? e1 : 0.0);
+            aC += ((n >= bnd2) ? e0 : 0.0) + ((n + 1 >= bnd2) ? e1 : 0.0);
+            const int c0 = (v0 > 0.0) - (v0 < 0.0), c1 = (v1 > 0.0) - (v1 < 0.0);
+            const int last = P.even ? c1 : c0;                 // the element's last sample
+            const int first_left = have_left ? carry : __builtin_amdgcn_readfirstlane(c0);      // (the frame's first sample meets itself)
+            const int left = wg_shr1(last, first_left);
+            if (in) zc += abs(c0 - left) + (P.even ? abs(c1 - c0) : 0);
+            carry = __builtin_amdgcn_readlane(last, 63);
+            have_left = true;
+        }
+        aA = wsum(aA); aC = wsum(aC); aT = wsum(aT);
         zc = wsum_i(zc);
-        if (lane == 0) { red[5 * wave] = a0; red[5 * wave + 1] = a1; red[5 * wave + 2] = a2; red[5 * wave + 3] = (double)zc; red[5 * wave + 4] = (double)b0; }
+        if (lane == 0) { red[5 * wave] = aA; red[5 * wave + 1] = (aT - aA) - aC; red[5 * wave + 2] = aC; red[5 * wave + 3] = (double)zc; red[5 * wave + 4] = (double)b0; }
     }
     __syncthreads();          // every wave has read its samples: the passes may overwrite the buffer
     if (P.mode == 0 && !fr.halo && wave == 0) {
@@ -190,44 +256,59 @@ __global__ __launch_bounds__(kThreads) void wg_spectrum_kernel(PlanDev P, WgLayo
     }
     // ---- in-place DIF passes (kernels_mix.hpp's butterflies; two waves per SIMD and two butterflies per lane hide the latency)
     const Tw2 tw = {twlo, twhi};
-    for (int p = 0; p < L.n_pass; ++p) {
+    for (int p = 0; p < ((kAblate & 4) ? 0 : L.n_pass); ++p) {
         const int M = L.span[p], ts = L.tws[p];
         const unsigned mg = L.magic[p];
         switch (L.radix[p]) {
-            case 2: wg_dif_pass<2>(buf, Nc, M, ts, mg, tw, tid); break;
-            case 3: wg_dif_pass<3>(buf, Nc, M, ts, mg, tw, tid); break;
-            case 4: wg_dif_pass<4>(buf, Nc, M, ts, mg, tw, tid); break;
-            case 5: wg_dif_pass<5>(buf, Nc, M, ts, mg, tw, tid); break;
-            case 7: wg_dif_pass<7>(buf, Nc, M, ts, mg, tw, tid); break;
-            case 8: wg_dif_pass<8>(buf, Nc, M, ts, mg, tw, tid); break;
-            case 11: wg_dif_pass<11>(buf, Nc, M, ts, mg, tw, tid); break;
-            case 13: wg_dif_pass<13>(buf, Nc, M, ts, mg, tw, tid); break;
-            default: wg_dif_pass<16>(buf, Nc, M, ts, mg, tw, tid); break;
+            case 2: wg_dif_pass<2, NT>(buf, Nc, M, ts, mg, mtop, p == 0, tw, tid); break;
+            case 3: wg_dif_pass<3, NT>(buf, Nc, M, ts, mg, mtop, p == 0, tw, tid); break;
+            case 4: wg_dif_pass<4, NT>(buf, Nc, M, ts, mg, mtop, p == 0, tw, tid); break;
+            case 5: wg_dif_pass<5, NT>(buf, Nc, M, ts, mg, mtop, p == 0, tw, tid); break;
+            case 7: wg_dif_pass<7, NT>(buf, Nc, M, ts, mg, mtop, p == 0, tw, tid); break;
+            case 8: wg_dif_pass<8, NT>(buf, Nc, M, ts, mg, mtop, p == 0, tw, tid); break;
+            case 11: if constexpr (NT == 512) wg_dif_pass<11, NT>(buf, Nc, M, ts, mg, mtop, p == 0, tw, tid); break;
+            case 13: if constexpr (NT == 512) wg_dif_pass<13, NT>(buf, Nc, M, ts, mg, mtop, p == 0, tw, tid); break;
+            default: if constexpr (NT == 512) wg_dif_pass<16, NT>(buf, Nc, M, ts, mg, mtop, p == 0, tw, tid); break;
         }
         __syncthreads();
+    }
+    // ---- the next frame of this workgroup: its records now, a touch of its samples (one load per lane and 128-byte line of the
+    // frame: they land in L2 / L1 while the magnitudes below are formed; the sum keeps the loads alive)
+    Cur cu_next = cu;
+    const int f_next = fidx + (int)gridDim.x;
+    if (f_next < n_frames) {
+        cu_next = fetch(f_next);
+        const char *xn = reinterpret_cast<const char *>(sig + cu_next.x_off);
+        const int bytes = W * (int)sizeof(T);
+        int touch = 0;
+        for (int o = tid * 128; o < bytes; o += kThreads * 128) touch += *reinterpret_cast<const volatile char *>(xn + o);
+        asm volatile("" ::"v"(touch));
     }
     // ---- |X| / num_fft (:617-621) through the digit-reversal permutation, written once to the frame's row
     double *row = (P.mode == 1) ? out + c.out_off + (long long)fr.t * Nf : spec + (long long)fr.row * Nf;
     const double invNf = 1.0 / (double)Nf;
     const unsigned short *perm = L.perm_lds ? perm_l : perm_g;
-    if (P.even) {
+    if (kAblate & 8) {
+        if (tid == 0) row[0] = buf[5].x;
+    } else if (P.even) {
         // bins k and Nc - k from one pair: X[k] = E + w^k O, X[Nc - k] = conj(E - w^k O), E = (Z[k] + conj Z[Nc - k]) / 2,
         // O = -i (Z[k] - conj Z[Nc - k]) / 2; four pairs in flight per lane
         const int npairs = Nc / 2 + 1;
-        for (int k0 = tid; (k0 & ~63) < npairs; k0 += 4 * kThreads) {
-            int kk[4], pa[4], pb[4];
-            double2 pw[4], zk[4], zm[4];
+        constexpr int MU = (NT == 512) ? 4 : 2;          // pairs in flight per lane
+        for (int k0 = tid; (k0 & ~63) < npairs; k0 += MU * kThreads) {
+            int kk[MU], pa[MU], pb[MU];
+            double2 pw[MU], zk[MU], zm[MU];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < MU; ++u) {
                 kk[u] = min(k0 + u * kThreads, npairs - 1);
                 pw[u] = P.post[kk[u]];
                 pa[u] = L.perm_lds ? perm_l[kk[u]] : perm_g[kk[u]];
                 pb[u] = L.perm_lds ? perm_l[kk[u] == 0 ? 0 : Nc - kk[u]] : perm_g[kk[u] == 0 ? 0 : Nc - kk[u]];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { zk[u] = buf[pa[u]]; zm[u] = buf[pb[u]]; }
+            for (int u = 0; u < MU; ++u) { zk[u] = buf[pa[u]]; zm[u] = buf[pb[u]]; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < MU; ++u) {
                 const int k = kk[u];
                 const double2 e = make_double2(0.5 * (zk[u].x + zm[u].x), 0.5 * (zk[u].y - zm[u].y));
                 const double2 o = make_double2(0.5 * (zk[u].y + zm[u].y), 0.5 * (zm[u].x - zk[u].x));
@@ -246,6 +327,9 @@ __global__ __launch_bounds__(kThreads) void wg_spectrum_kernel(PlanDev P, WgLayo
             row[k] = mag_sqrt(fma(z.x, z.x, z.y * z.y)) * invNf;
         }
     }
+    __syncthreads();          // the buffer is free for the next frame
+    cu = cu_next;
+    }       // frames of this workgroup
 }
 
 // sum over the workgroup: every wave's total through LDS (slot[kFeatWaves]); all threads return the same bits
@@ -270,21 +354,19 @@ __global__ __launch_bounds__(kFeatThreads) void wg_feat_kernel(PlanDev P, const 
     const ClipDev c = clips[fr.clip];
     const int Nf = P.Nf, W = P.W;
     double *cur = reinterpret_cast<double *>(smem);
-    double *prv = cur + Nf;
-    double *fv = prv + Nf;               // [48]
+    double *fv = cur + Nf;               // [48]
     double *msp = fv + 48;               // [40]
     double *red = msp + 40;              // [kFeatWaves][16]
     double *slot = red + kFeatWaves * 16;      // [kFeatWaves]
     int *redi = reinterpret_cast<int *>(slot + kFeatWaves);
+    // the frame's own row is staged in LDS (it is swept five times, two of them as gathers); the previous frame's row -- two
+    // coalesced sweeps -- is read where it lies (L2): 8 Nf bytes of LDS per workgroup, so two workgroups share a CU and the
+    // staging of one runs under the sweeps of the other
+    const double *gc = spec + (long long)fr.row * Nf;
+    const double *prv = (fr.t == 0) ? gc : gc - Nf;          // frames are laid out in clip order: the previous frame is the previous row
     {
-        const double *gc = spec + (long long)fr.row * Nf;
-        const double *gp = (fr.t == 0) ? gc : gc - Nf;      // frames are laid out in clip order: the previous frame is the previous row
 #pragma unroll 8
-        for (int k = tid; k < Nf; k += kFeatThreads) cur[k] = gc[k];
-        if (P.mode == 0) {
-#pragma unroll 8
-            for (int k = tid; k < Nf; k += kFeatThreads) prv[k] = gp[k];
-        }
+        for (int k = tid; k < ((kAblate & 16) ? 64 : Nf); k += kFeatThreads) cur[k] = gc[k];
     }
     __syncthreads();
     double *oc = out + c.out_off;
@@ -297,7 +379,7 @@ __global__ __launch_bounds__(kFeatThreads) void wg_feat_kernel(PlanDev P, const 
     for (int i = 0; i < 15; ++i) part[i] = 0.0;
 #pragma unroll
     for (int j = 0; j < 11; ++j) {
-        const int lo = j * LB, hi = (j < 10) ? lo + LB : Nf;
+        const int lo = j * LB, hi = (kAblate & 32) ? lo : ((j < 10) ? lo + LB : Nf);
         double p = 0.0;
         for (int k = lo + tid; k < hi; k += kFeatThreads) {
             const double X = cur[k];
@@ -364,7 +446,7 @@ __global__ __launch_bounds__(kFeatThreads) void wg_feat_kernel(PlanDev P, const 
     const double rX = fast_div(1.0, sXe), rXp = fast_div(1.0, sXp);
     double sSp = 0.0, sFl = 0.0;
 #pragma unroll 4
-    for (int k = tid; k < Nf; k += kFeatThreads) {
+    for (int k = tid; k < ((kAblate & 32) ? 0 : Nf); k += kFeatThreads) {
         const double X = cur[k];
         const double dv = (double)(k + 1) * f0 - cen;
         sSp = fma(dv * dv, X * r, sSp);
@@ -380,7 +462,7 @@ __global__ __launch_bounds__(kFeatThreads) void wg_feat_kernel(PlanDev P, const 
     {
         const double thr = 0.90 * sP;
         const int cch = ((Nf + kFeatThreads - 1) / kFeatThreads) | 1;
-        const int kb = min(tid * cch, Nf), ke = min(Nf, kb + cch);
+        const int kb = min(tid * cch, Nf), ke = (kAblate & 64) ? kb : min(Nf, kb + cch);
         double cs = 0.0;
         for (int k = kb; k < ke; ++k) { const double X = cur[k]; cs = fma(X, X, cs); }
         const double incl = wscan_incl(cs);
@@ -401,24 +483,50 @@ __global__ __launch_bounds__(kFeatThreads) void wg_feat_kernel(PlanDev P, const 
 #pragma unroll
         for (int w = 1; w < kFeatWaves; ++w) first = min(first, redi[w]);
     }
-    // ---- MFCC (:236-254): filter by filter, one wave per filter, all lanes on the filter's bins
-    for (int m = wave; m < 40; m += kFeatWaves) {
-        const int lo = tb.mel_lo[m], cnt = tb.mel_cnt[m];
-        const double *wv = tb.mel_w + tb.mel_off[m];
-        double a = 0.0;
-#pragma unroll 4
-        for (int i = lane; i < cnt; i += 64) a = fma(cur[lo + i], wv[i], a);
-        a = wsum(a);
-        if (lane == 0) msp[m] = fast_log10(a + kEps);
+    // ---- MFCC (:236-254): wave w owns the filters w, w + 8, ..., all 64 lanes on a filter's bins -- the five filters of a wave
+    // are walked TOGETHER (ten loads in flight per lane and step, five independent wave reductions, the five logarithms on
+    // five lanes at once): filter after filter, every step waited for one weight from L2
+    {
+        constexpr int NFW = 40 / kFeatWaves;
+        int lo[NFW], cnt[NFW];
+        const double *wv[NFW];
+        double a[NFW];
+        int maxc = 0;
+#pragma unroll
+        for (int j = 0; j < NFW; ++j) {
+            const int m = wave + kFeatWaves * j;
+            lo[j] = tb.mel_lo[m]; cnt[j] = (kAblate & 128) ? 0 : tb.mel_cnt[m]; wv[j] = tb.mel_w + tb.mel_off[m];
+            a[j] = 0.0;
+            maxc = max(maxc, cnt[j]);
+        }
+        for (int i = lane; i < maxc; i += 64) {
+#pragma unroll
+            for (int j = 0; j < NFW; ++j)
+                if (i < cnt[j]) a[j] = fma(cur[lo[j] + i], wv[j][i], a[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NFW; ++j) a[j] = wsum(a[j]);
+        double mine = a[0];
+#pragma unroll
+        for (int j = 1; j < NFW; ++j) mine = (lane == j) ? a[j] : mine;
+        if (lane < NFW) msp[wave + kFeatWaves * lane] = fast_log10(mine + kEps);
     }
-    // ---- chroma (:277-321)
-    for (int cls = wave; cls < 12; cls += kFeatWaves) {
-        const int b = tb.ch_start[cls], e = tb.ch_start[cls + 1];
-        double acc = 0.0;
-#pragma unroll 4
-        for (int i = b + lane; i < e; i += 64) { const double xv = cur[tb.ch_src[i]]; acc = fma(xv * xv, tb.ch_w[i], acc); }
-        acc = wsum(acc);
-        if (lane == 0) fv[21 + cls] = (sP == 0.0) ? acc / kEps : fast_div(acc, sP);
+    // ---- chroma (:277-321): the pitch classes w and w + 8 of a wave, walked together
+    {
+        const int c0 = wave, c1 = wave + kFeatWaves;
+        const bool two = c1 < 12;
+        const int b0 = tb.ch_start[c0], e0 = (kAblate & 128) ? b0 : tb.ch_start[c0 + 1];
+        const int b1 = two ? tb.ch_start[c1] : 0, e1 = (two && !(kAblate & 128)) ? tb.ch_start[c1 + 1] : 0;
+        double acc0 = 0.0, acc1 = 0.0;
+        const int n0 = e0 - b0, n1 = e1 - b1, nmax = max(n0, n1);
+#pragma unroll 2
+        for (int i = lane; i < nmax; i += 64) {
+            if (i < n0) { const double xv = cur[tb.ch_src[b0 + i]]; acc0 = fma(xv * xv, tb.ch_w[b0 + i], acc0); }
+            if (i < n1) { const double xv = cur[tb.ch_src[b1 + i]]; acc1 = fma(xv * xv, tb.ch_w[b1 + i], acc1); }
+        }
+        acc0 = wsum(acc0); acc1 = wsum(acc1);
+        if (lane == 0) fv[21 + c0] = (sP == 0.0) ? acc0 / kEps : fast_div(acc0, sP);
+        if (lane == 1 && two) fv[21 + c1] = (sP == 0.0) ? acc1 / kEps : fast_div(acc1, sP);
     }
     __syncthreads();
     if (tid < 13) {
@@ -469,26 +577,33 @@ __global__ __launch_bounds__(256) void wg_delta_kernel(const ClipDev *__restrict
 // 1: the transform of this window runs in one workgroup's LDS (fills L and perm); 0: it does not (kernels_big.hpp keeps it)
 inline int wg_layout(const FftPlan &fft, WgLayout &L, std::vector<unsigned short> &perm) {
     const int Nc = fft.len, Nf = fft.window / 2;
-    if (Nc < 256 || Nc > 65535) return 0;
+    if (Nc < 256 || Nc > 65000) return 0;
     std::vector<int> radix;
     if (!mix::mix_factor(Nc, radix)) return 0;
     memset(&L, 0, sizeof(L));
     auto up16 = [](size_t b) { return (b + 15) / 16 * 16; };
-    size_t off = up16((size_t)Nc * 16);
-    L.off_red = (int)off; off += up16((size_t)kWaves * 5 * 8);
+    L.top = Nc / radix[0];
+    L.magic_top = (unsigned)(((1ULL << 32) + (unsigned)L.top - 1) / (unsigned)L.top);
+    size_t off = up16((size_t)(Nc + radix[0]) * 16);
+    L.off_red = (int)off; off += up16((size_t)16 * 5 * 8);
     L.off_twlo = (int)off; off += (size_t)kTwLo * 16;
     L.n_twhi = (Nc + kTwLo - 1) / kTwLo;
-    if (L.n_twhi > kThreads - 256) return 0;
+    if (L.n_twhi > 256) return 0;
     L.off_twhi = (int)off; off += (size_t)L.n_twhi * 16;
     L.off_perm = (int)off;
     L.perm_lds = (off + up16((size_t)Nc * 2 + 4) <= 160 * 1024) ? 1 : 0;
     if (L.perm_lds) off += up16((size_t)Nc * 2 + 4);
     if (off > 160 * 1024) return 0;
     L.lds_bytes = (int)off;
-    const size_t feat = up16((size_t)Nf * 16 + (48 + 40 + kFeatWaves * 16 + kFeatWaves) * 8 + kFeatWaves * 4);
+    const size_t feat = up16((size_t)Nf * 8 + (48 + 40 + kFeatWaves * 16 + kFeatWaves) * 8 + kFeatWaves * 4);
     if (feat > 160 * 1024) return 0;
     L.feat_lds_bytes = (int)feat;
     L.n_pass = (int)radix.size();
+#ifndef PAA_WG_NT
+#define PAA_WG_NT 0                 // timing builds of scripts/rounds/r05 only: force the workgroup size of the spectrum kernel
+#endif
+    L.threads = PAA_WG_NT ? PAA_WG_NT : 768;
+    for (int r : radix) if (r > 8) L.threads = 512;
     int M = Nc;
     for (int p = 0; p < L.n_pass; ++p) {
         L.radix[p] = radix[p];
@@ -499,6 +614,7 @@ inline int wg_layout(const FftPlan &fft, WgLayout &L, std::vector<unsigned short
         M /= radix[p];
     }
     mix::mix_permutation(Nc, radix, perm);
+    for (auto &pp : perm) pp = (unsigned short)(pp + pp / L.top);          // positions in the padded buffer
     perm.push_back(0);          // (the LDS copy moves whole 32-bit words)
     return 1;
 }

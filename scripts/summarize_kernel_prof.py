@@ -22,6 +22,11 @@ def main(prof_dir, out_path):
                                                     "%st_tri_kernel%" if "_tri_" in stem else "%" + stem + "%")
     if line["case"] == "mid_stats":
         like = "%mid_stats_kernel%"
+    second = None
+    if "wg_lds_fft" in stem:                      # two kernels per step: the spectra of all frames, then their features
+        like, second = "%wg_spectrum_kernel%", "%wg_feat_kernel%"
+    if stem == "big_window_hbm_passes":
+        like = "%big_pass_kernel%"
     out["kernel_like"] = like
     if line["case"] == "mid_stats":
         # the profiled kernel is mid_stats_kernel alone: it reads the (68, T) short-term slabs once and writes (136, M)
@@ -43,14 +48,30 @@ def main(prof_dir, out_path):
         for r in con.execute("select counter_name, sum(counter_value) from pmc_events where name like ? group by counter_name", (like,)):
             pm[r[0]] = {"per_dispatch": r[1] / max(nd, 1), "dispatches": nd}
     out["pmc"] = pm
+    if second:
+        pm2 = {}
+        for n in sorted(os.listdir(prof_dir)):
+            db = os.path.join(prof_dir, n, "pmc_results.db")
+            if not os.path.exists(db):
+                continue
+            con = sqlite3.connect(db)
+            nd = con.execute("select count(distinct dispatch_id) from pmc_events where name like ?", (second,)).fetchone()[0]
+            for r in con.execute("select counter_name, sum(counter_value) from pmc_events where name like ? group by counter_name", (second,)):
+                pm2[r[0]] = {"per_dispatch": r[1] / max(nd, 1), "dispatches": nd}
+        out["pmc_second_kernel"] = {"kernel_like": second, "counters": pm2}
+        # HBM traffic of the step = both kernels
+        for key in ("FETCH_SIZE", "WRITE_SIZE"):
+            if key in pm and key in pm2:
+                pm[key + "_both_kernels"] = {"per_dispatch": pm[key]["per_dispatch"] + pm2[key]["per_dispatch"], "dispatches": pm[key]["dispatches"]}
     avg = [k for k in out["kernel_trace_stats"] if like.strip("%") in k["name"]]
     if avg:
         out["kernel_avg_us"] = avg[0]["avg_us"]
         out["achieved_GBps_kernel"] = line["algorithmic_bytes_per_launch"] / (avg[0]["avg_us"] * 1e-6) / 1e9
         out["hbm_frac"] = out["achieved_GBps_kernel"] / 8000.0
     if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
-        fetch = pm["FETCH_SIZE"]["per_dispatch"] * 1024.0 * 2.0
-        write = pm["WRITE_SIZE"]["per_dispatch"] * 1024.0
+        fk, wk = ("FETCH_SIZE_both_kernels", "WRITE_SIZE_both_kernels") if "FETCH_SIZE_both_kernels" in pm else ("FETCH_SIZE", "WRITE_SIZE")
+        fetch = pm[fk]["per_dispatch"] * 1024.0 * 2.0
+        write = pm[wk]["per_dispatch"] * 1024.0
         out["traffic"] = {"fetch_bytes_corrected_x2": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
                           "algorithmic_bytes_per_launch": line["algorithmic_bytes_per_launch"],
                           "traffic_over_algorithmic": (fetch + write) / line["algorithmic_bytes_per_launch"]}
