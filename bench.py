@@ -85,6 +85,10 @@ SHAPES = {
     "w2400_68": (48000, 2400, 1200, 1200, 1, 0, 0, 1),             # 50 ms at 48 kHz with deltas (what mid-term extraction runs)
     "w2205_stereo_68": (44100, 2205, 1102, 1200, 1, 2, 0, 1),
     "mid_stats": (16000, 800, 400, 30, 1000, 0, 0, 1),
+    "fast_s800": (16000, 800, 800, 30, 1000, 0, 0, 1),             # 50 ms / 50 ms (audioTrainTest.py:28-29), 1000 clips, 68 rows
+    "mix_4800": (96000, 4800, 2400, 300, 1, 0, 0, 0),              # 50 ms at 96 kHz: the in-place mixed-radix kernel, full instance
+    "mix_256": (16000, 256, 128, 3600, 1, 0, 0, 0),                # 16 ms windows: its lean, skewed instance
+    "generic_1103": (22050, 1103, 441, 600, 1, 0, 0, 0),           # a prime window: Stockham passes in LDS
     "big_16000": (16000, 16000, 8000, 600, 1, 0, 0, 0),            # music_thumbnailing's 1 s window (audioSegmentation.py:1137)
     "big_16000_1h": (16000, 16000, 8000, 3600, 1, 0, 0, 0),        # ... on the one-hour clip (7 199 frames: 28 per CU)
     "big_16000_68": (16000, 16000, 8000, 600, 1, 0, 0, 1),         # ... with deltas, as music_thumbnailing calls it
