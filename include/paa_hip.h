@@ -251,7 +251,8 @@ int paa_debug_fft_plan(int window, int32_t *radices, int32_t *fft_len);
  * drops for the selected device before RCCL is called (comm_rccl.hpp); needs a device                                */
 int paa_debug_comm_marker_name(const void *unique_id, int rank, char *out, int capacity);
 /* three-pass register-FFT kernels (csrc/kernels_tri.hpp), host only: shape8 = {R1, R2, R3, packed | group pitch of the second exchange << 8, plane row pitch P, waves per
- * workgroup, pass-3 lane jobs, LDS bytes}, offsets6 = byte offsets {tw2, p3, g_tw1, g_post, table_bytes, total_bytes} into the
+ * workgroup | H1 << 8 | H2 << 16 (lanes that share a prime butterfly of pass 1 / 2), pass-3 lane jobs, LDS bytes}, offsets6 = SEVEN
+ * byte offsets {tw2, p3, g_tw1, g_post, table_bytes, total_bytes, split tables} into the
  * table blob (spectrogram mode: no mel / chroma lists), which is copied to `blob` when that is not NULL.  Returns the blob
  * size, 0 when the window goes to another kernel                                                                     */
 int paa_debug_tri_plan(int window, double fs, int32_t *shape8, int32_t *offsets6, unsigned char *blob, int capacity);

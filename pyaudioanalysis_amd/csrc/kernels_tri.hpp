@@ -60,9 +60,12 @@ constexpr int pair_count(int R1, int R2, int R3) {
     return pairs;
 }
 
-template <int R1_, int R2_, int R3_, bool PACKED_, int P_, int NW_, int R3P_ = R3_>
+template <int R1_, int R2_, int R3_, bool PACKED_, int P_, int NW_, int R3P_ = R3_, int H1_ = 1, int H2_ = 1>
 struct Shape {
     static constexpr int R1 = R1_, R2 = R2_, R3 = R3_, P = P_, NW = NW_;
+    // prime first / second radix of a real-input shape: the O(R^2) butterfly of a pass-1 (pass-2) job is shared by H1 (H2) lanes,
+    // each forming a subset of the outputs (SplitSel below) -- the lanes a prime shape leaves idle take a share of the FMAs
+    static constexpr int H1 = H1_, H2 = H2_;
     // second exchange: element (q1, b, q2) sits at plane[q1 P + q2 R3P + b]; R3P = R3 + 1 for the radix-8 last pass (the jobs of a
     // pass-3 read group then hit 32 different bank pairs: q2 R3 = 8 q2 repeats every four jobs)
     static constexpr int R3P = R3P_;
@@ -82,7 +85,8 @@ struct Shape {
     // at zero (re-zeroed after every transform where the plane reaches into them), so the sweeps need no bounds masks
     // (+ one double at index NF, where the last pass parks the results that no bin takes)
     static constexpr int NFD = NF + 1;
-    static constexpr int SLOT00 = (PLANE > NFD ? PLANE : NFD) > 64 * C ? (PLANE > NFD ? PLANE : NFD) : 64 * C;
+    static constexpr int PLANED = PLANE + ((H1_ > 1 || H2_ > 1) ? 1 : 0);        // split passes: + a dummy double for dropped outputs
+    static constexpr int SLOT00 = (PLANED > NFD ? PLANED : NFD) > 64 * C ? (PLANED > NFD ? PLANED : NFD) : 64 * C;
     // the time-domain partials are summed through an LDS transpose of 11 x 65 doubles inside the frame's spectrum slot (free at
     // that point); a slot that is only a little smaller is padded to that size (both slots: 2 x the padding) when that is cheaper
     // than a scratch of its own -- 1024-sample windows: 12.3 instead of 15.7 KB per wave = ten waves per CU instead of eight
@@ -94,7 +98,9 @@ struct Shape {
     static constexpr int TSCR = (SLOT >= 11 * 65) ? 0 : 11 * 65;
     static constexpr int WAVE_DOUBLES = 2 * SLOT + 48 + 40 + 12 + TSCR;   // two slots, fv[48], msp[40], bnd[12], scratch
     static_assert(P >= L1 && P >= (R2 - 1) * R3P + R3 && R3P >= R3, "plane rows hold L1 elements (first exchange) and R2 groups of R3 (second)");
-    static_assert(J2 <= 64, "one pass-2 job per lane");
+    static_assert(J2 * H2 <= 64, "one pass-2 job (part) per lane");
+    static_assert(H1 == 1 || (!PACKED && L1 * H1 <= 64), "split first pass: real input, all parts of all jobs in one wave");
+    static_assert(H2 == 1 || !PACKED, "split second pass: real-input shapes");
     static_assert(!PACKED || NJ == 1, "packed shapes: one pass-1 job per lane");
     static_assert(PACKED || (R1 % 2 == 1), "real-input shapes: odd first radix");
     // packed shapes: a pass-3 table entry is PE x 8 ushorts = {plane offset of job A, of job B, (bin of X[k], bin of X[N - k]) x R3}
@@ -114,6 +120,8 @@ struct TriLayout {
                                     // passes: plane elements of the job, then where its R3 (<= 5) magnitudes go.  Two passes (R3 = 1):
                                     // ushort [R2][64]: where lane q1's magnitude q2 goes
     int off_mello, off_melcnt, off_meloff, off_melw, off_dct, off_chstart, off_chsrc, off_chw;
+    int off_split;                  // split prime passes: int [H1][8] then int [H2][16]: per part and output slot the true output index
+                                    // (bits 0-7), conjugate (bit 8), enabled (bit 9: the first part that produces an index writes it)
     int off_sync;                   // pacing of the waves of a SIMD: SIMD id [16], progress in half frames [16] (ints)
     int table_bytes;                // LDS part, multiple of 16
     int off_g_tw1;                  // global part: double2 [NQ1][L1]: W_N^(j q1)
@@ -242,8 +250,97 @@ __device__ __forceinline__ void rdft_prime(const double *x, double2 *a) {      /
         __builtin_amdgcn_sched_barrier(0);
     }
 }
+// ---- prime butterflies shared by H lanes ("parts"): every part runs the SAME code -- the outputs q of SplitSel<R, H>::q with
+// the same compile-time cos / sin constants -- on its inputs taken in the order n -> (n ginv_h) mod R, which makes output q of
+// part h the true output (g_h q) mod R (X'[q] = sum_n x[n ginv] W^(n q) = sum_m x[m] W^(m g q)); the multipliers g_h are chosen so
+// that the parts' outputs cover every index once or twice (second copies are dropped by the host tables).  Real input:
+// X[R - t] = conj X[t], so a part's output q stands for index min(t, R - t), conjugated when t > R / 2.  Same pivot form as
+// rdft_prime / cdft_prime: R equal inputs give exact zeros in the non-DC outputs.
+template <int R, int H> struct SplitSel;
+template <> struct SplitSel<29, 3> {            // {1,2,3,6,9} x {1,5,11} covers +-1 .. +-14 (5 of the 14 outputs / pairs per part)
+    static constexpr int NQ = 5;
+    static constexpr int q(int i) { constexpr int t[5] = {1, 2, 3, 6, 9}; return t[i]; }
+    static constexpr int g(int h) { constexpr int t[3] = {1, 5, 11}; return t[h]; }
+};
+template <> struct SplitSel<19, 3> {            // {1,2,4} x {1,7,8} covers +-1 .. +-9
+    static constexpr int NQ = 3;
+    static constexpr int q(int i) { constexpr int t[3] = {1, 2, 4}; return t[i]; }
+    static constexpr int g(int h) { constexpr int t[3] = {1, 7, 8}; return t[h]; }
+};
+template <int R, int H> struct SplitNQ { static constexpr int value = SplitSel<R, H>::NQ; };
+template <int R> struct SplitNQ<R, 1> { static constexpr int value = 0; };
+constexpr int mod_inverse(int g, int R) {
+    for (int x = 1; x < R; ++x)
+        if ((g * x) % R == 1) return x;
+    return 1;
+}
+// real input (in the part's order) -> a[0] = X[0] (real), a[1 + i] = X'[q_i]
+template <int R, typename SEL>
+__device__ __forceinline__ void rdft_prime_sel(const double *x, double2 *a) {
+    constexpr int H = (R - 1) / 2;
+    double sm[H], df[H];
+#pragma unroll
+    for (int j = 1; j <= H; ++j) { sm[j - 1] = x[j] + x[R - j]; df[j - 1] = x[j] - x[R - j]; }
+    double tot = x[0];
+#pragma unroll
+    for (int j = 0; j < H; ++j) tot += sm[j];
+    const double base = fma(-0.5, sm[H - 1], x[0]);
+#pragma unroll
+    for (int j = 0; j + 1 < H; ++j) sm[j] -= sm[H - 1];
+    a[0] = make_double2(tot, 0.0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < SEL::NQ; ++i) {
+        constexpr int dummy = 0; (void)dummy;
+        const int q = SEL::q(i);
+        double ar = base, br = 0.0;
+#pragma unroll
+        for (int j = 1; j <= H; ++j) {
+            if (j < H) ar = fma(PT<R>::c(j * q), sm[j - 1], ar);
+            br = fma(PT<R>::s(j * q), df[j - 1], br);
+        }
+        a[1 + i] = make_double2(ar, -br);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// complex input (in the part's order) -> o[0] = X[0], o[1 + 2 i] = X'[q_i], o[2 + 2 i] = X'[R - q_i]
+template <int R, typename SEL>
+__device__ __forceinline__ void cdft_prime_sel(const double2 *v, double2 *o) {
+    constexpr int H = (R - 1) / 2;
+    double2 sm[H], df[H];
+#pragma unroll
+    for (int j = 1; j <= H; ++j) { sm[j - 1] = cadd(v[j], v[R - j]); df[j - 1] = csub(v[j], v[R - j]); }
+    const double2 x0 = v[0];
+    double2 tot = x0;
+#pragma unroll
+    for (int j = 0; j < H; ++j) tot = cadd(tot, sm[j]);
+    const double2 base = make_double2(fma(-0.5, sm[H - 1].x, x0.x), fma(-0.5, sm[H - 1].y, x0.y));
+#pragma unroll
+    for (int j = 0; j + 1 < H; ++j) sm[j] = csub(sm[j], sm[H - 1]);
+    o[0] = tot;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < SEL::NQ; ++i) {
+        const int q = SEL::q(i);
+        double ar = base.x, ai = base.y, br = 0.0, bi = 0.0;
+#pragma unroll
+        for (int j = 1; j <= H; ++j) {
+            const double c = PT<R>::c(j * q), sn = PT<R>::s(j * q);
+            if (j < H) { ar = fma(c, sm[j - 1].x, ar); ai = fma(c, sm[j - 1].y, ai); }
+            br = fma(sn, df[j - 1].x, br);
+            bi = fma(sn, df[j - 1].y, bi);
+        }
+        o[1 + 2 * i] = make_double2(ar + bi, ai - br);         // X[q] = A - i B
+        o[2 + 2 * i] = make_double2(ar - bi, ai + br);         // X[R - q] = A + i B
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 template <> struct Cd<19> {
     static __device__ __forceinline__ void run(double2 *v) { cdft_prime<19>(v); }
+    static constexpr int pos(int q) { return q; }
+};
+template <> struct Cd<29> {
+    static __device__ __forceinline__ void run(double2 *v) { cdft_prime<29>(v); }
     static constexpr int pos(int q) { return q; }
 };
 template <> struct Cd<10> {
@@ -282,6 +379,9 @@ __device__ __forceinline__ void rdft7(const double *s, double2 *y) {
 }
 template <> struct RCd<29> {
     static __device__ __forceinline__ void run(const double *x, double2 *a) { rdft_prime<29>(x, a); }
+};
+template <> struct RCd<19> {
+    static __device__ __forceinline__ void run(const double *x, double2 *a) { rdft_prime<19>(x, a); }
 };
 template <> struct RCd<21> {
     static __device__ __forceinline__ void run(const double *x, double2 *a) {
@@ -595,9 +695,30 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
         asm volatile("" : "+v"(lane));
         PAA_TRI_PACE(0)
         // pass-2 job of this lane: (q1, b); idle lanes shadow the last job (their plane writes are masked)
-        const int m2 = min(lane, J2 - 1);
+        constexpr int H1 = SH::H1, H2 = SH::H2;
+        int part2 = 0;
+        if constexpr (H2 > 1) {
+#pragma unroll
+            for (int h = 1; h < H2; ++h) part2 = (lane >= h * J2) ? h : part2;
+        }
+        const int m2 = min(lane - part2 * J2, J2 - 1);
         const int q1_2 = m2 / R3, b_2 = m2 - R3 * q1_2;
-        const bool act2 = lane < J2;
+        const bool act2 = lane < J2 * H2;
+        const int *t_split = reinterpret_cast<const int *>(smem + L.off_split);
+        // a part reads its inputs in the order n -> (n ginv) mod R (SplitSel); R <= 29: (n ginv) * ceil(2^16 / R) >> 16 is the quotient
+        int ginv2 = 1;
+        if constexpr (H2 > 1) {
+#pragma unroll
+            for (int h = 1; h < H2; ++h) ginv2 = (part2 == h) ? mod_inverse(SplitSel<R2, H2>::g(h), R2) : ginv2;
+        }
+        auto col2 = [&](int k) {
+            if constexpr (H2 > 1) {
+                const int v = k * ginv2;
+                return v - R2 * ((v * ((65536 + R2 - 1) / R2)) >> 16);
+            } else {
+                return k;
+            }
+        };
         double *cur = slots + (odd ? SLOT : 0);
         const double *prv = slots + (odd ? 0 : SLOT);
         const T *xf = x0 + (long long)t * P.S;
@@ -755,20 +876,36 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                 double xr[NJ][R1];
                 int xi[INT_T ? NJ : 1][INT_T ? R1 : 1];        // integer samples (stereo: L + R), converted row by row below
                 double scl[NJ], meanl[NJ];                     // idle lanes shadow the last job with scale and mean 0: exact zeros
+                // split first pass: lane = part L1 + job; part 0 holds its rows in natural order (it also owns the time-domain sums),
+                // parts 1 .. fetch row (r ginv) mod R1 into register row r
+                int part1 = 0, ginv1 = 1;
+                if constexpr (H1 > 1) {
+#pragma unroll
+                    for (int h = 1; h < H1; ++h) {
+                        part1 = (lane >= h * L1) ? h : part1;
+                        ginv1 = (lane >= h * L1) ? mod_inverse(SplitSel<R1, H1>::g(h), R1) : ginv1;
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < NJ; ++u) {
-                    const int j = lane + 64 * u;
-                    const int jj = (j < L1) ? j : L1 - 1;
-                    scl[u] = (j < L1) ? sc : 0.0;
-                    meanl[u] = (j < L1) ? mean : 0.0;
+                    const int j = (H1 > 1) ? lane - part1 * L1 : lane + 64 * u;
+                    const bool in1 = (H1 > 1) ? lane < H1 * L1 : j < L1;
+                    const int jj = in1 ? j : L1 - 1;
+                    scl[u] = in1 ? sc : 0.0;
+                    meanl[u] = in1 ? mean : 0.0;
                     const T *xb = xf + jj;       // (one address per lane: the rows are immediate offsets of the loads)
 #pragma unroll
                     for (int r = 0; r < R1; ++r) {
+                        int row = r;
+                        if constexpr (H1 > 1) {
+                            const int v = r * ginv1;
+                            row = v - R1 * ((v * ((65536 + R1 - 1) / R1)) >> 16);
+                        }
                         if constexpr (INT_T) {
-                            xi[u][r] = load_int<T>(xb + L1 * r);
+                            xi[u][r] = load_int<T>(xb + L1 * row);
                             if (MODE != 0) xr[u][r] = fma((double)xi[u][r], scl[u], -meanl[u]);
                         } else {
-                            xr[u][r] = fma(load_sample<T>(xb + L1 * r), scl[u], -meanl[u]);
+                            xr[u][r] = fma(load_sample<T>(xb + L1 * row), scl[u], -meanl[u]);
                         }
                     }
                 }
@@ -783,7 +920,7 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                         for (int u = 0; u < NJ; ++u) {
                             if constexpr (INT_T) xr[u][r] = fma((double)xi[u][r], scl[u], -meanl[u]);
                             const double d = xr[u][r];
-                            const double e = d * d;
+                            const double e = (H1 > 1 && lane >= L1) ? 0.0 : d * d;       // (split first pass: part 0 owns the sums)
                             const int n0 = L1 * r + 64 * u;                     // sample of lane 0
                             const int jlo = (n0 / LT < 10) ? n0 / LT : 10;
                             const int jth = (jlo >= 10) ? 64 : (jlo + 1) * LT - n0;
@@ -807,6 +944,25 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                 }
                 finish_time();
                 PAA_TICK(1)
+                if constexpr (H1 > 1) {
+                    // every part forms DC + the SplitSel outputs of its permuted rows; slot s stands for the true output index t_s
+                    // (conjugated when (g q) mod R1 > R1 / 2), times W_N^(j t_s)
+                    typedef SplitSel<R1, H1> S1;
+                    const int jj = (lane < H1 * L1) ? lane - part1 * L1 : L1 - 1;
+                    rdft_prime_sel<R1, S1>(xr[0], a[0]);
+                    int code1[1 + S1::NQ];
+                    double2 wl1[1 + S1::NQ];
+#pragma unroll
+                    for (int sl = 1; sl <= S1::NQ; ++sl) {
+                        code1[sl] = t_split[8 * part1 + sl];
+                        wl1[sl] = g_tw1[(code1[sl] & 0xff) * L1 + jj];
+                    }
+#pragma unroll
+                    for (int sl = 1; sl <= S1::NQ; ++sl) {
+                        const double2 z = make_double2(a[0][sl].x, (code1[sl] & 0x100) ? -a[0][sl].y : a[0][sl].y);
+                        a[0][sl] = cmul(z, wl1[sl]);
+                    }
+                } else
 #pragma unroll
                 for (int u = 0; u < NJ; ++u) {
                     const int j = lane + 64 * u;
@@ -826,10 +982,11 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                 }
             }
         }
+        constexpr int NS1 = (H1 > 1) ? 1 + SplitNQ<R1, H1>::value : NQ1;      // pass-1 output slots a lane holds
 #pragma unroll
         for (int u = 0; u < NJ; ++u)
 #pragma unroll
-            for (int q = 0; q < NQ1; ++q) asm volatile("" : "+v"(a[u][q].x), "+v"(a[u][q].y));
+            for (int q = 0; q < NS1; ++q) asm volatile("" : "+v"(a[u][q].x), "+v"(a[u][q].y));
         PAA_TICK(2)
         wsync();               // the previous frame's readers of this slot are done
 
@@ -837,29 +994,74 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
         double2 c2[R2];
         {
             double *pl = cur;
+            int w1[NS1];           // split first pass: where slot s of this lane goes (second copies and idle lanes: a dummy double behind the plane)
+            if constexpr (H1 > 1) {
+                int part1 = 0;
 #pragma unroll
-            for (int u = 0; u < NJ; ++u)
-                if (lane + 64 * u < L1) {
+                for (int h = 1; h < H1; ++h) part1 = (lane >= h * L1) ? h : part1;
+                const int j = lane - part1 * L1;
 #pragma unroll
-                    for (int q = 0; q < NQ1; ++q) pl[q * PP + lane + 64 * u] = a[u][q].x;
+                for (int sl = 0; sl < NS1; ++sl) {
+                    const int code = t_split[8 * part1 + sl];
+                    w1[sl] = ((code & 0x200) && lane < H1 * L1) ? (code & 0xff) * PP + j : SH::PLANE;
                 }
+#pragma unroll
+                for (int sl = 0; sl < NS1; ++sl) pl[w1[sl]] = a[0][sl].x;
+            } else {
+#pragma unroll
+                for (int u = 0; u < NJ; ++u)
+                    if (lane + 64 * u < L1) {
+#pragma unroll
+                        for (int q = 0; q < NQ1; ++q) pl[q * PP + lane + 64 * u] = a[u][q].x;
+                    }
+            }
             wsync();
 #pragma unroll
-            for (int k = 0; k < R2; ++k) c2[k].x = pl[q1_2 * PP + R3 * k + b_2];
+            for (int k = 0; k < R2; ++k) c2[k].x = pl[q1_2 * PP + R3 * col2(k) + b_2];
+            wsync();
+            if constexpr (H1 > 1) {
+#pragma unroll
+                for (int sl = 0; sl < NS1; ++sl) pl[w1[sl]] = a[0][sl].y;
+            } else {
+#pragma unroll
+                for (int u = 0; u < NJ; ++u)
+                    if (lane + 64 * u < L1) {
+#pragma unroll
+                        for (int q = 0; q < NQ1; ++q) pl[q * PP + lane + 64 * u] = a[u][q].y;
+                    }
+            }
             wsync();
 #pragma unroll
-            for (int u = 0; u < NJ; ++u)
-                if (lane + 64 * u < L1) {
-#pragma unroll
-                    for (int q = 0; q < NQ1; ++q) pl[q * PP + lane + 64 * u] = a[u][q].y;
-                }
-            wsync();
-#pragma unroll
-            for (int k = 0; k < R2; ++k) c2[k].y = pl[q1_2 * PP + R3 * k + b_2];
+            for (int k = 0; k < R2; ++k) c2[k].y = pl[q1_2 * PP + R3 * col2(k) + b_2];
             wsync();
         }
         PAA_TICK(3)
         // ---------------- pass 2: radix R2 over a, outputs times W_L1^(b q2)
+        constexpr int NS2 = (H2 > 1) ? 1 + 2 * SplitNQ<R2, H2>::value : R2;        // pass-2 outputs a lane holds
+        double2 o2[(H2 > 1) ? NS2 : 1];
+        int code2[(H2 > 1) ? NS2 : 1];
+        if constexpr (H2 > 1) {
+            // every part forms DC + the SplitSel output pairs of its permuted column; slot s stands for the true output index of the
+            // host table (bit 9: this lane is the one that delivers it), times W_L1^(b t)
+            cdft_prime_sel<R2, SplitSel<R2, H2>>(c2, o2);
+#pragma unroll
+            for (int sl = 0; sl < NS2; ++sl) code2[sl] = t_split[8 * (H1 > 1 ? H1 : 1) + 16 * part2 + sl];
+            if constexpr (R3 > 1) {
+#pragma unroll
+                for (int s0 = 1; s0 < NS2; s0 += 4) {
+                    double2 wl[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (s0 + k < NS2) wl[k] = t_tw2[(code2[s0 + k] & 0xff) * R3 + b_2];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (s0 + k < NS2) o2[s0 + k] = cmul(o2[s0 + k], wl[k]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int sl = 0; sl < NS2; ++sl) asm volatile("" : "+v"(o2[sl].x), "+v"(o2[sl].y));
+        } else {
         Cd<R2>::run(c2);
 #pragma unroll
         for (int q0 = 1; q0 < (R3 > 1 ? R2 : 0); q0 += 4) {
@@ -876,6 +1078,7 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
         // them, keeping the twiddles and the codelet's outputs alive side by side -- 80 registers)
 #pragma unroll
         for (int q = 0; q < R2; ++q) asm volatile("" : "+v"(c2[q].x), "+v"(c2[q].y));
+        }
         PAA_TICK(4)
         // ---------------- exchange 2: element (q1, b, q2) at plane[q1 PP + q2 R3 + b]; pass 3 + |X| / num_fft (:617-621)
         if constexpr (R3 == 1) {
@@ -883,12 +1086,14 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
             // where (idle lanes and the results no bin takes: the parking double at index NF); no predicates around the stores
             const unsigned short *t_st = reinterpret_cast<const unsigned short *>(t_p3);
             unsigned char *plb = reinterpret_cast<unsigned char *>(cur);
-            unsigned so[R2];
+            unsigned so[NS2];
 #pragma unroll
-            for (int q = 0; q < R2; ++q) so[q] = t_st[q * 64 + lane];
+            for (int q = 0; q < NS2; ++q) so[q] = t_st[q * 64 + lane];
 #pragma unroll
-            for (int q = 0; q < R2; ++q) {
-                const double2 z = c2[Cd<R2>::pos(q)];
+            for (int q = 0; q < NS2; ++q) {
+                double2 z;
+                if constexpr (H2 > 1) z = o2[q];          // (split second pass: slot q of this lane; the table knows its bin)
+                else z = c2[Cd<R2>::pos(q)];
                 const double mg = mag_sqrt(fma(z.x, z.x, z.y * z.y)) * mscale;
                 *reinterpret_cast<double *>(plb + so[q]) = mg;
             }
@@ -971,7 +1176,14 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
             for (int u = 0; u < NR3; ++u) pe[u] = t_p3[lane + 64 * u];
             double *pl = cur;
             unsigned char *plb = reinterpret_cast<unsigned char *>(cur);
-            if (act2) {
+            int w2[(H2 > 1) ? NS2 : 1];        // split second pass: where slot s goes (second copies, idle lanes: the dummy double behind the plane)
+            if constexpr (H2 > 1) {
+#pragma unroll
+                for (int sl = 0; sl < NS2; ++sl)
+                    w2[sl] = ((code2[sl] & 0x200) && act2) ? q1_2 * PP + (code2[sl] & 0xff) * SH::R3P + b_2 : SH::PLANE;
+#pragma unroll
+                for (int sl = 0; sl < NS2; ++sl) pl[w2[sl]] = o2[sl].x;
+            } else if (act2) {
 #pragma unroll
                 for (int q = 0; q < R2; ++q) pl[q1_2 * PP + q * SH::R3P + b_2] = c2[Cd<R2>::pos(q)].x;
             }
@@ -983,7 +1195,10 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                 for (int b = 0; b < R3; ++b) d3[u][b].x = pa[b];
             }
             wsync();
-            if (act2) {
+            if constexpr (H2 > 1) {
+#pragma unroll
+                for (int sl = 0; sl < NS2; ++sl) pl[w2[sl]] = o2[sl].y;
+            } else if (act2) {
 #pragma unroll
                 for (int q = 0; q < R2; ++q) pl[q1_2 * PP + q * SH::R3P + b_2] = c2[Cd<R2>::pos(q)].y;
             }
@@ -1058,8 +1273,10 @@ typedef Shape<21, 21, 2, true, 42, 8> S1764;        // 40 ms at 44.1 kHz (audioA
 typedef Shape<20, 16, 3, true, 49, 8> S1920;        // 40 ms at 48 kHz: 960 complex points
 typedef Shape<20, 20, 2, true, 40, 8> S1600;        // 50 ms at 32 kHz: 800 complex points
 typedef Shape<20, 10, 3, true, 30, 8> S1200;        // 50 ms at 24 kHz / 25 ms at 48 kHz: 600 complex points
-typedef Shape<29, 19, 1, false, 19, 8> S551;        // 50 ms at 11.025 kHz / 25 ms at 22.05 kHz: 551 real points, two passes
-typedef Shape<29, 19, 2, false, 38, 8> S1102;       // 25 ms at 44.1 kHz (BASELINE config 5) / 50 ms at 22.05 kHz: 1102 real points
+typedef Shape<29, 19, 1, false, 19, 12, 1, 3, 3> S551;   // 50 ms at 11.025 kHz / 25 ms at 22.05 kHz: 551 real points, two passes; both prime
+                                                         // butterflies shared by three lanes (57 / 45 lanes busy instead of 19 / 15)
+typedef Shape<19, 29, 2, false, 58, 8, 2, 1, 3> S1102;   // 25 ms at 44.1 kHz (BASELINE config 5) / 50 ms at 22.05 kHz: 1102 real points;
+                                                         // radix 19 first (58 lanes), then radix 29 shared by three lanes (20 jobs: 60 lanes)
 // power-of-two windows (what callers outside the reference's 50 ms default pass most often, ShortTermFeatures.py:563-564 takes any
 // window): every pass on all 64 lanes where the factorisation allows it.  Plane row pitches from scripts/dev/tri_model.py's LDS
 // model (ds_write_b64: 16-lane groups mod 16 doubles, ds_read_b64: 32-lane groups mod 32): the radix-8 shapes use row pitch 72
@@ -1118,6 +1335,7 @@ inline void tri_fill(double fs, const MelTable *mel, const ChromaTable *chroma, 
     L.off_chstart = take(13 * 4);
     L.off_chsrc = take(std::max<size_t>(n_ch, 1) * 4);
     L.off_chw = take(std::max<size_t>(n_ch, 1) * 8);
+    L.off_split = take((size_t)(8 * SH::H1 + 16 * SH::H2) * 4);
     L.off_sync = take(32 * 4);
     L.table_bytes = off;
     L.off_g_tw1 = take((size_t)NQ1 * L1 * 16);
@@ -1172,10 +1390,53 @@ inline void tri_fill(double fs, const MelTable *mel, const ChromaTable *chroma, 
         constexpr int NF = SH::NF;
         auto where = [&](int q1, int k) { return 8 * ((k < NF) ? k : (q1 > 0 && N - k < NF) ? N - k : NF); };
         unsigned short *pt = reinterpret_cast<unsigned short *>(b + L.off_p3);
+        // split prime passes (Shape::H1 / H2): per part and output slot the true index, conjugate flag, and whether this part is the
+        // one that delivers it (the first part that produces an index)
+        int *sp = reinterpret_cast<int *>(b + L.off_split);
+        if constexpr (SH::H1 > 1) {
+            typedef SplitSel<R1, SH::H1> S1;
+            std::vector<char> seen(R1, 0);
+            for (int h = 0; h < SH::H1; ++h) {
+                sp[8 * h] = 0 | (h == 0 ? 0x200 : 0);
+                for (int i = 0; i < S1::NQ; ++i) {
+                    const int gq = (S1::g(h) * S1::q(i)) % R1;
+                    const int t = gq <= R1 / 2 ? gq : R1 - gq;
+                    sp[8 * h + 1 + i] = t | (gq > R1 / 2 ? 0x100 : 0) | (seen[t] ? 0 : 0x200);
+                    seen[t] = 1;
+                }
+            }
+        }
+        if constexpr (SH::H2 > 1) {
+            typedef SplitSel<R2, SH::H2> S2;
+            int *sp2 = sp + 8 * SH::H1;
+            std::vector<char> seen(R2, 0);
+            for (int h = 0; h < SH::H2; ++h) {
+                sp2[16 * h] = 0 | (h == 0 ? 0x200 : 0);
+                for (int i = 0; i < S2::NQ; ++i) {
+                    const int tp = (S2::g(h) * S2::q(i)) % R2, tm = R2 - tp;
+                    sp2[16 * h + 1 + 2 * i] = tp | (seen[tp] ? 0 : 0x200);
+                    sp2[16 * h + 2 + 2 * i] = tm | (seen[tm] ? 0 : 0x200);
+                    seen[tp] = seen[tm] = 1;
+                }
+            }
+        }
         if (R3 == 1) {
+            if constexpr (SH::H2 > 1) {
+                // where slot s of lane (part, q1) puts its magnitude: the bin of Z[q1 + R1 t], its mirror, or the parking double
+                const int *sp2 = sp + 8 * SH::H1;
+                constexpr int NS2 = 1 + 2 * SplitNQ<R2, SH::H2>::value;
+                for (int sl = 0; sl < NS2; ++sl)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int part = lane / SH::J2, q1 = lane % SH::J2;
+                        const bool on = part < SH::H2 && (sp2[16 * (part < SH::H2 ? part : 0) + sl] & 0x200);
+                        const int t = sp2[16 * (part < SH::H2 ? part : 0) + sl] & 0xff;
+                        pt[sl * 64 + lane] = (unsigned short)(on ? where(q1, q1 + R1 * t) : 8 * NF);
+                    }
+            } else {
             for (int q2 = 0; q2 < R2; ++q2)
                 for (int lane = 0; lane < 64; ++lane)
                     pt[q2 * 64 + lane] = (unsigned short)(lane < NQ1 ? where(lane, lane + R1 * q2) : 8 * NF);
+            }
         } else {
             for (int m3 = 0; m3 < 64 * NR3; ++m3) {
                 const int q1 = m3 / R2, q2 = m3 % R2;
@@ -1214,12 +1475,12 @@ inline int tri_select(int window, int mode, double fs, const MelTable *mel, cons
     tl.shape = sh;
     static const char *names[3][11] = {
         {"st_tri_20x20x3", "st_tri_r21x21x5", "st_tri_21x21x2", "st_tri_20x16x3", "st_tri_20x20x2", "st_tri_20x10x3", "st_tri_r29x19",
-         "st_tri_r29x19x2", "st_tri_8x8x8", "st_tri_16x16x4", "st_tri_4x8x8"},
+         "st_tri_r19x29x2", "st_tri_8x8x8", "st_tri_16x16x4", "st_tri_4x8x8"},
         {"spectrogram_tri_20x20x3", "spectrogram_tri_r21x21x5", "spectrogram_tri_21x21x2", "spectrogram_tri_20x16x3",
-         "spectrogram_tri_20x20x2", "spectrogram_tri_20x10x3", "spectrogram_tri_r29x19", "spectrogram_tri_r29x19x2",
+         "spectrogram_tri_20x20x2", "spectrogram_tri_20x10x3", "spectrogram_tri_r29x19", "spectrogram_tri_r19x29x2",
          "spectrogram_tri_8x8x8", "spectrogram_tri_16x16x4", "spectrogram_tri_4x8x8"},
         {"chromagram_tri_20x20x3", "chromagram_tri_r21x21x5", "chromagram_tri_21x21x2", "chromagram_tri_20x16x3",
-         "chromagram_tri_20x20x2", "chromagram_tri_20x10x3", "chromagram_tri_r29x19", "chromagram_tri_r29x19x2",
+         "chromagram_tri_20x20x2", "chromagram_tri_20x10x3", "chromagram_tri_r29x19", "chromagram_tri_r19x29x2",
          "chromagram_tri_8x8x8", "chromagram_tri_16x16x4", "chromagram_tri_4x8x8"}};
     tl.name = names[mode][sh];
     switch (sh) {

@@ -155,14 +155,14 @@ extern "C" int paa_debug_tri_plan(int window, double fs, int32_t *shape8, int32_
     switch (tl.shape) {
 #define PAA_TRI_DESCRIBE(ID, SH)                                                                               \
         case ID: shape8[0] = tri::SH::R1; shape8[1] = tri::SH::R2; shape8[2] = tri::SH::R3; shape8[3] = (tri::SH::PACKED ? 1 : 0) | (tri::SH::R3P << 8);    \
-                 shape8[4] = tri::SH::P; shape8[5] = tri::SH::NW; shape8[6] = tri::SH::NJOB3; shape8[7] = (int32_t)tl.lds; break;
+                 shape8[4] = tri::SH::P; shape8[5] = tri::SH::NW | (tri::SH::H1 << 8) | (tri::SH::H2 << 16); shape8[6] = tri::SH::NJOB3; shape8[7] = (int32_t)tl.lds; break;
         PAA_TRI_SHAPES(PAA_TRI_DESCRIBE)
 #undef PAA_TRI_DESCRIBE
         default: return 0;
     }
     const tri::TriLayout &L = tl.layout;
     offsets6[0] = L.off_tw2; offsets6[1] = L.off_p3; offsets6[2] = L.off_g_tw1; offsets6[3] = L.off_g_post;
-    offsets6[4] = L.table_bytes; offsets6[5] = L.total_bytes;
+    offsets6[4] = L.table_bytes; offsets6[5] = L.total_bytes; offsets6[6] = L.off_split;
     if (blob) {
         if (capacity < (int)b.size()) return fail(PAA_ERR_ARG, "capacity %d < %zu", capacity, b.size());
         memcpy(blob, b.data(), b.size());

@@ -410,6 +410,10 @@ def test_profile_records_the_bench_line_quotes_are_this_rounds():
     assert 0.25 < ex["issued_tflops"] / peak_at < 0.45
 
 
+def L1_ok(L1, H1):
+    return L1 * H1 <= 64
+
+
 @pytest.mark.parametrize("window", [2400, 2205, 1764, 1920, 1600, 1200, 1102, 551, 1024, 2048, 512])
 def test_three_pass_tables_reproduce_the_fft(window):
     """Host tables of csrc/kernels_tri.hpp (no device): the three passes restated in NumPy FROM THE LIBRARY'S OWN TABLES --
@@ -419,7 +423,7 @@ def test_three_pass_tables_reproduce_the_fft(window):
     import ctypes
     lib = _ffi.lib()
     shape = np.zeros(8, dtype=np.int32)
-    off = np.zeros(6, dtype=np.int32)
+    off = np.zeros(7, dtype=np.int32)
     size = lib.paa_debug_tri_plan(window, 44100.0, shape.ctypes.data_as(_ffi.c_i32p), off.ctypes.data_as(_ffi.c_i32p), None, 0)
     assert size > 0
     blob = np.zeros(size, dtype=np.uint8)
@@ -427,29 +431,90 @@ def test_three_pass_tables_reproduce_the_fft(window):
                                   blob.ctypes.data_as(ctypes.c_void_p), size) == size
     R1, R2, R3, packed, P, NW, njob3, lds = (int(v) for v in shape)
     packed, R3P = packed & 1, packed >> 8          # second exchange: element (q1, b, q2) at plane[q1 P + q2 R3P + b]
+    NW, H1, H2 = NW & 0xff, (NW >> 8) & 0xff, NW >> 16      # H1 / H2 lanes share a prime butterfly of pass 1 / 2 (SplitSel in kernels_tri.hpp)
+    # the output indices q every part computes and the parts' multipliers g (part h reads its inputs in the order
+    # n -> (n g^-1) mod R, which makes its output q the true output (g q) mod R): the constants of kernels_tri.hpp's SplitSel
+    SEL = {(29, 3): ((1, 2, 3, 6, 9), (1, 5, 11)), (19, 3): ((1, 2, 4), (1, 7, 8))}
+    split = blob[off[6]:off[6] + 4 * (8 * H1 + 16 * H2)].view(np.int32)
     assert R3P >= R3 and P >= (R2 - 1) * R3P + R3
     N = R1 * R2 * R3
     assert N == (window // 2 if packed else window) and (packed == 1) == (window % 2 == 0 and window != 1102)
-    assert R3 <= 8
+    assert R3 <= 8 and (H1 == 1 or L1_ok(R2 * R3, H1)) and R3 * ((R1 if packed else (R1 + 1) // 2)) * H2 <= 64
     L1, NQ1, NF = R2 * R3, (R1 if packed else (R1 + 1) // 2), window // 2
-    assert P >= L1 and NQ1 * R3 <= 64 and lds <= 160 * 1024 and 7 <= NW <= 12
+    assert P >= L1 and NQ1 * R3 * H2 <= 64 and lds <= 160 * 1024 and 7 <= NW <= 12
     cplx = lambda o, n: blob[o:o + 16 * n].view(np.float64).reshape(n, 2) @ np.array([1.0, 1j])
     tw2 = cplx(off[0], R2 * R3).reshape(R2, R3)
     tw1 = cplx(off[2], NQ1 * L1).reshape(NQ1, L1)
     rng = np.random.default_rng(window)
     y = rng.standard_normal(window)
     z = (y[0::2] + 1j * y[1::2]) if packed else y.astype(complex)
-    plane = np.zeros(NQ1 * P, dtype=complex)
-    for j in range(L1):                                         # pass 1 + exchange 1: element (j, q1) at plane[q1 P + j]
-        plane[np.arange(NQ1) * P + j] = np.fft.fft(z[j + L1 * np.arange(R1)])[:NQ1] * tw1[:, j]
-    plane2 = np.zeros(NQ1 * P, dtype=complex)
-    for q1 in range(NQ1):                                       # pass 2 + exchange 2: (q1, b, q2) at plane[q1 P + q2 R3P + b]
-        for b in range(R3):
-            c = np.fft.fft(plane[q1 * P + R3 * np.arange(R2) + b]) * tw2[:, b]
-            plane2[q1 * P + np.arange(R2) * R3P + b] = c
+    plane = np.full(NQ1 * P + 1, np.nan, dtype=complex)
+    if H1 > 1:
+        # split first pass: part h of job j forms DC + the outputs q of SEL from its rows in permuted order; the host table says
+        # which true index a slot stands for, whether it is conjugated, and whether this part delivers it
+        qs, gs = SEL[(R1, H1)]
+        written = np.zeros(NQ1, dtype=int)
+        for h in range(H1):
+            ginv = pow(gs[h], -1, R1)
+            for j in range(L1):
+                Y = np.fft.fft(z[j + L1 * ((np.arange(R1) * ginv) % R1)])
+                slots = [Y[0]] + [Y[q] for q in qs]
+                for sl, val in enumerate(slots):
+                    code = int(split[8 * h + sl])
+                    t, conj, on = code & 0xff, bool(code & 0x100), bool(code & 0x200)
+                    assert t == (0 if sl == 0 else min((gs[h] * qs[sl - 1]) % R1, R1 - (gs[h] * qs[sl - 1]) % R1))
+                    assert conj == (sl > 0 and (gs[h] * qs[sl - 1]) % R1 > R1 // 2)
+                    if on:
+                        plane[t * P + j] = (np.conj(val) if conj else val) * tw1[t, j]
+                        written[t] += (j == 0)
+        assert np.all(written == 1), written                   # every pass-1 output delivered by exactly one part
+    else:
+        for j in range(L1):                                     # pass 1 + exchange 1: element (j, q1) at plane[q1 P + j]
+            plane[np.arange(NQ1) * P + j] = np.fft.fft(z[j + L1 * np.arange(R1)])[:NQ1] * tw1[:, j]
+    plane2 = np.full(NQ1 * P + 1, np.nan, dtype=complex)
+    lane_mag = {}                                               # two-pass split shapes: (slot, lane) -> magnitude
+    if H2 > 1:
+        qs, gs = SEL[(R2, H2)]
+        s2 = split[8 * H1:]
+        J2 = NQ1 * R3
+        written = np.zeros((NQ1, R3, R2), dtype=int)
+        for h in range(H2):
+            ginv = pow(gs[h], -1, R2)
+            for m2 in range(J2):
+                q1, b = divmod(m2, R3)
+                Y = np.fft.fft(plane[q1 * P + R3 * ((np.arange(R2) * ginv) % R2) + b])
+                slots = [Y[0]]
+                for q in qs:
+                    slots += [Y[q], Y[R2 - q]]
+                for sl, val in enumerate(slots):
+                    code = int(s2[16 * h + sl])
+                    t, on = code & 0xff, bool(code & 0x200)
+                    want_t = 0 if sl == 0 else ((gs[h] * qs[(sl - 1) // 2]) % R2 if sl % 2 == 1 else R2 - (gs[h] * qs[(sl - 1) // 2]) % R2)
+                    assert t == want_t
+                    val = val * tw2[t, b]
+                    lane_mag[(sl, h * J2 + m2)] = (val, q1, t, on)
+                    if on:
+                        plane2[q1 * P + t * R3P + b] = val
+                        written[q1, b, t] += 1
+        assert np.all(written == 1)                             # every pass-2 output delivered by exactly one part
+    else:
+        for q1 in range(NQ1):                                   # pass 2 + exchange 2: (q1, b, q2) at plane[q1 P + q2 R3P + b]
+            for b in range(R3):
+                c = np.fft.fft(plane[q1 * P + R3 * np.arange(R2) + b]) * tw2[:, b]
+                plane2[q1 * P + np.arange(R2) * R3P + b] = c
     X = np.full(NF, np.nan)
     hits = np.zeros(NF, dtype=int)
-    if R3 == 1:                                                 # two passes: lane q1 holds Z[q1 + R1 q2]
+    if R3 == 1 and H2 > 1:                                      # two passes, split second pass: slot s of lane (part, q1)
+        assert not packed
+        ns2 = 1 + 2 * len(SEL[(R2, H2)][0])
+        where = blob[off[1]:off[1] + 2 * 64 * ns2].view(np.uint16).reshape(ns2, 64)      # byte offset of the lane's magnitude of slot s
+        assert np.all(where % 8 == 0) and np.all(where[:, NQ1 * H2:] == 8 * NF)          # idle lanes: the parking double
+        for (sl, lane), (val, q1, t, on) in lane_mag.items():
+            k = int(where[sl, lane]) // 8
+            assert k <= NF and (k == NF if not on else k in (q1 + R1 * t, N - q1 - R1 * t, NF))
+            if k < NF:
+                X[k] = abs(val); hits[k] += 1
+    elif R3 == 1:                                               # two passes: lane q1 holds Z[q1 + R1 q2]
         assert not packed
         where = blob[off[1]:off[1] + 2 * 64 * R2].view(np.uint16).reshape(R2, 64)      # byte offset of lane q1's magnitude q2
         assert np.all(where % 8 == 0) and np.all(where[:, NQ1:] == 8 * NF)              # idle lanes: the parking double
