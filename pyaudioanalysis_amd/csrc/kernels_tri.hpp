@@ -60,9 +60,12 @@ constexpr int pair_count(int R1, int R2, int R3) {
     return pairs;
 }
 
-template <int R1_, int R2_, int R3_, bool PACKED_, int P_, int NW_, int R3P_ = R3_, int H1_ = 1, int H2_ = 1>
+template <int R1_, int R2_, int R3_, bool PACKED_, int P_, int NW_, int R3P_ = R3_, int H1_ = 1, int H2_ = 1, int NWR_ = NW_>
 struct Shape {
     static constexpr int R1 = R1_, R2 = R2_, R3 = R3_, P = P_, NW = NW_;
+    // waves per workgroup of the spectrogram / chromagram instances (no feature stage: fewer registers, so a third wave per SIMD fits
+    // where the feature instance needs more than 168)
+    static constexpr int NWR = NWR_;
     // prime first / second radix of a real-input shape: the O(R^2) butterfly of a pass-1 (pass-2) job is shared by H1 (H2) lanes,
     // each forming a subset of the outputs (SplitSel below) -- the lanes a prime shape leaves idle take a share of the FMAs
     static constexpr int H1 = H1_, H2 = H2_;
@@ -588,7 +591,7 @@ __device__ __forceinline__ void tri_features(const TriLayout &L, const Tabs &tb,
 
 // MODE 0: short-term features (DELTAS: 68 rows), 1: spectrogram rows, 2: chromagram rows
 template <typename SH, typename T, int MODE, int DELTAS>
-__global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(PlanDev P, TriLayout L,
+__global__ __launch_bounds__(64 * (MODE == 0 ? SH::NW : SH::NWR), ((MODE == 0 ? SH::NW : SH::NWR) + 3) / 4) void st_tri_kernel(PlanDev P, TriLayout L,
                                                                                const unsigned char *__restrict__ blob,
                                                                                const T *__restrict__ sig,
                                                                                const ClipDev *__restrict__ clips,
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(64 * SH::NW, (SH::NW + 3) / 4) void st_tri_kernel(P
                                                                                double *__restrict__ out) {
     constexpr int R1 = SH::R1, R2 = SH::R2, R3 = SH::R3, N = SH::N, W = SH::W, NF = SH::NF, L1 = SH::L1, NQ1 = SH::NQ1;
     constexpr int NJ = SH::NJ, J2 = SH::J2, NR3 = SH::NR3, PP = SH::P, SLOT = SH::SLOT, LT = SH::LT;
-    constexpr int NW = SH::NW, N3 = R1 * R2;
+    constexpr int NW = (MODE == 0) ? SH::NW : SH::NWR, N3 = R1 * R2;
     constexpr bool PACKED = SH::PACKED;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     {
@@ -1275,7 +1278,7 @@ typedef Shape<20, 20, 2, true, 40, 8> S1600;        // 50 ms at 32 kHz: 800 comp
 typedef Shape<20, 10, 3, true, 30, 8> S1200;        // 50 ms at 24 kHz / 25 ms at 48 kHz: 600 complex points
 typedef Shape<29, 19, 1, false, 19, 12, 1, 3, 3> S551;   // 50 ms at 11.025 kHz / 25 ms at 22.05 kHz: 551 real points, two passes; both prime
                                                          // butterflies shared by three lanes (57 / 45 lanes busy instead of 19 / 15)
-typedef Shape<19, 29, 2, false, 58, 8, 2, 1, 3> S1102;   // 25 ms at 44.1 kHz (BASELINE config 5) / 50 ms at 22.05 kHz: 1102 real points;
+typedef Shape<19, 29, 2, false, 58, 8, 2, 1, 3, 12> S1102;  // 25 ms at 44.1 kHz (BASELINE config 5) / 50 ms at 22.05 kHz: 1102 real points;
                                                          // radix 19 first (58 lanes), then radix 29 shared by three lanes (20 jobs: 60 lanes)
 // power-of-two windows (what callers outside the reference's 50 ms default pass most often, ShortTermFeatures.py:563-564 takes any
 // window): every pass on all 64 lanes where the factorisation allows it.  Plane row pitches from scripts/dev/tri_model.py's LDS
@@ -1318,7 +1321,7 @@ inline int tri_shape_of(int window) {
     X(8, S1024) X(9, S2048) X(10, S512)
 
 template <typename SH>
-inline void tri_fill(double fs, const MelTable *mel, const ChromaTable *chroma, TriLaunch &tl, std::vector<unsigned char> &blob) {
+inline void tri_fill(double fs, int mode, const MelTable *mel, const ChromaTable *chroma, TriLaunch &tl, std::vector<unsigned char> &blob) {
     constexpr int R1 = SH::R1, R2 = SH::R2, R3 = SH::R3, N = SH::N, L1 = SH::L1, NQ1 = SH::NQ1, NR3 = SH::NR3;
     TriLayout &L = tl.layout;
     memset(&L, 0, sizeof(L));
@@ -1463,8 +1466,8 @@ inline void tri_fill(double fs, const MelTable *mel, const ChromaTable *chroma, 
         memcpy(b + L.off_chsrc, chroma->src.data(), n_ch * 4);
         memcpy(b + L.off_chw, chroma->w.data(), n_ch * 8);
     }
-    tl.waves = SH::NW;
-    tl.lds = (size_t)L.table_bytes + (size_t)SH::NW * SH::WAVE_DOUBLES * 8;
+    tl.waves = (mode == 0) ? SH::NW : SH::NWR;
+    tl.lds = (size_t)L.table_bytes + (size_t)tl.waves * SH::WAVE_DOUBLES * 8;
 }
 
 // returns 1 when a three-pass instance exists for this window (fills tl and the table blob), 0 otherwise
@@ -1484,7 +1487,7 @@ inline int tri_select(int window, int mode, double fs, const MelTable *mel, cons
          "chromagram_tri_8x8x8", "chromagram_tri_16x16x4", "chromagram_tri_4x8x8"}};
     tl.name = names[mode][sh];
     switch (sh) {
-#define PAA_TRI_FILL(ID, SH) case ID: tri_fill<SH>(fs, mel, chroma, tl, blob); break;
+#define PAA_TRI_FILL(ID, SH) case ID: tri_fill<SH>(fs, mode, mel, chroma, tl, blob); break;
         PAA_TRI_SHAPES(PAA_TRI_FILL)
 #undef PAA_TRI_FILL
         default: return 0;
@@ -1504,8 +1507,9 @@ static inline int tri_launch_one(const TriLaunch &tl, const PlanDev &P, const un
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl.lds) != hipSuccess) return -1;
         attr.set(tl.lds);
     }
-    const unsigned grid = (unsigned)((n_tiles + SH::NW - 1) / SH::NW);
-    hipLaunchKernelGGL((st_tri_kernel<SH, T, MODE, DELTAS>), dim3(grid), dim3(64 * SH::NW), tl.lds, stream, P, tl.layout, blob,
+    constexpr int NWM = (MODE == 0) ? SH::NW : SH::NWR;
+    const unsigned grid = (unsigned)((n_tiles + NWM - 1) / NWM);
+    hipLaunchKernelGGL((st_tri_kernel<SH, T, MODE, DELTAS>), dim3(grid), dim3(64 * NWM), tl.lds, stream, P, tl.layout, blob,
                        (const T *)d_packed, clips, norms, tiles, (int)n_tiles, d_out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

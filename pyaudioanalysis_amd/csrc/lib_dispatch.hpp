@@ -3,6 +3,13 @@
 // Adding a family = one more entry (and its family_<name>.hip).  Included by paa_lib.hip after the plan structure.
 #pragma once
 
+// A/B builds of scripts/rounds/r05/gpu_r05j.sh: 1 lets the three-pass kernel (radix 19 first, radix 29 shared by three lanes) take
+// config 5's spectrogram / chromagram rows too.  Measured: spectrogram 0.2161 against 0.221 ms on the prime-factor kernel,
+// chromagram 0.2336 against 0.2262 ms -- a draw; the rows stay with st_reg
+#ifndef PAA_TRI_1102_ROWS
+#define PAA_TRI_1102_ROWS 0
+#endif
+
 struct FamilyCtx {
     paa_plan *p;
     TableSet *tab;
@@ -84,7 +91,7 @@ static int fam_ct_launch(paa_plan *p, const void *d_packed, double *d_out, const
 // PAA_REG_1102=1 puts it back for A/B runs)
 static int fam_reg_select(FamilyCtx &c) {
     if (g_force_generic || !c.tab->fft.even || !reg::reg_supported(c.window)) return 0;
-    if (c.mode == 0 && !experiment_env("PAA_REG_1102")) return 0;
+    if ((c.mode == 0 || PAA_TRI_1102_ROWS) && !experiment_env("PAA_REG_1102")) return 0;
     using SH = reg::Shape1102;
     std::vector<unsigned char> blob;
     reg::reg_layout<SH>(c.tab->fft, c.mel(), c.chroma(), c.F, c.p->rl, &blob);
@@ -108,7 +115,7 @@ static int fam_reg_launch(paa_plan *p, const void *d_packed, double *d_out, cons
 // ---- kernels_tri.hpp: three-pass register FFT -- the reference's default 50 ms windows at 48 / 44.1 kHz (2400, 2205), the
 // 40 ms ones (1920, 1764), 1600, 1200, config 5's feature matrix (1102) and the odd 551 (50 ms at 11.025 kHz)
 static int fam_tri_select(FamilyCtx &c) {
-    if (g_force_generic || (c.window == 1102 && c.mode != 0)) return 0;
+    if (g_force_generic || (c.window == 1102 && c.mode != 0 && !PAA_TRI_1102_ROWS)) return 0;
     std::vector<unsigned char> blob;
     if (!tri::tri_select(c.window, c.mode, c.fs, c.mel(), c.chroma(), c.p->trl, blob)) return 0;
     const int rc = upload_blob(c.p, blob);
