@@ -126,6 +126,8 @@ struct TriLayout {
     int off_split;                  // split prime passes: int [H1][8] then int [H2][16]: per part and output slot the true output index
                                     // (bits 0-7), conjugate (bit 8), enabled (bit 9: the first part that produces an index writes it)
     int off_sync;                   // pacing of the waves of a SIMD: SIMD id [16], progress in half frames [16] (ints)
+    int waves;                      // waves per workgroup of this launch: the shape's maximum (Shape::NW / NWR, which also sets the
+                                    // register budget) or fewer when the table blob of this (fs, window) leaves less LDS
     int table_bytes;                // LDS part, multiple of 16
     int off_g_tw1;                  // global part: double2 [NQ1][L1]: W_N^(j q1)
     int off_g_post;                 // packed: double2 [64 NR3][R3]: W_W^(kA + N3 k3)
@@ -303,6 +305,38 @@ __device__ __forceinline__ void rdft_prime_sel(const double *x, double2 *a) {
             br = fma(PT<R>::s(j * q), df[j - 1], br);
         }
         a[1 + i] = make_double2(ar, -br);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// one real plane of a complex column (in the part's order): tot = sum, A[i] = sum_n x_n cos(2 pi n q_i / R), B[i] = sum_n x_n
+// sin(2 pi n q_i / R) -- the complex butterfly is this, once on the real and once on the imaginary parts (X[q] = (A_r + B_i) +
+// i (A_i - B_r), X[R - q] = (A_r - B_i) + i (A_i + B_r)): the same operations in the same order as cdft_prime_sel, with half of its
+// registers live (the exchange delivers the planes one after the other anyway)
+template <int R, typename SEL>
+__device__ __forceinline__ void prime_sel_plane(const double *x, double &tot_out, double *A, double *B) {
+    constexpr int H = (R - 1) / 2;
+    double sm[H], df[H];
+#pragma unroll
+    for (int j = 1; j <= H; ++j) { sm[j - 1] = x[j] + x[R - j]; df[j - 1] = x[j] - x[R - j]; }
+    double tot = x[0];
+#pragma unroll
+    for (int j = 0; j < H; ++j) tot += sm[j];
+    const double base = fma(-0.5, sm[H - 1], x[0]);
+#pragma unroll
+    for (int j = 0; j + 1 < H; ++j) sm[j] -= sm[H - 1];
+    tot_out = tot;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < SEL::NQ; ++i) {
+        const int q = SEL::q(i);
+        double ar = base, br = 0.0;
+#pragma unroll
+        for (int j = 1; j <= H; ++j) {
+            if (j < H) ar = fma(PT<R>::c(j * q), sm[j - 1], ar);
+            br = fma(PT<R>::s(j * q), df[j - 1], br);
+        }
+        A[i] = ar;
+        B[i] = br;
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -600,7 +634,8 @@ __global__ __launch_bounds__(64 * (MODE == 0 ? SH::NW : SH::NWR), ((MODE == 0 ? 
                                                                                double *__restrict__ out) {
     constexpr int R1 = SH::R1, R2 = SH::R2, R3 = SH::R3, N = SH::N, W = SH::W, NF = SH::NF, L1 = SH::L1, NQ1 = SH::NQ1;
     constexpr int NJ = SH::NJ, J2 = SH::J2, NR3 = SH::NR3, PP = SH::P, SLOT = SH::SLOT, LT = SH::LT;
-    constexpr int NW = (MODE == 0) ? SH::NW : SH::NWR, N3 = R1 * R2;
+    constexpr int N3 = R1 * R2;
+    const int NW = L.waves;
     constexpr bool PACKED = SH::PACKED;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     {
@@ -640,7 +675,6 @@ __global__ __launch_bounds__(64 * (MODE == 0 ? SH::NW : SH::NWR), ((MODE == 0 ? 
             pace[16 + wave] = (tile_id < n_tiles) ? 0 : 0x7fffffff;
         }
         __syncthreads();
-#pragma unroll
         for (int w = 0; w < NW; ++w) partner = (w != wave && pace[w] == my_simd) ? w : partner;
         partner = __builtin_amdgcn_readfirstlane(partner);
     }
@@ -995,6 +1029,9 @@ __global__ __launch_bounds__(64 * (MODE == 0 ? SH::NW : SH::NWR), ((MODE == 0 ? 
 
         // ---------------- exchange 1: element (j, q1) at plane[q1 PP + j]; pass-2 lane (q1, b) reads B[R3 a + b][q1]
         double2 c2[R2];
+        // split second pass: the butterfly runs plane by plane as the exchange delivers them (real parts, then imaginary parts)
+        constexpr int NP2 = (H2 > 1) ? SplitNQ<R2, H2>::value : 1;
+        double p2_tot_r = 0.0, p2_tot_i = 0.0, p2_Ar[NP2], p2_Br[NP2], p2_Ai[NP2], p2_Bi[NP2];
         {
             double *pl = cur;
             int w1[NS1];           // split first pass: where slot s of this lane goes (second copies and idle lanes: a dummy double behind the plane)
@@ -1019,8 +1056,15 @@ __global__ __launch_bounds__(64 * (MODE == 0 ? SH::NW : SH::NWR), ((MODE == 0 ? 
                     }
             }
             wsync();
+            if constexpr (H2 > 1) {
+                double cx[R2];
+#pragma unroll
+                for (int k = 0; k < R2; ++k) cx[k] = pl[q1_2 * PP + R3 * col2(k) + b_2];
+                prime_sel_plane<R2, SplitSel<R2, H2>>(cx, p2_tot_r, p2_Ar, p2_Br);
+            } else {
 #pragma unroll
             for (int k = 0; k < R2; ++k) c2[k].x = pl[q1_2 * PP + R3 * col2(k) + b_2];
+            }
             wsync();
             if constexpr (H1 > 1) {
 #pragma unroll
@@ -1034,8 +1078,15 @@ __global__ __launch_bounds__(64 * (MODE == 0 ? SH::NW : SH::NWR), ((MODE == 0 ? 
                     }
             }
             wsync();
+            if constexpr (H2 > 1) {
+                double cx[R2];
+#pragma unroll
+                for (int k = 0; k < R2; ++k) cx[k] = pl[q1_2 * PP + R3 * col2(k) + b_2];
+                prime_sel_plane<R2, SplitSel<R2, H2>>(cx, p2_tot_i, p2_Ai, p2_Bi);
+            } else {
 #pragma unroll
             for (int k = 0; k < R2; ++k) c2[k].y = pl[q1_2 * PP + R3 * col2(k) + b_2];
+            }
             wsync();
         }
         PAA_TICK(3)
@@ -1046,7 +1097,12 @@ __global__ __launch_bounds__(64 * (MODE == 0 ? SH::NW : SH::NWR), ((MODE == 0 ? 
         if constexpr (H2 > 1) {
             // every part forms DC + the SplitSel output pairs of its permuted column; slot s stands for the true output index of the
             // host table (bit 9: this lane is the one that delivers it), times W_L1^(b t)
-            cdft_prime_sel<R2, SplitSel<R2, H2>>(c2, o2);
+            o2[0] = make_double2(p2_tot_r, p2_tot_i);
+#pragma unroll
+            for (int i = 0; i < NP2; ++i) {
+                o2[1 + 2 * i] = make_double2(p2_Ar[i] + p2_Bi[i], p2_Ai[i] - p2_Br[i]);          // X[q] = A - i B
+                o2[2 + 2 * i] = make_double2(p2_Ar[i] - p2_Bi[i], p2_Ai[i] + p2_Br[i]);          // X[R - q] = A + i B
+            }
 #pragma unroll
             for (int sl = 0; sl < NS2; ++sl) code2[sl] = t_split[8 * (H1 > 1 ? H1 : 1) + 16 * part2 + sl];
             if constexpr (R3 > 1) {
@@ -1278,7 +1334,7 @@ typedef Shape<20, 20, 2, true, 40, 8> S1600;        // 50 ms at 32 kHz: 800 comp
 typedef Shape<20, 10, 3, true, 30, 8> S1200;        // 50 ms at 24 kHz / 25 ms at 48 kHz: 600 complex points
 typedef Shape<29, 19, 1, false, 19, 12, 1, 3, 3> S551;   // 50 ms at 11.025 kHz / 25 ms at 22.05 kHz: 551 real points, two passes; both prime
                                                          // butterflies shared by three lanes (57 / 45 lanes busy instead of 19 / 15)
-typedef Shape<19, 29, 2, false, 58, 8, 2, 1, 3, 12> S1102;  // 25 ms at 44.1 kHz (BASELINE config 5) / 50 ms at 22.05 kHz: 1102 real points;
+typedef Shape<19, 29, 2, false, 58, 12, 2, 1, 3, 12> S1102;  // 25 ms at 44.1 kHz (BASELINE config 5) / 50 ms at 22.05 kHz: 1102 real points;
                                                          // radix 19 first (58 lanes), then radix 29 shared by three lanes (20 jobs: 60 lanes)
 // power-of-two windows (what callers outside the reference's 50 ms default pass most often, ShortTermFeatures.py:563-564 takes any
 // window): every pass on all 64 lanes where the factorisation allows it.  Plane row pitches from scripts/dev/tri_model.py's LDS
@@ -1286,7 +1342,7 @@ typedef Shape<19, 29, 2, false, 58, 8, 2, 1, 3, 12> S1102;  // 25 ms at 44.1 kHz
 // and group pitch 9 in the second exchange -- the two exchanges then cost 48 + 80 LDS cycles per plane against 48 + 64 conflict-free
 // (row pitch 64, group pitch 8: 312; 69 / 8, the first version: 176, measured conflict ratio 0.36); P = 68 is the best pitch of 16 x 16 x 4
 #ifndef PAA_NW_1024
-#define PAA_NW_1024 11              // (A/B builds of scripts/rounds/r05: 8 / 10 / 11 waves per workgroup)
+#define PAA_NW_1024 12              // (A/B builds of scripts/rounds/r05: 8 / 10 / 11 waves per workgroup; 12 where the tables leave room)
 #endif
 typedef Shape<8, 8, 8, true, 72, PAA_NW_1024, 9> S1024;          // 512 complex points: 64 x radix 8, three times
 typedef Shape<16, 16, 4, true, 68, 7> S2048;        // 1024 complex points
@@ -1466,7 +1522,10 @@ inline void tri_fill(double fs, int mode, const MelTable *mel, const ChromaTable
         memcpy(b + L.off_chsrc, chroma->src.data(), n_ch * 4);
         memcpy(b + L.off_chw, chroma->w.data(), n_ch * 8);
     }
+    // as many waves as the shape allows and the LDS holds beside this (fs, window)'s table blob (longer mel lists at low rates)
     tl.waves = (mode == 0) ? SH::NW : SH::NWR;
+    while (tl.waves > 4 && (size_t)L.table_bytes + (size_t)tl.waves * SH::WAVE_DOUBLES * 8 > 160 * 1024) --tl.waves;
+    L.waves = tl.waves;
     tl.lds = (size_t)L.table_bytes + (size_t)tl.waves * SH::WAVE_DOUBLES * 8;
 }
 
@@ -1507,9 +1566,9 @@ static inline int tri_launch_one(const TriLaunch &tl, const PlanDev &P, const un
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl.lds) != hipSuccess) return -1;
         attr.set(tl.lds);
     }
-    constexpr int NWM = (MODE == 0) ? SH::NW : SH::NWR;
-    const unsigned grid = (unsigned)((n_tiles + NWM - 1) / NWM);
-    hipLaunchKernelGGL((st_tri_kernel<SH, T, MODE, DELTAS>), dim3(grid), dim3(64 * NWM), tl.lds, stream, P, tl.layout, blob,
+    const int nwm = tl.waves;           // (<= the shape's maximum, which is what __launch_bounds__ promises)
+    const unsigned grid = (unsigned)((n_tiles + nwm - 1) / nwm);
+    hipLaunchKernelGGL((st_tri_kernel<SH, T, MODE, DELTAS>), dim3(grid), dim3(64 * nwm), tl.lds, stream, P, tl.layout, blob,
                        (const T *)d_packed, clips, norms, tiles, (int)n_tiles, d_out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

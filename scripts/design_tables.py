@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Markdown tables of DESIGN.md section 5, generated from the tracked records of the round (profiles/bench_<round>_n1_local.json:
+the bench line of the consolidation GPU pass; profiles/<round>_<case>_summary.json: rocprofv3 kernel trace + counter passes of
+scripts/profile_kernel.sh).  usage: python scripts/design_tables.py r05"""
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main(rnd):
+    line = json.load(open(os.path.join(ROOT, "profiles", "bench_%s_n1_local.json" % rnd)))
+    others = line["config"]["others"]
+    print("| config | kernel | step (ms) | frames/s | algorithmic GB/s (fraction of 8 TB/s) |")
+    print("|---|---|---|---|---|")
+    print("| cfg2 (headline) | `%s` | %.4f | %.3g | %.0f (%.3f) |" % (line["roofline"]["kernel"], line["ms_per_step"], line["value"],
+                                                                  line["roofline"]["achieved"], line["roofline"]["frac"]))
+    for key, e in others.items():
+        if isinstance(e, dict) and "frames_per_s" in e:
+            print("| %s | `%s` | %.4f | %.3g | %.0f (%.3f) |" % (key, e["kernel"], e["ms_per_step"], e["frames_per_s"], e["achieved_GBps"], e["hbm_frac"]))
+    print()
+    print("| case (scripts/kernel_loop.py) | kernel | kernel (us, rocprofv3) | step (ms) | HBM traffic / algorithmic | LDS conflict ratio | VALU issue |")
+    print("|---|---|---|---|---|---|---|")
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "%s_*_summary.json" % rnd))):
+        d = json.load(open(f))
+        r = d.get("run_under_trace")
+        if not r or "case" not in r:
+            continue
+        tr = d.get("traffic", {})
+        fmt = lambda v, s: (s % v) if v else "-"
+        print("| %s | `%s` | %s | %.4f | %s | %s | %s |" % (r["case"], r["kernel"], fmt(d.get("kernel_avg_us"), "%.1f"), r["ms_per_step"],
+                                                     fmt(tr.get("traffic_over_algorithmic"), "%.2f"),
+                                                     fmt(d.get("lds_bank_conflict_ratio"), "%.2f"), fmt(d.get("valu_issue_fraction"), "%.2f")))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r05")

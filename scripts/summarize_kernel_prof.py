@@ -22,6 +22,8 @@ def main(prof_dir, out_path):
                                                     "%st_tri_kernel%" if "_tri_" in stem else "%" + stem + "%")
     if line["case"] == "mid_stats":
         like = "%mid_stats_kernel%"
+    if stem.startswith("st_fast_800"):
+        like = "%st_fast_800_kernel%"
     second = None
     if "wg_lds_fft" in stem:                      # two kernels per step: the spectra of all frames, then their features
         like, second = "%wg_spectrum_kernel%", "%wg_feat_kernel%"
