@@ -10,6 +10,7 @@
 namespace paa {
 namespace launch {
 
+#if defined(PAA_EXPERIMENTS) || !PAA_TRI_1102_ROWS
 template <typename T>
 static int reg_one(const reg::RegLayout &rl, size_t lds, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                    const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
@@ -34,6 +35,13 @@ int reg(const reg::RegLayout &rl, size_t lds, int sample_kind, const PlanDev &P,
     if (sample_kind == 2) return reg_one<stereo16>(rl, lds, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
     return reg_one<double>(rl, lds, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
 }
+#else
+// (the default build routes window 1102 to the three-pass family: st_reg is never dispatched, so it is not compiled in)
+int reg(const reg::RegLayout &, size_t, int, const PlanDev &, const unsigned char *, const void *, const ClipDev *, const ClipNorm *,
+        const Tile *, long long, double *, hipStream_t) {
+    return -1;
+}
+#endif
 
 template <typename T, int TWG, int LEAN>
 static int mix_one(const mix::MixLayout &ml, size_t lds, const PlanDev &P, const unsigned char *blob, const void *d_packed,

@@ -100,6 +100,8 @@ struct Shape {
     // ... in a scratch of its own for the small windows
     static constexpr int TSCR = (SLOT >= 11 * 65) ? 0 : 11 * 65;
     static constexpr int WAVE_DOUBLES = 2 * SLOT + 48 + 40 + 12 + TSCR;   // two slots, fv[48], msp[40], bnd[12], scratch
+    static constexpr int WAVE_DOUBLES_ROWS = SLOT + 16;                   // spectrogram / chromagram instances: no previous spectrum,
+                                                                          // no feature staging -- one slot, up to sixteen waves per CU
     static_assert(P >= L1 && P >= (R2 - 1) * R3P + R3 && R3P >= R3, "plane rows hold L1 elements (first exchange) and R2 groups of R3 (second)");
     static_assert(J2 * H2 <= 64, "one pass-2 job (part) per lane");
     static_assert(H1 == 1 || (!PACKED && L1 * H1 <= 64), "split first pass: real input, all parts of all jobs in one wave");
@@ -693,8 +695,8 @@ __global__ __launch_bounds__(64 * (MODE == 0 ? SH::NW : SH::NWR), ((MODE == 0 ? 
         else if (d_ > 0) __builtin_amdgcn_s_setprio(0);                                                \
         else __builtin_amdgcn_s_setprio(1);                                                            \
     }
-    double *slots = reinterpret_cast<double *>(smem + L.table_bytes) + (size_t)wave * SH::WAVE_DOUBLES;
-    double *fv = slots + 2 * SLOT;
+    double *slots = reinterpret_cast<double *>(smem + L.table_bytes) + (size_t)wave * (MODE == 0 ? SH::WAVE_DOUBLES : SH::WAVE_DOUBLES_ROWS);
+    double *fv = slots + ((MODE == 0) ? 2 * SLOT : SLOT);          // (row instances never touch fv / msp / bnd)
     double *msp = fv + 48;
     double *bnd = msp + 40;
 
@@ -756,8 +758,8 @@ __global__ __launch_bounds__(64 * (MODE == 0 ? SH::NW : SH::NWR), ((MODE == 0 ? 
                 return k;
             }
         };
-        double *cur = slots + (odd ? SLOT : 0);
-        const double *prv = slots + (odd ? 0 : SLOT);
+        double *cur = slots + ((MODE == 0 && odd) ? SLOT : 0);
+        const double *prv = slots + ((MODE == 0 && !odd) ? SLOT : 0);
         const T *xf = x0 + (long long)t * P.S;
         const bool want = (MODE == 0) && ((t >= tl.t0) || (DELTAS && t == tl.t0 - 1));
 
@@ -1332,9 +1334,9 @@ typedef Shape<21, 21, 2, true, 42, 8> S1764;        // 40 ms at 44.1 kHz (audioA
 typedef Shape<20, 16, 3, true, 49, 8> S1920;        // 40 ms at 48 kHz: 960 complex points
 typedef Shape<20, 20, 2, true, 40, 8> S1600;        // 50 ms at 32 kHz: 800 complex points
 typedef Shape<20, 10, 3, true, 30, 8> S1200;        // 50 ms at 24 kHz / 25 ms at 48 kHz: 600 complex points
-typedef Shape<29, 19, 1, false, 19, 12, 1, 3, 3> S551;   // 50 ms at 11.025 kHz / 25 ms at 22.05 kHz: 551 real points, two passes; both prime
+typedef Shape<29, 19, 1, false, 19, 12, 1, 3, 3, 16> S551;   // 50 ms at 11.025 kHz / 25 ms at 22.05 kHz: 551 real points, two passes; both prime
                                                          // butterflies shared by three lanes (57 / 45 lanes busy instead of 19 / 15)
-typedef Shape<19, 29, 2, false, 58, 12, 2, 1, 3, 12> S1102;  // 25 ms at 44.1 kHz (BASELINE config 5) / 50 ms at 22.05 kHz: 1102 real points;
+typedef Shape<19, 29, 2, false, 58, 12, 2, 1, 3, 16> S1102;  // 25 ms at 44.1 kHz (BASELINE config 5) / 50 ms at 22.05 kHz: 1102 real points;
                                                          // radix 19 first (58 lanes), then radix 29 shared by three lanes (20 jobs: 60 lanes)
 // power-of-two windows (what callers outside the reference's 50 ms default pass most often, ShortTermFeatures.py:563-564 takes any
 // window): every pass on all 64 lanes where the factorisation allows it.  Plane row pitches from scripts/dev/tri_model.py's LDS
@@ -1344,9 +1346,9 @@ typedef Shape<19, 29, 2, false, 58, 12, 2, 1, 3, 12> S1102;  // 25 ms at 44.1 kH
 #ifndef PAA_NW_1024
 #define PAA_NW_1024 12              // (A/B builds of scripts/rounds/r05: 8 / 10 / 11 waves per workgroup; 12 where the tables leave room)
 #endif
-typedef Shape<8, 8, 8, true, 72, PAA_NW_1024, 9> S1024;          // 512 complex points: 64 x radix 8, three times
+typedef Shape<8, 8, 8, true, 72, PAA_NW_1024, 9, 1, 1, 16> S1024;          // 512 complex points: 64 x radix 8, three times
 typedef Shape<16, 16, 4, true, 68, 7> S2048;        // 1024 complex points
-typedef Shape<4, 8, 8, true, 72, 12, 9> S512;           // 256 complex points (odd entropy blocks: 51 samples)
+typedef Shape<4, 8, 8, true, 72, 12, 9, 1, 1, 16> S512;           // 256 complex points (odd entropy blocks: 51 samples)
 
 struct TriLaunch {
     int shape = -1;                 // index into the shape list above
@@ -1524,9 +1526,10 @@ inline void tri_fill(double fs, int mode, const MelTable *mel, const ChromaTable
     }
     // as many waves as the shape allows and the LDS holds beside this (fs, window)'s table blob (longer mel lists at low rates)
     tl.waves = (mode == 0) ? SH::NW : SH::NWR;
-    while (tl.waves > 4 && (size_t)L.table_bytes + (size_t)tl.waves * SH::WAVE_DOUBLES * 8 > 160 * 1024) --tl.waves;
+    const size_t wave_bytes = (size_t)(mode == 0 ? SH::WAVE_DOUBLES : SH::WAVE_DOUBLES_ROWS) * 8;
+    while (tl.waves > 4 && (size_t)L.table_bytes + (size_t)tl.waves * wave_bytes > 160 * 1024) --tl.waves;
     L.waves = tl.waves;
-    tl.lds = (size_t)L.table_bytes + (size_t)tl.waves * SH::WAVE_DOUBLES * 8;
+    tl.lds = (size_t)L.table_bytes + (size_t)tl.waves * wave_bytes;
 }
 
 // returns 1 when a three-pass instance exists for this window (fills tl and the table blob), 0 otherwise

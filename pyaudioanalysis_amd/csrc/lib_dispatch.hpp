@@ -3,13 +3,6 @@
 // Adding a family = one more entry (and its family_<name>.hip).  Included by paa_lib.hip after the plan structure.
 #pragma once
 
-// A/B builds of scripts/rounds/r05/gpu_r05j.sh: 1 lets the three-pass kernel (radix 19 first, radix 29 shared by three lanes) take
-// config 5's spectrogram / chromagram rows too.  Measured: spectrogram 0.2161 against 0.221 ms on the prime-factor kernel,
-// chromagram 0.2336 against 0.2262 ms -- a draw; the rows stay with st_reg
-#ifndef PAA_TRI_1102_ROWS
-#define PAA_TRI_1102_ROWS 0
-#endif
-
 struct FamilyCtx {
     paa_plan *p;
     TableSet *tab;

@@ -43,8 +43,8 @@ def test_plans_dispatch_the_mixed_radix_kernel(gpu_lib):
     assert name(16000, 256, 128) == "st_mix"
     assert name(44100, 4096, 2048) == "st_mix"
     assert name(44100, 1102, 441) == "st_tri_r19x29x2"         # config 5's features: real-input 19 x 29 x 2, the radix-29 butterflies shared by three lanes
-    assert name(44100, 1102, 441, kind=2, mode=1) == "spectrogram_reg_29x19"      # its rows keep the prime-factor kernel
-    assert name(44100, 1102, 441, mode=2) == "chromagram_reg_29x19"
+    assert name(44100, 1102, 441, kind=2, mode=1) == "spectrogram_tri_r19x29x2"   # its rows too since round 5 (one slot, sixteen waves per CU)
+    assert name(44100, 1102, 441, mode=2) == "chromagram_tri_r19x29x2"
     assert name(16000, 800, 400) == "st_fast_800_w8"
     assert name(22050, 1103, 441) == "st_generic"              # 1103 is prime: Stockham passes with an O(R^2) radix
 

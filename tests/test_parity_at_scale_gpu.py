@@ -176,3 +176,35 @@ def test_ranged_host_call_equals_the_single_launch_bit_for_bit(gpu_lib):
     Fy, _ = ShortTermFeatures.feature_extraction(y, FS, 800, 400, True)
     assert Fy.shape[1] == 65535
     assert np.array_equal(Fy, _plan_matrix(y, True, Fy.shape))
+
+
+@pytest.mark.parametrize("fs,window,step,deltas,family", [
+    (16000, 640, 320, True, "st_ct_20x16"),            # 2 RA RB family: runs after a clip's first start one or two frames early (halo inside)
+    (48000, 2400, 1200, True, "st_tri_20x20x3"),       # three-pass family, with deltas
+    (16000, 1024, 512, False, "st_tri_8x8x8"),         # ... a power-of-two shape of round 5
+    (16000, 256, 128, False, "st_mix"),                # in-place mixed-radix kernel (lean, skewed instance)
+    (11025, 551, 275, True, "st_tri_r29x19"),          # shared prime butterflies
+])
+def test_ranged_host_call_on_the_other_families(gpu_lib, fs, window, step, deltas, family):
+    """The four-range copy-back pipeline of the host-buffer API applies to every kernel family (advisor, round 4): a clip of
+    more than 65 536 frames through ct / tri / mix equals the device-resident plan's single launch bit for bit, and the profiling
+    events count the ranged launches."""
+    import ctypes
+    n = 66000 * step + window
+    x = np.tile(synth_clip(31, 60 * fs, fs), -(-n // (60 * fs)))[:n]
+    _ffi.check(gpu_lib.paa_prof_enable(1))
+    F, _ = ShortTermFeatures.feature_extraction(x, fs, window, step, deltas)
+    ms, cnt = ctypes.c_double(), ctypes.c_int64()
+    _ffi.check(gpu_lib.paa_prof_read(ctypes.byref(ms), ctypes.byref(cnt)))
+    _ffi.check(gpu_lib.paa_prof_enable(0))
+    assert F.shape[1] == 66000 and cnt.value >= 2, cnt.value          # several ranged launches, every one bracketed
+    plan = _ffi.Plan(np.array([0, len(x)], dtype=np.int64), fs, window, step, deltas=deltas, sample_kind=0)
+    try:
+        assert plan.kernel_name == family
+        d_in = _ffi.DeviceBuffer.from_host(x)
+        d_out = _ffi.DeviceBuffer(plan.out_doubles * 8)
+        plan.execute(d_in, d_out)
+        _ffi.sync()
+        assert np.array_equal(F, d_out.to_host(np.float64, plan.out_doubles).reshape(F.shape))
+    finally:
+        plan.destroy()
