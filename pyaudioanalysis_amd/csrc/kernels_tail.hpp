@@ -9,9 +9,10 @@ namespace paa {
 template <typename T>
 __global__ __launch_bounds__(256) void chroma_tail_kernel(PlanDev P, const T *__restrict__ sig, long long pos0,
                                                            long long n_total, const ClipNorm *__restrict__ norms,
-                                                           double *__restrict__ out) {
+                                                           double *__restrict__ out, double *spill) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *spec = reinterpret_cast<double *>(smem);
+    // the frame's spectrum: in LDS, or -- more than 20 000 bins -- in the caller's scratch (one row per tail frame)
+    double *spec = spill ? spill + (long long)blockIdx.x * P.Nf : reinterpret_cast<double *>(smem);
     __shared__ double red[4];
     const long long pos = pos0 + (long long)blockIdx.x * P.S;
     const int L = (int)(n_total - pos);
@@ -45,10 +46,19 @@ __global__ __launch_bounds__(256) void chroma_tail_kernel(PlanDev P, const T *__
     }
 }
 
+// bytes of scratch launch_chroma_tail needs for `count` tail frames (0: their spectra fit the LDS)
+inline size_t chroma_tail_spill_bytes(const PlanDev &P, int count) {
+    return ((size_t)P.Nf * 8 + 16 > (size_t)160 * 1024) ? (size_t)count * (size_t)P.Nf * 8 : 0;
+}
 inline int launch_chroma_tail(const PlanDev &P, int sample_kind, const void *d_sig, long long pos0, long long n_total,
-                              int count, const ClipNorm *norms, double *d_out, hipStream_t stream) {
-    const size_t lds = (size_t)P.Nf * 8 + 16;
-    if (lds > 160 * 1024) return -2;          // spectrum of the tail frame does not fit LDS
+                              int count, const ClipNorm *norms, double *d_out, double *spill, hipStream_t stream) {
+    size_t lds = (size_t)P.Nf * 8 + 16;
+    if (lds > 160 * 1024) {
+        if (!spill) return -2;
+        lds = 16;
+    } else {
+        spill = nullptr;
+    }
     if (lds > 64 * 1024) {
         const void *fn = sample_kind == 0 ? reinterpret_cast<const void *>(&chroma_tail_kernel<int16_t>)
                        : sample_kind == 2 ? reinterpret_cast<const void *>(&chroma_tail_kernel<stereo16>)
@@ -57,13 +67,13 @@ inline int launch_chroma_tail(const PlanDev &P, int sample_kind, const void *d_s
     }
     if (sample_kind == 0)
         hipLaunchKernelGGL(chroma_tail_kernel<int16_t>, dim3(count), dim3(256), lds, stream, P, (const int16_t *)d_sig,
-                           pos0, n_total, norms, d_out);
+                           pos0, n_total, norms, d_out, spill);
     else if (sample_kind == 2)        // interleaved stereo int16, summed in the loads (fused stereo_to_mono)
         hipLaunchKernelGGL(chroma_tail_kernel<stereo16>, dim3(count), dim3(256), lds, stream, P, (const stereo16 *)d_sig,
-                           pos0, n_total, norms, d_out);
+                           pos0, n_total, norms, d_out, spill);
     else
         hipLaunchKernelGGL(chroma_tail_kernel<double>, dim3(count), dim3(256), lds, stream, P, (const double *)d_sig,
-                           pos0, n_total, norms, d_out);
+                           pos0, n_total, norms, d_out, spill);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -50,7 +50,13 @@ struct WgLayout {
     int perm_lds;                   // 1: the digit-reversal permutation fits the LDS beside the buffer
     int threads;                    // spectrum kernel: 768 when every radix is <= 8, else 512
     int lds_bytes;                  // spectrum kernel
-    int feat_lds_bytes;             // feature kernel: the frame's spectrum row + 2 KB
+    int feat_lds_bytes;             // feature kernel: the frame's spectrum row + 2 KB (2 KB alone when the row is not staged)
+    int feat_staged;                // 1: the feature kernel stages the frame's row in LDS; 0: the row exceeds the LDS, it is read where it lies
+    // split transforms (wg_split_kernel): the sequence is longer than the LDS -- its first radix-r0 pass runs straight from the
+    // samples, one sub-transform q (of r0) at a time, and the schedule above describes ONE sub-transform of `sub` elements
+    // (span[0] = sub, tws[p] = Nc / span[p]); 0: the whole transform is in LDS (wg_spectrum_kernel)
+    int r0, sub;
+    int off_cv;                     // [8] complex: W_r0^(r q) of the task
 };
 // one frame of the launch: its clip, its index in the clip, the row of the spectrum scratch it writes, and whether it is only
 // there to provide the previous spectrum of the next one (a chunk that starts inside a clip)
@@ -85,7 +91,9 @@ __device__ __forceinline__ void wg_dif_batch(double2 *buf, int nb, int stride, i
         const int blk = (stride == 1) ? be : (int)__umulhi((unsigned)be, magic);
         const int k = be - __mul24(blk, stride);
         const int e0 = __mul24(blk, M) + k;
-        base[u] = FIRST ? e0 : e0 + (int)__umulhi((unsigned)e0, magic_top);      // (later passes: a butterfly stays inside one block)
+        base[u] = FIRST ? e0 + blk * R : e0 + (int)__umulhi((unsigned)e0, magic_top);      // (first pass: e0 / top = blk R -- blk > 0 only in
+                                                                                           // the two sub-transforms of wg_split_kernel; later passes:
+                                                                                           // a butterfly stays inside one top-level block)
         t1[u] = __mul24(k, tws);
 #pragma unroll
         for (int r = 0; r < R; ++r) v[u][r] = buf[base[u] + r * lstride];
@@ -123,8 +131,105 @@ __device__ __forceinline__ void wg_dif_pass(double2 *buf, int Nc, int M, int tws
     }
 }
 
+// all in-place passes of the schedule over the `n_el` elements of the buffer (one transform of span[0] elements, or the two
+// sub-transforms of wg_split_kernel side by side); ends with a barrier
+template <int NT>
+__device__ __forceinline__ void wg_run_passes(double2 *buf, int n_el, const WgLayout &L, const Tw2 &tw, int tid) {
+    const unsigned mtop = L.magic_top;
+    for (int p = 0; p < ((kAblate & 4) ? 0 : L.n_pass); ++p) {
+        const int M = L.span[p], ts = L.tws[p];
+        const unsigned mg = L.magic[p];
+        switch (L.radix[p]) {
+            case 2: wg_dif_pass<2, NT>(buf, n_el, M, ts, mg, mtop, p == 0, tw, tid); break;
+            case 3: wg_dif_pass<3, NT>(buf, n_el, M, ts, mg, mtop, p == 0, tw, tid); break;
+            case 4: wg_dif_pass<4, NT>(buf, n_el, M, ts, mg, mtop, p == 0, tw, tid); break;
+            case 5: wg_dif_pass<5, NT>(buf, n_el, M, ts, mg, mtop, p == 0, tw, tid); break;
+            case 7: wg_dif_pass<7, NT>(buf, n_el, M, ts, mg, mtop, p == 0, tw, tid); break;
+            case 8: wg_dif_pass<8, NT>(buf, n_el, M, ts, mg, mtop, p == 0, tw, tid); break;
+            case 11: if constexpr (NT == 512) wg_dif_pass<11, NT>(buf, n_el, M, ts, mg, mtop, p == 0, tw, tid); break;
+            case 13: if constexpr (NT == 512) wg_dif_pass<13, NT>(buf, n_el, M, ts, mg, mtop, p == 0, tw, tid); break;
+            default: if constexpr (NT == 512) wg_dif_pass<16, NT>(buf, n_el, M, ts, mg, mtop, p == 0, tw, tid); break;
+        }
+        __syncthreads();
+    }
+}
+
 // lane l receives the value of lane l - 1 (lane 0: `first`)
 __device__ __forceinline__ int wg_shr1(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xF, 0xF, false); }
+
+// ---- time domain (ShortTermFeatures.py:22-51) of one frame by a workgroup of kWaves waves.  `get(p)` returns element p of the
+// normalised sequence (a sample pair for even windows, (sample, 0) for odd ones).  Wave w owns the elements [w per, (w + 1) per);
+// its samples meet at most three of the ten entropy blocks (or the tail the reference leaves out of them, block "10"): the energy
+// of the first, of the last and of all of them are summed, the middle one is the rest.  Sign codes are formed once per sample;
+// the left neighbour comes from the lane below (lane 0: the previous iteration's lane 63, or the element before the range).
+// red[5 w ..]: first / middle / last block energy, zero-crossing count, first block index of wave w.
+template <int kWaves, typename Get>
+__device__ __forceinline__ void wg_time_partials(const PlanDev &P, int Nc, int lane, int wave, double *red, Get get) {
+    const int LT = P.blk_t;
+    const int spe = P.even ? 2 : 1;                       // samples per element
+    const int per = (Nc + kWaves - 1) / kWaves;
+    const int p0 = wave * per, p1 = min(Nc, p0 + per);
+    const int b0 = min((p0 * spe) / LT, 10);
+    const int bnd1 = (b0 < 10) ? (b0 + 1) * LT : 0x7fffffff, bnd2 = (b0 + 1 < 10) ? (b0 + 2) * LT : 0x7fffffff;
+    double aA = 0.0, aC = 0.0, aT = 0.0;
+    int zc = 0;
+    int carry = 0;            // sign code of the sample before this iteration's first one
+    bool have_left = false;
+    if (p0 > 0 && p0 < p1) {
+        const double2 zl = get(p0 - 1);
+        const double vl = P.even ? zl.y : zl.x;
+        carry = (vl > 0.0) - (vl < 0.0);
+        have_left = true;
+    }
+    constexpr int TB = 4;            // elements per lane whose loads are in flight together (the sign chain below is sequential)
+    for (int pq = p0; pq < p1; pq += 64 * TB) {
+        double2 zz[TB];
+#pragma unroll
+        for (int u = 0; u < TB; ++u) zz[u] = get(min(pq + 64 * u + lane, p1 - 1));
+#pragma unroll
+        for (int u = 0; u < TB; ++u) {
+        const int pb = pq + 64 * u;
+        if (pb >= p1) break;
+        const int p = pb + lane;
+        const bool in = p < p1;
+        const int pe = in ? p : p1 - 1;
+        const double2 z = zz[u];
+        const double v0 = in ? z.x : 0.0, v1 = (in && P.even) ? z.y : 0.0;
+        const int n = pe * spe;
+        const double e0 = v0 * v0, e1 = v1 * v1;
+        aT += e0 + e1;
+        aA += ((n < bnd1) ? e0 : 0.0) + ((n + 1 < bnd1) ? e1 : 0.0);
+        aC += ((n >= bnd2) ? e0 : 0.0) + ((n + 1 >= bnd2) ? e1 : 0.0);
+        const int c0 = (v0 > 0.0) - (v0 < 0.0), c1 = (v1 > 0.0) - (v1 < 0.0);
+        const int last = P.even ? c1 : c0;                 // the element's last sample
+        const int first_left = have_left ? carry : __builtin_amdgcn_readfirstlane(c0);      // (the frame's first sample meets itself)
+        const int left = wg_shr1(last, first_left);
+        if (in) zc += abs(c0 - left) + (P.even ? abs(c1 - c0) : 0);
+        carry = __builtin_amdgcn_readlane(last, 63);
+        have_left = true;
+        }
+    }
+    aA = wsum(aA); aC = wsum(aC); aT = wsum(aT);
+    zc = wsum_i(zc);
+    if (lane == 0) { red[5 * wave] = aA; red[5 * wave + 1] = (aT - aA) - aC; red[5 * wave + 2] = aC; red[5 * wave + 3] = (double)zc; red[5 * wave + 4] = (double)b0; }
+}
+// (one wave, after a barrier) block j (lane j < 11) = the parts of every wave that fall into it, added in wave order
+template <int kWaves>
+__device__ __forceinline__ void wg_time_finish(const double *red, int lane, double *tfp) {
+    double E = 0.0, zct = 0.0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        const int bw = (int)red[5 * w + 4];
+        E += (bw == lane) ? red[5 * w] : 0.0;
+        E += (bw + 1 == lane) ? red[5 * w + 1] : 0.0;
+        E += (bw + 2 == lane) ? red[5 * w + 2] : 0.0;
+        zct += red[5 * w + 3];
+    }
+    const double e_tot = wsum((lane < 11) ? E : 0.0);
+    const double s = fast_div(E, e_tot + kEps);
+    const double ent = wsum((lane < 10) ? -(s * fast_log2(s + kEps)) : 0.0);
+    if (lane == 0) { tfp[0] = e_tot; tfp[1] = ent; tfp[2] = zct; }
+}
 
 // P.mode decides where the row goes and whether the time-domain features are formed.  PERSISTENT: the transform buffer takes
 // the CU's LDS, so one workgroup lives on a CU and nothing overlaps the latency chain at the head of a frame (frame record ->
@@ -190,88 +295,14 @@ __global__ __launch_bounds__(NT) void wg_spectrum_kernel(PlanDev P, WgLayout L, 
             buf[n + (int)__umulhi((unsigned)n, mtop)] = make_double2(fma(load_sample<T>(x + n), sc, -nm.mean) * nm.inv, 0.0);
     }
     __syncthreads();
-    // ---- time domain (:22-51): wave w owns the elements [w per, (w + 1) per) of the sequence (sample pairs for even windows); its
-    // samples meet at most three of the ten entropy blocks (or the tail the reference leaves out of them, block "10"): the energy
-    // of the first, of the last and of all of them are summed, the middle one is the rest.  Sign codes are formed once per
-    // sample; the left neighbour comes from the lane below (lane 0: the previous iteration's lane 63, or the element before the range)
-    if (P.mode == 0 && !fr.halo && !(kAblate & 2)) {
-        const int LT = P.blk_t;
-        const int spe = P.even ? 2 : 1;                       // samples per element
-        const int per = (Nc + kWaves - 1) / kWaves;
-        const int p0 = wave * per, p1 = min(Nc, p0 + per);
-        const int b0 = min((p0 * spe) / LT, 10);
-        const int bnd1 = (b0 < 10) ? (b0 + 1) * LT : 0x7fffffff, bnd2 = (b0 + 1 < 10) ? (b0 + 2) * LT : 0x7fffffff;
-        double aA = 0.0, aC = 0.0, aT = 0.0;
-        int zc = 0;
-        int carry = 0;            // sign code of the sample before this iteration's first one
-        bool have_left = false;
-        if (p0 > 0 && p0 < p1) {
-            const double2 zl = buf[(p0 - 1) + (int)__umulhi((unsigned)(p0 - 1), mtop)];
-            const double vl = P.even ? zl.y : zl.x;
-            carry = (vl > 0.0) - (vl < 0.0);
-            have_left = true;
-        }
-        for (int pb = p0; pb < p1; pb += 64) {
-            const int p = pb + lane;
-            const bool in = p < p1;
-            const int pe = in ? p : p1 - 1;
-            const double2 z = buf[pe + (int)__umulhi((unsigned)pe, mtop)];
-            const double v0 = in ? z.x : 0.0, v1 = (in && P.even) ? z.y : 0.0;
-            const int n = pe * spe;
-            const double e0 = v0 * v0, e1 = v1 * v1;
-            aT += e0 + e1;
-            aA += ((n < bnd1) ? e0 : 0.0) + ((n + 1 < bnd1) ? e1 : 0.0);
-            aC += ((n >= bnd2) ? e0 : 0.0) + ((n + 1 >= bnd2) ? e1 : 0.0);
-            const int c0 = (v0 > 0.0) - (v0 < 0.0), c1 = (v1 > 0.0) - (v1 < 0.0);
-            const int last = P.even ? c1 : c0;                 // the element's last sample
-            const int first_left = have_left ? carry : __builtin_amdgcn_readfirstlane(c0);      // (the frame's first sample meets itself)
-            const int left = wg_shr1(last, first_left);
-            if (in) zc += abs(c0 - left) + (P.even ? abs(c1 - c0) : 0);
-            carry = __builtin_amdgcn_readlane(last, 63);
-            have_left = true;
-        }
-        aA = wsum(aA); aC = wsum(aC); aT = wsum(aT);
-        zc = wsum_i(zc);
-        if (lane == 0) { red[5 * wave] = aA; red[5 * wave + 1] = (aT - aA) - aC; red[5 * wave + 2] = aC; red[5 * wave + 3] = (double)zc; red[5 * wave + 4] = (double)b0; }
-    }
+    // ---- time domain (:22-51) straight from the buffer
+    if (P.mode == 0 && !fr.halo && !(kAblate & 2))
+        wg_time_partials<kWaves>(P, Nc, lane, wave, red, [&](int p) { return buf[p + (int)__umulhi((unsigned)p, mtop)]; });
     __syncthreads();          // every wave has read its samples: the passes may overwrite the buffer
-    if (P.mode == 0 && !fr.halo && wave == 0) {
-        // block j (lane j < 11) = the parts of every wave that fall into it, added in wave order
-        double E = 0.0, zct = 0.0;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            const int bw = (int)red[5 * w + 4];
-            E += (bw == lane) ? red[5 * w] : 0.0;
-            E += (bw + 1 == lane) ? red[5 * w + 1] : 0.0;
-            E += (bw + 2 == lane) ? red[5 * w + 2] : 0.0;
-            zct += red[5 * w + 3];
-        }
-        const double e_tot = wsum((lane < 11) ? E : 0.0);
-        const double s = fast_div(E, e_tot + kEps);
-        const double ent = wsum((lane < 10) ? -(s * fast_log2(s + kEps)) : 0.0);
-        if (lane == 0) {
-            double *tfp = tfeat + 3 * (long long)fr.row;
-            tfp[0] = e_tot; tfp[1] = ent; tfp[2] = zct;
-        }
-    }
+    if (P.mode == 0 && !fr.halo && wave == 0) wg_time_finish<kWaves>(red, lane, tfeat + 3 * (long long)fr.row);
     // ---- in-place DIF passes (kernels_mix.hpp's butterflies; two waves per SIMD and two butterflies per lane hide the latency)
     const Tw2 tw = {twlo, twhi};
-    for (int p = 0; p < ((kAblate & 4) ? 0 : L.n_pass); ++p) {
-        const int M = L.span[p], ts = L.tws[p];
-        const unsigned mg = L.magic[p];
-        switch (L.radix[p]) {
-            case 2: wg_dif_pass<2, NT>(buf, Nc, M, ts, mg, mtop, p == 0, tw, tid); break;
-            case 3: wg_dif_pass<3, NT>(buf, Nc, M, ts, mg, mtop, p == 0, tw, tid); break;
-            case 4: wg_dif_pass<4, NT>(buf, Nc, M, ts, mg, mtop, p == 0, tw, tid); break;
-            case 5: wg_dif_pass<5, NT>(buf, Nc, M, ts, mg, mtop, p == 0, tw, tid); break;
-            case 7: wg_dif_pass<7, NT>(buf, Nc, M, ts, mg, mtop, p == 0, tw, tid); break;
-            case 8: wg_dif_pass<8, NT>(buf, Nc, M, ts, mg, mtop, p == 0, tw, tid); break;
-            case 11: if constexpr (NT == 512) wg_dif_pass<11, NT>(buf, Nc, M, ts, mg, mtop, p == 0, tw, tid); break;
-            case 13: if constexpr (NT == 512) wg_dif_pass<13, NT>(buf, Nc, M, ts, mg, mtop, p == 0, tw, tid); break;
-            default: if constexpr (NT == 512) wg_dif_pass<16, NT>(buf, Nc, M, ts, mg, mtop, p == 0, tw, tid); break;
-        }
-        __syncthreads();
-    }
+    wg_run_passes<NT>(buf, Nc, L, tw, tid);
     // ---- the next frame of this workgroup: its records now, a touch of its samples (one load per lane and 128-byte line of the
     // frame: they land in L2 / L1 while the magnitudes below are formed; the sum keeps the loads alive)
     Cur cu_next = cu;
@@ -332,6 +363,191 @@ __global__ __launch_bounds__(NT) void wg_spectrum_kernel(PlanDev P, WgLayout L, 
     }       // frames of this workgroup
 }
 
+// ---- sequences longer than one CU's LDS (44 100-sample windows: 22 050 complex points = 353 KB) ----------------------------------
+// Decimation in frequency by r0 FIRST, straight from the samples: y_q[k] = W_Nc^(q k) sum_r z[k + r sub] W_r0^(r q) for k < sub is
+// the input of sub-transform q, whose output kappa is Z[q + r0 kappa].  The real-FFT recombination pairs bin k with Nc - k, i.e.
+// sub-transform q (output kappa) with sub-transform r0 - q (output sub - 1 - kappa; q = 0: with itself at sub - kappa).  A TASK is
+// therefore one frame and the sub-transforms {q, r0 - q} -- both in LDS side by side, passes run over both at once -- or {0} or
+// {r0 / 2} alone; a persistent workgroup walks tasks.  Magnitudes go straight to the frame's row (8-byte stores r0 doubles
+// apart: the row's lines fill up in L2 from the tasks of the frame).  The time-domain features come from wg_time_kernel.
+// FrameRef::halo of a task: bit 0 = halo frame, bits 8.. = q.
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void wg_split_kernel(PlanDev P, WgLayout L, const unsigned short *__restrict__ perm_g,
+                                                      const T *__restrict__ sig, const ClipDev *__restrict__ clips,
+                                                      const ClipNorm *__restrict__ norms,
+                                                      const FrameRef *__restrict__ tasks, int n_tasks, int *next_task,
+                                                      double *__restrict__ spec, double *__restrict__ out) {
+    constexpr int kThreads = NT;
+    __shared__ int s_next;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double2 *buf = reinterpret_cast<double2 *>(smem);
+    double2 *twlo = reinterpret_cast<double2 *>(smem + L.off_twlo), *twhi = reinterpret_cast<double2 *>(smem + L.off_twhi);
+    double2 *cv = reinterpret_cast<double2 *>(smem + L.off_cv);
+    unsigned short *perm_l = reinterpret_cast<unsigned short *>(smem + L.off_perm);
+    const int tid = threadIdx.x;
+    const int Nc = P.Nc, Nf = P.Nf, S = L.sub, R0 = L.r0;
+    const int pitch = S + L.radix[0];                    // padded elements per sub-transform
+    const double sc = sample_scale<T>();
+    if (tid < kTwLo) twlo[tid] = P.tw[tid];
+    if (tid >= 256 && tid - 256 < L.n_twhi) twhi[tid - 256] = P.tw[(tid - 256) * kTwLo];
+    if (L.perm_lds) {
+        const unsigned *src = reinterpret_cast<const unsigned *>(perm_g);
+        unsigned *dst = reinterpret_cast<unsigned *>(perm_l);
+        for (int i = tid; i < (S + 1) / 2; i += kThreads) dst[i] = src[i];
+    }
+    const Tw2 tw = {twlo, twhi};
+    const unsigned mtop = L.magic_top;
+    const unsigned short *perm = L.perm_lds ? perm_l : perm_g;
+    const double invNf = 1.0 / (double)Nf;
+    // (only the fields that are used travel from task to task, like wg_spectrum_kernel's)
+    struct Cur { long long x_off, out_off; double mean, inv; int t, row, q, pad; };
+    auto fetch = [&](int ti) {
+        const FrameRef r = tasks[ti];
+        const ClipDev cd = clips[r.clip];
+        const ClipNorm n_ = norms[r.clip];
+        Cur c;
+        c.x_off = cd.sample_off + P.frame_origin + (long long)r.t * P.S;
+        c.out_off = cd.out_off; c.mean = n_.mean; c.inv = n_.inv; c.t = r.t; c.row = r.row; c.q = r.halo >> 8; c.pad = 0;
+        return c;
+    };
+    if ((int)blockIdx.x >= n_tasks) return;
+    Cur cu = fetch(blockIdx.x);
+    // tasks are handed out through a counter (*next_task, zero at launch): pair tasks cost twice what single ones do and come
+    // first in the list -- a fixed stride gave some workgroups nothing but pairs
+    for (int ti = blockIdx.x; ti < n_tasks;) {
+        const T *x = sig + cu.x_off;
+        struct { double mean, inv; } nm = {cu.mean, cu.inv};
+        struct { int t, row; } fr = {cu.t, cu.row};
+        struct { long long out_off; } cd = {cu.out_off};
+        const int qa = cu.q, qb = (qa == 0) ? 0 : R0 - qa;
+        const bool two = qb != qa;
+        __syncthreads();          // the previous task's magnitudes have been read (and the tables are in place)
+        if (tid < R0) cv[tid] = P.tw[((tid * qa) % R0) * S];             // W_Nc^(S m) = W_r0^m
+        if (tid == 64) s_next = (int)gridDim.x + atomicAdd(next_task, 1);          // (read after the barriers of the passes)
+        __syncthreads();
+        // ---- first pass from the samples: up to eight elements k + r sub of the normalised sequence per output
+#pragma unroll 2
+        for (int k = tid; k < S; k += kThreads) {
+            double2 z[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if (r < R0) {
+                    const int e = k + r * S;
+                    if (P.even) {
+                        const double2 xx = ct::PairLoad<T>::get(x + 2 * e);
+                        z[r] = make_double2(fma(xx.x, sc, -nm.mean) * nm.inv, fma(xx.y, sc, -nm.mean) * nm.inv);
+                    } else {
+                        z[r] = make_double2(fma(load_sample<T>(x + e), sc, -nm.mean) * nm.inv, 0.0);
+                    }
+                }
+            }
+            double ax = 0.0, ay = 0.0, bx = 0.0, by = 0.0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if (r < R0) {
+                    const double2 c = cv[r];
+                    const double p0 = z[r].x * c.x, p1 = z[r].y * c.y, p2 = z[r].x * c.y, p3 = z[r].y * c.x;
+                    ax += p0 - p1; ay += p2 + p3;              // z c
+                    bx += p0 + p1; by += p3 - p2;              // z conj(c): sub-transform r0 - q
+                }
+            }
+            const int pos = k + (int)__umulhi((unsigned)k, mtop);
+            buf[pos] = cmul(make_double2(ax, ay), tw.get(qa * k));
+            if (two) buf[pitch + pos] = cmul(make_double2(bx, by), tw.get(qb * k));
+        }
+        __syncthreads();
+        wg_run_passes<NT>(buf, two ? 2 * S : S, L, tw, tid);
+        // ---- the next task of this workgroup: its records now, a touch of its samples (they land in L2 while the magnitudes are formed)
+        Cur cu_next = cu;
+        const int t_next = s_next;
+        if (t_next < n_tasks) {
+            cu_next = fetch(t_next);
+            const char *xn = reinterpret_cast<const char *>(sig + cu_next.x_off);
+            const int bytes = P.W * (int)sizeof(T);
+            int touch = 0;
+            for (int o = tid * 128; o < bytes; o += kThreads * 128) touch += *reinterpret_cast<const volatile char *>(xn + o);
+            asm volatile("" ::"v"(touch));
+        }
+        // ---- magnitudes (:617-621): bin k = qa + r0 kappa from sub-transform a, its partner Nc - k from b
+        double *row = (P.mode == 1) ? out + cd.out_off + (long long)fr.t * Nf : spec + (long long)fr.row * Nf;
+        const double2 *bufb = two ? buf + pitch : buf;
+        if (P.even) {
+            // single sub-transforms pair with themselves: kappa <= its partner's index only
+            const int n_k = two ? S : (qa == 0 ? S / 2 + 1 : (S + 1) / 2);
+            for (int k0 = tid; (k0 & ~63) < n_k; k0 += 2 * kThreads) {
+                int ka[2], lo[2];
+                bool flip[2];
+                double2 pw[2], zk[2], zm[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    ka[u] = min(k0 + u * kThreads, n_k - 1);
+                    const int kb = (qa == 0) ? (ka[u] == 0 ? 0 : S - ka[u]) : S - 1 - ka[u];
+                    const int k = qa + R0 * ka[u];
+                    flip[u] = 2 * k > Nc;                         // the pair is (lo, Nc - lo) with lo <= Nc / 2
+                    lo[u] = flip[u] ? Nc - k : k;
+                    pw[u] = P.post[lo[u]];
+                    zk[u] = buf[perm[ka[u]]];
+                    zm[u] = bufb[perm[kb]];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const double2 zl = flip[u] ? zm[u] : zk[u], zh = flip[u] ? zk[u] : zm[u];
+                    const double2 e = make_double2(0.5 * (zl.x + zh.x), 0.5 * (zl.y - zh.y));
+                    const double2 o = make_double2(0.5 * (zl.y + zh.y), 0.5 * (zh.x - zl.x));
+                    const double2 wo = cmul(pw[u], o);
+                    const double ar = e.x + wo.x, ai = e.y + wo.y, br = e.x - wo.x, bi = e.y - wo.y;
+                    if (k0 + u * kThreads < n_k) {
+                        const int l = lo[u];
+                        row[l] = mag_sqrt(fma(ar, ar, ai * ai)) * invNf;
+                        if (l > 0 && Nc - l != l) row[Nc - l] = mag_sqrt(fma(br, br, bi * bi)) * invNf;
+                    }
+                }
+            }
+        } else {
+            // odd windows: one sample per element, X[k] = Z[k] for k < Nf
+            for (int h = 0; h < (two ? 2 : 1); ++h) {
+                const int q = h ? qb : qa;
+                const double2 *bb = h ? bufb : buf;
+                for (int ka = tid; ka < S; ka += kThreads) {
+                    const int k = q + R0 * ka;
+                    if (k < Nf) {
+                        const double2 z = bb[perm[ka]];
+                        row[k] = mag_sqrt(fma(z.x, z.x, z.y * z.y)) * invNf;
+                    }
+                }
+            }
+        }
+        cu = cu_next;
+        ti = t_next;
+    }
+}
+
+// time-domain features of the frames of a split plan: one workgroup per frame, the samples read where they lie
+constexpr int kTimeWaves = 16;
+template <typename T>
+__global__ __launch_bounds__(64 * kTimeWaves) void wg_time_kernel(PlanDev P, const T *__restrict__ sig, const ClipDev *__restrict__ clips,
+                                                      const ClipNorm *__restrict__ norms, const FrameRef *__restrict__ frames,
+                                                      double *__restrict__ tfeat) {
+    __shared__ double red[kTimeWaves * 5];
+    const FrameRef fr = frames[blockIdx.x];
+    if (fr.halo) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const ClipDev cd = clips[fr.clip];
+    const ClipNorm nm = norms[fr.clip];
+    const T *x = sig + cd.sample_off + P.frame_origin + (long long)fr.t * P.S;
+    const double sc = sample_scale<T>();
+    const bool even = P.even;
+    wg_time_partials<kTimeWaves>(P, P.Nc, lane, wave, red, [&](int p) {
+        if (even) {
+            const double2 xx = ct::PairLoad<T>::get(x + 2 * p);
+            return make_double2(fma(xx.x, sc, -nm.mean) * nm.inv, fma(xx.y, sc, -nm.mean) * nm.inv);
+        }
+        return make_double2(fma(load_sample<T>(x + p), sc, -nm.mean) * nm.inv, 0.0);
+    });
+    __syncthreads();
+    if (wave == 0) wg_time_finish<kTimeWaves>(red, lane, tfeat + 3 * (long long)fr.row);
+}
+
 // sum over the workgroup: every wave's total through LDS (slot[kFeatWaves]); all threads return the same bits
 __device__ __forceinline__ double bsum8(double v, double *slot, int lane, int wave) {
     v = wsum(v);
@@ -344,6 +560,7 @@ __device__ __forceinline__ double bsum8(double v, double *slot, int lane, int wa
 
 // the 34 features (or the 12 chromagram values) of one frame from its spectrum row and the previous frame's: both rows are
 // staged in LDS first (16 independent loads per lane and row), every sweep then runs from there
+template <bool STAGED>
 __global__ __launch_bounds__(kFeatThreads) void wg_feat_kernel(PlanDev P, const FrameRef *__restrict__ frames,
                                                               const ClipDev *__restrict__ clips, const double *__restrict__ spec,
                                                               const double *__restrict__ tfeat, double *__restrict__ out) {
@@ -353,8 +570,8 @@ __global__ __launch_bounds__(kFeatThreads) void wg_feat_kernel(PlanDev P, const 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const ClipDev c = clips[fr.clip];
     const int Nf = P.Nf, W = P.W;
-    double *cur = reinterpret_cast<double *>(smem);
-    double *fv = cur + Nf;               // [48]
+    double *cur_l = reinterpret_cast<double *>(smem);
+    double *fv = cur_l + (STAGED ? Nf : 0);               // [48]
     double *msp = fv + 48;               // [40]
     double *red = msp + 40;              // [kFeatWaves][16]
     double *slot = red + kFeatWaves * 16;      // [kFeatWaves]
@@ -364,11 +581,13 @@ __global__ __launch_bounds__(kFeatThreads) void wg_feat_kernel(PlanDev P, const 
     // staging of one runs under the sweeps of the other
     const double *gc = spec + (long long)fr.row * Nf;
     const double *prv = (fr.t == 0) ? gc : gc - Nf;          // frames are laid out in clip order: the previous frame is the previous row
-    {
+    if (STAGED) {
 #pragma unroll 8
-        for (int k = tid; k < ((kAblate & 16) ? 64 : Nf); k += kFeatThreads) cur[k] = gc[k];
+        for (int k = tid; k < ((kAblate & 16) ? 64 : Nf); k += kFeatThreads) cur_l[k] = gc[k];
     }
     __syncthreads();
+    // (a row beyond the LDS -- more than 20 000 bins -- is swept from L2 instead)
+    const double *cur = STAGED ? cur_l : gc;
     double *oc = out + c.out_off;
     const long long Tc = c.T;
     const Tabs tb = tabs_global(P);
@@ -377,19 +596,38 @@ __global__ __launch_bounds__(kFeatThreads) void wg_feat_kernel(PlanDev P, const 
     double part[15];          // 0..9 blocks, 10 tail, 11 sum X, 12 sum X_prev, 13 sum (k + 1) X, 14 max
 #pragma unroll
     for (int i = 0; i < 15; ++i) part[i] = 0.0;
-#pragma unroll
-    for (int j = 0; j < 11; ++j) {
-        const int lo = j * LB, hi = (kAblate & 32) ? lo : ((j < 10) ? lo + LB : Nf);
-        double p = 0.0;
-        for (int k = lo + tid; k < hi; k += kFeatThreads) {
+    if constexpr (!STAGED) {
+        // the row lies in L2: ONE strided sweep with eight loads in flight (block by block, every short loop waited for its own
+        // loads).  (Which thread adds which element differs from the staged form: last-bit differences between the two forms,
+        // which never meet -- a window always takes the same one.)
+        const unsigned mlb = (unsigned)(((1ULL << 32) + (unsigned)LB - 1) / (unsigned)LB);
+#pragma unroll 4
+        for (int k = tid; k < Nf; k += kFeatThreads) {
             const double X = cur[k];
             part[11] += X;
             part[12] += prv[k];
             part[13] = fma((double)(k + 1), X, part[13]);
             part[14] = fmax(part[14], X);
-            p = fma(X, X, p);
+            const int j = min((int)__umulhi((unsigned)k, mlb), 10);
+            const double sq = X * X;
+#pragma unroll
+            for (int i = 0; i < 11; ++i) part[i] += (i == j) ? sq : 0.0;
         }
-        part[j] = p;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {
+            const int lo = j * LB, hi = (kAblate & 32) ? lo : ((j < 10) ? lo + LB : Nf);
+            double p = 0.0;
+            for (int k = lo + tid; k < hi; k += kFeatThreads) {
+                const double X = cur[k];
+                part[11] += X;
+                part[12] += prv[k];
+                part[13] = fma((double)(k + 1), X, part[13]);
+                part[14] = fmax(part[14], X);
+                p = fma(X, X, p);
+            }
+            part[j] = p;
+        }
     }
 #pragma unroll
     for (int i = 0; i < 14; ++i) part[i] = wsum(part[i]);
@@ -464,6 +702,7 @@ __global__ __launch_bounds__(kFeatThreads) void wg_feat_kernel(PlanDev P, const 
         const int cch = ((Nf + kFeatThreads - 1) / kFeatThreads) | 1;
         const int kb = min(tid * cch, Nf), ke = (kAblate & 64) ? kb : min(Nf, kb + cch);
         double cs = 0.0;
+#pragma unroll 8
         for (int k = kb; k < ke; ++k) { const double X = cur[k]; cs = fma(X, X, cs); }
         const double incl = wscan_incl(cs);
         if (lane == 63) slot[wave] = incl;
@@ -574,37 +813,17 @@ __global__ __launch_bounds__(256) void wg_delta_kernel(const ClipDev *__restrict
 }
 
 // ---- host: does the window fit, radix schedule, permutation ----------------------------------------------------------------
-// 1: the transform of this window runs in one workgroup's LDS (fills L and perm); 0: it does not (kernels_big.hpp keeps it)
-inline int wg_layout(const FftPlan &fft, WgLayout &L, std::vector<unsigned short> &perm) {
-    const int Nc = fft.len, Nf = fft.window / 2;
-    if (Nc < 256 || Nc > 65000) return 0;
-    std::vector<int> radix;
-    if (!mix::mix_factor(Nc, radix)) return 0;
-    memset(&L, 0, sizeof(L));
-    auto up16 = [](size_t b) { return (b + 15) / 16 * 16; };
-    L.top = Nc / radix[0];
+// fills the schedule of a transform of `n` elements whose twiddles come from the table of `Nc` (n = Nc, or one sub-transform)
+inline void wg_schedule(int Nc, int n, const std::vector<int> &radix, WgLayout &L, std::vector<unsigned short> &perm) {
+    L.top = n / radix[0];
     L.magic_top = (unsigned)(((1ULL << 32) + (unsigned)L.top - 1) / (unsigned)L.top);
-    size_t off = up16((size_t)(Nc + radix[0]) * 16);
-    L.off_red = (int)off; off += up16((size_t)16 * 5 * 8);
-    L.off_twlo = (int)off; off += (size_t)kTwLo * 16;
-    L.n_twhi = (Nc + kTwLo - 1) / kTwLo;
-    if (L.n_twhi > 256) return 0;
-    L.off_twhi = (int)off; off += (size_t)L.n_twhi * 16;
-    L.off_perm = (int)off;
-    L.perm_lds = (off + up16((size_t)Nc * 2 + 4) <= 160 * 1024) ? 1 : 0;
-    if (L.perm_lds) off += up16((size_t)Nc * 2 + 4);
-    if (off > 160 * 1024) return 0;
-    L.lds_bytes = (int)off;
-    const size_t feat = up16((size_t)Nf * 8 + (48 + 40 + kFeatWaves * 16 + kFeatWaves) * 8 + kFeatWaves * 4);
-    if (feat > 160 * 1024) return 0;
-    L.feat_lds_bytes = (int)feat;
     L.n_pass = (int)radix.size();
 #ifndef PAA_WG_NT
 #define PAA_WG_NT 0                 // timing builds of scripts/rounds/r05 only: force the workgroup size of the spectrum kernel
 #endif
     L.threads = PAA_WG_NT ? PAA_WG_NT : 768;
     for (int r : radix) if (r > 8) L.threads = 512;
-    int M = Nc;
+    int M = n;
     for (int p = 0; p < L.n_pass; ++p) {
         L.radix[p] = radix[p];
         L.span[p] = M;
@@ -613,9 +832,63 @@ inline int wg_layout(const FftPlan &fft, WgLayout &L, std::vector<unsigned short
         L.tws[p] = Nc / M;
         M /= radix[p];
     }
-    mix::mix_permutation(Nc, radix, perm);
+    mix::mix_permutation(n, radix, perm);
     for (auto &pp : perm) pp = (unsigned short)(pp + pp / L.top);          // positions in the padded buffer
     perm.push_back(0);          // (the LDS copy moves whole 32-bit words)
+}
+
+// 1: the transform of this window runs in one workgroup's LDS -- whole (L.r0 = 0) or as r0 sub-transforms (L.r0 > 0); fills L and
+// perm.  0: neither (a length with a prime factor above 13, or more than 32 768 points): kernels_big.hpp keeps it
+inline int wg_layout(const FftPlan &fft, WgLayout &L, std::vector<unsigned short> &perm) {
+    const int Nc = fft.len, Nf = fft.window / 2;
+    if (Nc < 256 || Nc > 32768) return 0;
+    std::vector<int> radix;
+    if (!mix::mix_factor(Nc, radix)) return 0;
+    memset(&L, 0, sizeof(L));
+    auto up16 = [](size_t b) { return (b + 15) / 16 * 16; };
+    constexpr size_t kLds = 160 * 1024;
+    L.n_twhi = (Nc + kTwLo - 1) / kTwLo;
+    if (L.n_twhi > 256) return 0;
+    // the feature kernel: the row staged in LDS when it fits
+    const size_t feat_small = up16((size_t)(48 + 40 + kFeatWaves * 16 + kFeatWaves) * 8 + kFeatWaves * 4);
+    L.feat_staged = ((size_t)Nf * 8 + feat_small <= kLds) ? 1 : 0;
+    L.feat_lds_bytes = (int)(feat_small + (L.feat_staged ? up16((size_t)Nf * 8) : 0));
+    auto place = [&](size_t buf_elems, int n_perm) -> bool {
+        size_t off = up16(buf_elems * 16);
+        L.off_red = (int)off; off += up16((size_t)16 * 5 * 8);
+        L.off_twlo = (int)off; off += (size_t)kTwLo * 16;
+        L.off_twhi = (int)off; off += (size_t)L.n_twhi * 16;
+        L.off_cv = (int)off; off += 8 * 16;
+        L.off_perm = (int)off;
+        L.perm_lds = (off + up16((size_t)n_perm * 2 + 4) <= kLds) ? 1 : 0;
+        if (L.perm_lds) off += up16((size_t)n_perm * 2 + 4);
+        L.lds_bytes = (int)off;
+        return off <= kLds;
+    };
+    if (place((size_t)(Nc + radix[0]), Nc)) {
+        wg_schedule(Nc, Nc, radix, L, perm);
+        return 1;
+    }
+    // split: the first pass (radix r0 <= 8, any divisor) straight from the samples, two sub-transforms side by side in LDS;
+    // fewest passes + a quarter pass per point of r0 (the first pass costs r0 complex multiply-adds per output)
+    int best = 0;
+    double best_cost = 1e30;
+    for (int r0 = 2; r0 <= 8; ++r0) {
+        if (Nc % r0) continue;
+        std::vector<int> rs;
+        const int S = Nc / r0;
+        if (S < 256 || !mix::mix_factor(S, rs)) continue;
+        if (!place((size_t)2 * (S + rs[0]), S)) continue;
+        const double cost = (double)rs.size() + 0.25 * r0;
+        if (cost < best_cost) { best_cost = cost; best = r0; }
+    }
+    if (!best) return 0;
+    std::vector<int> rs;
+    const int S = Nc / best;
+    mix::mix_factor(S, rs);
+    place((size_t)2 * (S + rs[0]), S);
+    wg_schedule(Nc, S, rs, L, perm);
+    L.r0 = best; L.sub = S;
     return 1;
 }
 

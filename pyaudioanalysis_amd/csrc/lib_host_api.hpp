@@ -244,8 +244,15 @@ static int run_host_spec(const void *signal, int64_t n, int sample_kind, double 
             if (last_len < window / 2)
                 return fail(PAA_ERR_CHROMA_VALUE, "truncated last chromagram frame shorter than num_fft "
                             "(ValueError in the reference, ShortTermFeatures.py:288)");
-            rc = launch_chroma_tail(plan->P, sample_kind, d_samples, pos, n, (int)(filled - plan->clips[0].T), plan->d_norms,
-                                    (double *)lane.l->out.p + (long long)plan->clips[0].T * 12, cs());
+            const int n_tail = (int)(filled - plan->clips[0].T);
+            const size_t spill = chroma_tail_spill_bytes(plan->P, n_tail);
+            if (spill) {
+                std::lock_guard<std::mutex> lk(g_mu);
+                if ((rc = scratch_reserve(lane.l->mid, spill))) return rc;
+            }
+            rc = launch_chroma_tail(plan->P, sample_kind, d_samples, pos, n, n_tail, plan->d_norms,
+                                    (double *)lane.l->out.p + (long long)plan->clips[0].T * 12,
+                                    spill ? (double *)lane.l->mid.p : nullptr, cs());
             if (rc == -2) return fail(PAA_ERR_UNSUPPORTED, "truncated chromagram tail frame with window %d does not fit LDS", window);
             if (rc) return fail(PAA_ERR_HIP, "chromagram tail launch failed");
         }

@@ -11,7 +11,12 @@ constexpr int kStatChunk = 65536;          // samples per statistics workgroup (
 // chunk per CU is therefore cut into a whole multiple of num_cu chunks (1024 x 56 256 samples for the hour).
 static int stat_chunk_for(long long total_samples, int num_cu) {
     const long long blocks = (total_samples + kStatChunk - 1) / kStatChunk;
-    if (blocks < num_cu) return kStatChunk;
+    if (blocks < num_cu) {
+        // a short batch (one 60 s stereo clip = 41 chunks of 64 K) left 215 CUs idle and each workgroup with sixteen dependent
+        // rounds of loads: 16.7 us for 10.6 MB.  Four chunks per CU of at least 4096 samples (one round of loads) instead.
+        const long long len = ((total_samples + 4LL * num_cu - 1) / (4LL * num_cu) + 63) / 64 * 64;
+        return (int)std::min<long long>(kStatChunk, std::max<long long>(len, 4096));
+    }
     const long long want = (blocks + num_cu - 1) / num_cu * num_cu;
     const long long len = ((total_samples + want - 1) / want + 63) / 64 * 64;      // multiples of 64 samples keep the 16-byte body aligned
     return (int)std::min<long long>(kStatChunk, std::max<long long>(len, 4096));
@@ -86,6 +91,9 @@ struct paa_plan {
     std::vector<wg::FrameRef> wg_frames;              // every frame of the plan, chunk after chunk (a chunk's rows fit the scratch)
     std::vector<std::pair<long long, long long>> wg_chunks;     // [first, last) into wg_frames
     wg::FrameRef *d_wg_frames = nullptr;
+    std::vector<wg::FrameRef> wg_tasks;               // split transforms (wl.r0 > 0): (frame, sub-transform pair) records, chunk after chunk
+    std::vector<std::pair<long long, long long>> wg_task_chunks;
+    wg::FrameRef *d_wg_tasks = nullptr;
     unsigned short *d_wg_perm = nullptr;
     long long wg_rows = 0;           // spectrum rows of the largest chunk
     long long mid_off_step = -1;
@@ -112,6 +120,7 @@ static void plan_free(paa_plan *p) {
     pool_free(p->d_block);          // clips, tiles, statistics chunks / partials, clip constants: one pooled block
     pool_free(p->d_mid_off);
     pool_free(p->d_wg_frames);
+    pool_free(p->d_wg_tasks);
     pool_free(p->d_wg_perm);
     if (!p->blob_cached) pool_free(p->d_gen_blob);
     if (p->d_big) (void)hipFree(p->d_big);
@@ -294,9 +303,29 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
                 for (long long i = ch.first; i < ch.second; ++i) p->wg_frames[(size_t)i].row = (int)(i - ch.first);
             }
             if ((rc = upload_pooled(&p->d_wg_frames, p->wg_frames.data(), std::max<size_t>(p->wg_frames.size(), 1)))) return rc;
+            if (p->wl.r0) {
+                // tasks of a frame: sub-transform 0 alone, the pairs {q, r0 - q}, r0 / 2 alone (FrameRef::halo = halo | q << 8)
+                const int r0 = p->wl.r0;
+                for (auto &ch : p->wg_chunks) {
+                    const long long t0 = (long long)p->wg_tasks.size();
+                    // (the pairs first: they cost twice what the single sub-transforms do, and tasks are handed out in list order)
+                    for (int pairs = 1; pairs >= 0; --pairs)
+                        for (long long i = ch.first; i < ch.second; ++i)
+                            for (int q = 0; 2 * q <= r0; ++q) {
+                                if ((q != 0 && 2 * q != r0) != (pairs != 0)) continue;
+                                wg::FrameRef f = p->wg_frames[(size_t)i];
+                                f.halo |= q << 8;
+                                p->wg_tasks.push_back(f);
+                            }
+                    p->wg_task_chunks.emplace_back(t0, (long long)p->wg_tasks.size());
+                }
+                if (p->wg_tasks.size() > 0x7fffffffULL) return fail(PAA_ERR_UNSUPPORTED, "too many frames for the split transform");
+                if ((rc = upload_pooled(&p->d_wg_tasks, p->wg_tasks.data(), std::max<size_t>(p->wg_tasks.size(), 1)))) return rc;
+            }
             if ((rc = upload_pooled(&p->d_wg_perm, perm.data(), perm.size()))) return rc;
             p->wg = 1;
-            p->kernel_name = (mode == 0) ? "st_wg_lds_fft" : (mode == 1 ? "spectrogram_wg_lds_fft" : "chromagram_wg_lds_fft");
+            p->kernel_name = p->wl.r0 ? ((mode == 0) ? "st_wg_split_fft" : (mode == 1 ? "spectrogram_wg_split_fft" : "chromagram_wg_split_fft"))
+                                      : ((mode == 0) ? "st_wg_lds_fft" : (mode == 1 ? "spectrogram_wg_lds_fft" : "chromagram_wg_lds_fft"));
         }
     }
     // every one-launch feature kernel folds the statistics partials into the clip constants itself (its waves' prologue);
@@ -429,7 +458,7 @@ struct ProfScope {
 template <typename T>
 static int run_wg(paa_plan *p, const void *d_packed, double *d_out) {
     const PlanDev &P = p->P;
-    const size_t need = (size_t)p->wg_rows * ((size_t)P.Nf * 8 + 24) + 256;
+    const size_t need = (size_t)p->wg_rows * ((size_t)P.Nf * 8 + 24) + 256;       // (+ the task counter of the split transform)
     if (need > p->big_bytes) {
         if (p->d_big) { HIP_TRY(hipStreamSynchronize(cs())); (void)hipFree(p->d_big); p->d_big = nullptr; p->big_bytes = 0; }
         HIP_TRY(hipMalloc(&p->d_big, need));
@@ -437,25 +466,49 @@ static int run_wg(paa_plan *p, const void *d_packed, double *d_out) {
     }
     double *spec = reinterpret_cast<double *>(p->d_big);
     double *tfeat = spec + (size_t)p->wg_rows * P.Nf;
+    int *task_counter = reinterpret_cast<int *>(tfeat + 3 * (size_t)p->wg_rows);
     static LdsAttrCache attr;
     if (!attr.covers((size_t)p->wl.lds_bytes)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wg::wg_spectrum_kernel<T, 512>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, p->wl.lds_bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wg::wg_spectrum_kernel<T, 768>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, p->wl.lds_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wg::wg_split_kernel<T, 512>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, p->wl.lds_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wg::wg_split_kernel<T, 768>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, p->wl.lds_bytes));
         attr.set((size_t)p->wl.lds_bytes);
     }
     static LdsAttrCache attr_feat;
     if (!attr_feat.covers((size_t)p->wl.feat_lds_bytes)) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wg::wg_feat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wg::wg_feat_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     p->wl.feat_lds_bytes));
         attr_feat.set((size_t)p->wl.feat_lds_bytes);
     }
-    for (const auto &ch : p->wg_chunks) {
+    for (size_t ci = 0; ci < p->wg_chunks.size(); ++ci) {
+        const auto &ch = p->wg_chunks[ci];
         const unsigned n = (unsigned)(ch.second - ch.first);
         const wg::FrameRef *fr = p->d_wg_frames + ch.first;
         ProfScope prof_scope;          // (bench.py's event pairs bracket the spectrum kernel: the dominant one of this path)
         { const int rc_p = prof_scope.begin(); if (rc_p) return rc_p; }
+        if (p->wl.r0) {
+            // split transforms: persistent workgroups over (frame, sub-transform pair) tasks, one per CU
+            const auto &tc = p->wg_task_chunks[ci];
+            const unsigned nt = (unsigned)(tc.second - tc.first);
+            const wg::FrameRef *tk = p->d_wg_tasks + tc.first;
+            const unsigned grid = std::min<unsigned>(nt, (unsigned)g_num_cu);
+            HIP_TRY(hipMemsetAsync(task_counter, 0, sizeof(int), cs()));
+            if (p->wl.threads == 768)
+                hipLaunchKernelGGL((wg::wg_split_kernel<T, 768>), dim3(grid), dim3(768), (size_t)p->wl.lds_bytes, cs(), P, p->wl,
+                                   p->d_wg_perm, (const T *)d_packed, p->d_clips, p->d_norms, tk, (int)nt, task_counter, spec, d_out);
+            else
+                hipLaunchKernelGGL((wg::wg_split_kernel<T, 512>), dim3(grid), dim3(512), (size_t)p->wl.lds_bytes, cs(), P, p->wl,
+                                   p->d_wg_perm, (const T *)d_packed, p->d_clips, p->d_norms, tk, (int)nt, task_counter, spec, d_out);
+            if (prof_scope.stop) { (void)hipEventRecord(prof_scope.stop, cs()); prof_scope.stop = nullptr; }
+            if (P.mode == 0)
+                hipLaunchKernelGGL((wg::wg_time_kernel<T>), dim3(n), dim3(64 * wg::kTimeWaves), 0, cs(), P, (const T *)d_packed, p->d_clips, p->d_norms,
+                                   fr, tfeat);
+        } else {
         // persistent workgroups: as many as the LDS footprint lets the chip hold at once, each walks frames b, b + grid, ...
         const unsigned per_cu = (unsigned)std::max<size_t>(1, ((size_t)160 * 1024) / (size_t)p->wl.lds_bytes);
         const unsigned grid = std::min<unsigned>(n, (unsigned)g_num_cu * std::min<unsigned>(per_cu, p->wl.threads == 768 ? 2u : 4u));
@@ -466,9 +519,15 @@ static int run_wg(paa_plan *p, const void *d_packed, double *d_out) {
             hipLaunchKernelGGL((wg::wg_spectrum_kernel<T, 512>), dim3(grid), dim3(512), (size_t)p->wl.lds_bytes, cs(), P, p->wl,
                                p->d_wg_perm, (const T *)d_packed, p->d_clips, p->d_norms, fr, (int)n, spec, tfeat, d_out);
         if (prof_scope.stop) { (void)hipEventRecord(prof_scope.stop, cs()); prof_scope.stop = nullptr; }
-        if (P.mode != 1)
-            hipLaunchKernelGGL(wg::wg_feat_kernel, dim3(n), dim3(wg::kFeatThreads), (size_t)p->wl.feat_lds_bytes, cs(), P, fr,
-                               p->d_clips, spec, tfeat, d_out);
+        }
+        if (P.mode != 1) {
+            if (p->wl.feat_staged)
+                hipLaunchKernelGGL(wg::wg_feat_kernel<true>, dim3(n), dim3(wg::kFeatThreads), (size_t)p->wl.feat_lds_bytes, cs(), P, fr,
+                                   p->d_clips, spec, tfeat, d_out);
+            else
+                hipLaunchKernelGGL(wg::wg_feat_kernel<false>, dim3(n), dim3(wg::kFeatThreads), (size_t)p->wl.feat_lds_bytes, cs(), P, fr,
+                                   p->d_clips, spec, tfeat, d_out);
+        }
         HIP_TRY(hipGetLastError());
     }
     if (P.mode == 0 && P.deltas) {

@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 5, GPU pass q: chromagram tail frames of windows beyond 40 960 samples (spectrum row in scratch), the split-transform
+# rows / batch test, counter passes of the split transform and of config 5's spectrogram rows (statistics pass with 4 chunks per CU)
+out=gpurun_out/r05q; mkdir -p $out
+(timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q --no-header --durations=8 --maxfail=20 -k "big or workgroup" 2>&1 | tail -40) > $out/tests.log
+tail -8 $out/tests.log
+for c in big_44100 reg_spectrogram_stereo; do
+  timeout 300 bash scripts/profile_kernel.sh r05 $c 40 > $out/prof_$c.log 2>&1
+done
+python - <<'PY'
+import json
+for c in ('big_44100', 'reg_spectrogram_stereo'):
+    d = json.load(open('gpurun_out/r05_%s_summary.json' % c))
+    print(c, d['run_under_trace']['ms_per_step'])
+    for k in d['kernel_trace_stats'][:6]: print('   ', k['name'][:100], k['calls'], k['avg_us'])
+PY

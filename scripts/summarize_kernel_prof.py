@@ -27,6 +27,8 @@ def main(prof_dir, out_path):
     second = None
     if "wg_lds_fft" in stem:                      # two kernels per step: the spectra of all frames, then their features
         like, second = "%wg_spectrum_kernel%", "%wg_feat_kernel%"
+    if "wg_split_fft" in stem:                    # split transforms: sub-transform tasks, then the features (+ a small time-domain kernel)
+        like, second = "%wg_split_kernel%", "%wg_feat_kernel%"
     if stem == "big_window_hbm_passes":
         like = "%big_pass_kernel%"
     out["kernel_like"] = like

@@ -190,7 +190,7 @@ def test_ranged_host_call_on_the_other_families(gpu_lib, fs, window, step, delta
     more than 65 536 frames through ct / tri / mix equals the device-resident plan's single launch bit for bit, and the profiling
     events count the ranged launches."""
     import ctypes
-    n = 66000 * step + window
+    n = 65999 * step + window                                                           # 66 000 frames
     x = np.tile(synth_clip(31, 60 * fs, fs), -(-n // (60 * fs)))[:n]
     _ffi.check(gpu_lib.paa_prof_enable(1))
     F, _ = ShortTermFeatures.feature_extraction(x, fs, window, step, deltas)

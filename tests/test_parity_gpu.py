@@ -346,7 +346,8 @@ def test_delta_rows_reformed_on_the_device_equal_the_68_row_plan(gpu_lib):
 
 def test_big_window_kernel_choice(gpu_lib):
     """Windows beyond the one-wave kernels: the transform runs in ONE WORKGROUP's LDS when it fits (kernels_wg.hpp: up to 10 000
-    complex points made of 2, 3, 5, 7, 11, 13), otherwise through HBM scratch (kernels_big.hpp).  No window falls back to the CPU."""
+    complex points made of 2, 3, 5, 7, 11, 13); longer ones (up to 32 768 points) as r0 <= 8 sub-transforms whose first pass runs
+    straight from the samples (wg_split_kernel); the rest through HBM scratch (kernels_big.hpp).  No window falls back to the CPU."""
     def name(fs, w, s, mode=0):
         plan = _ffi.Plan(np.array([0, 4 * w], dtype=np.int64), fs, w, s, deltas=False, mode=mode)
         try:
@@ -357,7 +358,11 @@ def test_big_window_kernel_choice(gpu_lib):
     assert name(16000, 8000, 4000, mode=1) == "spectrogram_wg_lds_fft"
     assert name(16000, 8000, 4000, mode=2) == "chromagram_wg_lds_fft"
     assert name(16000, 9009, 4500) == "st_wg_lds_fft"                  # odd: 9009 = 7 x 9 x 11 x 13 real points, 144 KB of LDS
-    assert name(44100, 44100, 22050) == "big_window_hbm_passes"        # 22 050 complex points: 353 KB
+    assert name(44100, 44100, 22050) == "st_wg_split_fft"              # 22 050 complex points = 353 KB: 6 sub-transforms of 3675
+    assert name(48000, 48000, 24000, mode=1) == "spectrogram_wg_split_fft"     # 24 000 points: 6 x 4000
+    assert name(44100, 11025, 5000, mode=2) == "chromagram_wg_split_fft"       # odd: 11 025 real points, 3 x 3675
+    assert name(16000, 65536, 32768) == "st_wg_split_fft"              # the largest table: 32 768 points = 8 x 4096
+    assert name(16000, 80000, 40000) == "big_window_hbm_passes"        # 40 000 points: beyond the two-level twiddle table
     assert name(16000, 9001, 4500) == "big_window_hbm_passes"          # prime
 
 
@@ -368,6 +373,12 @@ def test_big_window_kernel_choice(gpu_lib):
     ("f64", 8000, 8000, 8000, 9.0, False),       # 1 s at 8 kHz, float64 samples
     ("i16", 16000, 9009, 3000, 4.0, True),       # odd window: real points, radices 13 11 7 3 3
     ("i16", 16000, 20000, 10000, 6.0, False),    # the edge of the LDS: 10 000 complex points = 160 000 bytes
+    ("i16", 44100, 44100, 22050, 6.0, True),     # split transform: 22 050 points = 6 x 3675 (tasks {0} {1,5} {2,4} {3}), row not staged
+    ("stereo", 48000, 48000, 24000, 4.0, False), # 24 000 = 6 x 4000 (radices 8 4 5 5 5), interleaved stereo
+    ("f64", 22050, 22050, 7000, 3.0, True),      # 11 025 points = 3 x 3675 (tasks {0} {1,2}), float64 samples
+    ("i16", 44100, 11025, 5000, 2.0, False),     # odd window of 11 025 REAL points through the split transform
+    ("i16", 16000, 32000, 16000, 9.0, False),    # 16 000 points = 4 x 4000 (tasks {0} {1,3} {2})
+    ("f64", 16000, 65536, 30000, 14.0, False),   # 32 768 points = 8 x 4096: radix-16 passes (512-thread instance)
 ])
 def test_workgroup_lds_kernel_full_matrix(gpu_lib, kind, fs, window, step, seconds, deltas):
     """kernels_wg.hpp against the NumPy oracle, every frame and row, every sample type (contract + tight gate)."""
@@ -400,13 +411,30 @@ def test_workgroup_lds_kernel_batches_and_rows(gpu_lib, capsys):
     chroma, _, _ = ShortTermFeatures.chromagram(x, fs, W, S)
     ref_c, _, _ = O.chromagram(x, fs, W, S)
     assert_parity(np.ascontiguousarray(chroma.T), np.ascontiguousarray(ref_c.T), "big-window chromagram")
+    # the same through the split transform (48 000-sample windows), stereo input, a ragged batch
+    fs, W, S = 48000, 48000, 24000
+    xs = synth_clip(6300, 4 * fs + 1000, fs, stereo=True)
+    mono = O.stereo_to_mono(xs)
+    spec, _, _ = ShortTermFeatures.spectrogram(xs, fs, W, S)
+    capsys.readouterr()
+    ref_s, _, _ = O.spectrogram(mono, fs, W, S)
+    assert_parity(np.ascontiguousarray(spec.T), np.ascontiguousarray(ref_s.T), "split-transform spectrogram")
+    chroma, _, _ = ShortTermFeatures.chromagram(xs, fs, W, S)
+    ref_c, _, _ = O.chromagram(mono, fs, W, S)
+    assert_parity(np.ascontiguousarray(chroma.T), np.ascontiguousarray(ref_c.T), "split-transform chromagram")
+    clips = [synth_clip(6400 + i, n, fs) for i, n in enumerate([W, 3 * W + 17, 2 * W - 1])]
+    res, _ = ShortTermFeatures.feature_extraction_batch(clips, fs, W, S, deltas=True)
+    for c, r in zip(clips, res):
+        single, _ = ShortTermFeatures.feature_extraction(c, fs, W, S)
+        assert np.array_equal(single, r)
 
 
 @pytest.mark.parametrize("fs,window,step,seconds", [
     (16000, 8000, 4000, 6.0),       # 0.5 s window: beyond the one-wave kernels -> one workgroup per frame (kernels_wg.hpp)
     (16000, 16000, 16000, 8.0),     # 1 s / 1 s, the music_thumbnailing shape (audioSegmentation.py:1137)
     (16000, 9001, 4500, 3.0),       # odd prime window: Stockham passes through HBM scratch, one O(N^2) pass
-    (44100, 44100, 22050, 3.0),     # 1 s at 44.1 kHz: 22 050 complex points do not fit the LDS -> HBM passes
+    (44100, 44100, 22050, 3.0),     # 1 s at 44.1 kHz: 22 050 complex points do not fit the LDS -> split transform
+    (16000, 80000, 40000, 12.0),    # 5 s windows: 40 000 complex points -> radix passes through HBM scratch (kernels_big.hpp)
 ])
 def test_big_windows_match_oracle(gpu_lib, fs, window, step, seconds):
     x = synth_clip(700 + window, int(seconds * fs), fs=fs)
