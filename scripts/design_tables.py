@@ -30,9 +30,12 @@ def main(rnd):
             continue
         tr = d.get("traffic", {})
         fmt = lambda v, s: (s % v) if v else "-"
-        print("| %s | `%s` | %s | %.4f | %s | %s | %s |" % (r["case"], r["kernel"], fmt(d.get("kernel_avg_us"), "%.1f"), r["ms_per_step"],
+        kernel, issue = r["kernel"], d.get("valu_issue_fraction")
+        if r["case"] == "mid_stats":            # the loop runs the short-term plan first; the profiled kernel is mid_stats_kernel (a stream:
+            kernel, issue = "mid_stats_kernel", None          # the issue fraction is not a meaningful figure for it)
+        print("| %s | `%s` | %s | %.4f | %s | %s | %s |" % (r["case"], kernel, fmt(d.get("kernel_avg_us"), "%.1f"), r["ms_per_step"],
                                                      fmt(tr.get("traffic_over_algorithmic"), "%.2f"),
-                                                     fmt(d.get("lds_bank_conflict_ratio"), "%.2f"), fmt(d.get("valu_issue_fraction"), "%.2f")))
+                                                     fmt(d.get("lds_bank_conflict_ratio"), "%.2f"), fmt(issue, "%.2f")))
 
 
 if __name__ == "__main__":
