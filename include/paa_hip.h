@@ -268,6 +268,11 @@ int paa_debug_run_plan(const int64_t *frames, int64_t n_clips, int quantum, int 
 /* the same for kernels whose runs after a clip's first are `shrink` frames shorter (halo inside the first iteration) */
 int paa_debug_run_plan_shrink(const int64_t *frames, int64_t n_clips, int quantum, int min_run, int max_run, int shrink,
                               int wg_runs, int num_cu, int32_t *run_cap, int64_t *n_runs, int32_t *longest);
+/* the run lengths a plan that fills LESS than one round of a one-workgroup-per-CU kernel gets instead of equal runs (the hot
+ * kernel: num_cu x wg_runs runs whose iteration counts differ by at most one; csrc/lib_plan.hpp: balanced_runs).  Writes them clip
+ * after clip to lens[capacity]; returns their number, 0 when the equal runs of `run_cap` stay                              */
+int64_t paa_debug_balanced_runs(const int64_t *frames, int64_t n_clips, int run_cap, int quantum, int shrink, int wg_runs,
+                                int num_cu, int min_run, int32_t *lens, int64_t capacity);
 
 #ifdef __cplusplus
 }

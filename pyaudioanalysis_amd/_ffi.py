@@ -115,6 +115,8 @@ _SIGNATURES = {
                                      c_i64p, c_i32p]),
     "paa_debug_run_plan_shrink": (C.c_int, [c_i64p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p,
                                      c_i64p, c_i32p]),
+    "paa_debug_balanced_runs": (C.c_int64, [c_i64p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p,
+                                            C.c_int64]),
 }
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
 

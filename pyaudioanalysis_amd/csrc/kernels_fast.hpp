@@ -18,7 +18,7 @@
 //             mel -> log10 -> 13x40 DCT, chroma gather; deltas from the previous column in registers
 //   store   : lane = feature row; the row's last seven values wait in registers until a 64-byte aligned chunk of eight
 //             frames is complete, which is stored whole and non-temporally (store_row_chunked)
-// Halo: a run with t0 > 0 first processes the quad t0-4..t0-1 without storing it.
+// Halo: a run with t0 > 0 starts its first quad one frame early (two with deltas) and does not store those frames.
 //
 // Replaces ShortTermFeatures.py:608-682 (+ helpers :22-140, :236-321) for this configuration.
 #pragma once
@@ -485,12 +485,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
     const int zc_shift = mu_whole ? 0 : 1;
 
     const int r0 = tl.t0, t_end = tl.t0 + tl.cnt;      // frames [r0, t_end) are this wave's to store
-    int q0 = r0 >= QUAD ? r0 - QUAD : 0;
+    // a run that starts inside a clip begins its first quad HALO frames early: the spectrum of frame r0 - 1 (flux of the first stored
+    // frame) and, with deltas, the complete features of r0 - 1 (whose flux needs the spectrum of r0 - 2) come out of that quad, whose
+    // other frames are already the run's own -- until round 5 a whole halo quad ran first (one iteration of 19 for nothing)
+    constexpr int HALO = DELTAS ? 2 : 1;
+    int q0 = r0 >= HALO ? r0 - HALO : 0;
     int slot0 = 2;                   // slots of a quad: slot0 .. slot0+3 (mod 5) after the rotation at the loop head; previous = slot0-1
     double vlast = 0.0;              // lane l < 34: feature l of the frame before this quad
     double hold[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};    // ... and the row's last seven values / deltas, waiting for
     double holdd[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // their 64-byte chunk (store_row_chunked)
-    bool first_quad = true;          // the run's first iteration: the halo quad when r0 >= 4
+    bool first_quad = true;          // the run's first iteration (its first HALO frames belong to the run before when r0 > 0)
     int n_done = 0;                  // quads of this run whose FFT stages are complete (pacing)
 
     // software prefetch of the next quad's samples (NPRE x 16 B per lane) into registers
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
     int16_t before_next = 0;         // lane 0: the sample just before the NEXT quad (saved while raw[] still holds it)
     int16_t before_reg = 0;          // lane 0: the sample just before THIS quad
     for (;; first_quad = false) {
-        // next quad: the halo quad first (frames r0-4 .. r0-1, nothing stored), then the run's own quads
+        // next quad
         if (!first_quad) q0 += QUAD;
         if (q0 >= t_end) break;
         slot0 = (slot0 + 4) % 5;
@@ -546,9 +550,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
             msp = spec + prev_slot * NF;
             fv = msp + QUAD * 40;
         }
-        // a halo quad of a 34-row run only has to leave its last spectrum behind (flux of the first stored frame):
-        // no time-domain stage, no features, no store
-        const bool spec_only = (DELTAS == 0) && (q0 + QUAD <= r0);
         // ---------------- stage raw samples [q0*S - 1, q0*S + 2000)
         {
             const long long base = (long long)q0 * S;
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
         // Two samples per 32-bit lane operation: v_dot2 gives x0^2 + x1^2 and x0 + x1, the sign of x - mu comes from
         // packed 16-bit saturating arithmetic:  s = clamp(sat(x - floor(mu)), lo, 1) * a + c  with (lo, a, c) =
         // (-1, 1, 0) when mu is a whole number (sign 0 exists) and (0, 2, -1) otherwise (x - floor(mu) >= 1 <=> +1).
-        for (int ch = spec_only ? NCHUNK : lane; ch < NCHUNK; ch += 64) {
+        for (int ch = lane; ch < NCHUNK; ch += 64) {
             const int4 *p4 = reinterpret_cast<const int4 *>(raw + G::PAD + CHUNK * ch);
             // the dword before the chunk holds the previous sample in its upper half (chunk 0 without a pad: lane 0's register)
             s16x2 sp;
@@ -740,7 +741,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void st_fast_800_kernel(PlanDev P,
         }
         wsync();
         ++n_done;
-        if (spec_only) continue;
         PAA_F800_PACE(-1)
 
         PAA_TICK(4)

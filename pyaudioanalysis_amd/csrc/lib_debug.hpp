@@ -112,6 +112,24 @@ extern "C" int paa_debug_run_plan_shrink(const int64_t *frames, int64_t n_clips,
     *run_cap = cap; *n_runs = runs; *longest = lmax;
     return PAA_OK;
 }
+// the run lengths paa_plan_create gives a plan that fills less than one round of a one-workgroup-per-CU kernel (lib_plan.hpp:
+// balanced_runs).  Returns the number of runs written to `lens` (clip after clip), 0 when the equal runs stay, < 0 on error.
+extern "C" int64_t paa_debug_balanced_runs(const int64_t *frames, int64_t n_clips, int run_cap, int quantum, int shrink, int wg_runs,
+                                           int num_cu, int min_run, int32_t *lens, int64_t capacity) {
+    if (!frames || n_clips < 0 || !lens || quantum < 1 || run_cap < quantum || wg_runs < 1 || num_cu < 1 || min_run < 1)
+        return fail(PAA_ERR_ARG, "bad argument");
+    std::vector<ClipDev> clips((size_t)n_clips);
+    for (int64_t c = 0; c < n_clips; ++c) { memset(&clips[(size_t)c], 0, sizeof(ClipDev)); clips[(size_t)c].T = (int)frames[c]; }
+    std::vector<std::vector<int>> out;
+    if (!balanced_runs(clips, run_cap, quantum, shrink, wg_runs, num_cu, min_run, out)) return 0;
+    int64_t n = 0;
+    for (const auto &l : out)
+        for (int v : l) {
+            if (n >= capacity) return fail(PAA_ERR_ARG, "capacity %lld too small", (long long)capacity);
+            lens[n++] = v;
+        }
+    return n;
+}
 // host side of the mixed-radix kernel for a window (no device needed): radix schedule of the in-place DIF transform and the
 // position that holds Z[k] afterwards.  Returns the number of passes, 0 when the window is not for that kernel.
 extern "C" int paa_debug_mix_plan(int window, int32_t *radices, int32_t *fft_len, uint16_t *perm, int perm_capacity,

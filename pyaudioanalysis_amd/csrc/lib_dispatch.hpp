@@ -19,6 +19,8 @@ struct FamilyCtx {
 // shorter (kernels whose look-back frames ride inside the run's first iteration)
 struct RunRule {
     int run = 64, quantum = 4, halo_inside = 0;
+    int fill_wg_runs = 0;        // > 0: runs per workgroup of a kernel with ONE workgroup per CU -- a plan whose equal runs fill less than
+                                 // one round of the chip is re-cut into num_cu x fill_wg_runs runs of two lengths (lib_plan.hpp: balanced_runs)
 };
 struct Family {
     const char *id;
@@ -48,9 +50,13 @@ static int fam_fast_select(FamilyCtx &c) {
     return rc;
 }
 static void fam_fast_rule(FamilyCtx &c, RunRule &r) {
-    // one wave per run, in multiples of the 4-frame quad, at most fl.run frames (halo = one quad); see choose_run_cap
+    // one wave per run of whole 4-frame quads, at most fl.run frames; a run after a clip's first starts its first quad one frame
+    // early (two with deltas: the flux of the last halo frame feeds a delta) -- the halo rides inside the first iteration, the run
+    // stores that many frames less (kernels_fast.hpp: HALO); see choose_run_cap
     r.quantum = 4;
-    r.run = choose_run_cap(c.p->clips, 4, 16, c.p->fl.run, 4, c.p->fl.waves_per_cu, c.num_cu());
+    r.halo_inside = c.deltas ? 2 : 1;
+    r.run = choose_run_cap(c.p->clips, 4, 16, c.p->fl.run, 0, c.p->fl.waves_per_cu, c.num_cu(), r.halo_inside);
+    r.fill_wg_runs = c.p->fl.waves_per_cu;
     if (const char *rc_env = experiment_env("PAA_RUN_CAP")) r.run = std::max(16, atoi(rc_env) / 4 * 4);      // A/B experiments only
 }
 static int fam_fast_launch(paa_plan *p, const void *d_packed, double *d_out, const Tile *tiles, long long n, hipStream_t s) {

@@ -60,6 +60,67 @@ static inline int clip_run_length(long long T, int cap, int quantum) {
     return (int)(((T + k - 1) / k + quantum - 1) / quantum * quantum);
 }
 
+// Run lengths of a plan that fills LESS than one round of a one-workgroup-per-CU kernel (the one-hour clip: 2000 equal runs of
+// 72 frames = 250 workgroups of eight on 256 CUs, scripts/experiments/run_geometry.py: 256 workgroups take the same time).  Every
+// clip is re-cut into its share of num_cu x wg_runs runs whose ITERATION counts (quanta) differ by at most one; runs after a
+// clip's first hold `shrink` halo frames inside their first iteration, i.e. store that many frames less.  Along the order
+// (workgroup, SIMD, first / second wave of the SIMD) long and short runs alternate, so the two waves that share a SIMD (w and
+// w + wg_runs / 2) get a long and a short one where the ratio allows.  Returns false (lens untouched) when the equal runs stay.
+static bool balanced_runs(const std::vector<ClipDev> &clips, int run, int quantum, int shrink, int wg_runs, int num_cu, int min_run,
+                          std::vector<std::vector<int>> &lens) {
+    if (wg_runs < 2 || (wg_runs & 1) || quantum < 1 || shrink < 0 || shrink >= quantum) return false;
+    long long total = 0, runs = 0;
+    std::vector<long long> need(clips.size(), 0);
+    for (size_t c = 0; c < clips.size(); ++c) {
+        const long long T = clips[c].T;
+        if (T <= 0) continue;
+        total += T;
+        const long long len = clip_run_length(T, run, quantum), later = std::max<long long>(len - shrink, 1);
+        need[c] = (T <= len) ? 1 : 1 + (T - len + later - 1) / later;          // the tile rule of the equal runs
+        runs += need[c];
+    }
+    const long long slots = (long long)num_cu * wg_runs;
+    if (runs >= slots || (runs + wg_runs - 1) / wg_runs > num_cu || total < slots * min_run) return false;
+    // runs per clip: proportional to its frames (at least what the cap asks for), never shorter than min_run frames
+    std::vector<long long> k(clips.size(), 0);
+    long long given = 0;
+    for (size_t c = 0; c < clips.size(); ++c) {
+        const long long T = clips[c].T;
+        if (T <= 0) continue;
+        k[c] = std::max<long long>(need[c], std::min<long long>(slots * T / total, std::max<long long>(T / min_run, 1)));
+        given += k[c];
+    }
+    if (given > slots) return false;
+    std::vector<std::vector<int>> out(clips.size());
+    const int half = wg_runs / 2;
+    long long first_tile = 0;          // tile index of the clip's first run (runs of all clips are laid out consecutively)
+    for (size_t c = 0; c < clips.size(); ++c) {
+        const long long T = clips[c].T, kc = k[c];
+        if (T <= 0) continue;
+        const long long iters = (T + (kc - 1) * shrink + quantum - 1) / quantum, base = iters / kc, longs = iters % kc;
+        if (base < 1 || (base + (longs ? 1 : 0)) * quantum > run) return false;
+        std::vector<int> &l = out[c];
+        l.assign((size_t)kc, (int)(base * quantum));
+        // position u of the (workgroup, SIMD, member) order -> run; `longs` of the kc positions get one more iteration, spread evenly
+        std::vector<std::pair<long long, long long>> order;
+        order.reserve((size_t)kc);
+        for (long long i = 0; i < kc; ++i) {
+            const long long tile = first_tile + i, w = tile % wg_runs, j = tile / wg_runs;
+            order.emplace_back((j * half + w % half) * 2 + w / half, i);
+        }
+        std::sort(order.begin(), order.end());
+        for (long long u = 0; u < kc; ++u)
+            if ((u + 1) * longs / kc > u * longs / kc) l[(size_t)order[(size_t)u].second] += quantum;
+        long long sum = 0;
+        for (size_t i = 0; i < l.size(); ++i) { if (i > 0) l[i] -= shrink; sum += l[i]; }
+        l.back() -= (int)(sum - T);          // the iterations cover whole quanta: the last run gives back what the clip does not have
+        if (l.back() <= 0) return false;
+        first_tile += kc;
+    }
+    lens.swap(out);
+    return true;
+}
+
 struct paa_plan {
     long long n_clips = 0;
     int sample_kind = 0;
@@ -230,9 +291,24 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     const int run = rr.run, run_quantum = rr.quantum, run_halo = rr.halo_inside;
     std::vector<Tile> tiles;
     tiles.reserve((size_t)(total_frames / run + n_clips));
+    std::vector<std::vector<int>> run_lens;
+#ifndef PAA_BALANCED_RUNS
+#define PAA_BALANCED_RUNS 1           // (0: A/B build of scripts/rounds/r05/gpu_r05w.sh -- equal runs, 250 workgroups for the one-hour clip)
+#endif
+    const bool balanced = PAA_BALANCED_RUNS && rr.fill_wg_runs > 0 && ranges <= 1 &&
+                          balanced_runs(p->clips, run, run_quantum, run_halo, rr.fill_wg_runs, g_num_cu, 16, run_lens);
     for (int64_t c = 0; c < n_clips; ++c) {
         const long long T = p->clips[c].T;
         if (T <= 0) continue;
+        if (balanced) {
+            long long t0 = 0;
+            for (int cnt : run_lens[(size_t)c]) {
+                Tile tl; tl.clip = (int)c; tl.t0 = (int)t0; tl.cnt = cnt; tl.pad = 0;
+                tiles.push_back(tl);
+                t0 += cnt;
+            }
+            continue;
+        }
         const int len = clip_run_length(T, run, run_quantum);          // equal runs per clip
         for (long long t0 = 0; t0 < T;) {
             const long long want = (t0 > 0) ? len - run_halo : len;

@@ -216,6 +216,42 @@ def test_run_length_choice_for_the_baseline_batches():
             assert wgs <= 256 and longest.value <= 256
 
 
+def test_balanced_runs_of_a_one_round_plan():
+    """A plan whose equal runs fill less than one round of the hot kernel (one workgroup per CU, eight runs each) is re-cut into
+    256 x 8 runs (csrc/lib_plan.hpp: balanced_runs): the lengths cover the clip exactly, runs after a clip's first store `shrink`
+    frames less (their halo rides inside the first quad), iteration counts differ by at most one, and the two waves that share a
+    SIMD (w and w + 4 of a workgroup) get a long and a short run where the ratio allows."""
+    def lens_of(frames, cap, shrink, wg_runs=8, num_cu=256, quantum=4, min_run=16):
+        arr = np.ascontiguousarray(frames, dtype=np.int64)
+        out = np.zeros(8192, dtype=np.int32)
+        n = _ffi.lib().paa_debug_balanced_runs(_ffi.as_i64p(arr), len(arr), cap, quantum, shrink, wg_runs, num_cu, min_run,
+                                               out.ctypes.data_as(_ffi.c_i32p), len(out))
+        assert n >= 0
+        return out[:n]
+    def cap_of(frames, shrink):
+        arr = np.ascontiguousarray(frames, dtype=np.int64)
+        cap, longest, runs = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
+        _ffi.check(_ffi.lib().paa_debug_run_plan_shrink(_ffi.as_i64p(arr), len(arr), 4, 16, 256, shrink, 8, 256,
+                                                        ctypes.byref(cap), ctypes.byref(runs), ctypes.byref(longest)))
+        return cap.value, runs.value
+    for shrink in (1, 2):
+        cap, equal_runs = cap_of([143999], shrink)                # config 2 (34 rows: one halo frame, 68 rows: two)
+        assert equal_runs < 2048
+        l = lens_of([143999], cap, shrink)                        # 2048 runs instead
+        assert len(l) == 2048 and int(l.sum()) == 143999
+        iters = (l + np.where(np.arange(len(l)) > 0, shrink, 0) + 3) // 4
+        assert iters[:-1].max() - iters[:-1].min() <= 1 and iters[-1] <= iters[:-1].max()
+        assert iters.max() == (18 if shrink == 1 else 19)       # (until round 5: 18 iterations + a halo quad for both)
+        pairs = iters[:-8].reshape(-1, 2, 4)                      # (workgroup, first / second wave of a SIMD, SIMD)
+        assert np.abs(pairs.sum(axis=1) - pairs.sum(axis=1).mean()).max() <= 1.0       # SIMD loads within one iteration
+        assert iters.reshape(-1, 8).sum(axis=1).max() - iters.reshape(-1, 8).sum(axis=1).min() <= 2
+    l = lens_of([40000, 60000, 43999], 72, 1)                     # three clips share the slots in proportion
+    assert len(l) <= 2048 and int(l.sum()) == 143999 and l.min() >= 16
+    assert len(lens_of([399] * 12500, 100, 1)) == 0               # many rounds: the equal runs stay
+    assert len(lens_of([2048 * 72], 72, 0)) == 0                  # already one full round
+    assert len(lens_of([20000], 72, 1)) == 0                      # too short for 2048 runs of 16 frames
+
+
 def test_result_pool_tracks_liveness_through_views_of_views():
     """_ffi.result_array hands out views of pooled storage; the storage is idle again only when the LAST view derived
     from the result is gone -- slices, reshapes and transposes of the result count (no reference-count heuristics)."""
