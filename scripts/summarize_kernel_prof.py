@@ -20,10 +20,10 @@ def main(prof_dir, out_path):
     like = {"st_reg_29x19": "%st_reg_kernel%", "spectrogram_reg_29x19": "%st_reg_kernel%", "chromagram_reg_29x19": "%st_reg_kernel%",
             "st_generic": "%st_generic_kernel%"}.get(stem, "%st_ct_kernel%" if "_ct_" in stem else
                                                     "%st_tri_kernel%" if "_tri_" in stem else "%" + stem + "%")
-    if line["case"] == "mid_stats":
-        like = "%mid_stats_kernel%"
     if stem.startswith("st_fast_800"):
         like = "%st_fast_800_kernel%"
+    if line["case"] == "mid_stats":
+        like = "%mid_stats_kernel%"
     second = None
     if "wg_lds_fft" in stem:                      # two kernels per step: the spectra of all frames, then their features
         like, second = "%wg_spectrum_kernel%", "%wg_feat_kernel%"
