@@ -59,3 +59,17 @@ if n > 0:
     for b in (0, 1, 100, 249):
         sl = slice(8 * b, 8 * b + 8) if "w8" in plan.kernel_name else slice(4 * b, 4 * b + 4)
         print("block", b, "life", np.round(life[sl], 0), "simd", simd[sl], "slot", slot[sl], "xcc", xcc[sl][:1])
+    # where the spread of the wave lives comes from: per XCD, per workgroup, per iteration count (round 5)
+    if "w8" in plan.kernel_name and nw % 8 == 0:
+        wg_life = life.reshape(-1, 8)
+        wg_end = ((t1 - base) / 100.0).reshape(-1, 8).max(axis=1)
+        wg_xcc = xcc.reshape(-1, 8)[:, 0].astype(int)
+        wg_cyc = cyc.reshape(-1, 8).mean(axis=1)
+        print("workgroup end us: min %.1f p10 %.1f median %.1f p90 %.1f max %.1f" % tuple(np.percentile(wg_end, [0, 10, 50, 90, 100])))
+        for xq in sorted(set(wg_xcc)):
+            m = wg_xcc == xq
+            print("xcc %d: %3d workgroups, end us mean %.1f min %.1f max %.1f | cycles/wave mean %.0f | clock %.3f GHz" % (
+                xq, m.sum(), wg_end[m].mean(), wg_end[m].min(), wg_end[m].max(), wg_cyc[m].mean(),
+                np.median((cyc.reshape(-1, 8)[m] / (wg_life[m] * 1e3)))))
+        order = np.argsort(wg_end)
+        print("slowest workgroups", order[-6:], "xcc", wg_xcc[order[-6:]], "fastest", order[:6], "xcc", wg_xcc[order[:6]])
