@@ -26,7 +26,7 @@ def main(rnd):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "%s_*_summary.json" % rnd))):
         d = json.load(open(f))
         r = d.get("run_under_trace")
-        if not r or "case" not in r:
+        if not r or "case" not in r or "kernel" not in r:
             continue
         tr = d.get("traffic", {})
         fmt = lambda v, s: (s % v) if v else "-"
@@ -36,6 +36,16 @@ def main(rnd):
         print("| %s | `%s` | %s | %.4f | %s | %s | %s |" % (r["case"], kernel, fmt(d.get("kernel_avg_us"), "%.1f"), r["ms_per_step"],
                                                      fmt(tr.get("traffic_over_algorithmic"), "%.2f"),
                                                      fmt(d.get("lds_bank_conflict_ratio"), "%.2f"), fmt(issue, "%.2f")))
+    aux = os.path.join(ROOT, "profiles", "%s_aux_kernels_summary.json" % rnd)
+    if os.path.exists(aux):
+        d = json.load(open(aux))
+        print()
+        print("| kernel (scripts/aux_kernels_loop.py, kernel trace only) | calls | mean (us) |")
+        print("|---|---|---|")
+        for k in d["kernel_trace_stats"]:
+            n = k["name"].split("(")[0].replace("void ", "").replace("paa::", "")
+            if any(t in n for t in ("beat_kernel", "big_", "chroma_tail", "expand_deltas", "svm_binary", "wg_delta")):
+                print("| `%s` | %d | %.1f |" % (n[:60], k["calls"], k["avg_us"]))
 
 
 if __name__ == "__main__":
