@@ -21,6 +21,7 @@ struct RunRule {
     int run = 64, quantum = 4, halo_inside = 0;
     int fill_wg_runs = 0;        // > 0: runs per workgroup of a kernel with ONE workgroup per CU -- a plan whose equal runs fill less than
                                  // one round of the chip is re-cut into num_cu x fill_wg_runs runs of two lengths (lib_plan.hpp: balanced_runs)
+    int fill_min_run = 16;       // ... none of them shorter than this
 };
 struct Family {
     const char *id;
@@ -126,6 +127,8 @@ static void fam_tri_rule(FamilyCtx &c, RunRule &r) {
     // one wave per run, one frame per iteration; a run with t0 > 0 recomputes 1 frame (2 with deltas) first
     r.quantum = 1;
     r.run = choose_run_cap(c.p->clips, 1, 8, 96, (c.mode == 0) ? (c.deltas ? 2 : 1) : 0, c.p->trl.waves, c.num_cu());
+    // (balanced runs -- RunRule::fill_wg_runs = trl.waves -- were A/B-ed here too, scripts/rounds/r05/gpu_r05ad.sh: 3072 runs of 19 / 20
+    // frames instead of 3000 of 20 for config 5 changed nothing beyond the noise, 0.3202 / 0.3184 ms: the equal runs stay)
 }
 static int fam_tri_launch(paa_plan *p, const void *d_packed, double *d_out, const Tile *tiles, long long n, hipStream_t s) {
     return launch::tri(p->trl, p->sample_kind, p->P, p->d_gen_blob, d_packed, p->d_clips, p->d_norms, tiles, n, d_out, s);

@@ -64,11 +64,11 @@ static inline int clip_run_length(long long T, int cap, int quantum) {
 // 72 frames = 250 workgroups of eight on 256 CUs, scripts/experiments/run_geometry.py: 256 workgroups take the same time).  Every
 // clip is re-cut into its share of num_cu x wg_runs runs whose ITERATION counts (quanta) differ by at most one; runs after a
 // clip's first hold `shrink` halo frames inside their first iteration, i.e. store that many frames less.  Along the order
-// (workgroup, SIMD, first / second wave of the SIMD) long and short runs alternate, so the two waves that share a SIMD (w and
-// w + wg_runs / 2) get a long and a short one where the ratio allows.  Returns false (lens untouched) when the equal runs stay.
+// (workgroup, SIMD, wave of the SIMD) long and short runs alternate, so the waves that share a SIMD (w, w + 4, ...) get long and
+// short ones in the plan's overall ratio.  Returns false (lens untouched) when the equal runs stay.
 static bool balanced_runs(const std::vector<ClipDev> &clips, int run, int quantum, int shrink, int wg_runs, int num_cu, int min_run,
                           std::vector<std::vector<int>> &lens) {
-    if (wg_runs < 2 || (wg_runs & 1) || quantum < 1 || shrink < 0 || shrink >= quantum) return false;
+    if (wg_runs < 2 || quantum < 1 || shrink < 0 || (shrink > 0 && shrink >= quantum)) return false;
     long long total = 0, runs = 0;
     std::vector<long long> need(clips.size(), 0);
     for (size_t c = 0; c < clips.size(); ++c) {
@@ -92,7 +92,8 @@ static bool balanced_runs(const std::vector<ClipDev> &clips, int run, int quantu
     }
     if (given > slots) return false;
     std::vector<std::vector<int>> out(clips.size());
-    const int half = wg_runs / 2;
+    // waves w, w + 4, w + 8 ... of a workgroup share a SIMD (profiles/r05_fast800_wave_trace.txt): per = waves per SIMD
+    const int per = (wg_runs % 4 == 0) ? wg_runs / 4 : 0;
     long long first_tile = 0;          // tile index of the clip's first run (runs of all clips are laid out consecutively)
     for (size_t c = 0; c < clips.size(); ++c) {
         const long long T = clips[c].T, kc = k[c];
@@ -106,7 +107,7 @@ static bool balanced_runs(const std::vector<ClipDev> &clips, int run, int quantu
         order.reserve((size_t)kc);
         for (long long i = 0; i < kc; ++i) {
             const long long tile = first_tile + i, w = tile % wg_runs, j = tile / wg_runs;
-            order.emplace_back((j * half + w % half) * 2 + w / half, i);
+            order.emplace_back(per ? (j * 4 + w % 4) * per + w / 4 : tile, i);
         }
         std::sort(order.begin(), order.end());
         for (long long u = 0; u < kc; ++u)
@@ -296,7 +297,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
 #define PAA_BALANCED_RUNS 1           // (0: A/B build of scripts/rounds/r05/gpu_r05w.sh -- equal runs, 250 workgroups for the one-hour clip)
 #endif
     const bool balanced = PAA_BALANCED_RUNS && rr.fill_wg_runs > 0 && ranges <= 1 &&
-                          balanced_runs(p->clips, run, run_quantum, run_halo, rr.fill_wg_runs, g_num_cu, 16, run_lens);
+                          balanced_runs(p->clips, run, run_quantum, run_halo, rr.fill_wg_runs, g_num_cu, rr.fill_min_run, run_lens);
     for (int64_t c = 0; c < n_clips; ++c) {
         const long long T = p->clips[c].T;
         if (T <= 0) continue;
@@ -785,7 +786,7 @@ extern "C" int paa_dev_expand_deltas(const double *d_base, const int64_t *frames
     hipStream_t s = comm_stream_or_null();
     if (s) { const int rc_o = comm_order_after_compute(s); if (rc_o) return rc_o; }
     else s = cs();
-    hipLaunchKernelGGL(expand_deltas_kernel, dim3((unsigned)dc.n_tiles), dim3(256), 0, s, dc.d_tiles, d_base, d_out);
+    hipLaunchKernelGGL(expand_deltas_kernel, dim3((unsigned)dc.n_tiles, (unsigned)kBase), dim3(256), 0, s, dc.d_tiles, d_base, d_out);
     HIP_TRY(hipGetLastError());
     return PAA_OK;
 }

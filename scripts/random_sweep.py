@@ -8,7 +8,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 import paa_oracle as O
 from pyaudioanalysis_amd import ShortTermFeatures, _ffi
 from synth import synth_clip
-from test_parity_gpu import assert_parity
+from test_parity_gpu import assert_parity, tight_violations
+import checks
 
 n, first = int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 0
 _ffi.lib(); _ffi.init(0)
@@ -16,16 +17,19 @@ kernels, bad = collections.Counter(), []
 for seed in range(first, first + n):
     rng = np.random.default_rng(50000 + seed)
     fs = int(rng.choice([8000, 11025, 12000, 16000, 22050, 24000, 32000, 44100, 48000, 96000]))
-    if rng.random() < 0.5:          # the windows people use: 20 / 25 / 30 / 40 / 50 / 64 ms, powers of two
+    u = rng.random()
+    if u < 0.45:          # the windows people use: 20 / 25 / 30 / 40 / 50 / 64 ms, powers of two
         window = int(rng.choice([int(fs * ms / 1000) for ms in (20, 25, 30, 40, 50, 64)] + [256, 512, 1024, 2048]))
-    else:
+    elif u < 0.85:
         window = int(rng.integers(max(200, fs // 60), fs // 12))
+    else:                 # big windows (round 5): 0.25 s .. 1.5 s -- workgroup-per-frame, split transforms, HBM passes
+        window = int(rng.choice([fs // 4, fs // 2, fs, fs + fs // 2, int(rng.integers(fs // 4, fs + fs // 2))]))
     if window / 2 < 12 * np.log2((fs / 2) / 27.5) + 2:
         window = int(fs // 20)
     step = int(rng.choice([window // 4, window // 2, window, int(rng.integers(window // 5, window + window // 4))]))
     kind = int(rng.integers(0, 3))
     deltas = bool(rng.integers(0, 2))
-    seconds = float(rng.choice([0.7, 1.3, 2.9]))
+    seconds = float(rng.choice([0.7, 1.3, 2.9])) + (2.0 * window / fs if window > fs // 8 else 0.0)
     xs = synth_clip(60000 + seed, int(fs * seconds) + window, fs=fs, stereo=True)
     mono = O.stereo_to_mono(xs)
     sig = xs[:, 0].copy() if kind == 0 else (mono if kind == 1 else xs)
@@ -45,7 +49,24 @@ for seed in range(first, first + n):
     plan.destroy()
     try:
         got, _ = ShortTermFeatures.feature_extraction(sig, fs, window, step, deltas)
-        assert_parity(got, ref, "seed %d" % seed, O.ill_conditioned_mfcc_frames(ref_in, fs, window, step))
+        info = checks.ill_info(ref_in, fs, window, step)
+        try:
+            assert_parity(got, ref, "seed %d" % seed, ill=info, sig=(ref_in, fs, window, step), max_other_share=0.02, max_other_abs=2)
+        except AssertionError:
+            # the one documented exception the tight gate bounds numerically: the spectral spread (rows 4 / 38) of a digitally silent
+            # frame is a function of the FFT's round-off in the reference itself; kernels without exact-zero codelets (lengths with a
+            # prime factor above 13: Stockham + one O(N p) pass) leave more noise there than 1e-7 x scale.  Such a shape passes here
+            # when the contract gate holds everywhere and every tight-gate entry is such a spread value below 1e-6 x scale
+            assert_parity(got, ref, "seed %d (contract)" % seed, ill=info, sig=(ref_in, fs, window, step), tight=False, max_other_share=0.02,
+                          max_other_abs=2)
+            nt, tb = tight_violations(got, ref, info.mask)
+            rows, cols = np.nonzero(tb)
+            near = info.silent.copy()
+            near[1:] |= info.silent[:-1]                                   # (flux / deltas of the frame after a silent one)
+            scale4 = np.abs(ref[4]).max()
+            if not (set(rows) <= {4, 38} and near[cols].all() and np.abs(got - ref)[tb].max() <= 1e-6 * scale4):
+                raise
+            kernels["spread-of-silence:" + kname] += 1
     except Exception as exc:
         bad.append((seed, kname, fs, window, step, kind, repr(exc)[:160]))
     if seed % 3 == 0:               # spectrogram / chromagram rows of the same clip (modes 1 / 2 of the same kernels)

@@ -245,6 +245,12 @@ def test_balanced_runs_of_a_one_round_plan():
         pairs = iters[:-8].reshape(-1, 2, 4)                      # (workgroup, first / second wave of a SIMD, SIMD)
         assert np.abs(pairs.sum(axis=1) - pairs.sum(axis=1).mean()).max() <= 1.0       # SIMD loads within one iteration
         assert iters.reshape(-1, 8).sum(axis=1).max() - iters.reshape(-1, 8).sum(axis=1).min() <= 2
+    # the same function for twelve waves per workgroup (three per SIMD), one frame per iteration, the halo outside the run (the shape of the
+    # three-pass family, where the A/B showed no gain and the equal runs stay)
+    l = lens_of([59998], 20, 0, wg_runs=12, quantum=1, min_run=8)             # config 5: 3072 runs of 19 / 20 instead of 3000 of 20
+    assert len(l) == 3072 and int(l.sum()) == 59998 and set(l[:-1]) <= {19, 20}
+    per_simd = l[:3072 - 12].reshape(-1, 3, 4).sum(axis=1)                    # (workgroup, wave of the SIMD, SIMD)
+    assert per_simd.max() - per_simd.min() <= 1
     l = lens_of([40000, 60000, 43999], 72, 1)                     # three clips share the slots in proportion
     assert len(l) <= 2048 and int(l.sum()) == 143999 and l.min() >= 16
     assert len(lens_of([399] * 12500, 100, 1)) == 0               # many rounds: the equal runs stay
