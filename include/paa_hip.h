@@ -256,6 +256,10 @@ int paa_debug_comm_marker_name(const void *unique_id, int rank, char *out, int c
  * table blob (spectrogram mode: no mel / chroma lists), which is copied to `blob` when that is not NULL.  Returns the blob
  * size, 0 when the window goes to another kernel                                                                     */
 int paa_debug_tri_plan(int window, double fs, int32_t *shape8, int32_t *offsets6, unsigned char *blob, int capacity);
+/* the 64 lane jobs {start, n, woff, ctl} the three-pass kernels cut the sums of n_owners <= 64 owners (40 mel filters / 12 pitch
+ * classes) into: owner k has cnt[k] consecutive entries from first[k] (weights from wfirst[k]); a job's ctl = position of the piece
+ * in its owner's run of lanes | (lanes k < n_owners: the lane that ends up with owner k's total) << 8 (csrc/kernels_tri.hpp)   */
+int paa_debug_lane_jobs(const int32_t *first, const int32_t *wfirst, const int32_t *cnt, int n_owners, int32_t *jobs256);
 /* mixed-radix kernel (csrc/kernels_mix.hpp): radix schedule of its in-place DIF transform and the position that holds
  * Z[k] afterwards (perm: fft_len entries); returns the number of passes, 0 when the window goes to another kernel   */
 int paa_debug_mix_plan(int window, int32_t *radices, int32_t *fft_len, uint16_t *perm, int perm_capacity,

@@ -133,6 +133,7 @@ struct TriLayout {
     int table_bytes;                // LDS part, multiple of 16
     int off_g_tw1;                  // global part: double2 [NQ1][L1]: W_N^(j q1)
     int off_g_post;                 // packed: double2 [64 NR3][R3]: W_W^(kA + N3 k3)
+    int off_g_meljob, off_g_chjob;  // int4 [64] each: the lane jobs of the mel sums / the chroma gather (LaneJob below)
     int total_bytes;
     double f0, rf0, r_half_fs, f0sq;                    // fs / W, its reciprocal, 2 / fs, f0^2 (host-computed: scalar registers)
 };
@@ -471,14 +472,120 @@ __device__ __forceinline__ void row_put(RowChunk &rc, double *row, int t, int lo
 }
 
 
+// ---- mel sums and chroma gather on all 64 lanes (round 5).  Until then lane m < 40 walked mel filter m (the widest filter set the
+// trip count: 8 % of the 1024 kernel) and lane c < 12 its pitch class (NF / 12 entries each: 3-6 %).  Now every OWNER (filter,
+// class) is cut into lane jobs of at most `m` consecutive entries on consecutive lanes of ONE 16-lane row (host: lane_jobs);
+// a lane sums its piece, a segmented scan inside the row (row_shr DPP, a lane adds its left neighbours of the same owner only)
+// leaves the owner's total in its last lane, and the owner's lane (lane m < 40 / lane c < 12) fetches it.  Deterministic order.
+struct LaneJob {
+    int start;        // mel: first bin; chroma: first entry of the gather list
+    int n;            // entries of this piece
+    int woff;         // mel: index of the first weight
+    int ctl;          // bits 0-3: position of the piece in its owner's run of lanes; bits 8-13: (owner lanes only) lane that ends up with the owner's total
+};
+// inclusive sum over the lanes [lane - head, lane] (all inside one 16-lane row)
+__device__ __forceinline__ double seg_row_scan(double v, int head) {
+    double t;
+    t = dpp_mov<0x111>(v); v += (head >= 1) ? t : 0.0;
+    // after step k a lane holds the sum of min(head, 2^k - 1) + 1 lanes ending at itself: the next step adds the partial sum 2^k lanes to
+    // the left when that lane belongs to the same owner (its own partial then covers exactly the missing lanes or stops at the owner's first)
+    t = dpp_mov<0x112>(v); v += (head >= 2) ? t : 0.0;
+    t = dpp_mov<0x114>(v); v += (head >= 4) ? t : 0.0;
+    t = dpp_mov<0x118>(v); v += (head >= 8) ? t : 0.0;
+    return v;
+}
+__device__ __forceinline__ double lane_fetch(double v, int src_lane) {
+    const int lo = __shfl(__double2loint(v), src_lane, 64), hi = __shfl(__double2hiint(v), src_lane, 64);
+    return __hiloint2double(hi, lo);
+}
+// mel band energies: returns (in lane m < 40) sum_k X[k] w_m[k]
+__device__ __forceinline__ double mel_sums_balanced(const Tabs &tb, const double *cur, const int4 job, int lane) {
+    const double *w = tb.mel_w + job.z;
+    const double *x = cur + job.x;
+    double a0 = 0.0, a1 = 0.0;
+    int i = 0;
+    for (; i + 4 <= job.y; i += 4) {
+        double xb[4], wb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { xb[u] = x[i + u]; wb[u] = w[i + u]; }
+        a0 = fma(xb[0], wb[0], a0); a1 = fma(xb[1], wb[1], a1);
+        a0 = fma(xb[2], wb[2], a0); a1 = fma(xb[3], wb[3], a1);
+    }
+    for (; i < job.y; ++i) a0 = fma(x[i], w[i], a0);
+    const double tot = seg_row_scan(a0 + a1, job.w & 15);
+    return lane_fetch(tot, (job.w >> 8) & 63);
+}
+// chroma numerators: returns (in lane c < 12) sum over the class's entries of X[src]^2 w
+__device__ __forceinline__ double chroma_sums_balanced(const Tabs &tb, const double *cur, const int4 job, int lane) {
+    const int *src = tb.ch_src + job.x;
+    const double *w = tb.ch_w + job.x;
+    double a0 = 0.0, a1 = 0.0;
+    int i = 0;
+    for (; i + 4 <= job.y; i += 4) {
+        int sb[4];
+        double xb[4], wb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sb[u] = src[i + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { xb[u] = cur[sb[u]]; wb[u] = w[i + u]; }
+        a0 = fma(xb[0] * xb[0], wb[0], a0); a1 = fma(xb[1] * xb[1], wb[1], a1);
+        a0 = fma(xb[2] * xb[2], wb[2], a0); a1 = fma(xb[3] * xb[3], wb[3], a1);
+    }
+    for (; i < job.y; ++i) { const double xv = cur[src[i]]; a0 = fma(xv * xv, w[i], a0); }
+    const double tot = seg_row_scan(a0 + a1, job.w & 15);
+    return lane_fetch(tot, (job.w >> 8) & 63);
+}
+// host: cut K owners with cnt[k] entries starting at first[k] (weights at wfirst[k]) into 64 lane jobs.  The smallest piece
+// length m for which every owner's ceil(cnt / m) <= 16 lanes fit, unsplit, into the four 16-lane rows (first fit, longest first).
+inline void lane_jobs(int K, const int *first, const int *wfirst, const int *cnt, LaneJob *jobs) {
+    int best_m = 0;
+    std::vector<int> row_of((size_t)K, 0), pos_of((size_t)K, 0), lanes((size_t)K, 1);
+    int max_cnt = 1;
+    for (int k = 0; k < K; ++k) max_cnt = std::max(max_cnt, cnt[k]);
+    for (int m = 1; m <= max_cnt; ++m) {
+        std::vector<int> order((size_t)K);
+        bool ok = true;
+        for (int k = 0; k < K; ++k) {
+            order[(size_t)k] = k;
+            lanes[(size_t)k] = std::max(1, (cnt[k] + m - 1) / m);
+            ok = ok && lanes[(size_t)k] <= 16;
+        }
+        if (!ok) continue;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lanes[(size_t)a] > lanes[(size_t)b]; });
+        int used[4] = {0, 0, 0, 0};
+        for (int k : order) {
+            int r = 0;
+            while (r < 4 && used[r] + lanes[(size_t)k] > 16) ++r;
+            if (r == 4) { ok = false; break; }
+            row_of[(size_t)k] = r; pos_of[(size_t)k] = used[r];
+            used[r] += lanes[(size_t)k];
+        }
+        if (ok) { best_m = m; break; }
+    }
+    for (int l = 0; l < 64; ++l) jobs[l] = LaneJob{0, 0, 0, 0};
+    if (!best_m) return;          // (cannot happen for K <= 64: m = max_cnt gives one lane per owner)
+    for (int k = 0; k < K; ++k) {
+        const int nl = lanes[(size_t)k], l0 = 16 * row_of[(size_t)k] + pos_of[(size_t)k];
+        int done = 0;
+        for (int i = 0; i < nl; ++i) {
+            const int n = (cnt[k] - done + (nl - i) - 1) / (nl - i);          // nearly equal pieces, the longer ones first
+            LaneJob &j = jobs[l0 + i];
+            j.start = first[k] + done; j.woff = wfirst[k] + done; j.n = n; j.ctl = (j.ctl & ~15) | i;
+            done += n;
+        }
+        jobs[k].ctl = (jobs[k].ctl & 0xff) | ((l0 + nl - 1) << 8);          // owner k is read by lane k
+    }
+}
+
 // ---- the 34 base features of one frame into fv[0..33] (ShortTermFeatures.py:626-667): all 64 lanes on one spectrum,
 // lane i owns bins [C i, C i + C) in registers for both sweeps; spectral-entropy blocks from the cumulative energy at the
 // block boundaries (kernels_ct.hpp's scheme with 64-lane scans)
 template <typename SH>
 __device__ __forceinline__ void tri_features(const TriLayout &L, const Tabs &tb, const TimeFeat &tf, const double *cur,
                                              const double *prv, bool first_frame, double *fv, double *msp, double *bnd,
-                                             int lane) {
+                                             const int4 *g_meljob, const int4 *g_chjob, int lane) {
     constexpr int NF = SH::NF, C = SH::C, LB = SH::LB, W = SH::W;
+    const int4 mjob = g_meljob[lane], cjob = g_chjob[lane];          // (L2; used after the two sweeps)
     const double f0 = L.f0, rf0 = L.rf0, r_half_fs = L.r_half_fs, f0sq = L.f0sq;
     const int kb = C * lane;
     double Xc[C], Xv[C];
@@ -565,9 +672,25 @@ __device__ __forceinline__ void tri_features(const TriLayout &L, const Tabs &tb,
     sFl = wsum(sFl);
     const double spread = fast_sqrt(sSp * rden);
     const int first = mix::wmin_nonneg_i((below < C) ? kb + below : 0x7fffffff);
-    // MFCC (:236-254): lane m < 40 = mel filter m (sparse list), log10, then the 13 x 40 DCT on 52 lanes
+    // MFCC (:236-254): mel band energies on all 64 lanes (mel_sums_balanced), log10 in lane m < 40, then the 13 x 40 DCT on 52 lanes
+#ifndef PAA_TRI_ABLATE
+#define PAA_TRI_ABLATE 0          // timing builds of scripts/rounds/r05 only: 1 = no mel sums, 2 = no chroma gather
+#endif
+#ifndef PAA_TRI_LANE_JOBS
+#define PAA_TRI_LANE_JOBS 1       // 0: A/B build of scripts/rounds/r05/gpu_r05ai.sh -- lane m < 40 walks mel filter m, lane c < 12 its pitch class
+#endif
+#if PAA_TRI_LANE_JOBS
+    {
+        const double e = (PAA_TRI_ABLATE & 1) ? 0.0 : mel_sums_balanced(tb, cur, mjob, lane);
+        if (lane < 40) msp[lane] = fast_log10(e + kEps);
+    }
+    // chroma (:277-321)
+    double chroma = (PAA_TRI_ABLATE & 2) ? 0.0 : chroma_sums_balanced(tb, cur, cjob, lane);
+    chroma = (sP == 0.0) ? chroma / kEps : fast_div(chroma, sP);
+#else
+    (void)mjob; (void)cjob;
     if (lane < 40) {
-        const int lo = tb.mel_lo[lane], cnt = tb.mel_cnt[lane];
+        const int lo = tb.mel_lo[lane], cnt = (PAA_TRI_ABLATE & 1) ? 0 : tb.mel_cnt[lane];
         const double *w = tb.mel_w + tb.mel_off[lane];
         double a0 = 0.0, a1 = 0.0;
         int i = 0;
@@ -585,8 +708,8 @@ __device__ __forceinline__ void tri_features(const TriLayout &L, const Tabs &tb,
         if (i < cnt) a0 = fma(cur[lo + i], w[i], a0);
         msp[lane] = fast_log10((a0 + a1) + kEps);
     }
-    // chroma (:277-321)
-    const double chroma = mix::chroma_class_batched(tb, cur, sP, lane);
+    const double chroma = (PAA_TRI_ABLATE & 2) ? 0.0 : mix::chroma_class_batched(tb, cur, sP, lane);
+#endif
     wsync();
     {
         // lane 4 q + part: ten terms of DCT row q; the four parts meet through two quad permutes
@@ -661,6 +784,7 @@ __global__ __launch_bounds__(64 * (MODE == 0 ? SH::NW : SH::NWR), ((MODE == 0 ? 
     const uint4 *t_p3 = reinterpret_cast<const uint4 *>(smem + L.off_p3);
     const double2 *g_tw1 = reinterpret_cast<const double2 *>(blob + L.off_g_tw1);
     const double2 *g_post = reinterpret_cast<const double2 *>(blob + L.off_g_post);
+    const int4 *g_meljob = reinterpret_cast<const int4 *>(blob + L.off_g_meljob), *g_chjob = reinterpret_cast<const int4 *>(blob + L.off_g_chjob);
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tile_id = blockIdx.x * NW + wave;
@@ -1302,10 +1426,15 @@ __global__ __launch_bounds__(64 * (MODE == 0 ? SH::NW : SH::NWR), ((MODE == 0 ? 
             double p = 0.0;
             for (int k = lane; k < NF; k += kWave) { const double X = cur[k]; p = fma(X, X, p); }
             p = wsum(p);
+#if PAA_TRI_LANE_JOBS
+            double chv = chroma_sums_balanced(tb, cur, g_chjob[lane], lane);
+            chv = (p == 0.0) ? chv / kEps : fast_div(chv, p);
+#else
             const double chv = chroma_class(tb, cur, p, lane);
+#endif
             if (lane < 12) oc[(long long)t * 12 + lane] = chv;
         } else if (want) {
-            tri_features<SH>(L, tb, tf, cur, (t == 0) ? cur : prv, t == 0, fv, msp, bnd, lane);
+            tri_features<SH>(L, tb, tf, cur, (t == 0) ? cur : prv, t == 0, fv, msp, bnd, g_meljob, g_chjob, lane);
             PAA_TICK(7)
             const double v = (lane < kBase) ? fv[lane] : 0.0;
             if (t >= tl.t0 && lane < kBase) {
@@ -1401,6 +1530,8 @@ inline void tri_fill(double fs, int mode, const MelTable *mel, const ChromaTable
     L.table_bytes = off;
     L.off_g_tw1 = take((size_t)NQ1 * L1 * 16);
     L.off_g_post = take(SH::PACKED ? (size_t)64 * NR3 * R3 * 16 : 16);
+    L.off_g_meljob = take(64 * 16);
+    L.off_g_chjob = take(64 * 16);
     L.total_bytes = off;
     L.f0 = fs / (2.0 * (double)SH::NF);
     L.rf0 = 1.0 / L.f0;
@@ -1523,7 +1654,12 @@ inline void tri_fill(double fs, int mode, const MelTable *mel, const ChromaTable
         memcpy(b + L.off_chstart, chroma->class_start, 13 * 4);
         memcpy(b + L.off_chsrc, chroma->src.data(), n_ch * 4);
         memcpy(b + L.off_chw, chroma->w.data(), n_ch * 8);
+        int first[12], cnt[12];
+        for (int c = 0; c < 12; ++c) { first[c] = chroma->class_start[c]; cnt[c] = chroma->class_start[c + 1] - chroma->class_start[c]; }
+        lane_jobs(12, first, first, cnt, reinterpret_cast<LaneJob *>(b + L.off_g_chjob));
     }
+    if (mel && !mel->w.empty())
+        lane_jobs(40, mel->lo.data(), mel->off.data(), mel->cnt.data(), reinterpret_cast<LaneJob *>(b + L.off_g_meljob));
     // as many waves as the shape allows and the LDS holds beside this (fs, window)'s table blob (longer mel lists at low rates)
     tl.waves = (mode == 0) ? SH::NW : SH::NWR;
     const size_t wave_bytes = (size_t)(mode == 0 ? SH::WAVE_DOUBLES : SH::WAVE_DOUBLES_ROWS) * 8;

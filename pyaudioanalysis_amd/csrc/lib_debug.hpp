@@ -112,6 +112,15 @@ extern "C" int paa_debug_run_plan_shrink(const int64_t *frames, int64_t n_clips,
     *run_cap = cap; *n_runs = runs; *longest = lmax;
     return PAA_OK;
 }
+// the lane jobs the three-pass kernels cut the mel sums (K = 40 filters) and the chroma gather (K = 12 classes) into
+// (kernels_tri.hpp: lane_jobs): jobs256 = 64 x {start, n, woff, ctl}
+extern "C" int paa_debug_lane_jobs(const int32_t *first, const int32_t *wfirst, const int32_t *cnt, int n_owners, int32_t *jobs256) {
+    if (!first || !wfirst || !cnt || !jobs256 || n_owners < 1 || n_owners > 64) return fail(PAA_ERR_ARG, "bad argument");
+    for (int k = 0; k < n_owners; ++k)
+        if (cnt[k] < 0) return fail(PAA_ERR_ARG, "negative count");
+    tri::lane_jobs(n_owners, first, wfirst, cnt, reinterpret_cast<tri::LaneJob *>(jobs256));
+    return PAA_OK;
+}
 // the run lengths paa_plan_create gives a plan that fills less than one round of a one-workgroup-per-CU kernel (lib_plan.hpp:
 // balanced_runs).  Returns the number of runs written to `lens` (clip after clip), 0 when the equal runs stay, < 0 on error.
 extern "C" int64_t paa_debug_balanced_runs(const int64_t *frames, int64_t n_clips, int run_cap, int quantum, int shrink, int wg_runs,

@@ -216,6 +216,40 @@ def test_run_length_choice_for_the_baseline_batches():
             assert wgs <= 256 and longest.value <= 256
 
 
+def test_lane_jobs_cover_every_owner_once_inside_one_row():
+    """csrc/kernels_tri.hpp: lane_jobs -- the mel sums (40 filters) and the chroma gather (12 classes) of the three-pass kernels run on
+    all 64 lanes: every owner's entries are cut into consecutive pieces on consecutive lanes of ONE 16-lane row (the segmented scan is a
+    row_shr DPP scan), piece i of an owner carries i in its control word, and lane k carries the lane that ends up with owner k's total."""
+    rng = np.random.default_rng(12)
+    cases = [(40, rng.integers(0, 60, 40)) for _ in range(30)] + [(12, rng.integers(20, 120, 12)) for _ in range(30)]
+    cases += [(40, np.arange(2, 42)), (40, np.full(40, 1)), (12, np.full(12, 46)), (12, np.array([0] * 11 + [700])), (40, np.zeros(40, dtype=np.int64))]
+    for K, cnt in cases:
+        cnt = np.ascontiguousarray(cnt, dtype=np.int32)
+        first = np.ascontiguousarray(np.concatenate(([0], np.cumsum(cnt)[:-1])) + 5, dtype=np.int32)
+        wfirst = np.ascontiguousarray(first * 3 + 1, dtype=np.int32)
+        jobs = np.zeros(256, dtype=np.int32)
+        _ffi.check(_ffi.lib().paa_debug_lane_jobs(first.ctypes.data_as(_ffi.c_i32p), wfirst.ctypes.data_as(_ffi.c_i32p),
+                                                  cnt.ctypes.data_as(_ffi.c_i32p), K, jobs.ctypes.data_as(_ffi.c_i32p)))
+        j = jobs.reshape(64, 4)
+        seen = np.zeros(int(cnt.sum()) + 5, dtype=np.int32)
+        for k in range(K):
+            last = (j[k, 3] >> 8) & 63
+            lanes = [last]
+            while j[lanes[0], 3] & 15:                                  # walk back to the owner's first piece
+                lanes.insert(0, lanes[0] - 1)
+            assert len(lanes) <= 16 and lanes[0] // 16 == lanes[-1] // 16           # one row
+            assert [int(j[l, 3] & 15) for l in lanes] == list(range(len(lanes)))
+            pos = int(first[k])
+            for l in lanes:
+                assert j[l, 0] == pos and j[l, 2] == wfirst[k] + (pos - first[k]) and j[l, 1] >= 0
+                seen[pos:pos + j[l, 1]] += 1
+                pos += int(j[l, 1])
+            assert pos == first[k] + cnt[k]
+            sizes = [int(j[l, 1]) for l in lanes]
+            assert max(sizes) - min(sizes) <= 1
+        assert np.all(seen[5:] == 1) and j[:, 1].sum() == cnt.sum()
+
+
 def test_balanced_runs_of_a_one_round_plan():
     """A plan whose equal runs fill less than one round of the hot kernel (one workgroup per CU, eight runs each) is re-cut into
     256 x 8 runs (csrc/lib_plan.hpp: balanced_runs): the lengths cover the clip exactly, runs after a clip's first store `shrink`
