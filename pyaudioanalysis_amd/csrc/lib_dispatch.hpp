@@ -80,6 +80,7 @@ static void fam_ct_rule(FamilyCtx &c, RunRule &r) {
     r.quantum = 4;
     r.halo_inside = (c.mode == 0) ? (c.deltas ? 2 : 1) : 0;
     r.run = choose_run_cap(c.p->clips, 4, 16, 256, 0, c.p->cl.waves, c.num_cu(), r.halo_inside);
+    r.fill_wg_runs = c.p->cl.waves;          // (one workgroup per CU; A/B scripts/rounds/r05/gpu_r05aj.sh: -0.4 ... -2.0 % on the feature shapes)
 }
 static int fam_ct_launch(paa_plan *p, const void *d_packed, double *d_out, const Tile *tiles, long long n, hipStream_t s) {
     return launch::ct(p->cl, p->sample_kind, p->P, p->d_gen_blob, d_packed, p->d_clips, p->d_norms, tiles, n, d_out, s);

@@ -5,7 +5,11 @@
 // ------------------------------------------------------------------------------------------
 // plans
 // ------------------------------------------------------------------------------------------
-constexpr int kStatChunk = 65536;          // samples per statistics workgroup (upper bound, see stat_chunk_for)
+#ifndef PAA_STAT_CHUNK
+#define PAA_STAT_CHUNK 65536          // (A/B build of scripts/rounds/r05/gpu_r05aj.sh: 131072 -- two workgroups per CU for the one-hour clip instead of
+                                      // four -- left the pass at 20.4 us)
+#endif
+constexpr int kStatChunk = PAA_STAT_CHUNK;          // samples per statistics workgroup (upper bound, see stat_chunk_for)
 // The statistics pass is an HBM-bound stream with every workgroup resident at once (8 per CU): 879 chunks of a one-hour
 // clip put 4 workgroups on some CUs and 3 on others, and the pass lasts as long as the CUs with 4.  A batch of at least one
 // chunk per CU is therefore cut into a whole multiple of num_cu chunks (1024 x 56 256 samples for the hour).
