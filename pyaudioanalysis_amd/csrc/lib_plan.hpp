@@ -6,13 +6,14 @@
 // plans
 // ------------------------------------------------------------------------------------------
 #ifndef PAA_STAT_CHUNK
-#define PAA_STAT_CHUNK 65536          // (A/B build of scripts/rounds/r05/gpu_r05aj.sh: 131072 -- two workgroups per CU for the one-hour clip instead of
-                                      // four -- left the pass at 20.4 us)
+#define PAA_STAT_CHUNK 131072         // (A/B of scripts/rounds/r05/gpu_r05aj.sh against 65536: two workgroups per CU for the one-hour clip instead of
+                                      // four leave the pass at 20.4 us and halve the partials every wave of the feature kernel folds
+                                      // in its prologue: 259.9 -> 258.5 us.  int32 partial sums: 512 samples of |v| < 2^16 per thread)
 #endif
 constexpr int kStatChunk = PAA_STAT_CHUNK;          // samples per statistics workgroup (upper bound, see stat_chunk_for)
-// The statistics pass is an HBM-bound stream with every workgroup resident at once (8 per CU): 879 chunks of a one-hour
-// clip put 4 workgroups on some CUs and 3 on others, and the pass lasts as long as the CUs with 4.  A batch of at least one
-// chunk per CU is therefore cut into a whole multiple of num_cu chunks (1024 x 56 256 samples for the hour).
+// The statistics pass is an HBM-bound stream with every workgroup resident at once (8 per CU): 879 chunks of 64 K samples of a
+// one-hour clip put 4 workgroups on some CUs and 3 on others, and the pass lasts as long as the CUs with 4.  A batch of at least
+// one chunk per CU is therefore cut into a whole multiple of num_cu chunks (512 x 112 512 samples for the hour).
 static int stat_chunk_for(long long total_samples, int num_cu) {
     const long long blocks = (total_samples + kStatChunk - 1) / kStatChunk;
     if (blocks < num_cu) {
