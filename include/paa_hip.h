@@ -256,6 +256,11 @@ int paa_debug_comm_marker_name(const void *unique_id, int rank, char *out, int c
  * table blob (spectrogram mode: no mel / chroma lists), which is copied to `blob` when that is not NULL.  Returns the blob
  * size, 0 when the window goes to another kernel                                                                     */
 int paa_debug_tri_plan(int window, double fs, int32_t *shape8, int32_t *offsets6, unsigned char *blob, int capacity);
+/* workgroup-per-frame kernels (csrc/kernels_wg.hpp), host only: info32[48] = {complex points, bins, passes, r0 (0: whole transform in one
+ * workgroup's LDS, else r0 sub-transforms whose first pass runs from the samples), elements per (sub-)transform, elements between pad
+ * slots, threads, LDS bytes, permutation in LDS, feature kernel stages the row, its LDS bytes, then (radix, span, twiddle stride) per
+ * pass}; perm[k] = padded LDS position of output k of the (sub-)transform.  Returns 1, 0 when the window goes to another path        */
+int paa_debug_wg_plan(int window, int32_t *info32, uint16_t *perm, int perm_capacity);
 /* the 64 lane jobs {start, n, woff, ctl} the three-pass kernels cut the sums of n_owners <= 64 owners (40 mel filters / 12 pitch
  * classes) into: owner k has cnt[k] consecutive entries from first[k] (weights from wfirst[k]); a job's ctl = position of the piece
  * in its owner's run of lanes | (lanes k < n_owners: the lane that ends up with owner k's total) << 8 (csrc/kernels_tri.hpp)   */

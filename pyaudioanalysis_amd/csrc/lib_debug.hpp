@@ -160,6 +160,29 @@ extern "C" int paa_debug_mix_plan(int window, int32_t *radices, int32_t *fft_len
     if (tw_global) *tw_global = L.tw_global;
     return L.n_pass;
 }
+// host side of the workgroup-per-frame kernels (kernels_wg.hpp) for a window, no device needed.  info32: {0: complex points Nc,
+// 1: bins Nf, 2: passes, 3: r0 (0: the whole transform in LDS; > 0: split into r0 sub-transforms), 4: elements per (sub-)transform,
+// 5: top (elements between pad slots), 6: threads of the spectrum kernel, 7: its LDS bytes, 8: permutation in LDS, 9: feature
+// kernel stages the row, 10: its LDS bytes, 11 ...: per pass radix, span, twiddle stride (three ints each)}; perm: the padded LDS
+// position of output k of the (sub-)transform.  Returns 1, or 0 when the window is not for these kernels.
+extern "C" int paa_debug_wg_plan(int window, int32_t *info32, uint16_t *perm, int perm_capacity) {
+    if (window < 2 || !info32) return fail(PAA_ERR_ARG, "bad argument");
+    FftPlan p;
+    build_fft_plan(window, p);
+    wg::WgLayout L;
+    std::vector<unsigned short> pm;
+    if (!wg::wg_layout(p, L, pm)) return 0;
+    memset(info32, 0, 48 * sizeof(int32_t));
+    info32[0] = p.len; info32[1] = window / 2; info32[2] = L.n_pass; info32[3] = L.r0; info32[4] = L.r0 ? L.sub : p.len;
+    info32[5] = L.top; info32[6] = L.threads; info32[7] = L.lds_bytes; info32[8] = L.perm_lds; info32[9] = L.feat_staged;
+    info32[10] = L.feat_lds_bytes;
+    for (int i = 0; i < L.n_pass && i < 12; ++i) { info32[11 + 3 * i] = L.radix[i]; info32[12 + 3 * i] = L.span[i]; info32[13 + 3 * i] = L.tws[i]; }
+    if (perm) {
+        if (perm_capacity < info32[4]) return fail(PAA_ERR_ARG, "perm capacity %d < %d", perm_capacity, info32[4]);
+        memcpy(perm, pm.data(), (size_t)info32[4] * 2);
+    }
+    return 1;
+}
 extern "C" int paa_debug_fft_plan(int window, int32_t *radices, int32_t *fft_len) {
     if (window < 2 || !radices || !fft_len) return fail(PAA_ERR_ARG, "bad argument");
     FftPlan p;

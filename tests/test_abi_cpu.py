@@ -216,6 +216,107 @@ def test_run_length_choice_for_the_baseline_batches():
             assert wgs <= 256 and longest.value <= 256
 
 
+@pytest.mark.parametrize("window", [16000, 8000, 9009, 44100, 48000, 11025, 22050, 32000, 65536])
+def test_workgroup_fft_plan_reproduces_the_spectrum(window):
+    """Host side of csrc/kernels_wg.hpp (no device): the in-place decimation-in-frequency passes, the padded LDS layout and the
+    digit-reversal permutation -- and, for sequences beyond one CU's LDS, the first radix-r0 pass straight from the samples with the
+    pairing of sub-transform q with r0 - q -- restated in NumPy FROM THE LIBRARY'S OWN PLAN give |fft(frame)|[0:W/2] / (W/2), every bin
+    written exactly once (ShortTermFeatures.py:617-621).  The kernels execute exactly this index algebra."""
+    lib = _ffi.lib()
+    info = np.zeros(48, dtype=np.int32)
+    assert lib.paa_debug_wg_plan(window, info.ctypes.data_as(_ffi.c_i32p), None, 0) == 1
+    Nc, Nf, n_pass, r0, n_el, top = (int(v) for v in info[:6])
+    perm = np.zeros(n_el, dtype=np.uint16)
+    assert lib.paa_debug_wg_plan(window, info.ctypes.data_as(_ffi.c_i32p), perm.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), n_el) == 1
+    passes = [tuple(int(v) for v in info[11 + 3 * i:14 + 3 * i]) for i in range(n_pass)]
+    packed = window % 2 == 0
+    assert Nc == (window // 2 if packed else window) and Nf == window // 2
+    assert int(np.prod([p[0] for p in passes])) == n_el and (r0 == 0 or r0 * n_el == Nc) and int(info[7]) <= 160 * 1024
+    for (R, M, tws) in passes:
+        assert tws * M == Nc                                   # twiddle W_M^j = W_Nc^(j tws): one table for every pass
+    rng = np.random.default_rng(window)
+    x = rng.standard_normal(window)
+    z = (x[0::2] + 1j * x[1::2]) if packed else x.astype(np.complex128)
+    W = np.exp(-2j * np.pi * np.arange(Nc) / Nc)               # the twiddle table P.tw
+    pad = lambda e: e + e // top                                # element e of a (sub-)transform sits at e + e / top
+    pitch = n_el + passes[0][0]
+
+    def run_passes(buf, n_sub):
+        """wg_run_passes: butterfly b of a pass works on base + r stride, output q times W_M^(q k) goes back to base + q stride"""
+        for (R, M, tws) in passes:
+            stride = M // R
+            F = np.exp(-2j * np.pi * np.outer(np.arange(R), np.arange(R)) / R)
+            for sub in range(n_sub):
+                b = np.arange(n_el // R)
+                blk, k = b // stride, b % stride
+                e0 = blk * M + k
+                idx = sub * pitch + pad(e0[:, None] + np.arange(R)[None, :] * stride)
+                v = buf[idx] @ F.T
+                v *= W[(np.arange(R)[None, :] * (k[:, None] * tws)) % Nc]
+                buf[idx] = v
+        return buf
+
+    ref = np.abs(np.fft.fft(x))[:Nf] / Nf
+    row = np.full(Nf, np.nan)
+    writes = np.zeros(Nf, dtype=np.int32)
+    post = np.exp(-2j * np.pi * np.arange(Nc // 2 + 1) / (2 * Nc)) if packed else None      # P.post: w^k of the real-FFT recombination
+
+    def put(k, v):
+        row[k] = v
+        writes[k] += 1
+
+    def pair(lo, zl, zh):
+        e = 0.5 * (zl + np.conj(zh))
+        o = -0.5j * (zl - np.conj(zh))
+        wo = post[lo] * o
+        put(lo, abs(e + wo) / Nf)
+        if lo > 0 and Nc - lo != lo:
+            put(Nc - lo, abs(np.conj(e - wo)) / Nf)
+
+    if r0 == 0:
+        buf = np.zeros(Nc + passes[0][0] + 8, dtype=np.complex128)
+        buf[pad(np.arange(Nc))] = z
+        run_passes(buf, 1)
+        Z = buf[perm.astype(np.int64)]
+        assert np.allclose(Z, np.fft.fft(z), atol=1e-9 * np.abs(z).sum())
+        if packed:
+            for k in range(Nc // 2 + 1):
+                pair(k, Z[k], Z[0 if k == 0 else Nc - k])
+        else:
+            for k in range(Nf):
+                put(k, abs(Z[k]) / Nf)
+    else:
+        S = n_el
+        for qa in range(r0 // 2 + 1):
+            qb = 0 if qa == 0 else r0 - qa
+            two = qb != qa
+            buf = np.zeros(2 * pitch + 8, dtype=np.complex128)
+            k = np.arange(S)
+            zr = z[k[None, :] + np.arange(r0)[:, None] * S]                              # z[k + r S]
+            cv = W[((np.arange(r0) * qa) % r0) * S]                                      # W_r0^(r qa)
+            buf[pad(k)] = (zr * cv[:, None]).sum(axis=0) * W[(qa * k) % Nc]
+            if two:
+                buf[pitch + pad(k)] = (zr * np.conj(cv)[:, None]).sum(axis=0) * W[(qb * k) % Nc]
+            run_passes(buf, 2 if two else 1)
+            A = buf[perm.astype(np.int64)]
+            B = buf[pitch + perm.astype(np.int64)] if two else A
+            if packed:
+                n_k = S if two else (S // 2 + 1 if qa == 0 else (S + 1) // 2)
+                for ka in range(n_k):
+                    kb = (0 if ka == 0 else S - ka) if qa == 0 else S - 1 - ka
+                    kk = qa + r0 * ka
+                    flip = 2 * kk > Nc
+                    lo = Nc - kk if flip else kk
+                    pair(lo, B[kb] if flip else A[ka], A[ka] if flip else B[kb])
+            else:
+                for q, buf_q in ((qa, A),) + (((qb, B),) if two else ()):
+                    for ka in range(S):
+                        if q + r0 * ka < Nf:
+                            put(q + r0 * ka, abs(buf_q[ka]) / Nf)
+    assert np.all(writes == 1)
+    assert np.allclose(row, ref, rtol=1e-9, atol=1e-11)
+
+
 def test_lane_jobs_cover_every_owner_once_inside_one_row():
     """csrc/kernels_tri.hpp: lane_jobs -- the mel sums (40 filters) and the chroma gather (12 classes) of the three-pass kernels run on
     all 64 lanes: every owner's entries are cut into consecutive pieces on consecutive lanes of ONE 16-lane row (the segmented scan is a
