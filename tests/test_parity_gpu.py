@@ -344,6 +344,14 @@ def test_delta_rows_reformed_on_the_device_equal_the_68_row_plan(gpu_lib):
         p68.destroy()
 
 
+def test_driver_smoke_entry(gpu_lib, capsys):
+    """__graft_entry__.smoke() -- what the driver runs before the bench: one short- + mid-term extraction against both oracles."""
+    import importlib
+    smoke = importlib.import_module("__graft_entry__").smoke
+    smoke()
+    assert "smoke ok" in capsys.readouterr().out
+
+
 def test_big_window_kernel_choice(gpu_lib):
     """Windows beyond the one-wave kernels: the transform runs in ONE WORKGROUP's LDS when it fits (kernels_wg.hpp: up to 10 000
     complex points made of 2, 3, 5, 7, 11, 13); longer ones (up to 32 768 points) as r0 <= 8 sub-transforms whose first pass runs
