@@ -121,7 +121,11 @@ __device__ __forceinline__ void wg_dif_batch(double2 *buf, int nb, int stride, i
 template <int R, int NT>
 __device__ __forceinline__ void wg_dif_pass(double2 *buf, int Nc, int M, int tws, unsigned magic, unsigned magic_top, bool first,
                                             const Tw2 &tw, int tid) {
-    constexpr int U = (NT <= 768 && R <= (NT == 512 ? 8 : 5)) ? 2 : 1;          // two butterflies in flight per lane where the registers allow it
+#ifndef PAA_WG_U8
+#define PAA_WG_U8 0               // 1: A/B build of scripts/rounds/r05/gpu_r05ao.sh -- two radix-8 butterflies in flight per lane in the 768-thread
+                                  // instance too (153 registers): 1.5-5 % SLOWER at 16 000 / 8 000, and wg_split_kernel spills
+#endif
+    constexpr int U = (NT <= 768 && R <= ((NT == 512 || PAA_WG_U8) ? 8 : 5)) ? 2 : 1;          // two butterflies in flight per lane where the registers allow it
     const int stride = M / R, nb = Nc / R;
     // (wave-uniform trip count: a wave whose first butterfly exists runs the batch)
     if (first) {
