@@ -388,6 +388,29 @@ def test_balanced_runs_of_a_one_round_plan():
     assert per_simd.max() - per_simd.min() <= 1
     l = lens_of([40000, 60000, 43999], 72, 1)                     # three clips share the slots in proportion
     assert len(l) <= 2048 and int(l.sum()) == 143999 and l.min() >= 16
+    # random one-round batches: whatever the function returns covers every clip exactly, in whole quanta (later runs minus the halo,
+    # the last run of a clip minus what the clip does not have), never longer than the cap, never more runs than wave slots
+    rng = np.random.default_rng(77)
+    for _ in range(200):
+        n_clips = int(rng.integers(1, 12))
+        frames = rng.integers(200, 40000, n_clips)
+        shrink = int(rng.integers(0, 3))
+        cap, _runs = cap_of(frames, shrink)
+        l = lens_of(frames, cap, shrink)
+        if len(l) == 0:
+            continue
+        assert len(l) <= 2048 and l.min() > 0 and l.max() <= cap and int(l.sum()) == int(frames.sum())
+        pos = 0
+        for T in frames:                                            # the runs of a clip are consecutive in the list
+            acc, first = 0, True
+            while acc < T:
+                n = int(l[pos]); pos += 1
+                last = acc + n == T
+                assert acc + n <= T
+                if not last:
+                    assert (n + (0 if first else shrink)) % 4 == 0
+                acc += n; first = False
+        assert pos == len(l)
     assert len(lens_of([399] * 12500, 100, 1)) == 0               # many rounds: the equal runs stay
     assert len(lens_of([2048 * 72], 72, 0)) == 0                  # already one full round
     assert len(lens_of([20000], 72, 1)) == 0                      # too short for 2048 runs of 16 frames
