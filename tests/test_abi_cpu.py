@@ -184,7 +184,8 @@ def _run_plan(frames, quantum=4, min_run=16, max_run=256, halo=4, wg_runs=8, num
 
 def test_run_length_choice_for_the_baseline_batches():
     """paa_plan_create's run sizing (host only): equal runs per clip, the cap minimising rounds x (run + halo)."""
-    cap, runs, longest = _run_plan([143999])                      # config 2: one round of 250 workgroups
+    cap, runs, longest = _run_plan([143999])                      # config 2: one round of 250 workgroups (the equal-run rule; since round 5 such a
+                                                                  # plan is re-cut into 256 x 8 runs: test_balanced_runs_of_a_one_round_plan)
     assert (runs, longest) == (2000, 72)
     cap, runs, longest = _run_plan([399] * 12500)                 # config 4 shard: 4 x 100 per clip, not 244 + 155
     assert (runs, longest) == (50000, 100)
