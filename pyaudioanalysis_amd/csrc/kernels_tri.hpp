@@ -79,7 +79,11 @@ struct Shape {
     static constexpr int NQ1 = PACKED ? R1 : (R1 + 1) / 2;  // pass-1 outputs that are needed
     static constexpr int NJ = (L1 + 63) / 64;               // pass-1 jobs per lane
     static constexpr int J2 = NQ1 * R3;                     // pass-2 jobs (one per lane)
-    static constexpr int NJOB3 = PACKED ? pair_count(R1, R2, R3) : NQ1 * R2;
+    // 16 x 16 x 4 (2048 samples): 127 pairs + the two self-paired jobs 0 and R1 R2 / 2 = 129 lane jobs -- a third pass-3 round for one
+    // job.  Job 0 needs three of its lane's four result slots (bins N3 & N - N3, 2 N3, and bin 0, which is two additions of its own),
+    // job R1 R2 / 2 two (its pairs k3 <-> 3 - k3): the two share lane 0 (FOLD) and the pass has 128 jobs = two rounds
+    static constexpr bool FOLD = PACKED && R3 == 4 && (R1 * R2) % 2 == 0 && pair_count(R1, R2, R3) % 64 == 1;
+    static constexpr int NJOB3 = PACKED ? pair_count(R1, R2, R3) - (FOLD ? 1 : 0) : NQ1 * R2;
     static constexpr int NR3 = (NJOB3 + 63) / 64;           // pass-3 rounds
     static constexpr int PLANE = NQ1 * P;
     static constexpr int C0 = (NF + 63) / 64;
@@ -1335,11 +1339,22 @@ __global__ __launch_bounds__(64 * (MODE == 0 ? SH::NW : SH::NWR), ((MODE == 0 ? 
                 Cd<R3>::run(dB[u]);
 #pragma unroll
                 for (int k3 = 0; k3 < R3; ++k3) {
-                    const double2 zk = dA[u][Cd<R3>::pos(k3)];
+                    double2 zk = dA[u][Cd<R3>::pos(k3)];
                     double2 zm = dB[u][Cd<R3>::pos(R3 - 1 - k3)];
                     if (u == 0) {
-                        const double2 z0 = dA[u][Cd<R3>::pos((R3 - k3) % R3)];
-                        zm = make_double2((lane == 0) ? z0.x : zm.x, (lane == 0) ? z0.y : zm.y);
+                        if constexpr (SH::FOLD) {
+                            // lane 0 of round 0: job 0 (dA) and the self-paired job R1 R2 / 2 (dB) share the four slots (the host
+                            // table holds their bins and post-twiddles): slot 0 <- B's pair (0, 3), slot 1 <- A's (1, 3), slot 2 <-
+                            // A's (2, 2), slot 3 <- B's (1, 2); bin 0 follows below
+                            const double2 zk0 = (k3 == 0) ? dB[u][Cd<R3>::pos(0)] : (k3 == 3) ? dB[u][Cd<R3>::pos(1)] : dA[u][Cd<R3>::pos(k3)];
+                            const double2 zm0 = (k3 == 0) ? dB[u][Cd<R3>::pos(3)] : (k3 == 1) ? dA[u][Cd<R3>::pos(3)]
+                                              : (k3 == 2) ? dA[u][Cd<R3>::pos(2)] : dB[u][Cd<R3>::pos(2)];
+                            zk = make_double2((lane == 0) ? zk0.x : zk.x, (lane == 0) ? zk0.y : zk.y);
+                            zm = make_double2((lane == 0) ? zm0.x : zm.x, (lane == 0) ? zm0.y : zm.y);
+                        } else {
+                            const double2 z0 = dA[u][Cd<R3>::pos((R3 - k3) % R3)];
+                            zm = make_double2((lane == 0) ? z0.x : zm.x, (lane == 0) ? z0.y : zm.y);
+                        }
                     }
                     // 2E = Z[k] + conj Z[N-k],  2O = -i (Z[k] - conj Z[N-k]);  X[k] = E + w^k O,  X[N-k] = conj(E - w^k O)
                     const double2 e = make_double2(zk.x + zm.x, zk.y - zm.y);
@@ -1351,6 +1366,14 @@ __global__ __launch_bounds__(64 * (MODE == 0 ? SH::NW : SH::NWR), ((MODE == 0 ? 
                     const unsigned st = pw32[u][1 + k3];
                     *reinterpret_cast<double *>(plb + (st & 0xffffu)) = mk;
                     *reinterpret_cast<double *>(plb + (st >> 16)) = mm;
+                }
+                if constexpr (SH::FOLD) {
+                    // bin 0: Z[0] pairs with itself and w^0 = 1, so E + w O = (Re Z[0] + Im Z[0]) x 2 (same form as the slots above)
+                    if (u == 0 && lane == 0) {
+                        const double2 z0 = dA[0][Cd<R3>::pos(0)];
+                        const double xr0 = (z0.x + z0.x) + (z0.y + z0.y);
+                        *reinterpret_cast<double *>(plb) = mag_sqrt(xr0 * xr0) * mscale;
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1476,7 +1499,7 @@ typedef Shape<19, 29, 2, false, 58, 12, 2, 1, 3, 16> S1102;  // 25 ms at 44.1 kH
 #define PAA_NW_1024 12              // (A/B builds of scripts/rounds/r05: 8 / 10 / 11 waves per workgroup; 12 where the tables leave room)
 #endif
 typedef Shape<8, 8, 8, true, 72, PAA_NW_1024, 9, 1, 1, 16> S1024;          // 512 complex points: 64 x radix 8, three times
-typedef Shape<16, 16, 4, true, 68, 7> S2048;        // 1024 complex points
+typedef Shape<16, 16, 4, true, 68, 7, 4, 1, 1, 16> S2048;   // 2048 samples: 1024 complex points; with the folded pass 3 the row instances need 108 registers: sixteen waves per CU
 typedef Shape<4, 8, 8, true, 72, 12, 9, 1, 1, 16> S512;           // 256 complex points (odd entropy blocks: 51 samples)
 
 struct TriLaunch {
@@ -1561,6 +1584,22 @@ inline void tri_fill(double fs, int mode, const MelTable *mel, const ChromaTable
                 const int p1 = m % R1, p2 = (m / R1) % R2;
                 if (!(p1 > q1 || (p1 == q1 && p2 >= q2))) continue;
                 const bool self = (p1 == q1 && p2 == q2);
+                if (SH::FOLD && self && k != 0) continue;          // the second self-paired job rides in entry 0 (below)
+                if (SH::FOLD && k == 0) {
+                    // entry 0: job 0 (A) + the self-paired job kf = R1 R2 / 2 (B); slots: B's pair (kf, N - kf), A's (N3, N - N3),
+                    // A's 2 N3 alone, B's pair (kf + N3, N - kf - N3); bin 0 is written by the kernel itself
+                    const int kf = R1 * R2 / 2, N3h = R1 * R2;
+                    pt[0] = 0;
+                    pt[1] = (unsigned short)(8 * ((kf % R1) * SH::P + (kf / R1) * SH::R3P));
+                    const int bins[4][2] = {{kf, N - kf}, {N3h, N - N3h}, {2 * N3h, SH::NF}, {kf + N3h, N - kf - N3h}};
+                    for (int k3 = 0; k3 < NK; ++k3) {
+                        pt[2 + 2 * k3] = (unsigned short)(8 * (k3 < 4 ? bins[k3][0] : SH::NF));
+                        pt[3 + 2 * k3] = (unsigned short)(8 * (k3 < 4 ? bins[k3][1] : SH::NF));
+                    }
+                    for (int k3 = 0; k3 < 4; ++k3) put_w(L.off_g_post, (size_t)k3, (long long)bins[k3][0], 2LL * N);
+                    ++p;
+                    continue;
+                }
                 pt[E * p] = (unsigned short)(8 * (q1 * SH::P + q2 * SH::R3P));
                 pt[E * p + 1] = (unsigned short)(8 * (p1 * SH::P + p2 * SH::R3P));
                 for (int k3 = 0; k3 < NK; ++k3) {

@@ -736,12 +736,22 @@ def test_three_pass_tables_reproduce_the_fft(window):
         post = cplx(off[3], 64 * ((njob3 + 63) // 64) * R3).reshape(-1, R3)
         assert np.all(p3 % 8 == 0) and np.all(p3[njob3:, 2:] == 8 * NF) and np.all(p3[:, 2 + 2 * R3:] == 8 * NF)
         p3 = p3 // 8
+        # 16 x 16 x 4 (2048 samples): entry 0 holds job 0 (A) AND the second self-paired job R1 R2 / 2 (B) -- 128 lane jobs instead of
+        # 129; its slots: B's pair (0, 3), A's (1, 3), A's (2, 2), B's (1, 2); bin 0 comes from Z[0] alone (Shape::FOLD)
+        fold = int(p3[0, 0]) != int(p3[0, 1])
+        assert fold == (R3 == 4 and njob3 % 64 == 0 and R1 * R2 == 256)
         for p in range(njob3):
             offA, offB = int(p3[p, 0]), int(p3[p, 1])
             zA, zB = np.fft.fft(plane2[offA:offA + R3]), np.fft.fft(plane2[offB:offB + R3])
+            if fold and p == 0:
+                kf = R1 * R2 // 2
+                assert offB == (kf % R1) * P + (kf // R1) * R3P
+                X[0] = abs(zA[0].real + zA[0].imag); hits[0] += 1
             for k3 in range(R3):
                 zk = zA[k3]
                 zm = zA[(R3 - k3) % R3] if p == 0 else zB[R3 - 1 - k3]          # job 0 is (q1, q2) = (0, 0): its own partner
+                if fold and p == 0:
+                    zk, zm = ((zB[0], zB[3]), (zA[1], zA[3]), (zA[2], zA[2]), (zB[1], zB[2]))[k3]
                 e, o = 0.5 * (zk + np.conj(zm)), -0.5j * (zk - np.conj(zm))
                 ka, kb = int(p3[p, 2 + 2 * k3]), int(p3[p, 3 + 2 * k3])
                 assert ka <= NF and kb <= NF and (ka == NF or kb == NF or ka + kb == N)
