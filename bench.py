@@ -251,7 +251,7 @@ def other_configs(ffi, steps=10):
     run_shape("big_16000_1h", "w16000_16kHz_1h", "1 h at 16 kHz, 16000 / 8000", launches=10)
     run_shape("big_16000_68", "w16000_16kHz_68rows", "10 min at 16 kHz, 16000 / 8000, 68 rows", launches=20)
     run_shape("big_8000_batch", "w8000_batch", "200 clips x 30 s at 16 kHz, 8000 / 4000, one plan", launches=20)
-    run_shape("big_44100", "w44100_44kHz", "5 min at 44.1 kHz, 1 s / 0.5 s (44100 / 22050): Stockham passes through HBM scratch", launches=3)
+    run_shape("big_44100", "w44100_44kHz", "5 min at 44.1 kHz, 1 s / 0.5 s (44100 / 22050): split transform, pairs of sub-transforms in LDS", launches=3)
     return out
 
 
@@ -343,6 +343,122 @@ def compact(entry):
     def r4(v):
         return float("%.4g" % v)
     return [r4(entry["frames_per_s"]), r4(entry["ms_per_step"]), r4(entry["hbm_frac"]), entry["kernel"]]
+
+
+LINE_LIMIT = 7600                     # the driver keeps the last 8 018 characters of stdout: the ONE line must fit whole
+
+
+def _r(v, digits=5):
+    """numbers of the line rounded to `digits` significant digits (the full-precision record goes to the side file)"""
+    if isinstance(v, bool) or v is None:
+        return v
+    if isinstance(v, float):
+        return float("%.*g" % (digits, v))
+    if isinstance(v, dict):
+        return {k: _r(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, digits) for x in v]
+    return v
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def format_line(result, side_path=None, limit=LINE_LIMIT):
+    """The ONE JSON line of the run, at most `limit` characters (BENCH_r05: a 20.5 KB line did not fit the driver's 8 KB tail
+    and was recorded as unparsed).  `result` is the full record -- it goes to `side_path` (named in the line) untouched; the
+    line keeps the contract's keys, the whole `roofline` and `cpu_baseline` objects with their numbers and short provenance
+    strings, the parity check, and ends with the compact `configs` table.  Sections are dropped from the END of a fixed
+    priority list until the line fits, never the contract keys."""
+    cfg = result.get("config", {})
+    line = {k: result[k] for k in ("metric", "value", "unit", "n_gpus", "ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                   "scaling", "vs_baseline", "dtype", "data") if k in result}
+    line["config"] = _pick(cfg, ("workload", "kernel", "rows", "window", "step", "frames_per_step_job", "frames_per_step_rank0", "clips_in_job",
+                                 "input_buffers_rotated", "devices", "distinct_devices", "rccl_ranks", "launched_by", "multi_gpu",
+                                 "gather_note", "value_is"))
+    roof = result.get("roofline") or {}
+    r = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_avg_ms", "launches_timed",
+                     "algorithmic_bytes_per_frame", "traffic_over_algorithmic", "traffic_round", "traffic_stale"))
+    if roof.get("traffic") is not None:
+        r["traffic_source"] = "committed PMC pass of this command, not this run"
+    fv = roof.get("fp64_valu")
+    if fv:
+        r["fp64_valu"] = _pick(fv, ("achieved_tflops", "peak_tflops", "frac", "issued_kflop_per_frame_measured", "issued_frac",
+                                    "sustained_clock_ghz", "issued_frac_at_sustained_clock"))
+    r["note"] = "FP64-VALU bound (~40 flop/B); HBM fraction reported as the metric asks"
+    line["roofline"] = r
+    cb = result.get("cpu_baseline")
+    if cb:
+        c = _pick(cb, ("value", "unit", "cores", "kind", "sample", "numpy_port", "c_port", "cpu_model", "host_cores",
+                       "reference_cost_port", "reference_note"))
+        if isinstance(cb.get("all_cores"), dict):
+            c["all_cores"] = _pick(cb["all_cores"], ("value", "cores", "kind", "error"))
+        ref = cb.get("reference")
+        if isinstance(ref, dict) and "frames_per_s" in ref:
+            c["reference_in_build_container"] = {"frames_per_s_cfg2": (ref["frames_per_s"] or {}).get("cfg2_60s_34rows"),
+                                                 "cores": 1, "cpu_model": ref.get("cpu_model"), "source": ref.get("source")}
+        line["cpu_baseline"] = c
+    elif "cpu_baseline" in result:
+        line["cpu_baseline"] = None
+    if "parity_check" in result:
+        line["parity_check"] = _pick(result["parity_check"], ("status", "violations", "entries", "max_abs_diff", "gate"))
+    if "sustained" in result:
+        line["sustained"] = _pick(result["sustained"], ("seconds", "steps", "frames_per_s"))
+    h2h = result.get("host_to_host")
+    if isinstance(h2h, dict):
+        line["host_to_host"] = {k: _pick(v, ("frames_per_s", "ms", "pcie_GBps")) for k, v in h2h.items() if isinstance(v, dict)}
+    if side_path:
+        line["full_record"] = side_path
+    # N > 1: the three rates of the job and what the short gather can reach, in one compact object near the tail
+    scale_keys = ("frames_per_s", "frames_per_s_without_gather", "frames_per_s_mid_gather", "frames_per_s_short_gather",
+                  "gather_bytes_per_step_into_root", "rccl_ranks", "distinct_devices")
+    if any(k in cfg for k in scale_keys[:4]):
+        sc = _pick(cfg, scale_keys)
+        es = cfg.get("expected_speedup_short_gather")
+        if es:
+            sc["expected_speedup_short_gather"] = _pick(es, ("speedup_over_one_gpu", "ideal", "bound"))
+        line["scale"] = sc
+    if "configs" in result:
+        line["configs_columns"] = result.get("configs_columns")
+        line["configs"] = result["configs"]
+    line = _r(line)
+    droppable = ["host_to_host", "sustained", ("cpu_baseline", "reference_in_build_container"), ("config", "launched_by"),
+                 ("config", "multi_gpu"), ("roofline", "note"), ("cpu_baseline", "sample")]
+    text = json.dumps(line, separators=(",", ":"))
+    while len(text) > limit and droppable:
+        key = droppable.pop(0)
+        if isinstance(key, tuple):
+            if isinstance(line.get(key[0]), dict):
+                line[key[0]].pop(key[1], None)
+        else:
+            line.pop(key, None)
+        text = json.dumps(line, separators=(",", ":"))
+    if len(text) > limit and isinstance(line.get("configs"), dict):
+        # still too long: the configs table loses its non-BASELINE rows, last first
+        keep = ("cfg2", "cfg2_job", "cfg4_job", "cfg3", "cfg4_shard", "cfg5_features", "cfg5_spectrogram", "cfg5_chromagram")
+        for k in [k for k in reversed(list(line["configs"])) if k not in keep]:
+            del line["configs"][k]
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) <= limit:
+                break
+    return text
+
+
+def write_side_record(result, world):
+    """The full record (verbose config.others, every provenance string) beside the line: gpurun_out/ when the tree has one
+    or can have one (it is what travels back from a GPU box), else the working directory.  Returns the path written, or None."""
+    name = "bench_full_n%d.json" % world
+    for d in (os.path.join(ROOT, "gpurun_out"), os.getcwd()):
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, name)
+            with open(path, "w") as fh:
+                json.dump(result, fh, indent=1)
+            return os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+        except OSError:
+            continue
+    return None
 
 
 def main():
@@ -627,8 +743,11 @@ def main():
         achieved = bytes_per_frame * frames / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
         result = {
             "metric": "short-term frames/sec (34-feat, 16 kHz, 50 ms/25 ms) + HBM GB/s vs peak",
-            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            # n_gpus = the DEVICES that ran (advisor, round 5): ranks that share a device (--no-gather on a box with fewer
+            # GPUs than ranks) do not make it a multi-GPU figure -- `ranks` says how many processes, `scaling` is null then
+            "value": value, "unit": "frames/s", "n_gpus": len(set(devices)), "ranks": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": (scaling if len(set(devices)) == world else None), "vs_baseline": None,
             "prewarm_seconds": args.prewarm_seconds,
             "dtype": "f64", "data": "synthetic (oracle/synth.py; SURVEY 8d seeds)",
             "config": {"workload": desc, "frames_per_step_job": int(total_frames),
@@ -795,6 +914,12 @@ def main():
                                 one["seconds_of_audio"], one["frames"], one["numpy_port_seconds"], one["c_port_seconds"]),
                   "ports_vs_reference": "both ports hoist the frame-invariant tables (mel bank, chroma map, DCT) that "
                                         "the reference rebuilds per call / per frame and are 8-18x faster than it"}
+            try:
+                cb["reference_cost_port"] = cpu_bench.reference_cost(host_clip, FS, WINDOW, STEP)
+                cb["reference_note"] = ("kind stays 'port': the Python reference may not travel to this host in any form; "
+                                        "reference_cost_port = its cost structure restated, within 3 % of it where both run")
+            except Exception as exc:
+                cb["reference_cost_port"] = {"error": repr(exc)}
             # the UNMODIFIED reference, timed by scripts/reference_cpu_baseline.py in the build container (the GPU box has
             # no /root/reference): embedded so that the stated baseline travels with the line
             try:
@@ -824,7 +949,7 @@ def main():
                 result["config"][key + "_hbm_frac"] = configs[key][2]
         result["configs_columns"] = ["frames_per_s", "ms_per_step", "hbm_frac", "kernel"]
         result["configs"] = configs
-        print(json.dumps(result))
+        print(format_line(result, write_side_record(result, world)))
         sys.stdout.flush()
     if comm is not None:
         comm.close()

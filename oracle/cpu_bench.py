@@ -58,6 +58,26 @@ def single_core(x, fs, window, step, budget_frames):
     return out
 
 
+def reference_cost(x, fs, window, step, budget_frames=4000):
+    """The cost-faithful restatement of the reference loop (paa_oracle.feature_extraction_reference_cost: chroma tables rebuilt
+    per frame, scipy DCT per frame, list + concatenate -- what the unmodified Python reference does, which cannot travel to
+    this host) on a prefix of the bench clip, one thread; with the ratio to the real reference measured in the build container."""
+    import json
+    import paa_oracle as O
+    n = min(len(x), window + step * (budget_frames - 1))
+    t0 = time.perf_counter()
+    F, _ = O.feature_extraction_reference_cost(x[:n], fs, window, step, deltas=False)
+    dt = time.perf_counter() - t0
+    out = {"value": F.shape[1] / dt, "unit": "frames/s", "cores": 1, "frames": int(F.shape[1]), "seconds": dt,
+           "what": "oracle restatement with the reference's per-frame costs (not the reference itself)"}
+    try:
+        cal = json.load(open(os.path.join(os.path.dirname(_HERE), "profiles", "r06_reference_cost_port.json")))
+        out["over_reference_in_build_container"] = cal["cost_port_over_reference"]
+    except Exception:
+        pass
+    return out
+
+
 def _worker(args):
     seed, fs, window, step, clip_seconds, reps = args
     os.environ["OMP_NUM_THREADS"] = "1"

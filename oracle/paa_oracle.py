@@ -268,6 +268,63 @@ def feature_extraction(signal, sampling_rate, window, step, deltas=True):
     return np.ascontiguousarray(np.stack(cols, axis=1)), feature_names(deltas)
 
 
+def feature_extraction_reference_cost(signal, sampling_rate, window, step, deltas=True):
+    """The same numbers as feature_extraction() above, produced with the reference's COST STRUCTURE -- for bench.py's
+    cpu_baseline only.  The Python reference cannot travel to the GPU box (no /root/reference there), and the ports above
+    are 8-18x faster than it because they hoist what it recomputes; this variant puts those per-frame costs back:
+      * the chroma tables are rebuilt for EVERY frame (chroma_features calls chroma_features_init, ShortTermFeatures.py:281
+        -> :257-274: a Python list comprehension over the bins, np.unique, one np.nonzero per distinct slot) and the chroma
+        vector goes through the dense scatter / divide / pad / reshape / column-sum of :286-302;
+      * the MFCCs go through scipy.fftpack.dct(type=2, norm='ortho') per frame (:253);
+      * per-frame results are (F, 1) columns collected in a Python list and joined by one np.concatenate (:684).
+    The mel bank is built once per call (:578), as there.  Calibrated against the unmodified reference in the build
+    container (profiles/r06_reference_cost_port.json, scripts/reference_cpu_baseline.py)."""
+    from scipy.fftpack import dct as fftpack_dct, fft as fftpack_fft
+    window, step = int(window), int(step)
+    x_all = normalize_clip(signal)
+    n = len(x_all)
+    fs = sampling_rate
+    nfft = int(window / 2)
+    tab = Tables(fs, window)
+    cols = []
+    pos = 0
+    prev_X = None
+    prev_v = None
+    while pos + window - 1 < n:
+        x = x_all[pos:pos + window]
+        pos += step
+        X = abs(fftpack_fft(x))[0:nfft] / nfft
+        if prev_X is None:
+            prev_X = X.copy()
+        v = frame_vector(x, X, prev_X, tab)
+        # ---- the reference's per-frame chroma: tables rebuilt, dense scatter (identical values, its cost)
+        slot, count = chroma_bins(fs, nfft)
+        P = X ** 2
+        dense = np.zeros((nfft,))
+        dense[slot] = P
+        dense /= count[slot]
+        rows = int(np.ceil(nfft / 12.0))
+        padded = np.zeros((rows * 12,))
+        padded[:nfft] = dense
+        folded = np.sum(padded.reshape(rows, 12), axis=0)
+        p_tot = P.sum()
+        folded = folded / EPS if p_tot == 0 else folded / p_tot
+        v[21:33] = folded
+        v[33] = folded.std()
+        # ---- its MFCC call: scipy's DCT on the log mel spectrum
+        v[8:21] = fftpack_dct(np.log10(np.dot(X, tab.mel.T) + EPS), type=2, norm="ortho", axis=-1)[:N_MFCC]
+        col = np.zeros((2 * N_BASE if deltas else N_BASE, 1))
+        col[:N_BASE, 0] = v
+        if deltas and prev_v is not None:
+            col[N_BASE:, 0] = v - prev_v
+        prev_v = v
+        cols.append(col)
+        prev_X = X.copy()
+    if not cols:
+        raise ValueError("need at least one array to concatenate")
+    return np.concatenate(cols, 1), feature_names(deltas)
+
+
 def mid_ratios(mid_window, mid_step, short_window, short_step):
     """(ratio, step_ratio) exactly as MidTermFeatures.py:100-102 (Python round)."""
     ratio = round((mid_window - (short_window - short_step)) / short_step)

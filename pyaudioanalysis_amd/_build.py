@@ -13,10 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpaa_hip.so")
 SOURCES = ["paa_lib.hip", "family_fast.hip", "family_ct.hip", "family_tri_a.hip", "family_tri_b.hip", "family_tri_c.hip", "family_reg_mix_generic.hip"]
-HEADERS = ["device_common.hpp", "kernels_generic.hpp", "kernels_fast.hpp", "kernels_aux.hpp",
-           "kernels_tail.hpp", "kernels_big.hpp", "kernels_ct.hpp", "kernels_mix.hpp", "kernels_tri.hpp", "kernels_sim.hpp", "kernels_reg.hpp", "kernels_svm.hpp", "comm_rccl.hpp", "tables.hpp",
-           "family_launch.hpp", "lib_plan.hpp", "lib_dispatch.hpp", "lib_host_api.hpp", "lib_similarity.hpp", "lib_debug.hpp",
-           os.path.join("..", "..", "include", "paa_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "paa_hip.h")]
 # -disable-machine-licm: the feature kernels' loop bodies are thousands of instructions long; hoisting every FP64 literal
 # and per-lane LDS address out of them creates >100 loop-invariant registers that then spill (AGPR copies at one wave per
 # SIMD, scratch at two).  Re-materialising a literal at its use costs two s_mov / v_mov.

@@ -13,7 +13,9 @@ Trust model: the token keeps OTHER JOBS and stray listeners apart; it is not a c
 run id are guessable.  On a network where hosts outside the job can reach rank 0's ports, export the same PAA_RDZV_SECRET
 on every rank: it is mixed into the token (HMAC-SHA256), and a peer without it cannot claim a rank slot.  Rank 0 listens on
 loopback only when MASTER_ADDR is a loopback literal (single-node jobs), on MASTER_ADDR's own interface when that is a
-non-loopback address of this host, and on all interfaces otherwise (_bind_hosts); every handshake runs on its own thread
+non-loopback address of this host, on the resolved loopback address when a NAME resolves to loopback and the launcher says
+the job is single-node (LOCAL_WORLD_SIZE == WORLD_SIZE), and on all interfaces otherwise (_bind_hosts; a warning is issued
+when that happens without PAA_RDZV_SECRET); every handshake runs on its own thread
 with a 5 s budget, so a half-open connection cannot stall the accept loop.
 """
 import base64
@@ -107,13 +109,15 @@ class SocketGroup:
 
     # ---- connection set-up
     @staticmethod
-    def _bind_hosts(addr):
+    def _bind_hosts(addr, single_node=False):
         """Interfaces rank 0 tries to listen on, in order.  MASTER_ADDR given as a loopback LITERAL (127.x.y.z, localhost)
         declares a single-node job: every peer connects to that same literal, so loopback is enough and nothing off the node
         can connect.  A NAME that merely resolves to loopback here (Debian / Ubuntu map the host's own name to 127.0.1.1 in
         /etc/hosts) says nothing about where the peers are -- remote ranks resolve it to the real interface -- so all
-        interfaces are bound, as for a name that resolves elsewhere (NAT).  A non-loopback address of this host is bound
-        itself, with all interfaces as the fallback when it turns out not to be bindable here."""
+        interfaces are bound, as for a name that resolves elsewhere (NAT) -- UNLESS the launcher says the whole job is on this
+        node (single_node: LOCAL_WORLD_SIZE == WORLD_SIZE, what torchrun exports for --nnodes=1): then the loopback address the
+        name resolved to is enough and nothing off the node can reach the listener (advisor, round 5).  A non-loopback address
+        of this host is bound itself, with all interfaces as the fallback when it turns out not to be bindable here."""
         literal = addr.strip().lower()
         try:
             packed = socket.inet_aton(literal)
@@ -127,12 +131,17 @@ class SocketGroup:
         except OSError:
             return [""]
         if resolved.startswith("127."):
-            return [""]
+            return [resolved] if single_node else [""]
         return [resolved, ""]
 
     def _serve(self, addr, port, deadline):
         last = None
-        hosts = self._bind_hosts(addr)
+        local_world = os.environ.get("LOCAL_WORLD_SIZE", "")
+        hosts = self._bind_hosts(addr, single_node=local_world.isdigit() and int(local_world) == self.world_size)
+        if "" in hosts and not os.environ.get("PAA_RDZV_SECRET"):
+            import warnings
+            warnings.warn("control-plane listener of rank 0 binds all interfaces (MASTER_ADDR=%r) without PAA_RDZV_SECRET: "
+                          "export the same secret on every rank when hosts outside the job can reach this one" % addr)
         for cand in range(port + 1, port + 1 + _PORT_SPAN):
             srv = None
             for host in hosts:

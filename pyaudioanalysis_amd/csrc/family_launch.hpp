@@ -10,17 +10,7 @@
 #include "kernels_fast.hpp"
 #include "kernels_generic.hpp"
 #include "kernels_mix.hpp"
-#include "kernels_reg.hpp"
 #include "kernels_tri.hpp"
-
-// config 5's spectrogram / chromagram rows (window 1102): 1 = the three-pass kernel (radix 19 first, radix 29 shared by three lanes,
-// one spectrum slot per wave, sixteen waves per CU), 0 = the prime-factor kernel st_reg (kernels_reg.hpp, three frames per
-// iteration, eight waves per CU) that served them until round 5.  A/B on one box (scripts/rounds/r05/gpu_r05n.sh): spectrogram
-// from interleaved stereo 0.2004 against 0.2040 ms, chromagram 0.2002 against 0.2139 ms, spectrogram from int16 mono 0.1927 against
-// 0.1943 ms (the first A/B, with two slots and twelve waves, had been a draw: gpu_r05k.sh)
-#ifndef PAA_TRI_1102_ROWS
-#define PAA_TRI_1102_ROWS 1
-#endif
 
 namespace paa {
 namespace launch {
@@ -43,11 +33,6 @@ int tri_part_b(const tri::TriLaunch &tl, int sample_kind, const PlanDev &P, cons
 int tri_part_c(const tri::TriLaunch &tl, int sample_kind, const PlanDev &P, const unsigned char *blob, const void *d_packed,
                const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
                hipStream_t stream);
-// kernels_reg.hpp: prime-factor register FFT (window 1102: spectrogram / chromagram rows until round 5; instantiated only in
-// builds that can still dispatch it: -DPAA_EXPERIMENTS (PAA_REG_1102=1) or -DPAA_TRI_1102_ROWS=0)
-int reg(const reg::RegLayout &rl, size_t lds, int sample_kind, const PlanDev &P, const unsigned char *blob,
-        const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
-        hipStream_t stream);
 // kernels_mix.hpp: in-place mixed-radix transform (every other length made of 2, 3, 5, 7, 11, 13)
 int mix(const mix::MixLayout &ml, size_t lds, int sample_kind, const PlanDev &P, const unsigned char *blob,
         const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,

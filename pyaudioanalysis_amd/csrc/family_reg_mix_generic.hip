@@ -1,5 +1,6 @@
-// The prime-factor register FFT (kernels_reg.hpp: rows of window 1102), the in-place mixed-radix kernel (kernels_mix.hpp) and
-// the generic Stockham kernel (kernels_generic.hpp) -- own translation unit, see family_launch.hpp.
+// The in-place mixed-radix kernel (kernels_mix.hpp) and the generic Stockham kernel (kernels_generic.hpp) -- own translation
+// unit, see family_launch.hpp.  (The prime-factor kernel st_reg that gave the unit its name left the tree in round 6:
+// scripts/experiments/kernels_reg.hpp.)
 #define PAA_NO_HOST_LAUNCHERS
 #include <algorithm>
 #include <cstdlib>
@@ -9,39 +10,6 @@
 
 namespace paa {
 namespace launch {
-
-#if defined(PAA_EXPERIMENTS) || !PAA_TRI_1102_ROWS
-template <typename T>
-static int reg_one(const reg::RegLayout &rl, size_t lds, const PlanDev &P, const unsigned char *blob, const void *d_packed,
-                   const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
-                   hipStream_t stream) {
-    using SH = reg::Shape1102;
-    static LdsAttrCache attr;
-    if (!attr.covers(lds)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&reg::st_reg_kernel<SH, T>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds, 64 * 1024)) != hipSuccess)
-            return -1;
-        attr.set(std::max<size_t>(lds, 64 * 1024));
-    }
-    const unsigned grid = (unsigned)((n_tiles + rl.waves - 1) / rl.waves);
-    hipLaunchKernelGGL((reg::st_reg_kernel<SH, T>), dim3(grid), dim3(64 * rl.waves), lds, stream, P, rl, blob,
-                       (const T *)d_packed, clips, norms, tiles, (int)n_tiles, d_out);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-int reg(const reg::RegLayout &rl, size_t lds, int sample_kind, const PlanDev &P, const unsigned char *blob,
-        const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
-        hipStream_t stream) {
-    if (sample_kind == 0) return reg_one<int16_t>(rl, lds, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
-    if (sample_kind == 2) return reg_one<stereo16>(rl, lds, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
-    return reg_one<double>(rl, lds, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
-}
-#else
-// (the default build routes window 1102 to the three-pass family: st_reg is never dispatched, so it is not compiled in)
-int reg(const reg::RegLayout &, size_t, int, const PlanDev &, const unsigned char *, const void *, const ClipDev *, const ClipNorm *,
-        const Tile *, long long, double *, hipStream_t) {
-    return -1;
-}
-#endif
 
 template <typename T, int TWG, int LEAN>
 static int mix_one(const mix::MixLayout &ml, size_t lds, const PlanDev &P, const unsigned char *blob, const void *d_packed,

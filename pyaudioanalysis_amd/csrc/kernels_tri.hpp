@@ -37,7 +37,7 @@
 #include <vector>
 
 #include "kernels_mix.hpp"
-#include "kernels_reg.hpp"          // PrimeTab
+#include "prime_tables.hpp"        // PrimeTab
 
 namespace paa {
 namespace tri {
@@ -198,7 +198,7 @@ template <> struct Cd<21> {
 };
 
 // ---- odd primes: O(R^2) butterflies from the sums / differences of the pairs (x_j, x_{R-j}), in the pivot form of
-// mix::dft_prime (R equal inputs give exact zeros in the non-DC outputs); cos / sin from kernels_reg.hpp's half tables
+// mix::dft_prime (R equal inputs give exact zeros in the non-DC outputs); cos / sin from the half tables of prime_tables.hpp
 template <int R> struct PT {
     static constexpr int H = (R - 1) / 2;
     static constexpr double c(int m) { return (m % R == 0) ? 1.0 : reg::PrimeTab<R>::c[((m % R) <= H ? (m % R) : R - (m % R)) - 1]; }

@@ -86,37 +86,10 @@ static int fam_ct_launch(paa_plan *p, const void *d_packed, double *d_out, const
     return launch::ct(p->cl, p->sample_kind, p->P, p->d_gen_blob, d_packed, p->d_clips, p->d_norms, tiles, n, d_out, s);
 }
 
-// ---- kernels_reg.hpp: prime-factor register FFT, window 1102 (config 5): spectrogram / chromagram rows (2.8e8 frames/s
-// against 2.3e8 of the three-pass kernel); the FEATURE matrix goes to kernels_tri.hpp since round 4 -- same rate
-// (1.28e8 / 1.30e8) but 64-byte chunked row stores instead of 6-frame row segments (-DPAA_EXPERIMENTS builds:
-// PAA_REG_1102=1 puts it back for A/B runs)
-static int fam_reg_select(FamilyCtx &c) {
-    if (g_force_generic || !c.tab->fft.even || !reg::reg_supported(c.window)) return 0;
-    if ((c.mode == 0 || PAA_TRI_1102_ROWS) && !experiment_env("PAA_REG_1102")) return 0;
-    using SH = reg::Shape1102;
-    std::vector<unsigned char> blob;
-    reg::reg_layout<SH>(c.tab->fft, c.mel(), c.chroma(), c.F, c.p->rl, &blob);
-    if ((size_t)c.p->rl.table_bytes + (size_t)c.p->rl.wave_bytes > 160 * 1024) return 0;
-    const int rc = upload_blob(c.p, blob);
-    if (rc) return rc;
-    c.p->reg = 1;
-    c.p->lds = (size_t)c.p->rl.table_bytes + (size_t)c.p->rl.waves * c.p->rl.wave_bytes;
-    c.p->kernel_name = (c.mode == 0) ? "st_reg_29x19" : (c.mode == 1 ? "spectrogram_reg_29x19" : "chromagram_reg_29x19");
-    return 1;
-}
-static void fam_reg_rule(FamilyCtx &c, RunRule &r) {
-    const int q = reg::Shape1102::Q;          // runs are multiples of Q frames (halo = one iteration); see choose_run_cap
-    r.quantum = q;
-    r.run = choose_run_cap(c.p->clips, q, 4 * q, 32 * q, q, c.p->rl.waves, c.num_cu());
-}
-static int fam_reg_launch(paa_plan *p, const void *d_packed, double *d_out, const Tile *tiles, long long n, hipStream_t s) {
-    return launch::reg(p->rl, p->lds, p->sample_kind, p->P, p->d_gen_blob, d_packed, p->d_clips, p->d_norms, tiles, n, d_out, s);
-}
-
 // ---- kernels_tri.hpp: three-pass register FFT -- the reference's default 50 ms windows at 48 / 44.1 kHz (2400, 2205), the
 // 40 ms ones (1920, 1764), 1600, 1200, config 5's feature matrix (1102) and the odd 551 (50 ms at 11.025 kHz)
 static int fam_tri_select(FamilyCtx &c) {
-    if (g_force_generic || (c.window == 1102 && c.mode != 0 && !PAA_TRI_1102_ROWS)) return 0;
+    if (g_force_generic) return 0;
     std::vector<unsigned char> blob;
     if (!tri::tri_select(c.window, c.mode, c.fs, c.mel(), c.chroma(), c.p->trl, blob)) return 0;
     const int rc = upload_blob(c.p, blob);
@@ -184,7 +157,6 @@ static int fam_generic_launch(paa_plan *p, const void *d_packed, double *d_out, 
 static const Family kFamilies[] = {
     {"fast", fam_fast_select, fam_fast_rule, fam_fast_launch},
     {"ct", fam_ct_select, fam_ct_rule, fam_ct_launch},
-    {"reg", fam_reg_select, fam_reg_rule, fam_reg_launch},
     {"tri", fam_tri_select, fam_tri_rule, fam_tri_launch},
     {"mix", fam_mix_select, fam_mix_rule, fam_mix_launch},
     {"generic", fam_generic_select, fam_generic_rule, fam_generic_launch},
@@ -195,10 +167,9 @@ constexpr int kNumFamilies = (int)(sizeof(kFamilies) / sizeof(kFamilies[0]));
 // it back instead of rebuilding the layout and uploading the table blob again
 struct FamilyChoice {
     int family = -1;
-    int fast = 0, ct = 0, reg = 0, tri = 0, mixk = 0, big = 0;
+    int fast = 0, ct = 0, tri = 0, mixk = 0, big = 0;
     FastLaunch fl;
     ct::CtLaunch cl;
-    reg::RegLayout rl;
     tri::TriLaunch trl;
     mix::MixLayout ml;
     GenLayout gl;
@@ -222,8 +193,8 @@ static int choose_family(FamilyCtx &c, RunRule &rr) {
     if (it != c.tab->choices.end() && !g_force_generic) {
         const FamilyChoice &fc = *it->second;
         p->family = fc.family;
-        p->fast = fc.fast; p->ct = fc.ct; p->reg = fc.reg; p->tri = fc.tri; p->mixk = fc.mixk; p->big = fc.big;
-        p->fl = fc.fl; p->cl = fc.cl; p->rl = fc.rl; p->trl = fc.trl; p->ml = fc.ml; p->gl = fc.gl;
+        p->fast = fc.fast; p->ct = fc.ct; p->tri = fc.tri; p->mixk = fc.mixk; p->big = fc.big;
+        p->fl = fc.fl; p->cl = fc.cl; p->trl = fc.trl; p->ml = fc.ml; p->gl = fc.gl;
         p->lds = fc.lds; p->kernel_name = fc.kernel_name;
         p->d_gen_blob = fc.d_blob; p->blob_cached = true;
         kFamilies[p->family].run_rule(c, rr);
@@ -240,8 +211,8 @@ static int choose_family(FamilyCtx &c, RunRule &rr) {
         if (!g_force_generic) {
             auto fc = std::make_shared<FamilyChoice>();
             fc->family = i;
-            fc->fast = p->fast; fc->ct = p->ct; fc->reg = p->reg; fc->tri = p->tri; fc->mixk = p->mixk; fc->big = p->big;
-            fc->fl = p->fl; fc->cl = p->cl; fc->rl = p->rl; fc->trl = p->trl; fc->ml = p->ml; fc->gl = p->gl;
+            fc->fast = p->fast; fc->ct = p->ct; fc->tri = p->tri; fc->mixk = p->mixk; fc->big = p->big;
+            fc->fl = p->fl; fc->cl = p->cl; fc->trl = p->trl; fc->ml = p->ml; fc->gl = p->gl;
             fc->lds = p->lds; fc->kernel_name = p->kernel_name;
             fc->d_blob = p->d_gen_blob;            // ownership moves to the table set
             p->blob_cached = true;

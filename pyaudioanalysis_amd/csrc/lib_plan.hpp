@@ -145,8 +145,6 @@ struct paa_plan {
     void *d_psum = nullptr, *d_pmin = nullptr, *d_pmax = nullptr;
     long long *d_mid_off = nullptr;
     GenLayout gl;                    // generic kernel: LDS layout + table blob
-    reg::RegLayout rl;               // register-FFT kernel (windows 2 R1 R2): LDS layout, blob in d_gen_blob
-    int reg = 0;
     unsigned char *d_gen_blob = nullptr;
     bool blob_cached = false;        // d_gen_blob belongs to the table set's FamilyChoice (not freed with the plan)
     void *d_block = nullptr;         // the plan's one device block: d_clips, d_tiles, d_chunks, d_norms, d_psum / pmin / pmax point into it
@@ -616,10 +614,15 @@ static int run_wg(paa_plan *p, const void *d_packed, double *d_out) {
         long long maxT = 0;
         for (auto &cd : p->clips) maxT = std::max<long long>(maxT, cd.T);
         const long long gx = ((long long)kBase * maxT + 255) / 256;
-        if (gx > 0x7fffffffLL || p->n_clips > 65535)
-            return fail(PAA_ERR_UNSUPPORTED, "delta grid too large (%lld clips)", (long long)p->n_clips);
-        hipLaunchKernelGGL(wg::wg_delta_kernel, dim3((unsigned)gx, (unsigned)p->n_clips), dim3(256), 0, cs(), p->d_clips, d_out);
-        HIP_TRY(hipGetLastError());
+        if (gx > 0x7fffffffLL)
+            return fail(PAA_ERR_UNSUPPORTED, "delta grid too large (%lld frames in one clip)", maxT);
+        // gridDim.y holds at most 65 535 clips: larger batches go in blocks (advisor, round 5: they used to be refused here
+        // although run_big, which took them before round 5, loops the same way)
+        for (long long c0 = 0; c0 < p->n_clips; c0 += 65535) {
+            const unsigned ny = (unsigned)std::min<long long>(65535, p->n_clips - c0);
+            hipLaunchKernelGGL(wg::wg_delta_kernel, dim3((unsigned)gx, ny), dim3(256), 0, cs(), p->d_clips + c0, d_out);
+            HIP_TRY(hipGetLastError());
+        }
     }
     return PAA_OK;
 }
@@ -779,9 +782,9 @@ extern "C" int paa_dev_expand_deltas(const double *d_base, const int64_t *frames
             tot += T;
         }
         if (tiles.size() > 0x7fffffffULL) return fail(PAA_ERR_UNSUPPORTED, "too many tiles");
-        // (a launch that still reads the old list may be in flight on either stream)
-        if (cs()) HIP_TRY(hipStreamSynchronize(cs()));
-        { const int rc_s = comm_sync(); if (rc_s) return rc_s; }
+        // a launch that still reads the old list may be in flight on ANY lane's stream or on the communication stream (another
+        // host thread may have queued it): the list is replaced once per batch shape, so a device-wide wait is affordable
+        HIP_TRY(hipDeviceSynchronize());
         const int rc = upload_pooled(&dc.d_tiles, tiles.data(), tiles.size());
         if (rc) return rc;
         dc.n_tiles = (long long)tiles.size();

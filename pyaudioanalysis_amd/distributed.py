@@ -230,7 +230,7 @@ def mid_windows_per_clip(frames, mid_step_ratio):
 
 
 def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank, comm, root=0, engine=None,
-                    restart_dir=None, chunks=1, gather="short", mid_window=None, mid_step=None):
+                    restart_dir=None, chunks=1, gather="short", mid_window=None, mid_step=None, ship_base_rows=None):
     """Rank-local part of a sharded batch extraction.
 
     clips: the FULL list of int16 clips (every rank sees the list; only its own range is uploaded).
@@ -242,6 +242,9 @@ def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank
                        travel and the root re-forms the delta rows on its device (bit-identical, half the link bytes);
             "mid"   -- the (136, M_c) mid-term matrices of mid_feature_extraction(mid_window, mid_step in samples,
                        MidTermFeatures.py:87-127) and nothing else: 1/40 of the bytes at 1.0 s / 1.0 s over 50 / 25 ms.
+    ship_base_rows: gather="short" with deltas -- True: the 34 base rows travel and the root re-forms rows 34..67; False: all 68
+        travel; None (default): True.  A function of the ARGUMENTS only, so every rank derives the same gather sizes (it used
+        to depend on the rank's engine object: ranks with different engines would have posted mismatched sends / receives).
     restart_dir: when given, every rank leaves its finished block there (shard_<rank>_of_<world>.npz, keyed by the
         parameters and a digest of its clips) and a rerun of the same job loads the block instead of extracting it
         again -- a 100 000-clip job that died in the gather or on another rank restarts without redoing finished shards.
@@ -265,8 +268,8 @@ def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank
     elif gather == "short":
         # with deltas the ranks compute and ship the 34 BASE rows only: rows 34..67 are exact differences of consecutive columns
         # of rows 0..33 (ShortTermFeatures.py:668-680), so the root re-forms them on its device (engine.expand_deltas) -- half the
-        # bytes on the xGMI links, and the peers run the cheaper 34-row kernel.  An engine without expand_deltas ships all 68.
-        base_only = bool(deltas) and hasattr(engine, "expand_deltas")
+        # bytes on the xGMI links, and the peers run the cheaper 34-row kernel (ship_base_rows=False ships all 68).
+        base_only = bool(deltas) and (True if ship_base_rows is None else bool(ship_base_rows))
         units, n_rows = frames, (34 if (base_only or not deltas) else 68)
         what = ("short", "base34") if base_only else "short"
     else:
@@ -328,13 +331,21 @@ def extract_sharded(clips, sampling_rate, window, step, deltas, world_size, rank
         tmp = shard_file + ".tmp.npz"
         np.savez(tmp, key=np.array(key), block=np.concatenate(parts) if len(parts) > 1 else parts[0])
         os.replace(tmp, shard_file)
+    d_base = None
     if rank == root and base_only:
+        if not hasattr(engine, "expand_deltas"):
+            raise TypeError("ship_base_rows needs an engine with expand_deltas() on the root (HipEngine has it); pass "
+                            "ship_base_rows=False on EVERY rank for an engine without")
         d_full = engine.alloc(2 * int(counts.sum()))
         engine.expand_deltas(d_all, frames, d_full)          # on the device, behind the gathers
-        d_all, n_rows, total = d_full, 68, 2 * int(counts.sum())
+        # the gathered base rows stay referenced until the sync below: the expansion kernel is only QUEUED behind the gathers
+        # and still reads them (dropping the last reference here would free a buffer with a reader in flight)
+        d_base, d_all = d_all, d_full
+        n_rows, total = 68, 2 * int(counts.sum())
     else:
         total = int(counts.sum())
     engine.sync()
+    del d_base
     if rank != root:
         return None
     flat = engine.to_host(d_all, total)

@@ -35,50 +35,7 @@
 namespace paa {
 namespace reg {
 
-template <int R> struct PrimeTab;
-// cos / sin (2 pi m / R), m = 1 .. (R-1)/2, for the odd primes the register-FFT kernel instantiates
-// (generated with mpmath at 40 digits, printed to 21: scripts/gen_prime_tables.py)
-template <> struct PrimeTab<3> {
-    static constexpr double c[1] = {-0.500000000000000000000};
-    static constexpr double s[1] = {0.866025403784438646764};
-};
-template <> struct PrimeTab<5> {
-    static constexpr double c[2] = {0.309016994374947424102, -0.809016994374947424102};
-    static constexpr double s[2] = {0.951056516295153572116, 0.587785252292473129169};
-};
-template <> struct PrimeTab<7> {
-    static constexpr double c[3] = {0.623489801858733530525, -0.222520933956314404289, -0.900968867902419126236};
-    static constexpr double s[3] = {0.781831482468029808708, 0.974927912181823607018, 0.433883739117558120476};
-};
-template <> struct PrimeTab<11> {
-    static constexpr double c[5] = {0.841253532831181168862, 0.415415013001886425529, -0.142314838273285140444, -0.654860733945285064057, -0.959492973614497389890};
-    static constexpr double s[5] = {0.540640817455597582108, 0.909631995354518371412, 0.989821441880932732376, 0.755749574354258283774, 0.281732556841429697711};
-};
-template <> struct PrimeTab<13> {
-    static constexpr double c[6] = {0.885456025653209895900, 0.568064746731155802512, 0.120536680255323053349, -0.354604887042535625970, -0.748510748171101098635, -0.970941817426052027157};
-    static constexpr double s[6] = {0.464723172043768545656, 0.822983865893656394580, 0.992708874098053992801, 0.935016242685414823440, 0.663122658240795202377, 0.239315664287557767149};
-};
-template <> struct PrimeTab<17> {
-    static constexpr double c[8] = {0.932472229404355804573, 0.739008917220659115925, 0.445738355776538267396, 0.0922683594633019952397, -0.273662990072082863539, -0.602634636379256389179, -0.850217135729614152134, -0.982973099683901778282};
-    static constexpr double s[8] = {0.361241666187152948745, 0.673695643646557211713, 0.895163291355062322067, 0.995734176295034521871, 0.961825643172819070409, 0.798017227280239503333, 0.526432162877355800245, 0.183749517816570331574};
-};
-template <> struct PrimeTab<19> {
-    static constexpr double c[9] = {0.945817241700634679020, 0.789140509396393599219, 0.546948158122426874712, 0.245485487140799148922, -0.0825793454723323246003, -0.401695424652969457517, -0.677281571625741074762, -0.879473751206489071391, -0.986361303402722373603};
-    static constexpr double s[9] = {0.324699469204683487408, 0.614212712689667817444, 0.837166478262528574806, 0.969400265939330416736, 0.996584493006669849819, 0.915773326655057439919, 0.735723910673131624774, 0.475947393037073544431, 0.164594590280733894144};
-};
-template <> struct PrimeTab<23> {
-    static constexpr double c[11] = {0.962917287347799295015, 0.854419404546488552548, 0.682553143218654082875, 0.460065037731152126042, 0.203456013052633789878, -0.0682424133646709759212, -0.334879612170986151958, -0.576680322114867141251, -0.775711290704419807041, -0.917211301505453017844, -0.990685946036330752342};
-    static constexpr double s[11] = {0.269796771157024271245, 0.519583950035433578133, 0.730835964278124101651, 0.887885218402375234984, 0.979084087682322875633, 0.997668769190539198454, 0.942260922118820495618, 0.816969893010442016973, 0.631087944326052789367, 0.398401089846241457998, 0.136166649096246590761};
-};
-template <> struct PrimeTab<29> {
-    static constexpr double c[14] = {0.976620555710086683208, 0.907575419670957053620, 0.796093065705643745998, 0.647386284781827639182, 0.468408440699790139216, 0.267528338529220821195, 0.0541389085854175261499, -0.161781996552764726544, -0.370138155339914356864, -0.561187065362382369270, -0.725995491923130858138, -0.856857176167589244523, -0.947653171182802444274, -0.994137957154359608955};
-    static constexpr double s[14] = {0.214970440211024067182, 0.419889101560264576974, 0.605174215193765165924, 0.762162055127636463256, 0.883512044446022922827, 0.963549992519222960043, 0.998533413851123864572, 0.986826522541526151769, 0.928976719816791441790, 0.827688998156890556136, 0.687699458853423293084, 0.515553857177021739710, 0.319301530135979973197, 0.108119018423941763031};
-};
-template <> struct PrimeTab<31> {
-    static constexpr double c[15] = {0.979529941252494493938, 0.918957811620230629127, 0.820763441207276326364, 0.688966919075686567801, 0.528964010326962457365, 0.347305252844820285542, 0.151427777504576663657, -0.0506491688387127122788, -0.250652532258720539315, -0.440394151557634309516, -0.612105982547662844147, -0.758758122692790901913, -0.874346616144582118827, -0.954139256400048851476, -0.994869323391895146321};
-    static constexpr double s[15] = {0.201298520088660079142, 0.394355855113318580102, 0.571268215094792279157, 0.724792787229119958865, 0.848644257494750950464, 0.937752132147080458429, 0.988468324328111399162, 0.998716507171052807146, 0.968077118866204305153, 0.897804539570741657137, 0.790775736937698582078, 0.651372482722222207454, 0.485301962531081025215, 0.299363122973357954008, 0.101168321987432177786};
-};
-
+// (the PrimeTab literals moved to csrc/prime_tables.hpp in round 6; this file is an archived experiment and is no longer built)
 // output pair (k, R-k), 1 <= k <= (R-1)/2, of the length-R DFT from v0 and the sums / differences s_j = v_j + v_{R-j},
 // d_j = v_j - v_{R-j}:  X[k] = A - iB, X[R-k] = A + iB with A = v0 + sum_j s_j cos(2 pi jk/R), B = sum_j d_j sin(2 pi jk/R)
 template <int R, int K>

@@ -276,6 +276,8 @@ def test_rank0_listener_interfaces(monkeypatch):
     assert hosts("localhost") == ["127.0.0.1"]
     monkeypatch.setattr(R.socket, "gethostbyname", lambda name: {"node7": "127.0.1.1", "node8": "10.1.2.3"}.get(name, name))
     assert hosts("node7") == [""]
+    assert hosts("node7", single_node=True) == ["127.0.1.1"]      # LOCAL_WORLD_SIZE == WORLD_SIZE: nothing off the node needs it
+    assert hosts("node8", single_node=True) == ["10.1.2.3", ""]
     assert hosts("node8") == ["10.1.2.3", ""]
     assert hosts("10.1.2.3") == ["10.1.2.3", ""]
 
