@@ -261,6 +261,11 @@ int paa_debug_tri_plan(int window, double fs, int32_t *shape8, int32_t *offsets6
  * slots, threads, LDS bytes, permutation in LDS, feature kernel stages the row, its LDS bytes, then (radix, span, twiddle stride) per
  * pass}; perm[k] = padded LDS position of output k of the (sub-)transform.  Returns 1, 0 when the window goes to another path        */
 int paa_debug_wg_plan(int window, int32_t *info32, uint16_t *perm, int perm_capacity);
+/* Host side of the Bluestein kernel (kernels_blu.hpp: windows whose FFT length has a prime factor above 13; replaces
+ * scipy.fftpack.fft at ShortTermFeatures.py:617 for them): info8 = {log2 M, R0, R1, R2, waves per workgroup, LDS bytes,
+ * table_bytes, total_bytes}, offsets3 = byte offsets of {conj chirp [W], FFT(b) / M in pass order [M], pass twiddles} in the
+ * blob.  Returns the blob size, 0 when the window goes to another kernel (blob may be NULL to query the size). */
+int paa_debug_blu_plan(int window, double fs, int32_t *info8, int32_t *offsets3, unsigned char *blob, int capacity);
 /* the 64 lane jobs {start, n, woff, ctl} the three-pass kernels cut the sums of n_owners <= 64 owners (40 mel filters / 12 pitch
  * classes) into: owner k has cnt[k] consecutive entries from first[k] (weights from wfirst[k]); a job's ctl = position of the piece
  * in its owner's run of lanes | (lanes k < n_owners: the lane that ends up with owner k's total) << 8 (csrc/kernels_tri.hpp)   */

@@ -114,7 +114,7 @@ def main():
     print("total %.2f MB" % (tot / 1e6))
 
 
-if __name__ == "__main__" and not any(a in sys.argv for a in ("--dir", "--thumb", "--wide", "--silence", "--round3", "--round4", "--round5")):
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--dir", "--thumb", "--wide", "--silence", "--round3", "--round4", "--round5", "--round6")):
     main()
 
 
@@ -424,3 +424,59 @@ def round5_goldens():
 
 if __name__ == "__main__" and "--round5" in sys.argv:
     round5_goldens()
+
+
+def round6_goldens():
+    """Round 6: outputs of the unmodified reference at windows whose FFT length has a prime factor above 13 -- the shapes the
+    Bluestein kernel took over (csrc/kernels_blu.hpp; the reference takes any int(window), ShortTermFeatures.py:563-564): the
+    prime 1103 and 0.030 x 22050 = 661 (prime) on seeded 22.05 kHz clips (with their digitally silent span), 46 ms at 16 kHz =
+    736 = 2^5 x 23 on the reference's own doremi.wav, 202 = 2 x 101 (convolution length 512), the prime 2203 at 44.1 kHz
+    (length 4096), their spectrogram / chromagram, and a spectrogram at 158 = 2 x 79 (length 256: too small for the
+    reference's mel bank / chroma, its spectrogram works)."""
+    from synth import synth_clip
+    ref_st, ref_mt, ref_io = load_reference.load()
+
+    def st_case(name, sig, fs, win, step, deltas=True):
+        F, names = ref_st.feature_extraction(sig, fs, win, step, deltas)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="st", signal=sig, fs=fs, window=win, step=step,
+                            deltas=deltas, features=F, names=np.array(names))
+        print(name, F.shape)
+
+    def mid_case(name, sig, fs, mw, ms, sw, ss):
+        mid, st, names = ref_mt.mid_feature_extraction(sig, fs, mw, ms, sw, ss)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="mid", signal=sig, fs=fs, mid_window=mw, mid_step=ms,
+                            window=sw, step=ss, mid=mid, features=st, names=np.array(names))
+        print(name, mid.shape, st.shape)
+
+    def spec_case(name, sig, fs, win, step, chroma=True):
+        with contextlib.redirect_stdout(io.StringIO()):
+            S, t_ax, f_ax = ref_st.spectrogram(sig, fs, win, step)
+        extra = {}
+        if chroma:
+            C, ct_ax, cf_ax = ref_st.chromagram(sig, fs, win, step)
+            extra = dict(chromagram=C, chroma_time=np.array(ct_ax), chroma_names=np.array(cf_ax))
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="spec" if chroma else "spec_only", signal=sig, fs=fs, window=win,
+                            step=step, specgram=S, spec_time=np.array(t_ax), spec_freq=np.array(f_ax), **extra)
+        print(name, S.shape)
+
+    x22 = synth_clip(1103, 3 * 22050, 22050)
+    st_case("synth22k_1103_441", x22, 22050, 1103, 441)
+    spec_case("synth22k_spec_1103_441", x22[:22050], 22050, 1103, 441)
+    x22b = synth_clip(661, 2 * 22050, 22050)
+    st_case("synth22k_661_220", x22b, 22050, 661, 220)
+    mid_case("synth22k_mid_661_330", x22b, 22050, 22050, 11025, 661, 330)
+    spec_case("synth22k_spec_661_220", x22b[:21750], 22050, 661, 220)     # (a truncated chromagram tail frame of 409 >= 330 samples)
+    fs, x = wav("pyAudioAnalysis/data/doremi.wav", 2.5)                      # 16 kHz
+    st_case("doremi_736_368", x, fs, 736, 368)
+    x16 = synth_clip(202, 16000, 16000)
+    st_case("synth16k_202_101_nodelta", x16, 16000, 202, 101, deltas=False)
+    x44 = synth_clip(2203, 2 * 44100, 44100)
+    st_case("synth44k_2203_1100_nodelta", x44, 44100, 2203, 1100, deltas=False)
+    xs = synth_clip(5, 44100, 44100, stereo=True)
+    st_case("synth44k_stereo_to_mono_f64_1103_441", (xs[:, 1] / 2) + (xs[:, 0] / 2), 44100, 1103, 441)
+    x8 = synth_clip(158, 8000, 8000)
+    spec_case("synth8k_spec_only_158_79", x8, 8000, 158, 79, chroma=False)
+
+
+if __name__ == "__main__" and "--round6" in sys.argv:
+    round6_goldens()

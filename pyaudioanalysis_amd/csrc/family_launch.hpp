@@ -11,6 +11,7 @@
 #include "kernels_generic.hpp"
 #include "kernels_mix.hpp"
 #include "kernels_tri.hpp"
+#include "kernels_blu.hpp"
 
 namespace paa {
 namespace launch {
@@ -37,6 +38,10 @@ int tri_part_c(const tri::TriLaunch &tl, int sample_kind, const PlanDev &P, cons
 int mix(const mix::MixLayout &ml, size_t lds, int sample_kind, const PlanDev &P, const unsigned char *blob,
         const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
         hipStream_t stream);
+// kernels_blu.hpp: Bluestein convolution on power-of-two transforms (lengths with a prime factor above 13)
+int blu(const blu::BluLayout &bl, size_t lds, int sample_kind, const PlanDev &P, const unsigned char *blob,
+        const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
+        hipStream_t stream);
 // kernels_generic.hpp: Stockham passes in LDS (what is left)
 int generic(const GenLayout &gl, size_t lds, int sample_kind, const PlanDev &P, const unsigned char *blob,
             const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,
@@ -51,6 +56,7 @@ int phase_tri_a(unsigned long long *acc16, unsigned long long *trace, int max_wa
 int phase_tri_b(unsigned long long *acc16, unsigned long long *trace, int max_waves);
 int phase_tri_c(unsigned long long *acc16, unsigned long long *trace, int max_waves);
 int phase_rmg(unsigned long long *acc16, unsigned long long *trace, int max_waves);
+int phase_blu(unsigned long long *acc16, unsigned long long *trace, int max_waves);
 
 }  // namespace launch
 }  // namespace paa

@@ -15,7 +15,7 @@ extern "C" int paa_debug_phase_cycles(uint64_t *out16) {
     unsigned long long acc[16] = {0};
     // every translation unit with kernels keeps its own counters (family_*.hip)
     if (launch::phase_fast(acc, nullptr, 0) < 0 || launch::phase_ct(acc, nullptr, 0) < 0 || launch::phase_tri_a(acc, nullptr, 0) < 0 ||
-        launch::phase_tri_b(acc, nullptr, 0) < 0 || launch::phase_tri_c(acc, nullptr, 0) < 0 || launch::phase_rmg(acc, nullptr, 0) < 0)
+        launch::phase_tri_b(acc, nullptr, 0) < 0 || launch::phase_tri_c(acc, nullptr, 0) < 0 || launch::phase_rmg(acc, nullptr, 0) < 0 || launch::phase_blu(acc, nullptr, 0) < 0)
         return fail(PAA_ERR_HIP, "reading the phase counters failed");
     for (int i = 0; i < 16; ++i) out16[i] = acc[i];
 #endif
@@ -182,6 +182,28 @@ extern "C" int paa_debug_wg_plan(int window, int32_t *info32, uint16_t *perm, in
         memcpy(perm, pm.data(), (size_t)info32[4] * 2);
     }
     return 1;
+}
+// host side of the Bluestein kernel for a window (no device needed): info8 = {log2 M, R0, R1, R2, waves, LDS bytes, table_bytes,
+// total_bytes}, offsets3 = {chirp, FFT(b) / M in pass order, pass twiddles} into the blob (LDS tables first, global tables behind them).
+// Returns the blob size (0: the window goes to another kernel; blob may be null to query the size).
+extern "C" int paa_debug_blu_plan(int window, double fs, int32_t *info8, int32_t *offsets3, unsigned char *blob, int capacity) {
+    if (window < 2 || !info8 || !offsets3) return fail(PAA_ERR_ARG, "bad argument");
+    (void)fs;
+    FftPlan p;
+    build_fft_plan(window, p);
+    blu::BluLayout L;
+    std::vector<unsigned char> b;
+    if (!blu::blu_layout(p, nullptr, nullptr, 0, L, &b)) return 0;
+    int r[3];
+    blu::blu_radices(L.log2m, r);
+    info8[0] = L.log2m; info8[1] = r[0]; info8[2] = r[1]; info8[3] = r[2]; info8[4] = L.waves;
+    info8[5] = (int32_t)blu::blu_lds_bytes(L); info8[6] = L.table_bytes; info8[7] = L.total_bytes;
+    offsets3[0] = L.off_g_chirp; offsets3[1] = L.off_g_bp; offsets3[2] = L.off_g_tw;
+    if (blob) {
+        if (capacity < (int)b.size()) return fail(PAA_ERR_ARG, "blob capacity %d < %d", capacity, (int)b.size());
+        memcpy(blob, b.data(), b.size());
+    }
+    return (int)b.size();
 }
 extern "C" int paa_debug_fft_plan(int window, int32_t *radices, int32_t *fft_len) {
     if (window < 2 || !radices || !fft_len) return fail(PAA_ERR_ARG, "bad argument");

@@ -129,7 +129,31 @@ static int fam_mix_launch(paa_plan *p, const void *d_packed, double *d_out, cons
     return launch::mix(p->ml, p->lds, p->sample_kind, p->P, p->d_gen_blob, d_packed, p->d_clips, p->d_norms, tiles, n, d_out, s);
 }
 
-// ---- kernels_generic.hpp: Stockham passes in LDS (lengths with a prime factor above 13, tiny windows); windows beyond the
+// ---- kernels_blu.hpp: lengths with a prime factor above 13 (661, 1103, 736 ...): Bluestein's convolution on power-of-two transforms
+static int fam_blu_select(FamilyCtx &c) {
+    if (g_force_generic || experiment_env("PAA_NO_BLU")) return 0;
+    std::vector<unsigned char> blob;
+    if (!blu::blu_layout(c.tab->fft, c.mel(), c.chroma(), c.F, c.p->bl, &blob)) return 0;
+    const int rc = upload_blob(c.p, blob);
+    if (rc) return rc;
+    c.p->bluk = 1;
+    c.p->lds = blu::blu_lds_bytes(c.p->bl);
+    static const char *names[3][5] = {{"st_blu_256", "st_blu_512", "st_blu_1024", "st_blu_2048", "st_blu_4096"},
+                                      {"spectrogram_blu_256", "spectrogram_blu_512", "spectrogram_blu_1024", "spectrogram_blu_2048", "spectrogram_blu_4096"},
+                                      {"chromagram_blu_256", "chromagram_blu_512", "chromagram_blu_1024", "chromagram_blu_2048", "chromagram_blu_4096"}};
+    c.p->kernel_name = names[c.mode][c.p->bl.log2m - 8];
+    return 1;
+}
+static void fam_blu_rule(FamilyCtx &c, RunRule &r) {
+    // one wave per run, one frame at a time (halo: 1 frame, 2 with deltas)
+    r.quantum = 4;
+    r.run = two_round_run(c.total_frames, c.p->bl.waves, c.num_cu());
+}
+static int fam_blu_launch(paa_plan *p, const void *d_packed, double *d_out, const Tile *tiles, long long n, hipStream_t s) {
+    return launch::blu(p->bl, p->lds, p->sample_kind, p->P, p->d_gen_blob, d_packed, p->d_clips, p->d_norms, tiles, n, d_out, s);
+}
+
+// ---- kernels_generic.hpp: Stockham passes in LDS (what no other family takes: tiny windows, prime factors above 13 beyond 2730 samples); windows beyond the
 // LDS envelope take the same passes through HBM scratch (kernels_big.hpp: plan->big, no CPU fallback)
 static int fam_generic_select(FamilyCtx &c) {
     std::vector<unsigned char> blob;
@@ -159,6 +183,7 @@ static const Family kFamilies[] = {
     {"ct", fam_ct_select, fam_ct_rule, fam_ct_launch},
     {"tri", fam_tri_select, fam_tri_rule, fam_tri_launch},
     {"mix", fam_mix_select, fam_mix_rule, fam_mix_launch},
+    {"blu", fam_blu_select, fam_blu_rule, fam_blu_launch},
     {"generic", fam_generic_select, fam_generic_rule, fam_generic_launch},
 };
 constexpr int kNumFamilies = (int)(sizeof(kFamilies) / sizeof(kFamilies[0]));
@@ -167,11 +192,12 @@ constexpr int kNumFamilies = (int)(sizeof(kFamilies) / sizeof(kFamilies[0]));
 // it back instead of rebuilding the layout and uploading the table blob again
 struct FamilyChoice {
     int family = -1;
-    int fast = 0, ct = 0, tri = 0, mixk = 0, big = 0;
+    int fast = 0, ct = 0, tri = 0, mixk = 0, bluk = 0, big = 0;
     FastLaunch fl;
     ct::CtLaunch cl;
     tri::TriLaunch trl;
     mix::MixLayout ml;
+    blu::BluLayout bl;
     GenLayout gl;
     size_t lds = 0;
     std::string kernel_name;
@@ -193,8 +219,8 @@ static int choose_family(FamilyCtx &c, RunRule &rr) {
     if (it != c.tab->choices.end() && !g_force_generic) {
         const FamilyChoice &fc = *it->second;
         p->family = fc.family;
-        p->fast = fc.fast; p->ct = fc.ct; p->tri = fc.tri; p->mixk = fc.mixk; p->big = fc.big;
-        p->fl = fc.fl; p->cl = fc.cl; p->trl = fc.trl; p->ml = fc.ml; p->gl = fc.gl;
+        p->fast = fc.fast; p->ct = fc.ct; p->tri = fc.tri; p->mixk = fc.mixk; p->bluk = fc.bluk; p->big = fc.big;
+        p->fl = fc.fl; p->cl = fc.cl; p->trl = fc.trl; p->ml = fc.ml; p->bl = fc.bl; p->gl = fc.gl;
         p->lds = fc.lds; p->kernel_name = fc.kernel_name;
         p->d_gen_blob = fc.d_blob; p->blob_cached = true;
         kFamilies[p->family].run_rule(c, rr);
@@ -211,8 +237,8 @@ static int choose_family(FamilyCtx &c, RunRule &rr) {
         if (!g_force_generic) {
             auto fc = std::make_shared<FamilyChoice>();
             fc->family = i;
-            fc->fast = p->fast; fc->ct = p->ct; fc->tri = p->tri; fc->mixk = p->mixk; fc->big = p->big;
-            fc->fl = p->fl; fc->cl = p->cl; fc->trl = p->trl; fc->ml = p->ml; fc->gl = p->gl;
+            fc->fast = p->fast; fc->ct = p->ct; fc->tri = p->tri; fc->mixk = p->mixk; fc->bluk = p->bluk; fc->big = p->big;
+            fc->fl = p->fl; fc->cl = p->cl; fc->trl = p->trl; fc->ml = p->ml; fc->bl = p->bl; fc->gl = p->gl;
             fc->lds = p->lds; fc->kernel_name = p->kernel_name;
             fc->d_blob = p->d_gen_blob;            // ownership moves to the table set
             p->blob_cached = true;

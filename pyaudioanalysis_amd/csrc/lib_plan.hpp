@@ -168,6 +168,8 @@ struct paa_plan {
     FastLaunch fl;
     int mixk = 0;                    // 1: in-place mixed-radix kernel (kernels_mix.hpp); table blob in d_gen_blob
     mix::MixLayout ml;
+    int bluk = 0;                    // 1: Bluestein kernel (kernels_blu.hpp); table blob (LDS + global tables) in d_gen_blob
+    blu::BluLayout bl;
     int ct = 0;                      // 1: register-FFT family for windows 2 RA RB (kernels_ct.hpp); table blob in d_gen_blob
     ct::CtLaunch cl;
     int tri = 0;                     // 1: three-pass register FFT for the large default windows (kernels_tri.hpp); blob in d_gen_blob

@@ -801,3 +801,85 @@ def test_bench_self_launch_refuses_a_job_the_box_cannot_run(monkeypatch, capsys)
     with pytest.raises(SystemExit) as exc:
         bench.main()
     assert "WORLD_SIZE=1" in str(exc.value)
+
+
+@pytest.mark.parametrize("window", [661, 1103, 736, 202, 158, 2203, 2731, 1322])
+def test_bluestein_tables_reproduce_the_spectrum(window):
+    """Host tables of csrc/kernels_blu.hpp (no device): the kernel's passes restated in NumPy FROM THE LIBRARY'S OWN TABLES -- the
+    conjugate chirp, FFT(b) / M stored where the decimation-in-frequency passes leave each bin, the per-pass twiddles -- forward
+    DIF passes 0 / 1 / 2, product, conjugate, DIT passes 2 / 1 / 0 -- give |fft(frame)|[0:W/2] / (W/2) (ShortTermFeatures.py:617-621)
+    without any permutation.  The kernel executes exactly this index algebra on its LDS buffer."""
+    import ctypes
+    lib = _ffi.lib()
+    info = np.zeros(8, dtype=np.int32)
+    off = np.zeros(3, dtype=np.int32)
+    size = lib.paa_debug_blu_plan(window, 22050.0, info.ctypes.data_as(_ffi.c_i32p), off.ctypes.data_as(_ffi.c_i32p), None, 0)
+    assert size > 0
+    blob = np.zeros(size, dtype=np.uint8)
+    assert lib.paa_debug_blu_plan(window, 22050.0, info.ctypes.data_as(_ffi.c_i32p), off.ctypes.data_as(_ffi.c_i32p),
+                                  blob.ctypes.data_as(ctypes.c_void_p), size) == size
+    lg, R0, R1, R2, waves, lds, table_bytes, total = (int(v) for v in info)
+    M, W, Nf = 1 << lg, window, window // 2
+    assert R0 * R1 * R2 == M and M >= W + Nf - 1 and (M // 2 < W + Nf - 1 or M == 256)      # the smallest power of two that holds it
+    assert 1 <= waves <= 16 and lds <= 160 * 1024 and table_bytes % 256 == 0 and total == size
+    cplx = lambda o, n: blob[o:o + 16 * n].view(np.float64).reshape(n, 2) @ np.array([1.0, 1j])      # noqa: E731
+    S0, S1 = M // R0, M // R0 // R1
+    chirp = cplx(off[0], W)
+    bp = cplx(off[1], M)
+    tw = cplx(off[2], (R0 - 1) * S0 + (R1 - 1) * S1)
+    tw0 = tw[:(R0 - 1) * S0].reshape(R0 - 1, S0)
+    tw1 = tw[(R0 - 1) * S0:].reshape(R1 - 1, S1)
+    n = np.arange(W, dtype=np.int64)
+    assert np.allclose(chirp, np.exp(-1j * np.pi * ((n * n) % (2 * W)) / W), rtol=0, atol=1e-14)
+    rng = np.random.default_rng(window)
+    y = rng.standard_normal(W)
+    buf = np.zeros(M, dtype=complex)
+    buf[:W] = y * chirp
+    # pass 0 forward: span M, stride S0, output twiddles
+    for k in range(S0):
+        v = np.fft.fft(buf[k::S0])
+        v[1:] *= tw0[:, k]
+        buf[k::S0] = v
+    # pass 1 forward: span S0, stride S1
+    for b in range(M // R1):
+        blk, k = divmod(b, S1)
+        idx = blk * S0 + k + S1 * np.arange(R1)
+        v = np.fft.fft(buf[idx])
+        v[1:] *= tw1[:, k]
+        buf[idx] = v
+    # pass 2 forward, product, conjugate, pass 2 back -- R2 contiguous elements
+    for b in range(M // R2):
+        idx = b * R2 + np.arange(R2)
+        buf[idx] = np.fft.fft(np.conj(np.fft.fft(buf[idx]) * bp[idx]))
+    # pass 1 back: input twiddles
+    for b in range(M // R1):
+        blk, k = divmod(b, S1)
+        idx = blk * S0 + k + S1 * np.arange(R1)
+        v = buf[idx].copy()
+        v[1:] *= tw1[:, k]
+        buf[idx] = np.fft.fft(v)
+    # pass 0 back + magnitudes: natural order, bins k < Nf
+    out = np.zeros(M, dtype=complex)
+    for k in range(S0):
+        v = buf[k::S0].copy()
+        v[1:] *= tw0[:, k]
+        out[k::S0] = np.fft.fft(v)
+    got = np.abs(out[:Nf]) / Nf
+    ref = np.abs(np.fft.fft(y))[:Nf] / Nf
+    assert np.max(np.abs(got - ref)) < 1e-13 * max(1.0, ref.max())
+    # the bins the last pass can deliver: k + q S0 < Nf only for q < QMAX of the kernel's Shape
+    qmax = {16: 6, 8: 3, 4: 2}[R0]
+    assert (Nf - 1) // S0 < qmax
+
+
+def test_bluestein_kernel_takes_the_lengths_with_large_prime_factors():
+    """Which windows the Bluestein layout accepts (host side, no device): a prime factor above 13 in the FFT length, at least 64
+    bins, convolution length at most 4096; smooth lengths and the register-FFT shapes are declined."""
+    lib = _ffi.lib()
+    info = np.zeros(8, dtype=np.int32)
+    off = np.zeros(3, dtype=np.int32)
+    plan = lambda w: lib.paa_debug_blu_plan(w, 16000.0, info.ctypes.data_as(_ffi.c_i32p), off.ctypes.data_as(_ffi.c_i32p), None, 0)      # noqa: E731
+    for w, lg in ((661, 10), (1103, 11), (736, 11), (202, 9), (158, 8), (2203, 12), (2731, 12), (683, 10), (684, 11)):
+        assert plan(w) > 0 and info[0] == lg, (w, info[0])
+    for w in (800, 1024, 2400, 2205, 1323, 4800, 34, 126, 2732 + 1, 9001):      # smooth / too few bins / too long
+        assert plan(w) == 0, w

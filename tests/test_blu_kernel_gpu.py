@@ -1,0 +1,163 @@
+"""The Bluestein kernel (csrc/kernels_blu.hpp: windows whose FFT length has a prime factor above 13 -- 0.030 x 22050 = 661, the
+prime 1103, 46 ms at 16 kHz = 736 = 2^5 x 23 ...; the reference takes any int(window), ShortTermFeatures.py:563-564, :617)
+against the plain-C oracle on every frame, through the C ABI: every convolution length (256 .. 4096), every sample type,
+features / spectrogram / chromagram, both gates.  -m gpu."""
+import numpy as np
+import pytest
+
+import c_oracle
+import paa_oracle as O
+from pyaudioanalysis_amd import MidTermFeatures, ShortTermFeatures, _ffi
+from synth import synth_clip
+from test_ct_kernels_gpu import ill_info, make_signal, reference_matrix
+from test_parity_gpu import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def kernel_name(fs, w, s, kind=0, mode=0):
+    plan = _ffi.Plan(np.array([0, 20 * fs], dtype=np.int64), fs, w, s, deltas=False, sample_kind=kind, mode=mode)
+    try:
+        return plan.kernel_name
+    finally:
+        plan.destroy()
+
+
+def test_plans_dispatch_the_bluestein_kernel(gpu_lib):
+    assert kernel_name(22050, 1103, 441) == "st_blu_2048"             # prime
+    assert kernel_name(22050, 661, 220) == "st_blu_1024"              # 0.030 x 22050 = 661.5 -> 661, prime
+    assert kernel_name(16000, 736, 368, kind=1) == "st_blu_2048"      # 46 ms at 16 kHz: 2^5 x 23
+    assert kernel_name(16000, 202, 101, kind=2) == "st_blu_512"       # 2 x 101
+    assert kernel_name(44100, 2203, 1100) == "st_blu_4096"            # prime
+    assert kernel_name(8000, 158, 79, mode=1) == "spectrogram_blu_256"
+    assert kernel_name(22050, 1103, 441, mode=1) == "spectrogram_blu_2048"
+    assert kernel_name(22050, 661, 220, kind=2, mode=2) == "chromagram_blu_1024"
+    assert kernel_name(44100, 2735, 1000) in ("st_generic", "big_window_hbm_passes")      # 5 x 547: beyond the 4096-point convolution
+    assert kernel_name(22050, 1102, 441) == "st_tri_r19x29x2"         # the register-FFT shapes keep their windows
+    assert kernel_name(22050, 1100, 550) == "st_mix"
+
+
+CASES = [
+    # fs, window, step, kind, seconds, deltas
+    (22050, 1103, 441, "i16", 20, True),       # convolution length 2048
+    (22050, 1103, 1103, "stereo", 15, False),
+    (44100, 1103, 300, "f64", 5, True),
+    (22050, 661, 220, "i16", 20, True),        # 1024
+    (22050, 661, 661, "f64", 15, False),
+    (22050, 661, 330, "stereo", 10, True),
+    (16000, 736, 368, "i16", 15, True),        # even window, 2^5 x 23: 2048
+    (16000, 682, 341, "f64", 10, False),       # 2 x 11 x 31: 1024 exactly (682 + 341 - 1 = 1022)
+    (16000, 202, 101, "i16", 10, True),        # 512
+    (16000, 202, 64, "stereo", 6, False),
+    (16000, 340, 170, "i16", 8, True),         # 2^2 x 5 x 17: 512 (509 needed)
+    (44100, 2203, 1100, "i16", 12, True),      # 4096
+    (44100, 2203, 2203, "f64", 10, False),
+    (48000, 2731, 1365, "stereo", 8, True),    # the longest window of the kernel: 2731 + 1365 - 1 = 4095
+    (16000, 1366, 683, "i16", 10, False),      # 2 x 683: 2048 exactly
+    (16000, 1001 + 18, 500, "unit", 6, True),  # 1019 is prime, float input in [-1, 1]
+]
+
+
+@pytest.mark.parametrize("fs,window,step,kind,seconds,deltas", CASES,
+                         ids=["%d_%d_%d_%s_%ds_%s" % (c[0], c[1], c[2], c[3], c[4], "d" if c[5] else "n") for c in CASES])
+def test_full_matrix_against_c_oracle(gpu_lib, fs, window, step, kind, seconds, deltas):
+    assert "_blu_" in kernel_name(fs, window, step)
+    sig, mono = make_signal(kind, 9000 + window + step, seconds, fs)
+    F, names = ShortTermFeatures.feature_extraction(sig, fs, window, step, deltas)
+    ref = reference_matrix(mono, fs, window, step, deltas)
+    assert F.shape == ref.shape and len(names) == ref.shape[0]
+    assert_parity(F, ref, "%s %d/%d @%d" % (kind, window, step, fs), ill=ill_info(mono, fs, window, step), sig=(mono, fs, window, step))
+    if deltas:
+        assert np.array_equal(F[34:, 1:], F[:34, 1:] - F[:34, :-1]) and np.all(F[34:, 0] == 0.0)
+        G, _ = ShortTermFeatures.feature_extraction(sig, fs, window, step, False)
+        assert np.array_equal(G, F[:34])
+
+
+@pytest.mark.parametrize("fs,window,step,kind", [(22050, 1103, 441, "i16"), (22050, 661, 220, "stereo"), (16000, 736, 736, "f64"),
+                                                  (16000, 202, 101, "i16"), (44100, 2203, 1100, "stereo"), (8000, 158, 79, "i16"),
+                                                  (48000, 2731, 2731, "i16")])
+def test_spectrogram_chromagram_full_against_c_oracle(gpu_lib, capsys, fs, window, step, kind):
+    sig, mono = make_signal(kind, 9100 + window, 9.3, fs)
+    spec, t_ax, f_ax = ShortTermFeatures.spectrogram(sig, fs, window, step)
+    capsys.readouterr()
+    ref = c_oracle.spectrogram(mono, window, step)
+    assert spec.shape == ref.shape and len(t_ax) == ref.shape[0] and len(f_ax) == window // 2
+    assert_parity(np.ascontiguousarray(spec.T), np.ascontiguousarray(ref.T), "spectrogram %s %d/%d" % (kind, window, step))
+    if window == 158:
+        return          # (too few bins for the reference's chroma tables at 8 kHz: it raises, and so does the package)
+    # the reference FFTs what is left of a truncated last frame and fails when that is shorter than num_fft (:349-355, :288)
+    last = window + step * ((len(mono) - step - 1 - window) // step)
+    if len(mono) - last < window // 2:
+        with pytest.raises(ValueError):
+            ShortTermFeatures.chromagram(sig, fs, window, step)
+        sig, mono = sig[:last + window // 2 + 7], mono[:last + window // 2 + 7]      # a tail of num_fft + 7 samples works
+    chroma, ct_ax, cnames = ShortTermFeatures.chromagram(sig, fs, window, step)
+    cref = c_oracle.chromagram(mono, fs, window, step)
+    assert chroma.shape == cref.shape and cnames == O.CHROMA_NAMES
+    assert_parity(np.ascontiguousarray(chroma.T), np.ascontiguousarray(cref.T), "chromagram %s %d/%d" % (kind, window, step))
+
+
+def test_degenerate_clips_and_ragged_batches(gpu_lib):
+    fs, W, S = 22050, 1103, 441
+    cases = {
+        "zeros": np.zeros(5 * W, dtype=np.int16),
+        "one_window": synth_clip(91, W, fs),
+        "w_plus_s_minus_1": synth_clip(92, W + S - 1, fs),
+        "dc": np.full(4 * W, 1234, dtype=np.int16),
+    }
+    x = synth_clip(93, 3 * fs, fs).copy()
+    x[fs:2 * fs] = 0
+    cases["silence_inside"] = x
+    y = synth_clip(95, 2 * fs, fs).copy()
+    y[fs // 2:fs] = -321                       # a constant span that is not the clip mean: frames of digital silence with a DC bin
+    cases["constant_inside"] = y
+    for label, sig in cases.items():
+        F, _ = ShortTermFeatures.feature_extraction(sig, fs, W, S)
+        ref, _ = O.feature_extraction(sig, fs, W, S)
+        assert_parity(F, ref, label, sig=(sig, fs, W, S))
+    with pytest.raises(ValueError):
+        ShortTermFeatures.feature_extraction(synth_clip(94, W - 1, fs), fs, W, S)
+    lens = [W, 50000, 2 * W - 1, 96000, W + S, 7 * W + 3]
+    clips = [synth_clip(9600 + i, n, fs) for i, n in enumerate(lens)]
+    res, _ = ShortTermFeatures.feature_extraction_batch(clips, fs, W, S, deltas=True)
+    for c, r in zip(clips, res):
+        single, _ = ShortTermFeatures.feature_extraction(c, fs, W, S)
+        assert np.array_equal(single, r)
+        assert_parity(r, reference_matrix(c, fs, W, S, True), "ragged batch", ill=ill_info(c, fs, W, S), sig=(c, fs, W, S))
+
+
+def test_mid_term_on_a_prime_window(gpu_lib):
+    """mid_feature_extraction (MidTermFeatures.py:87-127) with float arguments the way callers pass them: 0.030 x 22050 = 661.5 ->
+    661 (prime) through int() (ShortTermFeatures.py:563-564)."""
+    fs = 22050
+    x = synth_clip(661, 6 * fs, fs)
+    mid, st, names = MidTermFeatures.mid_feature_extraction(x, fs, 1.0 * fs, 0.5 * fs, 0.030 * fs, 0.015 * fs)
+    rmid, rst, rnames = O.mid_feature_extraction(x, fs, 1.0 * fs, 0.5 * fs, 0.030 * fs, 0.015 * fs)
+    assert names == rnames and st.shape == rst.shape and mid.shape == rmid.shape
+    sig = (x, fs, 661, 330)
+    assert_parity(st, rst, "short 661/330", sig=sig)
+    assert_parity(mid, rmid, "mid 661/330", sig=sig)
+
+
+def test_random_windows_with_large_prime_factors(gpu_lib):
+    """40 random (fs, window, step, sample type) shapes the Bluestein layout accepts, whole matrices against the oracle."""
+    rng = np.random.default_rng(6)
+    done = 0
+    while done < 40:
+        fs = int(rng.choice([8000, 11025, 16000, 22050, 32000, 44100, 48000]))
+        window = int(rng.integers(200, 2732))
+        step = int(rng.integers(window // 4, window + 1))
+        try:
+            name = kernel_name(fs, window, step)
+        except Exception:
+            continue                            # (mel bins beyond num_fft / chroma slots beyond the bins: the reference raises too)
+        if "_blu_" not in name:
+            continue
+        kind = ("i16", "f64", "stereo")[done % 3]
+        deltas = bool(done % 2)
+        sig, mono = make_signal(kind, 7000 + done, 40.0 * window / fs, fs)
+        F, _ = ShortTermFeatures.feature_extraction(sig, fs, window, step, deltas)
+        ref = reference_matrix(mono, fs, window, step, deltas)
+        assert_parity(F, ref, "%s %d/%d @%d (%s)" % (kind, window, step, fs, name), ill=ill_info(mono, fs, window, step),
+                      sig=(mono, fs, window, step))
+        done += 1

@@ -46,7 +46,7 @@ def test_plans_dispatch_the_mixed_radix_kernel(gpu_lib):
     assert name(44100, 1102, 441, kind=2, mode=1) == "spectrogram_tri_r19x29x2"   # its rows too since round 5 (one slot, sixteen waves per CU)
     assert name(44100, 1102, 441, mode=2) == "chromagram_tri_r19x29x2"
     assert name(16000, 800, 400) == "st_fast_800_w8"
-    assert name(22050, 1103, 441) == "st_generic"              # 1103 is prime: Stockham passes with an O(R^2) radix
+    assert name(22050, 1103, 441) == "st_blu_2048"             # 1103 is prime: Bluestein convolution of length 2048 (round 6; st_generic until then)
 
 
 CASES = [
