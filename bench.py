@@ -88,7 +88,12 @@ SHAPES = {
     "fast_s800": (16000, 800, 800, 30, 1000, 0, 0, 1),             # 50 ms / 50 ms (audioTrainTest.py:28-29), 1000 clips, 68 rows
     "mix_4800": (96000, 4800, 2400, 300, 1, 0, 0, 0),              # 50 ms at 96 kHz: the in-place mixed-radix kernel, full instance
     "mix_256": (16000, 256, 128, 3600, 1, 0, 0, 0),                # 16 ms windows: its lean, skewed instance
-    "generic_1103": (22050, 1103, 441, 600, 1, 0, 0, 0),           # a prime window: Stockham passes in LDS
+    "blu_1103": (22050, 1103, 441, 3600, 1, 0, 0, 0),               # a prime window: Bluestein convolution of length 2048 (st_generic until round 5)
+    "blu_661": (22050, 661, 220, 3600, 1, 0, 0, 0),                 # 0.030 x 22050 = 661 (prime): convolution length 1024
+    "blu_736": (16000, 736, 368, 1800, 1, 0, 0, 0),                # 46 ms at 16 kHz = 2^5 x 23: length 2048
+    "blu_1103_spectrogram": (22050, 1103, 441, 1800, 1, 0, 1, 0),
+    "blu_2203": (44100, 2203, 1100, 1200, 1, 0, 0, 0),             # a prime 50 ms window at 44.1 kHz: convolution length 4096
+    "blu_202": (16000, 202, 101, 1800, 1, 0, 0, 0),                # 2 x 101: length 512
     "big_16000": (16000, 16000, 8000, 600, 1, 0, 0, 0),            # music_thumbnailing's 1 s window (audioSegmentation.py:1137)
     "big_16000_1h": (16000, 16000, 8000, 3600, 1, 0, 0, 0),        # ... on the one-hour clip (7 199 frames: 28 per CU)
     "big_16000_68": (16000, 16000, 8000, 600, 1, 0, 0, 1),         # ... with deltas, as music_thumbnailing calls it
@@ -246,6 +251,12 @@ def other_configs(ffi, steps=10):
     run_shape("w1920", "w1920_48kHz", "20 min at 48 kHz, 40 ms / 40 ms (1920 / 1920)")
     run_shape("w551_11k", "w551_11kHz", "1 h at 11.025 kHz, 50 ms / 25 ms (551 / 275, odd window 19 x 29)")
     run_shape("w551_22k", "w551_22kHz", "30 min at 22.05 kHz, 25 ms / 10 ms (551 / 220)")
+    # windows whose FFT length has a prime factor above 13 (the reference takes any int(window), :563-564): Bluestein kernel
+    run_shape("blu_1103", "w1103_22kHz", "1 h at 22.05 kHz, window 1103 (prime) / step 441: chirp convolution of length 2048")
+    run_shape("blu_661", "w661_22kHz", "1 h at 22.05 kHz, 30 ms / 10 ms (661, prime / 220): convolution length 1024")
+    run_shape("blu_736", "w736_16kHz", "30 min at 16 kHz, 46 ms / 23 ms (736 = 2^5 x 23 / 368): convolution length 2048")
+    run_shape("blu_1103_spectrogram", "w1103_spectrogram", "30 min at 22.05 kHz, 1103 / 441, spectrogram rows")
+    run_shape("mix_256", "w256_16kHz", "1 h at 16 kHz, window 256 / step 128")
     # the window of music_thumbnailing (audioSegmentation.py:1137: 1 s / 0.5 s): beyond the LDS envelope, passes through HBM
     run_shape("big_16000", "w16000_16kHz", "10 min at 16 kHz, 1 s / 0.5 s (16000 / 8000): one workgroup per frame, transform in LDS", launches=20)
     run_shape("big_16000_1h", "w16000_16kHz_1h", "1 h at 16 kHz, 16000 / 8000", launches=10)

@@ -30,7 +30,9 @@
 //   pass 1'  : DIT radix R1 (input twiddles)
 //   pass 0'  : DIT radix R0; only the outputs k < Nf are formed (the others are dead code in the codelet), |.| / Nf goes to
 //              the frame's spectrum -- held in registers until every lane has read its operands (the spectrum overlaps the buffer)
-//   features : kernels_mix.hpp's spectral stage (run-time Nf), rows staged [kFlush][F] and stored as row segments
+//   features : kernels_mix.hpp's spectral stage (run-time Nf); lane = feature row, a row's values wait in eight registers until a
+//              64-byte aligned chunk is complete (kernels_tri.hpp: row_put) -- no staging tile in LDS: 38 KB per wave at M = 2048,
+//              four waves per CU
 //
 // Replaces the while loop at ShortTermFeatures.py:608-682 (+ helpers :22-140, :236-321) and the loops of spectrogram
 // (:415-422) / chromagram (:349-359) for those windows.
@@ -38,14 +40,21 @@
 #include <vector>
 
 #include "kernels_mix.hpp"
+#include "kernels_tri.hpp"        // row_put: a feature row's pending 64-byte chunk in registers
 
 namespace paa {
 namespace blu {
+#if defined(PAA_F800_TIMING) || defined(PAA_F800_TRACE)
+using f800::g_phase_cycles;
+using f800::g_wave_trace;
+#endif
 
 template <int LOG2M> struct Sched;
-template <> struct Sched<8> { static constexpr int R0 = 4, R1 = 8, R2 = 8, NW = 16; };
-template <> struct Sched<9> { static constexpr int R0 = 8, R1 = 8, R2 = 8, NW = 12; };
-template <> struct Sched<10> { static constexpr int R0 = 16, R1 = 8, R2 = 8, NW = 8; };
+// NW = waves per workgroup: it sets the register budget (512 / ceil(NW / 4) per lane).  More waves than these spilled to scratch --
+// 288 bytes per lane at M = 1024 with eight waves, and 12 x the algorithmic bytes in HBM writes (profiles/r06_blu_661_w8_summary.json)
+template <> struct Sched<8> { static constexpr int R0 = 4, R1 = 8, R2 = 8, NW = 8; };
+template <> struct Sched<9> { static constexpr int R0 = 8, R1 = 8, R2 = 8, NW = 8; };
+template <> struct Sched<10> { static constexpr int R0 = 16, R1 = 8, R2 = 8, NW = 4; };
 template <> struct Sched<11> { static constexpr int R0 = 16, R1 = 16, R2 = 8, NW = 4; };
 template <> struct Sched<12> { static constexpr int R0 = 16, R1 = 16, R2 = 16, NW = 2; };
 
@@ -59,6 +68,16 @@ struct Shape {
     static constexpr int TW0 = 0, TW1 = (R0 - 1) * S0, NTW = TW1 + (R1 - 1) * S1;      // twiddle tables [q - 1][k] of pass 0 / 1
     // outputs of the last pass that can be bins: k + q S0 < Nf <= (M + 1) / 3
     static constexpr int QMAX = (R0 == 16) ? 6 : (R0 == 8 ? 3 : 2);
+    // rows of pass 0 that can hold samples: W <= (2 M + 3) / 3 (M >= W + W / 2 - 1), the rows from RZ on are zeros for every window
+    static constexpr int WMAX = (2 * M + 3) / 3, RZ = (WMAX + S0 - 1) / S0;
+    static constexpr int NB0 = S0 / 64;                        // pass-0 butterflies per lane
+    // the chirp values of a frame are requested at the top of the frame when they fit the registers beside the frame's samples (two
+    // butterflies per lane: 44 + 22 doubles); M = 4096 (four: 88 + 44) fetches them butterfly by butterfly inside pass 0
+    static constexpr bool CHIRP_AHEAD = NB0 <= 2;
+    static constexpr bool SEEDS_RESIDENT = NB0 <= 2;           // pass-0 twiddle seeds live in registers for the whole run (else: fetched per use)
+    static constexpr int NSD0 = SEEDS_RESIDENT ? NB0 : 1;
+    static constexpr int NCW = CHIRP_AHEAD ? NB0 : 1;
+    static constexpr int NB2 = (M / R2 + 63) / 64, U2 = (NB2 >= 2 && R2 <= 8) ? 2 : 1;      // pass 2: butterflies per lane, in flight
     static_assert(R0 * R1 * R2 == M && S1 == R2, "three passes");
     static_assert(S0 % 64 == 0, "pass 0: every lane has the same number of butterflies");
 };
@@ -74,48 +93,99 @@ struct BluLayout {
     int off_g_chirp;     // global part: double2 [W]: conj(c[n])
     int off_g_bp;        // double2 [M]: FFT(b) / M at the positions the DIF passes leave the bins
     int off_g_tw;        // double2 [NTW]: pass tables
+    int off_g_meljob, off_g_chjob;      // int4 [64] each: the lane jobs of the mel sums / the chroma gather (kernels_tri.hpp: LaneJob)
     int total_bytes;
 };
 
-__device__ __forceinline__ int sw(int e) { return e ^ ((e >> 4) & 15); }
+__device__ __forceinline__ constexpr int sw(int e) { return e ^ ((e >> 4) & 15); }
+// the swizzle is linear over GF(2): for a compile-time offset c whose bits are clear in `base`, sw(base + c) = sw(base) ^ sw(c) --
+// one XOR per element of a butterfly (base is the butterfly's first element: the offsets r S of its other elements fill bit
+// fields that are zero in it) instead of shift / and / xor / add
+#define PAA_BLU_AT(swbase, c) ((swbase) ^ sw(c))
 
-// ---- pass 0 forward, fused with the chirp: y (doubles at the front of the buffer) -> buf
+// The twiddles of a butterfly, W^(q k) for q = 1 .. R - 1, depend on the lane only -- not on the frame: a lane keeps the SEEDS
+// W^k, W^2k, W^3k, W^4k of its butterflies in registers for the whole run (loaded once from the pass tables) and forms the others
+// as products of at most three table values (relative error <= 3 ulp): no twiddle loads inside the frame loop.  (The first
+// version fetched 15 twiddles per radix-16 butterfly from the L2 in every pass: 92 loads of 1 KB per wave and frame, and
+// one exposed L2 round trip per butterfly.)
+struct Seeds {
+    double2 w[4];           // W^(j k), j = 1 .. 4
+};
+__device__ __forceinline__ Seeds load_seeds(const double2 *__restrict__ tab, int stride, int k, int radix) {
+    Seeds sd;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sd.w[j] = (j + 1 < radix) ? tab[j * stride + k] : make_double2(1.0, 0.0);
+    return sd;
+}
+template <int R>
+__device__ __forceinline__ void expand_twiddles(const Seeds &sd, double2 *w) {      // w[q] = W^(q k), q = 1 .. R - 1
+#pragma unroll
+    for (int q = 1; q < R && q <= 4; ++q) w[q] = sd.w[q - 1];
+    if constexpr (R >= 8) {
+        w[5] = cmul(sd.w[3], sd.w[0]);
+        w[6] = cmul(sd.w[3], sd.w[1]);
+        w[7] = cmul(sd.w[3], sd.w[2]);
+    }
+    if constexpr (R >= 16) {
+        w[8] = cmul(sd.w[3], sd.w[3]);
+        w[9] = cmul(w[8], sd.w[0]);
+        w[10] = cmul(w[8], sd.w[1]);
+        w[11] = cmul(w[8], sd.w[2]);
+        w[12] = cmul(w[8], sd.w[3]);
+        w[13] = cmul(w[12], sd.w[0]);
+        w[14] = cmul(w[12], sd.w[1]);
+        w[15] = cmul(w[12], sd.w[2]);
+    }
+}
+
+// ---- pass 0 forward, fused with the chirp: y (doubles at the front of the buffer) -> buf.  The chirp values of a lane are
+// requested at the top of the frame (chirp_prefetch: their L2 round trip runs under the frame load and the time-domain stage)
 template <typename SH>
-__device__ __forceinline__ void fwd_pass0(double2 *buf, const double2 *__restrict__ g_chirp, const double2 *__restrict__ g_tw,
-                                          int W, int lane) {
-    constexpr int R = SH::R0, S = SH::S0, NB = S / 64;
+__device__ __forceinline__ void chirp_prefetch(const double2 *__restrict__ g_chirp, int W, int lane, double2 (&cw)[SH::NCW][SH::RZ]) {
+    if constexpr (SH::CHIRP_AHEAD) {
+#pragma unroll
+        for (int u = 0; u < SH::NB0; ++u)
+#pragma unroll
+            for (int r = 0; r < SH::RZ; ++r) cw[u][r] = g_chirp[min(lane + 64 * u + r * SH::S0, W - 1)];      // (beyond W: y is 0)
+    }
+}
+template <typename SH>
+__device__ __forceinline__ void fwd_pass0(double2 *buf, const double2 *__restrict__ g_chirp, const double2 (&cw)[SH::NCW][SH::RZ],
+                                          const Seeds *sd0, const double2 *__restrict__ g_tw, int W, int lane) {
+    constexpr int R = SH::R0, S = SH::S0, NB = SH::NB0, RZ = SH::RZ;
     const double *st = reinterpret_cast<const double *>(buf);
-    double y[NB][R];
+    double y[NB][RZ];
 #pragma unroll
     for (int u = 0; u < NB; ++u)
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
+        for (int r = 0; r < RZ; ++r) {
             const int n = lane + 64 * u + r * S;
             y[u][r] = (n < W) ? st[min(n, W - 1)] : 0.0;
         }
     wsync();           // every lane has its samples: the buffer may be overwritten
-    const double2 *tw = g_tw + SH::TW0;
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int k = lane + 64 * u;
-        double2 v[R], w[R];
+        double2 v[R], w[R], cu[RZ];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            // rows at or beyond W are zeros for every lane: no chirp loads (r S >= W is wave-uniform)
-            if (r * S < W) {
-                const double2 cw = g_chirp[min(k + r * S, W - 1)];
-                v[r] = make_double2(y[u][r] * cw.x, y[u][r] * cw.y);
-            } else {
-                v[r] = make_double2(0.0, 0.0);
-            }
+        for (int r = 0; r < RZ; ++r) {
+            if constexpr (SH::CHIRP_AHEAD) cu[r] = cw[u < SH::NCW ? u : 0][r];
+            else cu[r] = g_chirp[min(k + r * S, W - 1)];
         }
 #pragma unroll
-        for (int q = 1; q < R; ++q) w[q] = tw[(q - 1) * S + k];
+        for (int r = 0; r < R; ++r)
+            v[r] = (r < RZ) ? make_double2(y[u][r < RZ ? r : 0] * cu[r < RZ ? r : 0].x, y[u][r < RZ ? r : 0] * cu[r < RZ ? r : 0].y)
+                            : make_double2(0.0, 0.0);
         mix::Bfly<R>::run(v);
+        // (M = 4096: four butterflies per lane -- their seeds are fetched where they are used instead of living in 64 registers)
+        expand_twiddles<R>(SH::SEEDS_RESIDENT ? sd0[SH::SEEDS_RESIDENT ? u : 0] : load_seeds(g_tw + SH::TW0, S, k, R), w);
 #pragma unroll
         for (int q = 1; q < R; ++q) v[mix::Bfly<R>::pos(q)] = cmul(v[mix::Bfly<R>::pos(q)], w[q]);
+        const int swk = sw(k);          // (k < S: the fields of q S are clear)
 #pragma unroll
-        for (int q = 0; q < R; ++q) buf[sw(k + q * S)] = v[mix::Bfly<R>::pos(q)];
+        for (int q = 0; q < R; ++q) buf[PAA_BLU_AT(swk, q * S)] = v[mix::Bfly<R>::pos(q)];
+        // (four butterflies per lane: the scheduler would fetch the operands of all of them first -- 1 KB of scratch per lane at M = 4096)
+        if constexpr (NB > 2) __builtin_amdgcn_sched_barrier(0);
     }
     wsync();
 }
@@ -130,13 +200,15 @@ __device__ __forceinline__ void locate(int b, int &base, int &k) {
 
 // ---- pass 1: DIF (FWD: output twiddles) or DIT (!FWD: input twiddles) over the blocks of S0 elements
 template <typename SH, bool FWD>
-__device__ __forceinline__ void pass1(double2 *buf, const double2 *__restrict__ g_tw, int lane) {
+__device__ __forceinline__ void pass1(double2 *buf, const Seeds &sd1, int lane) {
     constexpr int R = SH::R1, SPAN = SH::SP1, S = SH::S1, NBT = SH::M / R, NB = (NBT + 63) / 64;
-    constexpr int U = (NB >= 2 && R <= 8) ? 2 : 1;          // butterflies in flight per lane (radix 16: 62 registers of operands each)
-    const double2 *tw = g_tw + SH::TW1;
+    constexpr int U = (NB >= 2 && R <= 8) ? 2 : 1;          // butterflies in flight per lane (radix 16: 32 registers of operands each)
+    static_assert(S <= 64 && 64 % S == 0, "every butterfly of a lane has the same offset k = lane mod S: one set of twiddles");
+    double2 w[R];
+    expand_twiddles<R>(sd1, w);
 #pragma unroll
     for (int u0 = 0; u0 < NB; u0 += U) {
-        double2 v[U][R], w[U][R];
+        double2 v[U][R];
         int base[U], k[U];
         bool act[U];
 #pragma unroll
@@ -144,53 +216,63 @@ __device__ __forceinline__ void pass1(double2 *buf, const double2 *__restrict__ 
             const int b = lane + 64 * (u0 + u);
             act[u] = (NBT % 64 == 0) || b < NBT;
             locate<R, SPAN>(act[u] ? b : NBT - 1, base[u], k[u]);
+            base[u] = sw(base[u]);          // (base = blk SPAN + k, k < S: the fields of r S are clear)
 #pragma unroll
-            for (int r = 0; r < R; ++r) v[u][r] = buf[sw(base[u] + r * S)];
-#pragma unroll
-            for (int q = 1; q < R; ++q) w[u][q] = tw[(q - 1) * S + k[u]];
+            for (int r = 0; r < R; ++r) v[u][r] = buf[PAA_BLU_AT(base[u], r * S)];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!FWD) {
 #pragma unroll
-                for (int r = 1; r < R; ++r) v[u][r] = cmul(v[u][r], w[u][r]);
+                for (int r = 1; r < R; ++r) v[u][r] = cmul(v[u][r], w[r]);
             }
             mix::Bfly<R>::run(v[u]);
             if (FWD) {
 #pragma unroll
-                for (int q = 1; q < R; ++q) v[u][mix::Bfly<R>::pos(q)] = cmul(v[u][mix::Bfly<R>::pos(q)], w[u][q]);
+                for (int q = 1; q < R; ++q) v[u][mix::Bfly<R>::pos(q)] = cmul(v[u][mix::Bfly<R>::pos(q)], w[q]);
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (act[u]) {
 #pragma unroll
-                for (int q = 0; q < R; ++q) buf[sw(base[u] + q * S)] = v[u][mix::Bfly<R>::pos(q)];
+                for (int q = 0; q < R; ++q) buf[PAA_BLU_AT(base[u], q * S)] = v[u][mix::Bfly<R>::pos(q)];
             }
+        if constexpr (NB > 2) __builtin_amdgcn_sched_barrier(0);
     }
     wsync();
 }
 
-// ---- pass 2 forward + product with FFT(b) / M + conjugate + pass 2 back: the R2 elements of a butterfly are contiguous
+// ---- pass 2 forward + product with FFT(b) / M + conjugate + pass 2 back: the R2 elements of a butterfly are contiguous.
+// FFT(b) / M comes from the L2: the values of a batch of butterflies are requested one batch ahead (bp_load; the first batch
+// before pass 1 starts), so that their round trip runs under a batch of butterflies instead of in front of it
 template <typename SH>
-__device__ __forceinline__ void pass2_product(double2 *buf, const double2 *__restrict__ g_bp, int lane) {
-    constexpr int R = SH::R2, NBT = SH::M / R, NB = (NBT + 63) / 64;
-    constexpr int U = (NB >= 2 && R <= 8) ? 2 : 1;
+__device__ __forceinline__ void bp_load(const double2 *__restrict__ g_bp, int lane, int u0, double2 (&bp)[SH::U2][SH::R2]) {
+    constexpr int R = SH::R2, NBT = SH::M / R;
+#pragma unroll
+    for (int u = 0; u < SH::U2; ++u) {
+        const int b = min(lane + 64 * (u0 + u), NBT - 1);
+#pragma unroll
+        for (int q = 0; q < R; ++q) bp[u][q] = g_bp[b * R + q];
+    }
+}
+template <typename SH>
+__device__ __forceinline__ void pass2_product(double2 *buf, const double2 *__restrict__ g_bp, double2 (&bp)[SH::U2][SH::R2], int lane) {
+    constexpr int R = SH::R2, NBT = SH::M / R, NB = SH::NB2, U = SH::U2;
 #pragma unroll
     for (int u0 = 0; u0 < NB; u0 += U) {
-        double2 v[U][R], bp[U][R];
+        double2 v[U][R], bp_next[U][R];
         int base[U];
         bool act[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int b = lane + 64 * (u0 + u);
             act[u] = (NBT % 64 == 0) || b < NBT;
-            base[u] = (act[u] ? b : NBT - 1) * R;
+            base[u] = sw((act[u] ? b : NBT - 1) * R);          // (multiples of R: the low bits are clear)
 #pragma unroll
-            for (int r = 0; r < R; ++r) v[u][r] = buf[sw(base[u] + r)];
-#pragma unroll
-            for (int q = 0; q < R; ++q) bp[u][q] = g_bp[base[u] + q];
+            for (int r = 0; r < R; ++r) v[u][r] = buf[PAA_BLU_AT(base[u], r)];
         }
+        if (u0 + U < NB) bp_load<SH>(g_bp, lane, u0 + U, bp_next);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             mix::Bfly<R>::run(v[u]);
@@ -208,28 +290,33 @@ __device__ __forceinline__ void pass2_product(double2 *buf, const double2 *__res
         for (int u = 0; u < U; ++u)
             if (act[u]) {
 #pragma unroll
-                for (int q = 0; q < R; ++q) buf[sw(base[u] + q)] = v[u][q];
+                for (int q = 0; q < R; ++q) buf[PAA_BLU_AT(base[u], q)] = v[u][q];
             }
+        if (u0 + U < NB) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int q = 0; q < R; ++q) bp[u][q] = bp_next[u][q];
+        }
     }
     wsync();
 }
 
 // ---- pass 0 back (DIT, input twiddles) + |.| / Nf (ShortTermFeatures.py:617-621): bins k + q S0 < Nf only
 template <typename SH>
-__device__ __forceinline__ void back_pass0_magnitudes(const double2 *buf, double *cur, const double2 *__restrict__ g_tw, int Nf,
-                                                      int lane) {
+__device__ __forceinline__ void back_pass0_magnitudes(const double2 *buf, double *cur, const Seeds *sd0, const double2 *__restrict__ g_tw,
+                                                      int Nf, int lane) {
     constexpr int R = SH::R0, S = SH::S0, NB = S / 64, QM = SH::QMAX;
-    const double2 *tw = g_tw + SH::TW0;
     const double invNf = 1.0 / (double)Nf;
     double res[NB][QM];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int k = lane + 64 * u;
         double2 v[R], w[R];
+        const int swk = sw(k);
 #pragma unroll
-        for (int r = 0; r < R; ++r) v[r] = buf[sw(k + r * S)];
-#pragma unroll
-        for (int r = 1; r < R; ++r) w[r] = tw[(r - 1) * S + k];
+        for (int r = 0; r < R; ++r) v[r] = buf[PAA_BLU_AT(swk, r * S)];
+        expand_twiddles<R>(SH::SEEDS_RESIDENT ? sd0[SH::SEEDS_RESIDENT ? u : 0] : load_seeds(g_tw + SH::TW0, S, k, R), w);
 #pragma unroll
         for (int r = 1; r < R; ++r) v[r] = cmul(v[r], w[r]);
         mix::Bfly<R>::run(v);
@@ -238,6 +325,7 @@ __device__ __forceinline__ void back_pass0_magnitudes(const double2 *buf, double
             const double2 z = v[mix::Bfly<R>::pos(q)];
             res[u][q] = mag_sqrt(fma(z.x, z.x, z.y * z.y)) * invNf;
         }
+        if constexpr (NB > 2) __builtin_amdgcn_sched_barrier(0);
     }
     wsync();           // every lane has read its operands: the spectrum may overwrite the buffer
 #pragma unroll
@@ -250,56 +338,59 @@ __device__ __forceinline__ void back_pass0_magnitudes(const double2 *buf, double
     wsync();
 }
 
-// load + normalise one frame as doubles at st[0 .. W); returns (wave-uniform) whether all samples are equal, y0 = sample 0
-template <typename T>
-__device__ __forceinline__ bool frame_load_real(const PlanDev &P, const T *__restrict__ x, const ClipNorm &nm, double *st, int lane,
-                                                double &y0) {
+// The samples of a frame: all NL = ceil(WMAX / 64) loads of the lane in flight at once (frame_request, index clamped at W - 1),
+// then normalised + written to st[0 .. W) (frame_commit).
+template <typename T, typename SH>
+__device__ __forceinline__ void frame_request(const T *__restrict__ x, int W, int lane, double (&q)[(SH::WMAX + 63) / 64 + 1]) {
+    constexpr int NL = (SH::WMAX + 63) / 64;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) q[i] = load_sample<T>(x + min(lane + kWave * i, W - 1));
+    q[NL] = load_sample<T>(x);          // (sample 0: every lane compares against it)
+}
+// returns (wave-uniform) whether all samples of the frame are equal; y0 = sample 0
+template <typename T, typename SH>
+__device__ __forceinline__ bool frame_commit(const PlanDev &P, const double (&q)[(SH::WMAX + 63) / 64 + 1], const ClipNorm &nm, double *st,
+                                             int lane, double &y0) {
+    constexpr int NL = (SH::WMAX + 63) / 64;
     const double sc = sample_scale<T>();
     const int W = P.W;
-    double first = 0.0;
+    const double first = fma(q[NL], sc, -nm.mean) * nm.inv;
     bool differs = false;
-    int n = lane;
-    {
-        // (lane 0's first sample is sample 0; every lane compares against it after the broadcast below)
-        const double q0 = load_sample<T>(x);
-        first = fma(q0, sc, -nm.mean) * nm.inv;
-    }
-    for (; n + 3 * kWave < W; n += 4 * kWave) {
-        double q[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) q[u] = load_sample<T>(x + n + kWave * u);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const double yv = fma(q[u], sc, -nm.mean) * nm.inv;
+    for (int i = 0; i < NL; ++i) {
+        const int n = lane + kWave * i;
+        const double yv = fma(q[i], sc, -nm.mean) * nm.inv;
+        if (n < W) {
             differs |= (yv != first);
-            st[n + kWave * u] = yv;
+            st[n] = yv;
         }
-    }
-    for (; n < W; n += kWave) {
-        const double yv = fma(load_sample<T>(x + n), sc, -nm.mean) * nm.inv;
-        differs |= (yv != first);
-        st[n] = yv;
     }
     y0 = first;
     wsync();
     return __ballot(differs) == 0ull;
 }
 
-// zcr count, energy and energy entropy of the normalised frame (contiguous doubles): kernels_mix.hpp's time_features_chunked
-// on the plain layout (ShortTermFeatures.py:22-51)
-__device__ __forceinline__ TimeFeat time_features_real(const double *y, const mix::Chunk &ch, int lane) {
-    double ea = 0.0, eb = 0.0;
+// zcr count, energy and energy entropy of the normalised frame (contiguous doubles), ShortTermFeatures.py:22-51.  Lane l owns the
+// contiguous chunk of kernels_mix.hpp (make_chunk).  The ten block energies come from the RUNNING energy at the block boundaries
+// (one wave scan of the lanes' chunk energies; the lane whose chunk contains boundary j writes the running value there to bnd[j]):
+// kernels_mix.hpp reduces every block over the wave -- eleven reductions of ~25 instructions each per stage, a fifth of this
+// kernel's frame at one wave per SIMD.
+__device__ __forceinline__ TimeFeat time_features_real(const double *y, const mix::Chunk &ch, int W, int LT, double *bnd, int lane) {
+    double own = 0.0;
     int zc = 0;
     auto sgn = [](double x) {
         const int hi = __double2hiint(x), lo = __double2loint(x);
         return (((hi & 0x7fffffff) | lo) != 0) ? ((hi >> 31) | 1) : 0;
     };
     int sprev = sgn(y[max(ch.kb - 1, 0)]);                 // (lane 0: sample 0 against itself counts nothing)
+    // first boundary at or after the lane's first sample; the running energy BEFORE sample jb LT is bnd[jb]
+    const int jb = (ch.kb + LT - 1) / LT;
+    const int kbound = jb * LT;
+    double part = 0.0;                                     // chunk energy before the boundary
+    bool hit = false;
     auto one = [&](int n, double x) {
-        const double sq = x * x;
-        const double sa = (n < ch.bound) ? sq : 0.0;
-        ea += sa;
-        eb += sq - sa;
+        if (n == kbound) { part = own; hit = true; }
+        own = fma(x, x, own);
         const int sx = sgn(x);
         zc += abs(sx - sprev);
         sprev = sx;
@@ -313,20 +404,147 @@ __device__ __forceinline__ TimeFeat time_features_real(const double *y, const mi
         for (int u = 0; u < 4; ++u) one(ch.kb + i + u, v[u]);
     }
     for (int n = ch.kb + i; n < ch.ke; ++n) one(n, y[n]);
-    double eblk[10], e_tail;
-    mix::block_sums(ch, ea, eb, eblk, e_tail);
+    const double incl = wscan_incl(own);
+    const double before = incl - own;
     TimeFeat tf;
-    tf.e_tot = e_tail;
-#pragma unroll
-    for (int j = 0; j < 10; ++j) tf.e_tot += eblk[j];
+    tf.e_tot = readlane63(incl);
+    if (hit && jb <= 10) bnd[jb] = before + part;
+    if (10 * LT == W && lane == 0) bnd[10] = tf.e_tot;     // (the blocks tile the frame: no sample sits on boundary 10)
     tf.zc = wsum_i(zc);
-    double num = 0.0;
-#pragma unroll
-    for (int j = 0; j < 10; ++j)
-        if (lane == j) num = eblk[j];
-    const double s = fast_div(num, tf.e_tot + kEps);
+    wsync();
+    const int ib = min(lane, 9);
+    const double s = fast_div(bnd[ib + 1] - bnd[ib], tf.e_tot + kEps);
     tf.ent_e = wsum((lane < 10) ? -(s * fast_log2(s + kEps)) : 0.0);
+    wsync();
     return tf;
+}
+
+// the 34 base features of one frame into fv[0..33] (ShortTermFeatures.py:626-667): kernels_mix.hpp's frame_features_chunked with
+// the block energies from the running energy at the block boundaries (see above; the roll-off needs that scan anyway), the mel sums
+// and the chroma gather cut into lane jobs on all 64 lanes and the 13 x 40 DCT on 52 lanes (kernels_tri.hpp)
+__device__ __forceinline__ void frame_features_blu(const PlanDev &P, const Tabs &tb, const TimeFeat &tf, const double *cur,
+                                                   const double *prv, double *fv, double *msp, double *bnd, const mix::Chunk &ch,
+                                                   const int4 mjob, const int4 cjob, int lane) {
+    const int W = P.W, Nf = P.Nf, LB = P.blk_f;
+    const double f0 = P.fs / (2.0 * (double)Nf);
+    // ---------- sweep A over the lane's bins: sums, max, chunk energy (:57-107)
+    double sX = 0.0, sXp = 0.0, sIX = 0.0, mx = 0.0, own = 0.0;
+    auto sweep_a = [&](int k, double X, double Xp) {
+        sX += X;
+        sXp += Xp;
+        sIX = fma((double)(k + 1), X, sIX);
+        mx = fmax(mx, X);
+        own = fma(X, X, own);
+    };
+    {
+        int i = 0;
+        for (; i + 4 <= ch.base; i += 4) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = cur[ch.kb + i + u]; b[u] = prv[ch.kb + i + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sweep_a(ch.kb + i + u, a[u], b[u]);
+        }
+        for (int k = ch.kb + i; k < ch.ke; ++k) sweep_a(k, cur[k], prv[k]);
+    }
+    const double incl = wscan_incl(own);
+    const double before = incl - own;
+    const double sP = readlane63(incl);                   // sum X^2 over all bins
+    sX = wsum(sX);
+    sXp = wsum(sXp);
+    sIX = wsum(sIX) * f0;
+    mx = wmax_nonneg(mx);
+    const double sXe = sX + (double)Nf * kEps;              // np.sum(X + eps) (:118-119)
+    sXp += (double)Nf * kEps;
+    // ---------- centroid, then sweep B: spread + flux + roll-off + the running energy at the lane's block boundary (:57-140)
+    const double r = (mx == 0.0) ? 1.0 / kEps : fast_div(1.0, mx);
+    const double den = sX * r + kEps;
+    const double cen = fast_div(sIX * r, den);
+    const double rX = fast_div(1.0, sXe), rXp = fast_div(1.0, sXp);
+    const double thr = 0.90 * sP;
+    const int jb = (ch.kb + LB - 1) / LB;
+    const int kbound = jb * LB;
+    double sSp = 0.0, sFl = 0.0, run = before, cumb = 0.0;
+    bool hit = false;
+    int first = 0x7fffffff;
+    auto sweep_b = [&](int k, double X, double Xp) {
+        const double dv = (double)(k + 1) * f0 - cen;
+        sSp = fma(dv * dv, X * r, sSp);
+        const double df = X * rX - Xp * rXp;
+        sFl = fma(df, df, sFl);
+        if (k == kbound) { cumb = run; hit = true; }
+        run = fma(X, X, run);                                   // cumsum(X^2)[k]
+        if (run + kEps > thr) first = min(first, k);            // first k with cumsum + eps > 0.9 sum (:134-139)
+    };
+    {
+        int i = 0;
+        for (; i + 4 <= ch.base; i += 4) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = cur[ch.kb + i + u]; b[u] = prv[ch.kb + i + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sweep_b(ch.kb + i + u, a[u], b[u]);
+        }
+        for (int k = ch.kb + i; k < ch.ke; ++k) sweep_b(k, cur[k], prv[k]);
+    }
+    if (hit && jb <= 10) bnd[jb] = cumb;
+    if (10 * LB == Nf && lane == 0) bnd[10] = sP;
+    sSp = wsum(sSp);
+    sFl = wsum(sFl);
+    first = mix::wmin_nonneg_i(first);
+    const double spread = fast_sqrt(fast_div(sSp, den));
+    wsync();
+    // spectral entropy (:85-107): lane j < 10 owns block j
+    double ent_f;
+    {
+        const int ib = min(lane, 9);
+        const double sf = fast_div(bnd[ib + 1] - bnd[ib], sP + kEps);
+        ent_f = wsum((lane < 10) ? -(sf * fast_log2(sf + kEps)) : 0.0);
+    }
+    // ---------- MFCC (:236-254): mel band energies on all 64 lanes, log10 in lane m < 40, the 13 x 40 DCT on 52 lanes
+    {
+        const double e = tri::mel_sums_balanced(tb, cur, mjob, lane);
+        if (lane < 40) msp[lane] = fast_log10(e + kEps);
+    }
+    // ---------- chroma (:277-321)
+    double chroma = tri::chroma_sums_balanced(tb, cur, cjob, lane);
+    chroma = (sP == 0.0) ? chroma / kEps : fast_div(chroma, sP);
+    wsync();
+    {
+        // lane 4 q + part: ten terms of DCT row q; the four parts meet through two quad permutes
+        const int q = min(lane >> 2, 12), part = lane & 3;
+        const double *dm = tb.dct + q * tb.dct_stride + 10 * part;
+        const double *mv = msp + 10 * part;
+        double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+        for (int n = 0; n < 10; n += 2) {
+            c0 = fma(dm[n], mv[n], c0);
+            c1 = fma(dm[n + 1], mv[n + 1], c1);
+        }
+        double cc = c0 + c1;
+        cc += dpp_mov<PAA_DPP_X1>(cc);
+        cc += dpp_mov<PAA_DPP_X2>(cc);
+        if (lane < 52 && part == 0) fv[8 + q] = cc;
+    }
+    {   // population std of the 12 chroma values (:667): lanes 0..11 of the first row
+        const double cv = (lane < 12) ? chroma : 0.0;
+        const double mean = group_sum(cv) / 12.0;
+        const double d = (lane < 12) ? cv - mean : 0.0;
+        const double var = group_sum(d * d) / 12.0;
+        if (lane < 12) fv[21 + lane] = chroma;
+        if (lane == 0) {
+            fv[0] = ((double)tf.zc / 2.0) / (double)(W - 1);
+            fv[1] = tf.e_tot / (double)W;
+            fv[2] = tf.ent_e;
+            fv[3] = cen / (P.fs / 2.0);
+            fv[4] = spread / (P.fs / 2.0);
+            fv[5] = ent_f;
+            fv[6] = (cur == prv) ? 0.0 : sFl;      // first frame: previous spectrum = itself (:624-625)
+            fv[7] = (first == 0x7fffffff) ? 0.0 : (double)first / (double)Nf;
+            fv[33] = fast_sqrt(var);
+        }
+    }
+    wsync();
 }
 
 template <typename T, int LOG2M>
@@ -357,15 +575,17 @@ __global__ __launch_bounds__(64 * Sched<LOG2M>::NW) void st_blu_kernel(PlanDev P
     const double2 *g_chirp = reinterpret_cast<const double2 *>(blob + L.off_g_chirp);
     const double2 *g_bp = reinterpret_cast<const double2 *>(blob + L.off_g_bp);
     const double2 *g_tw = reinterpret_cast<const double2 *>(blob + L.off_g_tw);
+    const int4 *g_meljob = reinterpret_cast<const int4 *>(blob + L.off_g_meljob), *g_chjob = reinterpret_cast<const int4 *>(blob + L.off_g_chjob);
 
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane_id = threadIdx.x & 63;
     const int tile_id = blockIdx.x * L.waves + wave;
     if (tile_id >= n_tiles) return;
-    const int Nf = P.Nf, W = P.W, F = P.F > 0 ? P.F : 1;
+    const int Nf = P.Nf, W = P.W;
+    int lane = lane_id;
     unsigned char *wb = smem + L.table_bytes + wave * L.wave_bytes;
-    double *otile = reinterpret_cast<double *>(wb + L.buf_bytes + L.unit_bytes);
-    double *fv = otile + kFlush * F;
+    double *fv = reinterpret_cast<double *>(wb + L.buf_bytes + L.unit_bytes);
     double *msp = fv + 48;
+    double *bnd = msp + 40;
 
     const Tile tl = tiles[tile_id];
     const ClipDev c = clips[tl.clip];
@@ -377,10 +597,35 @@ __global__ __launch_bounds__(64 * Sched<LOG2M>::NW) void st_blu_kernel(PlanDev P
     const int hneed = (P.mode == 0) ? (P.deltas ? 2 : 1) : 0;
     const int h = min(hneed, tl.t0);
     double vprev = 0.0;
-    int nslot = 0, tbase = tl.t0, odd = 0;
+    int odd = 0;
     const int tend = tl.t0 + tl.cnt;
-    const mix::Chunk ch_t = mix::make_chunk(W, P.blk_t, lane), ch_f = mix::make_chunk(Nf, P.blk_f, lane);
+    // the twiddle seeds of this lane's butterflies (frame-invariant: see Seeds)
+    Seeds sd0[SH::NSD0], sd1;
+#pragma unroll
+    for (int u = 0; u < SH::NSD0; ++u) sd0[u] = load_seeds(g_tw + SH::TW0, SH::S0, lane + 64 * u, SH::R0);
+    sd1 = load_seeds(g_tw + SH::TW1, SH::S1, lane & (SH::S1 - 1), SH::R1);
+    tri::RowChunk rc, rcd;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { rc.h[i] = 0.0; rcd.h[i] = 0.0; }
+    const mix::Chunk ch_t = mix::make_chunk(W, P.blk_t, lane_id), ch_f = mix::make_chunk(Nf, P.blk_f, lane_id);
+    // a frame's row values are stored at the top of the NEXT iteration (row_put after frame_commit): vmcnt counts loads and stores
+    // in one sequence on this chip, so stores issued at the end of an iteration made the next frame's first load wait for their
+    // completion in HBM -- 5 k cycles per frame
+    double v_pend = 0.0, d_pend = 0.0;
+    int t_pend = -1;
+    PAA_T0()
     for (int t = tl.t0 - h; t < tend; ++t, odd ^= 1) {
+        // everything derived from the lane number and from the twiddle seeds is re-formed per frame: hoisted out of the loop, the
+        // per-lane LDS addresses of all passes and the 15 twiddle products per butterfly are hundreds of loop-invariant registers
+        // (they ended up in scratch: 850 bytes per lane, passes 0 - 2 at a third of their speed)
+        lane = lane_id;
+        asm volatile("" : "+v"(lane));
+#pragma unroll
+        for (int u = 0; u < SH::NSD0; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(sd0[u].w[j].x), "+v"(sd0[u].w[j].y));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(sd1.w[j].x), "+v"(sd1.w[j].y));
         // even frames of the run: transform at the front, spectrum at the very front, previous spectrum behind the buffer;
         // odd frames: transform one unit further, spectrum in its last unit, previous spectrum at the very front
         double2 *buf = reinterpret_cast<double2 *>(wb + (odd ? L.unit_bytes : 0));
@@ -388,32 +633,46 @@ __global__ __launch_bounds__(64 * Sched<LOG2M>::NW) void st_blu_kernel(PlanDev P
         double *prv = reinterpret_cast<double *>(wb + (odd ? 0 : L.buf_bytes));
         double *st = reinterpret_cast<double *>(buf);
         const T *x = x0 + (long long)t * P.S;
+        double2 cw[SH::NCW][SH::RZ];
+        chirp_prefetch<SH>(g_chirp, W, lane, cw);
+        double raw[(SH::WMAX + 63) / 64 + 1];
+        frame_request<T, SH>(x, W, lane, raw);
         double y0;
-        const bool silent = frame_load_real<T>(P, x, nm, st, lane, y0);
+        PAA_TICK(8)
+        const bool silent = frame_commit<T, SH>(P, raw, nm, st, lane, y0);
+        if (t_pend >= 0 && lane < kBase) {
+            tri::row_put(rc, oc + (long long)lane * Tc, t_pend, tl.t0, tend, v_pend);
+            if (P.deltas) tri::row_put(rcd, oc + (long long)(kBase + lane) * Tc, t_pend, tl.t0, tend, d_pend);
+        }
+        t_pend = -1;
+
+        PAA_TICK(0)
         const bool want = (P.mode == 0) && ((t >= tl.t0) || (P.deltas && t == tl.t0 - 1));
         TimeFeat tf;
         tf.e_tot = 0.0; tf.ent_e = 0.0; tf.zc = 0;
-        if (want) tf = time_features_real(st, ch_t, lane);
-        int touched = 0;
-        if (t + 1 < tend) {
-            // pull the next frame's new samples towards the L2 / L1: their latency runs under this frame's transform
-            const char *nb = reinterpret_cast<const char *>(x + W);
-            const int nbytes = P.S * (int)sizeof(T);
-            for (int o = 64 * lane; o + 4 <= nbytes; o += 64 * kWave) touched ^= *reinterpret_cast<const int *>(nb + o);
-        }
+        if (want) tf = time_features_real(st, ch_t, W, P.blk_t, bnd, lane);
         wsync();
+        PAA_TICK(1)
         if (silent) {
             // all samples equal: X[0] = |sum y| / Nf, every other bin exactly 0 (what pocketfft returns for a constant frame)
             const double x0m = fabs((double)W * y0) / (double)Nf;
             for (int k = lane; k < Nf; k += kWave) cur[k] = (k == 0) ? x0m : 0.0;
             wsync();
         } else {
-            fwd_pass0<SH>(buf, g_chirp, g_tw, W, lane);
-            pass1<SH, true>(buf, g_tw, lane);
-            pass2_product<SH>(buf, g_bp, lane);
-            pass1<SH, false>(buf, g_tw, lane);
-            back_pass0_magnitudes<SH>(buf, cur, g_tw, Nf, lane);
+            fwd_pass0<SH>(buf, g_chirp, cw, sd0, g_tw, W, lane);
+            PAA_TICK(2)
+            double2 bp[SH::U2][SH::R2];
+            bp_load<SH>(g_bp, lane, 0, bp);
+            pass1<SH, true>(buf, sd1, lane);
+            PAA_TICK(3)
+            pass2_product<SH>(buf, g_bp, bp, lane);
+            PAA_TICK(4)
+            pass1<SH, false>(buf, sd1, lane);
+            PAA_TICK(5)
+            back_pass0_magnitudes<SH>(buf, cur, sd0, g_tw, Nf, lane);
+            PAA_TICK(6)
         }
+
         if (P.mode == 1) {            // spectrogram row (ShortTermFeatures.py:422)
             double *row = oc + (long long)t * Nf;
             for (int k = lane; k < Nf; k += kWave) __builtin_nontemporal_store(cur[k], row + k);
@@ -421,36 +680,26 @@ __global__ __launch_bounds__(64 * Sched<LOG2M>::NW) void st_blu_kernel(PlanDev P
             double p = 0.0;
             for (int k = lane; k < Nf; k += kWave) { const double X = cur[k]; p = fma(X, X, p); }
             p = wsum(p);
-            const double chv = chroma_class(tb, cur, p, lane);
+            double chv = tri::chroma_sums_balanced(tb, cur, g_chjob[lane], lane);
+            chv = (p == 0.0) ? chv / kEps : fast_div(chv, p);
             if (lane < 12) oc[(long long)t * 12 + lane] = chv;
         } else {
             if (want) {
-                mix::frame_features_chunked(P, tb, tf, cur, (t == 0) ? cur : prv, fv, msp, ch_f, lane);
+                frame_features_blu(P, tb, tf, cur, (t == 0) ? cur : prv, fv, msp, bnd, ch_f, g_meljob[lane], g_chjob[lane], lane);
+                PAA_TICK(7)
                 const double v = (lane < kBase) ? fv[lane] : 0.0;
-                if (t >= tl.t0) {
-                    if (lane < kBase) {
-                        otile[nslot * F + lane] = v;
-                        if (P.deltas) otile[nslot * F + kBase + lane] = (t == 0) ? 0.0 : v - vprev;
-                    }
-                    ++nslot;
-                }
+                if (t >= tl.t0) { t_pend = t; v_pend = v; d_pend = (t == 0) ? 0.0 : v - vprev; }
                 vprev = v;
             }
-            if (nslot == kFlush || (t == tend - 1 && nslot > 0)) {
-                wsync();
-                // row segments: nslot consecutive frames of feature row f are contiguous in [F][T]
-                for (int idx = lane; idx < F * kFlush; idx += kWave) {
-                    const int f = idx / kFlush, i = idx % kFlush;
-                    if (i < nslot) oc[(long long)f * Tc + tbase + i] = otile[i * F + f];
-                }
-                wsync();
-                tbase += nslot;
-                nslot = 0;
-            }
         }
-        asm volatile("" ::"v"(touched));      // (the prefetch loads retire here at the latest)
         wsync();
+        PAA_TICK(10)
     }
+    if (t_pend >= 0 && lane < kBase) {
+        tri::row_put(rc, oc + (long long)lane * Tc, t_pend, tl.t0, tend, v_pend);
+        if (P.deltas) tri::row_put(rcd, oc + (long long)(kBase + lane) * Tc, t_pend, tl.t0, tend, d_pend);
+    }
+    PAA_TEND()
 }
 
 // ---- host: does the window take this kernel, LDS layout, tables ---------------------------------------------------------
@@ -509,7 +758,8 @@ inline int blu_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
     L.unit_bytes = (Nf * 8 + 255) / 256 * 256;
     L.buf_bytes = M * 16;
     const int FF = F > 0 ? F : 1;
-    L.wave_bytes = (L.buf_bytes + L.unit_bytes + kFlush * FF * 8 + 48 * 8 + 40 * 8 + 255) / 256 * 256;
+    (void)FF;
+    L.wave_bytes = (L.buf_bytes + L.unit_bytes + 48 * 8 + 40 * 8 + 12 * 8 + 255) / 256 * 256;      // + fv[48], msp[40], bnd[12]
     const size_t n_melw = mel ? mel->w.size() : 0, n_ch = chroma ? chroma->src.size() : 0;
     int off = 0;
     auto take = [&off](size_t bytes) { const int o = off; off += (int)((bytes + 15) / 16 * 16); return o; };
@@ -530,8 +780,10 @@ inline int blu_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
     L.off_g_chirp = take((size_t)W * 16);
     L.off_g_bp = take((size_t)M * 16);
     L.off_g_tw = take((size_t)ntw * 16);
+    L.off_g_meljob = take(64 * 16);
+    L.off_g_chjob = take(64 * 16);
     L.total_bytes = off;
-    static const int max_waves[13] = {0, 0, 0, 0, 0, 0, 0, 0, 16, 12, 8, 4, 2};
+    static const int max_waves[13] = {0, 0, 0, 0, 0, 0, 0, 0, 8, 8, 4, 4, 2};          // (the kernel's Sched<>::NW)
     L.waves = max_waves[lg];
     while (L.waves > 1 && (size_t)L.table_bytes + (size_t)L.waves * L.wave_bytes > 160 * 1024) --L.waves;
     if ((size_t)L.table_bytes + (size_t)L.waves * L.wave_bytes > 160 * 1024) return 0;
@@ -553,7 +805,12 @@ inline int blu_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
         memcpy(b + L.off_chstart, chroma->class_start, 13 * 4);
         memcpy(b + L.off_chsrc, chroma->src.data(), n_ch * 4);
         memcpy(b + L.off_chw, chroma->w.data(), n_ch * 8);
+        int first[12], cnt[12];
+        for (int c = 0; c < 12; ++c) { first[c] = chroma->class_start[c]; cnt[c] = chroma->class_start[c + 1] - chroma->class_start[c]; }
+        tri::lane_jobs(12, first, first, cnt, reinterpret_cast<tri::LaneJob *>(b + L.off_g_chjob));
     }
+    if (mel && !mel->w.empty())
+        tri::lane_jobs(40, mel->lo.data(), mel->off.data(), mel->cnt.data(), reinterpret_cast<tri::LaneJob *>(b + L.off_g_meljob));
     const long double pi = 3.141592653589793238462643383279502884L;
     // c[m] = exp(i pi m^2 / W): m^2 is reduced mod 2 W in integers first
     auto chirp = [&](long long m, long double &cr, long double &ci) {

@@ -22,6 +22,8 @@ def main(prof_dir, out_path):
                                                     "%st_tri_kernel%" if "_tri_" in stem else "%" + stem + "%")
     if stem.startswith("st_fast_800"):
         like = "%st_fast_800_kernel%"
+    if "_blu_" in stem:
+        like = "%st_blu_kernel%"
     if line["case"] == "mid_stats":
         like = "%mid_stats_kernel%"
     second = None

@@ -86,11 +86,16 @@ def test_spectrogram_chromagram_full_against_c_oracle(gpu_lib, capsys, fs, windo
     if window == 158:
         return          # (too few bins for the reference's chroma tables at 8 kHz: it raises, and so does the package)
     # the reference FFTs what is left of a truncated last frame and fails when that is shorter than num_fft (:349-355, :288)
-    last = window + step * ((len(mono) - step - 1 - window) // step)
-    if len(mono) - last < window // 2:
+    def tail(n):                    # samples of the last frame of range(window, n - step, step)
+        last = window + step * ((n - step - 1 - window) // step)
+        return n - last
+    if tail(len(mono)) < window // 2:
         with pytest.raises(ValueError):
             ShortTermFeatures.chromagram(sig, fs, window, step)
-        sig, mono = sig[:last + window // 2 + 7], mono[:last + window // 2 + 7]      # a tail of num_fft + 7 samples works
+        n = len(mono)
+        while not (window // 2 <= tail(n) < window):          # shorten the clip until the tail frame is truncated but long enough
+            n -= 1
+        sig, mono = sig[:n], mono[:n]
     chroma, ct_ax, cnames = ShortTermFeatures.chromagram(sig, fs, window, step)
     cref = c_oracle.chromagram(mono, fs, window, step)
     assert chroma.shape == cref.shape and cnames == O.CHROMA_NAMES
