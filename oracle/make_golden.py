@@ -476,6 +476,10 @@ def round6_goldens():
     st_case("synth44k_stereo_to_mono_f64_1103_441", (xs[:, 1] / 2) + (xs[:, 0] / 2), 44100, 1103, 441)
     x8 = synth_clip(158, 8000, 8000)
     spec_case("synth8k_spec_only_158_79", x8, 8000, 158, 79, chroma=False)
+    # 16 ms at 16 kHz: 256 = 2 x 4 x 4 x 8 moved to the three-pass register FFT (entropy blocks of 25 samples + a tail of 6)
+    x256 = synth_clip(256, 2 * 16000, 16000)
+    st_case("synth16k_256_128", x256, 16000, 256, 128)
+    spec_case("synth16k_spec_256_128", x256[:16000], 16000, 256, 128)
 
 
 if __name__ == "__main__" and "--round6" in sys.argv:

@@ -1,7 +1,7 @@
 // Three-pass register FFT (kernels_tri.hpp), third unit: the power-of-two windows 1024, 2048, 512 -- see family_launch.hpp.
 #define PAA_NO_HOST_LAUNCHERS
 #define PAA_LAUNCH_TRI
-#define PAA_TRI_SHAPES_HERE(X) X(8, S1024) X(9, S2048) X(10, S512)
+#define PAA_TRI_SHAPES_HERE(X) X(8, S1024) X(9, S2048) X(10, S512) X(11, S256)
 #include <cstdlib>
 #include <cstring>
 

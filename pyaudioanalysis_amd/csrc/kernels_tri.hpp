@@ -1501,6 +1501,9 @@ typedef Shape<19, 29, 2, false, 58, 12, 2, 1, 3, 16> S1102;  // 25 ms at 44.1 kH
 typedef Shape<8, 8, 8, true, 72, PAA_NW_1024, 9, 1, 1, 16> S1024;          // 512 complex points: 64 x radix 8, three times
 typedef Shape<16, 16, 4, true, 68, 7, 4, 1, 1, 16> S2048;   // 2048 samples: 1024 complex points; with the folded pass 3 the row instances need 108 registers: sixteen waves per CU
 typedef Shape<4, 8, 8, true, 72, 12, 9, 1, 1, 16> S512;           // 256 complex points (odd entropy blocks: 51 samples)
+// 16 ms at 16 kHz (round 6; st_mix until then: 1.4e8 frames/s): 128 complex points = 4 x 4 x 8 -- half of the lanes carry a pass-1 / pass-2 job,
+// nine a pair of radix-8 pass-3 jobs; what a frame costs is the time-domain and feature stages, which are on all 64 lanes
+typedef Shape<4, 4, 8, true, 40, 12, 9, 1, 1, 16> S256;
 
 struct TriLaunch {
     int shape = -1;                 // index into the shape list above
@@ -1523,12 +1526,13 @@ inline int tri_shape_of(int window) {
         case 1024: return 8;
         case 2048: return 9;
         case 512: return 10;
+        case 256: return 11;
         default: return -1;
     }
 }
 // PAA_TRI_SHAPE(SH) is expanded once per shape, in tri_shape_of's order
 #define PAA_TRI_SHAPES(X) X(0, S2400) X(1, S2205) X(2, S1764) X(3, S1920) X(4, S1600) X(5, S1200) X(6, S551) X(7, S1102) \
-    X(8, S1024) X(9, S2048) X(10, S512)
+    X(8, S1024) X(9, S2048) X(10, S512) X(11, S256)
 
 template <typename SH>
 inline void tri_fill(double fs, int mode, const MelTable *mel, const ChromaTable *chroma, TriLaunch &tl, std::vector<unsigned char> &blob) {
@@ -1713,15 +1717,15 @@ inline int tri_select(int window, int mode, double fs, const MelTable *mel, cons
     const int sh = tri_shape_of(window);
     if (sh < 0) return 0;
     tl.shape = sh;
-    static const char *names[3][11] = {
+    static const char *names[3][12] = {
         {"st_tri_20x20x3", "st_tri_r21x21x5", "st_tri_21x21x2", "st_tri_20x16x3", "st_tri_20x20x2", "st_tri_20x10x3", "st_tri_r29x19",
-         "st_tri_r19x29x2", "st_tri_8x8x8", "st_tri_16x16x4", "st_tri_4x8x8"},
+         "st_tri_r19x29x2", "st_tri_8x8x8", "st_tri_16x16x4", "st_tri_4x8x8", "st_tri_4x4x8"},
         {"spectrogram_tri_20x20x3", "spectrogram_tri_r21x21x5", "spectrogram_tri_21x21x2", "spectrogram_tri_20x16x3",
          "spectrogram_tri_20x20x2", "spectrogram_tri_20x10x3", "spectrogram_tri_r29x19", "spectrogram_tri_r19x29x2",
-         "spectrogram_tri_8x8x8", "spectrogram_tri_16x16x4", "spectrogram_tri_4x8x8"},
+         "spectrogram_tri_8x8x8", "spectrogram_tri_16x16x4", "spectrogram_tri_4x8x8", "spectrogram_tri_4x4x8"},
         {"chromagram_tri_20x20x3", "chromagram_tri_r21x21x5", "chromagram_tri_21x21x2", "chromagram_tri_20x16x3",
          "chromagram_tri_20x20x2", "chromagram_tri_20x10x3", "chromagram_tri_r29x19", "chromagram_tri_r19x29x2",
-         "chromagram_tri_8x8x8", "chromagram_tri_16x16x4", "chromagram_tri_4x8x8"}};
+         "chromagram_tri_8x8x8", "chromagram_tri_16x16x4", "chromagram_tri_4x8x8", "chromagram_tri_4x4x8"}};
     tl.name = names[mode][sh];
     switch (sh) {
 #define PAA_TRI_FILL(ID, SH) case ID: tri_fill<SH>(fs, mode, mel, chroma, tl, blob); break;

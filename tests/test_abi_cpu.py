@@ -617,7 +617,7 @@ def L1_ok(L1, H1):
     return L1 * H1 <= 64
 
 
-@pytest.mark.parametrize("window", [2400, 2205, 1764, 1920, 1600, 1200, 1102, 551, 1024, 2048, 512])
+@pytest.mark.parametrize("window", [2400, 2205, 1764, 1920, 1600, 1200, 1102, 551, 1024, 2048, 512, 256])
 def test_three_pass_tables_reproduce_the_fft(window):
     """Host tables of csrc/kernels_tri.hpp (no device): the three passes restated in NumPy FROM THE LIBRARY'S OWN TABLES --
     pass-1 twiddles W_N^(j q1), pass-2 twiddles W_L1^(b q2), for packed (even) windows the pass-3 job pairs with their plane

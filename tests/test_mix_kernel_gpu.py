@@ -34,13 +34,14 @@ def test_plans_dispatch_the_mixed_radix_kernel(gpu_lib):
     assert name(11025, 551, 275) == "st_tri_r29x19"
     assert name(22050, 551, 220, kind=1) == "st_tri_r29x19"
     assert name(44100, 1755, 877, mode=1) == "spectrogram_mix"   # other lengths made of 2, 3, 5, 7, 11, 13 stay mixed-radix
-    # power-of-two windows: three-pass register FFT since round 5 (8 x 8 x 8, 16 x 16 x 4, 4 x 8 x 8); 256 and 4096 stay mixed-radix
+    # power-of-two windows: three-pass register FFT since round 5 (8 x 8 x 8, 16 x 16 x 4, 4 x 8 x 8) and round 6 (256 = 4 x 4 x 8); 4096 stays mixed-radix
     assert name(16000, 1024, 512, kind=1) == "st_tri_8x8x8"
     assert name(44100, 2048, 1024) == "st_tri_16x16x4"
     assert name(16000, 512, 256, kind=2) == "st_tri_4x8x8"
     assert name(16000, 1024, 512, mode=1) == "spectrogram_tri_8x8x8"
     assert name(44100, 2048, 512, mode=2) == "chromagram_tri_16x16x4"
-    assert name(16000, 256, 128) == "st_mix"
+    assert name(16000, 256, 128) == "st_tri_4x4x8"             # 16 ms at 16 kHz: three-pass register FFT since round 6
+    assert name(16000, 256, 64, kind=2, mode=1) == "spectrogram_tri_4x4x8"
     assert name(44100, 4096, 2048) == "st_mix"
     assert name(44100, 1102, 441) == "st_tri_r19x29x2"         # config 5's features: real-input 19 x 29 x 2, the radix-29 butterflies shared by three lanes
     assert name(44100, 1102, 441, kind=2, mode=1) == "spectrogram_tri_r19x29x2"   # its rows too since round 5 (one slot, sixteen waves per CU)
@@ -76,7 +77,9 @@ CASES = [
     (32000, 1600, 1600, "f64", 10, True),
     (16000, 390, 200, "i16", 10, True),        # 195 = 3 5 13
     (16000, 1001, 500, "unit", 10, False),     # odd: 7 11 13
-    (16000, 256, 128, "i16", 5, True),
+    (16000, 256, 128, "i16", 5, True),         # 128 = 4 x 4 x 8 (round 6); entropy blocks of 25 samples, tail of 6
+    (16000, 256, 256, "stereo", 8, False),
+    (22050, 256, 100, "f64", 4, True),
     (96000, 4800, 2400, "i16", 6, True),       # 50 ms at 96 kHz: 2400 complex points, 70 KB per wave (two waves per CU)
     (44100, 3465, 1000, "f64", 4, False),      # odd and large: 3 3 5 7 11, 73 KB per wave
     (44100, 6000, 3000, "stereo", 5, False),   # the edge of the magnitude pass's register slots (1501 pairs)         # small window: 128 = 8 4 4
@@ -101,7 +104,8 @@ def test_full_matrix_against_c_oracle(gpu_lib, fs, window, step, kind, seconds, 
                                                   (44100, 1764, 1764, "i16"), (48000, 1920, 1920, "f64"),
                                                   (16000, 1024, 300, "i16"), (11025, 551, 275, "i16"),
                                                   (32000, 1600, 800, "stereo"), (24000, 1200, 1200, "f64"),
-                                                  (44100, 2048, 1024, "stereo"), (16000, 512, 256, "i16"), (16000, 1024, 512, "f64")])
+                                                  (44100, 2048, 1024, "stereo"), (16000, 512, 256, "i16"), (16000, 1024, 512, "f64"),
+                                                  (16000, 256, 128, "i16"), (16000, 256, 64, "stereo")])
 def test_spectrogram_chromagram_full_against_c_oracle(gpu_lib, capsys, fs, window, step, kind):
     sig, mono = make_signal(kind, 9100 + window, 12.7, fs)
     spec, t_ax, f_ax = ShortTermFeatures.spectrogram(sig, fs, window, step)
@@ -148,7 +152,7 @@ def test_degenerate_clips_and_ragged_batches(gpu_lib):
                                                   (48000, 2400, 1200, "stereo"), (48000, 2400, 1200, "i16"),
                                                   (11025, 551, 275, "stereo"), (44100, 1764, 882, "f64"), (16000, 800, 400, "i16"),
                                                   (16000, 640, 320, "stereo"), (16000, 1024, 512, "i16"), (16000, 512, 256, "stereo"),
-                                                  (44100, 2048, 1024, "i16")])
+                                                  (44100, 2048, 1024, "i16"), (16000, 256, 128, "i16"), (16000, 256, 128, "stereo")])
 def test_samples_that_sit_on_a_whole_number_mean(gpu_lib, fs, window, step, kind):
     """The kernels decide sign(x / 2^15 - mean) of integer PCM in integer arithmetic (x against floor(mean 2^15), with a
     separate rule when the clip mean is a whole count: then samples can sit exactly ON the mean and np.sign gives 0,
