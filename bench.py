@@ -49,7 +49,7 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6          # datasheet; informational only
 KFLOP_PER_FRAME = 45.0                # ~35-55 kflop of FP64 per 800/400 frame
 CFG4_TOTAL_CLIPS = 100000
-PROFILE_ROUND = "r05"                 # profiles/latest_traffic.json must come from this round's PMC pass of the headline
+PROFILE_ROUND = "r06"                 # profiles/latest_traffic.json must come from this round's PMC pass of the headline
                                       # kernel (scripts/profile.sh r04): an older file is reported, flagged traffic_stale
 XGMI_LINK_GBS = 76.8                  # one xGMI link, one direction (7 links into the root at N = 8)
 

@@ -43,7 +43,9 @@ def main(summary_path, out_path):
     summ = json.load(open(summary_path))
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(ROOT, "pyaudioanalysis_amd", "csrc", "family_fast.hip")
-        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-disable-machine-licm", "-I/opt/rocm/include",
+        sys.path.insert(0, ROOT)
+        from pyaudioanalysis_amd import _build          # the unit's own flags (the ISA histogram must be the shipped kernel's)
+        subprocess.run(["hipcc"] + _build.BASE_FLAGS + _build.UNIT_FLAGS.get("family_fast.hip", []) + ["-O3",
                         "-c", src, "-o", os.path.join(d, "x.o"), "-save-temps"], cwd=d, check=True, capture_output=True)
         lines = open(os.path.join(d, "family_fast-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
     body = loop_body(lines, "st_fast_800_kernelILi400ELi0ELi1ELi8E")

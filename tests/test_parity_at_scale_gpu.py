@@ -182,12 +182,14 @@ def test_ranged_host_call_equals_the_single_launch_bit_for_bit(gpu_lib):
     (16000, 640, 320, True, "st_ct_20x16"),            # 2 RA RB family: runs after a clip's first start one or two frames early (halo inside)
     (48000, 2400, 1200, True, "st_tri_20x20x3"),       # three-pass family, with deltas
     (16000, 1024, 512, False, "st_tri_8x8x8"),         # ... a power-of-two shape of round 5
-    (16000, 256, 128, False, "st_mix"),                # in-place mixed-radix kernel (lean, skewed instance)
+    (16000, 256, 128, False, "st_tri_4x4x8"),          # ... and of round 6 (st_mix until then)
+    (16000, 390, 195, False, "st_mix"),                # in-place mixed-radix kernel (195 = 3 x 5 x 13, lean instance)
+    (22050, 661, 330, True, "st_blu_1024"),            # Bluestein kernel (round 6): row chunks in registers, stored one frame late
     (11025, 551, 275, True, "st_tri_r29x19"),          # shared prime butterflies
 ])
 def test_ranged_host_call_on_the_other_families(gpu_lib, fs, window, step, deltas, family):
     """The four-range copy-back pipeline of the host-buffer API applies to every kernel family (advisor, round 4): a clip of
-    more than 65 536 frames through ct / tri / mix equals the device-resident plan's single launch bit for bit, and the profiling
+    more than 65 536 frames through ct / tri / mix / blu equals the device-resident plan's single launch bit for bit, and the profiling
     events count the ranged launches."""
     import ctypes
     n = 65999 * step + window                                                           # 66 000 frames
