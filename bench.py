@@ -94,6 +94,7 @@ SHAPES = {
     "blu_1103_spectrogram": (22050, 1103, 441, 1800, 1, 0, 1, 0),
     "blu_2203": (44100, 2203, 1100, 1200, 1, 0, 0, 0),             # a prime 50 ms window at 44.1 kHz: convolution length 4096
     "blu_202": (16000, 202, 101, 1800, 1, 0, 0, 0),                # 2 x 101: length 512
+    "blu_4001": (96000, 4001, 2000, 600, 1, 0, 0, 0),              # a prime window at 96 kHz: length 8192, one wave per CU
     "big_16000": (16000, 16000, 8000, 600, 1, 0, 0, 0),            # music_thumbnailing's 1 s window (audioSegmentation.py:1137)
     "big_16000_1h": (16000, 16000, 8000, 3600, 1, 0, 0, 0),        # ... on the one-hour clip (7 199 frames: 28 per CU)
     "big_16000_68": (16000, 16000, 8000, 600, 1, 0, 0, 1),         # ... with deltas, as music_thumbnailing calls it

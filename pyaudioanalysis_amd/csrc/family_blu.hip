@@ -36,6 +36,7 @@ static int blu_any(const blu::BluLayout &bl, size_t lds, const PlanDev &P, const
         case 10: return blu_one<T, 10>(bl, lds, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
         case 11: return blu_one<T, 11>(bl, lds, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
         case 12: return blu_one<T, 12>(bl, lds, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
+        case 13: return blu_one<T, 13>(bl, lds, P, blob, d_packed, clips, norms, tiles, n_tiles, d_out, stream);
         default: return -1;
     }
 }

@@ -52,20 +52,24 @@ using f800::g_wave_trace;
 template <int LOG2M> struct Sched;
 // NW = waves per workgroup: it sets the register budget (512 / ceil(NW / 4) per lane).  More waves than these spilled to scratch --
 // 288 bytes per lane at M = 1024 with eight waves, and 12 x the algorithmic bytes in HBM writes (profiles/r06_blu_661_w8_summary.json)
-template <> struct Sched<8> { static constexpr int R0 = 4, R1 = 8, R2 = 8, NW = 8; };
-template <> struct Sched<9> { static constexpr int R0 = 8, R1 = 8, R2 = 8, NW = 8; };
-template <> struct Sched<10> { static constexpr int R0 = 16, R1 = 8, R2 = 8, NW = 4; };
-template <> struct Sched<11> { static constexpr int R0 = 16, R1 = 16, R2 = 8, NW = 4; };
-template <> struct Sched<12> { static constexpr int R0 = 16, R1 = 16, R2 = 16, NW = 2; };
+// R1B > 1: a second middle pass (M = 8192 = 16 x 8 x 8 x 8: four passes; 128 KB of LDS, one wave per CU -- windows up to 5461 samples)
+template <> struct Sched<8> { static constexpr int R0 = 4, R1 = 8, R1B = 1, R2 = 8, NW = 8; };
+template <> struct Sched<9> { static constexpr int R0 = 8, R1 = 8, R1B = 1, R2 = 8, NW = 8; };
+template <> struct Sched<10> { static constexpr int R0 = 16, R1 = 8, R1B = 1, R2 = 8, NW = 4; };
+template <> struct Sched<11> { static constexpr int R0 = 16, R1 = 16, R1B = 1, R2 = 8, NW = 4; };
+template <> struct Sched<12> { static constexpr int R0 = 16, R1 = 16, R1B = 1, R2 = 16, NW = 2; };
+template <> struct Sched<13> { static constexpr int R0 = 16, R1 = 8, R1B = 8, R2 = 8, NW = 1; };
 
 template <int LOG2M_>
 struct Shape {
     static constexpr int LOG2M = LOG2M_, M = 1 << LOG2M_;
-    static constexpr int R0 = Sched<LOG2M_>::R0, R1 = Sched<LOG2M_>::R1, R2 = Sched<LOG2M_>::R2;
+    static constexpr int R0 = Sched<LOG2M_>::R0, R1 = Sched<LOG2M_>::R1, R1B = Sched<LOG2M_>::R1B, R2 = Sched<LOG2M_>::R2;
     static constexpr int NW = Sched<LOG2M_>::NW;               // most waves per workgroup (sets the register budget)
     static constexpr int S0 = M / R0;                          // pass 0: span M, element stride S0, S0 butterflies
     static constexpr int SP1 = S0, S1 = SP1 / R1;              // pass 1: span S0, stride S1
-    static constexpr int TW0 = 0, TW1 = (R0 - 1) * S0, NTW = TW1 + (R1 - 1) * S1;      // twiddle tables [q - 1][k] of pass 0 / 1
+    static constexpr int SP1B = S1, S1B = S1 / R1B;            // pass 1b (R1B > 1 only): span S1, stride S1B
+    static constexpr int TW0 = 0, TW1 = (R0 - 1) * S0, TW1B = TW1 + (R1 - 1) * S1;      // twiddle tables [q - 1][k] of pass 0 / 1 / 1b
+    static constexpr int NTW = TW1B + (R1B > 1 ? (R1B - 1) * S1B : 0);
     // outputs of the last pass that can be bins: k + q S0 < Nf <= (M + 1) / 3
     static constexpr int QMAX = (R0 == 16) ? 6 : (R0 == 8 ? 3 : 2);
     // rows of pass 0 that can hold samples: W <= (2 M + 3) / 3 (M >= W + W / 2 - 1), the rows from RZ on are zeros for every window
@@ -78,13 +82,17 @@ struct Shape {
     static constexpr int NSD0 = SEEDS_RESIDENT ? NB0 : 1;
     static constexpr int NCW = CHIRP_AHEAD ? NB0 : 1;
     static constexpr int NB2 = (M / R2 + 63) / 64, U2 = (NB2 >= 2 && R2 <= 8) ? 2 : 1;      // pass 2: butterflies per lane, in flight
-    static_assert(R0 * R1 * R2 == M && S1 == R2, "three passes");
+    // pass 0 takes its samples from the staged frame in LDS (two butterflies per lane: the lane reads all of them before any lane writes
+    // the buffer) or, with more butterflies per lane than registers for that, again from global memory (L2 hits), butterfly by butterfly
+    static constexpr bool Y_FROM_LDS = NB0 <= 2;
+    static_assert(R0 * R1 * R1B * R2 == M && S1B == R2, "three or four passes");
     static_assert(S0 % 64 == 0, "pass 0: every lane has the same number of butterflies");
 };
 
 struct BluLayout {
     int off_mello, off_melcnt, off_meloff, off_melw, off_dct, off_chstart, off_chsrc, off_chw;
-    int table_bytes;     // LDS part of the blob, multiple of 256
+    int table_bytes;     // feature tables at the front of the blob (mel, DCT, chroma), multiple of 256
+    int lds_table_bytes; // ... copied to LDS: table_bytes, or 0 for M = 8192 (the 128 KB buffer leaves no room: the kernel reads them from global memory)
     int wave_bytes;      // per-wave region, multiple of 256
     int waves;
     int unit_bytes;      // U: one spectrum (Nf doubles) rounded to 256 bytes
@@ -149,35 +157,46 @@ __device__ __forceinline__ void chirp_prefetch(const double2 *__restrict__ g_chi
             for (int r = 0; r < SH::RZ; ++r) cw[u][r] = g_chirp[min(lane + 64 * u + r * SH::S0, W - 1)];      // (beyond W: y is 0)
     }
 }
-template <typename SH>
+template <typename T, typename SH>
 __device__ __forceinline__ void fwd_pass0(double2 *buf, const double2 *__restrict__ g_chirp, const double2 (&cw)[SH::NCW][SH::RZ],
-                                          const Seeds *sd0, const double2 *__restrict__ g_tw, int W, int lane) {
+                                          const Seeds *sd0, const double2 *__restrict__ g_tw, const T *__restrict__ x,
+                                          const ClipNorm &nm, int W, int lane) {
     constexpr int R = SH::R0, S = SH::S0, NB = SH::NB0, RZ = SH::RZ;
     const double *st = reinterpret_cast<const double *>(buf);
-    double y[NB][RZ];
+    double y[SH::Y_FROM_LDS ? NB : 1][RZ];
+    if constexpr (SH::Y_FROM_LDS) {
 #pragma unroll
-    for (int u = 0; u < NB; ++u)
+        for (int u = 0; u < NB; ++u)
 #pragma unroll
-        for (int r = 0; r < RZ; ++r) {
-            const int n = lane + 64 * u + r * S;
-            y[u][r] = (n < W) ? st[min(n, W - 1)] : 0.0;
-        }
-    wsync();           // every lane has its samples: the buffer may be overwritten
+            for (int r = 0; r < RZ; ++r) {
+                const int n = lane + 64 * u + r * S;
+                y[u][r] = (n < W) ? st[min(n, W - 1)] : 0.0;
+            }
+        wsync();           // every lane has its samples: the buffer may be overwritten
+    }
+    const double sc = sample_scale<T>();
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int k = lane + 64 * u;
         double2 v[R], w[R], cu[RZ];
+        double yu[RZ];
 #pragma unroll
         for (int r = 0; r < RZ; ++r) {
             if constexpr (SH::CHIRP_AHEAD) cu[r] = cw[u < SH::NCW ? u : 0][r];
             else cu[r] = g_chirp[min(k + r * S, W - 1)];
+            if constexpr (SH::Y_FROM_LDS) yu[r] = y[u < (SH::Y_FROM_LDS ? NB : 1) ? u : 0][r];
+            else yu[r] = load_sample<T>(x + min(k + r * S, W - 1));          // (the frame is in the L2: loaded for the time-domain stage)
+        }
+        if constexpr (!SH::Y_FROM_LDS) {
+#pragma unroll
+            for (int r = 0; r < RZ; ++r) yu[r] = (k + r * S < W) ? fma(yu[r], sc, -nm.mean) * nm.inv : 0.0;
         }
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            v[r] = (r < RZ) ? make_double2(y[u][r < RZ ? r : 0] * cu[r < RZ ? r : 0].x, y[u][r < RZ ? r : 0] * cu[r < RZ ? r : 0].y)
+            v[r] = (r < RZ) ? make_double2(yu[r < RZ ? r : 0] * cu[r < RZ ? r : 0].x, yu[r < RZ ? r : 0] * cu[r < RZ ? r : 0].y)
                             : make_double2(0.0, 0.0);
         mix::Bfly<R>::run(v);
-        // (M = 4096: four butterflies per lane -- their seeds are fetched where they are used instead of living in 64 registers)
+        // (M >= 4096: four and more butterflies per lane -- their seeds are fetched where they are used instead of living in registers)
         expand_twiddles<R>(SH::SEEDS_RESIDENT ? sd0[SH::SEEDS_RESIDENT ? u : 0] : load_seeds(g_tw + SH::TW0, S, k, R), w);
 #pragma unroll
         for (int q = 1; q < R; ++q) v[mix::Bfly<R>::pos(q)] = cmul(v[mix::Bfly<R>::pos(q)], w[q]);
@@ -199,9 +218,10 @@ __device__ __forceinline__ void locate(int b, int &base, int &k) {
 }
 
 // ---- pass 1: DIF (FWD: output twiddles) or DIT (!FWD: input twiddles) over the blocks of S0 elements
-template <typename SH, bool FWD>
+template <typename SH, bool FWD, int WHICH = 0>
 __device__ __forceinline__ void pass1(double2 *buf, const Seeds &sd1, int lane) {
-    constexpr int R = SH::R1, SPAN = SH::SP1, S = SH::S1, NBT = SH::M / R, NB = (NBT + 63) / 64;
+    constexpr int R = WHICH ? SH::R1B : SH::R1, SPAN = WHICH ? SH::SP1B : SH::SP1, S = WHICH ? SH::S1B : SH::S1, NBT = SH::M / R,
+                  NB = (NBT + 63) / 64;
     constexpr int U = (NB >= 2 && R <= 8) ? 2 : 1;          // butterflies in flight per lane (radix 16: 32 registers of operands each)
     static_assert(S <= 64 && 64 % S == 0, "every butterfly of a lane has the same offset k = lane mod S: one set of twiddles");
     double2 w[R];
@@ -298,6 +318,7 @@ __device__ __forceinline__ void pass2_product(double2 *buf, const double2 *__res
 #pragma unroll
                 for (int q = 0; q < R; ++q) bp[u][q] = bp_next[u][q];
         }
+        if constexpr (NB > 4) __builtin_amdgcn_sched_barrier(0);
     }
     wsync();
 }
@@ -364,6 +385,36 @@ __device__ __forceinline__ bool frame_commit(const PlanDev &P, const double (&q)
             differs |= (yv != first);
             st[n] = yv;
         }
+    }
+    y0 = first;
+    wsync();
+    return __ballot(differs) == 0ull;
+}
+
+// the same in chunks of sixteen loads per lane (the long windows of M >= 4096: 43 / 86 samples per lane would be 86 / 172 registers)
+template <typename T, typename SH>
+__device__ __forceinline__ bool frame_load_chunked(const PlanDev &P, const T *__restrict__ x, const ClipNorm &nm, double *st, int lane,
+                                                   double &y0) {
+    constexpr int NL = (SH::WMAX + 63) / 64, CH = 16;
+    const double sc = sample_scale<T>();
+    const int W = P.W;
+    const double first = fma(load_sample<T>(x), sc, -nm.mean) * nm.inv;
+    bool differs = false;
+#pragma unroll
+    for (int i0 = 0; i0 < NL; i0 += CH) {
+        double q[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) q[i] = (i0 + i < NL) ? load_sample<T>(x + min(lane + kWave * (i0 + i), W - 1)) : 0.0;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int n = lane + kWave * (i0 + i);
+            const double yv = fma(q[i], sc, -nm.mean) * nm.inv;
+            if (i0 + i < NL && n < W) {
+                differs |= (yv != first);
+                st[n] = yv;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
     y0 = first;
     wsync();
@@ -555,23 +606,35 @@ __global__ __launch_bounds__(64 * Sched<LOG2M>::NW) void st_blu_kernel(PlanDev P
                                                                        double *__restrict__ out) {
     typedef Shape<LOG2M> SH;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
-    {
+    constexpr bool TABLES_IN_LDS = LOG2M < 13;
+    if constexpr (TABLES_IN_LDS) {
         const int4 *src4 = reinterpret_cast<const int4 *>(blob);
         int4 *dst4 = reinterpret_cast<int4 *>(smem);
         for (int n = threadIdx.x; n < L.table_bytes / 16; n += blockDim.x) dst4[n] = src4[n];
+        __syncthreads();       // the only workgroup-wide barrier
     }
-    __syncthreads();       // the only workgroup-wide barrier
     Tabs tb;
     tb.tw = nullptr; tb.post = nullptr;
-    tb.mel_lo = reinterpret_cast<const int *>(smem + L.off_mello);
-    tb.mel_cnt = reinterpret_cast<const int *>(smem + L.off_melcnt);
-    tb.mel_off = reinterpret_cast<const int *>(smem + L.off_meloff);
-    tb.mel_w = reinterpret_cast<const double *>(smem + L.off_melw);
-    tb.dct = reinterpret_cast<const double *>(smem + L.off_dct);
+    if constexpr (TABLES_IN_LDS) {
+        tb.mel_lo = reinterpret_cast<const int *>(smem + L.off_mello);
+        tb.mel_cnt = reinterpret_cast<const int *>(smem + L.off_melcnt);
+        tb.mel_off = reinterpret_cast<const int *>(smem + L.off_meloff);
+        tb.mel_w = reinterpret_cast<const double *>(smem + L.off_melw);
+        tb.dct = reinterpret_cast<const double *>(smem + L.off_dct);
+        tb.ch_start = reinterpret_cast<const int *>(smem + L.off_chstart);
+        tb.ch_src = reinterpret_cast<const int *>(smem + L.off_chsrc);
+        tb.ch_w = reinterpret_cast<const double *>(smem + L.off_chw);
+    } else {
+        tb.mel_lo = reinterpret_cast<const int *>(blob + L.off_mello);
+        tb.mel_cnt = reinterpret_cast<const int *>(blob + L.off_melcnt);
+        tb.mel_off = reinterpret_cast<const int *>(blob + L.off_meloff);
+        tb.mel_w = reinterpret_cast<const double *>(blob + L.off_melw);
+        tb.dct = reinterpret_cast<const double *>(blob + L.off_dct);
+        tb.ch_start = reinterpret_cast<const int *>(blob + L.off_chstart);
+        tb.ch_src = reinterpret_cast<const int *>(blob + L.off_chsrc);
+        tb.ch_w = reinterpret_cast<const double *>(blob + L.off_chw);
+    }
     tb.dct_stride = 41;
-    tb.ch_start = reinterpret_cast<const int *>(smem + L.off_chstart);
-    tb.ch_src = reinterpret_cast<const int *>(smem + L.off_chsrc);
-    tb.ch_w = reinterpret_cast<const double *>(smem + L.off_chw);
     const double2 *g_chirp = reinterpret_cast<const double2 *>(blob + L.off_g_chirp);
     const double2 *g_bp = reinterpret_cast<const double2 *>(blob + L.off_g_bp);
     const double2 *g_tw = reinterpret_cast<const double2 *>(blob + L.off_g_tw);
@@ -582,7 +645,7 @@ __global__ __launch_bounds__(64 * Sched<LOG2M>::NW) void st_blu_kernel(PlanDev P
     if (tile_id >= n_tiles) return;
     const int Nf = P.Nf, W = P.W;
     int lane = lane_id;
-    unsigned char *wb = smem + L.table_bytes + wave * L.wave_bytes;
+    unsigned char *wb = smem + L.lds_table_bytes + wave * L.wave_bytes;
     double *fv = reinterpret_cast<double *>(wb + L.buf_bytes + L.unit_bytes);
     double *msp = fv + 48;
     double *bnd = msp + 40;
@@ -600,10 +663,11 @@ __global__ __launch_bounds__(64 * Sched<LOG2M>::NW) void st_blu_kernel(PlanDev P
     int odd = 0;
     const int tend = tl.t0 + tl.cnt;
     // the twiddle seeds of this lane's butterflies (frame-invariant: see Seeds)
-    Seeds sd0[SH::NSD0], sd1;
+    Seeds sd0[SH::NSD0], sd1, sd1b;
 #pragma unroll
     for (int u = 0; u < SH::NSD0; ++u) sd0[u] = load_seeds(g_tw + SH::TW0, SH::S0, lane + 64 * u, SH::R0);
     sd1 = load_seeds(g_tw + SH::TW1, SH::S1, lane & (SH::S1 - 1), SH::R1);
+    sd1b = (SH::R1B > 1) ? load_seeds(g_tw + SH::TW1B, SH::S1B, lane & (SH::S1B - 1), SH::R1B) : sd1;
     tri::RowChunk rc, rcd;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { rc.h[i] = 0.0; rcd.h[i] = 0.0; }
@@ -626,6 +690,10 @@ __global__ __launch_bounds__(64 * Sched<LOG2M>::NW) void st_blu_kernel(PlanDev P
             for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(sd0[u].w[j].x), "+v"(sd0[u].w[j].y));
 #pragma unroll
         for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(sd1.w[j].x), "+v"(sd1.w[j].y));
+        if constexpr (SH::R1B > 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(sd1b.w[j].x), "+v"(sd1b.w[j].y));
+        }
         // even frames of the run: transform at the front, spectrum at the very front, previous spectrum behind the buffer;
         // odd frames: transform one unit further, spectrum in its last unit, previous spectrum at the very front
         double2 *buf = reinterpret_cast<double2 *>(wb + (odd ? L.unit_bytes : 0));
@@ -635,11 +703,17 @@ __global__ __launch_bounds__(64 * Sched<LOG2M>::NW) void st_blu_kernel(PlanDev P
         const T *x = x0 + (long long)t * P.S;
         double2 cw[SH::NCW][SH::RZ];
         chirp_prefetch<SH>(g_chirp, W, lane, cw);
-        double raw[(SH::WMAX + 63) / 64 + 1];
-        frame_request<T, SH>(x, W, lane, raw);
         double y0;
-        PAA_TICK(8)
-        const bool silent = frame_commit<T, SH>(P, raw, nm, st, lane, y0);
+        bool silent;
+        if constexpr ((SH::WMAX + 63) / 64 > 32) {
+            PAA_TICK(8)
+            silent = frame_load_chunked<T, SH>(P, x, nm, st, lane, y0);
+        } else {
+            double raw[(SH::WMAX + 63) / 64 + 1];
+            frame_request<T, SH>(x, W, lane, raw);
+            PAA_TICK(8)
+            silent = frame_commit<T, SH>(P, raw, nm, st, lane, y0);
+        }
         if (t_pend >= 0 && lane < kBase) {
             tri::row_put(rc, oc + (long long)lane * Tc, t_pend, tl.t0, tend, v_pend);
             if (P.deltas) tri::row_put(rcd, oc + (long long)(kBase + lane) * Tc, t_pend, tl.t0, tend, d_pend);
@@ -659,14 +733,16 @@ __global__ __launch_bounds__(64 * Sched<LOG2M>::NW) void st_blu_kernel(PlanDev P
             for (int k = lane; k < Nf; k += kWave) cur[k] = (k == 0) ? x0m : 0.0;
             wsync();
         } else {
-            fwd_pass0<SH>(buf, g_chirp, cw, sd0, g_tw, W, lane);
+            fwd_pass0<T, SH>(buf, g_chirp, cw, sd0, g_tw, x, nm, W, lane);
             PAA_TICK(2)
             double2 bp[SH::U2][SH::R2];
             bp_load<SH>(g_bp, lane, 0, bp);
             pass1<SH, true>(buf, sd1, lane);
+            if constexpr (SH::R1B > 1) pass1<SH, true, 1>(buf, sd1b, lane);
             PAA_TICK(3)
             pass2_product<SH>(buf, g_bp, bp, lane);
             PAA_TICK(4)
+            if constexpr (SH::R1B > 1) pass1<SH, false, 1>(buf, sd1b, lane);
             pass1<SH, false>(buf, sd1, lane);
             PAA_TICK(5)
             back_pass0_magnitudes<SH>(buf, cur, sd0, g_tw, Nf, lane);
@@ -705,18 +781,21 @@ __global__ __launch_bounds__(64 * Sched<LOG2M>::NW) void st_blu_kernel(PlanDev P
 // ---- host: does the window take this kernel, LDS layout, tables ---------------------------------------------------------
 inline int blu_log2m(int window) {
     const int Nf = window / 2, need = window + Nf - 1;
-    for (int lg = 8; lg <= 12; ++lg)
+    for (int lg = 8; lg <= 13; ++lg)
         if ((1 << lg) >= need) return lg;
     return 0;
 }
 // radices of the DIF passes of M = 2^lg (the kernel's Sched)
-inline void blu_radices(int lg, int r[3]) {
+// (r[0], r[1], r[2] [, r[3]]: pass 0, the middle pass(es), the last pass; r[3] = 0 for the three-pass lengths)
+inline void blu_radices(int lg, int r[4]) {
+    r[3] = 0;
     switch (lg) {
         case 8: r[0] = 4; r[1] = 8; r[2] = 8; break;
         case 9: r[0] = 8; r[1] = 8; r[2] = 8; break;
         case 10: r[0] = 16; r[1] = 8; r[2] = 8; break;
         case 11: r[0] = 16; r[1] = 16; r[2] = 8; break;
-        default: r[0] = 16; r[1] = 16; r[2] = 16; break;
+        case 12: r[0] = 16; r[1] = 16; r[2] = 16; break;
+        default: r[0] = 16; r[1] = 8; r[2] = 8; r[3] = 8; break;
     }
 }
 // in-place radix-2 FFT in long double (host tables only: M <= 4096)
@@ -773,20 +852,22 @@ inline int blu_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
     L.off_chw = take(std::max<size_t>(n_ch, 1) * 8);
     off = (off + 255) / 256 * 256;
     L.table_bytes = off;
-    int rdx[3];
+    int rdx[4];
     blu_radices(lg, rdx);
-    const int S0 = M / rdx[0], S1 = S0 / rdx[1];
-    const int ntw = (rdx[0] - 1) * S0 + (rdx[1] - 1) * S1;
+    const int np = rdx[3] ? 4 : 3;
+    const int S0 = M / rdx[0], S1 = S0 / rdx[1], S1B = rdx[3] ? S1 / rdx[2] : 0;
+    const int ntw = (rdx[0] - 1) * S0 + (rdx[1] - 1) * S1 + (rdx[3] ? (rdx[2] - 1) * S1B : 0);
     L.off_g_chirp = take((size_t)W * 16);
     L.off_g_bp = take((size_t)M * 16);
     L.off_g_tw = take((size_t)ntw * 16);
     L.off_g_meljob = take(64 * 16);
     L.off_g_chjob = take(64 * 16);
     L.total_bytes = off;
-    static const int max_waves[13] = {0, 0, 0, 0, 0, 0, 0, 0, 8, 8, 4, 4, 2};          // (the kernel's Sched<>::NW)
+    static const int max_waves[14] = {0, 0, 0, 0, 0, 0, 0, 0, 8, 8, 4, 4, 2, 1};          // (the kernel's Sched<>::NW)
     L.waves = max_waves[lg];
-    while (L.waves > 1 && (size_t)L.table_bytes + (size_t)L.waves * L.wave_bytes > 160 * 1024) --L.waves;
-    if ((size_t)L.table_bytes + (size_t)L.waves * L.wave_bytes > 160 * 1024) return 0;
+    L.lds_table_bytes = (lg < 13) ? L.table_bytes : 0;
+    while (L.waves > 1 && (size_t)L.lds_table_bytes + (size_t)L.waves * L.wave_bytes > 160 * 1024) --L.waves;
+    if ((size_t)L.lds_table_bytes + (size_t)L.waves * L.wave_bytes > 160 * 1024) return 0;
     if (!blob) return 1;
     blob->assign((size_t)L.total_bytes, 0);
     unsigned char *b = blob->data();
@@ -837,7 +918,7 @@ inline int blu_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
     double *gb = reinterpret_cast<double *>(b + L.off_g_bp);
     for (int k = 0; k < M; ++k) {
         int rest = k, weight = M, pos = 0;
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < np; ++p) {
             weight /= rdx[p];
             pos += (rest % rdx[p]) * weight;
             rest /= rdx[p];
@@ -848,8 +929,8 @@ inline int blu_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
     const long double two_pi = 2.0L * pi;
     double *gt = reinterpret_cast<double *>(b + L.off_g_tw);
     size_t at = 0;
-    const int spans[2] = {M, S0}, strides[2] = {S0, S1};
-    for (int p = 0; p < 2; ++p)
+    const int spans[3] = {M, S0, S1}, strides[3] = {S0, S1, S1B};
+    for (int p = 0; p < np - 1; ++p)
         for (int q = 1; q < rdx[p]; ++q)
             for (int k = 0; k < strides[p]; ++k) {
                 const long double ang = -two_pi * (long double)(((long long)q * k) % spans[p]) / (long double)spans[p];
@@ -859,7 +940,7 @@ inline int blu_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
             }
     return 1;
 }
-inline size_t blu_lds_bytes(const BluLayout &L) { return (size_t)L.table_bytes + (size_t)L.waves * L.wave_bytes; }
+inline size_t blu_lds_bytes(const BluLayout &L) { return (size_t)L.lds_table_bytes + (size_t)L.waves * L.wave_bytes; }
 
 }  // namespace blu
 }  // namespace paa

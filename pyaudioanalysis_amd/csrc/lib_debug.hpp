@@ -194,9 +194,10 @@ extern "C" int paa_debug_blu_plan(int window, double fs, int32_t *info8, int32_t
     blu::BluLayout L;
     std::vector<unsigned char> b;
     if (!blu::blu_layout(p, nullptr, nullptr, 0, L, &b)) return 0;
-    int r[3];
+    int r[4];
     blu::blu_radices(L.log2m, r);
-    info8[0] = L.log2m; info8[1] = r[0]; info8[2] = r[1]; info8[3] = r[2]; info8[4] = L.waves;
+    // (four passes: r[1], r[2] are the middle passes, r[3] the last; info8[2] = first middle pass | second << 8, info8[3] = last pass)
+    info8[0] = L.log2m; info8[1] = r[0]; info8[2] = r[3] ? (r[1] | (r[2] << 8)) : r[1]; info8[3] = r[3] ? r[3] : r[2]; info8[4] = L.waves;
     info8[5] = (int32_t)blu::blu_lds_bytes(L); info8[6] = L.table_bytes; info8[7] = L.total_bytes;
     offsets3[0] = L.off_g_chirp; offsets3[1] = L.off_g_bp; offsets3[2] = L.off_g_tw;
     if (blob) {

@@ -138,9 +138,11 @@ static int fam_blu_select(FamilyCtx &c) {
     if (rc) return rc;
     c.p->bluk = 1;
     c.p->lds = blu::blu_lds_bytes(c.p->bl);
-    static const char *names[3][5] = {{"st_blu_256", "st_blu_512", "st_blu_1024", "st_blu_2048", "st_blu_4096"},
-                                      {"spectrogram_blu_256", "spectrogram_blu_512", "spectrogram_blu_1024", "spectrogram_blu_2048", "spectrogram_blu_4096"},
-                                      {"chromagram_blu_256", "chromagram_blu_512", "chromagram_blu_1024", "chromagram_blu_2048", "chromagram_blu_4096"}};
+    static const char *names[3][6] = {{"st_blu_256", "st_blu_512", "st_blu_1024", "st_blu_2048", "st_blu_4096", "st_blu_8192"},
+                                      {"spectrogram_blu_256", "spectrogram_blu_512", "spectrogram_blu_1024", "spectrogram_blu_2048", "spectrogram_blu_4096",
+                                       "spectrogram_blu_8192"},
+                                      {"chromagram_blu_256", "chromagram_blu_512", "chromagram_blu_1024", "chromagram_blu_2048", "chromagram_blu_4096",
+                                       "chromagram_blu_8192"}};
     c.p->kernel_name = names[c.mode][c.p->bl.log2m - 8];
     return 1;
 }

@@ -32,7 +32,9 @@ def test_plans_dispatch_the_bluestein_kernel(gpu_lib):
     assert kernel_name(8000, 158, 79, mode=1) == "spectrogram_blu_256"
     assert kernel_name(22050, 1103, 441, mode=1) == "spectrogram_blu_2048"
     assert kernel_name(22050, 661, 220, kind=2, mode=2) == "chromagram_blu_1024"
-    assert kernel_name(44100, 2735, 1000) in ("st_generic", "big_window_hbm_passes")      # 5 x 547: beyond the 4096-point convolution
+    assert kernel_name(44100, 2735, 1000) == "st_blu_8192"            # 5 x 547: four passes, one wave per CU
+    assert kernel_name(96000, 5461, 2000) == "st_blu_8192"            # the longest window of the kernel
+    assert kernel_name(96000, 5463, 2000) in ("st_generic", "big_window_hbm_passes")      # 3 x 3 x 607: beyond the 8192-point convolution
     assert kernel_name(22050, 1102, 441) == "st_tri_r19x29x2"         # the register-FFT shapes keep their windows
     assert kernel_name(22050, 1100, 550) == "st_mix"
 
@@ -55,6 +57,9 @@ CASES = [
     (48000, 2731, 1365, "stereo", 8, True),    # the longest window of the kernel: 2731 + 1365 - 1 = 4095
     (16000, 1366, 683, "i16", 10, False),      # 2 x 683: 2048 exactly
     (16000, 1001 + 18, 500, "unit", 6, True),  # 1019 is prime, float input in [-1, 1]
+    (44100, 2735, 1000, "i16", 10, True),      # 8192: four passes (16 x 8 x 8 x 8), the samples of pass 0 come from global memory again
+    (96000, 5147, 2573, "stereo", 8, False),
+    (48000, 5461, 5461, "f64", 6, True),       # the longest window: 5461 + 2730 - 1 = 8190
 ]
 
 
@@ -75,7 +80,7 @@ def test_full_matrix_against_c_oracle(gpu_lib, fs, window, step, kind, seconds, 
 
 @pytest.mark.parametrize("fs,window,step,kind", [(22050, 1103, 441, "i16"), (22050, 661, 220, "stereo"), (16000, 736, 736, "f64"),
                                                   (16000, 202, 101, "i16"), (44100, 2203, 1100, "stereo"), (8000, 158, 79, "i16"),
-                                                  (48000, 2731, 2731, "i16")])
+                                                  (48000, 2731, 2731, "i16"), (96000, 4001, 2000, "stereo")])
 def test_spectrogram_chromagram_full_against_c_oracle(gpu_lib, capsys, fs, window, step, kind):
     sig, mono = make_signal(kind, 9100 + window, 9.3, fs)
     spec, t_ax, f_ax = ShortTermFeatures.spectrogram(sig, fs, window, step)
@@ -150,7 +155,7 @@ def test_random_windows_with_large_prime_factors(gpu_lib):
     done = 0
     while done < 40:
         fs = int(rng.choice([8000, 11025, 16000, 22050, 32000, 44100, 48000]))
-        window = int(rng.integers(200, 2732))
+        window = int(rng.integers(200, 5462))
         step = int(rng.integers(window // 4, window + 1))
         try:
             name = kernel_name(fs, window, step)
