@@ -36,7 +36,8 @@ def main():
     traffic["round"] = rnd
     json.dump(traffic, open(os.path.join(prof, "latest_traffic.json"), "w"), indent=1)
     subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "fp64_executed.py"),
-                           os.path.join(prof, "%s_fast800_w8_summary.json" % rnd)])
+                           os.path.join(prof, "%s_fast800_w8_summary.json" % rnd),
+                           os.path.join(prof, "%s_fast800_fp64_executed.json" % rnd)], stdout=subprocess.DEVNULL)
     wt = os.path.join(src, "wave_trace.txt")
     if os.path.exists(wt) and os.path.getsize(wt) > 200:
         text = open(wt).read()

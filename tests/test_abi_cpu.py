@@ -550,7 +550,9 @@ def test_shipped_kernels_hold_their_register_budget():
     for r in blu:
         short = r["kernel"].endswith(", 8>") or r["kernel"].endswith(", 9>")
         longest = r["kernel"].endswith(", 13>")
-        assert r["vgpr"] <= 256 and (r["scratch_bytes_per_lane"] <= 2048 if longest else (r["scratch_bytes_per_lane"] == 0 and r["vgpr_spill"] == 0)), r
+        # ("vgpr" is the unified count: architected + accumulation registers, 512 per lane at one wave per SIMD)
+        assert r["vgpr"] <= (256 if short else 512), r
+        assert r["scratch_bytes_per_lane"] <= 2048 if longest else (r["scratch_bytes_per_lane"] == 0 and r["vgpr_spill"] == 0), r
         assert (r["agpr"] == 0 and r["waves_per_simd_by_registers"] >= 2) if short else r["waves_per_simd_by_registers"] >= 1, r
     for r in rows:
         lean_skewed = r["kernel"].startswith("mix::st_mix_kernel<") and r["kernel"].endswith(", 2>")
