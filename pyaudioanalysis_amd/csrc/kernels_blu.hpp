@@ -51,7 +51,7 @@ using f800::g_wave_trace;
 
 template <int LOG2M> struct Sched;
 // NW = waves per workgroup: it sets the register budget (512 / ceil(NW / 4) per lane).  More waves than these spilled to scratch --
-// 288 bytes per lane at M = 1024 with eight waves, and 12 x the algorithmic bytes in HBM writes (profiles/r06_blu_661_w8_summary.json)
+// 288 bytes per lane at M = 1024 with eight waves, and 12 x the algorithmic bytes in HBM writes (profiles/r06a_blu_661_eight_waves_spill_summary.json)
 // R1B > 1: a second middle pass (M = 8192 = 16 x 8 x 8 x 8: four passes; 128 KB of LDS, one wave per CU -- windows up to 5461 samples)
 template <> struct Sched<8> { static constexpr int R0 = 4, R1 = 8, R1B = 1, R2 = 8, NW = 8; };
 template <> struct Sched<9> { static constexpr int R0 = 8, R1 = 8, R1B = 1, R2 = 8, NW = 8; };

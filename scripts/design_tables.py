@@ -11,7 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main(rnd):
-    line = json.load(open(os.path.join(ROOT, "profiles", "bench_%s_n1_local.json" % rnd)))
+    # (round 6: the printed line is trimmed to fit the driver's 8 KB tail; the full record of the same run sits beside it)
+    full = os.path.join(ROOT, "profiles", "bench_%s_n1_full.json" % rnd)
+    line = json.load(open(full if os.path.exists(full) else os.path.join(ROOT, "profiles", "bench_%s_n1_local.json" % rnd)))
     others = line["config"]["others"]
     print("| config | kernel | step (ms) | frames/s | algorithmic GB/s (fraction of 8 TB/s) |")
     print("|---|---|---|---|---|")
