@@ -60,8 +60,12 @@ template <> struct Sched<11> { static constexpr int R0 = 16, R1 = 16, R1B = 1, R
 template <> struct Sched<12> { static constexpr int R0 = 16, R1 = 16, R1B = 1, R2 = 16, NW = 2; };
 template <> struct Sched<13> { static constexpr int R0 = 16, R1 = 8, R1B = 8, R2 = 8, NW = 1; };
 
-template <int LOG2M_>
+// PACKED: even windows as W / 2 complex points z[m] = y[2m] + i y[2m+1] (the real-input trick of every other kernel here): the convolution only has to
+// hold 2 (W / 2) - 1 points, so M >= W - 1 instead of W + W / 2 - 1 -- half the length for 58 % of the even windows (736: 1024 instead of 2048).  The price:
+// all W / 2 outputs Z[k] are needed as COMPLEX numbers (times conj c[k]) and Z[k], Z[W/2 - k] meet in one more pass over the buffer (pair_magnitudes).
+template <int LOG2M_, bool PACKED_ = false>
 struct Shape {
+    static constexpr bool PACKED = PACKED_;
     static constexpr int LOG2M = LOG2M_, M = 1 << LOG2M_;
     static constexpr int R0 = Sched<LOG2M_>::R0, R1 = Sched<LOG2M_>::R1, R1B = Sched<LOG2M_>::R1B, R2 = Sched<LOG2M_>::R2;
     static constexpr int NW = Sched<LOG2M_>::NW;               // most waves per workgroup (sets the register budget)
@@ -70,10 +74,11 @@ struct Shape {
     static constexpr int SP1B = S1, S1B = S1 / R1B;            // pass 1b (R1B > 1 only): span S1, stride S1B
     static constexpr int TW0 = 0, TW1 = (R0 - 1) * S0, TW1B = TW1 + (R1 - 1) * S1;      // twiddle tables [q - 1][k] of pass 0 / 1 / 1b
     static constexpr int NTW = TW1B + (R1B > 1 ? (R1B - 1) * S1B : 0);
-    // outputs of the last pass that can be bins: k + q S0 < Nf <= (M + 1) / 3
-    static constexpr int QMAX = (R0 == 16) ? 6 : (R0 == 8 ? 3 : 2);
-    // rows of pass 0 that can hold samples: W <= (2 M + 3) / 3 (M >= W + W / 2 - 1), the rows from RZ on are zeros for every window
-    static constexpr int WMAX = (2 * M + 3) / 3, RZ = (WMAX + S0 - 1) / S0;
+    // outputs of the last pass that can be bins: k + q S0 < Nf <= (M + 1) / 3 (packed: all Z[k], k < W / 2 <= M / 2)
+    static constexpr int QMAX = PACKED ? R0 / 2 : ((R0 == 16) ? 6 : (R0 == 8 ? 3 : 2));
+    // WMAX = the longest window in samples, LMAX = the longest sequence in elements: W <= (2 M + 3) / 3 (M >= W + W / 2 - 1), packed W <= M (M >= W - 1, W
+    // even) as W / 2 elements.  The rows of pass 0 from RZ on are zeros for every window
+    static constexpr int WMAX = PACKED ? M : (2 * M + 3) / 3, LMAX = PACKED ? M / 2 : WMAX, RZ = (LMAX + S0 - 1) / S0;
     static constexpr int NB0 = S0 / 64;                        // pass-0 butterflies per lane
     // the chirp values of a frame are requested at the top of the frame when they fit the registers beside the frame's samples (two
     // butterflies per lane: 44 + 22 doubles); M = 4096 (four: 88 + 44) fetches them butterfly by butterfly inside pass 0
@@ -101,6 +106,8 @@ struct BluLayout {
     int off_g_chirp;     // global part: double2 [W]: conj(c[n])
     int off_g_bp;        // double2 [M]: FFT(b) / M at the positions the DIF passes leave the bins
     int off_g_tw;        // double2 [NTW]: pass tables
+    int off_g_post;      // packed: double2 [W / 4 + 1]: exp(-2 pi i k / W)
+    int packed;          // 1: even window as W / 2 complex points (M >= W - 1)
     int off_g_meljob, off_g_chjob;      // int4 [64] each: the lane jobs of the mel sums / the chroma gather (kernels_tri.hpp: LaneJob)
     int total_bytes;
 };
@@ -160,17 +167,25 @@ __device__ __forceinline__ void chirp_prefetch(const double2 *__restrict__ g_chi
 template <typename T, typename SH>
 __device__ __forceinline__ void fwd_pass0(double2 *buf, const double2 *__restrict__ g_chirp, const double2 (&cw)[SH::NCW][SH::RZ],
                                           const Seeds *sd0, const double2 *__restrict__ g_tw, const T *__restrict__ x,
-                                          const ClipNorm &nm, int W, int lane) {
+                                          const ClipNorm &nm, int L, int lane) {
+    // L = elements of the sequence: W samples, or W / 2 sample pairs (packed)
     constexpr int R = SH::R0, S = SH::S0, NB = SH::NB0, RZ = SH::RZ;
+    constexpr bool PK = SH::PACKED;
     const double *st = reinterpret_cast<const double *>(buf);
-    double y[SH::Y_FROM_LDS ? NB : 1][RZ];
+    const double2 *st2 = reinterpret_cast<const double2 *>(buf);
+    double2 y[SH::Y_FROM_LDS ? NB : 1][RZ];          // (direct: .y unused)
     if constexpr (SH::Y_FROM_LDS) {
 #pragma unroll
         for (int u = 0; u < NB; ++u)
 #pragma unroll
             for (int r = 0; r < RZ; ++r) {
                 const int n = lane + 64 * u + r * S;
-                y[u][r] = (n < W) ? st[min(n, W - 1)] : 0.0;
+                if constexpr (PK) {
+                    const double2 z = st2[min(n, L - 1)];
+                    y[u][r] = (n < L) ? z : make_double2(0.0, 0.0);
+                } else {
+                    y[u][r] = make_double2((n < L) ? st[min(n, L - 1)] : 0.0, 0.0);
+                }
             }
         wsync();           // every lane has its samples: the buffer may be overwritten
     }
@@ -178,23 +193,33 @@ __device__ __forceinline__ void fwd_pass0(double2 *buf, const double2 *__restric
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int k = lane + 64 * u;
-        double2 v[R], w[R], cu[RZ];
-        double yu[RZ];
+        double2 v[R], w[R], cu[RZ], yu[RZ];
 #pragma unroll
         for (int r = 0; r < RZ; ++r) {
             if constexpr (SH::CHIRP_AHEAD) cu[r] = cw[u < SH::NCW ? u : 0][r];
-            else cu[r] = g_chirp[min(k + r * S, W - 1)];
+            else cu[r] = g_chirp[min(k + r * S, L - 1)];
             if constexpr (SH::Y_FROM_LDS) yu[r] = y[u < (SH::Y_FROM_LDS ? NB : 1) ? u : 0][r];
-            else yu[r] = load_sample<T>(x + min(k + r * S, W - 1));          // (the frame is in the L2: loaded for the time-domain stage)
+            else if constexpr (PK) yu[r] = ct::PairLoad<T>::get(x + 2 * min(k + r * S, L - 1));      // (the frame is in the L2: loaded for the time-domain stage)
+            else yu[r] = make_double2(load_sample<T>(x + min(k + r * S, L - 1)), 0.0);
         }
         if constexpr (!SH::Y_FROM_LDS) {
 #pragma unroll
-            for (int r = 0; r < RZ; ++r) yu[r] = (k + r * S < W) ? fma(yu[r], sc, -nm.mean) * nm.inv : 0.0;
+            for (int r = 0; r < RZ; ++r) {
+                const bool in = k + r * S < L;
+                yu[r].x = in ? fma(yu[r].x, sc, -nm.mean) * nm.inv : 0.0;
+                if constexpr (PK) yu[r].y = in ? fma(yu[r].y, sc, -nm.mean) * nm.inv : 0.0;
+            }
         }
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-            v[r] = (r < RZ) ? make_double2(yu[r < RZ ? r : 0] * cu[r < RZ ? r : 0].x, yu[r < RZ ? r : 0] * cu[r < RZ ? r : 0].y)
-                            : make_double2(0.0, 0.0);
+        for (int r = 0; r < R; ++r) {
+            if (r < RZ) {
+                const double2 a = yu[r < RZ ? r : 0], c = cu[r < RZ ? r : 0];
+                if constexpr (PK) v[r] = cmul(a, c);
+                else v[r] = make_double2(a.x * c.x, a.x * c.y);
+            } else {
+                v[r] = make_double2(0.0, 0.0);
+            }
+        }
         mix::Bfly<R>::run(v);
         // (M >= 4096: four and more butterflies per lane -- their seeds are fetched where they are used instead of living in registers)
         expand_twiddles<R>(SH::SEEDS_RESIDENT ? sd0[SH::SEEDS_RESIDENT ? u : 0] : load_seeds(g_tw + SH::TW0, S, k, R), w);
@@ -356,6 +381,69 @@ __device__ __forceinline__ void back_pass0_magnitudes(const double2 *buf, double
             const int idx = lane + 64 * u + q * S;
             if (idx < Nf) cur[idx] = res[u][q];
         }
+    wsync();
+}
+
+// ---- packed windows: pass 0 back leaves Z[k] = conj(c[k]) conj(v[k]) IN PLACE (an in-place DIT butterfly writes where it read: no hazard), then the
+// real-FFT recombination pairs bin k with W/2 - k: X[k] = E + w^k O, X[W/2 - k] = conj(E - w^k O), E = (Z[k] + conj Z[W/2 - k]) / 2,
+// O = -i (Z[k] - conj Z[W/2 - k]) / 2, w = exp(-2 pi i / W) (g_post) -- |.| / Nf into the frame's spectrum, held in registers until every lane has read
+template <typename SH>
+__device__ __forceinline__ void back_pass0_packed(double2 *buf, double *cur, const Seeds *sd0, const double2 *__restrict__ g_tw,
+                                                  const double2 *__restrict__ g_chirp, const double2 *__restrict__ g_post, int Nc, int lane) {
+    constexpr int R = SH::R0, S = SH::S0, NB = S / 64, QM = SH::QMAX;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int k = lane + 64 * u;
+        double2 v[R], w[R], cq[QM];
+#pragma unroll
+        for (int q = 0; q < QM; ++q) cq[q] = g_chirp[min(k + q * S, Nc - 1)];
+        const int swk = sw(k);
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = buf[PAA_BLU_AT(swk, r * S)];
+        expand_twiddles<R>(SH::SEEDS_RESIDENT ? sd0[SH::SEEDS_RESIDENT ? u : 0] : load_seeds(g_tw + SH::TW0, S, k, R), w);
+#pragma unroll
+        for (int r = 1; r < R; ++r) v[r] = cmul(v[r], w[r]);
+        mix::Bfly<R>::run(v);
+#pragma unroll
+        for (int q = 0; q < QM; ++q) {
+            const double2 z = v[mix::Bfly<R>::pos(q)];
+            buf[PAA_BLU_AT(swk, q * S)] = cmul(cq[q], make_double2(z.x, -z.y));        // (indices >= Nc: never read)
+        }
+        if constexpr (NB > 2) __builtin_amdgcn_sched_barrier(0);
+    }
+    wsync();
+    constexpr int NPL = SH::M / 256 + 1;             // pairs per lane: W/2 / 2 + 1 <= M / 4 + 1
+    const int npairs = Nc / 2 + 1;
+    const double hs = 0.5 / (double)Nc;              // E, O carry 1/2; X / len(X), len = Nf = W / 2 (:621)
+    double r0[NPL], r1[NPL];
+#pragma unroll
+    for (int i0 = 0; i0 < NPL; i0 += 4) {
+        double2 zk[4], zm[4], pw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = min(lane + 64 * (i0 + i), npairs - 1);
+            if (i0 + i < NPL) { zk[i] = buf[sw(k)]; zm[i] = buf[sw(k == 0 ? 0 : Nc - k)]; pw[i] = g_post[k]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i0 + i < NPL) {
+                const double2 e = make_double2(zk[i].x + zm[i].x, zk[i].y - zm[i].y);
+                const double2 o = make_double2(zk[i].y + zm[i].y, zm[i].x - zk[i].x);
+                const double2 wo = cmul(pw[i], o);
+                const double ar = e.x + wo.x, ai = e.y + wo.y, br = e.x - wo.x, bi = e.y - wo.y;
+                r0[i0 + i] = mag_sqrt(fma(ar, ar, ai * ai)) * hs;
+                r1[i0 + i] = mag_sqrt(fma(br, br, bi * bi)) * hs;
+            }
+    }
+    wsync();           // every lane has read its operands: the spectrum may overwrite the buffer
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int k = lane + 64 * i;
+        if (k < npairs) {
+            cur[k] = r0[i];
+            if (k > 0 && Nc - k != k) cur[Nc - k] = r1[i];
+        }
+    }
     wsync();
 }
 
@@ -598,13 +686,13 @@ __device__ __forceinline__ void frame_features_blu(const PlanDev &P, const Tabs 
     wsync();
 }
 
-template <typename T, int LOG2M>
+template <typename T, int LOG2M, bool PK = false>
 __global__ __launch_bounds__(64 * Sched<LOG2M>::NW) void st_blu_kernel(PlanDev P, BluLayout L, const unsigned char *__restrict__ blob,
                                                                        const T *__restrict__ sig, const ClipDev *__restrict__ clips,
                                                                        const ClipNorm *__restrict__ norms,
                                                                        const Tile *__restrict__ tiles, int n_tiles,
                                                                        double *__restrict__ out) {
-    typedef Shape<LOG2M> SH;
+    typedef Shape<LOG2M, PK> SH;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     constexpr bool TABLES_IN_LDS = LOG2M < 13;
     if constexpr (TABLES_IN_LDS) {
@@ -638,12 +726,14 @@ __global__ __launch_bounds__(64 * Sched<LOG2M>::NW) void st_blu_kernel(PlanDev P
     const double2 *g_chirp = reinterpret_cast<const double2 *>(blob + L.off_g_chirp);
     const double2 *g_bp = reinterpret_cast<const double2 *>(blob + L.off_g_bp);
     const double2 *g_tw = reinterpret_cast<const double2 *>(blob + L.off_g_tw);
+    const double2 *g_post = reinterpret_cast<const double2 *>(blob + L.off_g_post);          // (packed windows only)
     const int4 *g_meljob = reinterpret_cast<const int4 *>(blob + L.off_g_meljob), *g_chjob = reinterpret_cast<const int4 *>(blob + L.off_g_chjob);
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane_id = threadIdx.x & 63;
     const int tile_id = blockIdx.x * L.waves + wave;
     if (tile_id >= n_tiles) return;
     const int Nf = P.Nf, W = P.W;
+    const int Lseq = PK ? W / 2 : W;          // elements of the convolved sequence: samples, or sample pairs (packed)
     int lane = lane_id;
     unsigned char *wb = smem + L.lds_table_bytes + wave * L.wave_bytes;
     double *fv = reinterpret_cast<double *>(wb + L.buf_bytes + L.unit_bytes);
@@ -702,7 +792,7 @@ __global__ __launch_bounds__(64 * Sched<LOG2M>::NW) void st_blu_kernel(PlanDev P
         double *st = reinterpret_cast<double *>(buf);
         const T *x = x0 + (long long)t * P.S;
         double2 cw[SH::NCW][SH::RZ];
-        chirp_prefetch<SH>(g_chirp, W, lane, cw);
+        chirp_prefetch<SH>(g_chirp, Lseq, lane, cw);
         double y0;
         bool silent;
         if constexpr ((SH::WMAX + 63) / 64 > 32) {
@@ -733,7 +823,7 @@ __global__ __launch_bounds__(64 * Sched<LOG2M>::NW) void st_blu_kernel(PlanDev P
             for (int k = lane; k < Nf; k += kWave) cur[k] = (k == 0) ? x0m : 0.0;
             wsync();
         } else {
-            fwd_pass0<T, SH>(buf, g_chirp, cw, sd0, g_tw, x, nm, W, lane);
+            fwd_pass0<T, SH>(buf, g_chirp, cw, sd0, g_tw, x, nm, Lseq, lane);
             PAA_TICK(2)
             double2 bp[SH::U2][SH::R2];
             bp_load<SH>(g_bp, lane, 0, bp);
@@ -745,7 +835,8 @@ __global__ __launch_bounds__(64 * Sched<LOG2M>::NW) void st_blu_kernel(PlanDev P
             if constexpr (SH::R1B > 1) pass1<SH, false, 1>(buf, sd1b, lane);
             pass1<SH, false>(buf, sd1, lane);
             PAA_TICK(5)
-            back_pass0_magnitudes<SH>(buf, cur, sd0, g_tw, Nf, lane);
+            if constexpr (PK) back_pass0_packed<SH>(buf, cur, sd0, g_tw, g_chirp, g_post, Lseq, lane);
+            else back_pass0_magnitudes<SH>(buf, cur, sd0, g_tw, Nf, lane);
             PAA_TICK(6)
         }
 
@@ -783,6 +874,13 @@ inline int blu_log2m(int window) {
     const int Nf = window / 2, need = window + Nf - 1;
     for (int lg = 8; lg <= 13; ++lg)
         if ((1 << lg) >= need) return lg;
+    return 0;
+}
+// even windows as W / 2 complex points: M >= W - 1, lengths 512 .. 4096 (0: not possible)
+inline int blu_log2m_packed(int window) {
+    if (window % 2) return 0;
+    for (int lg = 9; lg <= 12; ++lg)
+        if ((1 << lg) >= window - 1) return lg;
     return 0;
 }
 // radices of the DIF passes of M = 2^lg (the kernel's Sched)
@@ -829,11 +927,17 @@ inline int blu_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
     if (Nf < 64) return 0;                      // (chunks of the feature stages: at most two entropy blocks per lane)
     std::vector<int> radix;
     if (mix::mix_factor(fft.len, radix)) return 0;       // smooth lengths have their own kernels
-    const int lg = blu_log2m(W);
+    int lg = blu_log2m(W);
+    // the packed form when it halves the convolution (or is the only one that fits)
+    const int lgp = blu_log2m_packed(W);
+    const bool packed = lgp && (!lg || lgp < lg);
+    if (packed) lg = lgp;
     if (!lg) return 0;
     const int M = 1 << lg;
     memset(&L, 0, sizeof(L));
     L.log2m = lg;
+    L.packed = packed ? 1 : 0;
+    const int Lseq = packed ? W / 2 : W, Lout = packed ? W / 2 : Nf;          // elements in, outputs needed
     L.unit_bytes = (Nf * 8 + 255) / 256 * 256;
     L.buf_bytes = M * 16;
     const int FF = F > 0 ? F : 1;
@@ -857,7 +961,8 @@ inline int blu_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
     const int np = rdx[3] ? 4 : 3;
     const int S0 = M / rdx[0], S1 = S0 / rdx[1], S1B = rdx[3] ? S1 / rdx[2] : 0;
     const int ntw = (rdx[0] - 1) * S0 + (rdx[1] - 1) * S1 + (rdx[3] ? (rdx[2] - 1) * S1B : 0);
-    L.off_g_chirp = take((size_t)W * 16);
+    L.off_g_chirp = take((size_t)Lseq * 16);
+    L.off_g_post = take(packed ? (size_t)(W / 4 + 1) * 16 : 16);
     L.off_g_bp = take((size_t)M * 16);
     L.off_g_tw = take((size_t)ntw * 16);
     L.off_g_meljob = take(64 * 16);
@@ -893,21 +998,29 @@ inline int blu_layout(const FftPlan &fft, const MelTable *mel, const ChromaTable
     if (mel && !mel->w.empty())
         tri::lane_jobs(40, mel->lo.data(), mel->off.data(), mel->cnt.data(), reinterpret_cast<tri::LaneJob *>(b + L.off_g_meljob));
     const long double pi = 3.141592653589793238462643383279502884L;
-    // c[m] = exp(i pi m^2 / W): m^2 is reduced mod 2 W in integers first
+    // c[m] = exp(i pi m^2 / Lseq): m^2 is reduced mod 2 Lseq in integers first
     auto chirp = [&](long long m, long double &cr, long double &ci) {
-        const long long r = (m * m) % (2LL * W);
-        const long double ang = pi * (long double)r / (long double)W;
+        const long long r = (m * m) % (2LL * Lseq);
+        const long double ang = pi * (long double)r / (long double)Lseq;
         cr = cosl(ang); ci = sinl(ang);
     };
+    if (packed) {
+        double *gp = reinterpret_cast<double *>(b + L.off_g_post);
+        for (int k = 0; k <= W / 4; ++k) {
+            const long double ang = -2.0L * pi * (long double)k / (long double)W;
+            gp[2 * k] = (double)cosl(ang);
+            gp[2 * k + 1] = (double)sinl(ang);
+        }
+    }
     double *gc = reinterpret_cast<double *>(b + L.off_g_chirp);
-    for (int n = 0; n < W; ++n) {
+    for (int n = 0; n < Lseq; ++n) {
         long double cr, ci;
         chirp(n, cr, ci);
         gc[2 * n] = (double)cr;
         gc[2 * n + 1] = (double)(-ci);                 // conj(c[n])
     }
     std::vector<long double> re((size_t)M, 0.0L), im((size_t)M, 0.0L);
-    for (long long m = -(long long)(W - 1); m <= (long long)Nf - 1; ++m) {
+    for (long long m = -(long long)(Lseq - 1); m <= (long long)Lout - 1; ++m) {
         long double cr, ci;
         chirp(m, cr, ci);
         const size_t idx = (size_t)(((m % M) + M) % M);

@@ -200,6 +200,8 @@ extern "C" int paa_debug_blu_plan(int window, double fs, int32_t *info8, int32_t
     info8[0] = L.log2m; info8[1] = r[0]; info8[2] = r[3] ? (r[1] | (r[2] << 8)) : r[1]; info8[3] = r[3] ? r[3] : r[2]; info8[4] = L.waves;
     info8[5] = (int32_t)blu::blu_lds_bytes(L); info8[6] = L.table_bytes; info8[7] = L.total_bytes;
     offsets3[0] = L.off_g_chirp; offsets3[1] = L.off_g_bp; offsets3[2] = L.off_g_tw;
+    if (L.packed) info8[0] |= 0x100;          // packed form: W / 2 complex points; the post-twiddles exp(-2 pi i k / W) sit right behind the chirp
+
     if (blob) {
         if (capacity < (int)b.size()) return fail(PAA_ERR_ARG, "blob capacity %d < %d", capacity, (int)b.size());
         memcpy(blob, b.data(), b.size());

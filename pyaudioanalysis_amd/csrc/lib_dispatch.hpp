@@ -143,7 +143,10 @@ static int fam_blu_select(FamilyCtx &c) {
                                        "spectrogram_blu_8192"},
                                       {"chromagram_blu_256", "chromagram_blu_512", "chromagram_blu_1024", "chromagram_blu_2048", "chromagram_blu_4096",
                                        "chromagram_blu_8192"}};
-    c.p->kernel_name = names[c.mode][c.p->bl.log2m - 8];
+    static const char *names_p[3][4] = {{"st_blu_512p", "st_blu_1024p", "st_blu_2048p", "st_blu_4096p"},
+                                        {"spectrogram_blu_512p", "spectrogram_blu_1024p", "spectrogram_blu_2048p", "spectrogram_blu_4096p"},
+                                        {"chromagram_blu_512p", "chromagram_blu_1024p", "chromagram_blu_2048p", "chromagram_blu_4096p"}};
+    c.p->kernel_name = c.p->bl.packed ? names_p[c.mode][c.p->bl.log2m - 9] : names[c.mode][c.p->bl.log2m - 8];
     return 1;
 }
 static void fam_blu_rule(FamilyCtx &c, RunRule &r) {

@@ -546,21 +546,21 @@ def test_shipped_kernels_hold_their_register_budget():
     # (M = 8192, windows of 2732 .. 5461 samples: 128 KB of LDS, ONE wave per CU, eight radix-16 butterflies per lane in the outer passes --
     # that instance spills 2 KB per lane to scratch; it replaces an O(N p) kernel and is the slow tail of the family)
     blu = by_family["blu::st_blu_kernel"]
-    assert len(blu) == 18, len(blu)
+    assert len(blu) == 30, len(blu)          # 6 lengths x 3 sample types + the packed form of 512 .. 4096
     for r in blu:
-        short = r["kernel"].endswith(", 8>") or r["kernel"].endswith(", 9>")
-        longest = r["kernel"].endswith(", 13>")
+        short = ", 8, " in r["kernel"] or ", 9, " in r["kernel"]
+        longest = ", 13, " in r["kernel"]
         # ("vgpr" is the unified count: architected + accumulation registers, 512 per lane at one wave per SIMD)
         assert r["vgpr"] <= (256 if short else 512), r
-        assert r["scratch_bytes_per_lane"] <= 2048 if longest else (r["scratch_bytes_per_lane"] == 0 and r["vgpr_spill"] == 0), r
+        assert r["scratch_bytes_per_lane"] <= 2048 if longest else (r["scratch_bytes_per_lane"] == 0 and r["vgpr_spill"] <= 8), r
         assert (r["agpr"] == 0 and r["waves_per_simd_by_registers"] >= 2) if short else r["waves_per_simd_by_registers"] >= 1, r
     for r in rows:
         lean_skewed = r["kernel"].startswith("mix::st_mix_kernel<") and r["kernel"].endswith(", 2>")
         full = r["kernel"].startswith("mix::st_mix_kernel<") and r["kernel"].endswith(", 0>")
-        blu_long = r["kernel"].startswith("blu::st_blu_kernel<") and not (r["kernel"].endswith(", 8>") or r["kernel"].endswith(", 9>"))
-        blu_8192 = r["kernel"].startswith("blu::st_blu_kernel<") and r["kernel"].endswith(", 13>")
+        blu_long = r["kernel"].startswith("blu::st_blu_kernel<") and not (", 8, " in r["kernel"] or ", 9, " in r["kernel"])
+        blu_8192 = r["kernel"].startswith("blu::st_blu_kernel<") and ", 13, " in r["kernel"]
         assert (r["scratch_bytes_per_lane"] > 0) <= (lean_skewed or blu_8192), r
-        assert blu_8192 or (r["scratch_bytes_per_lane"] <= 20 and r["vgpr_spill"] <= 2), r
+        assert blu_8192 or (r["scratch_bytes_per_lane"] <= 20 and r["vgpr_spill"] <= (8 if blu_long else 2)), r
         assert (r["agpr"] > 0) <= (full or blu_long), r
     import bench
     import json
@@ -818,7 +818,7 @@ def test_bench_self_launch_refuses_a_job_the_box_cannot_run(monkeypatch, capsys)
     assert "WORLD_SIZE=1" in str(exc.value)
 
 
-@pytest.mark.parametrize("window", [661, 1103, 736, 202, 158, 2203, 2731, 1322, 2735, 5147, 5461])
+@pytest.mark.parametrize("window", [661, 1103, 736, 202, 158, 2203, 2731, 1322, 2735, 5147, 5461, 1486, 3002, 4094])
 def test_bluestein_tables_reproduce_the_spectrum(window):
     """Host tables of csrc/kernels_blu.hpp (no device): the kernel's passes restated in NumPy FROM THE LIBRARY'S OWN TABLES -- the
     conjugate chirp, FFT(b) / M stored where the decimation-in-frequency passes leave each bin, the per-pass twiddles -- forward
@@ -835,24 +835,30 @@ def test_bluestein_tables_reproduce_the_spectrum(window):
                                   blob.ctypes.data_as(ctypes.c_void_p), size) == size
     lg, R0, R1, R2, waves, lds, table_bytes, total = (int(v) for v in info)
     R1, R1B = R1 & 0xff, R1 >> 8                      # a second middle pass (M = 8192 = 16 x 8 x 8 x 8), 0: three passes
+    lg, packed = lg & 0xff, bool(lg & 0x100)          # packed: the even window as W / 2 complex points, M >= W - 1
     M, W, Nf = 1 << lg, window, window // 2
-    assert R0 * R1 * max(R1B, 1) * R2 == M and M >= W + Nf - 1 and (M // 2 < W + Nf - 1 or M == 256)      # the smallest power of two that holds it
+    assert R0 * R1 * max(R1B, 1) * R2 == M
+    if packed:
+        assert W % 2 == 0 and M >= W - 1 and M // 2 < W - 1 and M < W + Nf - 1          # ... and shorter than the direct form would be
+    else:
+        assert M >= W + Nf - 1 and (M // 2 < W + Nf - 1 or M == 256)      # the smallest power of two that holds it
     assert 1 <= waves <= 16 and lds <= 160 * 1024 and table_bytes % 256 == 0 and total == size
     cplx = lambda o, n: blob[o:o + 16 * n].view(np.float64).reshape(n, 2) @ np.array([1.0, 1j])      # noqa: E731
     S0, S1 = M // R0, M // R0 // R1
     S1B = S1 // R1B if R1B else 0
-    chirp = cplx(off[0], W)
+    L = W // 2 if packed else W                        # elements of the convolved sequence
+    chirp = cplx(off[0], L)
     bp = cplx(off[1], M)
     tw = cplx(off[2], (R0 - 1) * S0 + (R1 - 1) * S1 + ((R1B - 1) * S1B if R1B else 0))
     tw0 = tw[:(R0 - 1) * S0].reshape(R0 - 1, S0)
     tw1 = tw[(R0 - 1) * S0:(R0 - 1) * S0 + (R1 - 1) * S1].reshape(R1 - 1, S1)
     tw1b = tw[(R0 - 1) * S0 + (R1 - 1) * S1:].reshape(R1B - 1, S1B) if R1B else None
-    n = np.arange(W, dtype=np.int64)
-    assert np.allclose(chirp, np.exp(-1j * np.pi * ((n * n) % (2 * W)) / W), rtol=0, atol=1e-14)
+    n = np.arange(L, dtype=np.int64)
+    assert np.allclose(chirp, np.exp(-1j * np.pi * ((n * n) % (2 * L)) / L), rtol=0, atol=1e-14)
     rng = np.random.default_rng(window)
     y = rng.standard_normal(W)
     buf = np.zeros(M, dtype=complex)
-    buf[:W] = y * chirp
+    buf[:L] = ((y[0::2] + 1j * y[1::2]) if packed else y) * chirp
     # pass 0 forward: span M, stride S0, output twiddles
     for k in range(S0):
         v = np.fft.fft(buf[k::S0])
@@ -898,12 +904,29 @@ def test_bluestein_tables_reproduce_the_spectrum(window):
         v = buf[k::S0].copy()
         v[1:] *= tw0[:, k]
         out[k::S0] = np.fft.fft(v)
-    got = np.abs(out[:Nf]) / Nf
     ref = np.abs(np.fft.fft(y))[:Nf] / Nf
+    if packed:
+        # Z[k] = conj(c[k]) conj(v[k]) in place, then the real-FFT recombination of the pairs (k, W/2 - k) with the post-twiddles
+        # exp(-2 pi i k / W) that sit right behind the chirp in the blob
+        Nc = L
+        post = cplx(off[0] + 16 * L, Nc // 2 + 1)
+        assert np.allclose(post, np.exp(-2j * np.pi * np.arange(Nc // 2 + 1) / W), rtol=0, atol=1e-14)
+        Z = chirp * np.conj(out[:Nc])
+        assert np.allclose(Z, np.fft.fft(y[0::2] + 1j * y[1::2]), rtol=0, atol=1e-11)
+        got = np.full(Nf, np.nan)
+        for k in range(Nc // 2 + 1):
+            zk, zm = Z[k], Z[0 if k == 0 else Nc - k]
+            e, o = zk + np.conj(zm), -1j * (zk - np.conj(zm))
+            got[k] = abs(e + post[k] * o) * 0.5 / Nc
+            if k > 0 and Nc - k != k:
+                got[Nc - k] = abs(e - post[k] * o) * 0.5 / Nc
+        assert (Nc - 1) // S0 < R0 // 2                  # the outputs the last pass forms: q < R0 / 2
+    else:
+        got = np.abs(out[:Nf]) / Nf
+        # the bins the last pass can deliver: k + q S0 < Nf only for q < QMAX of the kernel's Shape
+        qmax = {16: 6, 8: 3, 4: 2}[R0]
+        assert (Nf - 1) // S0 < qmax
     assert np.max(np.abs(got - ref)) < 1e-13 * max(1.0, ref.max())
-    # the bins the last pass can deliver: k + q S0 < Nf only for q < QMAX of the kernel's Shape
-    qmax = {16: 6, 8: 3, 4: 2}[R0]
-    assert (Nf - 1) // S0 < qmax
 
 
 def test_bluestein_kernel_takes_the_lengths_with_large_prime_factors():
@@ -913,8 +936,8 @@ def test_bluestein_kernel_takes_the_lengths_with_large_prime_factors():
     info = np.zeros(8, dtype=np.int32)
     off = np.zeros(3, dtype=np.int32)
     plan = lambda w: lib.paa_debug_blu_plan(w, 16000.0, info.ctypes.data_as(_ffi.c_i32p), off.ctypes.data_as(_ffi.c_i32p), None, 0)      # noqa: E731
-    for w, lg in ((661, 10), (1103, 11), (736, 11), (202, 9), (158, 8), (2203, 12), (2731, 12), (683, 10), (684, 11), (2733, 13),
-                  (5461, 13)):
-        assert plan(w) > 0 and info[0] == lg, (w, info[0])
+    for w, lg in ((661, 10), (1103, 11), (736, 0x100 | 10), (202, 9), (158, 8), (2203, 12), (2731, 12), (683, 10), (2733, 13),
+                  (5461, 13), (1322, 11), (1486, 0x100 | 11), (4094, 0x100 | 12), (3002, 0x100 | 12)):
+        assert plan(w) > 0 and info[0] == lg, (w, info[0])          # (0x100: the packed form halves the convolution)
     for w in (800, 1024, 2400, 2205, 1323, 4800, 34, 126, 5462 + 1, 9001):      # smooth / too few bins / too long
         assert plan(w) == 0, w

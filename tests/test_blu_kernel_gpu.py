@@ -26,7 +26,10 @@ def kernel_name(fs, w, s, kind=0, mode=0):
 def test_plans_dispatch_the_bluestein_kernel(gpu_lib):
     assert kernel_name(22050, 1103, 441) == "st_blu_2048"             # prime
     assert kernel_name(22050, 661, 220) == "st_blu_1024"              # 0.030 x 22050 = 661.5 -> 661, prime
-    assert kernel_name(16000, 736, 368, kind=1) == "st_blu_2048"      # 46 ms at 16 kHz: 2^5 x 23
+    assert kernel_name(16000, 736, 368, kind=1) == "st_blu_1024p"     # 46 ms at 16 kHz: 2^5 x 23, packed as 368 complex points (735 <= 1024)
+    assert kernel_name(22050, 1322, 661) == "st_blu_2048"             # 2 x 661: packing does not shorten the convolution (1321 / 1982 -> 2048): direct
+    assert kernel_name(44100, 3002, 1500, mode=1) == "spectrogram_blu_4096p"      # 2 x 19 x 79: packed 4096 instead of the four-pass 8192
+    assert kernel_name(48000, 4094, 2000, kind=2) == "st_blu_4096p"   # 2 x 23 x 89: the longest packed window
     assert kernel_name(16000, 202, 101, kind=2) == "st_blu_512"       # 2 x 101
     assert kernel_name(44100, 2203, 1100) == "st_blu_4096"            # prime
     assert kernel_name(8000, 158, 79, mode=1) == "spectrogram_blu_256"
@@ -47,7 +50,12 @@ CASES = [
     (22050, 661, 220, "i16", 20, True),        # 1024
     (22050, 661, 661, "f64", 15, False),
     (22050, 661, 330, "stereo", 10, True),
-    (16000, 736, 368, "i16", 15, True),        # even window, 2^5 x 23: 2048
+    (16000, 736, 368, "i16", 15, True),        # even window, 2^5 x 23: packed, 1024
+    (16000, 736, 736, "stereo", 10, False),
+    (44100, 1486, 743, "f64", 6, True),        # 2 x 743: packed 2048 (direct: 4096)
+    (44100, 3002, 1501, "i16", 8, True),       # 2 x 19 x 79: packed 4096 (direct: 8192) -- sample pairs of pass 0 from global memory
+    (48000, 4094, 2047, "stereo", 8, False),   # the longest packed window: 4093 <= 4096
+    (16000, 404, 202, "i16", 6, True),         # 2 x 2 x 101: packed 512 (403), direct would be 1024
     (16000, 682, 341, "f64", 10, False),       # 2 x 11 x 31: 1024 exactly (682 + 341 - 1 = 1022)
     (16000, 202, 101, "i16", 10, True),        # 512
     (16000, 202, 64, "stereo", 6, False),
@@ -80,7 +88,8 @@ def test_full_matrix_against_c_oracle(gpu_lib, fs, window, step, kind, seconds, 
 
 @pytest.mark.parametrize("fs,window,step,kind", [(22050, 1103, 441, "i16"), (22050, 661, 220, "stereo"), (16000, 736, 736, "f64"),
                                                   (16000, 202, 101, "i16"), (44100, 2203, 1100, "stereo"), (8000, 158, 79, "i16"),
-                                                  (48000, 2731, 2731, "i16"), (96000, 4001, 2000, "stereo")])
+                                                  (48000, 2731, 2731, "i16"), (96000, 4001, 2000, "stereo"), (16000, 736, 368, "i16"),
+                                                  (44100, 3002, 1000, "f64")])
 def test_spectrogram_chromagram_full_against_c_oracle(gpu_lib, capsys, fs, window, step, kind):
     sig, mono = make_signal(kind, 9100 + window, 9.3, fs)
     spec, t_ax, f_ax = ShortTermFeatures.spectrogram(sig, fs, window, step)
