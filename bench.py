@@ -90,7 +90,8 @@ SHAPES = {
     "mix_256": (16000, 256, 128, 3600, 1, 0, 0, 0),                # 16 ms windows: its lean, skewed instance
     "blu_1103": (22050, 1103, 441, 3600, 1, 0, 0, 0),               # a prime window: Bluestein convolution of length 2048 (st_generic until round 5)
     "blu_661": (22050, 661, 220, 3600, 1, 0, 0, 0),                 # 0.030 x 22050 = 661 (prime): convolution length 1024
-    "blu_736": (16000, 736, 368, 1800, 1, 0, 0, 0),                # 46 ms at 16 kHz = 2^5 x 23: length 2048
+    "blu_736": (16000, 736, 368, 1800, 1, 0, 0, 0),                # 46 ms at 16 kHz = 2^5 x 23: packed as 368 complex points, length 1024
+    "blu_3002": (44100, 3002, 1501, 600, 1, 0, 0, 0),              # 2 x 19 x 79: packed, length 4096 (the direct form would need 8192)
     "blu_1103_spectrogram": (22050, 1103, 441, 1800, 1, 0, 1, 0),
     "blu_2203": (44100, 2203, 1100, 1200, 1, 0, 0, 0),             # a prime 50 ms window at 44.1 kHz: convolution length 4096
     "blu_202": (16000, 202, 101, 1800, 1, 0, 0, 0),                # 2 x 101: length 512
@@ -255,7 +256,7 @@ def other_configs(ffi, steps=10):
     # windows whose FFT length has a prime factor above 13 (the reference takes any int(window), :563-564): Bluestein kernel
     run_shape("blu_1103", "w1103_22kHz", "1 h at 22.05 kHz, window 1103 (prime) / step 441: chirp convolution of length 2048")
     run_shape("blu_661", "w661_22kHz", "1 h at 22.05 kHz, 30 ms / 10 ms (661, prime / 220): convolution length 1024")
-    run_shape("blu_736", "w736_16kHz", "30 min at 16 kHz, 46 ms / 23 ms (736 = 2^5 x 23 / 368): convolution length 2048")
+    run_shape("blu_736", "w736_16kHz", "30 min at 16 kHz, 46 ms / 23 ms (736 = 2^5 x 23 / 368): packed as 368 complex points, convolution length 1024")
     run_shape("blu_1103_spectrogram", "w1103_spectrogram", "30 min at 22.05 kHz, 1103 / 441, spectrogram rows")
     run_shape("mix_256", "w256_16kHz", "1 h at 16 kHz, window 256 / step 128")
     # the window of music_thumbnailing (audioSegmentation.py:1137: 1 s / 0.5 s): beyond the LDS envelope, passes through HBM

@@ -1,7 +1,7 @@
-// Bluestein (chirp-z) feature kernel: every window whose FFT length has a prime factor above 13 and that no register-FFT
-// shape covers -- 0.030 x 22050 = 661 (prime), 1103, 46 ms at 16 kHz = 736 = 2^5 x 23 ... (the reference takes any
-// int(window), ShortTermFeatures.py:563-564, :617).  Until round 6 these ran O(N p) Stockham passes in kernels_generic.hpp
-// (1103 / 441: 6.6e5 frames/s, 800 x slower than the headline).
+// Bluestein (chirp-z) feature kernel: every window of up to 5 461 samples whose FFT length has a prime factor above 13 and
+// that no register-FFT shape covers -- 0.030 x 22050 = 661 (prime), 1103, 46 ms at 16 kHz = 736 = 2^5 x 23 ... (the reference
+// takes any int(window), ShortTermFeatures.py:563-564, :617).  Until round 6 these ran O(N p) Stockham passes in
+// kernels_generic.hpp (1103 / 441: 6.6e5 frames/s, 800 x slower than the headline; this kernel: 5.2e7).
 //
 // The DFT of a real frame y[0 .. W) at the bins the reference keeps, k < Nf = W / 2 (:617-621), as a convolution
 // (n k = (n^2 + k^2 - (k - n)^2) / 2):
@@ -15,13 +15,15 @@
 // One wave = one run of consecutive frames of one clip, one frame at a time, the M complex points in the wave's LDS buffer
 // (16 M bytes, XOR-swizzled: element e sits at e ^ ((e >> 4) & 15), conflict-free ds_read_b128 / ds_write_b128 for the
 // strides of all passes at M = 256 / 2048 / 4096 and within 4/3 at 512 / 1024: scripts/dev/blu_model.py).  Three radix
-// passes (16 / 8 / 4 codelets in registers), decimation in frequency on the way in, decimation in time on the way back, so
-// that NO permutation is ever applied: FFT(b) is stored in the forward transform's digit-reversed order.
+// passes (16 / 8 / 4 codelets in registers; four at M = 8192), decimation in frequency on the way in, decimation in time on
+// the way back, so that NO permutation is ever applied: FFT(b) is stored in the forward transform's digit-reversed order.
+// Even windows run PACKED (W / 2 complex points, M >= W - 1) when that halves the convolution: see Shape.
 //
 //   load     : W samples -> y (normalised) as doubles at the front of the buffer; a frame whose samples are all equal (digital
 //              silence) takes a shortcut: spectrum [W |y0| / Nf, 0, 0, ...] exactly, as the reference's pocketfft gives for a
 //              constant frame (the other kernels get this from exact-zero codelets; a chirp convolution cannot)
-//   time     : zero crossings, energy, energy entropy from y (kernels_mix.hpp's contiguous chunks)
+//   time     : zero crossings, energy, energy entropy from y (kernels_mix.hpp's contiguous chunks; the ten block energies from
+//              the running energy at the block boundaries: one wave scan instead of eleven reductions)
 //   pass 0   : DIF radix R0 over the whole sequence, straight from y: element n = y[n] conj(c[n]) for n < W, 0 beyond
 //   pass 1   : DIF radix R1 inside the R0 blocks
 //   pass 2   : the innermost radix-R2 butterflies are transformed forward, multiplied by FFT(b) / M, conjugated and transformed
@@ -30,9 +32,12 @@
 //   pass 1'  : DIT radix R1 (input twiddles)
 //   pass 0'  : DIT radix R0; only the outputs k < Nf are formed (the others are dead code in the codelet), |.| / Nf goes to
 //              the frame's spectrum -- held in registers until every lane has read its operands (the spectrum overlaps the buffer)
-//   features : kernels_mix.hpp's spectral stage (run-time Nf); lane = feature row, a row's values wait in eight registers until a
-//              64-byte aligned chunk is complete (kernels_tri.hpp: row_put) -- no staging tile in LDS: 38 KB per wave at M = 2048,
-//              four waves per CU
+//   features : kernels_mix.hpp's spectral stage (run-time Nf) with kernels_tri.hpp's lane-balanced mel sums / chroma gather and its
+//              52-lane DCT; lane = feature row, a row's values wait in eight registers until a 64-byte aligned chunk is complete
+//              (kernels_tri.hpp: row_put; stored at the top of the NEXT iteration: vmcnt counts loads and stores in one sequence) -- no
+//              staging tile in LDS: 38 KB per wave at M = 2048, four waves per CU
+// Twiddles are never loaded inside the frame loop (register-resident seeds W^k .. W^4k, products of at most three table values);
+// the chirp values and FFT(b) / M are requested ahead of their use (see Seeds, chirp_prefetch, bp_load).
 //
 // Replaces the while loop at ShortTermFeatures.py:608-682 (+ helpers :22-140, :236-321) and the loops of spectrogram
 // (:415-422) / chromagram (:349-359) for those windows.
