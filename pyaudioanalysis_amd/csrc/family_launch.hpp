@@ -42,6 +42,10 @@ int mix(const mix::MixLayout &ml, size_t lds, int sample_kind, const PlanDev &P,
 int blu(const blu::BluLayout &bl, size_t lds, int sample_kind, const PlanDev &P, const unsigned char *blob,
         const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles, double *d_out,
         hipStream_t stream);
+// kernels_wgr.hpp: workgroup-wide three-pass register transform with fused features (16 000- / 8 000-sample windows); `runs`:
+// runs of consecutive frames, one workgroup walks runs b, b + grid, ...
+int wgr(int shape_id, int sample_kind, int mode, const PlanDev &P, const void *d_packed, const ClipDev *clips, const ClipNorm *norms,
+        const Tile *runs, long long n_runs, int num_cu, double *d_out, hipStream_t stream);
 // kernels_generic.hpp: Stockham passes in LDS (what is left)
 int generic(const GenLayout &gl, size_t lds, int sample_kind, const PlanDev &P, const unsigned char *blob,
             const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,

@@ -161,6 +161,9 @@ struct paa_plan {
     wg::FrameRef *d_wg_tasks = nullptr;
     unsigned short *d_wg_perm = nullptr;
     long long wg_rows = 0;           // spectrum rows of the largest chunk
+    int wgr = 0;                     // > 0: shape id of the fused three-pass kernel (kernels_wgr.hpp): 16 000- / 8 000-sample windows
+    std::vector<Tile> wgr_runs;      // runs of consecutive frames, about one per CU
+    Tile *d_wgr_runs = nullptr;
     long long mid_off_step = -1;
     long long n_tiles = 0, n_chunks = 0;
     size_t lds = 0;
@@ -189,6 +192,7 @@ static void plan_free(paa_plan *p) {
     pool_free(p->d_wg_frames);
     pool_free(p->d_wg_tasks);
     pool_free(p->d_wg_perm);
+    pool_free(p->d_wgr_runs);
     if (!p->blob_cached) pool_free(p->d_gen_blob);
     if (p->d_big) (void)hipFree(p->d_big);
     delete p;
@@ -361,7 +365,14 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         p->d_psum = b + o_sum; p->d_pmin = b + o_min; p->d_pmax = b + o_max;
     }
     // windows beyond the one-wave kernels whose transform fits one workgroup's LDS: the frame list of kernels_wg.hpp
-    if (p->big) {
+    if (p->big && wgr::wgr_shape_id(window)) {
+        // the 1 s windows of music_thumbnailing at 16 / 8 kHz: one fused launch, the transform in registers (kernels_wgr.hpp)
+        p->wgr = wgr::wgr_shape_id(window);
+        wgr::wgr_build_runs(p->clips, g_num_cu, p->wgr_runs);
+        if (p->wgr_runs.size() > 0x7fffffffULL) return fail(PAA_ERR_UNSUPPORTED, "too many runs for one launch");
+        if ((rc = upload_pooled(&p->d_wgr_runs, p->wgr_runs.data(), std::max<size_t>(p->wgr_runs.size(), 1)))) return rc;
+        p->kernel_name = std::string(mode == 0 ? "st" : (mode == 1 ? "spectrogram" : "chromagram")) + "_wgr_" + wgr::wgr_shape_name(p->wgr);
+    } else if (p->big) {
         std::vector<unsigned short> perm;
         if (wg::wg_layout(tab->fft, p->wl, perm)) {
             // spectrum scratch: one row of Nf doubles per frame of a chunk, at most 1 GiB; a chunk that starts inside a clip
@@ -629,6 +640,30 @@ static int run_wg(paa_plan *p, const void *d_packed, double *d_out) {
     return PAA_OK;
 }
 
+// the fused three-pass kernel (kernels_wgr.hpp): ONE launch for all frames of all clips, then the delta rows
+static int run_wgr(paa_plan *p, const void *d_packed, double *d_out) {
+    const PlanDev &P = p->P;
+    if (!p->wgr_runs.empty()) {
+        ProfScope prof_scope;
+        { const int rc_p = prof_scope.begin(); if (rc_p) return rc_p; }
+        if (launch::wgr(p->wgr, p->sample_kind, P.mode, P, d_packed, p->d_clips, p->d_norms, p->d_wgr_runs, (long long)p->wgr_runs.size(),
+                        g_num_cu, d_out, cs()))
+            return fail(PAA_ERR_HIP, "launch of %s failed: %s", p->kernel_name.c_str(), hipGetErrorString(hipGetLastError()));
+    }
+    if (P.mode == 0 && P.deltas) {
+        long long maxT = 0;
+        for (auto &cd : p->clips) maxT = std::max<long long>(maxT, cd.T);
+        const long long gx = ((long long)kBase * maxT + 255) / 256;
+        if (gx > 0x7fffffffLL) return fail(PAA_ERR_UNSUPPORTED, "delta grid too large (%lld frames in one clip)", maxT);
+        for (long long c0 = 0; c0 < p->n_clips; c0 += 65535) {
+            const unsigned ny = (unsigned)std::min<long long>(65535, p->n_clips - c0);
+            hipLaunchKernelGGL(wg::wg_delta_kernel, dim3((unsigned)gx, ny), dim3(256), 0, cs(), p->d_clips + c0, d_out);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return PAA_OK;
+}
+
 extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *d_out) {
     if (!plan || !d_packed || !d_out) return fail(PAA_ERR_ARG, "null plan / buffer");
     { const int rc_init = ensure_init(); if (rc_init) return rc_init; }
@@ -637,6 +672,7 @@ extern "C" int paa_plan_execute(paa_plan_t *plan, const void *d_packed, double *
     if (rc) return rc;
     rc = launch_stats(plan, d_packed);
     if (rc) return rc;
+    if (plan->wgr) return run_wgr(plan, d_packed, d_out);
     if (plan->wg)
         return plan->sample_kind == 0 ? run_wg<int16_t>(plan, d_packed, d_out)
              : plan->sample_kind == 2 ? run_wg<stereo16>(plan, d_packed, d_out) : run_wg<double>(plan, d_packed, d_out);

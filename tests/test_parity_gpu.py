@@ -394,9 +394,10 @@ def test_big_window_kernel_choice(gpu_lib):
             return plan.kernel_name
         finally:
             plan.destroy()
-    assert name(16000, 16000, 8000) == "st_wg_lds_fft"                 # music_thumbnailing's 1 s window (audioSegmentation.py:1137)
-    assert name(16000, 8000, 4000, mode=1) == "spectrogram_wg_lds_fft"
-    assert name(16000, 8000, 4000, mode=2) == "chromagram_wg_lds_fft"
+    assert name(16000, 16000, 8000) == "st_wgr_20x20x20"               # music_thumbnailing's 1 s window (audioSegmentation.py:1137): fused three-pass kernel
+    assert name(16000, 8000, 4000, mode=1) == "spectrogram_wgr_10x20x20"
+    assert name(16000, 8000, 4000, mode=2) == "chromagram_wgr_10x20x20"
+    assert name(16000, 12000, 4000, mode=1) == "spectrogram_wg_lds_fft"    # 6000 points: the in-place LDS transform of round 5
     assert name(16000, 9009, 4500) == "st_wg_lds_fft"                  # odd: 9009 = 7 x 9 x 11 x 13 real points, 144 KB of LDS
     assert name(44100, 44100, 22050) == "st_wg_split_fft"              # 22 050 complex points = 353 KB: 6 sub-transforms of 3675
     assert name(48000, 48000, 24000, mode=1) == "spectrogram_wg_split_fft"     # 24 000 points: 6 x 4000
