@@ -261,6 +261,15 @@ int paa_debug_tri_plan(int window, double fs, int32_t *shape8, int32_t *offsets6
  * slots, threads, LDS bytes, permutation in LDS, feature kernel stages the row, its LDS bytes, then (radix, span, twiddle stride) per
  * pass}; perm[k] = padded LDS position of output k of the (sub-)transform.  Returns 1, 0 when the window goes to another path        */
 int paa_debug_wg_plan(int window, int32_t *info32, uint16_t *perm, int perm_capacity);
+/* Host tables of the fused three-pass kernel of the 1 s windows (csrc/kernels_wgr.hpp: 16 000 / 8 000 samples -- the windows
+ * audioSegmentation.py:1134-1138 passes to feature_extraction), host only.  mel6[40][6] = {rising slope, falling slope, low edge, high
+ * edge, first bin, rising bins} per mel filter (the constants ShortTermFeatures.py:225-231 forms its weights from: the kernel evaluates
+ * the triangles itself); ch_n[12], ch_src[12][64], ch_w[12][64] = the chroma gather lists (:277-321), one entry per lane.  Returns the
+ * shape id (1: 20 x 20 x 20, 2: 10 x 20 x 20), 0 when the window goes to another kernel, -1 when a table cannot be held              */
+int paa_debug_wgr_tables(double fs, int window, double *mel6, int32_t *ch_n, int32_t *ch_src, double *ch_w);
+/* ... and its runs of consecutive frames (one workgroup walks runs b, b + grid, ...): per-clip frame counts -> (clip, t0, cnt)
+ * triples; *n_runs = their number (runs3 may be NULL to query it)                                                                */
+int paa_debug_wgr_runs(const int64_t *frames, int64_t n_clips, int num_cu, int32_t *runs3, int64_t capacity, int64_t *n_runs);
 /* Host side of the Bluestein kernel (kernels_blu.hpp: windows whose FFT length has a prime factor above 13; replaces
  * scipy.fftpack.fft at ShortTermFeatures.py:617 for them): info8 = {log2 M, R0, R1, R2, waves per workgroup, LDS bytes,
  * table_bytes, total_bytes}, offsets3 = byte offsets of {conj chirp [W], FFT(b) / M in pass order [M], pass twiddles} in the

@@ -10,7 +10,8 @@
 //   load     : thread j < J1 = R2 R3 fetches z[j + J1 n0], n0 < R1 (sample pairs 2 (j + J1 n0): per load instruction the threads read one
 //              contiguous span) and normalises them (ShortTermFeatures.py:567-570)
 //   time     : the same registers give the energy, the ten entropy-block energies (block = n0 / (R1 / 10): static per register row) and
-//              the sign changes (the sample before a pair is in the lane below: DPP wave_shr:1; lane 0 of a wave fetches it)
+//              the sign changes (integer sign codes; the sample before a pair is in the lane below: DPP wave_shr:1; what lane 0 of a wave
+//              misses -- the last lane of the wave before it -- crosses in 2-bit codes through LDS behind the first exchange's barrier)
 //   pass 1   : radix-R1 codelet (kernels_ct.hpp: 20 = 4 x 5 / 10 = 2 x 5 prime-factor forms, exact zeros for equal inputs), outputs
 //              times W_N^(j k0) -- the powers of ONE table value, formed by squaring / multiplying
 //   exchange : element (k0, n1, n2) at buf[k0 A1 + n1 R3 + n2]          (16-byte elements; A1, A2: scripts/dev/wgr_model.py -- every
@@ -23,8 +24,11 @@
 //              clip transforms the frame before it once more: halo) -- and go, in natural order, over the dead transform buffer
 //   features : sums / maximum / spread / flux from the registers; ONE scan of the LDS row (contiguous chunks of R1 bins) gives the
 //              roll-off bin and, as differences of the running energy at the block boundaries, the ten spectral-entropy blocks; mel
-//              filters and chroma classes one wave at a time (kernels_wg.hpp's walk); the logarithms of the two entropies, the DCT and the
-//              chroma deviation on four different waves at once
+//              filters one wave at a time with the triangle weights formed from the filter's four constants (MelAn: the 53 KB weight table
+//              of these windows does not fit beside the buffer, and a load from L2 per step of the walk cost 11 k of 59 k cycles per
+//              frame); the chroma gather lists live in registers (two classes per wave, one entry per lane); the logarithms of the two
+//              entropies, the DCT and the chroma deviation on four different waves at once
+//   The next frame's samples are touched (one load per line) before the feature stage starts.
 // Nothing but the samples (read once + the overlap of the windows from L2) and the feature columns touches HBM; spectrogram plans write
 // each row once from the registers.  Three passes instead of five, three exchanges through LDS instead of ten round trips.
 // Replaces ShortTermFeatures.py:608-682 (+ helpers :22-140, :236-321), spectrogram (:415-422), chromagram (:349-359) for these windows.
@@ -33,6 +37,10 @@
 
 namespace paa {
 namespace wgr {
+#if defined(PAA_F800_TIMING) || defined(PAA_F800_TRACE)
+using f800::g_phase_cycles;
+using f800::g_wave_trace;
+#endif
 
 template <int R1_, int R2_, int R3_, int A1_, int A2_, int B2_>
 struct Shape {
@@ -56,7 +64,12 @@ struct Shape {
     static constexpr int OFF_MSP = OFF_BND + 12 * 8;
     static constexpr int OFF_FV = OFF_MSP + 40 * 8;
     static constexpr int OFF_REDI = OFF_FV + 48 * 8;
-    static constexpr int LDS_BYTES = (OFF_REDI + NW * 4 + 15) / 16 * 16;
+    static constexpr int OFF_EDGE = OFF_REDI + NW * 4;    // unsigned [NW][2]: packed sign codes of each wave's last pass-1 lane
+    static constexpr int OFF_MELA = (OFF_EDGE + NW * 8 + 15) / 16 * 16;      // MelAn [40]
+    static constexpr int OFF_DCT = OFF_MELA + 40 * 48;    // double [13][40]
+    static constexpr int OFF_WS = OFF_DCT + 13 * 40 * 8;  // double2 [NW][3][64]: the waves' pair-sum scratch (pair_sums)
+    static constexpr int LDS_BYTES = OFF_WS + NW * 3 * 64 * 16;
+    static constexpr int SCR = NJR * J1;                  // double2 elements of one previous-spectrum block (two per workgroup)
     static_assert(R1 % 10 == 0, "time-domain entropy blocks: static per register row");
     static_assert(J1 % 10 == 0, "spectral entropy blocks: whole scan chunks");
     static_assert(A1 >= (R2 - 1) * R3 + R3 && B2 >= R3 && A2 >= (R2 - 1) * B2 + R3, "exchange rows");
@@ -67,29 +80,84 @@ struct Shape {
 typedef Shape<20, 20, 20, 404, 401, 20> S16000;
 typedef Shape<10, 20, 20, 404, 439, 22> S8000;
 
+// the plan's tables (global memory, built by wgr_build_tab): a mel filter as the four constants of its two slopes (weights: tables.hpp
+// build_mel, ShortTermFeatures.py:225-231) and the chroma gather lists, one entry per lane (at most 64 per pitch class: one per
+// semitone the bins reach)
+struct MelAn {
+    double up, dn, lo, hi;          // w(k) = up (f_k - lo) for the first n_rise bins, dn (hi - f_k) for the rest; f_k = k fs / num_fft
+    int k_lo, n_rise, cnt, pad;
+};
+struct WgrTab {
+    MelAn mel[40];
+    int ch_n[12];
+    int ch_src[12][64];
+    double ch_w[12][64];
+};
+
+// two consecutive samples as loaded (held across the feature stage as the NEXT frame's prefetch: integer types only)
+template <typename T> struct Smp {
+    ct::PairRaw<T> r;
+    static constexpr bool kInt = true;
+    static __device__ __forceinline__ Smp get(const T *p) { Smp s; s.r = ct::PairRaw<T>::get(p); return s; }
+    __device__ __forceinline__ int i0() const { return r.x0(); }
+    __device__ __forceinline__ int i1() const { return r.x1(); }
+    __device__ __forceinline__ double d0() const { return (double)r.x0(); }
+    __device__ __forceinline__ double d1() const { return (double)r.x1(); }
+};
+template <> struct Smp<double> {
+    double2 v;
+    static constexpr bool kInt = false;
+    static __device__ __forceinline__ Smp get(const double *p) { Smp s; s.v = ct::PairLoad<double>::get(p); return s; }
+    __device__ __forceinline__ int i0() const { return 0; }
+    __device__ __forceinline__ int i1() const { return 0; }
+    __device__ __forceinline__ double d0() const { return v.x; }
+    __device__ __forceinline__ double d1() const { return v.y; }
+};
+
 __device__ __forceinline__ double2 csqr(double2 a) { return make_double2(fma(a.x, a.x, -a.y * a.y), 2.0 * (a.x * a.y)); }
 // lane l receives the value of lane l - 1 (lane 0: `first`)
 __device__ __forceinline__ int shr1(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xF, 0xF, false); }
 
-// W^q, q = 1 .. R - 1, as products of earlier powers (depth log2 R), times the codelet outputs
+// Sums over the wave of NP <= 3 pairs of values at once: every lane parks its pairs in the wave's LDS scratch, lane (row i, column c) adds
+// the four rows' values of pair i at column c (conflict-free: 16 consecutive 16-byte elements per read), a 16-lane DPP reduction finishes:
+// all lanes of row i < NP return the totals of pair i.  37 + NP instructions instead of 29 per value on DPP alone.
+template <int NP>
+__device__ __forceinline__ double2 pair_sums(const double2 *v, double2 *ws, int lane) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) ws[64 * i + lane] = v[i];
+    wsync();
+    const int row = lane >> 4, i = row < NP ? row : NP - 1, c = lane & 15;
+    const double2 *q = ws + 64 * i + c;
+    const double2 a0 = q[0], a1 = q[16], a2 = q[32], a3 = q[48];
+    wsync();
+    double2 a = make_double2((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y));
+    a.x = group_sum(a.x);
+    a.y = group_sum(a.y);
+    return a;
+}
+
+// the codelet outputs times W^q, q = 1 .. R - 1: four chains W^q = W^(q - 4) W^4 from W, W^2, W^3, W^4 (five complex values live instead
+// of the R / 2 a squaring tree keeps; at most six roundings deep -- 1e-15, far inside the gates)
 template <int R, typename CD>
 __device__ __forceinline__ void twiddle_outputs(double2 *v, double2 w) {
     // (opaque: the powers of a loop-invariant value would be hoisted out of the frame loop -- 2 x 19 complex values per thread -- and spilled)
     asm volatile("" : "+v"(w.x), "+v"(w.y));
-    double2 wq[R];
-    wq[1] = w;
+    double2 c[4];
+    c[0] = w; c[1] = csqr(w); c[2] = cmul(c[1], w);
+    const double2 w4 = csqr(c[1]);
+    c[3] = w4;
 #pragma unroll
-    for (int q = 2; q < R; ++q) wq[q] = (q % 2 == 0) ? csqr(wq[q / 2]) : cmul(wq[q / 2], wq[q - q / 2]);
-#pragma unroll
-    for (int q = 1; q < R; ++q) v[CD::pos(q)] = cmul(v[CD::pos(q)], wq[q]);
+    for (int q = 1; q < R; ++q) {
+        if (q > 4) c[(q - 1) & 3] = cmul(c[(q - 1) & 3], w4);
+        v[CD::pos(q)] = cmul(v[CD::pos(q)], c[(q - 1) & 3]);
+    }
 }
-
-__device__ __forceinline__ int sign_code(double d) { return ((d > 0.0) ? 1 : 0) - ((d < 0.0) ? 1 : 0); }
 
 // MODE 0: the 34 feature rows, 1: spectrogram rows, 2: chromagram rows
 template <typename SH, typename T, int MODE>
 __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restrict__ sig, const ClipDev *__restrict__ clips,
                                                      const ClipNorm *__restrict__ norms, const Tile *__restrict__ runs, int n_runs,
+                                                     const WgrTab *__restrict__ tab, double2 *__restrict__ scr_all,
                                                      double *__restrict__ out) {
     constexpr int R1 = SH::R1, R2 = SH::R2, R3 = SH::R3, A1 = SH::A1, A2 = SH::A2, B2 = SH::B2, N = SH::N, NF = SH::NF, W = SH::W;
     constexpr int J1 = SH::J1, J2 = SH::J2, J3 = SH::J3, NW = SH::NW, NJR = SH::NJR, C = SH::C;
@@ -106,20 +174,42 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
     double *msp = reinterpret_cast<double *>(smem + SH::OFF_MSP);
     double *fv = reinterpret_cast<double *>(smem + SH::OFF_FV);
     int *redi = reinterpret_cast<int *>(smem + SH::OFF_REDI);
+    unsigned *edge = reinterpret_cast<unsigned *>(smem + SH::OFF_EDGE);
+    MelAn *melan = reinterpret_cast<MelAn *>(smem + SH::OFF_MELA);
+    double *dct = reinterpret_cast<double *>(smem + SH::OFF_DCT);
+    double2 *ws = reinterpret_cast<double2 *>(smem + SH::OFF_WS) + 3 * 64 * (threadIdx.x >> 6);
+    // the previous frame's magnitudes of this thread's bins wait in global memory (L2), two blocks per workgroup used alternately: held in
+    // registers across the passes they were spilled by the compiler -- at a place and time of its choosing
+    double2 *scr = scr_all + (size_t)blockIdx.x * 2 * SH::SCR;
+    constexpr bool INT_T = Smp<T>::kInt;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- the thread's jobs (threads past a pass's job count shadow its last job; their stores are masked)
-    const bool a1 = tid < J1, a2 = tid < J2, a3 = tid < J3;
-    const int j1 = a1 ? tid : J1 - 1;
-    const int t2 = a2 ? tid : J2 - 1, k0_2 = t2 / R3, n2_2 = t2 - k0_2 * R3;
-    const int u3 = a3 ? tid : J3 - 1, k1_3 = u3 / R1, k0_3 = u3 - k1_3 * R1;
-    const double2 w1 = P.tw[j1];                         // W_N^j
-    const double2 w2 = P.tw[R1 * n2_2];                  // W_(R2 R3)^n2
-    const int e1r = k0_2 * A1 + n2_2, e2w = k0_2 * A2 + n2_2, e2r = k0_3 * A2 + k1_3 * B2;
+    const double2 w1 = P.tw[tid < J1 ? tid : J1 - 1];                        // W_N^j
+    const double2 w2 = P.tw[R1 * ((tid < J2 ? tid : J2 - 1) % R3)];          // W_(R2 R3)^n2
     const double sc = sample_scale<T>();
     const double invNf = 1.0 / (double)NF;
     const Tabs tb = tabs_global(P);
     const double f0 = P.fs / (2.0 * (double)NF);
+    const double dfm = P.fs / (double)NF;                // the mel bank's bin axis: k fs / num_fft (:216, num_fft = W / 2)
+    // ---- tables, once per workgroup: the mel constants to LDS, the wave's two chroma classes (w, w + NW) to registers
+    int ch_s0 = 0, ch_s1 = 0;
+    double ch_w0 = 0.0, ch_w1 = 0.0;
+    if (MODE == 0) {
+        const int *src = reinterpret_cast<const int *>(tab->mel);
+        int *dst = reinterpret_cast<int *>(melan);
+        for (int i = tid; i < 40 * 12; i += SH::NT) dst[i] = src[i];
+        for (int i = tid; i < 13 * 40; i += SH::NT) dct[i] = tb.dct[(i / 40) * tb.dct_stride + i % 40];
+    }
+    if (MODE != 1) {
+        const int c1 = wave + NW;
+        ch_s0 = tab->ch_src[wave][lane]; ch_w0 = tab->ch_w[wave][lane];
+        if (c1 < 12) { ch_s1 = tab->ch_src[c1][lane]; ch_w1 = tab->ch_w[c1][lane]; }
+    }
+    __syncthreads();
 
+    const int tile_id = blockIdx.x * NW + wave;          // (timing builds: the wave's slot in the trace)
+    (void)tile_id;
+    PAA_T0()
     for (int run = blockIdx.x; run < n_runs; run += gridDim.x) {
         const Tile tl = runs[run];
         const ClipDev c = clips[tl.clip];
@@ -127,56 +217,81 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
         const T *xc = sig + c.sample_off + P.frame_origin;
         double *oc = out + c.out_off;
         const long long Tc = c.T;
-        // inactive pass-1 threads re-read the last job's samples with scale and mean 0: exact zeros, no energy
-        const double scl = a1 ? sc : 0.0, meanl = a1 ? nm.mean : 0.0, inv = nm.inv;
-        double pm[2 * NJR];                              // the previous frame's magnitudes (this thread's bins)
-        double sXp = 0.0;                                // ... and their sum
-#pragma unroll
-        for (int i = 0; i < 2 * NJR; ++i) pm[i] = 0.0;
-        const int t_first = (MODE == 0 && tl.t0 > 0) ? tl.t0 - 1 : tl.t0;
-        for (int t = t_first; t < tl.t0 + tl.cnt; ++t) {
+        const double inv = nm.inv;
+        double sXp = 0.0;                                // sum of the previous frame's magnitudes
+        SignRule sr = {0, 0, 0};
+        if (INT_T && MODE == 0) sr = sign_rule<T>(nm.mean);
+        const int t_first = (MODE == 0 && tl.t0 > 0) ? tl.t0 - 1 : tl.t0, t_end = tl.t0 + tl.cnt;
+        for (int t = t_first; t < t_end; ++t) {
             const bool halo = t < tl.t0;
-            const T *x = xc + (long long)t * P.S;
+            // (the job indices are formed again in every iteration from an opaque copy of the thread index: as loop invariants they -- and
+            // the addresses, conversions and masks derived from them -- filled a hundred registers that were then spilled)
+            int tq = tid;
+            asm volatile("" : "+v"(tq));
+            const bool a1 = tq < J1, a2 = tq < J2, a3 = tq < J3;
+            const int j1 = a1 ? tq : J1 - 1;
+            const int t2 = a2 ? tq : J2 - 1, k0_2 = t2 / R3, n2_2 = t2 - k0_2 * R3;
+            const int u3 = a3 ? tq : J3 - 1, k1_3 = u3 / R1, k0_3 = u3 - k1_3 * R1;
+            const int e1r = k0_2 * A1 + n2_2, e2w = k0_2 * A2 + n2_2, e2r = k0_3 * A2 + k1_3 * B2;
+            // inactive pass-1 threads re-read the last job's samples with scale and mean 0: exact zeros, no energy
+            const double scl = a1 ? sc : 0.0, meanl = a1 ? nm.mean : 0.0;
+            const double mscale = a1 ? 0.5 * invNf : 0.0;
             // ---------------- load + normalise (:567-570)
+            Smp<T> smp[R1];
+            {
+                const T *x = xc + (long long)t * P.S + 2 * j1;
+#pragma unroll
+                for (int n0 = 0; n0 < R1; ++n0) smp[n0] = Smp<T>::get(x + 2 * n0 * J1);
+            }
             double2 v[R1];
 #pragma unroll
-            for (int n0 = 0; n0 < R1; ++n0) {
-                const double2 xx = ct::PairLoad<T>::get(x + 2 * (n0 * J1 + j1));
-                v[n0] = make_double2(fma(xx.x, scl, -meanl) * inv, fma(xx.y, scl, -meanl) * inv);
-            }
+            for (int n0 = 0; n0 < R1; ++n0)
+                v[n0] = make_double2(fma(smp[n0].d0(), scl, -meanl) * inv, fma(smp[n0].d1(), scl, -meanl) * inv);
+#ifdef PAA_F800_TIMING
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            PAA_TICK(0)
             // ---------------- time domain (:22-51) on the same registers
+            int zc_w = 0;                                  // the wave's sign changes, but for lane 0's left neighbours
+            unsigned pc0a = 0, pc0b = 0;                   // lane 0's first samples' codes, two bits per register row (wave-uniform)
             if (MODE == 0 && !halo) {
                 double eb[10];
 #pragma unroll
                 for (int b = 0; b < 10; ++b) eb[b] = 0.0;
-                // the sample before each pair: the lane below holds it; lane 0 of a wave fetches it (the frame's first sample meets itself)
-                int cl0[R1];
-#pragma unroll
-                for (int n0 = 0; n0 < R1; ++n0) cl0[n0] = 0;
-                if (lane == 0) {
-#pragma unroll
-                    for (int n0 = 0; n0 < R1; ++n0) {
-                        const int p = n0 * J1 + j1;
-                        cl0[n0] = sign_code((p > 0) ? fma(load_sample<T>(x + 2 * p - 1), sc, -nm.mean) : v[n0].x);
-                    }
-                }
+                const int last_lane = __builtin_amdgcn_readfirstlane((64 * wave + 63 < J1 - 1) ? 63 : J1 - 1 - 64 * wave);
+                // sign codes (device_common.hpp: integer samples are compared with the clip mean in integer arithmetic); the sample before
+                // a pair is the lane below's second one; lane 0 meets itself here and its true neighbour -- the last lane of the wave
+                // before -- behind the next barrier
                 int zc = 0;
+                unsigned pc1a = 0, pc1b = 0;
 #pragma unroll
                 for (int n0 = 0; n0 < R1; ++n0) {
                     eb[n0 / SH::RB] += fma(v[n0].x, v[n0].x, v[n0].y * v[n0].y);
-                    const int c0 = sign_code(v[n0].x), c1 = sign_code(v[n0].y);
-                    const int left = shr1(c1, cl0[n0]);
-                    zc += a1 ? abs(c0 - left) + abs(c1 - c0) : 0;
+                    int c0, c1;
+                    if constexpr (INT_T) { c0 = sgn1(smp[n0].i0(), sr); c1 = sgn1(smp[n0].i1(), sr); }
+                    else { c0 = sgn1(v[n0].x); c1 = sgn1(v[n0].y); }
+                    const int left = shr1(c1, c0);
+                    sad_acc(zc, c0, left);
+                    sad_acc(zc, c1, c0);
+                    // (scalar copies of the two lanes whose codes cross a wave boundary; packed by the scalar unit)
+                    const unsigned f0 = (unsigned)__builtin_amdgcn_readlane(c0, 0), f1 = (unsigned)__builtin_amdgcn_readlane(c1, last_lane);
+                    if (n0 < 16) { pc0a |= f0 << (2 * n0); pc1a |= f1 << (2 * n0); }
+                    else { pc0b |= f0 << (2 * (n0 - 16)); pc1b |= f1 << (2 * (n0 - 16)); }
                 }
-#pragma unroll
-                for (int b = 0; b < 10; ++b) eb[b] = wsum(eb[b]);
-                zc = wsum_i(zc);
-                if (lane == 0) {
-#pragma unroll
-                    for (int b = 0; b < 10; ++b) red[16 * wave + 4 + b] = eb[b];
-                    red[16 * wave + 14] = (double)zc;
+                if (lane == 0) { edge[2 * wave] = pc1a; edge[2 * wave + 1] = pc1b; }
+                zc_w = wsum_i(a1 ? zc : 0);
+                // the ten block energies: pairs (E0, E1) .. (E4, E5), then (E6, E7), (E8, E9)
+                {
+                    double2 pr[3] = {make_double2(eb[0], eb[1]), make_double2(eb[2], eb[3]), make_double2(eb[4], eb[5])};
+                    const double2 s1 = pair_sums<3>(pr, ws, lane);
+                    if ((lane & 15) == 0 && lane < 48) *reinterpret_cast<double2 *>(red + 16 * wave + 4 + 2 * (lane >> 4)) = s1;
+                    double2 pq[2] = {make_double2(eb[6], eb[7]), make_double2(eb[8], eb[9])};
+                    const double2 s2 = pair_sums<2>(pq, ws, lane);
+                    if ((lane & 15) == 0 && lane < 32) *reinterpret_cast<double2 *>(red + 16 * wave + 10 + 2 * (lane >> 4)) = s2;
                 }
             }
+            PAA_TICK(1)
+            __builtin_amdgcn_sched_barrier(0);             // (the time-domain stage interleaved with the first pass holds 60 registers more)
             // ---------------- pass 1: radix R1 over n0, outputs times W_N^(j k0)
             CD1::run(v);
             twiddle_outputs<R1, CD1>(v, w1);
@@ -184,13 +299,27 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
 #pragma unroll
                 for (int q = 0; q < R1; ++q) buf[q * A1 + j1] = v[CD1::pos(q)];
             }
+            PAA_TICK(2)
             __syncthreads();
+            if (MODE == 0 && !halo) {
+                // lane 0's left neighbours: row n0 of the wave before's last lane -- for wave 0: row n0 - 1 of the LAST pass-1 thread (the
+                // element before z[J1 n0] is z[J1 (n0 - 1) + J1 - 1]); the frame's first sample meets itself (:22-26 has W - 1 differences).
+                // Lane n0 < R1 takes row n0.
+                const int pwv = wave > 0 ? wave - 1 : NW - 1;
+                unsigned la = edge[2 * pwv], lb = edge[2 * pwv + 1];
+                if (wave == 0) { lb = (lb << 2) | (la >> 30); la = (la << 2) | (pc0a & 3u); }
+                const int n0 = lane < R1 ? lane : 0, sh = 2 * (n0 & 15);
+                const unsigned mine = ((n0 < 16 ? pc0a : pc0b) >> sh) & 3u, left = ((n0 < 16 ? la : lb) >> sh) & 3u;
+                const int zb = wsum_i(lane < R1 ? abs((int)mine - (int)left) : 0);
+                if (lane == 0) red[16 * wave + 14] = (double)((zc_w + zb) << (INT_T ? sr.sh : 0));
+            }
             // ---------------- pass 2: radix R2 over n1 for (k0, n2), outputs times W_(R2 R3)^(n2 k1)
             double2 v2[R2];
 #pragma unroll
             for (int r = 0; r < R2; ++r) v2[r] = buf[e1r + r * R3];
             CD2::run(v2);
             twiddle_outputs<R2, CD2>(v2, w2);
+            PAA_TICK(3)
             __syncthreads();
             if (a2) {
 #pragma unroll
@@ -201,7 +330,15 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
             double2 v3[R3];
 #pragma unroll
             for (int r = 0; r < R3; ++r) v3[r] = buf[e2r + r];
+            // (opaque copy of the thread's first bin: everything derived from it below -- table addresses, (double)(k + 1) f0, ... -- is
+            // formed again per frame instead of being hoisted out of the frame loop into 100 spilled registers)
+            const int jf = j1;
+            const bool first0 = jf == 0;                   // this thread's pair jj = 0 is k = 0: bins 0 and N / 2
+            double2 pw[NJR];                               // w^k of the recombination, requested ahead of the last pass
+#pragma unroll
+            for (int jj = 0; jj < NJR; ++jj) pw[jj] = P.post[jf + J1 * jj];
             CD3::run(v3);
+            PAA_TICK(4)
             __syncthreads();
             if (a3) {
 #pragma unroll
@@ -210,18 +347,12 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
             __syncthreads();
             // ---------------- real-FFT recombination + |X| / num_fft (:617-621): pairs k = t + J1 jj and N - k (k = 0: bins 0 and N / 2)
             double mg[2 * NJR];
-            // (opaque copy of the thread's first bin: everything derived from it below -- table addresses, (double)(k + 1) f0, ... -- is
-            // formed again per frame instead of being hoisted out of the frame loop into 100 spilled registers)
-            int jf = j1;
-            asm volatile("" : "+v"(jf));
-            const bool first0 = jf == 0;                   // this thread's pair jj = 0 is k = 0: bins 0 and N / 2
             {
-                double2 zk[NJR], zm[NJR], pw[NJR];
+                double2 zk[NJR], zm[NJR];
 #pragma unroll
                 for (int jj = 0; jj < NJR; ++jj) {
                     const int k = jf + J1 * jj;
                     const bool k0 = (jj == 0) && first0;
-                    pw[jj] = P.post[k];
                     zk[jj] = buf[k];
                     zm[jj] = buf[k0 ? N / 2 : N - k];
                 }
@@ -229,16 +360,48 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
                 for (int jj = 0; jj < NJR; ++jj) {
                     const bool k0 = (jj == 0) && first0;
                     const double2 zh = k0 ? zk[jj] : zm[jj];          // (k = 0 pairs with itself)
-                    const double2 e = make_double2(0.5 * (zk[jj].x + zh.x), 0.5 * (zk[jj].y - zh.y));
-                    const double2 o = make_double2(0.5 * (zk[jj].y + zh.y), 0.5 * (zh.x - zk[jj].x));
+                    // (2 E and 2 O: the halves ride in the scale -- exact; threads without bins scale by 0)
+                    const double2 e = make_double2(zk[jj].x + zh.x, zk[jj].y - zh.y);
+                    const double2 o = make_double2(zk[jj].y + zh.y, zh.x - zk[jj].x);
                     const double2 wo = cmul(pw[jj], o);
                     const double ar = e.x + wo.x, ai = e.y + wo.y;
-                    double br = e.x - wo.x, bi = e.y - wo.y;
-                    if (k0) { br = zm[jj].x; bi = zm[jj].y; }               // bin N / 2: |Z[N / 2]| (w^(N/2) = -i turns O into the imaginary part)
-                    mg[2 * jj] = a1 ? mag_sqrt(fma(ar, ar, ai * ai)) * invNf : 0.0;
-                    mg[2 * jj + 1] = a1 ? mag_sqrt(fma(br, br, bi * bi)) * invNf : 0.0;
+                    // (bin N / 2: |Z[N / 2]| -- w^(N/2) = -i turns O into the imaginary part)
+                    const double br = k0 ? 2.0 * zm[jj].x : e.x - wo.x, bi = k0 ? 2.0 * zm[jj].y : e.y - wo.y;
+                    mg[2 * jj] = mag_sqrt(fma(ar, ar, ai * ai)) * mscale;
+                    mg[2 * jj + 1] = mag_sqrt(fma(br, br, bi * bi)) * mscale;
                 }
             }
+            // the previous frame's magnitudes (requested now, used by the flux below), this frame's for the next one
+            double2 pm[NJR];
+            if (MODE == 0) {
+                const double2 *sp = scr + ((t & 1) ? 0 : SH::SCR) + jf;
+                double2 *sn = scr + ((t & 1) ? SH::SCR : 0) + jf;
+                if (!halo && t > t_first && a1) {          // (threads without bins hold zeros, as in mg)
+#pragma unroll
+                    for (int jj = 0; jj < NJR; ++jj) pm[jj] = sp[J1 * jj];
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < NJR; ++jj) pm[jj] = make_double2(0.0, 0.0);
+                }
+                if (a1 && t + 1 < t_end) {
+#pragma unroll
+                    for (int jj = 0; jj < NJR; ++jj) sn[J1 * jj] = make_double2(mg[2 * jj], mg[2 * jj + 1]);
+                }
+            }
+            // ---------------- the next frame's samples: one load per 128-byte line brings them to the L2 / L1 while the features are formed
+            // (holding them in registers across the feature stage made the compiler spill them -- one exposed HBM latency per register)
+            // (the loaded bytes are only "used" at the end of the iteration: nothing waits for them before)
+            int touch = 0;
+            if (t + 1 < t_end) {
+                const char *xn = reinterpret_cast<const char *>(xc + (long long)(t + 1) * P.S);
+                constexpr int kLines = W * (int)sizeof(T) / 128, kPer = (kLines + SH::NT - 1) / SH::NT;
+#pragma unroll
+                for (int u = 0; u < kPer; ++u) {
+                    const int o = (tq + u * SH::NT) * 128;
+                    if (o < W * (int)sizeof(T)) touch |= *reinterpret_cast<const char *>(xn + o);
+                }
+            }
+            PAA_TICK(5)
             if (MODE == 1) {
                 double *row = oc + (long long)t * NF;
                 if (a1) {
@@ -250,20 +413,26 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
                     }
                 }
                 __syncthreads();          // every pair has been read: the next frame may write the buffer
+                asm volatile("" ::"v"(touch));
                 continue;
             }
             // ---------------- sums over the thread's bins (:57-82, :110-124)
             double sXt = 0.0, sIXt = 0.0, mxt = 0.0;
+            const double kd1 = (double)(jf + 1);           // k + 1 of the thread's first bin; N - k + 1 = (N + 2) - (k + 1)
 #pragma unroll
             for (int jj = 0; jj < NJR; ++jj) {
-                const int k = jf + J1 * jj, kh = ((jj == 0) && first0) ? N / 2 : N - k;
+                const double kl = kd1 + (double)(J1 * jj), kh = ((jj == 0) && first0) ? (double)(N / 2 + 1) : (double)(N + 2) - kl;
                 sXt += mg[2 * jj] + mg[2 * jj + 1];
-                sIXt = fma((double)(k + 1), mg[2 * jj], sIXt);
-                sIXt = fma((double)(kh + 1), mg[2 * jj + 1], sIXt);
+                sIXt = fma(kl, mg[2 * jj], sIXt);
+                sIXt = fma(kh, mg[2 * jj + 1], sIXt);
                 mxt = fmax(mxt, fmax(mg[2 * jj], mg[2 * jj + 1]));
             }
-            sXt = wsum(sXt);
-            if (MODE == 0) { sIXt = wsum(sIXt); mxt = wmax_nonneg(mxt); }
+            {
+                double2 pr[1] = {make_double2(sXt, sIXt)};
+                const double2 st = pair_sums<1>(pr, ws, lane);
+                sXt = st.x; sIXt = st.y;
+            }
+            if (MODE == 0) mxt = wmax_nonneg(mxt);
             __syncthreads();              // every pair has been read: the magnitudes may overwrite the buffer
             if (lane == 0) { red[16 * wave] = sXt; red[16 * wave + 1] = sIXt; red[16 * wave + 2] = mxt; }
             if (!halo && a1) {
@@ -279,72 +448,72 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
 #pragma unroll
             for (int w = 0; w < NW; ++w) { sX += red[16 * w]; sIX += red[16 * w + 1]; mx = fmax(mx, red[16 * w + 2]); }
             if (halo) {
-#pragma unroll
-                for (int i = 0; i < 2 * NJR; ++i) pm[i] = mg[i];
                 sXp = sX;
                 __syncthreads();          // (red is rewritten by the next frame's time-domain stage)
+                asm volatile("" ::"v"(touch));
                 continue;
             }
+            PAA_TICK(6)
             // ---------------- one scan of the row: chunk energies -> running energy at every chunk start
-            double sq[C];
             double cs = 0.0;
             {
                 const double2 *m2 = reinterpret_cast<const double2 *>(mags + jf * C);
 #pragma unroll
                 for (int i = 0; i < C / 2; ++i) {
                     const double2 mm = m2[i];
-                    sq[2 * i] = a1 ? mm.x * mm.x : 0.0;
-                    sq[2 * i + 1] = a1 ? mm.y * mm.y : 0.0;
+                    cs += mm.x * mm.x;
+                    cs += mm.y * mm.y;
                 }
-#pragma unroll
-                for (int i = 0; i < C; ++i) cs += sq[i];
+                cs = a1 ? cs : 0.0;
             }
             const double incl = wscan_incl(cs);
             if (lane == 63) slot[wave] = incl;
-            int wo = wave;                                 // (opaque: the table records of the wave's filters / classes are fetched per frame,
-            asm volatile("" : "+s"(wo));                   // not kept in -- spilled -- scalar registers across the frame loop)
+            int wo = wave;                                 // (opaque: the records of the wave's filters are fetched per frame, not kept in
+            asm volatile("" : "+s"(wo));                   // -- spilled -- registers across the frame loop)
             if (MODE == 0) {
                 // ---------------- MFCC filter sums (:236-254): wave w owns the filters w, w + NW, ..., all 64 lanes on a filter's bins, the
                 // filters of a wave walked together (kernels_wg.hpp)
                 constexpr int NFW = SH::NFW;
-                int lo[NFW], cnt[NFW];
-                const double *wv[NFW];
-                double a[NFW];
-                int maxc = 0;
+                static_assert(NFW <= 6, "three pairs of filter sums per wave");
+                double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int j = 0; j < NFW; ++j) {
                     const int m = wo + NW * j;
-                    const int mm = (m < 40) ? m : 39;
-                    lo[j] = tb.mel_lo[mm]; cnt[j] = (m < 40) ? tb.mel_cnt[mm] : 0; wv[j] = tb.mel_w + tb.mel_off[mm];
-                    a[j] = 0.0;
-                    maxc = max(maxc, cnt[j]);
+                    if (m < 40) {
+                        const MelAn f = melan[m];
+                        double a = 0.0;
+                        for (int i = lane; i < f.cnt; i += 64) {
+                            const bool rise = i < f.n_rise;
+                            const double fk = (double)(f.k_lo + i) * dfm;
+                            const double wgt = (rise ? f.up : -f.dn) * (fk - (rise ? f.lo : f.hi));
+                            a = fma(mags[f.k_lo + i], wgt, a);
+                        }
+                        acc[j] = a;
+                    }
                 }
-                for (int i = lane; i < maxc; i += 64) {
-#pragma unroll
-                    for (int j = 0; j < NFW; ++j)
-                        if (i < cnt[j]) a[j] = fma(mags[lo[j] + i], wv[j][i], a[j]);
-                }
-#pragma unroll
-                for (int j = 0; j < NFW; ++j) a[j] = wsum(a[j]);
-                double mine = a[0];
-#pragma unroll
-                for (int j = 1; j < NFW; ++j) mine = (lane == j) ? a[j] : mine;
-                if (lane < NFW && wo + NW * lane < 40) msp[wo + NW * lane] = fast_log10(mine + kEps);
+                double2 pr[3] = {make_double2(acc[0], acc[1]), make_double2(acc[2], acc[3]), make_double2(acc[4], acc[5])};
+                const double2 sm = pair_sums<3>(pr, ws, lane);
+                // row i of the wave holds the sums of its filters 2 i and 2 i + 1: lanes 16 i and 16 i + 1 take one logarithm each
+                const int jm = 2 * (lane >> 4) + (lane & 1), mm = wo + NW * jm;
+                if ((lane & 15) < 2 && lane < 48 && jm < NFW && mm < 40) msp[mm] = fast_log10(((lane & 1) ? sm.y : sm.x) + kEps);
             }
+            PAA_TICK(7)
             __syncthreads();
             double run_e = incl - cs, sP = 0.0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) { run_e += (w < wave) ? slot[w] : 0.0; sP += slot[w]; }
             if (MODE == 2) {
                 // ---------------- chromagram row (:356-359)
-                for (int cls = wo; cls < 12; cls += NW) {
-                    const int b = tb.ch_start[cls], e = tb.ch_start[cls + 1];
-                    double acc = 0.0;
-                    for (int i = b + lane; i < e; i += 64) { const double xv = mags[tb.ch_src[i]]; acc = fma(xv * xv, tb.ch_w[i], acc); }
-                    acc = wsum(acc);
-                    if (lane == 0) oc[(long long)t * 12 + cls] = (sP == 0.0) ? acc / kEps : fast_div(acc, sP);
+                {
+                    const double x0 = mags[ch_s0], x1 = mags[ch_s1];
+                    double2 pr[1] = {make_double2((x0 * x0) * ch_w0, (x1 * x1) * ch_w1)};
+                    const double2 ac = pair_sums<1>(pr, ws, lane);
+                    const double mineq = (lane == 0) ? ac.x : ac.y;
+                    if (lane == 0 || (lane == 1 && wave + NW < 12))
+                        oc[(long long)t * 12 + wave + NW * lane] = (sP == 0.0) ? mineq / kEps : fast_div(mineq, sP);
                 }
                 __syncthreads();          // the row has been read: the next frame may write the buffer
+                asm volatile("" ::"v"(touch));
                 continue;
             }
             // the running energy at the ten block boundaries (spectral entropy, :85-107)
@@ -355,10 +524,15 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
                 const double thr = 0.90 * sP;
                 int first = 0x7fffffff;
                 double rr = run_e;
+                // (the chunk once more from LDS: its squares kept in registers since the scan were 40 of the 256)
+                const double2 *m2 = reinterpret_cast<const double2 *>(mags + jf * C);
 #pragma unroll
-                for (int i = 0; i < C; ++i) {
-                    rr += sq[i];
-                    first = (a1 && first == 0x7fffffff && rr + kEps > thr) ? jf * C + i : first;
+                for (int i = 0; i < C / 2; ++i) {
+                    const double2 mm = m2[i];
+                    rr += mm.x * mm.x;
+                    first = (a1 && first == 0x7fffffff && rr + kEps > thr) ? jf * C + 2 * i : first;
+                    rr += mm.y * mm.y;
+                    first = (a1 && first == 0x7fffffff && rr + kEps > thr) ? jf * C + 2 * i + 1 : first;
                 }
                 first = mix::wmin_nonneg_i(first);
                 if (lane == 0) redi[wave] = first;
@@ -374,39 +548,32 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
                 double sSp = 0.0, sFl = 0.0;
 #pragma unroll
                 for (int jj = 0; jj < NJR; ++jj) {
-                    const int k = jf + J1 * jj, kh = ((jj == 0) && first0) ? N / 2 : N - k;
-                    const double dl = (double)(k + 1) * f0 - cen, dh = (double)(kh + 1) * f0 - cen;
+                    const double kl = kd1 + (double)(J1 * jj), kh = ((jj == 0) && first0) ? (double)(N / 2 + 1) : (double)(N + 2) - kl;
+                    const double dl = kl * f0 - cen, dh = kh * f0 - cen;
                     sSp = fma(dl * dl, mg[2 * jj] * r, sSp);
                     sSp = fma(dh * dh, mg[2 * jj + 1] * r, sSp);
-                    const double fl = mg[2 * jj] * rX - pm[2 * jj] * rXp, fh = mg[2 * jj + 1] * rX - pm[2 * jj + 1] * rXp;
+                    const double fl = mg[2 * jj] * rX - pm[jj].x * rXp, fh = mg[2 * jj + 1] * rX - pm[jj].y * rXp;
                     sFl = fma(fl, fl, sFl);
                     sFl = fma(fh, fh, sFl);
                 }
-                sSp = wsum(sSp); sFl = wsum(sFl);
-                if (lane == 0) { red2[2 * wave] = sSp; red2[2 * wave + 1] = sFl; }
+                double2 pr[1] = {make_double2(sSp, sFl)};
+                const double2 st = pair_sums<1>(pr, ws, lane);
+                if (lane == 0) { red2[2 * wave] = st.x; red2[2 * wave + 1] = st.y; }
             }
-            // ---------------- chroma (:277-321): the pitch classes w and w + NW of a wave, walked together
+            // ---------------- chroma (:277-321): the pitch classes w and w + NW of a wave, one gather entry per lane (registers)
             {
-                const int c0 = wo, c1 = wo + NW;
-                const bool two = c1 < 12;
-                const int b0 = tb.ch_start[c0], e0 = tb.ch_start[c0 + 1];
-                const int b1 = two ? tb.ch_start[c1] : 0, e1 = two ? tb.ch_start[c1 + 1] : 0;
-                double acc0 = 0.0, acc1 = 0.0;
-                const int n0 = e0 - b0, n1 = e1 - b1, nmax = max(n0, n1);
-#pragma unroll 2
-                for (int i = lane; i < nmax; i += 64) {
-                    if (i < n0) { const double xv = mags[tb.ch_src[b0 + i]]; acc0 = fma(xv * xv, tb.ch_w[b0 + i], acc0); }
-                    if (i < n1) { const double xv = mags[tb.ch_src[b1 + i]]; acc1 = fma(xv * xv, tb.ch_w[b1 + i], acc1); }
-                }
-                acc0 = wsum(acc0); acc1 = wsum(acc1);
-                if (lane == 0) fv[21 + c0] = (sP == 0.0) ? acc0 / kEps : fast_div(acc0, sP);
-                if (lane == 1 && two) fv[21 + c1] = (sP == 0.0) ? acc1 / kEps : fast_div(acc1, sP);
+                const double x0 = mags[ch_s0], x1 = mags[ch_s1];
+                double2 pr[1] = {make_double2((x0 * x0) * ch_w0, (x1 * x1) * ch_w1)};
+                const double2 ac = pair_sums<1>(pr, ws, lane);
+                const double mineq = (lane == 0) ? ac.x : ac.y;
+                if (lane == 0 || (lane == 1 && wave + NW < 12)) fv[21 + wave + NW * lane] = (sP == 0.0) ? mineq / kEps : fast_div(mineq, sP);
             }
+            PAA_TICK(8)
             __syncthreads();
             // ---------------- the last mile, on five waves at once
             if (wave == 0) {
                 if (lane < 13) {                                   // DCT (:250)
-                    const double *m = tb.dct + lane * tb.dct_stride;
+                    const double *m = dct + lane * 40;
                     double a0 = 0.0, a1_ = 0.0, a2_ = 0.0, a3_ = 0.0;
 #pragma unroll
                     for (int n = 0; n < 40; n += 4) {
@@ -458,11 +625,12 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
             }
             __syncthreads();
             if (tid < kBase) oc[(long long)tid * Tc + t] = fv[tid];
-#pragma unroll
-            for (int i = 0; i < 2 * NJR; ++i) pm[i] = mg[i];
             sXp = sX;
+            asm volatile("" ::"v"(touch));
+            PAA_TICK(9)
         }       // frames of the run
     }       // runs of this workgroup
+    PAA_TEND()
 }
 
 // ---- host -----------------------------------------------------------------------------------------------------------------------
@@ -473,6 +641,43 @@ inline int wgr_shape_id(int window) {
     return 0;
 }
 inline const char *wgr_shape_name(int id) { return id == 1 ? "20x20x20" : "10x20x20"; }
+
+// The plan's tables.  Mel: the constants build_mel (tables.hpp) forms its weights from, per filter -- the kernel evaluates
+// up (k fs / num_fft - lo) / dn (hi - k fs / num_fft) itself (the product k (fs / num_fft) instead of the reference's (k / num_fft) fs: one
+// rounding apart).  Chroma: the gather list of every pitch class padded to 64 entries of weight 0.  false: a pitch class with more than
+// 64 entries (cannot happen: one entry per semitone the bins reach) -- the caller keeps kernels_wg.hpp for the window.
+inline bool wgr_build_tab(double fs, int nfft, const MelTable *mel, const ChromaTable *chroma, WgrTab &t) {
+    memset(&t, 0, sizeof(t));
+    if (mel) {
+        double edges[kNumMel + 2];
+        mel_edges(edges);
+        for (int m = 0; m < kNumMel; ++m) {
+            const double lo = edges[m], mid = edges[m + 1], hi = edges[m + 2];
+            const double peak = 2.0 / (hi - lo);
+            const long k_lo = (long)std::floor(lo * nfft / fs) + 1, k_mid = (long)std::floor(mid * nfft / fs) + 1;
+            MelAn &f = t.mel[m];
+            f.up = peak / (mid - lo); f.dn = peak / (hi - mid); f.lo = lo; f.hi = hi;
+            f.k_lo = mel->lo[m]; f.cnt = mel->cnt[m];
+            f.n_rise = (int)std::min<long>(std::max<long>(k_mid - k_lo, 0), f.cnt);
+            if ((long)f.k_lo != k_lo && f.cnt > 0) return false;
+        }
+    }
+    if (chroma) {
+        for (int c = 0; c < 12; ++c) {
+            const int b = chroma->class_start[c], n = chroma->class_start[c + 1] - b;
+            if (n > 64) return false;
+            t.ch_n[c] = n;
+            for (int i = 0; i < n; ++i) { t.ch_src[c][i] = chroma->src[(size_t)(b + i)]; t.ch_w[c][i] = chroma->w[(size_t)(b + i)]; }
+        }
+    }
+    return true;
+}
+
+// bytes of the previous-spectrum blocks of a launch on num_cu workgroups (feature plans)
+inline size_t wgr_scratch_bytes(int shape_id, int num_cu) {
+    const size_t per = (shape_id == 1) ? (size_t)S16000::SCR : (size_t)S8000::SCR;
+    return (size_t)num_cu * 2 * per * 16;
+}
 
 // Runs of consecutive frames, about one per CU (a run that starts inside a clip costs a halo transform in feature plans): every clip
 // is cut into ceil(T / L) runs of nearly equal length, L = the per-CU share of all frames
@@ -496,7 +701,7 @@ inline void wgr_build_runs(const std::vector<ClipDev> &clips, int num_cu, std::v
 
 template <typename SH, typename T, int MODE>
 inline int wgr_launch_one(const PlanDev &P, const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const Tile *runs,
-                          long long n_runs, int num_cu, double *d_out, hipStream_t stream) {
+                          long long n_runs, int num_cu, const WgrTab *d_tab, void *d_scr, double *d_out, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&wgr_kernel<SH, T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -505,7 +710,7 @@ inline int wgr_launch_one(const PlanDev &P, const void *d_packed, const ClipDev 
     }
     const unsigned grid = (unsigned)std::min<long long>(n_runs, num_cu);
     hipLaunchKernelGGL((wgr_kernel<SH, T, MODE>), dim3(grid), dim3(SH::NT), (size_t)SH::LDS_BYTES, stream, P, (const T *)d_packed, clips,
-                       norms, runs, (int)n_runs, d_out);
+                       norms, runs, (int)n_runs, d_tab, (double2 *)d_scr, d_out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

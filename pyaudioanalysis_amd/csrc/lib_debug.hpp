@@ -15,7 +15,8 @@ extern "C" int paa_debug_phase_cycles(uint64_t *out16) {
     unsigned long long acc[16] = {0};
     // every translation unit with kernels keeps its own counters (family_*.hip)
     if (launch::phase_fast(acc, nullptr, 0) < 0 || launch::phase_ct(acc, nullptr, 0) < 0 || launch::phase_tri_a(acc, nullptr, 0) < 0 ||
-        launch::phase_tri_b(acc, nullptr, 0) < 0 || launch::phase_tri_c(acc, nullptr, 0) < 0 || launch::phase_rmg(acc, nullptr, 0) < 0 || launch::phase_blu(acc, nullptr, 0) < 0)
+        launch::phase_tri_b(acc, nullptr, 0) < 0 || launch::phase_tri_c(acc, nullptr, 0) < 0 || launch::phase_rmg(acc, nullptr, 0) < 0 || launch::phase_blu(acc, nullptr, 0) < 0 ||
+        launch::phase_wgr(acc, nullptr, 0) < 0)
         return fail(PAA_ERR_HIP, "reading the phase counters failed");
     for (int i = 0; i < 16; ++i) out16[i] = acc[i];
 #endif
@@ -160,6 +161,42 @@ extern "C" int paa_debug_mix_plan(int window, int32_t *radices, int32_t *fft_len
     if (tw_global) *tw_global = L.tw_global;
     return L.n_pass;
 }
+// host tables of the fused three-pass kernel (kernels_wgr.hpp), no device needed.  Returns the shape id of the window (0: not its
+// window; -1: a table it cannot hold).  mel6[40][6]: up, dn, lo, hi, k_lo, n_rise per filter (cnt and k_lo equal build_mel's);
+// ch_n[12], ch_src[12][64], ch_w[12][64].  runs: wgr_build_runs for `frames` (per-clip frame counts) on num_cu workgroups ->
+// (clip, t0, cnt) triples into runs3 (capacity in triples); *n_runs = their number.
+extern "C" int paa_debug_wgr_tables(double fs, int window, double *mel6, int32_t *ch_n, int32_t *ch_src, double *ch_w) {
+    const int id = wgr::wgr_shape_id(window);
+    if (!id) return 0;
+    MelTable mel;
+    ChromaTable chroma;
+    if (build_mel(fs, window / 2, mel) != PAA_OK || build_chroma(fs, window / 2, chroma) != PAA_OK) return -1;
+    std::unique_ptr<wgr::WgrTab> t(new wgr::WgrTab());
+    if (!wgr::wgr_build_tab(fs, window / 2, &mel, &chroma, *t)) return -1;
+    for (int m = 0; m < 40 && mel6; ++m) {
+        const wgr::MelAn &f = t->mel[m];
+        double *o = mel6 + 6 * m;
+        o[0] = f.up; o[1] = f.dn; o[2] = f.lo; o[3] = f.hi; o[4] = (double)f.k_lo; o[5] = (double)f.n_rise;
+        if (f.cnt != mel.cnt[m]) return -1;
+    }
+    if (ch_n) memcpy(ch_n, t->ch_n, sizeof(t->ch_n));
+    if (ch_src) memcpy(ch_src, t->ch_src, sizeof(t->ch_src));
+    if (ch_w) memcpy(ch_w, t->ch_w, sizeof(t->ch_w));
+    return id;
+}
+extern "C" int paa_debug_wgr_runs(const int64_t *frames, int64_t n_clips, int num_cu, int32_t *runs3, int64_t capacity, int64_t *n_runs) {
+    if (!frames || n_clips < 0 || num_cu < 1 || !n_runs) return fail(PAA_ERR_ARG, "bad arguments");
+    std::vector<ClipDev> clips((size_t)n_clips);
+    for (int64_t c = 0; c < n_clips; ++c) { memset(&clips[(size_t)c], 0, sizeof(ClipDev)); clips[(size_t)c].T = (int)frames[c]; }
+    std::vector<Tile> runs;
+    wgr::wgr_build_runs(clips, num_cu, runs);
+    *n_runs = (int64_t)runs.size();
+    for (size_t i = 0; i < runs.size() && (int64_t)i < capacity && runs3; ++i) {
+        runs3[3 * i] = runs[i].clip; runs3[3 * i + 1] = runs[i].t0; runs3[3 * i + 2] = runs[i].cnt;
+    }
+    return PAA_OK;
+}
+
 // host side of the workgroup-per-frame kernels (kernels_wg.hpp) for a window, no device needed.  info32: {0: complex points Nc,
 // 1: bins Nf, 2: passes, 3: r0 (0: the whole transform in LDS; > 0: split into r0 sub-transforms), 4: elements per (sub-)transform,
 // 5: top (elements between pad slots), 6: threads of the spectrum kernel, 7: its LDS bytes, 8: permutation in LDS, 9: feature

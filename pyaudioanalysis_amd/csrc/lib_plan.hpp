@@ -164,6 +164,7 @@ struct paa_plan {
     int wgr = 0;                     // > 0: shape id of the fused three-pass kernel (kernels_wgr.hpp): 16 000- / 8 000-sample windows
     std::vector<Tile> wgr_runs;      // runs of consecutive frames, about one per CU
     Tile *d_wgr_runs = nullptr;
+    wgr::WgrTab *d_wgr_tab = nullptr;      // mel constants + chroma lists of the plan's (fs, window)
     long long mid_off_step = -1;
     long long n_tiles = 0, n_chunks = 0;
     size_t lds = 0;
@@ -193,6 +194,7 @@ static void plan_free(paa_plan *p) {
     pool_free(p->d_wg_tasks);
     pool_free(p->d_wg_perm);
     pool_free(p->d_wgr_runs);
+    pool_free(p->d_wgr_tab);
     if (!p->blob_cached) pool_free(p->d_gen_blob);
     if (p->d_big) (void)hipFree(p->d_big);
     delete p;
@@ -365,9 +367,15 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
         p->d_psum = b + o_sum; p->d_pmin = b + o_min; p->d_pmax = b + o_max;
     }
     // windows beyond the one-wave kernels whose transform fits one workgroup's LDS: the frame list of kernels_wg.hpp
+    std::unique_ptr<wgr::WgrTab> wgr_tab;
     if (p->big && wgr::wgr_shape_id(window)) {
+        wgr_tab.reset(new wgr::WgrTab());
+        if (!wgr::wgr_build_tab(fs, Nf, mode == 0 ? &tab->mel : nullptr, mode != 1 ? &tab->chroma : nullptr, *wgr_tab)) wgr_tab.reset();
+    }
+    if (wgr_tab) {
         // the 1 s windows of music_thumbnailing at 16 / 8 kHz: one fused launch, the transform in registers (kernels_wgr.hpp)
         p->wgr = wgr::wgr_shape_id(window);
+        if ((rc = upload_pooled(&p->d_wgr_tab, wgr_tab.get(), 1))) return rc;
         wgr::wgr_build_runs(p->clips, g_num_cu, p->wgr_runs);
         if (p->wgr_runs.size() > 0x7fffffffULL) return fail(PAA_ERR_UNSUPPORTED, "too many runs for one launch");
         if ((rc = upload_pooled(&p->d_wgr_runs, p->wgr_runs.data(), std::max<size_t>(p->wgr_runs.size(), 1)))) return rc;
@@ -644,10 +652,17 @@ static int run_wg(paa_plan *p, const void *d_packed, double *d_out) {
 static int run_wgr(paa_plan *p, const void *d_packed, double *d_out) {
     const PlanDev &P = p->P;
     if (!p->wgr_runs.empty()) {
+        // feature plans: two blocks per workgroup for the previous frame's magnitudes (they never leave the L2)
+        const size_t need = (P.mode == 0) ? wgr::wgr_scratch_bytes(p->wgr, g_num_cu) : 0;
+        if (need > p->big_bytes) {
+            if (p->d_big) { HIP_TRY(hipStreamSynchronize(cs())); (void)hipFree(p->d_big); p->d_big = nullptr; p->big_bytes = 0; }
+            HIP_TRY(hipMalloc(&p->d_big, need));
+            p->big_bytes = need;
+        }
         ProfScope prof_scope;
         { const int rc_p = prof_scope.begin(); if (rc_p) return rc_p; }
         if (launch::wgr(p->wgr, p->sample_kind, P.mode, P, d_packed, p->d_clips, p->d_norms, p->d_wgr_runs, (long long)p->wgr_runs.size(),
-                        g_num_cu, d_out, cs()))
+                        g_num_cu, p->d_wgr_tab, p->d_big, d_out, cs()))
             return fail(PAA_ERR_HIP, "launch of %s failed: %s", p->kernel_name.c_str(), hipGetErrorString(hipGetLastError()));
     }
     if (P.mode == 0 && P.deltas) {

@@ -56,12 +56,17 @@ struct MelTable {
     std::vector<double> w;
 };
 
-// returns PAA_OK or PAA_ERR_MEL_INDEX (the reference indexes fbank[i][lid] out of range)
-inline int build_mel(double fs, int nfft, MelTable &t) {
-    double edges[kNumMel + 2];
+// the 42 frequency points of the triangles (ShortTermFeatures.py:207-211)
+inline void mel_edges(double *edges) {
     for (int i = 0; i < kNumLin; ++i) edges[i] = 133.33 + (double)i * (200.0 / 3.0);
     for (int i = kNumLin; i < kNumMel + 2; ++i)
         edges[i] = edges[kNumLin - 1] * std::pow(1.0711703, (double)(i - kNumLin + 1));
+}
+
+// returns PAA_OK or PAA_ERR_MEL_INDEX (the reference indexes fbank[i][lid] out of range)
+inline int build_mel(double fs, int nfft, MelTable &t) {
+    double edges[kNumMel + 2];
+    mel_edges(edges);
     t.lo.assign(kNumMel, 0);
     t.cnt.assign(kNumMel, 0);
     t.off.assign(kNumMel, 0);
