@@ -13,7 +13,8 @@
 //              the sign changes (integer sign codes; the sample before a pair is in the lane below: DPP wave_shr:1; what lane 0 of a wave
 //              misses -- the last lane of the wave before it -- crosses in 2-bit codes through LDS behind the first exchange's barrier)
 //   pass 1   : radix-R1 codelet (kernels_ct.hpp: 20 = 4 x 5 / 10 = 2 x 5 prime-factor forms, exact zeros for equal inputs), outputs
-//              times W_N^(j k0) -- the powers of ONE table value, formed by squaring / multiplying
+//              times W_N^(j k0) -- the powers of ONE table value, formed by multiplying -- stored group by group under the
+//              remaining butterflies (group_pass)
 //   exchange : element (k0, n1, n2) at buf[k0 A1 + n1 R3 + n2]          (16-byte elements; A1, A2: scripts/dev/wgr_model.py -- every
 //   pass 2   : thread (k0, n2): radix R2 over n1, outputs times W_(R2 R3)^(n2 k1)         ds_write_b128 / ds_read_b128 of the three
 //   exchange : element (k0, k1, n2) at buf[k0 A2 + k1 B2 + n2]                               exchanges is bank-conflict free)
@@ -136,20 +137,68 @@ __device__ __forceinline__ double2 pair_sums(const double2 *v, double2 *ws, int 
     return a;
 }
 
-// the codelet outputs times W^q, q = 1 .. R - 1: four chains W^q = W^(q - 4) W^4 from W, W^2, W^3, W^4 (five complex values live instead
-// of the R / 2 a squaring tree keeps; at most six roundings deep -- 1e-15, far inside the gates)
-template <int R, typename CD>
-__device__ __forceinline__ void twiddle_outputs(double2 *v, double2 w) {
-    // (opaque: the powers of a loop-invariant value would be hoisted out of the frame loop -- 2 x 19 complex values per thread -- and spilled)
-    asm volatile("" : "+v"(w.x), "+v"(w.y));
-    double2 c[4];
-    c[0] = w; c[1] = csqr(w); c[2] = cmul(c[1], w);
-    const double2 w4 = csqr(c[1]);
-    c[3] = w4;
+// One pass of radix 20 = 4 x 5 / 10 = 2 x 5 (the prime-factor codelets of kernels_ct.hpp, exact zeros for equal inputs) whose outputs
+// leave GROUP BY GROUP: the second stage's radix-5 butterfly g produces X[g], X[g + G], .. X[g + 4 G] (G = 4 / 2 groups); they are
+// multiplied by W^q -- chain g: W^g, then times W^G per step, at most six roundings deep -- and handed to put(q, value) at once, so the
+// LDS stores of a pass (1 820 cycles of the CU's store path per exchange when all waves store together behind the butterflies) start
+// under the remaining butterflies, and no more than five outputs wait in registers for their twiddle
+template <int R> struct GroupPass;
+template <> struct GroupPass<20> {
+    static constexpr int G = 4;
+    static __device__ __forceinline__ void stage1(double2 *v) {
 #pragma unroll
-    for (int q = 1; q < R; ++q) {
-        if (q > 4) c[(q - 1) & 3] = cmul(c[(q - 1) & 3], w4);
-        v[CD::pos(q)] = cmul(v[CD::pos(q)], c[(q - 1) & 3]);
+        for (int n2 = 0; n2 < 5; ++n2) {
+            ct::dft4r(v[(4 * n2) % 20], v[(5 + 4 * n2) % 20], v[(10 + 4 * n2) % 20], v[(15 + 4 * n2) % 20]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    static __device__ __forceinline__ void stage2(double2 *v, int g) {
+        ct::dft5r(v[(5 * g) % 20], v[(5 * g + 4) % 20], v[(5 * g + 8) % 20], v[(5 * g + 12) % 20], v[(5 * g + 16) % 20]);
+    }
+};
+template <> struct GroupPass<10> {
+    static constexpr int G = 2;
+    static __device__ __forceinline__ void stage1(double2 *v) {
+#pragma unroll
+        for (int n2 = 0; n2 < 5; ++n2) {
+            const double2 a = v[(2 * n2) % 10], b = v[(5 + 2 * n2) % 10];
+            v[(2 * n2) % 10] = cadd(a, b);
+            v[(5 + 2 * n2) % 10] = csub(a, b);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    static __device__ __forceinline__ void stage2(double2 *v, int g) {
+        ct::dft5r(v[(5 * g) % 10], v[(5 * g + 2) % 10], v[(5 * g + 4) % 10], v[(5 * g + 6) % 10], v[(5 * g + 8) % 10]);
+    }
+};
+template <int R, bool TW, typename Put>
+__device__ __forceinline__ void group_pass(double2 *v, double2 w, Put put) {
+    typedef GroupPass<R> GP;
+    typedef tri::Cd<R> CD;
+    constexpr int G = GP::G;
+    GP::stage1(v);
+    double2 wp[5];                  // W^1 .. W^G (wp[0] unused)
+    if (TW) {
+        // (opaque: the powers of a loop-invariant value would be hoisted out of the frame loop and spilled)
+        asm volatile("" : "+v"(w.x), "+v"(w.y));
+        wp[1] = w; wp[2] = csqr(w);
+        if (G == 4) { wp[3] = cmul(wp[2], w); wp[4] = csqr(wp[2]); }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        GP::stage2(v, g);
+        double2 t = TW ? wp[g == 0 ? G : g] : make_double2(1.0, 0.0);
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            const int q = g + G * m;
+            double2 x = v[CD::pos(q)];
+            if (TW && q > 0) {
+                x = cmul(x, t);
+                if (m < 4) t = cmul(t, wp[G]);
+            }
+            put(q, x);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -161,9 +210,6 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
                                                      double *__restrict__ out) {
     constexpr int R1 = SH::R1, R2 = SH::R2, R3 = SH::R3, A1 = SH::A1, A2 = SH::A2, B2 = SH::B2, N = SH::N, NF = SH::NF, W = SH::W;
     constexpr int J1 = SH::J1, J2 = SH::J2, J3 = SH::J3, NW = SH::NW, NJR = SH::NJR, C = SH::C;
-    typedef tri::Cd<R1> CD1;
-    typedef tri::Cd<R2> CD2;
-    typedef tri::Cd<R3> CD3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double2 *buf = reinterpret_cast<double2 *>(smem);
     double *mags = reinterpret_cast<double *>(smem);              // the frame's spectrum, natural order, over the dead buffer
@@ -293,11 +339,9 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
             PAA_TICK(1)
             __builtin_amdgcn_sched_barrier(0);             // (the time-domain stage interleaved with the first pass holds 60 registers more)
             // ---------------- pass 1: radix R1 over n0, outputs times W_N^(j k0)
-            CD1::run(v);
-            twiddle_outputs<R1, CD1>(v, w1);
             if (a1) {
-#pragma unroll
-                for (int q = 0; q < R1; ++q) buf[q * A1 + j1] = v[CD1::pos(q)];
+                double2 *dst = buf + j1;
+                group_pass<R1, true>(v, w1, [&](int q, double2 x) { dst[q * A1] = x; });
             }
             PAA_TICK(2)
             __syncthreads();
@@ -317,14 +361,12 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
             double2 v2[R2];
 #pragma unroll
             for (int r = 0; r < R2; ++r) v2[r] = buf[e1r + r * R3];
-            CD2::run(v2);
-            twiddle_outputs<R2, CD2>(v2, w2);
-            PAA_TICK(3)
-            __syncthreads();
+            __syncthreads();              // every thread has read its pass-2 inputs
             if (a2) {
-#pragma unroll
-                for (int q = 0; q < R2; ++q) buf[e2w + q * B2] = v2[CD2::pos(q)];
+                double2 *dst = buf + e2w;
+                group_pass<R2, true>(v2, w2, [&](int q, double2 x) { dst[q * B2] = x; });
             }
+            PAA_TICK(3)
             __syncthreads();
             // ---------------- pass 3: radix R3 over n2 for (k0, k1): Z[k0 + R1 k1 + R1 R2 k2], natural order into the buffer
             double2 v3[R3];
@@ -337,14 +379,14 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
             double2 pw[NJR];                               // w^k of the recombination, requested ahead of the last pass
 #pragma unroll
             for (int jj = 0; jj < NJR; ++jj) pw[jj] = P.post[jf + J1 * jj];
-            CD3::run(v3);
+            __syncthreads();              // every thread has read its pass-3 inputs
+            if (a3) {
+                double2 *dst = buf + u3;
+                group_pass<R3, false>(v3, make_double2(1.0, 0.0), [&](int q, double2 x) { dst[q * J3] = x; });
+            }
             PAA_TICK(4)
             __syncthreads();
-            if (a3) {
-#pragma unroll
-                for (int q = 0; q < R3; ++q) buf[u3 + q * J3] = v3[CD3::pos(q)];
-            }
-            __syncthreads();
+            PAA_TICK(10)
             // ---------------- real-FFT recombination + |X| / num_fft (:617-621): pairs k = t + J1 jj and N - k (k = 0: bins 0 and N / 2)
             double mg[2 * NJR];
             {
@@ -371,6 +413,7 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
                     mg[2 * jj + 1] = mag_sqrt(fma(br, br, bi * bi)) * mscale;
                 }
             }
+            PAA_TICK(11)
             // the previous frame's magnitudes (requested now, used by the flux below), this frame's for the next one
             double2 pm[NJR];
             if (MODE == 0) {

@@ -10,7 +10,7 @@ from bench import SHAPES, shape_input
 lib = _ffi.lib(); _ffi.init(0)
 names = ["load", "time domain", "pass 1 + write", "barrier + read + pass 2", "barrier + write + barrier + read + pass 3",
          "barrier + write + barrier + recombination", "sums + barrier + row + barrier", "scan + mel", "barrier + roll-off / spread / flux / chroma",
-         "barrier + last mile + barrier + store", "-"]
+         "barrier + last mile + barrier + store", "(recombination: barrier + write + barrier)", "(recombination: reads + magnitudes)"]
 for case in sys.argv[1:] or ["big_16000", "big_16000_1h"]:
     fs, W, S, seconds, clips, kind, mode, deltas = SHAPES[case]
     x, offsets = shape_input(case)
@@ -25,9 +25,9 @@ for case in sys.argv[1:] or ["big_16000", "big_16000_1h"]:
     _ffi.sync()
     lib.paa_debug_phase_cycles(buf)
     v = np.array(list(buf), dtype=np.float64)
-    tot = max(v[:11].sum(), 1.0)
+    tot = max(v[:12].sum(), 1.0)
     waves = max(v[15], 1) / 5
     print(case, plan.kernel_name, "frames", plan.total_frames, "waves", int(waves), "cycles/wave %.0f" % (tot / max(v[15], 1)))
-    for nme, c in zip(names, v[:11]):
+    for nme, c in zip(names, v[:12]):
         if c: print("   %-50s %6.2f %%   %.0f cycles per wave and launch" % (nme, 100 * c / tot, c / max(v[15], 1)))
     plan.destroy()
