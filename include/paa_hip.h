@@ -262,11 +262,12 @@ int paa_debug_tri_plan(int window, double fs, int32_t *shape8, int32_t *offsets6
  * pass}; perm[k] = padded LDS position of output k of the (sub-)transform.  Returns 1, 0 when the window goes to another path        */
 int paa_debug_wg_plan(int window, int32_t *info32, uint16_t *perm, int perm_capacity);
 /* Host tables of the fused three-pass kernel of the 1 s windows (csrc/kernels_wgr.hpp: 16 000 / 8 000 samples -- the windows
- * audioSegmentation.py:1134-1138 passes to feature_extraction), host only.  mel6[40][6] = {rising slope, falling slope, low edge, high
- * edge, first bin, rising bins} per mel filter (the constants ShortTermFeatures.py:225-231 forms its weights from: the kernel evaluates
- * the triangles itself); ch_n[12], ch_src[12][64], ch_w[12][64] = the chroma gather lists (:277-321), one entry per lane.  Returns the
- * shape id (1: 20 x 20 x 20, 2: 10 x 20 x 20), 0 when the window goes to another kernel, -1 when a table cannot be held              */
-int paa_debug_wgr_tables(double fs, int window, double *mel6, int32_t *ch_n, int32_t *ch_src, double *ch_w);
+ * audioSegmentation.py:1134-1138 passes to feature_extraction), host only.  mel_job[512][4] = per thread {first bin, index of its weight
+ * in the mel table, stride, number of bins}: the thread's share of ONE mel filter (ShortTermFeatures.py:236-254; its bins are first
+ * bin + j stride); mel_fil[40][2] = per filter {first thread, threads}; ch_n[12], ch_src[12][64], ch_w[12][64] = the chroma gather lists
+ * (:277-321), one entry per lane.  Returns the shape id (1: 20 x 20 x 20, 2: 10 x 20 x 20), 0 when the window goes to another kernel,
+ * -1 when a table cannot be held (the plan then keeps csrc/kernels_wg.hpp)                                                         */
+int paa_debug_wgr_tables(double fs, int window, int32_t *mel_job, int32_t *mel_fil, int32_t *ch_n, int32_t *ch_src, double *ch_w);
 /* ... and its runs of consecutive frames (one workgroup walks runs b, b + grid, ...): per-clip frame counts -> (clip, t0, cnt)
  * triples; *n_runs = their number (runs3 may be NULL to query it)                                                                */
 int paa_debug_wgr_runs(const int64_t *frames, int64_t n_clips, int num_cu, int32_t *runs3, int64_t capacity, int64_t *n_runs);

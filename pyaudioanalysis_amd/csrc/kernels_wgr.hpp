@@ -25,9 +25,11 @@
 //              clip transforms the frame before it once more: halo) -- and go, in natural order, over the dead transform buffer
 //   features : sums / maximum / spread / flux from the registers; ONE scan of the LDS row (contiguous chunks of R1 bins) gives the
 //              roll-off bin and, as differences of the running energy at the block boundaries, the ten spectral-entropy blocks; mel
-//              filters one wave at a time with the triangle weights formed from the filter's four constants (MelAn: the 53 KB weight table
-//              of these windows does not fit beside the buffer, and a load from L2 per step of the walk cost 11 k of 59 k cycles per
-//              frame); the chroma gather lists live in registers (two classes per wave, one entry per lane); the logarithms of the two
+//              filters as LANE JOBS: filter m's bins are dealt round-robin to nl[m] consecutive threads, at most sixteen bins each (all
+//              threads of the workgroup carry about the same number), whose weights -- the reference's table -- are requested once per
+//              frame, ahead of the sums; the threads' partial sums meet in LDS, eight lanes per filter add them (wave w: filters w,
+//              w + 7, ...).  (One wave walking a filter with a load from L2 per step cost 11 k of 59 k cycles per frame.)  The chroma
+//              gather lists live in registers (two classes per wave, one entry per lane); the logarithms of the two
 //              entropies, the DCT and the chroma deviation on four different waves at once
 //   The next frame's samples are touched (one load per line) before the feature stage starts.
 // Nothing but the samples (read once + the overlap of the windows from L2) and the feature columns touches HBM; spectrogram plans write
@@ -66,30 +68,32 @@ struct Shape {
     static constexpr int OFF_FV = OFF_MSP + 40 * 8;
     static constexpr int OFF_REDI = OFF_FV + 48 * 8;
     static constexpr int OFF_EDGE = OFF_REDI + NW * 4;    // unsigned [NW][2]: packed sign codes of each wave's last pass-1 lane
-    static constexpr int OFF_MELA = (OFF_EDGE + NW * 8 + 15) / 16 * 16;      // MelAn [40]
-    static constexpr int OFF_DCT = OFF_MELA + 40 * 48;    // double [13][40]
+    static constexpr int OFF_MELA = (OFF_EDGE + NW * 8 + 15) / 16 * 16;      // int2 [40]: first thread and number of threads of each mel filter
+    static constexpr int OFF_DCT = OFF_MELA + 40 * 8;     // double [13][40]
+    static constexpr int OFF_PART = N * 8;                // double [NT]: the threads' mel partial sums, in the buffer behind the spectrum row
     static constexpr int OFF_WS = OFF_DCT + 13 * 40 * 8;  // double2 [NW][3][64]: the waves' pair-sum scratch (pair_sums)
     static constexpr int LDS_BYTES = OFF_WS + NW * 3 * 64 * 16;
-    static constexpr int SCR = NJR * J1;                  // double2 elements of one previous-spectrum block (two per workgroup)
+    static constexpr int SCR = NJR * NT;                  // double2 elements of one previous-spectrum block (two per workgroup)
     static_assert(R1 % 10 == 0, "time-domain entropy blocks: static per register row");
     static_assert(J1 % 10 == 0, "spectral entropy blocks: whole scan chunks");
     static_assert(A1 >= (R2 - 1) * R3 + R3 && B2 >= R3 && A2 >= (R2 - 1) * B2 + R3, "exchange rows");
     static_assert(LDS_BYTES <= 160 * 1024, "one workgroup's LDS");
+    static_assert(OFF_PART + NT * 8 <= BUF * 16, "the mel partial sums fit behind the spectrum row");
     static_assert(NW >= 5, "the final stage spreads over five waves");
 };
 // pads from scripts/dev/wgr_model.py (reads and writes of both exchanges at the conflict-free cycle count)
 typedef Shape<20, 20, 20, 404, 401, 20> S16000;
 typedef Shape<10, 20, 20, 404, 439, 22> S8000;
 
-// the plan's tables (global memory, built by wgr_build_tab): a mel filter as the four constants of its two slopes (weights: tables.hpp
-// build_mel, ShortTermFeatures.py:225-231) and the chroma gather lists, one entry per lane (at most 64 per pitch class: one per
-// semitone the bins reach)
-struct MelAn {
-    double up, dn, lo, hi;          // w(k) = up (f_k - lo) for the first n_rise bins, dn (hi - f_k) for the rest; f_k = k fs / num_fft
-    int k_lo, n_rise, cnt, pad;
-};
+// the plan's tables (global memory, built by wgr_build_tab): the mel lane jobs (ShortTermFeatures.py:236-254; weights: the plan's own
+// table, tables.hpp build_mel) and the chroma gather lists, one entry per lane (at most 64 per pitch class: one per semitone the bins
+// reach)
+constexpr int kMelPerLane = 16;     // bins of a mel lane job, at most
+constexpr int kMaxThreads = 512;
 struct WgrTab {
-    MelAn mel[40];
+    int mel_job[kMaxThreads][4];    // thread t: {first bin, index of its weight, stride = threads of the filter, number of bins}: bins
+                                    // kb + j stride, weights mel_w[eb + j stride], j < n
+    int mel_fil[40][2];             // filter m: {first thread, threads}
     int ch_n[12];
     int ch_src[12][64];
     double ch_w[12][64];
@@ -221,7 +225,8 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
     double *fv = reinterpret_cast<double *>(smem + SH::OFF_FV);
     int *redi = reinterpret_cast<int *>(smem + SH::OFF_REDI);
     unsigned *edge = reinterpret_cast<unsigned *>(smem + SH::OFF_EDGE);
-    MelAn *melan = reinterpret_cast<MelAn *>(smem + SH::OFF_MELA);
+    int2 *melfil = reinterpret_cast<int2 *>(smem + SH::OFF_MELA);
+    double *part = reinterpret_cast<double *>(smem + SH::OFF_PART);
     double *dct = reinterpret_cast<double *>(smem + SH::OFF_DCT);
     double2 *ws = reinterpret_cast<double2 *>(smem + SH::OFF_WS) + 3 * 64 * (threadIdx.x >> 6);
     // the previous frame's magnitudes of this thread's bins wait in global memory (L2), two blocks per workgroup used alternately: held in
@@ -236,14 +241,13 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
     const double invNf = 1.0 / (double)NF;
     const Tabs tb = tabs_global(P);
     const double f0 = P.fs / (2.0 * (double)NF);
-    const double dfm = P.fs / (double)NF;                // the mel bank's bin axis: k fs / num_fft (:216, num_fft = W / 2)
     // ---- tables, once per workgroup: the mel constants to LDS, the wave's two chroma classes (w, w + NW) to registers
     int ch_s0 = 0, ch_s1 = 0;
     double ch_w0 = 0.0, ch_w1 = 0.0;
+    int mj_kb = 0, mj_eb = 0, mj_st = 1, mj_n = 0;      // the thread's mel lane job
     if (MODE == 0) {
-        const int *src = reinterpret_cast<const int *>(tab->mel);
-        int *dst = reinterpret_cast<int *>(melan);
-        for (int i = tid; i < 40 * 12; i += SH::NT) dst[i] = src[i];
+        if (tid < 40) melfil[tid] = make_int2(tab->mel_fil[tid][0], tab->mel_fil[tid][1]);
+        mj_kb = tab->mel_job[tid][0]; mj_eb = tab->mel_job[tid][1]; mj_st = tab->mel_job[tid][2]; mj_n = tab->mel_job[tid][3];
         for (int i = tid; i < 13 * 40; i += SH::NT) dct[i] = tb.dct[(i / 40) * tb.dct_stride + i % 40];
     }
     if (MODE != 1) {
@@ -415,33 +419,26 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
             }
             PAA_TICK(11)
             // the previous frame's magnitudes (requested now, used by the flux below), this frame's for the next one
-            double2 pm[NJR];
+            // (every thread, every frame, no condition: loads or stores inside a branch make the compiler's vmcnt accounting wait for
+            // the younger ones too.  Threads without bins move zeros; the first frame of a run reads whatever the blocks hold -- its flux
+            // is not used: it is the clip's first frame, :624-625.)
             if (MODE == 0) {
-                const double2 *sp = scr + ((t & 1) ? 0 : SH::SCR) + jf;
-                double2 *sn = scr + ((t & 1) ? SH::SCR : 0) + jf;
-                if (!halo && t > t_first && a1) {          // (threads without bins hold zeros, as in mg)
+                double2 *sn = scr + ((t & 1) ? SH::SCR : 0) + tq;
 #pragma unroll
-                    for (int jj = 0; jj < NJR; ++jj) pm[jj] = sp[J1 * jj];
-                } else {
-#pragma unroll
-                    for (int jj = 0; jj < NJR; ++jj) pm[jj] = make_double2(0.0, 0.0);
-                }
-                if (a1 && t + 1 < t_end) {
-#pragma unroll
-                    for (int jj = 0; jj < NJR; ++jj) sn[J1 * jj] = make_double2(mg[2 * jj], mg[2 * jj + 1]);
-                }
+                for (int jj = 0; jj < NJR; ++jj) sn[SH::NT * jj] = make_double2(mg[2 * jj], mg[2 * jj + 1]);
             }
             // ---------------- the next frame's samples: one load per 128-byte line brings them to the L2 / L1 while the features are formed
             // (holding them in registers across the feature stage made the compiler spill them -- one exposed HBM latency per register)
             // (the loaded bytes are only "used" at the end of the iteration: nothing waits for them before)
             int touch = 0;
-            if (t + 1 < t_end) {
-                const char *xn = reinterpret_cast<const char *>(xc + (long long)(t + 1) * P.S);
+            {
+                // (the run's last frame touches its own samples again: no branch around the loads)
+                const char *xn = reinterpret_cast<const char *>(xc + (long long)(t + 1 < t_end ? t + 1 : t) * P.S);
                 constexpr int kLines = W * (int)sizeof(T) / 128, kPer = (kLines + SH::NT - 1) / SH::NT;
 #pragma unroll
                 for (int u = 0; u < kPer; ++u) {
                     const int o = (tq + u * SH::NT) * 128;
-                    if (o < W * (int)sizeof(T)) touch |= *reinterpret_cast<const char *>(xn + o);
+                    touch |= *reinterpret_cast<const char *>(xn + (o < W * (int)sizeof(T) ? o : 0));
                 }
             }
             PAA_TICK(5)
@@ -486,6 +483,18 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
                     mags[((jj == 0) && first0) ? N / 2 : N - k] = mg[2 * jj + 1];
                 }
             }
+            // the weights of the thread's mel bins (frame-invariant, but sixteen doubles held across the passes would be spilled: the index
+            // is opaque, the loads are issued here and land under the barrier and the scan)
+            double mw[kMelPerLane];
+            int mkb = mj_kb, mst = mj_st, mn = mj_n;
+            asm volatile("" : "+v"(mkb), "+v"(mst), "+v"(mn));
+            if (MODE == 0) {
+                int eb = mj_eb;
+                asm volatile("" : "+v"(eb));
+                const double *wp_ = P.mel_w + eb;
+#pragma unroll
+                for (int j = 0; j < kMelPerLane; ++j) mw[j] = wp_[(j < mn ? j : 0) * mst];
+            }
             __syncthreads();
             double sX = 0.0, sIX = 0.0, mx = 0.0;
 #pragma unroll
@@ -511,34 +520,19 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
             }
             const double incl = wscan_incl(cs);
             if (lane == 63) slot[wave] = incl;
-            int wo = wave;                                 // (opaque: the records of the wave's filters are fetched per frame, not kept in
-            asm volatile("" : "+s"(wo));                   // -- spilled -- registers across the frame loop)
             if (MODE == 0) {
-                // ---------------- MFCC filter sums (:236-254): wave w owns the filters w, w + NW, ..., all 64 lanes on a filter's bins, the
-                // filters of a wave walked together (kernels_wg.hpp)
-                constexpr int NFW = SH::NFW;
-                static_assert(NFW <= 6, "three pairs of filter sums per wave");
-                double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                // ---------------- MFCC filter sums (:236-254), first half: the thread's lane job -- bins kb + j stride of ONE filter
+                double a = 0.0;
 #pragma unroll
-                for (int j = 0; j < NFW; ++j) {
-                    const int m = wo + NW * j;
-                    if (m < 40) {
-                        const MelAn f = melan[m];
-                        double a = 0.0;
-                        for (int i = lane; i < f.cnt; i += 64) {
-                            const bool rise = i < f.n_rise;
-                            const double fk = (double)(f.k_lo + i) * dfm;
-                            const double wgt = (rise ? f.up : -f.dn) * (fk - (rise ? f.lo : f.hi));
-                            a = fma(mags[f.k_lo + i], wgt, a);
-                        }
-                        acc[j] = a;
-                    }
-                }
-                double2 pr[3] = {make_double2(acc[0], acc[1]), make_double2(acc[2], acc[3]), make_double2(acc[4], acc[5])};
-                const double2 sm = pair_sums<3>(pr, ws, lane);
-                // row i of the wave holds the sums of its filters 2 i and 2 i + 1: lanes 16 i and 16 i + 1 take one logarithm each
-                const int jm = 2 * (lane >> 4) + (lane & 1), mm = wo + NW * jm;
-                if ((lane & 15) < 2 && lane < 48 && jm < NFW && mm < 40) msp[mm] = fast_log10(((lane & 1) ? sm.y : sm.x) + kEps);
+                for (int j = 0; j < kMelPerLane; ++j) a = fma(mags[mkb + (j < mn ? j : 0) * mst], (j < mn) ? mw[j] : 0.0, a);
+                part[tid] = a;
+            }
+            // the previous frame's magnitudes of the thread's bins: requested now (the mel weights' registers are free), used by the flux
+            double2 pm[NJR];
+            if (MODE == 0) {
+                const double2 *sp = scr + ((t & 1) ? 0 : SH::SCR) + tq;
+#pragma unroll
+                for (int jj = 0; jj < NJR; ++jj) pm[jj] = sp[SH::NT * jj];
             }
             PAA_TICK(7)
             __syncthreads();
@@ -558,6 +552,17 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
                 __syncthreads();          // the row has been read: the next frame may write the buffer
                 asm volatile("" ::"v"(touch));
                 continue;
+            }
+            // ---------------- MFCC filter sums, second half: wave w adds the partial sums of the filters w, w + NW, ..: eight lanes per filter
+            {
+                const int jf_ = lane >> 3, i8 = lane & 7, m = wave + NW * jf_;
+                const int2 fl = melfil[m < 40 ? m : 39];
+                double a = 0.0;
+                for (int c = i8; c < fl.y; c += 8) a += part[fl.x + c];
+                a += dpp_mov<PAA_DPP_X1>(a);
+                a += dpp_mov<PAA_DPP_X2>(a);
+                a += dpp_mov<PAA_DPP_HM>(a);
+                if (i8 == 0 && m < 40 && jf_ < SH::NFW) msp[m] = fast_log10(a + kEps);
             }
             // the running energy at the ten block boundaries (spectral entropy, :85-107)
             if (a1 && (tid % SH::CB) == 0) bnd[tid / SH::CB] = run_e;
@@ -684,25 +689,35 @@ inline int wgr_shape_id(int window) {
     return 0;
 }
 inline const char *wgr_shape_name(int id) { return id == 1 ? "20x20x20" : "10x20x20"; }
+inline int wgr_threads(int id) { return id == 1 ? S16000::NT : S8000::NT; }
 
-// The plan's tables.  Mel: the constants build_mel (tables.hpp) forms its weights from, per filter -- the kernel evaluates
-// up (k fs / num_fft - lo) / dn (hi - k fs / num_fft) itself (the product k (fs / num_fft) instead of the reference's (k / num_fft) fs: one
-// rounding apart).  Chroma: the gather list of every pitch class padded to 64 entries of weight 0.  false: a pitch class with more than
-// 64 entries (cannot happen: one entry per semitone the bins reach) -- the caller keeps kernels_wg.hpp for the window.
-inline bool wgr_build_tab(double fs, int nfft, const MelTable *mel, const ChromaTable *chroma, WgrTab &t) {
+// The plan's tables.  Mel lane jobs: filter m gets nl[m] = ceil(cnt[m] / L) consecutive threads, L the smallest bin count per thread
+// (at most kMelPerLane) with which the filters' threads fit the workgroup; thread i of the filter takes its bins i, i + nl, i + 2 nl, ...
+// (neighbouring threads read neighbouring bins and weights).  Chroma: the gather list of every pitch class padded to 64 entries of
+// weight 0.  false: the filters need more threads than the workgroup has even at sixteen bins per thread (a window of more than
+// two seconds' worth of mel bins), or a pitch class has more than 64 entries (cannot happen: one entry per semitone the bins reach) -- the
+// caller keeps kernels_wg.hpp for the window.
+inline bool wgr_build_tab(int nt, const MelTable *mel, const ChromaTable *chroma, WgrTab &t) {
     memset(&t, 0, sizeof(t));
+    for (int i = 0; i < kMaxThreads; ++i) t.mel_job[i][2] = 1;
     if (mel) {
-        double edges[kNumMel + 2];
-        mel_edges(edges);
+        int L = 0;
+        for (int l = 1; l <= kMelPerLane && !L; ++l) {
+            long need = 0;
+            for (int m = 0; m < kNumMel; ++m) need += (mel->cnt[m] + l - 1) / l;
+            if (need <= nt) L = l;
+        }
+        if (!L || nt > kMaxThreads) return false;
+        int th = 0;
         for (int m = 0; m < kNumMel; ++m) {
-            const double lo = edges[m], mid = edges[m + 1], hi = edges[m + 2];
-            const double peak = 2.0 / (hi - lo);
-            const long k_lo = (long)std::floor(lo * nfft / fs) + 1, k_mid = (long)std::floor(mid * nfft / fs) + 1;
-            MelAn &f = t.mel[m];
-            f.up = peak / (mid - lo); f.dn = peak / (hi - mid); f.lo = lo; f.hi = hi;
-            f.k_lo = mel->lo[m]; f.cnt = mel->cnt[m];
-            f.n_rise = (int)std::min<long>(std::max<long>(k_mid - k_lo, 0), f.cnt);
-            if ((long)f.k_lo != k_lo && f.cnt > 0) return false;
+            const int cnt = mel->cnt[m], nl = (cnt + L - 1) / L;
+            t.mel_fil[m][0] = th; t.mel_fil[m][1] = nl;
+            for (int i = 0; i < nl; ++i, ++th) {
+                t.mel_job[th][0] = mel->lo[m] + i;
+                t.mel_job[th][1] = mel->off[m] + i;
+                t.mel_job[th][2] = nl;
+                t.mel_job[th][3] = (cnt - i + nl - 1) / nl;
+            }
         }
     }
     if (chroma) {

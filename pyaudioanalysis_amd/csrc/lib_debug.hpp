@@ -162,23 +162,18 @@ extern "C" int paa_debug_mix_plan(int window, int32_t *radices, int32_t *fft_len
     return L.n_pass;
 }
 // host tables of the fused three-pass kernel (kernels_wgr.hpp), no device needed.  Returns the shape id of the window (0: not its
-// window; -1: a table it cannot hold).  mel6[40][6]: up, dn, lo, hi, k_lo, n_rise per filter (cnt and k_lo equal build_mel's);
-// ch_n[12], ch_src[12][64], ch_w[12][64].  runs: wgr_build_runs for `frames` (per-clip frame counts) on num_cu workgroups ->
-// (clip, t0, cnt) triples into runs3 (capacity in triples); *n_runs = their number.
-extern "C" int paa_debug_wgr_tables(double fs, int window, double *mel6, int32_t *ch_n, int32_t *ch_src, double *ch_w) {
+// window; -1: a table it cannot hold -- the plan then keeps kernels_wg.hpp).  mel_job[512][4]: per thread {first bin, index of its
+// weight in the mel table, stride, bins}; mel_fil[40][2]: per filter {first thread, threads}; ch_n[12], ch_src[12][64], ch_w[12][64].
+extern "C" int paa_debug_wgr_tables(double fs, int window, int32_t *mel_job, int32_t *mel_fil, int32_t *ch_n, int32_t *ch_src, double *ch_w) {
     const int id = wgr::wgr_shape_id(window);
     if (!id) return 0;
     MelTable mel;
     ChromaTable chroma;
     if (build_mel(fs, window / 2, mel) != PAA_OK || build_chroma(fs, window / 2, chroma) != PAA_OK) return -1;
     std::unique_ptr<wgr::WgrTab> t(new wgr::WgrTab());
-    if (!wgr::wgr_build_tab(fs, window / 2, &mel, &chroma, *t)) return -1;
-    for (int m = 0; m < 40 && mel6; ++m) {
-        const wgr::MelAn &f = t->mel[m];
-        double *o = mel6 + 6 * m;
-        o[0] = f.up; o[1] = f.dn; o[2] = f.lo; o[3] = f.hi; o[4] = (double)f.k_lo; o[5] = (double)f.n_rise;
-        if (f.cnt != mel.cnt[m]) return -1;
-    }
+    if (!wgr::wgr_build_tab(wgr::wgr_threads(id), &mel, &chroma, *t)) return -1;
+    if (mel_job) memcpy(mel_job, t->mel_job, sizeof(t->mel_job));
+    if (mel_fil) memcpy(mel_fil, t->mel_fil, sizeof(t->mel_fil));
     if (ch_n) memcpy(ch_n, t->ch_n, sizeof(t->ch_n));
     if (ch_src) memcpy(ch_src, t->ch_src, sizeof(t->ch_src));
     if (ch_w) memcpy(ch_w, t->ch_w, sizeof(t->ch_w));

@@ -370,7 +370,9 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
     std::unique_ptr<wgr::WgrTab> wgr_tab;
     if (p->big && wgr::wgr_shape_id(window)) {
         wgr_tab.reset(new wgr::WgrTab());
-        if (!wgr::wgr_build_tab(fs, Nf, mode == 0 ? &tab->mel : nullptr, mode != 1 ? &tab->chroma : nullptr, *wgr_tab)) wgr_tab.reset();
+        if (!wgr::wgr_build_tab(wgr::wgr_threads(wgr::wgr_shape_id(window)), mode == 0 ? &tab->mel : nullptr,
+                                mode != 1 ? &tab->chroma : nullptr, *wgr_tab))
+            wgr_tab.reset();          // (a mel bank this kernel's lane jobs cannot hold: kernels_wg.hpp takes the window)
     }
     if (wgr_tab) {
         // the 1 s windows of music_thumbnailing at 16 / 8 kHz: one fused launch, the transform in registers (kernels_wgr.hpp)
