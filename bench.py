@@ -260,7 +260,7 @@ def other_configs(ffi, steps=10):
     run_shape("blu_1103_spectrogram", "w1103_spectrogram", "30 min at 22.05 kHz, 1103 / 441, spectrogram rows")
     run_shape("mix_256", "w256_16kHz", "1 h at 16 kHz, window 256 / step 128")
     # the window of music_thumbnailing (audioSegmentation.py:1137: 1 s / 0.5 s): beyond the LDS envelope, passes through HBM
-    run_shape("big_16000", "w16000_16kHz", "10 min at 16 kHz, 1 s / 0.5 s (16000 / 8000): one workgroup per frame, transform in LDS", launches=20)
+    run_shape("big_16000", "w16000_16kHz", "10 min at 16 kHz, 1 s / 0.5 s (16000 / 8000): fused three-pass kernel, one run of frames per workgroup, transform in registers", launches=20)
     run_shape("big_16000_1h", "w16000_16kHz_1h", "1 h at 16 kHz, 16000 / 8000", launches=10)
     run_shape("big_16000_68", "w16000_16kHz_68rows", "10 min at 16 kHz, 16000 / 8000, 68 rows", launches=20)
     run_shape("big_8000_batch", "w8000_batch", "200 clips x 30 s at 16 kHz, 8000 / 4000, one plan", launches=20)

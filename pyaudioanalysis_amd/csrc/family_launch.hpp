@@ -46,7 +46,7 @@ int blu(const blu::BluLayout &bl, size_t lds, int sample_kind, const PlanDev &P,
 // kernels_wgr.hpp: workgroup-wide three-pass register transform with fused features (16 000- / 8 000-sample windows); `runs`:
 // runs of consecutive frames, one workgroup walks runs b, b + grid, ...
 int wgr(int shape_id, int sample_kind, int mode, const PlanDev &P, const void *d_packed, const ClipDev *clips, const ClipNorm *norms,
-        const Tile *runs, long long n_runs, int num_cu, const wgr::WgrTab *d_tab, void *d_scr, double *d_out, hipStream_t stream);
+        const Tile *runs, long long n_runs, int num_cu, const wgr::WgrTab *d_tab, double *d_out, hipStream_t stream);
 // kernels_generic.hpp: Stockham passes in LDS (what is left)
 int generic(const GenLayout &gl, size_t lds, int sample_kind, const PlanDev &P, const unsigned char *blob,
             const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,

@@ -73,7 +73,6 @@ struct Shape {
     static constexpr int OFF_PART = N * 8;                // double [NT]: the threads' mel partial sums, in the buffer behind the spectrum row
     static constexpr int OFF_WS = OFF_DCT + 13 * 40 * 8;  // double2 [NW][3][64]: the waves' pair-sum scratch (pair_sums)
     static constexpr int LDS_BYTES = OFF_WS + NW * 3 * 64 * 16;
-    static constexpr int SCR = NJR * NT;                  // double2 elements of one previous-spectrum block (two per workgroup)
     static_assert(R1 % 10 == 0, "time-domain entropy blocks: static per register row");
     static_assert(J1 % 10 == 0, "spectral entropy blocks: whole scan chunks");
     static_assert(A1 >= (R2 - 1) * R3 + R3 && B2 >= R3 && A2 >= (R2 - 1) * B2 + R3, "exchange rows");
@@ -210,8 +209,7 @@ __device__ __forceinline__ void group_pass(double2 *v, double2 w, Put put) {
 template <typename SH, typename T, int MODE>
 __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restrict__ sig, const ClipDev *__restrict__ clips,
                                                      const ClipNorm *__restrict__ norms, const Tile *__restrict__ runs, int n_runs,
-                                                     const WgrTab *__restrict__ tab, double2 *__restrict__ scr_all,
-                                                     double *__restrict__ out) {
+                                                     const WgrTab *__restrict__ tab, double *__restrict__ out) {
     constexpr int R1 = SH::R1, R2 = SH::R2, R3 = SH::R3, A1 = SH::A1, A2 = SH::A2, B2 = SH::B2, N = SH::N, NF = SH::NF, W = SH::W;
     constexpr int J1 = SH::J1, J2 = SH::J2, J3 = SH::J3, NW = SH::NW, NJR = SH::NJR, C = SH::C;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -229,9 +227,6 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
     double *part = reinterpret_cast<double *>(smem + SH::OFF_PART);
     double *dct = reinterpret_cast<double *>(smem + SH::OFF_DCT);
     double2 *ws = reinterpret_cast<double2 *>(smem + SH::OFF_WS) + 3 * 64 * (threadIdx.x >> 6);
-    // the previous frame's magnitudes of this thread's bins wait in global memory (L2), two blocks per workgroup used alternately: held in
-    // registers across the passes they were spilled by the compiler -- at a place and time of its choosing
-    double2 *scr = scr_all + (size_t)blockIdx.x * 2 * SH::SCR;
     constexpr bool INT_T = Smp<T>::kInt;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- the thread's jobs (threads past a pass's job count shadow its last job; their stores are masked)
@@ -269,6 +264,9 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
         const long long Tc = c.T;
         const double inv = nm.inv;
         double sXp = 0.0;                                // sum of the previous frame's magnitudes
+        double pm[2 * NJR];                              // ... and the magnitudes themselves (this thread's bins)
+#pragma unroll
+        for (int i = 0; i < 2 * NJR; ++i) pm[i] = 0.0;
         SignRule sr = {0, 0, 0};
         if (INT_T && MODE == 0) sr = sign_rule<T>(nm.mean);
         const int t_first = (MODE == 0 && tl.t0 > 0) ? tl.t0 - 1 : tl.t0, t_end = tl.t0 + tl.cnt;
@@ -418,14 +416,11 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
                 }
             }
             PAA_TICK(11)
-            // the previous frame's magnitudes (requested now, used by the flux below), this frame's for the next one
-            // (every thread, every frame, no condition: loads or stores inside a branch make the compiler's vmcnt accounting wait for
-            // the younger ones too.  Threads without bins move zeros; the first frame of a run reads whatever the blocks hold -- its flux
-            // is not used: it is the clip's first frame, :624-625.)
-            if (MODE == 0) {
-                double2 *sn = scr + ((t & 1) ? SH::SCR : 0) + tq;
+            // (the previous frame's magnitudes stay in registers: twenty doubles.  Through blocks in global memory -- tried: no spills, the
+            // same speed -- every store reached the HBM: 7.5 - 12 x the algorithmic traffic, profiles/r06_wgr_variants.txt.)
+            if (MODE == 0 && halo) {
 #pragma unroll
-                for (int jj = 0; jj < NJR; ++jj) sn[SH::NT * jj] = make_double2(mg[2 * jj], mg[2 * jj + 1]);
+                for (int i = 0; i < 2 * NJR; ++i) pm[i] = mg[i];
             }
             // ---------------- the next frame's samples: one load per 128-byte line brings them to the L2 / L1 while the features are formed
             // (holding them in registers across the feature stage made the compiler spill them -- one exposed HBM latency per register)
@@ -527,13 +522,7 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
                 for (int j = 0; j < kMelPerLane; ++j) a = fma(mags[mkb + (j < mn ? j : 0) * mst], (j < mn) ? mw[j] : 0.0, a);
                 part[tid] = a;
             }
-            // the previous frame's magnitudes of the thread's bins: requested now (the mel weights' registers are free), used by the flux
-            double2 pm[NJR];
-            if (MODE == 0) {
-                const double2 *sp = scr + ((t & 1) ? 0 : SH::SCR) + tq;
-#pragma unroll
-                for (int jj = 0; jj < NJR; ++jj) pm[jj] = sp[SH::NT * jj];
-            }
+
             PAA_TICK(7)
             __syncthreads();
             double run_e = incl - cs, sP = 0.0;
@@ -600,13 +589,15 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
                     const double dl = kl * f0 - cen, dh = kh * f0 - cen;
                     sSp = fma(dl * dl, mg[2 * jj] * r, sSp);
                     sSp = fma(dh * dh, mg[2 * jj + 1] * r, sSp);
-                    const double fl = mg[2 * jj] * rX - pm[jj].x * rXp, fh = mg[2 * jj + 1] * rX - pm[jj].y * rXp;
+                    const double fl = mg[2 * jj] * rX - pm[2 * jj] * rXp, fh = mg[2 * jj + 1] * rX - pm[2 * jj + 1] * rXp;
                     sFl = fma(fl, fl, sFl);
                     sFl = fma(fh, fh, sFl);
                 }
                 double2 pr[1] = {make_double2(sSp, sFl)};
                 const double2 st = pair_sums<1>(pr, ws, lane);
                 if (lane == 0) { red2[2 * wave] = st.x; red2[2 * wave + 1] = st.y; }
+#pragma unroll
+                for (int i = 0; i < 2 * NJR; ++i) pm[i] = mg[i];
             }
             // ---------------- chroma (:277-321): the pitch classes w and w + NW of a wave, one gather entry per lane (registers)
             {
@@ -731,12 +722,6 @@ inline bool wgr_build_tab(int nt, const MelTable *mel, const ChromaTable *chroma
     return true;
 }
 
-// bytes of the previous-spectrum blocks of a launch on num_cu workgroups (feature plans)
-inline size_t wgr_scratch_bytes(int shape_id, int num_cu) {
-    const size_t per = (shape_id == 1) ? (size_t)S16000::SCR : (size_t)S8000::SCR;
-    return (size_t)num_cu * 2 * per * 16;
-}
-
 // Runs of consecutive frames, about one per CU (a run that starts inside a clip costs a halo transform in feature plans): every clip
 // is cut into ceil(T / L) runs of nearly equal length, L = the per-CU share of all frames
 inline void wgr_build_runs(const std::vector<ClipDev> &clips, int num_cu, std::vector<Tile> &runs) {
@@ -759,7 +744,7 @@ inline void wgr_build_runs(const std::vector<ClipDev> &clips, int num_cu, std::v
 
 template <typename SH, typename T, int MODE>
 inline int wgr_launch_one(const PlanDev &P, const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const Tile *runs,
-                          long long n_runs, int num_cu, const WgrTab *d_tab, void *d_scr, double *d_out, hipStream_t stream) {
+                          long long n_runs, int num_cu, const WgrTab *d_tab, double *d_out, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&wgr_kernel<SH, T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -768,7 +753,7 @@ inline int wgr_launch_one(const PlanDev &P, const void *d_packed, const ClipDev 
     }
     const unsigned grid = (unsigned)std::min<long long>(n_runs, num_cu);
     hipLaunchKernelGGL((wgr_kernel<SH, T, MODE>), dim3(grid), dim3(SH::NT), (size_t)SH::LDS_BYTES, stream, P, (const T *)d_packed, clips,
-                       norms, runs, (int)n_runs, d_tab, (double2 *)d_scr, d_out);
+                       norms, runs, (int)n_runs, d_tab, d_out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -654,17 +654,10 @@ static int run_wg(paa_plan *p, const void *d_packed, double *d_out) {
 static int run_wgr(paa_plan *p, const void *d_packed, double *d_out) {
     const PlanDev &P = p->P;
     if (!p->wgr_runs.empty()) {
-        // feature plans: two blocks per workgroup for the previous frame's magnitudes (they never leave the L2)
-        const size_t need = (P.mode == 0) ? wgr::wgr_scratch_bytes(p->wgr, g_num_cu) : 0;
-        if (need > p->big_bytes) {
-            if (p->d_big) { HIP_TRY(hipStreamSynchronize(cs())); (void)hipFree(p->d_big); p->d_big = nullptr; p->big_bytes = 0; }
-            HIP_TRY(hipMalloc(&p->d_big, need));
-            p->big_bytes = need;
-        }
         ProfScope prof_scope;
         { const int rc_p = prof_scope.begin(); if (rc_p) return rc_p; }
         if (launch::wgr(p->wgr, p->sample_kind, P.mode, P, d_packed, p->d_clips, p->d_norms, p->d_wgr_runs, (long long)p->wgr_runs.size(),
-                        g_num_cu, p->d_wgr_tab, p->d_big, d_out, cs()))
+                        g_num_cu, p->d_wgr_tab, d_out, cs()))
             return fail(PAA_ERR_HIP, "launch of %s failed: %s", p->kernel_name.c_str(), hipGetErrorString(hipGetLastError()));
     }
     if (P.mode == 0 && P.deltas) {

@@ -107,3 +107,61 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def inplace_search(R1, R2, R3):
+    """IN-PLACE layout (one (A, B) for all three exchanges: element (d0, d1, d2) at d0 A + d1 B + d2; pass 2 and pass 3 write where
+    they read, so no barrier separates their reads from their writes): scores of E1 writes (writer j = n1 R3 + n2), pass-2 reads = writes
+    (T -> (k0, n2)), pass-3 reads = writes (U -> (k0, k1)), partner reads of the recombination (U reads bin N - k), and the natural-order
+    8-byte stores of the magnitudes by U."""
+    N = R1 * R2 * R3
+    out = []
+    for B in (R3, R3 + 1):
+        for A in range((R2 - 1) * B + R3, (R2 - 1) * B + R3 + 26):
+            if R1 * A > 8600:
+                continue
+            for o2 in ("k0n2", "n2k0"):
+                for o3 in ("k0k1", "k1k0"):
+                    def e1w(j, q):
+                        n1, n2 = divmod(j, R3)
+                        return q * A + n1 * B + n2
+
+                    def p2(T, r):
+                        k0, n2 = divmod(T, R3) if o2 == "k0n2" else divmod(T, R1)[::-1]
+                        return k0 * A + r * B + n2
+
+                    def dig3(U):
+                        return divmod(U, R2) if o3 == "k0k1" else divmod(U, R1)[::-1]
+
+                    def p3(U, r):
+                        k0, k1 = dig3(U)
+                        return k0 * A + k1 * B + r
+
+                    def partner(U, r):
+                        k0, k1 = dig3(U)
+                        k = (N - (k0 + R1 * k1 + R1 * R2 * r)) % N
+                        return (k % R1) * A + ((k // R1) % R2) * B + k // (R1 * R2)
+
+                    w1, _ = score(R2 * R3, e1w, R1, WG, 8)
+                    r2, i2 = score(R1 * R3, p2, R2, RG, 16)
+                    w2, _ = score(R1 * R3, p2, R2, WG, 8)
+                    r3, i3 = score(R1 * R2, p3, R3, RG, 16)
+                    w3, _ = score(R1 * R2, p3, R3, WG, 8)
+                    rp, ip = score(R1 * R2, partner, R3, RG, 16)
+                    # natural-order magnitude stores (8 bytes: 4 groups of 16 contiguous lanes, bank = (a / 4) mod 32: 16-byte column pairs)
+                    G64 = [list(range(16 * i, 16 * i + 16)) for i in range(4)]
+
+                    def mag(U, r):
+                        k0, k1 = dig3(U)
+                        return k0 + R1 * k1 + R1 * R2 * r
+                    wm, im = score(R1 * R2, mag, R3, G64, 16)
+                    out.append((r2 + r3 + rp, w1 + w2 + w3, wm, A, B, o2, o3, (r2, i2), (r3, i3), (rp, ip), (w1, w2, w3), (wm, im)))
+    out.sort()
+    print("in-place layouts (reads pass 2 + pass 3 + partner | b128 writes | magnitude stores):")
+    for o in out[:12]:
+        print("  reads %d writes %d mags %d  A=%d B=%d pass-2 %s pass-3 %s  reads/ideal %s %s %s  writes %s  mags %s  size %d" % (
+            o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9], o[10], o[11], R1 * o[3]))
+
+
+if __name__ == "__main__" and len(sys.argv) >= 5 and sys.argv[4] == "inplace":
+    inplace_search(*(int(a) for a in sys.argv[1:4]))

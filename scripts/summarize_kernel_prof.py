@@ -27,6 +27,8 @@ def main(prof_dir, out_path):
     if line["case"] == "mid_stats":
         like = "%mid_stats_kernel%"
     second = None
+    if "_wgr_" in stem:                           # the fused three-pass kernel of the 1 s windows: one launch (+ the delta rows)
+        like = "%wgr_kernel%"
     if "wg_lds_fft" in stem:                      # two kernels per step: the spectra of all frames, then their features
         like, second = "%wg_spectrum_kernel%", "%wg_feat_kernel%"
     if "wg_split_fft" in stem:                    # split transforms: sub-transform tasks, then the features (+ a small time-domain kernel)

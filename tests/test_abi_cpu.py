@@ -941,3 +941,82 @@ def test_bluestein_kernel_takes_the_lengths_with_large_prime_factors():
         assert plan(w) > 0 and info[0] == lg, (w, info[0])          # (0x100: the packed form halves the convolution)
     for w in (800, 1024, 2400, 2205, 1323, 4800, 34, 126, 5462 + 1, 9001):      # smooth / too few bins / too long
         assert plan(w) == 0, w
+
+
+@pytest.mark.parametrize("fs,window", [(16000, 16000), (16000, 8000), (8000, 8000), (44100, 16000), (22050, 16000), (48000, 8000)])
+def test_fused_big_window_tables(fs, window):
+    """Host tables of the fused three-pass kernel of the 1 s windows (csrc/kernels_wgr.hpp), restated from the library's own mel bank:
+    the mel LANE JOBS deal every (filter, bin) of the reference's bank (ShortTermFeatures.py:191-233) to exactly one thread, at most
+    sixteen bins of ONE filter per thread, the threads of a filter consecutive and its bins round-robin among them; the chroma gather
+    lists (:277-321) are the oracle's, one entry per lane, padded with weight 0."""
+    lib = _ffi.lib()
+    nfft = window // 2
+    job = np.zeros((512, 4), dtype=np.int32)
+    fil = np.zeros((40, 2), dtype=np.int32)
+    ch_n = np.zeros(12, dtype=np.int32)
+    ch_src = np.zeros((12, 64), dtype=np.int32)
+    ch_w = np.zeros((12, 64))
+    i32 = lambda a: a.ctypes.data_as(_ffi.c_i32p)          # noqa: E731
+    sid = lib.paa_debug_wgr_tables(float(fs), window, i32(job), i32(fil), i32(ch_n), i32(ch_src), _ffi.as_f64p(ch_w))
+    assert sid == (1 if window == 16000 else 2)
+    dense = np.zeros((40, nfft))
+    _ffi.check(lib.paa_debug_mel_bank(float(fs), nfft, _ffi.as_f64p(dense)))
+    # the flat weight table: filter after filter, the bins of its support
+    lo = [int(np.flatnonzero(dense[m])[0]) for m in range(40)]
+    cnt = [int(np.flatnonzero(dense[m])[-1]) - lo[m] + 1 for m in range(40)]
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    seen = np.zeros(int(off[-1]), dtype=np.int32)
+    threads = 448
+    per_lane = 0
+    for m in range(40):
+        first, nl = fil[m]
+        assert nl >= 1 and (m == 0 and first == 0 or first == fil[m - 1][0] + fil[m - 1][1])
+        for i in range(nl):
+            kb, eb, st, n = job[first + i]
+            assert st == nl and 1 <= n <= 16 and kb == lo[m] + i and eb == off[m] + i
+            idx = eb + st * np.arange(n)
+            assert idx[-1] < off[m + 1] and idx[-1] + st >= off[m + 1]          # ... and no bin of the filter is left over
+            seen[idx] += 1
+            per_lane = max(per_lane, n)
+    assert fil[39][0] + fil[39][1] <= threads and np.all(seen == 1)
+    assert np.all(job[fil[39][0] + fil[39][1]:threads, 3] == 0)                   # threads without a job
+    # sixteen bins per thread at most, and no more than the smallest count that lets the filters' threads fit the workgroup
+    assert per_lane == min(L for L in range(1, 17) if sum(-(-c // L) for c in cnt) <= threads)
+    o_src, o_w, o_cls, _ = O.chroma_gather(fs, nfft)
+    for c in range(12):
+        sel = np.flatnonzero(np.asarray(o_cls) == c)
+        assert ch_n[c] == len(sel) <= 64
+        assert np.array_equal(ch_src[c, :len(sel)], np.asarray(o_src)[sel]) and np.array_equal(ch_w[c, :len(sel)], np.asarray(o_w)[sel])
+        assert np.all(ch_w[c, len(sel):] == 0.0) and np.all(ch_src[c, len(sel):] == 0)
+
+
+def test_fused_big_window_kernel_declines_what_it_cannot_hold():
+    """A window of the fused kernel at a sampling rate whose mel bank needs more than sixteen bins per thread (16 000 samples at 8 kHz:
+    two seconds) is declined (-1: the plan keeps the in-place LDS transform of csrc/kernels_wg.hpp); other windows are not its business."""
+    lib = _ffi.lib()
+    assert lib.paa_debug_wgr_tables(8000.0, 16000, None, None, None, None, None) == -1
+    assert lib.paa_debug_wgr_tables(16000.0, 12000, None, None, None, None, None) == 0
+    assert lib.paa_debug_wgr_tables(16000.0, 16000, None, None, None, None, None) == 1
+
+
+@pytest.mark.parametrize("frames", [[1199], [7199], [23] * 7, [1, 2, 3, 500, 4, 1], [119] * 200, [3]])
+def test_fused_big_window_runs(frames):
+    """Runs of consecutive frames of the fused kernel (one workgroup per CU walks runs b, b + grid, ...): every frame of every clip
+    exactly once, in order, no run longer than the per-CU share of all frames, the runs of a clip within one frame of each other."""
+    lib = _ffi.lib()
+    f = np.asarray(frames, dtype=np.int64)
+    n = ctypes.c_int64(0)
+    _ffi.check(lib.paa_debug_wgr_runs(f.ctypes.data_as(_ffi.c_i64p), len(f), 256, None, 0, ctypes.byref(n)))
+    runs = np.zeros((n.value, 3), dtype=np.int32)
+    _ffi.check(lib.paa_debug_wgr_runs(f.ctypes.data_as(_ffi.c_i64p), len(f), 256, runs.ctypes.data_as(_ffi.c_i32p), n.value, ctypes.byref(n)))
+    share = max(1, -(-int(f.sum()) // 256))
+    pos = {}
+    for clip, t0, cnt in runs:
+        assert cnt >= 1 and t0 == pos.get(clip, 0) and cnt <= share
+        pos[clip] = t0 + cnt
+    assert [pos.get(c, 0) for c in range(len(f))] == list(f)
+    for c in range(len(f)):
+        lens = runs[runs[:, 0] == c, 2]
+        assert lens.max() - lens.min() <= 1
+    if len(f) == 1 and f[0] >= 256:
+        assert len(runs) == -(-int(f[0]) // share) <= 256

@@ -398,6 +398,8 @@ def test_big_window_kernel_choice(gpu_lib):
     assert name(16000, 8000, 4000, mode=1) == "spectrogram_wgr_10x20x20"
     assert name(16000, 8000, 4000, mode=2) == "chromagram_wgr_10x20x20"
     assert name(16000, 12000, 4000, mode=1) == "spectrogram_wg_lds_fft"    # 6000 points: the in-place LDS transform of round 5
+    assert name(8000, 16000, 8000) == "st_wg_lds_fft"                  # 2 s windows at 8 kHz: more mel bins than the fused kernel's lane jobs hold
+    assert name(8000, 8000, 4000) == "st_wgr_10x20x20"                 # 1 s at 8 kHz
     assert name(16000, 9009, 4500) == "st_wg_lds_fft"                  # odd: 9009 = 7 x 9 x 11 x 13 real points, 144 KB of LDS
     assert name(44100, 44100, 22050) == "st_wg_split_fft"              # 22 050 complex points = 353 KB: 6 sub-transforms of 3675
     assert name(48000, 48000, 24000, mode=1) == "spectrogram_wg_split_fft"     # 24 000 points: 6 x 4000
@@ -430,6 +432,54 @@ def test_workgroup_lds_kernel_full_matrix(gpu_lib, kind, fs, window, step, secon
     assert_parity(got, ref, "%s %d/%d@%d" % (kind, window, step, fs), sig=(mono, fs, window, step))
     if deltas:
         assert np.array_equal(got[34:, 1:], got[:34, 1:] - got[:34, :-1]) and np.all(got[34:, 0] == 0.0)
+
+
+@pytest.mark.parametrize("kind,fs,window,step,seconds,mode", [
+    ("i16", 16000, 16000, 8000, 610.0, 0),       # ten minutes: 1 219 frames = 256 runs of 4 / 5 frames, a halo transform in front of 255 of them
+    ("f64", 16000, 16000, 16000, 40.0, 0),       # 1 s / 1 s (no overlap), float64 samples
+    ("stereo", 44100, 16000, 5000, 30.0, 0),     # the window at another rate: other mel lane jobs (6 bins per thread), stereo samples
+    ("stereo", 16000, 16000, 8000, 30.0, 1),     # spectrogram rows straight from the registers
+    ("f64", 16000, 16000, 4000, 20.0, 2),        # chromagram rows
+    ("i16", 8000, 8000, 2000, 300.0, 0),         # 10 x 20 x 20 on a five-minute clip
+])
+def test_fused_three_pass_kernel(gpu_lib, kind, fs, window, step, seconds, mode, capsys):
+    """kernels_wgr.hpp against the NumPy oracle on clips long enough for every workgroup to own a run that starts inside the clip (the
+    flux of a run's first frame comes from a halo transform), every sample type and mode."""
+    from test_ct_kernels_gpu import make_signal
+    sig, mono = make_signal(kind, 9100 + window + mode, seconds, fs)
+    if mode == 0:
+        ref, _ = O.feature_extraction(mono, fs, window, step, True)
+        got, _ = ShortTermFeatures.feature_extraction(sig, fs, window, step, True)
+        assert_parity(got, ref, "%s %d/%d@%d" % (kind, window, step, fs), sig=(mono, fs, window, step))
+        assert np.array_equal(got[34:, 1:], got[:34, 1:] - got[:34, :-1]) and np.all(got[34:, 0] == 0.0)
+    elif mode == 1:
+        got, _, _ = ShortTermFeatures.spectrogram(sig, fs, window, step)
+        capsys.readouterr()
+        ref, _, _ = O.spectrogram(mono, fs, window, step)
+        assert_parity(np.ascontiguousarray(got.T), np.ascontiguousarray(ref.T), "fused spectrogram")
+    else:
+        got, _, _ = ShortTermFeatures.chromagram(sig, fs, window, step)
+        ref, _, _ = O.chromagram(mono, fs, window, step)
+        assert_parity(np.ascontiguousarray(got.T), np.ascontiguousarray(ref.T), "fused chromagram")
+
+
+def test_fused_three_pass_kernel_many_clips(gpu_lib):
+    """More runs than workgroups (600 short clips: a workgroup walks runs b, b + grid, ...) and silent clips among them: bit-identical
+    to the single-clip calls, silent frames at the analytic values."""
+    fs, W, S = 16000, 16000, 8000
+    rng = np.random.default_rng(77)
+    clips = []
+    for i in range(600):
+        n = int(rng.integers(W, 4 * W))
+        clips.append(np.full(n, 1234, dtype=np.int16) if i % 97 == 5 else synth_clip(8800 + (i % 13), n, fs))
+    res, _ = ShortTermFeatures.feature_extraction_batch(clips, fs, W, S, deltas=False)
+    for i in (0, 5, 17, 102, 255, 256, 257, 511, 599):
+        single, _ = ShortTermFeatures.feature_extraction(clips[i], fs, W, S, deltas=False)
+        assert np.array_equal(single, res[i]), i
+    ref, _ = O.feature_extraction(clips[5], fs, W, S, False)
+    assert_parity(res[5], ref, "silent clip in a batch", sig=(clips[5], fs, W, S))
+    ref, _ = O.feature_extraction(clips[300], fs, W, S, False)
+    assert_parity(res[300], ref, "clip 300 of a batch", sig=(clips[300], fs, W, S))
 
 
 def test_workgroup_lds_kernel_batches_and_rows(gpu_lib, capsys):
