@@ -226,29 +226,20 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
     int2 *melfil = reinterpret_cast<int2 *>(smem + SH::OFF_MELA);
     double *part = reinterpret_cast<double *>(smem + SH::OFF_PART);
     double *dct = reinterpret_cast<double *>(smem + SH::OFF_DCT);
-    double2 *ws = reinterpret_cast<double2 *>(smem + SH::OFF_WS) + 3 * 64 * (threadIdx.x >> 6);
+    double2 *ws_all = reinterpret_cast<double2 *>(smem + SH::OFF_WS);
     constexpr bool INT_T = Smp<T>::kInt;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- the thread's jobs (threads past a pass's job count shadow its last job; their stores are masked)
-    const double2 w1 = P.tw[tid < J1 ? tid : J1 - 1];                        // W_N^j
-    const double2 w2 = P.tw[R1 * ((tid < J2 ? tid : J2 - 1) % R3)];          // W_(R2 R3)^n2
     const double sc = sample_scale<T>();
     const double invNf = 1.0 / (double)NF;
     const Tabs tb = tabs_global(P);
     const double f0 = P.fs / (2.0 * (double)NF);
     // ---- tables, once per workgroup: the mel constants to LDS, the wave's two chroma classes (w, w + NW) to registers
-    int ch_s0 = 0, ch_s1 = 0;
-    double ch_w0 = 0.0, ch_w1 = 0.0;
     int mj_kb = 0, mj_eb = 0, mj_st = 1, mj_n = 0;      // the thread's mel lane job
     if (MODE == 0) {
         if (tid < 40) melfil[tid] = make_int2(tab->mel_fil[tid][0], tab->mel_fil[tid][1]);
         mj_kb = tab->mel_job[tid][0]; mj_eb = tab->mel_job[tid][1]; mj_st = tab->mel_job[tid][2]; mj_n = tab->mel_job[tid][3];
         for (int i = tid; i < 13 * 40; i += SH::NT) dct[i] = tb.dct[(i / 40) * tb.dct_stride + i % 40];
-    }
-    if (MODE != 1) {
-        const int c1 = wave + NW;
-        ch_s0 = tab->ch_src[wave][lane]; ch_w0 = tab->ch_w[wave][lane];
-        if (c1 < 12) { ch_s1 = tab->ch_src[c1][lane]; ch_w1 = tab->ch_w[c1][lane]; }
     }
     __syncthreads();
 
@@ -276,6 +267,8 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
             // the addresses, conversions and masks derived from them -- filled a hundred registers that were then spilled)
             int tq = tid;
             asm volatile("" : "+v"(tq));
+            const int wv = tq >> 6, ln = tq & 63;              // (for LDS addresses: the scalar `wave` / `lane` forms were hoisted and spilled)
+            double2 *ws = ws_all + 3 * 64 * wv;
             const bool a1 = tq < J1, a2 = tq < J2, a3 = tq < J3;
             const int j1 = a1 ? tq : J1 - 1;
             const int t2 = a2 ? tq : J2 - 1, k0_2 = t2 / R3, n2_2 = t2 - k0_2 * R3;
@@ -284,6 +277,9 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
             // inactive pass-1 threads re-read the last job's samples with scale and mean 0: exact zeros, no energy
             const double scl = a1 ? sc : 0.0, meanl = a1 ? nm.mean : 0.0;
             const double mscale = a1 ? 0.5 * invNf : 0.0;
+            // the two twiddle bases of the thread, fetched with the samples (L2) instead of living in eight registers across the frame
+            const double2 w1 = P.tw[j1];                         // W_N^j
+            const double2 w2 = P.tw[R1 * n2_2];                  // W_(R2 R3)^n2
             // ---------------- load + normalise (:567-570)
             Smp<T> smp[R1];
             {
@@ -326,16 +322,16 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
                     if (n0 < 16) { pc0a |= f0 << (2 * n0); pc1a |= f1 << (2 * n0); }
                     else { pc0b |= f0 << (2 * (n0 - 16)); pc1b |= f1 << (2 * (n0 - 16)); }
                 }
-                if (lane == 0) { edge[2 * wave] = pc1a; edge[2 * wave + 1] = pc1b; }
+                if (lane == 0) { edge[2 * wv] = pc1a; edge[2 * wv + 1] = pc1b; }
                 zc_w = wsum_i(a1 ? zc : 0);
                 // the ten block energies: pairs (E0, E1) .. (E4, E5), then (E6, E7), (E8, E9)
                 {
                     double2 pr[3] = {make_double2(eb[0], eb[1]), make_double2(eb[2], eb[3]), make_double2(eb[4], eb[5])};
                     const double2 s1 = pair_sums<3>(pr, ws, lane);
-                    if ((lane & 15) == 0 && lane < 48) *reinterpret_cast<double2 *>(red + 16 * wave + 4 + 2 * (lane >> 4)) = s1;
+                    if ((lane & 15) == 0 && lane < 48) *reinterpret_cast<double2 *>(red + 16 * wv + 4 + 2 * (ln >> 4)) = s1;
                     double2 pq[2] = {make_double2(eb[6], eb[7]), make_double2(eb[8], eb[9])};
                     const double2 s2 = pair_sums<2>(pq, ws, lane);
-                    if ((lane & 15) == 0 && lane < 32) *reinterpret_cast<double2 *>(red + 16 * wave + 10 + 2 * (lane >> 4)) = s2;
+                    if ((lane & 15) == 0 && lane < 32) *reinterpret_cast<double2 *>(red + 16 * wv + 10 + 2 * (ln >> 4)) = s2;
                 }
             }
             PAA_TICK(1)
@@ -357,7 +353,7 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
                 const int n0 = lane < R1 ? lane : 0, sh = 2 * (n0 & 15);
                 const unsigned mine = ((n0 < 16 ? pc0a : pc0b) >> sh) & 3u, left = ((n0 < 16 ? la : lb) >> sh) & 3u;
                 const int zb = wsum_i(lane < R1 ? abs((int)mine - (int)left) : 0);
-                if (lane == 0) red[16 * wave + 14] = (double)((zc_w + zb) << (INT_T ? sr.sh : 0));
+                if (lane == 0) red[16 * wv + 14] = (double)((zc_w + zb) << (INT_T ? sr.sh : 0));
             }
             // ---------------- pass 2: radix R2 over n1 for (k0, n2), outputs times W_(R2 R3)^(n2 k1)
             double2 v2[R2];
@@ -391,17 +387,21 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
             PAA_TICK(10)
             // ---------------- real-FFT recombination + |X| / num_fft (:617-621): pairs k = t + J1 jj and N - k (k = 0: bins 0 and N / 2)
             double mg[2 * NJR];
-            {
+            // (two batches of pairs: all twenty elements in flight at once were 80 registers beside w^k, the magnitudes and the previous ones)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                constexpr int HB = (NJR + 1) / 2;
+                const int j0 = h * HB, j1e = (h == 0) ? HB : NJR;
                 double2 zk[NJR], zm[NJR];
 #pragma unroll
-                for (int jj = 0; jj < NJR; ++jj) {
+                for (int jj = j0; jj < j1e; ++jj) {
                     const int k = jf + J1 * jj;
                     const bool k0 = (jj == 0) && first0;
                     zk[jj] = buf[k];
                     zm[jj] = buf[k0 ? N / 2 : N - k];
                 }
 #pragma unroll
-                for (int jj = 0; jj < NJR; ++jj) {
+                for (int jj = j0; jj < j1e; ++jj) {
                     const bool k0 = (jj == 0) && first0;
                     const double2 zh = k0 ? zk[jj] : zm[jj];          // (k = 0 pairs with itself)
                     // (2 E and 2 O: the halves ride in the scale -- exact; threads without bins scale by 0)
@@ -414,6 +414,7 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
                     mg[2 * jj] = mag_sqrt(fma(ar, ar, ai * ai)) * mscale;
                     mg[2 * jj + 1] = mag_sqrt(fma(br, br, bi * bi)) * mscale;
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             PAA_TICK(11)
             // (the previous frame's magnitudes stay in registers: twenty doubles.  Through blocks in global memory -- tried: no spills, the
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
             }
             if (MODE == 0) mxt = wmax_nonneg(mxt);
             __syncthreads();              // every pair has been read: the magnitudes may overwrite the buffer
-            if (lane == 0) { red[16 * wave] = sXt; red[16 * wave + 1] = sIXt; red[16 * wave + 2] = mxt; }
+            if (lane == 0) { red[16 * wv] = sXt; red[16 * wv + 1] = sIXt; red[16 * wv + 2] = mxt; }
             if (!halo && a1) {
 #pragma unroll
                 for (int jj = 0; jj < NJR; ++jj) {
@@ -480,6 +481,14 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
             }
             // the weights of the thread's mel bins (frame-invariant, but sixteen doubles held across the passes would be spilled: the index
             // is opaque, the loads are issued here and land under the barrier and the scan)
+            // ... and the thread's two chroma gather entries (classes w and w + NW of its wave; w + NW >= 12: class w once more, weight unused)
+            int ch_s0, ch_s1;
+            double ch_w0, ch_w1;
+            {
+                const int c1 = (wv + NW < 12) ? wv + NW : wv;
+                ch_s0 = tab->ch_src[wv][ln]; ch_w0 = tab->ch_w[wv][ln];
+                ch_s1 = tab->ch_src[c1][ln]; ch_w1 = (wv + NW < 12) ? tab->ch_w[c1][ln] : 0.0;
+            }
             double mw[kMelPerLane];
             int mkb = mj_kb, mst = mj_st, mn = mj_n;
             asm volatile("" : "+v"(mkb), "+v"(mst), "+v"(mn));
@@ -514,13 +523,13 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
                 cs = a1 ? cs : 0.0;
             }
             const double incl = wscan_incl(cs);
-            if (lane == 63) slot[wave] = incl;
+            if (lane == 63) slot[wv] = incl;
             if (MODE == 0) {
                 // ---------------- MFCC filter sums (:236-254), first half: the thread's lane job -- bins kb + j stride of ONE filter
                 double a = 0.0;
 #pragma unroll
                 for (int j = 0; j < kMelPerLane; ++j) a = fma(mags[mkb + (j < mn ? j : 0) * mst], (j < mn) ? mw[j] : 0.0, a);
-                part[tid] = a;
+                part[tq] = a;
             }
 
             PAA_TICK(7)
@@ -544,7 +553,7 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
             }
             // ---------------- MFCC filter sums, second half: wave w adds the partial sums of the filters w, w + NW, ..: eight lanes per filter
             {
-                const int jf_ = lane >> 3, i8 = lane & 7, m = wave + NW * jf_;
+                const int jf_ = ln >> 3, i8 = ln & 7, m = wv + NW * jf_;
                 const int2 fl = melfil[m < 40 ? m : 39];
                 double a = 0.0;
                 for (int c = i8; c < fl.y; c += 8) a += part[fl.x + c];
@@ -554,7 +563,7 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
                 if (i8 == 0 && m < 40 && jf_ < SH::NFW) msp[m] = fast_log10(a + kEps);
             }
             // the running energy at the ten block boundaries (spectral entropy, :85-107)
-            if (a1 && (tid % SH::CB) == 0) bnd[tid / SH::CB] = run_e;
+            if (a1 && (tq % SH::CB) == 0) bnd[tq / SH::CB] = run_e;
             if (tid == 0) bnd[10] = sP;
             // ---------------- roll-off (:127-140): first k with cumsum(X^2)[k] + eps > 0.9 sum(X^2)
             {
@@ -572,7 +581,7 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
                     first = (a1 && first == 0x7fffffff && rr + kEps > thr) ? jf * C + 2 * i + 1 : first;
                 }
                 first = mix::wmin_nonneg_i(first);
-                if (lane == 0) redi[wave] = first;
+                if (lane == 0) redi[wv] = first;
             }
             // ---------------- spread and flux (:57-82, :110-124) from the registers
             const double r = (mx == 0.0) ? 1.0 / kEps : fast_div(1.0, mx);
@@ -595,7 +604,7 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
                 }
                 double2 pr[1] = {make_double2(sSp, sFl)};
                 const double2 st = pair_sums<1>(pr, ws, lane);
-                if (lane == 0) { red2[2 * wave] = st.x; red2[2 * wave + 1] = st.y; }
+                if (lane == 0) { red2[2 * wv] = st.x; red2[2 * wv + 1] = st.y; }
 #pragma unroll
                 for (int i = 0; i < 2 * NJR; ++i) pm[i] = mg[i];
             }
@@ -605,7 +614,7 @@ __global__ __launch_bounds__(SH::NT) void wgr_kernel(PlanDev P, const T *__restr
                 double2 pr[1] = {make_double2((x0 * x0) * ch_w0, (x1 * x1) * ch_w1)};
                 const double2 ac = pair_sums<1>(pr, ws, lane);
                 const double mineq = (lane == 0) ? ac.x : ac.y;
-                if (lane == 0 || (lane == 1 && wave + NW < 12)) fv[21 + wave + NW * lane] = (sP == 0.0) ? mineq / kEps : fast_div(mineq, sP);
+                if (lane == 0 || (lane == 1 && wave + NW < 12)) fv[21 + wv + NW * ln] = (sP == 0.0) ? mineq / kEps : fast_div(mineq, sP);
             }
             PAA_TICK(8)
             __syncthreads();
