@@ -1305,12 +1305,23 @@ __global__ __launch_bounds__(64 * (MODE == 0 ? SH::NW : SH::NWR), ((MODE == 0 ? 
                 for (int q = 0; q < R2; ++q) pl[q1_2 * PP + q * SH::R3P + b_2] = c2[Cd<R2>::pos(q)].x;
             }
             wsync();
+            // (R3 = 2 / 4 with unpadded groups: a job's R3 plane elements are consecutive and 16-byte aligned -- read as double2: half
+            // the LDS cycles of four-way conflicting 8-byte reads)
+            constexpr bool VEC3 = (R3 == 2 || R3 == 4) && SH::R3P == R3 && PP % 2 == 0 && SH::SLOT % 2 == 0 && SH::WAVE_DOUBLES % 2 == 0;
 #pragma unroll
             for (int u = 0; u < NR3; ++u) {
                 const double *pa = reinterpret_cast<const double *>(plb + (pw32[u][0] & 0xffffu));
                 const double *pb = reinterpret_cast<const double *>(plb + (pw32[u][0] >> 16));
+                if constexpr (VEC3) {
 #pragma unroll
-                for (int b = 0; b < R3; ++b) { dA[u][b].x = pa[b]; dB[u][b].x = pb[b]; }
+                    for (int b = 0; b < R3; b += 2) {
+                        const double2 va = *reinterpret_cast<const double2 *>(pa + b), vb = *reinterpret_cast<const double2 *>(pb + b);
+                        dA[u][b].x = va.x; dA[u][b + 1].x = va.y; dB[u][b].x = vb.x; dB[u][b + 1].x = vb.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int b = 0; b < R3; ++b) { dA[u][b].x = pa[b]; dB[u][b].x = pb[b]; }
+                }
             }
             wsync();
             if (act2) {
@@ -1322,8 +1333,16 @@ __global__ __launch_bounds__(64 * (MODE == 0 ? SH::NW : SH::NWR), ((MODE == 0 ? 
             for (int u = 0; u < NR3; ++u) {
                 const double *pa = reinterpret_cast<const double *>(plb + (pw32[u][0] & 0xffffu));
                 const double *pb = reinterpret_cast<const double *>(plb + (pw32[u][0] >> 16));
+                if constexpr (VEC3) {
 #pragma unroll
-                for (int b = 0; b < R3; ++b) { dA[u][b].y = pa[b]; dB[u][b].y = pb[b]; }
+                    for (int b = 0; b < R3; b += 2) {
+                        const double2 va = *reinterpret_cast<const double2 *>(pa + b), vb = *reinterpret_cast<const double2 *>(pb + b);
+                        dA[u][b].y = va.x; dA[u][b + 1].y = va.y; dB[u][b].y = vb.x; dB[u][b + 1].y = vb.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int b = 0; b < R3; ++b) { dA[u][b].y = pa[b]; dB[u][b].y = pb[b]; }
+                }
             }
             wsync();
             PAA_TICK(5)
