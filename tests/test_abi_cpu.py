@@ -554,7 +554,20 @@ def test_shipped_kernels_hold_their_register_budget():
         assert r["vgpr"] <= (256 if short else 512), r
         assert r["scratch_bytes_per_lane"] <= 2048 if longest else (r["scratch_bytes_per_lane"] == 0 and r["vgpr_spill"] <= 8), r
         assert (r["agpr"] == 0 and r["waves_per_simd_by_registers"] >= 2) if short else r["waves_per_simd_by_registers"] >= 1, r
+    # the fused three-pass kernel of the 1 s windows (round 6, csrc/kernels_wgr.hpp): 448 threads, two waves per SIMD; the feature instance
+    # of 20 x 20 x 20 (80 registers of data per pass + the previous frame's twenty magnitudes) is the one kernel of a caller's shape
+    # that spills: at most 24 registers / 96 bytes (kept in registers the magnitudes cost that; through memory 7 - 12 x the HBM
+    # traffic, profiles/r06_wgr_variants.txt); the 10 x 20 x 20 instances and the spectrogram / chromagram ones do not
+    wgr = by_family["wgr::wgr_kernel"]
+    assert len(wgr) == 18, len(wgr)          # 2 shapes x 3 sample types x 3 modes
+    for r in wgr:
+        big_features = "Shape<20, 20, 20" in r["kernel"] and r["kernel"].endswith(", 0>")
+        assert r["vgpr"] <= 256 and r["agpr"] == 0 and r["waves_per_simd_by_registers"] >= 2, r
+        assert (r["scratch_bytes_per_lane"] <= 96 and r["vgpr_spill"] <= 24) if big_features else \
+               (r["scratch_bytes_per_lane"] == 0 and r["vgpr_spill"] == 0), r
     for r in rows:
+        if r["kernel"].startswith("wgr::wgr_kernel<"):
+            continue
         lean_skewed = r["kernel"].startswith("mix::st_mix_kernel<") and r["kernel"].endswith(", 2>")
         full = r["kernel"].startswith("mix::st_mix_kernel<") and r["kernel"].endswith(", 0>")
         blu_long = r["kernel"].startswith("blu::st_blu_kernel<") and not (", 8, " in r["kernel"] or ", 9, " in r["kernel"])
