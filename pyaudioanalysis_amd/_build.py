@@ -12,7 +12,7 @@ import tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpaa_hip.so")
-SOURCES = ["paa_lib.hip", "family_fast.hip", "family_ct.hip", "family_tri_a.hip", "family_tri_b.hip", "family_tri_c.hip", "family_reg_mix_generic.hip", "family_blu.hip", "family_wgr.hip"]
+SOURCES = ["paa_lib.hip", "family_fast.hip", "family_ct.hip", "family_tri_a.hip", "family_tri_b.hip", "family_tri_c.hip", "family_reg_mix_generic.hip", "family_blu.hip", "family_wgr.hip", "family_wgs.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "paa_hip.h")]
 # -disable-machine-licm: the feature kernels' loop bodies are thousands of instructions long; hoisting every FP64 literal
 # and per-lane LDS address out of them creates >100 loop-invariant registers that then spill (AGPR copies at one wave per

@@ -59,6 +59,15 @@ struct Tile {           // a run of consecutive frames of one clip = one workgro
     int pad;
 };
 
+namespace wg {
+// one frame of a launch of the big-window kernels (kernels_wg.hpp, kernels_wgs.hpp): its clip, its index in the clip, the row of the
+// spectrum scratch it writes, and whether it is only there to provide the previous spectrum of the next one (a chunk that starts
+// inside a clip); task lists of the split transforms keep the sub-transform / task type in bits 8.. of `halo`
+struct FrameRef {
+    int clip, t, row, halo;
+};
+}  // namespace wg
+
 struct StatChunk {      // a span of samples of one clip = one workgroup of clip_stats_kernel
     long long start;    // absolute sample index in the packed buffer
     int len;

@@ -47,6 +47,11 @@ int blu(const blu::BluLayout &bl, size_t lds, int sample_kind, const PlanDev &P,
 // runs of consecutive frames, one workgroup walks runs b, b + grid, ...
 int wgr(int shape_id, int sample_kind, int mode, const PlanDev &P, const void *d_packed, const ClipDev *clips, const ClipNorm *norms,
         const Tile *runs, long long n_runs, int num_cu, const wgr::WgrTab *d_tab, double *d_out, hipStream_t stream);
+// kernels_wgs.hpp: 12 x 3675- / 6 x 3675-sample windows (44 100, 22 050): real-input split, three register passes per sub-transform; `tasks`:
+// (frame, task type) records handed out through `counter` (zero at launch); magnitudes go to the frames' rows of `spec` (spectrogram plans: d_out),
+// the time-domain partials of a frame to `tfeat`
+int wgs(int r0, int sample_kind, const PlanDev &P, const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const wg::FrameRef *tasks,
+        int n_tasks, int *counter, int num_cu, double *spec, double *tfeat, double *d_out, hipStream_t stream);
 // kernels_generic.hpp: Stockham passes in LDS (what is left)
 int generic(const GenLayout &gl, size_t lds, int sample_kind, const PlanDev &P, const unsigned char *blob,
             const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,

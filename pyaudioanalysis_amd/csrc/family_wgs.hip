@@ -1,0 +1,46 @@
+// The real-input split of the 12 x 3675- / 6 x 3675-sample windows on three register passes (kernels_wgs.hpp: 44 100- and 22 050-sample
+// windows) -- own translation unit, see family_launch.hpp.
+#define PAA_NO_HOST_LAUNCHERS
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "family_launch.hpp"
+#include "kernels_wgs.hpp"
+
+namespace paa {
+namespace launch {
+
+template <typename T, int R0>
+static int wgs_one(const PlanDev &P, const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const wg::FrameRef *tasks, int n_tasks,
+                   int *counter, int num_cu, double *spec, double *tfeat, double *d_out, hipStream_t stream) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&wgs::wgs_kernel<T, R0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                wgs::LDS_BYTES) != hipSuccess)
+            return -1;
+        attr = true;
+    }
+    const unsigned grid = (unsigned)std::min(n_tasks, num_cu);
+    if (grid == 0) return 0;
+    hipLaunchKernelGGL((wgs::wgs_kernel<T, R0>), dim3(grid), dim3(wgs::NT), (size_t)wgs::LDS_BYTES, stream, P, (const T *)d_packed, clips, norms,
+                       tasks, n_tasks, counter, spec, tfeat, d_out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+template <int R0>
+static int wgs_kinds(int sample_kind, const PlanDev &P, const void *d_packed, const ClipDev *clips, const ClipNorm *norms,
+                     const wg::FrameRef *tasks, int n_tasks, int *counter, int num_cu, double *spec, double *tfeat, double *d_out,
+                     hipStream_t stream) {
+    if (sample_kind == 0) return wgs_one<int16_t, R0>(P, d_packed, clips, norms, tasks, n_tasks, counter, num_cu, spec, tfeat, d_out, stream);
+    if (sample_kind == 2) return wgs_one<stereo16, R0>(P, d_packed, clips, norms, tasks, n_tasks, counter, num_cu, spec, tfeat, d_out, stream);
+    return wgs_one<double, R0>(P, d_packed, clips, norms, tasks, n_tasks, counter, num_cu, spec, tfeat, d_out, stream);
+}
+int wgs(int r0, int sample_kind, const PlanDev &P, const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const wg::FrameRef *tasks,
+        int n_tasks, int *counter, int num_cu, double *spec, double *tfeat, double *d_out, hipStream_t stream) {
+    if (r0 == 12) return wgs_kinds<12>(sample_kind, P, d_packed, clips, norms, tasks, n_tasks, counter, num_cu, spec, tfeat, d_out, stream);
+    if (r0 == 6) return wgs_kinds<6>(sample_kind, P, d_packed, clips, norms, tasks, n_tasks, counter, num_cu, spec, tfeat, d_out, stream);
+    return -1;
+}
+
+}  // namespace launch
+}  // namespace paa

@@ -58,11 +58,7 @@ struct WgLayout {
     int r0, sub;
     int off_cv;                     // [8] complex: W_r0^(r q) of the task
 };
-// one frame of the launch: its clip, its index in the clip, the row of the spectrum scratch it writes, and whether it is only
-// there to provide the previous spectrum of the next one (a chunk that starts inside a clip)
-struct FrameRef {
-    int clip, t, row, halo;
-};
+// (FrameRef -- one frame of the launch -- lives in device_common.hpp: kernels_wgs.hpp uses it too)
 
 struct Tw2 {
     const double2 *lo, *hi;

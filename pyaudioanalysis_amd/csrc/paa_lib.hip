@@ -27,6 +27,7 @@
 #include "kernels_big.hpp"
 #include "kernels_wg.hpp"
 #include "kernels_wgr.hpp"
+#include "kernels_wgs.hpp"
 #include "kernels_sim.hpp"
 #include "kernels_svm.hpp"
 #include "tables.hpp"

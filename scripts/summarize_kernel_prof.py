@@ -33,6 +33,8 @@ def main(prof_dir, out_path):
         like, second = "%wg_spectrum_kernel%", "%wg_feat_kernel%"
     if "wg_split_fft" in stem:                    # split transforms: sub-transform tasks, then the features (+ a small time-domain kernel)
         like, second = "%wg_split_kernel%", "%wg_feat_kernel%"
+    if "_wgs_" in stem:                           # real-input split on register passes (44 100 / 22 050 samples), then the features
+        like, second = "%wgs_kernel%", "%wg_feat_kernel%"
     if stem == "big_window_hbm_passes":
         like = "%big_pass_kernel%"
     out["kernel_like"] = like

@@ -401,7 +401,10 @@ def test_big_window_kernel_choice(gpu_lib):
     assert name(8000, 16000, 8000) == "st_wg_lds_fft"                  # 2 s windows at 8 kHz: more mel bins than the fused kernel's lane jobs hold
     assert name(8000, 8000, 4000) == "st_wgr_10x20x20"                 # 1 s at 8 kHz
     assert name(16000, 9009, 4500) == "st_wg_lds_fft"                  # odd: 9009 = 7 x 9 x 11 x 13 real points, 144 KB of LDS
-    assert name(44100, 44100, 22050) == "st_wg_split_fft"              # 22 050 complex points = 353 KB: 6 sub-transforms of 3675
+    assert name(44100, 44100, 22050) == "st_wgs_12x3675"               # 1 s at 44.1 kHz: real-input split, 6 independent transforms of 3675 points on register passes (kernels_wgs.hpp)
+    assert name(22050, 22050, 11025, mode=1) == "spectrogram_wgs_6x3675"   # 1 s at 22.05 kHz: 3 of them
+    assert name(44100, 22050, 11025, mode=2) == "chromagram_wgs_6x3675"
+    assert name(32000, 32000, 16000) == "st_wg_split_fft"              # 16 000 complex points: the packed split of round 5 (4 x 4000)
     assert name(48000, 48000, 24000, mode=1) == "spectrogram_wg_split_fft"     # 24 000 points: 6 x 4000
     assert name(44100, 11025, 5000, mode=2) == "chromagram_wg_split_fft"       # odd: 11 025 real points, 3 x 3675
     assert name(16000, 65536, 32768) == "st_wg_split_fft"              # the largest table: 32 768 points = 8 x 4096
@@ -416,9 +419,10 @@ def test_big_window_kernel_choice(gpu_lib):
     ("f64", 8000, 8000, 8000, 9.0, False),       # 1 s at 8 kHz, float64 samples
     ("i16", 16000, 9009, 3000, 4.0, True),       # odd window: real points, radices 13 11 7 3 3
     ("i16", 16000, 20000, 10000, 6.0, False),    # the edge of the LDS: 10 000 complex points = 160 000 bytes
-    ("i16", 44100, 44100, 22050, 6.0, True),     # split transform: 22 050 points = 6 x 3675 (tasks {0} {1,5} {2,4} {3}), row not staged
+    ("i16", 44100, 44100, 22050, 6.0, True),     # kernels_wgs.hpp: 12 x 3675 samples (tasks {1,2} {3,4} {5,packed}), row not staged
+    ("stereo", 44100, 44100, 44100, 5.0, False), # ... interleaved stereo, no overlap
     ("stereo", 48000, 48000, 24000, 4.0, False), # 24 000 = 6 x 4000 (radices 8 4 5 5 5), interleaved stereo
-    ("f64", 22050, 22050, 7000, 3.0, True),      # 11 025 points = 3 x 3675 (tasks {0} {1,2}), float64 samples
+    ("f64", 22050, 22050, 7000, 3.0, True),      # kernels_wgs.hpp: 6 x 3675 samples (tasks {1,2} {packed}), float64 samples
     ("i16", 44100, 11025, 5000, 2.0, False),     # odd window of 11 025 REAL points through the split transform
     ("i16", 16000, 32000, 16000, 9.0, False),    # 16 000 points = 4 x 4000 (tasks {0} {1,3} {2})
     ("f64", 16000, 65536, 30000, 14.0, False),   # 32 768 points = 8 x 4096: radix-16 passes (512-thread instance)
