@@ -13,7 +13,7 @@ namespace launch {
 
 template <typename T, int R0>
 static int wgs_one(const PlanDev &P, const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const wg::FrameRef *tasks, int n_tasks,
-                   int *counter, int num_cu, double *spec, double *tfeat, double *d_out, hipStream_t stream) {
+                   int *counter, int num_cu, double *spec, double *tfeat, double *psum, double *d_out, hipStream_t stream) {
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&wgs::wgs_kernel<T, R0>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -21,26 +21,51 @@ static int wgs_one(const PlanDev &P, const void *d_packed, const ClipDev *clips,
             return -1;
         attr = true;
     }
-    const unsigned grid = (unsigned)std::min(n_tasks, num_cu);
+    // one workgroup per CU; a multiple of eight (one segment of the task list per XCD) whenever every workgroup of such a grid has a task
+    unsigned grid = (unsigned)std::min(n_tasks, num_cu);
+    if (grid >= 64) grid &= ~7u;
     if (grid == 0) return 0;
     hipLaunchKernelGGL((wgs::wgs_kernel<T, R0>), dim3(grid), dim3(wgs::NT), (size_t)wgs::LDS_BYTES, stream, P, (const T *)d_packed, clips, norms,
-                       tasks, n_tasks, counter, spec, tfeat, d_out);
+                       tasks, n_tasks, counter, spec, tfeat, psum, d_out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 template <int R0>
 static int wgs_kinds(int sample_kind, const PlanDev &P, const void *d_packed, const ClipDev *clips, const ClipNorm *norms,
-                     const wg::FrameRef *tasks, int n_tasks, int *counter, int num_cu, double *spec, double *tfeat, double *d_out,
-                     hipStream_t stream) {
-    if (sample_kind == 0) return wgs_one<int16_t, R0>(P, d_packed, clips, norms, tasks, n_tasks, counter, num_cu, spec, tfeat, d_out, stream);
-    if (sample_kind == 2) return wgs_one<stereo16, R0>(P, d_packed, clips, norms, tasks, n_tasks, counter, num_cu, spec, tfeat, d_out, stream);
-    return wgs_one<double, R0>(P, d_packed, clips, norms, tasks, n_tasks, counter, num_cu, spec, tfeat, d_out, stream);
+                     const wg::FrameRef *tasks, int n_tasks, int *counter, int num_cu, double *spec, double *tfeat, double *psum,
+                     double *d_out, hipStream_t stream) {
+    if (sample_kind == 0) return wgs_one<int16_t, R0>(P, d_packed, clips, norms, tasks, n_tasks, counter, num_cu, spec, tfeat, psum, d_out, stream);
+    if (sample_kind == 2) return wgs_one<stereo16, R0>(P, d_packed, clips, norms, tasks, n_tasks, counter, num_cu, spec, tfeat, psum, d_out, stream);
+    return wgs_one<double, R0>(P, d_packed, clips, norms, tasks, n_tasks, counter, num_cu, spec, tfeat, psum, d_out, stream);
 }
 int wgs(int r0, int sample_kind, const PlanDev &P, const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const wg::FrameRef *tasks,
-        int n_tasks, int *counter, int num_cu, double *spec, double *tfeat, double *d_out, hipStream_t stream) {
-    if (r0 == 12) return wgs_kinds<12>(sample_kind, P, d_packed, clips, norms, tasks, n_tasks, counter, num_cu, spec, tfeat, d_out, stream);
-    if (r0 == 6) return wgs_kinds<6>(sample_kind, P, d_packed, clips, norms, tasks, n_tasks, counter, num_cu, spec, tfeat, d_out, stream);
+        int n_tasks, int *counter, int num_cu, double *spec, double *tfeat, double *psum, double *d_out, hipStream_t stream) {
+    if (r0 == 12) return wgs_kinds<12>(sample_kind, P, d_packed, clips, norms, tasks, n_tasks, counter, num_cu, spec, tfeat, psum, d_out, stream);
+    if (r0 == 6) return wgs_kinds<6>(sample_kind, P, d_packed, clips, norms, tasks, n_tasks, counter, num_cu, spec, tfeat, psum, d_out, stream);
     return -1;
 }
+
+template <int R0>
+static int wgs_feat_one(const PlanDev &P, const wg::FrameRef *frames, int n_frames, const ClipDev *clips, const double *spec, double *side,
+                        const double *tfeat, const double *psum, double *d_out, hipStream_t stream) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&wgs::wgs_feat_kernel<R0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                wgs::feat_lds<R0>()) != hipSuccess)
+            return -1;
+        attr = true;
+    }
+    if (n_frames <= 0) return 0;
+    hipLaunchKernelGGL((wgs::wgs_feat_kernel<R0>), dim3((unsigned)n_frames), dim3(wgs::kFeatT), (size_t)wgs::feat_lds<R0>(), stream, P, frames, clips, spec,
+                       side, tfeat, psum, d_out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int wgs_feat(int r0, const PlanDev &P, const wg::FrameRef *frames, int n_frames, const ClipDev *clips, const double *spec, double *side,
+             const double *tfeat, const double *psum, double *d_out, hipStream_t stream) {
+    if (r0 == 12) return wgs_feat_one<12>(P, frames, n_frames, clips, spec, side, tfeat, psum, d_out, stream);
+    if (r0 == 6) return wgs_feat_one<6>(P, frames, n_frames, clips, spec, side, tfeat, psum, d_out, stream);
+    return -1;
+}
+int wgs_side_doubles(int r0) { return r0 == 12 ? wgs::side_doubles<12>() : wgs::side_doubles<6>(); }
 
 }  // namespace launch
 }  // namespace paa

@@ -26,11 +26,16 @@
 // Features: kernels_wg.hpp's wg_feat_kernel on the rows, as before.
 // Replaces ShortTermFeatures.py:608-682 (transform part), spectrogram (:415-422), chromagram (:349-359) for these windows.
 #pragma once
-#include "kernels_tri.hpp"          // tri::Cd<21>
+#include "kernels_tri.hpp"          // tri::Cd<21>; kernels_generic.hpp: Tabs
 
 namespace paa {
 namespace wgs {
 
+#ifndef PAA_WGS_ABLATE
+#define PAA_WGS_ABLATE 0           // timing builds only (scripts/rounds/r06/gpu_r06y.sh): bit mask of phases that are skipped -- 1 stage 0, 2 pass 1,
+                                   // 4 pass 2, 8 pass 3 + magnitudes, 16 the next task's touch; feature kernel: 32 sweep A, 64 sweep B, 128 roll-off, 256 mel, 512 chroma
+#endif
+constexpr int kAblate = PAA_WGS_ABLATE;
 constexpr int R1 = 7, R2 = 21, R3 = 25;
 constexpr int Q = R1 * R2 * R3;                 // 3675 points per unit
 constexpr int J1 = R2 * R3, J2 = R1 * R3, J3 = R1 * R2;      // 525 / 175 / 147 lane jobs
@@ -41,8 +46,11 @@ constexpr int UNIT_ELEMS = R1 * A;              // 3745 double2
 constexpr int TU = 192, NT = 2 * TU;            // threads per unit / workgroup
 constexpr int NWV = NT / 64;                     // six waves
 constexpr int OFF_MISC = 2 * UNIT_ELEMS * 16;   // red [6][12] doubles (time domain: ten block energies, sign changes), next task
-constexpr int LDS_BYTES = OFF_MISC + NWV * 12 * 8 + 16;
+constexpr int OFF_UP = OFF_MISC + NWV * 12 * 8 + 16;          // double [6][4]: the waves' parts of their unit's sum X, sum (k + 1) X, max X
+constexpr int LDS_BYTES = OFF_UP + NWV * 4 * 8;
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup's LDS");
+static_assert(5 + 12 * (J3 - 1 + J3 * (R3 / 2 - 1)) < 6 * Q && 12 * J3 * (R3 / 2 + 1) > 6 * Q && 2 + 6 * (J3 - 1 + J3 * (R3 / 2 - 1)) < 3 * Q &&
+              6 * J3 * (R3 / 2 + 1) > 3 * Q, "pass-3 outputs k2 < 12 are bins below W / 2, k2 > 12 mirrors");
 
 __device__ __forceinline__ int pos_of(int k) { return k + (A - J1) * (int)__umulhi((unsigned)k, 8181136u); }      // k / 525 for k < 2^16 (ceil(2^32 / 525))
 static_assert(((unsigned long long)8181136u * 525ull) >> 32 == 1 && ((unsigned long long)8181136u * 524ull) >> 32 == 0, "magic of 525");
@@ -112,15 +120,14 @@ template <typename T, int R0>
 __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict__ sig, const ClipDev *__restrict__ clips,
                                                  const ClipNorm *__restrict__ norms, const wg::FrameRef *__restrict__ tasks, int n_tasks,
                                                  int *next_task, double *__restrict__ spec, double *__restrict__ tfeat,
-                                                 double *__restrict__ out) {
+                                                 double *__restrict__ psum, double *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double2 *buf_all = reinterpret_cast<double2 *>(smem);
     double *red = reinterpret_cast<double *>(smem + OFF_MISC);          // [6][12]
     int *s_next = reinterpret_cast<int *>(smem + OFF_MISC + NWV * 12 * 8);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int unit = __builtin_amdgcn_readfirstlane(tid >= TU ? 1 : 0);
-    const int tu = tid - unit * TU;
-    double2 *buf = buf_all + unit * UNIT_ELEMS;
+    double *upart = reinterpret_cast<double *>(smem + OFF_UP);
+    const int tid_ = threadIdx.x, lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const int unit = __builtin_amdgcn_readfirstlane(tid_ >= TU ? 1 : 0);
     const int W = P.W, Nf = P.Nf;
     const double sc = sample_scale<T>();
     const double invNf = 1.0 / (double)Nf;
@@ -135,18 +142,47 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
         c.out_off = cd.out_off; c.mean = n_.mean; c.inv = n_.inv; c.t = r.t; c.row = r.row; c.type = r.halo >> 8; c.halo = r.halo & 1;
         return c;
     };
-    if ((int)blockIdx.x >= n_tasks) return;
-    Cur cu = fetch(blockIdx.x);
-    for (int ti = blockIdx.x; ti < n_tasks;) {
+    // XCD-aware hand-out: workgroup b runs on XCD b % 8; the task list -- frame after frame, the tasks of a frame side by side -- is cut into eight
+    // segments of whole frames, workgroups take tasks of THEIR segment only (one counter per segment, zero at launch): the tasks of a frame,
+    // and frames that overlap, read their samples through one L2
+    constexpr int NTY = task_types<R0>();
+    const int nseg = (gridDim.x % 8 == 0) ? 8 : 1, seg = blockIdx.x % nseg, rank = blockIdx.x / nseg, per = gridDim.x / nseg;
+    const int n_fr = n_tasks / NTY;
+    const int seg_lo = (int)((long long)n_fr * seg / nseg) * NTY, seg_hi = (int)((long long)n_fr * (seg + 1) / nseg) * NTY;
+    const bool has_task = seg_lo + rank < seg_hi;
+    // a unit's sum X, sum (k + 1) X and max X -- what the feature kernel needs BEFORE its sweep over the row (centroid, the normalisations of
+    // spread and flux) -- are formed here from the magnitudes as they leave: psum [row][R0 / 2][4].  The waves of a task park their parts in LDS;
+    // the row's entries are written behind the next barrier of the workgroup (the next task's first one, or the one after the loop)
+    int flush_row = -1, flush_ua = -1, flush_ub = -1;
+    auto flush_partials = [&](int rw, int ua, int ub) {
+        if (tid_ < 2) {
+            const int un = tid_ == 0 ? ua : ub;
+            if (un >= 0) {
+                const double *u = upart + 12 * tid_;
+                double *d = psum + ((long long)rw * H0 + un) * 4;
+                d[0] = (u[0] + u[4]) + u[8];
+                d[1] = (u[1] + u[5]) + u[9];
+                d[2] = fmax(fmax(u[2], u[6]), u[10]);
+            }
+        }
+    };
+    Cur cu = fetch(has_task ? seg_lo + rank : 0);
+    for (int ti = has_task ? seg_lo + rank : seg_hi; ti < seg_hi;) {
         const T *x = sig + cu.x_off;
         const double mean = cu.mean, inv = cu.inv;
         const int type = __builtin_amdgcn_readfirstlane(cu.type);
+        // (the job indices are formed again in every task from an opaque copy of the thread index: as loop invariants they -- and the addresses
+        // derived from them -- were hoisted out of the task loop into registers that were then spilled)
+        int tid = tid_; asm volatile("" : "+v"(tid));
+        const int tu = tid - unit * TU;
+        double2 *buf = buf_all + unit * UNIT_ELEMS;
         const bool packed_task = (type == task_types<R0>() - 1);             // unit b is the packed one
         const bool a_on = !(R0 == 6 && packed_task);                          // (R0 = 6: the packed unit is alone in its task)
         const bool time_task = (type == 0) && P.mode == 0 && !cu.halo;
         double *row = (P.mode == 1) ? out + cu.out_off + (long long)cu.t * Nf : spec + (long long)cu.row * Nf;
-        __syncthreads();          // the previous task's reads of the buffers are done
-        if (tid == 64) *s_next = (int)gridDim.x + atomicAdd(next_task, 1);
+        __syncthreads();          // the previous task's reads of the buffers are done (and its waves' partial sums are in LDS)
+        if (tid == 64) *s_next = seg_lo + per + atomicAdd(next_task + seg, 1);
+        if (flush_row >= 0) { flush_partials(flush_row, flush_ua, flush_ub); flush_row = -1; }
         // ---------------- stage 0: a_q[k] of both units from the samples (+ the time-domain features :22-51 in the {1, 2} task)
         {
             constexpr bool INT_T = IntSample<T>::kInt;
@@ -169,26 +205,56 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
                 int zc = 0;
 #pragma unroll
                 for (int b = 0; b < 10; ++b) eb[b] = 0.0;
-#pragma unroll 2
-                for (int i = 0; i < (Q + NT - 1) / NT; ++i) {          // (the same trip count for every thread; the last round's spare threads shadow k = Q - 1)
-                    const int k0 = tid + NT * i;
-                    const bool in = k0 < Q;
-                    const int k = in ? k0 : Q - 1;
-                    N s[R0];
-                    N sl[R0];          // TIME: lane 0's left neighbours x[k - 1 + Q r] (the other lanes take them from the lane below)
-                    if constexpr (QA > 0) {
+                // k = tid + NT i, i < NI (the same trip count for every thread; the last round's spare threads shadow k = Q - 1).  The loads of BI
+                // rounds are requested TOGETHER (one exposed memory latency per batch instead of one per round: 71 of the kernel's 182 us were
+                // this stage with two rounds in flight), then the rounds are worked off in order
+                constexpr int NI = (Q + NT - 1) / NT;
+                constexpr int BI = INT_T ? 5 : ((TIME || QB == 0) ? 2 : 5);
+                static_assert(NI % BI == 0, "whole batches");
+#pragma unroll 1
+                for (int ib = 0; ib < NI; ib += BI) {
+                    N sa[BI][R0];
+                    N sla[BI][R0];          // TIME: lane 0's left neighbours x[k - 1 + Q r] (the other lanes take them from the lane below)
+                    double2 wa[BI];
+                    typename std::conditional<INT_T, ct::PairRaw<T>, double2>::type pra[BI][H0];
 #pragma unroll
-                        for (int r = 0; r < R0; ++r) s[r] = sample(x + k + Q * r);
-                        if constexpr (TIME) {
+                    for (int u = 0; u < BI; ++u) {
+                        const int k = min(tid + NT * (ib + u), Q - 1);
+                        if constexpr (QA > 0) {
 #pragma unroll
-                            for (int r = 0; r < R0; ++r) sl[r] = s[r];
-                            if (lane == 0) {
+                            for (int r = 0; r < R0; ++r) sa[u][r] = sample(x + k + Q * r);
+                        }
+                        if constexpr (QB == 0) {
 #pragma unroll
-                                for (int r = 0; r < R0; ++r) sl[r] = sample(x + max(k - 1 + Q * r, 0));          // (the frame's first sample meets itself)
+                            for (int r = 0; r < H0; ++r) {
+                                if constexpr (INT_T) pra[u][r] = ct::PairRaw<T>::get(x + 2 * k + 2 * Q * r);
+                                else pra[u][r] = ct::PairLoad<T>::get(x + 2 * k + 2 * Q * r);
+                            }
+                        }
+                        wa[u] = P.post[k];
+                    }
+                    if constexpr (TIME) {
+#pragma unroll
+                        for (int u = 0; u < BI; ++u)
+#pragma unroll
+                            for (int r = 0; r < R0; ++r) sla[u][r] = sa[u][r];
+                        if (lane == 0) {
+#pragma unroll
+                            for (int u = 0; u < BI; ++u) {
+                                const int k = min(tid + NT * (ib + u), Q - 1);
+#pragma unroll
+                                for (int r = 0; r < R0; ++r) sla[u][r] = sample(x + max(k - 1 + Q * r, 0));          // (the frame's first sample meets itself)
                             }
                         }
                     }
-                    const double2 w = P.post[k];
+#pragma unroll
+                    for (int u = 0; u < BI; ++u) {
+                    const int k0 = tid + NT * (ib + u);
+                    const bool in = k0 < Q;
+                    const int k = in ? k0 : Q - 1;
+                    const N *s = sa[u];
+                    const N *sl = sla[u];
+                    const double2 w = wa[u];
                     const int pk = pos_of(k);
                     if constexpr (QA > 0) {
                         const double2 d = split_dft<R0, QA, N>(s);
@@ -205,19 +271,15 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
                         if constexpr (INT_T) {
                             int ux = 0, uy = 0;
 #pragma unroll
-                            for (int r = 0; r < H0; ++r) {
-                                const ct::PairRaw<T> xx = ct::PairRaw<T>::get(x + 2 * k + 2 * Q * r);
-                                ux += xx.x0(); uy += xx.x1();
-                            }
+                            for (int r = 0; r < H0; ++r) { ux += pra[u][r].x0(); uy += pra[u][r].x1(); }
                             const double c0 = -(double)H0 * mean * inv;
                             v = make_double2(fma((double)ux, ys, c0), fma((double)uy, ys, c0));
                         } else {
                             v = make_double2(0.0, 0.0);
 #pragma unroll
                             for (int r = 0; r < H0; ++r) {
-                                const double2 xx = ct::PairLoad<T>::get(x + 2 * k + 2 * Q * r);
-                                v.x += fma(xx.x, sc, -mean) * inv;
-                                v.y += fma(xx.y, sc, -mean) * inv;
+                                v.x += fma(pra[u][r].x, sc, -mean) * inv;
+                                v.y += fma(pra[u][r].y, sc, -mean) * inv;
                             }
                         }
                         if (in) buf_all[UNIT_ELEMS + pk] = v;
@@ -256,6 +318,8 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
                             if (in) sad_acc(zc, c, left);
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);          // (one round at a time)
+                    }
                 }
                 if constexpr (TIME) {
 #pragma unroll
@@ -267,7 +331,9 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
             typedef std::integral_constant<int, 0> I0;
             typedef std::integral_constant<int, 1> I1;
             typedef std::integral_constant<int, 2> I2;
-            if (type == 0) {
+            if (kAblate & 1) {
+                for (int k = tid; k < Q; k += NT) buf_all[pos_of(k)] = buf_all[UNIT_ELEMS + pos_of(k)] = make_double2(1e-3 * (double)(k & 7), 1e-3);
+            } else if (type == 0) {
                 if (time_task) stage0(I1(), I2(), std::true_type());
                 else stage0(I1(), I2(), std::false_type());
             } else if constexpr (R0 == 12) {
@@ -293,7 +359,7 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
         }
         const bool u_on = unit == 1 || a_on;
         // ---------------- pass 1: radix 7 over n0 for the jobs j = tu, tu + 175, tu + 350; outputs times W_Q^(j k0); in place
-        if (u_on && tu < J2) {
+        if (u_on && tu < J2 && !(kAblate & 2)) {
             double2 v[3][R1];
             double2 w[3];
 #pragma unroll
@@ -321,7 +387,7 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
         }
         __syncthreads();
         // ---------------- pass 2: thread (n2, k0) = tu: radix 21 over n1, outputs times W_525^(n2 k1) = W_Q^(7 n2 k1); in place
-        if (u_on && tu < J2) {
+        if (u_on && tu < J2 && !(kAblate & 4)) {
             const int n2 = tu / R1, k0 = tu - n2 * R1;
             double2 *e = buf + k0 * A + n2;
             const double2 w = P.tw[H0 * R1 * n2];
@@ -329,32 +395,38 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
 #pragma unroll
             for (int n1 = 0; n1 < R2; ++n1) v[n1] = e[n1 * R3];
             tri::Cd<R2>::run(v);
-            // W^k1, k1 = 1 .. 20: squares and products, at most five multiplications deep
-            double2 wq[R2];
-            wq[1] = w;
-#pragma unroll
-            for (int q = 2; q < R2; ++q) wq[q] = (q % 2 == 0) ? csqr(wq[q / 2]) : cmul(wq[q / 2], wq[q - q / 2]);
+            // W^k1, k1 = 1 .. 20, as W^(4 m) W^j: at most seven multiplications deep, five values live (all twenty at once were 80 registers)
+            const double2 w2 = csqr(w), w3 = cmul(w2, w), w4 = csqr(w2);
+            double2 b4 = w4;
             e[0] = v[tri::Cd<R2>::pos(0)];
 #pragma unroll
-            for (int k1 = 1; k1 < R2; ++k1) e[k1 * R3] = cmul(v[tri::Cd<R2>::pos(k1)], wq[k1]);
+            for (int k1 = 1; k1 < R2; ++k1) {
+                const int j = k1 & 3;
+                const double2 wj = (j == 1) ? w : (j == 2) ? w2 : w3;
+                const double2 t = (k1 < 4) ? wj : ((j == 0) ? b4 : cmul(b4, wj));
+                e[k1 * R3] = cmul(v[tri::Cd<R2>::pos(k1)], t);
+                if (j == 3 && k1 > 3) b4 = cmul(b4, w4);
+            }
         }
         __syncthreads();
         // ---------------- the next task of this workgroup: its records now, a touch of its samples
         Cur cu_next = cu;
         const int t_next = *s_next;
-        if (t_next < n_tasks) {
+        if (t_next < seg_hi) {
             cu_next = fetch(t_next);
+            if (!(kAblate & 16)) {
             const char *xn = reinterpret_cast<const char *>(sig + cu_next.x_off);
             const int bytes = W * (int)sizeof(T);
             int touch = 0;
             for (int o = tid * 128; o < bytes; o += NT * 128) touch += *reinterpret_cast<const volatile char *>(xn + o);
             asm volatile("" ::"v"(touch));
+            }
         }
         // ---------------- pass 3: thread (k0, k1) = tu: radix 25 over n2 -> A[k0 + 7 k1 + 147 k2]
-        {
+        if (!(kAblate & 8)) {
             const bool a3 = u_on && tu < J3;
             const int u3 = a3 ? tu : J3 - 1;
-            const int k0 = u3 / R2, k1 = u3 - k0 * R2;
+            const int k1 = u3 / R1, k0 = u3 - k1 * R1;          // (k0 fastest: kappa = u3 + 147 k2, consecutive over the lanes)
             double2 v[R3];
             {
                 const double2 *e = buf + k0 * A + k1 * R3;
@@ -362,30 +434,56 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
                 for (int n2 = 0; n2 < R3; ++n2) v[n2] = e[n2];
             }
             ct::Dft<R3>::template run<1>(v);
-            const int kap0 = k0 + R1 * k1;
             const bool packed_unit = packed_task && unit == 1;
+            double us = 0.0, uw = 0.0, um = 0.0;          // this thread's part of its unit's sum X, sum (k + 1) X, max X
             if (!packed_unit) {
-                // complex unit q: bin q + R0 kappa, or its mirror W - (q + R0 kappa)
                 const int q = (R0 == 12) ? 2 * type + 1 + unit : 1 + unit;
-                if (a3) {
+                if (P.mode == 1) {
+                    // spectrogram rows go straight to the output, natural order: bin q + R0 kappa, or its mirror W - (q + R0 kappa)
+                    if (a3) {
+#pragma unroll
+                        for (int k2 = 0; k2 < R3; ++k2) {
+                            const double2 z = v[ct::Dft<R3>::pos(k2)];
+                            const int m = q + R0 * (u3 + J3 * k2);
+                            row[m < Nf ? m : W - m] = mag_sqrt(fma(z.x, z.x, z.y * z.y)) * invNf;
+                        }
+                    }
+                } else if (a3) {
+                    // scratch rows are UNIT-MAJOR: |A_q[kappa]| at (q - 1) Q + kappa -- 147 consecutive doubles per store instruction (natural
+                    // order: 8-byte stores 96 bytes apart, 44 100 write transactions per task = 106 of the kernel's 182 us)
+                    double *ru = row + (q - 1) * Q + u3;
+                    double sd = 0.0, sm = 0.0;
 #pragma unroll
                     for (int k2 = 0; k2 < R3; ++k2) {
                         const double2 z = v[ct::Dft<R3>::pos(k2)];
-                        const int m = q + R0 * (kap0 + J3 * k2);
-                        row[m < Nf ? m : W - m] = mag_sqrt(fma(z.x, z.x, z.y * z.y)) * invNf;
+                        const double mg = mag_sqrt(fma(z.x, z.x, z.y * z.y)) * invNf;
+                        ru[J3 * k2] = mg;
+                        // bin + 1 = c0 + R0 J3 k2 (direct) or W + 2 - c0 - R0 J3 k2 (mirror), c0 = q + R0 u3 + 1: the k2 part with a constant
+                        // per register, the rest once per thread from the two sums
+                        // (direct for k2 < 12, mirror for k2 > 12 -- R0 J3 k2 against W / 2, any q and u3 --: decided at compile time)
+                        const bool direct = k2 < R3 / 2 || (k2 == R3 / 2 && q + R0 * (u3 + J3 * k2) < Nf);
+                        um = fmax(um, mg);
+                        if (direct) { sd += mg; uw = fma((double)(R0 * J3 * k2), mg, uw); }
+                        else { sm += mg; uw = fma(-(double)(R0 * J3 * k2), mg, uw); }
                     }
+                    const double c0 = (double)(q + R0 * u3 + 1);
+                    us = sd + sm;
+                    uw = fma(c0, sd, fma((double)(W + 2) - c0, sm, uw));
                 }
             }
             if (packed_task) {          // (workgroup-uniform)
                 __syncthreads();          // every thread of the packed unit has read its pass-3 inputs
                 if (packed_unit && a3) {
 #pragma unroll
-                    for (int k2 = 0; k2 < R3; ++k2) buf[kap0 + J3 * k2] = v[ct::Dft<R3>::pos(k2)];
+                    for (int k2 = 0; k2 < R3; ++k2) buf[u3 + J3 * k2] = v[ct::Dft<R3>::pos(k2)];
                 }
                 __syncthreads();
                 if (packed_unit) {
                     // pairs (j, Q - j), j = 1 .. (Q - 1) / 2, and j = 0: X[H0 j] = E + w^j O, X[H0 (Q - j)] = conj(E - w^j O); X[0] = Re V[0] + Im V[0]
                     constexpr int NP = (Q - 1) / 2 + 1;
+                    const bool nat = P.mode == 1;
+                    double *rp = nat ? row : row + (H0 - 1) * Q;          // unit-major: |X[H0 j]| at (H0 - 1) Q + j
+                    const int st = nat ? H0 : 1;
 #pragma unroll 2
                     for (int i = 0; i < (NP + TU - 1) / TU; ++i) {
                         const int j0 = tu + TU * i;
@@ -398,16 +496,297 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
                         const double2 wo = cmul(pw, o);
                         const double ar = e.x + wo.x, ai = e.y + wo.y, br = e.x - wo.x, bi = e.y - wo.y;
                         if (in) {
-                            row[H0 * j] = mag_sqrt(fma(ar, ar, ai * ai)) * invNf;
-                            if (j > 0) row[H0 * (Q - j)] = mag_sqrt(fma(br, br, bi * bi)) * invNf;
+                            const double ma = mag_sqrt(fma(ar, ar, ai * ai)) * invNf;
+                            const double mb = (j > 0) ? mag_sqrt(fma(br, br, bi * bi)) * invNf : 0.0;
+                            rp[st * j] = ma;
+                            if (j > 0) rp[st * (Q - j)] = mb;
+                            us += ma + mb;
+                            uw = fma((double)(H0 * j + 1), ma, uw);
+                            uw = fma((j > 0) ? (double)(H0 * (Q - j) + 1) : 0.0, mb, uw);
+                            um = fmax(um, fmax(ma, mb));
                         }
                     }
                 }
+            }
+            if (P.mode != 1) {
+                us = wsum(us); uw = wsum(uw); um = wmax_nonneg(um);
+                if (lane == 0) { upart[4 * wave] = us; upart[4 * wave + 1] = uw; upart[4 * wave + 2] = um; }
+                flush_row = cu.row;
+                flush_ua = a_on ? ((R0 == 12) ? 2 * type : 0) : -1;          // unit index of q = 2 type + 1 (R0 = 6: q = 1)
+                flush_ub = packed_task ? H0 - 1 : ((R0 == 12) ? 2 * type + 1 : 1);
             }
         }
         cu = cu_next;
         ti = t_next;
     }
+    __syncthreads();
+    if (flush_row >= 0) flush_partials(flush_row, flush_ua, flush_ub);
+    // the last workgroup out clears the counters for the next launch (they are zeroed once, when the scratch is allocated): a memset in front of
+    // every launch was a 5 us fill kernel per counter word
+    if (tid_ == 0) {
+        __threadfence();
+        if (atomicAdd(next_task + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) next_task[i] = 0;
+        }
+    }
+}
+
+// ---- features of one frame from its UNIT-MAJOR row (and the previous frame's) -- kernels_wg.hpp's wg_feat_kernel for the rows above.
+// bin of row element idx: unit u = idx / Q (complex unit q = u + 1 for u < R0/2 - 1: bin q + R0 kappa or its mirror; last unit: bin (R0/2) kappa)
+template <int R0>
+__device__ __forceinline__ int bin_of(int idx) {
+    constexpr int H0 = R0 / 2, W = R0 * Q, NF = W / 2;
+    const int u = (int)__umulhi((unsigned)idx, 1168734u);          // idx / 3675 for idx < 2^16 (ceil(2^32 / 3675) = 1168734)
+    const int kap = idx - u * Q;
+    const int mm = (u + 1) + R0 * kap;
+    return (u == H0 - 1) ? H0 * kap : (mm < NF ? mm : W - mm);
+}
+static_assert(((unsigned long long)1168734u * 3675ull) >> 32 == 1 && ((unsigned long long)1168734u * 3674ull) >> 32 == 0 &&
+              ((unsigned long long)1168734u * 22049ull) >> 32 == 5, "magic of 3675");
+constexpr int kFeatT = 512, kFeatW = kFeatT / 64;
+constexpr int CAP = 20000;                          // bins of the row staged in LDS (natural order); the rest waits in a side row in global memory
+constexpr int FEAT_SMALL = (48 + 40 + kFeatW * 16 + kFeatW) * 8 + kFeatW * 4;
+template <int R0> constexpr int side_doubles() { return R0 * Q / 2 > CAP ? R0 * Q / 2 - CAP : 0; }
+template <int R0> constexpr int feat_lds() { return (R0 * Q / 2 - side_doubles<R0>()) * 8 + ((FEAT_SMALL + 15) / 16) * 16; }
+static_assert(feat_lds<12>() <= 160 * 1024, "feature kernel LDS");
+
+__device__ __forceinline__ double bsum8(double v, double *slot, int lane, int wave) {
+    v = wsum(v);
+    if (lane == 0) slot[wave] = v;
+    __syncthreads();
+    const double r = ((slot[0] + slot[1]) + (slot[2] + slot[3])) + ((slot[4] + slot[5]) + (slot[6] + slot[7]));
+    __syncthreads();
+    return r;
+}
+
+template <int R0>
+__global__ __launch_bounds__(kFeatT) void wgs_feat_kernel(PlanDev P, const wg::FrameRef *__restrict__ frames, const ClipDev *__restrict__ clips,
+                                                          const double *__restrict__ spec, double *__restrict__ side_all,
+                                                          const double *__restrict__ tfeat, const double *__restrict__ psum,
+                                                          double *__restrict__ out) {
+    constexpr int NF = R0 * Q / 2, W = R0 * Q, SIDE = side_doubles<R0>(), NL = NF < CAP ? NF : CAP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const wg::FrameRef fr = frames[blockIdx.x];
+    if (fr.halo) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const ClipDev c = clips[fr.clip];
+    double *cur_l = reinterpret_cast<double *>(smem);
+    double *fv = cur_l + NL;             // [48]
+    double *msp = fv + 48;               // [40]
+    double *red = msp + 40;              // [kFeatW][16]
+    double *slot = red + kFeatW * 16;    // [kFeatW]
+    int *redi = reinterpret_cast<int *>(slot + kFeatW);
+    const double *gc = spec + (long long)fr.row * NF;
+    const double *prv = (fr.t == 0) ? gc : gc - NF;          // frames are laid out in clip order: the previous frame is the previous row
+    double *side = side_all + (long long)fr.row * SIDE;
+    auto X = [&](int k) -> double { return (SIDE == 0 || k < CAP) ? cur_l[k] : side[k - CAP]; };
+    double *oc = out + c.out_off;
+    const long long Tc = c.T;
+    const Tabs tb = tabs_global(P);
+    // ---- the row's sums and maximum, and the previous row's sum, from the transform kernel's per-unit parts (fixed order: every frame gets the
+    // same bits wherever it runs) -- centroid and the normalisations of spread and flux are known BEFORE the sweep
+    constexpr int H0 = R0 / 2;
+    double sX = 0.0, sIXr = 0.0, mx = 0.0, sXpr = 0.0;
+    {
+        const double *pc = psum + (long long)fr.row * H0 * 4, *pp = (fr.t == 0) ? pc : pc - H0 * 4;
+#pragma unroll
+        for (int u = 0; u < H0; ++u) { sX += pc[4 * u]; sIXr += pc[4 * u + 1]; mx = fmax(mx, pc[4 * u + 2]); sXpr += pp[4 * u]; }
+    }
+    const double f0 = P.fs / (2.0 * (double)NF);
+    const double sIX = sIXr * f0;
+    const double sXe = sX + (double)NF * kEps;                // np.sum(X + eps) (:118-119)
+    const double sXp = sXpr + (double)NF * kEps;
+    const double r = (mx == 0.0) ? 1.0 / kEps : fast_div(1.0, mx);
+    const double den = sX * r + kEps;
+    const double cen = fast_div(sIX * r, den);
+    const double rX = fast_div(1.0, sXe), rXp = fast_div(1.0, sXp);
+    // ---- ONE sweep in row order (:57-124), one coalesced read of both rows: the ten block energies (+ tail), spread, flux; every value goes to
+    // its bin's place in LDS (natural order) on the way.  The loads of a batch of UB rounds -- both rows -- are requested before the first value
+    // is used: the rows come from the other CUs' stores, i.e. at HBM latency
+    const int LB = P.blk_f;
+    double part[11];          // 0..9 blocks, 10 tail
+#pragma unroll
+    for (int i = 0; i < 11; ++i) part[i] = 0.0;
+    double sSp = 0.0, sFl = 0.0;
+    constexpr int NI = (NF + kFeatT - 1) / kFeatT, UB = 11, NBATCH = (NI + UB - 1) / UB;
+    {
+        const unsigned mlb = (unsigned)(((1ULL << 32) + (unsigned)LB - 1) / (unsigned)LB);
+#pragma unroll 1
+        for (int bt = 0; bt < ((kAblate & 32) ? 0 : NBATCH); ++bt) {
+            double xv[UB], pv[UB];
+            const int i0 = tid + kFeatT * UB * bt;
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = min(i0 + kFeatT * u, NF - 1);
+                xv[u] = gc[idx];
+                pv[u] = prv[idx];
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = i0 + kFeatT * u;
+                const bool in = idx < NF;
+                const double Xv = in ? xv[u] : 0.0;
+                const int k = bin_of<R0>(in ? idx : NF - 1);
+                if (in) { if (SIDE == 0 || k < CAP) cur_l[k] = Xv; else side[k - CAP] = Xv; }
+                const int j = min((int)__umulhi((unsigned)k, mlb), 10);
+                const double sq = Xv * Xv;
+#pragma unroll
+                for (int i2 = 0; i2 < 11; ++i2) part[i2] += (i2 == j) ? sq : 0.0;
+                const double dv = (double)(k + 1) * f0 - cen;
+                sSp = fma(dv * dv, Xv * r, sSp);
+                const double df = Xv * rX - (in ? pv[u] : 0.0) * rXp;
+                sFl = fma(df, df, sFl);
+            }
+        }
+    }
+    double part2[2] = {sSp, sFl};
+#pragma unroll
+    for (int i = 0; i < 11; ++i) part[i] = wsum(part[i]);
+    part2[0] = wsum(part2[0]); part2[1] = wsum(part2[1]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 11; ++i) red[16 * wave + i] = part[i];
+        red[16 * wave + 11] = part2[0]; red[16 * wave + 12] = part2[1];
+    }
+    __syncthreads();          // (also: the row is in place -- LDS and the side row, written and read by this workgroup only)
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < kFeatW; ++w) a += red[16 * w + i];
+        part[i] = a;
+    }
+    sSp = 0.0; sFl = 0.0;
+#pragma unroll
+    for (int w = 0; w < kFeatW; ++w) { sSp += red[16 * w + 11]; sFl += red[16 * w + 12]; }
+    __syncthreads();
+    double sP = part[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) sP += part[j];
+    if (P.mode == 2) {
+        // ---- chromagram row (:356-359): pitch class by pitch class, one wave per class, all lanes on the class's bins
+        for (int cls = wave; cls < 12; cls += kFeatW) {
+            const int b = tb.ch_start[cls], e = tb.ch_start[cls + 1];
+            double acc = 0.0;
+            for (int i = b + lane; i < e; i += 64) { const double xv = X(tb.ch_src[i]); acc = fma(xv * xv, tb.ch_w[i], acc); }
+            acc = wsum(acc);
+            if (lane == 0) oc[(long long)fr.t * 12 + cls] = (sP == 0.0) ? acc / kEps : fast_div(acc, sP);
+        }
+        return;
+    }
+    double ent_f = 0.0;          // spectral entropy (:85-107)
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        const double sh = fast_div(part[j], sP + kEps);
+        ent_f -= sh * fast_log2(sh + kEps);
+    }
+    const double spread = fast_sqrt(fast_div(sSp, den));
+    // ---- roll-off (:127-140): first k with cumsum(X^2)[k] + eps > 0.9 sum(X^2); contiguous chunks of ODD length, workgroup-wide scan
+    int first = 0x7fffffff;
+    {
+        const double thr = 0.90 * sP;
+        constexpr int cch = ((NF + kFeatT - 1) / kFeatT) | 1;
+        const int kb = min(tid * cch, NF), ke = (kAblate & 128) ? kb : min(NF, kb + cch);
+        double xr[cch];          // the chunk's squares stay in registers for the second walk (each LDS read of it was a dependent trip)
+        double cs = 0.0;
+#pragma unroll
+        for (int i = 0; i < cch; ++i) { const double xv = (kb + i < ke) ? X(kb + i) : 0.0; xr[i] = xv * xv; }
+#pragma unroll
+        for (int i = 0; i < cch; ++i) cs += xr[i];
+        const double incl = wscan_incl(cs);
+        if (lane == 63) slot[wave] = incl;
+        __syncthreads();
+        double run = incl - cs;
+#pragma unroll
+        for (int w = 0; w < kFeatW; ++w) run += (w < wave) ? slot[w] : 0.0;
+#pragma unroll
+        for (int i = 0; i < cch; ++i) {
+            run += xr[i];
+            if (first == 0x7fffffff && kb + i < ke && run + kEps > thr) first = kb + i;
+        }
+        first = wmin_i(first);
+        if (lane == 0) redi[wave] = first;
+        __syncthreads();
+        first = redi[0];
+#pragma unroll
+        for (int w = 1; w < kFeatW; ++w) first = min(first, redi[w]);
+    }
+    // ---- MFCC (:236-254): wave w owns the filters w, w + 8, ..., walked together, all 64 lanes on a filter's bins
+    {
+        constexpr int NFW = 40 / kFeatW;
+        int lo[NFW], cnt[NFW];
+        const double *wv[NFW];
+        double a[NFW];
+        int maxc = 0;
+#pragma unroll
+        for (int j = 0; j < NFW; ++j) {
+            const int m = wave + kFeatW * j;
+            lo[j] = tb.mel_lo[m]; cnt[j] = (kAblate & 256) ? 0 : tb.mel_cnt[m]; wv[j] = tb.mel_w + tb.mel_off[m];
+            a[j] = 0.0;
+            maxc = max(maxc, cnt[j]);
+        }
+        for (int i = lane; i < maxc; i += 64) {
+#pragma unroll
+            for (int j = 0; j < NFW; ++j)
+                if (i < cnt[j]) a[j] = fma(X(lo[j] + i), wv[j][i], a[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NFW; ++j) a[j] = wsum(a[j]);
+        double mine = a[0];
+#pragma unroll
+        for (int j = 1; j < NFW; ++j) mine = (lane == j) ? a[j] : mine;
+        if (lane < NFW) msp[wave + kFeatW * lane] = fast_log10(mine + kEps);
+    }
+    // ---- chroma (:277-321): the pitch classes w and w + 8 of a wave, walked together
+    {
+        const int c0 = wave, c1 = wave + kFeatW;
+        const bool two = c1 < 12;
+        const int b0 = tb.ch_start[c0], e0 = (kAblate & 512) ? b0 : tb.ch_start[c0 + 1];
+        const int b1 = two ? tb.ch_start[c1] : 0, e1 = (two && !(kAblate & 512)) ? tb.ch_start[c1 + 1] : 0;
+        double acc0 = 0.0, acc1 = 0.0;
+        const int n0 = e0 - b0, n1 = e1 - b1, nmax = max(n0, n1);
+#pragma unroll 2
+        for (int i = lane; i < nmax; i += 64) {
+            if (i < n0) { const double xv = X(tb.ch_src[b0 + i]); acc0 = fma(xv * xv, tb.ch_w[b0 + i], acc0); }
+            if (i < n1) { const double xv = X(tb.ch_src[b1 + i]); acc1 = fma(xv * xv, tb.ch_w[b1 + i], acc1); }
+        }
+        acc0 = wsum(acc0); acc1 = wsum(acc1);
+        if (lane == 0) fv[21 + c0] = (sP == 0.0) ? acc0 / kEps : fast_div(acc0, sP);
+        if (lane == 1 && two) fv[21 + c1] = (sP == 0.0) ? acc1 / kEps : fast_div(acc1, sP);
+    }
+    __syncthreads();
+    if (tid < 13) {
+        const double *m = tb.dct + tid * tb.dct_stride;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int n = 0; n < 40; n += 4) {
+            a0 = fma(m[n], msp[n], a0);
+            a1 = fma(m[n + 1], msp[n + 1], a1);
+            a2 = fma(m[n + 2], msp[n + 2], a2);
+            a3 = fma(m[n + 3], msp[n + 3], a3);
+        }
+        fv[8 + tid] = (a0 + a1) + (a2 + a3);
+    }
+    if (tid == 64) {
+        const double *tfp = tfeat + 3 * (long long)fr.row;
+        fv[0] = (tfp[2] / 2.0) / (double)(W - 1);
+        fv[1] = tfp[0] / (double)W;
+        fv[2] = tfp[1];
+        fv[3] = cen / (P.fs / 2.0);
+        fv[4] = spread / (P.fs / 2.0);
+        fv[5] = ent_f;
+        fv[6] = (fr.t == 0) ? 0.0 : sFl;       // first frame: previous spectrum = itself (:624-625)
+        fv[7] = (first == 0x7fffffff) ? 0.0 : (double)first / (double)NF;
+        double mch = 0.0;                      // population std of the 12 chroma values (:667)
+        for (int i = 0; i < 12; ++i) mch += fv[21 + i];
+        mch /= 12.0;
+        double v = 0.0;
+        for (int i = 0; i < 12; ++i) { const double d = fv[21 + i] - mch; v = fma(d, d, v); }
+        fv[33] = fast_sqrt(v / 12.0);
+    }
+    __syncthreads();
+    if (tid < kBase) oc[(long long)tid * Tc + fr.t] = fv[tid];
 }
 
 // ---- host -------------------------------------------------------------------------------------------------------------------------

@@ -579,15 +579,23 @@ struct ProfScope {
 template <typename T>
 static int run_wg(paa_plan *p, const void *d_packed, double *d_out) {
     const PlanDev &P = p->P;
-    const size_t need = (size_t)p->wg_rows * ((size_t)P.Nf * 8 + 24) + 256;       // (+ the task counter of the split transform)
+    const size_t side_row = p->wgs_r0 ? (size_t)launch::wgs_side_doubles(p->wgs_r0) : 0;          // kernels_wgs.hpp: the bins of a row its feature kernel's LDS does not hold
+    const size_t psum_row = p->wgs_r0 ? (size_t)(p->wgs_r0 / 2) * 4 : 0;                                    // ... and its units' partial sums
+    const size_t need = (size_t)p->wg_rows * ((size_t)P.Nf * 8 + 24 + (side_row + psum_row) * 8) + 256;       // (+ the task counter of the split transform)
+    bool fresh = false;
     if (need > p->big_bytes) {
         if (p->d_big) { HIP_TRY(hipStreamSynchronize(cs())); (void)hipFree(p->d_big); p->d_big = nullptr; p->big_bytes = 0; }
         HIP_TRY(hipMalloc(&p->d_big, need));
         p->big_bytes = need;
+        fresh = true;
     }
     double *spec = reinterpret_cast<double *>(p->d_big);
     double *tfeat = spec + (size_t)p->wg_rows * P.Nf;
-    int *task_counter = reinterpret_cast<int *>(tfeat + 3 * (size_t)p->wg_rows);
+    double *side = tfeat + 3 * (size_t)p->wg_rows;
+    double *psum = side + side_row * (size_t)p->wg_rows;
+    int *task_counter = reinterpret_cast<int *>(psum + psum_row * (size_t)p->wg_rows);
+    // (kernels_wgs.hpp: one counter per XCD segment + the workgroups that are done; its last workgroup leaves them at zero)
+    if (fresh && p->wgs_r0) HIP_TRY(hipMemsetAsync(task_counter, 0, 16 * sizeof(int), cs()));
     static LdsAttrCache attr;
     if (!attr.covers((size_t)p->wl.lds_bytes)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wg::wg_spectrum_kernel<T, 512>),
@@ -618,9 +626,9 @@ static int run_wg(paa_plan *p, const void *d_packed, double *d_out) {
             const unsigned nt = (unsigned)(tc.second - tc.first);
             const wg::FrameRef *tk = p->d_wg_tasks + tc.first;
             const unsigned grid = std::min<unsigned>(nt, (unsigned)g_num_cu);
-            HIP_TRY(hipMemsetAsync(task_counter, 0, sizeof(int), cs()));
+            if (!p->wgs_r0) HIP_TRY(hipMemsetAsync(task_counter, 0, sizeof(int), cs()));
             if (p->wgs_r0) {
-                if (launch::wgs(p->wgs_r0, p->sample_kind, P, d_packed, p->d_clips, p->d_norms, tk, (int)nt, task_counter, g_num_cu, spec, tfeat, d_out, cs()))
+                if (launch::wgs(p->wgs_r0, p->sample_kind, P, d_packed, p->d_clips, p->d_norms, tk, (int)nt, task_counter, g_num_cu, spec, tfeat, psum, d_out, cs()))
                     return fail(PAA_ERR_HIP, "launch of %s failed: %s", p->kernel_name.c_str(), hipGetErrorString(hipGetLastError()));
             } else if (p->wl.threads == 768)
                 hipLaunchKernelGGL((wg::wg_split_kernel<T, 768>), dim3(grid), dim3(768), (size_t)p->wl.lds_bytes, cs(), P, p->wl,
@@ -644,7 +652,10 @@ static int run_wg(paa_plan *p, const void *d_packed, double *d_out) {
                                p->d_wg_perm, (const T *)d_packed, p->d_clips, p->d_norms, fr, (int)n, spec, tfeat, d_out);
         if (prof_scope.stop) { (void)hipEventRecord(prof_scope.stop, cs()); prof_scope.stop = nullptr; }
         }
-        if (P.mode != 1) {
+        if (P.mode != 1 && p->wgs_r0) {
+            if (launch::wgs_feat(p->wgs_r0, P, fr, (int)n, p->d_clips, spec, side, tfeat, psum, d_out, cs()))
+                return fail(PAA_ERR_HIP, "launch of the feature kernel of %s failed: %s", p->kernel_name.c_str(), hipGetErrorString(hipGetLastError()));
+        } else if (P.mode != 1) {
             if (p->wl.feat_staged)
                 hipLaunchKernelGGL(wg::wg_feat_kernel<true>, dim3(n), dim3(wg::kFeatThreads), (size_t)p->wl.feat_lds_bytes, cs(), P, fr,
                                    p->d_clips, spec, tfeat, d_out);
