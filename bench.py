@@ -100,7 +100,9 @@ SHAPES = {
     "big_16000_1h": (16000, 16000, 8000, 3600, 1, 0, 0, 0),        # ... on the one-hour clip (7 199 frames: 28 per CU)
     "big_16000_68": (16000, 16000, 8000, 600, 1, 0, 0, 1),         # ... with deltas, as music_thumbnailing calls it
     "big_8000_batch": (16000, 8000, 4000, 30, 200, 0, 0, 0),       # 0.5 s windows, 200 clips x 30 s in one plan
-    "big_44100": (44100, 44100, 22050, 300, 1, 0, 0, 0),           # 1 s at 44.1 kHz: 22 050 complex points do not fit the LDS
+    "big_44100": (44100, 44100, 22050, 300, 1, 0, 0, 0),           # 1 s at 44.1 kHz: 22 050 complex points do not fit the LDS: real-input split, 6 x 3675 points
+    "big_44100_20min": (44100, 44100, 22050, 1200, 1, 0, 0, 0),    # ... a 20-minute recording (2 399 frames: 28 tasks per CU)
+    "big_22050": (22050, 22050, 11025, 1200, 1, 0, 0, 0),          # 1 s at 22.05 kHz: 3 x 3675 points
 }
 SAMPLE_BYTES = {0: 2, 1: 8, 2: 4}
 
@@ -264,7 +266,9 @@ def other_configs(ffi, steps=10):
     run_shape("big_16000_1h", "w16000_16kHz_1h", "1 h at 16 kHz, 16000 / 8000", launches=10)
     run_shape("big_16000_68", "w16000_16kHz_68rows", "10 min at 16 kHz, 16000 / 8000, 68 rows", launches=20)
     run_shape("big_8000_batch", "w8000_batch", "200 clips x 30 s at 16 kHz, 8000 / 4000, one plan", launches=20)
-    run_shape("big_44100", "w44100_44kHz", "5 min at 44.1 kHz, 1 s / 0.5 s (44100 / 22050): split transform, pairs of sub-transforms in LDS", launches=3)
+    run_shape("big_44100", "w44100_44kHz", "5 min at 44.1 kHz, 1 s / 0.5 s (44100 / 22050): real-input split, six transforms of 3675 points on register passes", launches=5)
+    run_shape("big_44100_20min", "w44100_44kHz_20min", "20 min at 44.1 kHz, 44100 / 22050", launches=3)
+    run_shape("big_22050", "w22050_22kHz", "20 min at 22.05 kHz, 1 s / 0.5 s (22050 / 11025): three transforms of 3675 points", launches=5)
     return out
 
 

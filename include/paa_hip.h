@@ -261,6 +261,14 @@ int paa_debug_tri_plan(int window, double fs, int32_t *shape8, int32_t *offsets6
  * slots, threads, LDS bytes, permutation in LDS, feature kernel stages the row, its LDS bytes, then (radix, span, twiddle stride) per
  * pass}; perm[k] = padded LDS position of output k of the (sub-)transform.  Returns 1, 0 when the window goes to another path        */
 int paa_debug_wg_plan(int window, int32_t *info32, uint16_t *perm, int perm_capacity);
+/* Real-input split of the 12 x 3675- / 6 x 3675-sample windows (csrc/kernels_wgs.hpp: 44 100 and 22 050 samples -- the 1 s window
+ * audioSegmentation.py:1134-1138 passes to feature_extraction at 44.1 / 22.05 kHz), host only: info16 = {r0, points per sub-transform Q,
+ * R1, R2, R3 (three register passes), row pitch of the exchange buffer, threads per workgroup, LDS bytes, task types per frame, bins
+ * of a spectrum row the feature kernel holds in LDS, its LDS bytes, side-row doubles, threads of the feature kernel}; bin_of[W / 2] (may
+ * be null) = the bin that element idx of a UNIT-MAJOR spectrum row holds (the transform kernel stores |X| unit after unit: sub-transform
+ * q = 1 .. r0/2 - 1 delivers the bins q + r0 kappa and their mirrors, the last one the bins (r0/2) j).  Returns 1, 0 when the window goes
+ * to another kernel                                                                                                                  */
+int paa_debug_wgs_plan(int window, int32_t *info16, int32_t *bin_of, int capacity);
 /* Host tables of the fused three-pass kernel of the 1 s windows (csrc/kernels_wgr.hpp: 16 000 / 8 000 samples -- the windows
  * audioSegmentation.py:1134-1138 passes to feature_extraction), host only.  mel_job[512][4] = per thread {first bin, index of its weight
  * in the mel table, stride, number of bins}: the thread's share of ONE mel filter (ShortTermFeatures.py:236-254; its bins are first

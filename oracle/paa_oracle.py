@@ -386,6 +386,11 @@ def chromagram(signal, sampling_rate, window, step):
         X = np.abs(scipy.fft.fft(x))[0:nfft]
         X = X / len(X)
         P = X ** 2
+        if len(P) < nfft:
+            # a truncated last frame shorter than num_fft: the reference's scatter `C[num_chroma] = spec` (:288-293) fails with a
+            # shape mismatch -- ValueError, not the IndexError this gather form would raise (checked against the live reference)
+            raise ValueError("shape mismatch: value array of shape (%d,) could not be broadcast to indexing result of shape (%d,)"
+                             % (len(P), nfft))
         rows = int(np.ceil(nfft / 12.0))
         grid = np.zeros((rows * 12,))
         grid[tab.ch_pos] = P[tab.ch_src] * tab.ch_w

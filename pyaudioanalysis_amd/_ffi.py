@@ -111,6 +111,7 @@ _SIGNATURES = {
     "paa_debug_comm_marker_name": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
     "paa_debug_tri_plan": (C.c_int, [C.c_int, C.c_double, c_i32p, c_i32p, C.c_void_p, C.c_int]),
     "paa_debug_wg_plan": (C.c_int, [C.c_int, c_i32p, C.POINTER(C.c_uint16), C.c_int]),
+    "paa_debug_wgs_plan": (C.c_int, [C.c_int, c_i32p, c_i32p, C.c_int]),
     "paa_debug_wgr_tables": (C.c_int, [C.c_double, C.c_int, c_i32p, c_i32p, c_i32p, c_i32p, c_f64p]),
     "paa_debug_wgr_runs": (C.c_int, [c_i64p, C.c_int64, C.c_int, c_i32p, C.c_int64, c_i64p]),
     "paa_debug_blu_plan": (C.c_int, [C.c_int, C.c_double, c_i32p, c_i32p, C.c_void_p, C.c_int]),

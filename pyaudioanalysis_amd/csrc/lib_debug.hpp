@@ -215,6 +215,27 @@ extern "C" int paa_debug_wg_plan(int window, int32_t *info32, uint16_t *perm, in
     }
     return 1;
 }
+// kernels_wgs.hpp: the constants of the real-input split and the bin each element of a unit-major spectrum row holds (host restatement of
+// wgs::bin_of)
+extern "C" int paa_debug_wgs_plan(int window, int32_t *info16, int32_t *bin_of, int capacity) {
+    if (window < 2 || !info16) return fail(PAA_ERR_ARG, "bad argument");
+    const int r0 = wgs::wgs_r0(window);
+    if (!r0) return 0;
+    memset(info16, 0, 16 * sizeof(int32_t));
+    const int nf = window / 2, side = r0 == 12 ? wgs::side_doubles<12>() : wgs::side_doubles<6>();
+    info16[0] = r0; info16[1] = wgs::Q; info16[2] = wgs::R1; info16[3] = wgs::R2; info16[4] = wgs::R3; info16[5] = wgs::A;
+    info16[6] = wgs::NT; info16[7] = wgs::LDS_BYTES; info16[8] = r0 == 12 ? wgs::task_types<12>() : wgs::task_types<6>();
+    info16[9] = nf - side; info16[10] = r0 == 12 ? wgs::feat_lds<12>() : wgs::feat_lds<6>(); info16[11] = side; info16[12] = wgs::kFeatT;
+    if (bin_of) {
+        if (capacity < nf) return fail(PAA_ERR_ARG, "capacity %d < %d", capacity, nf);
+        const int h0 = r0 / 2;
+        for (int idx = 0; idx < nf; ++idx) {
+            const int u = idx / wgs::Q, kap = idx % wgs::Q, mm = (u + 1) + r0 * kap;
+            bin_of[idx] = (u == h0 - 1) ? h0 * kap : (mm < nf ? mm : window - mm);
+        }
+    }
+    return 1;
+}
 // host side of the Bluestein kernel for a window (no device needed): info8 = {log2 M, R0, R1, R2, waves, LDS bytes, table_bytes,
 // total_bytes}, offsets3 = {chirp, FFT(b) / M in pass order, pass twiddles} into the blob (LDS tables first, global tables behind them).
 // Returns the blob size (0: the window goes to another kernel; blob may be null to query the size).

@@ -217,6 +217,85 @@ def test_run_length_choice_for_the_baseline_batches():
             assert wgs <= 256 and longest.value <= 256
 
 
+@pytest.mark.parametrize("window", [44100, 22050])
+def test_real_input_split_plan_reproduces_the_spectrum(window):
+    """Host side of csrc/kernels_wgs.hpp (no device): the REAL-INPUT split of a 12 x 3675- / 6 x 3675-sample window into r0 / 2 independent
+    transforms of 3675 complex points -- complex unit q: a_q[k] = W_W^(q k) sum_r y[k + Q r] W_r0^(r q) in the kernel's difference form, the
+    packed unit from the sums over the even / odd samples --, each as three IN-PLACE register passes 7 x 21 x 25 over the padded exchange
+    buffer, and the UNIT-MAJOR spectrum row with the library's own bin map: restated in NumPy from the library's constants this gives
+    |fft(frame)|[0:W/2] / (W/2), every bin written exactly once (ShortTermFeatures.py:617-621); a constant frame gives exact zeros in every
+    complex unit's input (the exact spectrum of a digitally silent frame)."""
+    lib = _ffi.lib()
+    info = np.zeros(16, dtype=np.int32)
+    Nf = window // 2
+    bin_of = np.zeros(Nf, dtype=np.int32)
+    assert lib.paa_debug_wgs_plan(window, info.ctypes.data_as(_ffi.c_i32p), bin_of.ctypes.data_as(_ffi.c_i32p), Nf) == 1
+    r0, Q, R1, R2, R3, A, threads, lds, n_types, cap, feat_lds, side, feat_threads = (int(v) for v in info[:13])
+    assert r0 * Q == window and R1 * R2 * R3 == Q and A >= R2 * R3 and lds <= 160 * 1024 and feat_lds <= 160 * 1024
+    assert 2 * R1 * A * 16 <= lds and cap + side == Nf and cap * 8 <= feat_lds and n_types == (r0 // 2 + 1) // 2
+    assert sorted(bin_of.tolist()) == list(range(Nf))                       # a permutation: every bin exactly once
+    H0, J1 = r0 // 2, R2 * R3
+    rng = np.random.default_rng(window)
+    x = rng.standard_normal(window)
+    pos = lambda k: k + (A - J1) * (k // J1)                                # element k of a unit sits at k + 10 (k / 525)
+    S60 = np.sqrt(3.0) / 2
+
+    def split_dft(s, q):
+        """wgs::split_dft: the DFT over r of s[r] = y[k + Q r] at q, from sums and differences"""
+        if r0 == 6:
+            if q == 1:
+                d = s[0:3] - s[3:6]
+                return (d[0] + 0.5 * (d[1] - d[2])) + 1j * (-S60 * (d[1] + d[2]))
+            g = s[0:3] + s[3:6]
+            return (g[0] - 0.5 * (g[1] + g[2])) + 1j * (-S60 * (g[1] - g[2]))
+        e, o = s[0:6] + s[6:12], s[0:6] - s[6:12]
+        if q == 2:
+            d = e[0:3] - e[3:6]
+            return (d[0] + 0.5 * (d[1] - d[2])) + 1j * (-S60 * (d[1] + d[2]))
+        if q == 4:
+            g = e[0:3] + e[3:6]
+            return (g[0] - 0.5 * (g[1] + g[2])) + 1j * (-S60 * (g[1] - g[2]))
+        if q == 3:
+            return ((o[0] - o[2]) + o[4]) + 1j * (-((o[1] - o[3]) + o[5]))
+        sg = 1.0 if q == 1 else -1.0
+        return (o[0] + 0.5 * (o[2] - o[4]) + sg * S60 * (o[1] - o[5])) + 1j * (-(o[3] + 0.5 * (o[1] + o[5]) + sg * S60 * (o[2] + o[4])))
+
+    def three_passes(a):
+        buf = np.zeros(R1 * A, dtype=complex)
+        buf[pos(np.arange(Q))] = a
+        j = np.arange(J1)
+        F1 = np.exp(-2j * np.pi * np.outer(np.arange(R1), np.arange(R1)) / R1)
+        idx = np.arange(R1)[:, None] * A + j[None, :]                       # pass 1: job j, elements n0 A + j, in place
+        buf[idx] = (F1 @ buf[idx]) * np.exp(-2j * np.pi * np.outer(np.arange(R1), j) / Q)
+        F2 = np.exp(-2j * np.pi * np.outer(np.arange(R2), np.arange(R2)) / R2)
+        for k0 in range(R1):                                                # pass 2: job (n2, k0), elements k0 A + n1 R3 + n2, in place
+            idx = k0 * A + np.arange(R2)[:, None] * R3 + np.arange(R3)[None, :]
+            buf[idx] = (F2 @ buf[idx]) * np.exp(-2j * np.pi * np.outer(np.arange(R2), np.arange(R3)) / (R2 * R3))
+        F3 = np.exp(-2j * np.pi * np.outer(np.arange(R3), np.arange(R3)) / R3)
+        out = np.empty(Q, dtype=complex)
+        for k0 in range(R1):                                                # pass 3: job (k0, k1) -> A[k0 + R1 k1 + R1 R2 k2]
+            for k1 in range(R2):
+                out[k0 + R1 * k1 + R1 * R2 * np.arange(R3)] = F3 @ buf[k0 * A + k1 * R3 + np.arange(R3)]
+        return out
+
+    s = x.reshape(r0, Q)
+    k = np.arange(Q)
+    row = np.full(Nf, np.nan)                                               # unit-major
+    for q in range(1, H0):
+        a = split_dft(s, q) * np.exp(-2j * np.pi * k / window) ** q
+        assert np.all(split_dft(np.full((r0, Q), 0.37), q) == 0.0)           # equal samples: exact zeros
+        row[(q - 1) * Q:q * Q] = np.abs(three_passes(a)) / Nf
+    u = x.reshape(H0, 2 * Q).sum(axis=0)
+    V = three_passes(u[0::2] + 1j * u[1::2])
+    jj = np.arange(Q)
+    Vm = np.conj(V[(Q - jj) % Q])
+    row[(H0 - 1) * Q:] = np.abs(0.5 * (V + Vm) + np.exp(-2j * np.pi * H0 * jj / window) * (-0.5j * (V - Vm))) / Nf
+    natural = np.empty(Nf)
+    natural[bin_of] = row
+    ref = np.abs(np.fft.fft(x))[:Nf] / Nf
+    assert np.max(np.abs(natural - ref)) <= 1e-13 * ref.max()
+
+
 @pytest.mark.parametrize("window", [16000, 8000, 9009, 44100, 48000, 11025, 22050, 32000, 65536])
 def test_workgroup_fft_plan_reproduces_the_spectrum(window):
     """Host side of csrc/kernels_wg.hpp (no device): the in-place decimation-in-frequency passes, the padded LDS layout and the

@@ -53,3 +53,21 @@ def test_feature_extraction_and_rows_match_the_running_reference(seed, fs, windo
         gmid, gst, gnames = O.mid_feature_extraction(x, fs, mid_w, mid_s, window, step)
         assert list(gnames) == list(rnames) and gmid.shape == rmid.shape
         assert O.mixed_tolerance_violations(gmid, rmid, rel=1e-9, row_abs=1e-9, abs_floor=1e-12)[0] == 0
+
+
+@pytest.mark.parametrize("fs,window,step,n", [(16000, 800, 400, 800 + 400 * 7 + 150), (16000, 800, 400, 800 + 400 * 7 + 390), (16000, 800, 300, 4000),
+                                              (44100, 44100, 17000, 282240), (44100, 44100, 17000, 276574), (22050, 1103, 441, 9000)])
+def test_chromagram_truncated_tail_matches_the_running_reference(fs, window, step, n):
+    """chromagram (:324-386) FFTs what is left of a truncated last frame: a tail of at least num_fft samples gives a row, a shorter one fails
+    in the reference's scatter (:288-293) -- the oracle returns the same rows or raises the same exception TYPE (round 6: it raised IndexError
+    where the reference raises ValueError; found by tests/test_wgs_kernel_gpu.py, whose kernels had it right)."""
+    ref_st, _, _ = load_reference.load()
+    x = synth_clip(7300 + step, n, fs)
+    try:
+        ref, _, _ = ref_st.chromagram(x.astype(np.float64), fs, window, step)
+    except Exception as exc:
+        with pytest.raises(type(exc)):
+            O.chromagram(x, fs, window, step)
+        return
+    got, _, _ = O.chromagram(x, fs, window, step)
+    assert got.shape == ref.shape and np.max(np.abs(got - ref)) <= 1e-12
