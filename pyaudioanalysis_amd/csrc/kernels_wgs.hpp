@@ -33,7 +33,7 @@ namespace wgs {
 
 #ifndef PAA_WGS_ABLATE
 #define PAA_WGS_ABLATE 0           // timing builds only (scripts/rounds/r06/gpu_r06y.sh): bit mask of phases that are skipped -- 1 stage 0, 2 pass 1,
-                                   // 4 pass 2, 8 pass 3 + magnitudes, 16 the next task's touch; feature kernel: 32 sweep A, 64 sweep B, 128 roll-off, 256 mel, 512 chroma
+                                   // 4 pass 2, 8 pass 3 + magnitudes, 16 the next task's touch; feature kernel: 32 sweep A, 64 sweep B, 128 roll-off, 256 mel, 512 chroma; 1024: no time-domain features in stage 0
 #endif
 constexpr int kAblate = PAA_WGS_ABLATE;
 constexpr int R1 = 7, R2 = 21, R3 = 25;
@@ -174,11 +174,12 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
         // (the job indices are formed again in every task from an opaque copy of the thread index: as loop invariants they -- and the addresses
         // derived from them -- were hoisted out of the task loop into registers that were then spilled)
         int tid = tid_; asm volatile("" : "+v"(tid));
+        __builtin_assume(tid >= 0 && tid < NT);
         const int tu = tid - unit * TU;
         double2 *buf = buf_all + unit * UNIT_ELEMS;
         const bool packed_task = (type == task_types<R0>() - 1);             // unit b is the packed one
         const bool a_on = !(R0 == 6 && packed_task);                          // (R0 = 6: the packed unit is alone in its task)
-        const bool time_task = (type == 0) && P.mode == 0 && !cu.halo;
+        const bool time_task = (type == 0) && P.mode == 0 && !cu.halo && !(kAblate & 1024);
         double *row = (P.mode == 1) ? out + cu.out_off + (long long)cu.t * Nf : spec + (long long)cu.row * Nf;
         __syncthreads();          // the previous task's reads of the buffers are done (and its waves' partial sums are in LDS)
         if (tid == 64) *s_next = seg_lo + per + atomicAdd(next_task + seg, 1);
@@ -211,8 +212,7 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
                 constexpr int NI = (Q + NT - 1) / NT;
                 constexpr int BI = INT_T ? 5 : ((TIME || QB == 0) ? 2 : 5);
                 static_assert(NI % BI == 0, "whole batches");
-#pragma unroll 1
-                for (int ib = 0; ib < NI; ib += BI) {
+                auto batch = [&](const int ib) {
                     N sa[BI][R0];
                     N sla[BI][R0];          // TIME: lane 0's left neighbours x[k - 1 + Q r] (the other lanes take them from the lane below)
                     double2 wa[BI];
@@ -299,27 +299,39 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
                                 t = s[r];
                                 c = sgn1(s[r]); cl = sgn1(sl[r]);
                             }
-                            const double sq = in ? t * t : 0.0;
-                            const int b0 = (Q * r) / LT, b1 = (Q * r + Q - 1) / LT;          // (compile-time after unrolling)
-                            if (b1 == b0) eb[b0] += sq;
+                            // (k0 = tid + NT (ib + u) with 0 <= tid < NT known: the comparisons below are decided at compile time for every round
+                            // that does not straddle a block boundary / the end of the unit, and the selects fold into one fma)
+                            const double tm = (k0 < Q) ? t : 0.0;
+                            const int b0 = (Q * r) / LT, b1 = (Q * r + Q - 1) / LT;
+                            if (b1 == b0) eb[b0] = fma(tm, tm, eb[b0]);
                             else {
                                 const int kb1 = (b0 + 1) * LT - Q * r;
-                                const double lo = (k < kb1) ? sq : 0.0;
-                                eb[b0] += lo;
-                                if (b1 == b0 + 1) eb[b0 + 1] += sq - lo;
-                                else {
+                                if (b1 == b0 + 1) {
+                                    const double tl = (k0 < kb1) ? tm : 0.0, th = (k0 < kb1) ? 0.0 : tm;
+                                    eb[b0] = fma(tl, tl, eb[b0]);
+                                    eb[b0 + 1] = fma(th, th, eb[b0 + 1]);
+                                } else {
                                     const int kb2 = (b0 + 2) * LT - Q * r;
-                                    const double hi = (k >= kb2) ? sq : 0.0;
-                                    eb[b0 + 2] += hi;
-                                    eb[b0 + 1] += (sq - lo) - hi;
+                                    const double tl = (k0 < kb1) ? tm : 0.0, th = (k0 >= kb2) ? tm : 0.0, tc = (k0 >= kb1 && k0 < kb2) ? tm : 0.0;
+                                    eb[b0] = fma(tl, tl, eb[b0]);
+                                    eb[b0 + 1] = fma(tc, tc, eb[b0 + 1]);
+                                    eb[b0 + 2] = fma(th, th, eb[b0 + 2]);
                                 }
                             }
                             const int left = shr1(c, cl);
-                            if (in) sad_acc(zc, c, left);
+                            if (k0 < Q) sad_acc(zc, c, left);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);          // (one round at a time)
                     }
+                };
+                if constexpr (TIME && INT_T) {
+                    // (unrolled: the round numbers are compile-time, so the range checks of every round that straddles nothing fold)
+#pragma unroll
+                    for (int ib = 0; ib < NI; ib += BI) batch(ib);
+                } else {
+#pragma unroll 1
+                    for (int ib = 0; ib < NI; ib += BI) batch(ib);
                 }
                 if constexpr (TIME) {
 #pragma unroll
