@@ -264,7 +264,8 @@ int paa_debug_wg_plan(int window, int32_t *info32, uint16_t *perm, int perm_capa
 /* Real-input split of the 12 x 3675- / 6 x 3675-sample windows (csrc/kernels_wgs.hpp: 44 100 and 22 050 samples -- the 1 s window
  * audioSegmentation.py:1134-1138 passes to feature_extraction at 44.1 / 22.05 kHz), host only: info16 = {r0, points per sub-transform Q,
  * R1, R2, R3 (three register passes), row pitch of the exchange buffer, threads per workgroup, LDS bytes, task types per frame, bins
- * of a spectrum row the feature kernel holds in LDS, its LDS bytes, side-row doubles, threads of the feature kernel}; bin_of[W / 2] (may
+ * of a spectrum row the feature kernel keeps in LDS (the mel filters' range), its LDS bytes, natural blocks of 64 r0 bins per row (the
+ * roll-off is located block by block), threads of the feature kernel}; bin_of[W / 2] (may
  * be null) = the bin that element idx of a UNIT-MAJOR spectrum row holds (the transform kernel stores |X| unit after unit: sub-transform
  * q = 1 .. r0/2 - 1 delivers the bins q + r0 kappa and their mirrors, the last one the bins (r0/2) j).  Returns 1, 0 when the window goes
  * to another kernel                                                                                                                  */

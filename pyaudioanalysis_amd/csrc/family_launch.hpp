@@ -52,11 +52,9 @@ int wgr(int shape_id, int sample_kind, int mode, const PlanDev &P, const void *d
 // the time-domain partials of a frame to `tfeat`, the units' sum X / sum (k + 1) X / max X to `psum` (4 doubles per row and unit, r0 / 2 units)
 int wgs(int r0, int sample_kind, const PlanDev &P, const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const wg::FrameRef *tasks,
         int n_tasks, int *counter, int num_cu, double *spec, double *tfeat, double *psum, double *d_out, hipStream_t stream);
-// ... and the features of those frames from the unit-major rows (one workgroup per frame; `side`: wgs_side_doubles(r0) doubles per row for the
-// bins the LDS does not hold)
-int wgs_feat(int r0, const PlanDev &P, const wg::FrameRef *frames, int n_frames, const ClipDev *clips, const double *spec, double *side,
+// ... and the features of those frames from the unit-major rows (one workgroup per frame)
+int wgs_feat(int r0, const PlanDev &P, const wg::FrameRef *frames, int n_frames, const ClipDev *clips, const double *spec,
              const double *tfeat, const double *psum, double *d_out, hipStream_t stream);
-int wgs_side_doubles(int r0);
 // kernels_generic.hpp: Stockham passes in LDS (what is left)
 int generic(const GenLayout &gl, size_t lds, int sample_kind, const PlanDev &P, const unsigned char *blob,
             const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const Tile *tiles, long long n_tiles,

@@ -45,7 +45,7 @@ int wgs(int r0, int sample_kind, const PlanDev &P, const void *d_packed, const C
 }
 
 template <int R0>
-static int wgs_feat_one(const PlanDev &P, const wg::FrameRef *frames, int n_frames, const ClipDev *clips, const double *spec, double *side,
+static int wgs_feat_one(const PlanDev &P, const wg::FrameRef *frames, int n_frames, const ClipDev *clips, const double *spec,
                         const double *tfeat, const double *psum, double *d_out, hipStream_t stream) {
     static bool attr = false;
     if (!attr) {
@@ -55,17 +55,16 @@ static int wgs_feat_one(const PlanDev &P, const wg::FrameRef *frames, int n_fram
         attr = true;
     }
     if (n_frames <= 0) return 0;
-    hipLaunchKernelGGL((wgs::wgs_feat_kernel<R0>), dim3((unsigned)n_frames), dim3(wgs::kFeatT), (size_t)wgs::feat_lds<R0>(), stream, P, frames, clips, spec,
-                       side, tfeat, psum, d_out);
+    hipLaunchKernelGGL((wgs::wgs_feat_kernel<R0>), dim3(8u * (unsigned)((n_frames + 7) / 8)), dim3(wgs::kFeatT), (size_t)wgs::feat_lds<R0>(), stream, P, frames, clips, n_frames, spec,
+                       tfeat, psum, d_out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-int wgs_feat(int r0, const PlanDev &P, const wg::FrameRef *frames, int n_frames, const ClipDev *clips, const double *spec, double *side,
+int wgs_feat(int r0, const PlanDev &P, const wg::FrameRef *frames, int n_frames, const ClipDev *clips, const double *spec,
              const double *tfeat, const double *psum, double *d_out, hipStream_t stream) {
-    if (r0 == 12) return wgs_feat_one<12>(P, frames, n_frames, clips, spec, side, tfeat, psum, d_out, stream);
-    if (r0 == 6) return wgs_feat_one<6>(P, frames, n_frames, clips, spec, side, tfeat, psum, d_out, stream);
+    if (r0 == 12) return wgs_feat_one<12>(P, frames, n_frames, clips, spec, tfeat, psum, d_out, stream);
+    if (r0 == 6) return wgs_feat_one<6>(P, frames, n_frames, clips, spec, tfeat, psum, d_out, stream);
     return -1;
 }
-int wgs_side_doubles(int r0) { return r0 == 12 ? wgs::side_doubles<12>() : wgs::side_doubles<6>(); }
 
 }  // namespace launch
 }  // namespace paa

@@ -556,12 +556,39 @@ __device__ __forceinline__ int bin_of(int idx) {
 }
 static_assert(((unsigned long long)1168734u * 3675ull) >> 32 == 1 && ((unsigned long long)1168734u * 3674ull) >> 32 == 0 &&
               ((unsigned long long)1168734u * 22049ull) >> 32 == 5, "magic of 3675");
+// ... and the row element that holds bin k
+template <int R0>
+__device__ __forceinline__ int idx_of(int k) {
+    constexpr int H0 = R0 / 2;
+    const int kr = (R0 == 12) ? (int)__umulhi((unsigned)k, 357913942u) : (int)__umulhi((unsigned)k, 715827883u);          // k / R0 for k < 2^16
+    const int rho = k - kr * R0;
+    if (rho == 0) return (H0 - 1) * Q + 2 * kr;
+    if (rho == H0) return (H0 - 1) * Q + 2 * kr + 1;
+    return rho < H0 ? (rho - 1) * Q + kr : (R0 - rho - 1) * Q + Q - 1 - kr;
+}
+static_assert(((unsigned long long)357913942u * 12ull) >> 32 == 1 && ((unsigned long long)357913942u * 11ull) >> 32 == 0 &&
+              ((unsigned long long)357913942u * 22049ull) >> 32 == 1837 && ((unsigned long long)715827883u * 6ull) >> 32 == 1 &&
+              ((unsigned long long)715827883u * 5ull) >> 32 == 0 && ((unsigned long long)715827883u * 11024ull) >> 32 == 1837, "magics of 12 and 6");
+
+// The row is read as STREAMS whose elements are R0 (or R0 / 2) bins apart: residue stream rho (rho = 1 .. R0 - 1, rho != R0 / 2) = the bins
+// rho + R0 n -- unit rho read forwards, or unit R0 - rho read backwards (its mirrored half) --, and the packed unit's bins (R0 / 2) n.  64
+// consecutive elements of a residue stream (128 of the packed one) lie inside ONE natural block of 64 R0 bins, so a wave that takes 64 elements
+// per round reads both rows coalesced, knows every element's bin from two constants, and its sum of squares IS that stream's share of the
+// block's energy: the roll-off (:127-140) is located from the block energies and finished inside one block of 64 R0 bins, and no natural-order
+// copy of the row is needed but for the bins the mel filters use (LDS, a few thousand).  The workgroup keeps 45 KB of LDS instead of the
+// whole row's 160 KB: three of them share a CU (the sweep of one runs under the reductions and the mel walk of the others), and 599 frames are
+// one round of workgroups instead of three.
 constexpr int kFeatT = 512, kFeatW = kFeatT / 64;
-constexpr int CAP = 20000;                          // bins of the row staged in LDS (natural order); the rest waits in a side row in global memory
-constexpr int FEAT_SMALL = (48 + 40 + kFeatW * 16 + kFeatW) * 8 + kFeatW * 4;
-template <int R0> constexpr int side_doubles() { return R0 * Q / 2 > CAP ? R0 * Q / 2 - CAP : 0; }
-template <int R0> constexpr int feat_lds() { return (R0 * Q / 2 - side_doubles<R0>()) * 8 + ((FEAT_SMALL + 15) / 16) * 16; }
-static_assert(feat_lds<12>() <= 160 * 1024, "feature kernel LDS");
+constexpr int LCAP = 4096;                          // bins below LCAP are also kept in LDS, natural order (the mel filters' range for the usual rates)
+template <int R0> struct FeatGeo {
+    static constexpr int NF = R0 * Q / 2, SPB = R0, BLK = 64 * R0, NBLK = (NF + BLK - 1) / BLK, NIT = NBLK * SPB;
+    static constexpr int OFF_SLOT_E = LCAP * 8;                           // double [NBLK]: the natural blocks' energies
+    static constexpr int OFF_FINE = OFF_SLOT_E + 64 * 8;                  // double [BLK]: the squares of the block that holds the roll-off bin
+    static constexpr int OFF_SMALL = OFF_FINE + BLK * 8;                  // fv [48], msp [40], red [kFeatW][16], slot [kFeatW], redi [kFeatW + 2]
+    static constexpr int LDS = OFF_SMALL + (48 + 40 + kFeatW * 16 + kFeatW) * 8 + (kFeatW + 2) * 4 + 8;
+    static_assert(NBLK <= 64, "one lane per natural block");
+};
+template <int R0> constexpr int feat_lds() { return (FeatGeo<R0>::LDS + 15) / 16 * 16; }
 
 __device__ __forceinline__ double bsum8(double v, double *slot, int lane, int wave) {
     v = wsum(v);
@@ -573,32 +600,37 @@ __device__ __forceinline__ double bsum8(double v, double *slot, int lane, int wa
 }
 
 template <int R0>
-__global__ __launch_bounds__(kFeatT) void wgs_feat_kernel(PlanDev P, const wg::FrameRef *__restrict__ frames, const ClipDev *__restrict__ clips,
-                                                          const double *__restrict__ spec, double *__restrict__ side_all,
-                                                          const double *__restrict__ tfeat, const double *__restrict__ psum,
-                                                          double *__restrict__ out) {
-    constexpr int NF = R0 * Q / 2, W = R0 * Q, SIDE = side_doubles<R0>(), NL = NF < CAP ? NF : CAP;
+__global__ __launch_bounds__(kFeatT, 2) void wgs_feat_kernel(PlanDev P, const wg::FrameRef *__restrict__ frames, const ClipDev *__restrict__ clips,
+                                                             int n_frames, const double *__restrict__ spec, const double *__restrict__ tfeat,
+                                                             const double *__restrict__ psum, double *__restrict__ out) {
+    typedef FeatGeo<R0> G;
+    constexpr int NF = G::NF, W = R0 * Q, H0 = R0 / 2, SPB = G::SPB, NBLK = G::NBLK, NIT = G::NIT, BLK = G::BLK;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const wg::FrameRef fr = frames[blockIdx.x];
+    // XCD-aware: workgroup b runs on XCD b % 8 and takes frame (b % 8) per + b / 8 (grid = 8 per): the workgroups that run side by side on an XCD
+    // hold consecutive frames, so a row is fetched from HBM once -- as one frame's own row -- and found in that XCD's L2 as the next frame's
+    // previous row
+    const int per = (n_frames + 7) / 8, fi = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
+    if (fi >= n_frames) return;
+    const wg::FrameRef fr = frames[fi];
     if (fr.halo) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const ClipDev c = clips[fr.clip];
-    double *cur_l = reinterpret_cast<double *>(smem);
-    double *fv = cur_l + NL;             // [48]
+    double *low = reinterpret_cast<double *>(smem);
+    double *slotE = reinterpret_cast<double *>(smem + G::OFF_SLOT_E);
+    double *fine = reinterpret_cast<double *>(smem + G::OFF_FINE);
+    double *fv = reinterpret_cast<double *>(smem + G::OFF_SMALL);             // [48]
     double *msp = fv + 48;               // [40]
     double *red = msp + 40;              // [kFeatW][16]
     double *slot = red + kFeatW * 16;    // [kFeatW]
-    int *redi = reinterpret_cast<int *>(slot + kFeatW);
+    int *redi = reinterpret_cast<int *>(slot + kFeatW);      // [kFeatW + 2]
     const double *gc = spec + (long long)fr.row * NF;
     const double *prv = (fr.t == 0) ? gc : gc - NF;          // frames are laid out in clip order: the previous frame is the previous row
-    double *side = side_all + (long long)fr.row * SIDE;
-    auto X = [&](int k) -> double { return (SIDE == 0 || k < CAP) ? cur_l[k] : side[k - CAP]; };
+    auto X = [&](int k) -> double { return k < LCAP ? low[k] : gc[idx_of<R0>(k)]; };
     double *oc = out + c.out_off;
     const long long Tc = c.T;
     const Tabs tb = tabs_global(P);
     // ---- the row's sums and maximum, and the previous row's sum, from the transform kernel's per-unit parts (fixed order: every frame gets the
     // same bits wherever it runs) -- centroid and the normalisations of spread and flux are known BEFORE the sweep
-    constexpr int H0 = R0 / 2;
     double sX = 0.0, sIXr = 0.0, mx = 0.0, sXpr = 0.0;
     {
         const double *pc = psum + (long long)fr.row * H0 * 4, *pp = (fr.t == 0) ? pc : pc - H0 * 4;
@@ -613,55 +645,76 @@ __global__ __launch_bounds__(kFeatT) void wgs_feat_kernel(PlanDev P, const wg::F
     const double den = sX * r + kEps;
     const double cen = fast_div(sIX * r, den);
     const double rX = fast_div(1.0, sXe), rXp = fast_div(1.0, sXp);
-    // ---- ONE sweep in row order (:57-124), one coalesced read of both rows: the ten block energies (+ tail), spread, flux; every value goes to
-    // its bin's place in LDS (natural order) on the way.  The loads of a batch of UB rounds -- both rows -- are requested before the first value
-    // is used: the rows come from the other CUs' stores, i.e. at HBM latency
+    // ---- ONE sweep (:57-124), one coalesced read of both rows: wave w takes the natural blocks jb = w, w + 8, ... -- all SPB streams of a block
+    // at once: 2 SPB loads in flight per lane (the rows come from other CUs' stores: HBM latency), every stream's constants known at compile time
+    // (a first version that dealt (block, stream) pairs to the waves spent 200 vector instructions per 64 elements, most of them on finding out
+    // which stream it held: 77 us of this kernel's 108).  A block of 64 R0 bins meets at most two spectral-entropy blocks (:85-107): the
+    // lanes' sums of squares go to the block they belong to through ONE per-lane accumulator that is flushed when the entropy block changes.
     const int LB = P.blk_f;
-    double part[11];          // 0..9 blocks, 10 tail
-#pragma unroll
-    for (int i = 0; i < 11; ++i) part[i] = 0.0;
+    double *ered = red;                   // [kFeatW][16]: entropy blocks 0..9, 10 = the tail; 11 spread, 12 flux
+    if (lane < 16) ered[16 * wave + lane] = 0.0;
     double sSp = 0.0, sFl = 0.0;
-    constexpr int NI = (NF + kFeatT - 1) / kFeatT, UB = 11, NBATCH = (NI + UB - 1) / UB;
     {
-        const unsigned mlb = (unsigned)(((1ULL << 32) + (unsigned)LB - 1) / (unsigned)LB);
+        double accE = 0.0;                // this lane's squares of the entropy block e_cur
+        int e_cur = -1;
+        auto flush = [&](int e, double acc) {
+            const double v = wsum(acc);
+            if (lane == 0 && e >= 0) ered[16 * wave + e] += v;
+        };
+        const double kf = (double)(R0 * lane);          // (bin + 1) f0 - cen = (kb + rho + 1 + R0 lane) f0 - cen
 #pragma unroll 1
-        for (int bt = 0; bt < ((kAblate & 32) ? 0 : NBATCH); ++bt) {
-            double xv[UB], pv[UB];
-            const int i0 = tid + kFeatT * UB * bt;
+        for (int jb = wave; jb < ((kAblate & 32) ? 0 : NBLK); jb += kFeatW) {
+            const int n = 64 * jb + lane;
+            double xv[SPB], pv[SPB];
+            const bool full = jb < NBLK - 1;          // (only the last block has bins beyond the row: wave-uniform)
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int idx = min(i0 + kFeatT * u, NF - 1);
-                xv[u] = gc[idx];
-                pv[u] = prv[idx];
+            for (int s2 = 0; s2 < SPB; ++s2) {
+                const bool packed = s2 >= R0 - 2;
+                const int rho = (s2 < H0 - 1) ? s2 + 1 : s2 + 2;
+                const bool fwd = packed || rho < H0;
+                const int base = packed ? (H0 - 1) * Q : (fwd ? (rho - 1) * Q : (R0 - rho - 1) * Q + Q - 1);
+                const int ns = packed ? n + 64 * jb + 64 * (s2 - (R0 - 2)) : n;          // element of the stream: 64 (2 jb + h) + lane for the packed halves
+                const int k = packed ? H0 * ns : rho + R0 * ns;
+                const int idx = (full || k < NF) ? (fwd ? base + ns : base - ns) : 0;
+                xv[s2] = gc[idx];
+                pv[s2] = prv[idx];
             }
+            const int kb = BLK * jb;                                   // first bin of the block
+            const int e_first = min((int)((unsigned)kb / (unsigned)LB), 10), e_last = min((int)((unsigned)(kb + BLK - 1) / (unsigned)LB), 10);
+            const int bnd = (e_first + 1) * LB;                        // first bin of the next entropy block
+            const bool stage_low = kb < LCAP;
+            if (e_first != e_cur) { flush(e_cur, accE); accE = 0.0; e_cur = e_first; }
+            double accR = 0.0, accLo = 0.0;
+            const double c0 = (double)(kb + 1) * f0 - cen;
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int idx = i0 + kFeatT * u;
-                const bool in = idx < NF;
-                const double Xv = in ? xv[u] : 0.0;
-                const int k = bin_of<R0>(in ? idx : NF - 1);
-                if (in) { if (SIDE == 0 || k < CAP) cur_l[k] = Xv; else side[k - CAP] = Xv; }
-                const int j = min((int)__umulhi((unsigned)k, mlb), 10);
+            for (int s2 = 0; s2 < SPB; ++s2) {
+                const bool packed = s2 >= R0 - 2;
+                const int rho = (s2 < H0 - 1) ? s2 + 1 : s2 + 2;
+                const int ns = packed ? n + 64 * jb + 64 * (s2 - (R0 - 2)) : n;
+                const int k = packed ? H0 * ns : rho + R0 * ns;
+                const bool in = full || k < NF;
+                const double Xv = in ? xv[s2] : 0.0, Pv = in ? pv[s2] : 0.0;
+                if (stage_low && k < LCAP && in) low[k] = Xv;
                 const double sq = Xv * Xv;
-#pragma unroll
-                for (int i2 = 0; i2 < 11; ++i2) part[i2] += (i2 == j) ? sq : 0.0;
-                const double dv = (double)(k + 1) * f0 - cen;
+                accR += sq;
+                if (e_first != e_last) accLo += (k < bnd) ? sq : 0.0;
+                // (k + 1) f0 - cen with k - kb = rho + R0 lane (residue) / H0 (64 h + lane) (packed): a constant per stream + a constant per lane
+                const double dv = packed ? fma((double)(H0 * (64 * (s2 - (R0 - 2)))) + 0.5 * kf, f0, c0) : fma((double)rho + kf, f0, c0);
                 sSp = fma(dv * dv, Xv * r, sSp);
-                const double df = Xv * rX - (in ? pv[u] : 0.0) * rXp;
+                const double df = Xv * rX - Pv * rXp;
                 sFl = fma(df, df, sFl);
             }
+            const double eb = wsum(accR);                 // the natural block's energy (the roll-off is located from these)
+            if (lane == 0) slotE[jb] = eb;
+            if (e_first == e_last) accE += accR;
+            else { flush(e_cur, accE + accLo); accE = accR - accLo; e_cur = e_last; }
         }
+        flush(e_cur, accE);
     }
-    double part2[2] = {sSp, sFl};
-#pragma unroll
-    for (int i = 0; i < 11; ++i) part[i] = wsum(part[i]);
-    part2[0] = wsum(part2[0]); part2[1] = wsum(part2[1]);
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 11; ++i) red[16 * wave + i] = part[i];
-        red[16 * wave + 11] = part2[0]; red[16 * wave + 12] = part2[1];
-    }
-    __syncthreads();          // (also: the row is in place -- LDS and the side row, written and read by this workgroup only)
+    sSp = wsum(sSp); sFl = wsum(sFl);
+    if (lane == 0) { ered[16 * wave + 11] = sSp; ered[16 * wave + 12] = sFl; }
+    __syncthreads();          // (also: the low bins and the block energies are in place)
+    double part[11];
 #pragma unroll
     for (int i = 0; i < 11; ++i) {
         double a = 0.0;
@@ -672,7 +725,6 @@ __global__ __launch_bounds__(kFeatT) void wgs_feat_kernel(PlanDev P, const wg::F
     sSp = 0.0; sFl = 0.0;
 #pragma unroll
     for (int w = 0; w < kFeatW; ++w) { sSp += red[16 * w + 11]; sFl += red[16 * w + 12]; }
-    __syncthreads();
     double sP = part[10];
 #pragma unroll
     for (int j = 0; j < 10; ++j) sP += part[j];
@@ -694,35 +746,47 @@ __global__ __launch_bounds__(kFeatT) void wgs_feat_kernel(PlanDev P, const wg::F
         ent_f -= sh * fast_log2(sh + kEps);
     }
     const double spread = fast_sqrt(fast_div(sSp, den));
-    // ---- roll-off (:127-140): first k with cumsum(X^2)[k] + eps > 0.9 sum(X^2); contiguous chunks of ODD length, workgroup-wide scan
+    // ---- roll-off (:127-140): first k with cumsum(X^2)[k] + eps > 0.9 sum(X^2).  The natural blocks' energies (the streams' shares added in
+    // stream order) locate the block; its 64 R0 squares come back in natural order (L2: this workgroup has just read them) and one wave walks them
+    const double thr = 0.90 * sP;
+    if (wave == 0 && !(kAblate & 128)) {
+        const double En = (lane < NBLK) ? slotE[lane] : 0.0;
+        const double cum = wscan_incl(En);
+        const int jc = wmin_i((lane < NBLK && cum + kEps > thr) ? lane : 0x7fffffff);
+        if (lane == (jc == 0x7fffffff ? 0 : jc)) { redi[kFeatW] = jc; slot[0] = cum - En; }
+    }
+    __syncthreads();
     int first = 0x7fffffff;
     {
-        const double thr = 0.90 * sP;
-        constexpr int cch = ((NF + kFeatT - 1) / kFeatT) | 1;
-        const int kb = min(tid * cch, NF), ke = (kAblate & 128) ? kb : min(NF, kb + cch);
-        double xr[cch];          // the chunk's squares stay in registers for the second walk (each LDS read of it was a dependent trip)
-        double cs = 0.0;
-#pragma unroll
-        for (int i = 0; i < cch; ++i) { const double xv = (kb + i < ke) ? X(kb + i) : 0.0; xr[i] = xv * xv; }
-#pragma unroll
-        for (int i = 0; i < cch; ++i) cs += xr[i];
-        const double incl = wscan_incl(cs);
-        if (lane == 63) slot[wave] = incl;
-        __syncthreads();
-        double run = incl - cs;
-#pragma unroll
-        for (int w = 0; w < kFeatW; ++w) run += (w < wave) ? slot[w] : 0.0;
-#pragma unroll
-        for (int i = 0; i < cch; ++i) {
-            run += xr[i];
-            if (first == 0x7fffffff && kb + i < ke && run + kEps > thr) first = kb + i;
+        const int jc = redi[kFeatW];
+        const double base = slot[0];
+        if (jc != 0x7fffffff) {
+            for (int t = tid; t < BLK; t += kFeatT) {
+                const int k = BLK * jc + t;
+                const double xv = (k < NF) ? gc[idx_of<R0>(k)] : 0.0;
+                fine[t] = xv * xv;
+            }
         }
-        first = wmin_i(first);
-        if (lane == 0) redi[wave] = first;
         __syncthreads();
-        first = redi[0];
+        if (wave == 0 && jc != 0x7fffffff) {
+            double own = 0.0;
+            double xr[R0];
 #pragma unroll
-        for (int w = 1; w < kFeatW; ++w) first = min(first, redi[w]);
+            for (int i = 0; i < R0; ++i) { xr[i] = fine[R0 * lane + i]; own += xr[i]; }
+            double run = base + (wscan_incl(own) - own);
+#pragma unroll
+            for (int i = 0; i < R0; ++i) {
+                run += xr[i];
+                const int k = BLK * jc + R0 * lane + i;
+                if (first == 0x7fffffff && k < NF && run + kEps > thr) first = k;
+            }
+            first = wmin_i(first);
+            // (the block sums and this walk add in different orders: a crossing the walk misses by a rounding is the next block's first bin)
+            if (first == 0x7fffffff && BLK * (jc + 1) < NF) first = BLK * (jc + 1);
+            if (lane == 0) redi[kFeatW + 1] = first;
+        }
+        __syncthreads();
+        first = (jc != 0x7fffffff) ? redi[kFeatW + 1] : 0x7fffffff;
     }
     // ---- MFCC (:236-254): wave w owns the filters w, w + 8, ..., walked together, all 64 lanes on a filter's bins
     {

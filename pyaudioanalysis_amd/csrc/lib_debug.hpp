@@ -222,10 +222,11 @@ extern "C" int paa_debug_wgs_plan(int window, int32_t *info16, int32_t *bin_of, 
     const int r0 = wgs::wgs_r0(window);
     if (!r0) return 0;
     memset(info16, 0, 16 * sizeof(int32_t));
-    const int nf = window / 2, side = r0 == 12 ? wgs::side_doubles<12>() : wgs::side_doubles<6>();
+    const int nf = window / 2;
     info16[0] = r0; info16[1] = wgs::Q; info16[2] = wgs::R1; info16[3] = wgs::R2; info16[4] = wgs::R3; info16[5] = wgs::A;
     info16[6] = wgs::NT; info16[7] = wgs::LDS_BYTES; info16[8] = r0 == 12 ? wgs::task_types<12>() : wgs::task_types<6>();
-    info16[9] = nf - side; info16[10] = r0 == 12 ? wgs::feat_lds<12>() : wgs::feat_lds<6>(); info16[11] = side; info16[12] = wgs::kFeatT;
+    info16[9] = wgs::LCAP; info16[10] = r0 == 12 ? wgs::feat_lds<12>() : wgs::feat_lds<6>();
+    info16[11] = r0 == 12 ? wgs::FeatGeo<12>::NBLK : wgs::FeatGeo<6>::NBLK; info16[12] = wgs::kFeatT;
     if (bin_of) {
         if (capacity < nf) return fail(PAA_ERR_ARG, "capacity %d < %d", capacity, nf);
         const int h0 = r0 / 2;

@@ -579,9 +579,8 @@ struct ProfScope {
 template <typename T>
 static int run_wg(paa_plan *p, const void *d_packed, double *d_out) {
     const PlanDev &P = p->P;
-    const size_t side_row = p->wgs_r0 ? (size_t)launch::wgs_side_doubles(p->wgs_r0) : 0;          // kernels_wgs.hpp: the bins of a row its feature kernel's LDS does not hold
-    const size_t psum_row = p->wgs_r0 ? (size_t)(p->wgs_r0 / 2) * 4 : 0;                                    // ... and its units' partial sums
-    const size_t need = (size_t)p->wg_rows * ((size_t)P.Nf * 8 + 24 + (side_row + psum_row) * 8) + 256;       // (+ the task counter of the split transform)
+    const size_t psum_row = p->wgs_r0 ? (size_t)(p->wgs_r0 / 2) * 4 : 0;                            // kernels_wgs.hpp: the units' partial sums of a row
+    const size_t need = (size_t)p->wg_rows * ((size_t)P.Nf * 8 + 24 + psum_row * 8) + 256;       // (+ the task counter of the split transform)
     bool fresh = false;
     if (need > p->big_bytes) {
         if (p->d_big) { HIP_TRY(hipStreamSynchronize(cs())); (void)hipFree(p->d_big); p->d_big = nullptr; p->big_bytes = 0; }
@@ -591,8 +590,7 @@ static int run_wg(paa_plan *p, const void *d_packed, double *d_out) {
     }
     double *spec = reinterpret_cast<double *>(p->d_big);
     double *tfeat = spec + (size_t)p->wg_rows * P.Nf;
-    double *side = tfeat + 3 * (size_t)p->wg_rows;
-    double *psum = side + side_row * (size_t)p->wg_rows;
+    double *psum = tfeat + 3 * (size_t)p->wg_rows;
     int *task_counter = reinterpret_cast<int *>(psum + psum_row * (size_t)p->wg_rows);
     // (kernels_wgs.hpp: one counter per XCD segment + the workgroups that are done; its last workgroup leaves them at zero)
     if (fresh && p->wgs_r0) HIP_TRY(hipMemsetAsync(task_counter, 0, 16 * sizeof(int), cs()));
@@ -653,7 +651,7 @@ static int run_wg(paa_plan *p, const void *d_packed, double *d_out) {
         if (prof_scope.stop) { (void)hipEventRecord(prof_scope.stop, cs()); prof_scope.stop = nullptr; }
         }
         if (P.mode != 1 && p->wgs_r0) {
-            if (launch::wgs_feat(p->wgs_r0, P, fr, (int)n, p->d_clips, spec, side, tfeat, psum, d_out, cs()))
+            if (launch::wgs_feat(p->wgs_r0, P, fr, (int)n, p->d_clips, spec, tfeat, psum, d_out, cs()))
                 return fail(PAA_ERR_HIP, "launch of the feature kernel of %s failed: %s", p->kernel_name.c_str(), hipGetErrorString(hipGetLastError()));
         } else if (P.mode != 1) {
             if (p->wl.feat_staged)

@@ -230,9 +230,20 @@ def test_real_input_split_plan_reproduces_the_spectrum(window):
     Nf = window // 2
     bin_of = np.zeros(Nf, dtype=np.int32)
     assert lib.paa_debug_wgs_plan(window, info.ctypes.data_as(_ffi.c_i32p), bin_of.ctypes.data_as(_ffi.c_i32p), Nf) == 1
-    r0, Q, R1, R2, R3, A, threads, lds, n_types, cap, feat_lds, side, feat_threads = (int(v) for v in info[:13])
-    assert r0 * Q == window and R1 * R2 * R3 == Q and A >= R2 * R3 and lds <= 160 * 1024 and feat_lds <= 160 * 1024
-    assert 2 * R1 * A * 16 <= lds and cap + side == Nf and cap * 8 <= feat_lds and n_types == (r0 // 2 + 1) // 2
+    r0, Q, R1, R2, R3, A, threads, lds, n_types, low_bins, feat_lds, n_blocks, feat_threads = (int(v) for v in info[:13])
+    assert r0 * Q == window and R1 * R2 * R3 == Q and A >= R2 * R3 and lds <= 160 * 1024 and 3 * feat_lds <= 160 * 1024
+    assert 2 * R1 * A * 16 <= lds and low_bins * 8 <= feat_lds and n_blocks == -(-Nf // (64 * r0)) and n_types == (r0 // 2 + 1) // 2
+    # the feature kernel reads a row as residue streams: 64 consecutive elements of a stream lie in one natural block of 64 r0 bins
+    inv = np.empty(Nf, dtype=np.int64)
+    inv[bin_of] = np.arange(Nf)
+    for rho in range(1, r0):
+        if rho == r0 // 2:
+            continue
+        n = np.arange(-(-(Nf - rho) // r0))
+        idx = (rho - 1) * Q + n if rho < r0 // 2 else (r0 - rho - 1) * Q + Q - 1 - n
+        assert np.array_equal(bin_of[idx], rho + r0 * n) and np.array_equal((rho + r0 * n) // (64 * r0), n // 64)
+    n = np.arange(Q)
+    assert np.array_equal(bin_of[(r0 // 2 - 1) * Q + n], (r0 // 2) * n) and np.array_equal(((r0 // 2) * n) // (64 * r0), n // 128)
     assert sorted(bin_of.tolist()) == list(range(Nf))                       # a permutation: every bin exactly once
     H0, J1 = r0 // 2, R2 * R3
     rng = np.random.default_rng(window)
