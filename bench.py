@@ -103,6 +103,8 @@ SHAPES = {
     "big_44100": (44100, 44100, 22050, 300, 1, 0, 0, 0),           # 1 s at 44.1 kHz: 22 050 complex points do not fit the LDS: real-input split, 6 x 3675 points
     "big_44100_20min": (44100, 44100, 22050, 1200, 1, 0, 0, 0),    # ... a 20-minute recording (2 399 frames: 28 tasks per CU)
     "big_22050": (22050, 22050, 11025, 1200, 1, 0, 0, 0),          # 1 s at 22.05 kHz: 3 x 3675 points
+    "big_48000": (48000, 48000, 24000, 600, 1, 0, 0, 0),           # 1 s at 48 kHz: 6 x 4000 points (8 x 20 x 25 per sub-transform)
+    "big_32000": (32000, 32000, 16000, 600, 1, 0, 0, 0),           # 1 s at 32 kHz: 4 x 4000 points
 }
 SAMPLE_BYTES = {0: 2, 1: 8, 2: 4}
 
@@ -269,6 +271,8 @@ def other_configs(ffi, steps=10):
     run_shape("big_44100", "w44100_44kHz", "5 min at 44.1 kHz, 1 s / 0.5 s (44100 / 22050): real-input split, six transforms of 3675 points on register passes", launches=5)
     run_shape("big_44100_20min", "w44100_44kHz_20min", "20 min at 44.1 kHz, 44100 / 22050", launches=3)
     run_shape("big_22050", "w22050_22kHz", "20 min at 22.05 kHz, 1 s / 0.5 s (22050 / 11025): three transforms of 3675 points", launches=5)
+    run_shape("big_48000", "w48000_48kHz", "10 min at 48 kHz, 1 s / 0.5 s (48000 / 24000): real-input split, six transforms of 4000 points", launches=5)
+    run_shape("big_32000", "w32000_32kHz", "10 min at 32 kHz, 1 s / 0.5 s (32000 / 16000): four transforms of 4000 points", launches=5)
     return out
 
 

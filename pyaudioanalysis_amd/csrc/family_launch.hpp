@@ -47,13 +47,15 @@ int blu(const blu::BluLayout &bl, size_t lds, int sample_kind, const PlanDev &P,
 // runs of consecutive frames, one workgroup walks runs b, b + grid, ...
 int wgr(int shape_id, int sample_kind, int mode, const PlanDev &P, const void *d_packed, const ClipDev *clips, const ClipNorm *norms,
         const Tile *runs, long long n_runs, int num_cu, const wgr::WgrTab *d_tab, double *d_out, hipStream_t stream);
-// kernels_wgs.hpp: 12 x 3675- / 6 x 3675-sample windows (44 100, 22 050): real-input split, three register passes per sub-transform; `tasks`:
-// (frame, task type) records handed out through `counter` (zero at launch); magnitudes go to the frames' rows of `spec` (spectrogram plans: d_out),
-// the time-domain partials of a frame to `tfeat`, the units' sum X / sum (k + 1) X / max X to `psum` (4 doubles per row and unit, r0 / 2 units)
-int wgs(int r0, int sample_kind, const PlanDev &P, const void *d_packed, const ClipDev *clips, const ClipNorm *norms, const wg::FrameRef *tasks,
-        int n_tasks, int *counter, int num_cu, double *spec, double *tfeat, double *psum, double *d_out, hipStream_t stream);
+// kernels_wgs.hpp: real-input split of the long even windows r0 x q samples (12 / 6 x 3675: 44 100, 22 050; 12 / 8 / 6 x 4000: 48 000, 32 000, 24 000),
+// three register passes per sub-transform; `tasks`: (frame, task type) records handed out through `counter` (zero at the first launch; the kernel
+// leaves it at zero); magnitudes go to the frames' UNIT-MAJOR rows of `spec` (spectrogram plans: d_out, natural order), the time-domain partials of
+// a frame to `tfeat`, the units' sum X / sum (k + 1) X / max X to `psum` (4 doubles per row and unit, r0 / 2 units)
+int wgs(int r0, int q, int sample_kind, const PlanDev &P, const void *d_packed, const ClipDev *clips, const ClipNorm *norms,
+        const wg::FrameRef *tasks, int n_tasks, int *counter, int num_cu, double *spec, double *tfeat, double *psum, double *d_out,
+        hipStream_t stream);
 // ... and the features of those frames from the unit-major rows (one workgroup per frame)
-int wgs_feat(int r0, const PlanDev &P, const wg::FrameRef *frames, int n_frames, const ClipDev *clips, const double *spec,
+int wgs_feat(int r0, int q, const PlanDev &P, const wg::FrameRef *frames, int n_frames, const ClipDev *clips, const double *spec,
              const double *tfeat, const double *psum, double *d_out, hipStream_t stream);
 // kernels_generic.hpp: Stockham passes in LDS (what is left)
 int generic(const GenLayout &gl, size_t lds, int sample_kind, const PlanDev &P, const unsigned char *blob,

@@ -36,24 +36,39 @@ namespace wgs {
                                    // 4 pass 2, 8 pass 3 + magnitudes, 16 the next task's touch; feature kernel: 32 sweep A, 64 sweep B, 128 roll-off, 256 mel, 512 chroma; 1024: no time-domain features in stage 0
 #endif
 constexpr int kAblate = PAA_WGS_ABLATE;
-constexpr int R1 = 7, R2 = 21, R3 = 25;
-constexpr int Q = R1 * R2 * R3;                 // 3675 points per unit
-constexpr int J1 = R2 * R3, J2 = R1 * R3, J3 = R1 * R2;      // 525 / 175 / 147 lane jobs
-constexpr int A = 535;                          // row pitch of the exchange buffer: element (k0, n1, n2) at k0 A + 25 n1 + n2 (scripts/dev/wgs_model.py
-                                                // --lds: every ds_read_b128 / ds_write_b128 of the three passes at the conflict-free count but the
-                                                // pass-3 reads, 450 LDS cycles against 250)
-constexpr int UNIT_ELEMS = R1 * A;              // 3745 double2
-constexpr int TU = 192, NT = 2 * TU;            // threads per unit / workgroup
-constexpr int NWV = NT / 64;                     // six waves
-constexpr int OFF_MISC = 2 * UNIT_ELEMS * 16;   // red [6][12] doubles (time domain: ten block energies, sign changes), next task
-constexpr int OFF_UP = OFF_MISC + NWV * 12 * 8 + 16;          // double [6][4]: the waves' parts of their unit's sum X, sum (k + 1) X, max X
-constexpr int LDS_BYTES = OFF_UP + NWV * 4 * 8;
-static_assert(LDS_BYTES <= 160 * 1024, "one workgroup's LDS");
-static_assert(5 + 12 * (J3 - 1 + J3 * (R3 / 2 - 1)) < 6 * Q && 12 * J3 * (R3 / 2 + 1) > 6 * Q && 2 + 6 * (J3 - 1 + J3 * (R3 / 2 - 1)) < 3 * Q &&
-              6 * J3 * (R3 / 2 + 1) > 3 * Q, "pass-3 outputs k2 < 12 are bins below W / 2, k2 > 12 mirrors");
-
-__device__ __forceinline__ int pos_of(int k) { return k + (A - J1) * (int)__umulhi((unsigned)k, 8181136u); }      // k / 525 for k < 2^16 (ceil(2^32 / 525))
-static_assert(((unsigned long long)8181136u * 525ull) >> 32 == 1 && ((unsigned long long)8181136u * 524ull) >> 32 == 0, "magic of 525");
+// first-pass codelets (run() transforms v[] in place, X[q] ends at v[pos(q)])
+template <int R> struct C1;
+template <> struct C1<7> {
+    static __device__ __forceinline__ void run(double2 *v) { mix::dft_prime<7>(v); }
+    static constexpr int pos(int q) { return q; }
+};
+template <> struct C1<8> {
+    static __device__ __forceinline__ void run(double2 *v) { tri::Cd<8>::run(v); }
+    static constexpr int pos(int q) { return tri::Cd<8>::pos(q); }
+};
+// A sub-transform of Q = R1 R2 R3 points.  A: row pitch of the exchange buffer, element (k0, n1, n2) at k0 A + R3 n1 + n2 (scripts/dev/wgs_model.py
+// lds ...: every ds_read_b128 / ds_write_b128 of the three passes at or near the conflict-free count); TU: threads per unit; pass 1: thread tu < J1T takes
+// the jobs tu, tu + J1T, ... (JPT of them); P2K0: pass-2 thread (k0, n2) = tu with n2 fastest (else k0 fastest)
+template <int R1_, int R2_, int R3_, int A_, int TU_, int JPT_, int J1T_, bool P2K0_>
+struct Shape {
+    static constexpr int R1 = R1_, R2 = R2_, R3 = R3_, A = A_, TU = TU_, JPT = JPT_, J1T = J1T_;
+    static constexpr bool P2K0 = P2K0_;
+    static constexpr int Q = R1 * R2 * R3;
+    static constexpr int J1 = R2 * R3, J2 = R1 * R3, J3 = R1 * R2;          // lane jobs of the three passes
+    static constexpr int UNIT_ELEMS = R1 * A;              // double2
+    static constexpr int NT = 2 * TU, NWV = NT / 64;
+    static constexpr int OFF_MISC = 2 * UNIT_ELEMS * 16;   // red [NWV][12] doubles (time domain: ten block energies, sign changes), next task
+    static constexpr int OFF_UP = OFF_MISC + NWV * 12 * 8 + 16;          // double [NWV][4]: the waves' parts of their unit's sum X, sum (k + 1) X, max X
+    static constexpr int LDS_BYTES = OFF_UP + NWV * 4 * 8;
+    static_assert(JPT * J1T == J1 && J1T <= TU && J2 <= TU && J3 <= TU && A >= J1 && TU % 64 == 0, "lane jobs");
+    static_assert(LDS_BYTES <= 160 * 1024, "one workgroup's LDS");
+    static_assert(R3 == 25, "pass 3 is the radix-25 codelet");
+    // pass-3 output k2 < R3 / 2 is a bin below W / 2 for every thread and q, k2 > R3 / 2 a mirror (kappa = u3 + J3 k2 against Q / 2)
+    static_assert(J3 - 1 + J3 * (R3 / 2 - 1) < Q / 2 - 1 && J3 * (R3 / 2 + 1) > Q / 2, "mirror split at k2 = R3 / 2");
+    static __device__ __forceinline__ int pos_of(int k) { return k + (A - J1) * (int)((unsigned)k / (unsigned)J1); }
+};
+typedef Shape<7, 21, 25, 535, 192, 3, 175, false> S3675;       // 44 100 = 12 x 3675, 22 050 = 6 x 3675
+typedef Shape<8, 20, 25, 500, 256, 2, 250, true> S4000;        // 48 000 = 12 x 4000, 32 000 = 8 x 4000, 24 000 = 6 x 4000
 
 __device__ __forceinline__ double2 csqr(double2 a) { return make_double2(fma(a.x, a.x, -a.y * a.y), 2.0 * (a.x * a.y)); }
 
@@ -72,8 +87,16 @@ __device__ __forceinline__ double2 split_dft(const N *s) {
     if constexpr (R0 == 6) {
         if constexpr (QQ == 1) { const N d0 = s[0] - s[3], d1 = s[1] - s[4], d2 = s[2] - s[5]; return dw6(D(d0), D(d1 - d2), D(d1 + d2)); }
         else { const N g0 = s[0] + s[3], g1 = s[1] + s[4], g2 = s[2] + s[5]; return dw3(D(g0), D(g1 + g2), D(g1 - g2)); }
+    } else if constexpr (R0 == 8) {
+        constexpr double h = 0.70710678118654752440;
+        if constexpr (QQ == 2) return make_double2(D((s[0] + s[4]) - (s[2] + s[6])), -D((s[1] + s[5]) - (s[3] + s[7])));
+        else {
+            const N o0 = s[0] - s[4], o1 = s[1] - s[5], o2 = s[2] - s[6], o3 = s[3] - s[7];
+            if constexpr (QQ == 1) return make_double2(fma(h, D(o1 - o3), D(o0)), -fma(h, D(o1 + o3), D(o2)));
+            else return make_double2(fma(-h, D(o1 - o3), D(o0)), fma(-h, D(o1 + o3), D(o2)));
+        }
     } else {
-        static_assert(R0 == 12, "r0 = 6 or 12");
+        static_assert(R0 == 12, "r0 = 6, 8 or 12");
         if constexpr (QQ == 2) {
             const N d0 = (s[0] + s[6]) - (s[3] + s[9]), d1 = (s[1] + s[7]) - (s[4] + s[10]), d2 = (s[2] + s[8]) - (s[5] + s[11]);
             return dw6(D(d0), D(d1 - d2), D(d1 + d2));
@@ -114,16 +137,19 @@ __device__ __forceinline__ double2 cpow(double2 w) {
 
 // task types (FrameRef::halo >> 8).  R0 = 12: 0 = units {1, 2} (+ the time-domain features), 1 = {3, 4}, 2 = {5, packed};
 // R0 = 6: 0 = {1, 2} (+ time domain), 1 = {packed} (the first three waves idle)
-template <int R0> __host__ __device__ constexpr int task_types() { return R0 == 12 ? 3 : 2; }
+template <int R0> __host__ __device__ constexpr int task_types() { return R0 == 12 ? 3 : 2; }          // (R0 = 8: {1, 2}, {3, packed})
 
-template <typename T, int R0>
-__global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict__ sig, const ClipDev *__restrict__ clips,
+template <typename T, int R0, typename SH>
+__global__ __launch_bounds__(SH::NT) void wgs_kernel(PlanDev P, const T *__restrict__ sig, const ClipDev *__restrict__ clips,
                                                  const ClipNorm *__restrict__ norms, const wg::FrameRef *__restrict__ tasks, int n_tasks,
                                                  int *next_task, double *__restrict__ spec, double *__restrict__ tfeat,
                                                  double *__restrict__ psum, double *__restrict__ out) {
+    constexpr int R1 = SH::R1, R2 = SH::R2, R3 = SH::R3, Q = SH::Q, J2 = SH::J2, J3 = SH::J3, A = SH::A, TU = SH::TU, NT = SH::NT;
+    constexpr int NWV = SH::NWV, UNIT_ELEMS = SH::UNIT_ELEMS, OFF_MISC = SH::OFF_MISC, OFF_UP = SH::OFF_UP, JPT = SH::JPT, J1T = SH::J1T;
+    auto pos_of = [](int k) { return SH::pos_of(k); };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double2 *buf_all = reinterpret_cast<double2 *>(smem);
-    double *red = reinterpret_cast<double *>(smem + OFF_MISC);          // [6][12]
+    double *red = reinterpret_cast<double *>(smem + OFF_MISC);          // [NWV][12]
     int *s_next = reinterpret_cast<int *>(smem + OFF_MISC + NWV * 12 * 8);
     double *upart = reinterpret_cast<double *>(smem + OFF_UP);
     const int tid_ = threadIdx.x, lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
@@ -158,11 +184,12 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
         if (tid_ < 2) {
             const int un = tid_ == 0 ? ua : ub;
             if (un >= 0) {
-                const double *u = upart + 12 * tid_;
+                const double *u = upart + 4 * (TU / 64) * tid_;
                 double *d = psum + ((long long)rw * H0 + un) * 4;
-                d[0] = (u[0] + u[4]) + u[8];
-                d[1] = (u[1] + u[5]) + u[9];
-                d[2] = fmax(fmax(u[2], u[6]), u[10]);
+                double a0 = u[0], a1 = u[1], a2 = u[2];
+#pragma unroll
+                for (int w = 1; w < TU / 64; ++w) { a0 += u[4 * w]; a1 += u[4 * w + 1]; a2 = fmax(a2, u[4 * w + 2]); }
+                d[0] = a0; d[1] = a1; d[2] = a2;
             }
         }
     };
@@ -210,7 +237,8 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
                 // rounds are requested TOGETHER (one exposed memory latency per batch instead of one per round: 71 of the kernel's 182 us were
                 // this stage with two rounds in flight), then the rounds are worked off in order
                 constexpr int NI = (Q + NT - 1) / NT;
-                constexpr int BI = INT_T ? 5 : ((TIME || QB == 0) ? 2 : 5);
+                constexpr int B5 = (NI % 5 == 0) ? 5 : 4;
+                constexpr int BI = INT_T ? B5 : ((TIME || QB == 0) ? 2 : B5);
                 static_assert(NI % BI == 0, "whole batches");
                 auto batch = [&](const int ib) {
                     N sa[BI][R0];
@@ -351,6 +379,8 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
             } else if constexpr (R0 == 12) {
                 if (type == 1) stage0(std::integral_constant<int, 3>(), std::integral_constant<int, 4>(), std::false_type());
                 else stage0(std::integral_constant<int, 5>(), I0(), std::false_type());
+            } else if constexpr (R0 == 8) {
+                stage0(std::integral_constant<int, 3>(), I0(), std::false_type());
             } else {
                 stage0(I0(), I0(), std::false_type());
             }
@@ -370,37 +400,35 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
             }
         }
         const bool u_on = unit == 1 || a_on;
-        // ---------------- pass 1: radix 7 over n0 for the jobs j = tu, tu + 175, tu + 350; outputs times W_Q^(j k0); in place
-        if (u_on && tu < J2 && !(kAblate & 2)) {
-            double2 v[3][R1];
-            double2 w[3];
+        // ---------------- pass 1: radix R1 over n0 for the jobs j = tu, tu + J1T, ...; outputs times W_Q^(j k0); in place
+        if (u_on && tu < J1T && !(kAblate & 2)) {
+            double2 v[JPT][R1];
+            double2 w[JPT];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int j = tu + J2 * s;
+            for (int s = 0; s < JPT; ++s) {
+                const int j = tu + J1T * s;
                 w[s] = P.tw[H0 * j];
 #pragma unroll
                 for (int n0 = 0; n0 < R1; ++n0) v[s][n0] = buf[n0 * A + j];
             }
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int j = tu + J2 * s;
-                mix::dft_prime<R1>(v[s]);
-                const double2 w2 = csqr(w[s]), w3 = cmul(w2, w[s]);
-                const double2 w4 = csqr(w2), w5 = cmul(w3, w2), w6 = csqr(w3);
-                buf[j] = v[s][0];
-                buf[A + j] = cmul(v[s][1], w[s]);
-                buf[2 * A + j] = cmul(v[s][2], w2);
-                buf[3 * A + j] = cmul(v[s][3], w3);
-                buf[4 * A + j] = cmul(v[s][4], w4);
-                buf[5 * A + j] = cmul(v[s][5], w5);
-                buf[6 * A + j] = cmul(v[s][6], w6);
+            for (int s = 0; s < JPT; ++s) {
+                const int j = tu + J1T * s;
+                C1<R1>::run(v[s]);
+                double2 t = w[s];
+                buf[j] = v[s][C1<R1>::pos(0)];
+#pragma unroll
+                for (int k0 = 1; k0 < R1; ++k0) {          // W^k0: W, W^2, W^3 = W^2 W, ... (at most R1 - 2 multiplications deep)
+                    buf[k0 * A + j] = cmul(v[s][C1<R1>::pos(k0)], t);
+                    if (k0 + 1 < R1) t = (k0 == 1) ? csqr(w[s]) : cmul(t, w[s]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
-        // ---------------- pass 2: thread (n2, k0) = tu: radix 21 over n1, outputs times W_525^(n2 k1) = W_Q^(7 n2 k1); in place
+        // ---------------- pass 2: thread (n2, k0) = tu: radix R2 over n1, outputs times W_(R2 R3)^(n2 k1) = W_Q^(R1 n2 k1); in place
         if (u_on && tu < J2 && !(kAblate & 4)) {
-            const int n2 = tu / R1, k0 = tu - n2 * R1;
+            const int n2 = SH::P2K0 ? tu % R3 : tu / R1, k0 = SH::P2K0 ? tu / R3 : tu % R1;
             double2 *e = buf + k0 * A + n2;
             const double2 w = P.tw[H0 * R1 * n2];
             double2 v[R2];
@@ -449,7 +477,7 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
             const bool packed_unit = packed_task && unit == 1;
             double us = 0.0, uw = 0.0, um = 0.0;          // this thread's part of its unit's sum X, sum (k + 1) X, max X
             if (!packed_unit) {
-                const int q = (R0 == 12) ? 2 * type + 1 + unit : 1 + unit;
+                const int q = 2 * type + 1 + unit;
                 if (P.mode == 1) {
                     // spectrogram rows go straight to the output, natural order: bin q + R0 kappa, or its mirror W - (q + R0 kappa)
                     if (a3) {
@@ -491,8 +519,8 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
                 }
                 __syncthreads();
                 if (packed_unit) {
-                    // pairs (j, Q - j), j = 1 .. (Q - 1) / 2, and j = 0: X[H0 j] = E + w^j O, X[H0 (Q - j)] = conj(E - w^j O); X[0] = Re V[0] + Im V[0]
-                    constexpr int NP = (Q - 1) / 2 + 1;
+                    // pairs (j, Q - j), j = 1 .. Q / 2, and j = 0: X[H0 j] = E + w^j O, X[H0 (Q - j)] = conj(E - w^j O); X[0] = Re V[0] + Im V[0]
+                    constexpr int NP = Q / 2 + 1;          // (even Q: j = Q / 2 pairs with itself)
                     const bool nat = P.mode == 1;
                     double *rp = nat ? row : row + (H0 - 1) * Q;          // unit-major: |X[H0 j]| at (H0 - 1) Q + j
                     const int st = nat ? H0 : 1;
@@ -509,12 +537,13 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
                         const double ar = e.x + wo.x, ai = e.y + wo.y, br = e.x - wo.x, bi = e.y - wo.y;
                         if (in) {
                             const double ma = mag_sqrt(fma(ar, ar, ai * ai)) * invNf;
-                            const double mb = (j > 0) ? mag_sqrt(fma(br, br, bi * bi)) * invNf : 0.0;
+                            const bool two = j > 0 && Q - j != j;
+                            const double mb = two ? mag_sqrt(fma(br, br, bi * bi)) * invNf : 0.0;
                             rp[st * j] = ma;
-                            if (j > 0) rp[st * (Q - j)] = mb;
+                            if (two) rp[st * (Q - j)] = mb;
                             us += ma + mb;
                             uw = fma((double)(H0 * j + 1), ma, uw);
-                            uw = fma((j > 0) ? (double)(H0 * (Q - j) + 1) : 0.0, mb, uw);
+                            uw = fma(two ? (double)(H0 * (Q - j) + 1) : 0.0, mb, uw);
                             um = fmax(um, fmax(ma, mb));
                         }
                     }
@@ -524,8 +553,8 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
                 us = wsum(us); uw = wsum(uw); um = wmax_nonneg(um);
                 if (lane == 0) { upart[4 * wave] = us; upart[4 * wave + 1] = uw; upart[4 * wave + 2] = um; }
                 flush_row = cu.row;
-                flush_ua = a_on ? ((R0 == 12) ? 2 * type : 0) : -1;          // unit index of q = 2 type + 1 (R0 = 6: q = 1)
-                flush_ub = packed_task ? H0 - 1 : ((R0 == 12) ? 2 * type + 1 : 1);
+                flush_ua = a_on ? 2 * type : -1;          // unit index of q = 2 type + 1
+                flush_ub = packed_task ? H0 - 1 : 2 * type + 1;
             }
         }
         cu = cu_next;
@@ -545,30 +574,17 @@ __global__ __launch_bounds__(NT) void wgs_kernel(PlanDev P, const T *__restrict_
 }
 
 // ---- features of one frame from its UNIT-MAJOR row (and the previous frame's) -- kernels_wg.hpp's wg_feat_kernel for the rows above.
-// bin of row element idx: unit u = idx / Q (complex unit q = u + 1 for u < R0/2 - 1: bin q + R0 kappa or its mirror; last unit: bin (R0/2) kappa)
-template <int R0>
-__device__ __forceinline__ int bin_of(int idx) {
-    constexpr int H0 = R0 / 2, W = R0 * Q, NF = W / 2;
-    const int u = (int)__umulhi((unsigned)idx, 1168734u);          // idx / 3675 for idx < 2^16 (ceil(2^32 / 3675) = 1168734)
-    const int kap = idx - u * Q;
-    const int mm = (u + 1) + R0 * kap;
-    return (u == H0 - 1) ? H0 * kap : (mm < NF ? mm : W - mm);
-}
-static_assert(((unsigned long long)1168734u * 3675ull) >> 32 == 1 && ((unsigned long long)1168734u * 3674ull) >> 32 == 0 &&
-              ((unsigned long long)1168734u * 22049ull) >> 32 == 5, "magic of 3675");
-// ... and the row element that holds bin k
-template <int R0>
+// the row element that holds bin k: complex unit q = 1 .. R0/2 - 1 delivers the bins q + R0 kappa (kappa < Q) and, as mirrors, the bins
+// R0 - q + R0 (Q - 1 - kappa); the last unit the bins (R0 / 2) j
+template <int R0, int Q>
 __device__ __forceinline__ int idx_of(int k) {
     constexpr int H0 = R0 / 2;
-    const int kr = (R0 == 12) ? (int)__umulhi((unsigned)k, 357913942u) : (int)__umulhi((unsigned)k, 715827883u);          // k / R0 for k < 2^16
+    const int kr = (int)((unsigned)k / (unsigned)R0);
     const int rho = k - kr * R0;
     if (rho == 0) return (H0 - 1) * Q + 2 * kr;
     if (rho == H0) return (H0 - 1) * Q + 2 * kr + 1;
     return rho < H0 ? (rho - 1) * Q + kr : (R0 - rho - 1) * Q + Q - 1 - kr;
 }
-static_assert(((unsigned long long)357913942u * 12ull) >> 32 == 1 && ((unsigned long long)357913942u * 11ull) >> 32 == 0 &&
-              ((unsigned long long)357913942u * 22049ull) >> 32 == 1837 && ((unsigned long long)715827883u * 6ull) >> 32 == 1 &&
-              ((unsigned long long)715827883u * 5ull) >> 32 == 0 && ((unsigned long long)715827883u * 11024ull) >> 32 == 1837, "magics of 12 and 6");
 
 // The row is read as STREAMS whose elements are R0 (or R0 / 2) bins apart: residue stream rho (rho = 1 .. R0 - 1, rho != R0 / 2) = the bins
 // rho + R0 n -- unit rho read forwards, or unit R0 - rho read backwards (its mirrored half) --, and the packed unit's bins (R0 / 2) n.  64
@@ -580,7 +596,7 @@ static_assert(((unsigned long long)357913942u * 12ull) >> 32 == 1 && ((unsigned 
 // one round of workgroups instead of three.
 constexpr int kFeatT = 512, kFeatW = kFeatT / 64;
 constexpr int LCAP = 4096;                          // bins below LCAP are also kept in LDS, natural order (the mel filters' range for the usual rates)
-template <int R0> struct FeatGeo {
+template <int R0, int Q> struct FeatGeo {
     static constexpr int NF = R0 * Q / 2, SPB = R0, BLK = 64 * R0, NBLK = (NF + BLK - 1) / BLK, NIT = NBLK * SPB;
     static constexpr int OFF_SLOT_E = LCAP * 8;                           // double [NBLK]: the natural blocks' energies
     static constexpr int OFF_FINE = OFF_SLOT_E + 64 * 8;                  // double [BLK]: the squares of the block that holds the roll-off bin
@@ -588,7 +604,7 @@ template <int R0> struct FeatGeo {
     static constexpr int LDS = OFF_SMALL + (48 + 40 + kFeatW * 16 + kFeatW) * 8 + (kFeatW + 2) * 4 + 8;
     static_assert(NBLK <= 64, "one lane per natural block");
 };
-template <int R0> constexpr int feat_lds() { return (FeatGeo<R0>::LDS + 15) / 16 * 16; }
+template <int R0, int Q> constexpr int feat_lds() { return (FeatGeo<R0, Q>::LDS + 15) / 16 * 16; }
 
 __device__ __forceinline__ double bsum8(double v, double *slot, int lane, int wave) {
     v = wsum(v);
@@ -599,11 +615,11 @@ __device__ __forceinline__ double bsum8(double v, double *slot, int lane, int wa
     return r;
 }
 
-template <int R0>
+template <int R0, int Q>
 __global__ __launch_bounds__(kFeatT, 2) void wgs_feat_kernel(PlanDev P, const wg::FrameRef *__restrict__ frames, const ClipDev *__restrict__ clips,
                                                              int n_frames, const double *__restrict__ spec, const double *__restrict__ tfeat,
                                                              const double *__restrict__ psum, double *__restrict__ out) {
-    typedef FeatGeo<R0> G;
+    typedef FeatGeo<R0, Q> G;
     constexpr int NF = G::NF, W = R0 * Q, H0 = R0 / 2, SPB = G::SPB, NBLK = G::NBLK, NIT = G::NIT, BLK = G::BLK;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // XCD-aware: workgroup b runs on XCD b % 8 and takes frame (b % 8) per + b / 8 (grid = 8 per): the workgroups that run side by side on an XCD
@@ -625,7 +641,7 @@ __global__ __launch_bounds__(kFeatT, 2) void wgs_feat_kernel(PlanDev P, const wg
     int *redi = reinterpret_cast<int *>(slot + kFeatW);      // [kFeatW + 2]
     const double *gc = spec + (long long)fr.row * NF;
     const double *prv = (fr.t == 0) ? gc : gc - NF;          // frames are laid out in clip order: the previous frame is the previous row
-    auto X = [&](int k) -> double { return k < LCAP ? low[k] : gc[idx_of<R0>(k)]; };
+    auto X = [&](int k) -> double { return k < LCAP ? low[k] : gc[idx_of<R0, Q>(k)]; };
     double *oc = out + c.out_off;
     const long long Tc = c.T;
     const Tabs tb = tabs_global(P);
@@ -763,7 +779,7 @@ __global__ __launch_bounds__(kFeatT, 2) void wgs_feat_kernel(PlanDev P, const wg
         if (jc != 0x7fffffff) {
             for (int t = tid; t < BLK; t += kFeatT) {
                 const int k = BLK * jc + t;
-                const double xv = (k < NF) ? gc[idx_of<R0>(k)] : 0.0;
+                const double xv = (k < NF) ? gc[idx_of<R0, Q>(k)] : 0.0;
                 fine[t] = xv * xv;
             }
         }
@@ -866,8 +882,17 @@ __global__ __launch_bounds__(kFeatT, 2) void wgs_feat_kernel(PlanDev P, const wg
 }
 
 // ---- host -------------------------------------------------------------------------------------------------------------------------
-// r0 of a window this family takes (0: none)
-inline int wgs_r0(int window) { return window == 12 * Q ? 12 : (window == 6 * Q ? 6 : 0); }
+// (r0, points per sub-transform) of a window this family takes; r0 = 0: none
+struct Sel { int r0, q; };
+inline Sel wgs_select(int window) {
+    if (window == 12 * S3675::Q) return {12, S3675::Q};          // 44 100: 1 s at 44.1 kHz
+    if (window == 6 * S3675::Q) return {6, S3675::Q};            // 22 050: 1 s at 22.05 kHz, 0.5 s at 44.1 kHz
+    if (window == 12 * S4000::Q) return {12, S4000::Q};          // 48 000: 1 s at 48 kHz
+    if (window == 8 * S4000::Q) return {8, S4000::Q};            // 32 000: 1 s at 32 kHz
+    if (window == 6 * S4000::Q) return {6, S4000::Q};            // 24 000: 1 s at 24 kHz, 0.5 s at 48 kHz
+    return {0, 0};
+}
+inline int wgs_task_types(int r0) { return r0 == 12 ? task_types<12>() : (r0 == 8 ? task_types<8>() : task_types<6>()); }
 
 }  // namespace wgs
 }  // namespace paa

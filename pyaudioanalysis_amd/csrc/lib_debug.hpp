@@ -219,19 +219,26 @@ extern "C" int paa_debug_wg_plan(int window, int32_t *info32, uint16_t *perm, in
 // wgs::bin_of)
 extern "C" int paa_debug_wgs_plan(int window, int32_t *info16, int32_t *bin_of, int capacity) {
     if (window < 2 || !info16) return fail(PAA_ERR_ARG, "bad argument");
-    const int r0 = wgs::wgs_r0(window);
+    const wgs::Sel sel = wgs::wgs_select(window);
+    const int r0 = sel.r0, q = sel.q;
     if (!r0) return 0;
     memset(info16, 0, 16 * sizeof(int32_t));
     const int nf = window / 2;
-    info16[0] = r0; info16[1] = wgs::Q; info16[2] = wgs::R1; info16[3] = wgs::R2; info16[4] = wgs::R3; info16[5] = wgs::A;
-    info16[6] = wgs::NT; info16[7] = wgs::LDS_BYTES; info16[8] = r0 == 12 ? wgs::task_types<12>() : wgs::task_types<6>();
-    info16[9] = wgs::LCAP; info16[10] = r0 == 12 ? wgs::feat_lds<12>() : wgs::feat_lds<6>();
-    info16[11] = r0 == 12 ? wgs::FeatGeo<12>::NBLK : wgs::FeatGeo<6>::NBLK; info16[12] = wgs::kFeatT;
+    const bool a = q == wgs::S3675::Q;
+    info16[0] = r0; info16[1] = q;
+    info16[2] = a ? wgs::S3675::R1 : wgs::S4000::R1; info16[3] = a ? wgs::S3675::R2 : wgs::S4000::R2; info16[4] = a ? wgs::S3675::R3 : wgs::S4000::R3;
+    info16[5] = a ? wgs::S3675::A : wgs::S4000::A; info16[6] = a ? wgs::S3675::NT : wgs::S4000::NT;
+    info16[7] = a ? wgs::S3675::LDS_BYTES : wgs::S4000::LDS_BYTES; info16[8] = wgs::wgs_task_types(r0);
+    info16[9] = wgs::LCAP;
+    info16[10] = a ? (r0 == 12 ? wgs::feat_lds<12, wgs::S3675::Q>() : wgs::feat_lds<6, wgs::S3675::Q>())
+                   : (r0 == 12 ? wgs::feat_lds<12, wgs::S4000::Q>() : (r0 == 8 ? wgs::feat_lds<8, wgs::S4000::Q>() : wgs::feat_lds<6, wgs::S4000::Q>()));
+    info16[11] = (nf + 64 * r0 - 1) / (64 * r0); info16[12] = wgs::kFeatT;
+    info16[13] = a ? (wgs::S3675::P2K0 ? 1 : 0) : (wgs::S4000::P2K0 ? 1 : 0);
     if (bin_of) {
         if (capacity < nf) return fail(PAA_ERR_ARG, "capacity %d < %d", capacity, nf);
         const int h0 = r0 / 2;
         for (int idx = 0; idx < nf; ++idx) {
-            const int u = idx / wgs::Q, kap = idx % wgs::Q, mm = (u + 1) + r0 * kap;
+            const int u = idx / q, kap = idx % q, mm = (u + 1) + r0 * kap;
             bin_of[idx] = (u == h0 - 1) ? h0 * kap : (mm < nf ? mm : window - mm);
         }
     }

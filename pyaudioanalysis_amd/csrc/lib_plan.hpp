@@ -161,7 +161,7 @@ struct paa_plan {
     wg::FrameRef *d_wg_tasks = nullptr;
     unsigned short *d_wg_perm = nullptr;
     long long wg_rows = 0;           // spectrum rows of the largest chunk
-    int wgs_r0 = 0;                  // 12 / 6: the split runs on kernels_wgs.hpp (44 100- / 22 050-sample windows): wg_tasks holds (frame, task type) records
+    int wgs_r0 = 0, wgs_q = 0;       // r0 > 0: the split runs on kernels_wgs.hpp (r0 x q samples: 44 100, 22 050, 48 000, 32 000, 24 000): wg_tasks holds (frame, task type) records
     int wgr = 0;                     // > 0: shape id of the fused three-pass kernel (kernels_wgr.hpp): 16 000- / 8 000-sample windows
     std::vector<Tile> wgr_runs;      // runs of consecutive frames, about one per CU
     Tile *d_wgr_runs = nullptr;
@@ -407,10 +407,11 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
                 for (long long i = ch.first; i < ch.second; ++i) p->wg_frames[(size_t)i].row = (int)(i - ch.first);
             }
             if ((rc = upload_pooled(&p->d_wg_frames, p->wg_frames.data(), std::max<size_t>(p->wg_frames.size(), 1)))) return rc;
-            if (p->wl.r0 && wgs::wgs_r0(window)) {
+            if (p->wl.r0 && wgs::wgs_select(window).r0) {
                 // the real-input split on register passes (kernels_wgs.hpp): the tasks of a frame side by side (FrameRef::halo = halo | type << 8)
-                p->wgs_r0 = wgs::wgs_r0(window);
-                const int n_types = p->wgs_r0 == 12 ? wgs::task_types<12>() : wgs::task_types<6>();
+                p->wgs_r0 = wgs::wgs_select(window).r0;
+                p->wgs_q = wgs::wgs_select(window).q;
+                const int n_types = wgs::wgs_task_types(p->wgs_r0);
                 for (auto &ch : p->wg_chunks) {
                     const long long t0 = (long long)p->wg_tasks.size();
                     for (long long i = ch.first; i < ch.second; ++i)
@@ -444,7 +445,7 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
             }
             if ((rc = upload_pooled(&p->d_wg_perm, perm.data(), perm.size()))) return rc;
             p->wg = 1;
-            p->kernel_name = p->wgs_r0 ? std::string(mode == 0 ? "st" : (mode == 1 ? "spectrogram" : "chromagram")) + "_wgs_" + std::to_string(p->wgs_r0) + "x3675"
+            p->kernel_name = p->wgs_r0 ? std::string(mode == 0 ? "st" : (mode == 1 ? "spectrogram" : "chromagram")) + "_wgs_" + std::to_string(p->wgs_r0) + "x" + std::to_string(p->wgs_q)
                            : p->wl.r0 ? ((mode == 0) ? "st_wg_split_fft" : (mode == 1 ? "spectrogram_wg_split_fft" : "chromagram_wg_split_fft"))
                                       : ((mode == 0) ? "st_wg_lds_fft" : (mode == 1 ? "spectrogram_wg_lds_fft" : "chromagram_wg_lds_fft"));
         }
@@ -626,7 +627,7 @@ static int run_wg(paa_plan *p, const void *d_packed, double *d_out) {
             const unsigned grid = std::min<unsigned>(nt, (unsigned)g_num_cu);
             if (!p->wgs_r0) HIP_TRY(hipMemsetAsync(task_counter, 0, sizeof(int), cs()));
             if (p->wgs_r0) {
-                if (launch::wgs(p->wgs_r0, p->sample_kind, P, d_packed, p->d_clips, p->d_norms, tk, (int)nt, task_counter, g_num_cu, spec, tfeat, psum, d_out, cs()))
+                if (launch::wgs(p->wgs_r0, p->wgs_q, p->sample_kind, P, d_packed, p->d_clips, p->d_norms, tk, (int)nt, task_counter, g_num_cu, spec, tfeat, psum, d_out, cs()))
                     return fail(PAA_ERR_HIP, "launch of %s failed: %s", p->kernel_name.c_str(), hipGetErrorString(hipGetLastError()));
             } else if (p->wl.threads == 768)
                 hipLaunchKernelGGL((wg::wg_split_kernel<T, 768>), dim3(grid), dim3(768), (size_t)p->wl.lds_bytes, cs(), P, p->wl,
@@ -651,7 +652,7 @@ static int run_wg(paa_plan *p, const void *d_packed, double *d_out) {
         if (prof_scope.stop) { (void)hipEventRecord(prof_scope.stop, cs()); prof_scope.stop = nullptr; }
         }
         if (P.mode != 1 && p->wgs_r0) {
-            if (launch::wgs_feat(p->wgs_r0, P, fr, (int)n, p->d_clips, spec, tfeat, psum, d_out, cs()))
+            if (launch::wgs_feat(p->wgs_r0, p->wgs_q, P, fr, (int)n, p->d_clips, spec, tfeat, psum, d_out, cs()))
                 return fail(PAA_ERR_HIP, "launch of the feature kernel of %s failed: %s", p->kernel_name.c_str(), hipGetErrorString(hipGetLastError()));
         } else if (P.mode != 1) {
             if (p->wl.feat_staged)

@@ -217,11 +217,11 @@ def test_run_length_choice_for_the_baseline_batches():
             assert wgs <= 256 and longest.value <= 256
 
 
-@pytest.mark.parametrize("window", [44100, 22050])
+@pytest.mark.parametrize("window", [44100, 22050, 48000, 32000, 24000])
 def test_real_input_split_plan_reproduces_the_spectrum(window):
-    """Host side of csrc/kernels_wgs.hpp (no device): the REAL-INPUT split of a 12 x 3675- / 6 x 3675-sample window into r0 / 2 independent
-    transforms of 3675 complex points -- complex unit q: a_q[k] = W_W^(q k) sum_r y[k + Q r] W_r0^(r q) in the kernel's difference form, the
-    packed unit from the sums over the even / odd samples --, each as three IN-PLACE register passes 7 x 21 x 25 over the padded exchange
+    """Host side of csrc/kernels_wgs.hpp (no device): the REAL-INPUT split of a window of r0 x Q samples (12 / 6 x 3675, 12 / 8 / 6 x 4000) into
+    r0 / 2 independent transforms of Q complex points -- complex unit q: a_q[k] = W_W^(q k) sum_r y[k + Q r] W_r0^(r q) in the kernel's difference form, the
+    packed unit from the sums over the even / odd samples --, each as three IN-PLACE register passes (7 x 21 x 25 / 8 x 20 x 25) over the padded exchange
     buffer, and the UNIT-MAJOR spectrum row with the library's own bin map: restated in NumPy from the library's constants this gives
     |fft(frame)|[0:W/2] / (W/2), every bin written exactly once (ShortTermFeatures.py:617-621); a constant frame gives exact zeros in every
     complex unit's input (the exact spectrum of a digitally silent frame)."""
@@ -248,11 +248,19 @@ def test_real_input_split_plan_reproduces_the_spectrum(window):
     H0, J1 = r0 // 2, R2 * R3
     rng = np.random.default_rng(window)
     x = rng.standard_normal(window)
-    pos = lambda k: k + (A - J1) * (k // J1)                                # element k of a unit sits at k + 10 (k / 525)
+    pos = lambda k: k + (A - J1) * (k // J1)                                # element k of a unit sits at k + (A - R2 R3) (k / (R2 R3))
     S60 = np.sqrt(3.0) / 2
 
     def split_dft(s, q):
         """wgs::split_dft: the DFT over r of s[r] = y[k + Q r] at q, from sums and differences"""
+        if r0 == 8:
+            h = np.sqrt(0.5)
+            if q == 2:
+                return ((s[0] + s[4]) - (s[2] + s[6])) + 1j * (-((s[1] + s[5]) - (s[3] + s[7])))
+            o = s[0:4] - s[4:8]
+            if q == 1:
+                return (o[0] + h * (o[1] - o[3])) + 1j * (-(o[2] + h * (o[1] + o[3])))
+            return (o[0] - h * (o[1] - o[3])) + 1j * (o[2] - h * (o[1] + o[3]))
         if r0 == 6:
             if q == 1:
                 d = s[0:3] - s[3:6]

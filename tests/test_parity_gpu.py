@@ -404,8 +404,9 @@ def test_big_window_kernel_choice(gpu_lib):
     assert name(44100, 44100, 22050) == "st_wgs_12x3675"               # 1 s at 44.1 kHz: real-input split, 6 independent transforms of 3675 points on register passes (kernels_wgs.hpp)
     assert name(22050, 22050, 11025, mode=1) == "spectrogram_wgs_6x3675"   # 1 s at 22.05 kHz: 3 of them
     assert name(44100, 22050, 11025, mode=2) == "chromagram_wgs_6x3675"
-    assert name(32000, 32000, 16000) == "st_wg_split_fft"              # 16 000 complex points: the packed split of round 5 (4 x 4000)
-    assert name(48000, 48000, 24000, mode=1) == "spectrogram_wg_split_fft"     # 24 000 points: 6 x 4000
+    assert name(32000, 32000, 16000) == "st_wgs_8x4000"                # 1 s at 32 kHz: 4 transforms of 4000 points (8 x 20 x 25)
+    assert name(48000, 24000, 12000) == "st_wgs_6x4000"                # 0.5 s at 48 kHz
+    assert name(48000, 48000, 24000, mode=1) == "spectrogram_wgs_12x4000"      # 1 s at 48 kHz: 6 transforms of 4000 points
     assert name(44100, 11025, 5000, mode=2) == "chromagram_wg_split_fft"       # odd: 11 025 real points, 3 x 3675
     assert name(16000, 65536, 32768) == "st_wg_split_fft"              # the largest table: 32 768 points = 8 x 4096
     assert name(16000, 80000, 40000) == "big_window_hbm_passes"        # 40 000 points: beyond the two-level twiddle table

@@ -32,7 +32,9 @@ def test_plans_dispatch_the_real_input_split(gpu_lib):
     assert kernel_name(44100, 22050, 11025, kind=2, mode=1) == "spectrogram_wgs_6x3675"        # 0.5 s at 44.1 kHz
     assert kernel_name(48000, 44100, 22050) == "st_wgs_12x3675"                                # any sampling rate: the tables are per (fs, window)
     assert kernel_name(44100, 44102, 22050) != "st_wgs_12x3675"                                # neighbours keep their kernels
-    assert kernel_name(48000, 48000, 24000) == "st_wg_split_fft"
+    assert kernel_name(48000, 48000, 24000) == "st_wgs_12x4000"                                # 8 x 20 x 25 points per sub-transform
+    assert kernel_name(32000, 32000, 16000, kind=2, mode=2) == "chromagram_wgs_8x4000"
+    assert kernel_name(24000, 24000, 12000, kind=1) == "st_wgs_6x4000"
 
 
 @pytest.mark.parametrize("kind,fs,window,step,seconds,deltas", [
@@ -45,6 +47,14 @@ def test_plans_dispatch_the_real_input_split(gpu_lib):
     ("unit", 44100, 44100, 22050, 4.0, False),       # a float signal in [-1, 1]
     ("i16", 32000, 44100, 22050, 5.0, False),        # the window at another sampling rate: other mel / chroma tables
     ("i16", 44100, 22050, 11025, 5.0, True),         # 0.5 s at 44.1 kHz
+    ("i16", 48000, 48000, 24000, 7.0, True),         # 12 x 4000: sub-transforms of 8 x 20 x 25 points
+    ("stereo", 48000, 48000, 48000, 5.0, False),
+    ("f64", 48000, 48000, 20000, 4.0, False),
+    ("i16", 32000, 32000, 16000, 7.0, True),         # 8 x 4000: tasks {1,2} {3,packed}
+    ("stereo", 32000, 32000, 9000, 4.0, False),
+    ("f64", 32000, 32000, 32000, 5.0, True),
+    ("i16", 24000, 24000, 12000, 6.0, True),         # 6 x 4000
+    ("f64", 48000, 24000, 12000, 3.0, False),
 ])
 def test_full_matrix_against_oracle(gpu_lib, kind, fs, window, step, seconds, deltas):
     sig, mono = make_signal(kind, 8800 + window + step, seconds, fs)
@@ -59,7 +69,8 @@ def test_full_matrix_against_oracle(gpu_lib, kind, fs, window, step, seconds, de
 
 
 @pytest.mark.parametrize("kind,fs,window,step", [("i16", 44100, 44100, 22050), ("stereo", 44100, 44100, 17000), ("f64", 22050, 22050, 11025),
-                                                  ("stereo", 22050, 22050, 22050)])
+                                                  ("stereo", 22050, 22050, 22050), ("i16", 48000, 48000, 24000), ("stereo", 32000, 32000, 16000),
+                                                  ("f64", 24000, 24000, 7000)])
 def test_spectrogram_and_chromagram_rows(gpu_lib, capsys, kind, fs, window, step):
     """Spectrogram rows go to the output in natural order straight from the transform kernel; chromagram rows come from the unit-major
     scratch rows; the chromagram's truncated tail frame (the reference FFTs what is left, :349-355) keeps its own kernel."""
