@@ -12,8 +12,8 @@
 //   r0 / 2 units of equal cost per frame, NONE needs another one's outputs.  (scripts/dev/wgs_model.py restates this in NumPy.)
 //
 //   A TASK is one frame and two units -- {1, 2}, {3, 4}, {5, packed} for r0 = 12; {1, 2}, {packed} for r0 = 6 -- handled by a workgroup of
-//   384 threads, three waves per unit; persistent workgroups take tasks from a counter.
-//   stage 0 : all threads: k = tid + 384 i: the r0 samples y[k + Q r] (one coalesced 2-byte load per r), normalised (:567-570); the DFT over r
+//   512 threads, four waves per unit (passes 2 and 3 use three of them); persistent workgroups take tasks from a counter.
+//   stage 0 : all threads: k = tid + 512 i: the r0 samples y[k + Q r] (one coalesced 2-byte load per r), normalised (:567-570); the DFT over r
 //             in difference form (equal samples give exact zeros: a digitally silent frame keeps its exact spectrum) for BOTH units of the
 //             task, times W_W^(q k) (powers of ONE table value) -> a_q[k] into the unit's LDS buffer (natural order; rows of 525 padded to 535)
 //   pass 1  : thread j, j + 175, j + 350 (525 jobs): radix 7 over n0 of a[j + 525 n0], times W_Q^(j k0), back IN PLACE
@@ -67,7 +67,11 @@ struct Shape {
     static_assert(J3 - 1 + J3 * (R3 / 2 - 1) < Q / 2 - 1 && J3 * (R3 / 2 + 1) > Q / 2, "mirror split at k2 = R3 / 2");
     static __device__ __forceinline__ int pos_of(int k) { return k + (A - J1) * (int)((unsigned)k / (unsigned)J1); }
 };
-typedef Shape<7, 21, 25, 535, 192, 3, 175, false> S3675;       // 44 100 = 12 x 3675, 22 050 = 6 x 3675
+#ifndef PAA_WGS_TU3675
+#define PAA_WGS_TU3675 256         // threads per unit of the 3675-point shape: four waves (192 -- three, what passes 2 and 3 need -- is 4-6 % slower:
+                                   // stage 0 takes ten rounds of the workgroup instead of eight; A/B scripts/rounds/r06/gpu_r06ab.sh)
+#endif
+typedef Shape<7, 21, 25, 535, PAA_WGS_TU3675, 3, 175, false> S3675;       // 44 100 = 12 x 3675, 22 050 = 6 x 3675
 typedef Shape<8, 20, 25, 500, 256, 2, 250, true> S4000;        // 48 000 = 12 x 4000, 32 000 = 8 x 4000, 24 000 = 6 x 4000
 
 __device__ __forceinline__ double2 csqr(double2 a) { return make_double2(fma(a.x, a.x, -a.y * a.y), 2.0 * (a.x * a.y)); }
@@ -135,9 +139,10 @@ __device__ __forceinline__ double2 cpow(double2 w) {
     else return cmul(csqr(csqr(w)), w);
 }
 
-// task types (FrameRef::halo >> 8).  R0 = 12: 0 = units {1, 2} (+ the time-domain features), 1 = {3, 4}, 2 = {5, packed};
-// R0 = 6: 0 = {1, 2} (+ time domain), 1 = {packed} (the first three waves idle)
-template <int R0> __host__ __device__ constexpr int task_types() { return R0 == 12 ? 3 : 2; }          // (R0 = 8: {1, 2}, {3, packed})
+// task types (FrameRef::halo >> 8).  R0 = 12: 0 = units {1, 2} (+ the time-domain features), 1 = {3, 4}, 2 = {5, packed}; R0 = 8: 0 = {1, 2}, 1 = {3, packed};
+// R0 = 6: 0 = {1, 2} (+ time domain), 1 = the packed units of THIS frame and of the NEXT one of the clip (the next row), 2 = {packed} alone (a
+// frame without a partner: the first half of the workgroup idle)
+template <int R0> __host__ __device__ constexpr int task_types() { return (R0 == 12 || R0 == 6) ? 3 : 2; }
 
 template <typename T, int R0, typename SH>
 __global__ __launch_bounds__(SH::NT) void wgs_kernel(PlanDev P, const T *__restrict__ sig, const ClipDev *__restrict__ clips,
@@ -173,16 +178,16 @@ __global__ __launch_bounds__(SH::NT) void wgs_kernel(PlanDev P, const T *__restr
     // and frames that overlap, read their samples through one L2
     constexpr int NTY = task_types<R0>();
     const int nseg = (gridDim.x % 8 == 0) ? 8 : 1, seg = blockIdx.x % nseg, rank = blockIdx.x / nseg, per = gridDim.x / nseg;
-    const int n_fr = n_tasks / NTY;
-    const int seg_lo = (int)((long long)n_fr * seg / nseg) * NTY, seg_hi = (int)((long long)n_fr * (seg + 1) / nseg) * NTY;
+    const int n_fr = (n_tasks + NTY - 1) / NTY;          // (R0 = 6: groups of three tasks = two frames; a frame without a partner is a group of two)
+    const int seg_lo = min(n_tasks, (int)((long long)n_fr * seg / nseg) * NTY), seg_hi = min(n_tasks, (int)((long long)n_fr * (seg + 1) / nseg) * NTY);
     const bool has_task = seg_lo + rank < seg_hi;
     // a unit's sum X, sum (k + 1) X and max X -- what the feature kernel needs BEFORE its sweep over the row (centroid, the normalisations of
     // spread and flux) -- are formed here from the magnitudes as they leave: psum [row][R0 / 2][4].  The waves of a task park their parts in LDS;
     // the row's entries are written behind the next barrier of the workgroup (the next task's first one, or the one after the loop)
-    int flush_row = -1, flush_ua = -1, flush_ub = -1;
-    auto flush_partials = [&](int rw, int ua, int ub) {
+    int flush_row = -1, flush_row_b = -1, flush_ua = -1, flush_ub = -1;
+    auto flush_partials = [&](int rwa, int rwb, int ua, int ub) {
         if (tid_ < 2) {
-            const int un = tid_ == 0 ? ua : ub;
+            const int un = tid_ == 0 ? ua : ub, rw = tid_ == 0 ? rwa : rwb;
             if (un >= 0) {
                 const double *u = upart + 4 * (TU / 64) * tid_;
                 double *d = psum + ((long long)rw * H0 + un) * 4;
@@ -204,13 +209,16 @@ __global__ __launch_bounds__(SH::NT) void wgs_kernel(PlanDev P, const T *__restr
         __builtin_assume(tid >= 0 && tid < NT);
         const int tu = tid - unit * TU;
         double2 *buf = buf_all + unit * UNIT_ELEMS;
-        const bool packed_task = (type == task_types<R0>() - 1);             // unit b is the packed one
-        const bool a_on = !(R0 == 6 && packed_task);                          // (R0 = 6: the packed unit is alone in its task)
+        const bool pair_task = R0 == 6 && type == 1;                          // both units packed: this frame's and the next one's
+        const bool packed_task = R0 == 6 ? type >= 1 : (type == task_types<R0>() - 1);             // unit b is a packed one
+        const bool a_on = !(R0 == 6 && type == 2);                            // (a packed unit without a partner is alone in its task)
+        const T *xb = pair_task ? x + P.S : x;
         const bool time_task = (type == 0) && P.mode == 0 && !cu.halo && !(kAblate & 1024);
         double *row = (P.mode == 1) ? out + cu.out_off + (long long)cu.t * Nf : spec + (long long)cu.row * Nf;
+        if (pair_task && unit == 1) row += Nf;          // (the next frame of the clip: the next row of the scratch / of the output)
         __syncthreads();          // the previous task's reads of the buffers are done (and its waves' partial sums are in LDS)
         if (tid == 64) *s_next = seg_lo + per + atomicAdd(next_task + seg, 1);
-        if (flush_row >= 0) { flush_partials(flush_row, flush_ua, flush_ub); flush_row = -1; }
+        if (flush_row >= 0) { flush_partials(flush_row, flush_row_b, flush_ua, flush_ub); flush_row = -1; }
         // ---------------- stage 0: a_q[k] of both units from the samples (+ the time-domain features :22-51 in the {1, 2} task)
         {
             constexpr bool INT_T = IntSample<T>::kInt;
@@ -226,9 +234,10 @@ __global__ __launch_bounds__(SH::NT) void wgs_kernel(PlanDev P, const T *__restr
                 if constexpr (INT_T) return IntSample<T>::get(p);
                 else return fma(*p, sc, -mean) * inv;
             };
-            auto stage0 = [&](auto qa_c, auto qb_c, auto time_c) {
+            auto stage0 = [&](auto qa_c, auto qb_c, auto time_c, auto pa_c) {
                 constexpr int QA = decltype(qa_c)::value, QB = decltype(qb_c)::value;           // 0 = none / packed
                 constexpr bool TIME = decltype(time_c)::value;
+                constexpr bool PA = decltype(pa_c)::value;                                      // unit a is a packed unit too (of frame x; unit b: of frame xb)
                 double eb[10];
                 int zc = 0;
 #pragma unroll
@@ -244,7 +253,9 @@ __global__ __launch_bounds__(SH::NT) void wgs_kernel(PlanDev P, const T *__restr
                     N sa[BI][R0];
                     N sla[BI][R0];          // TIME: lane 0's left neighbours x[k - 1 + Q r] (the other lanes take them from the lane below)
                     double2 wa[BI];
-                    typename std::conditional<INT_T, ct::PairRaw<T>, double2>::type pra[BI][H0];
+                    typedef typename std::conditional<INT_T, ct::PairRaw<T>, double2>::type Pr;
+                    Pr pra[BI][H0];
+                    Pr praa[PA ? BI : 1][H0];          // unit a's pairs (pair task)
 #pragma unroll
                     for (int u = 0; u < BI; ++u) {
                         const int k = min(tid + NT * (ib + u), Q - 1);
@@ -255,8 +266,12 @@ __global__ __launch_bounds__(SH::NT) void wgs_kernel(PlanDev P, const T *__restr
                         if constexpr (QB == 0) {
 #pragma unroll
                             for (int r = 0; r < H0; ++r) {
-                                if constexpr (INT_T) pra[u][r] = ct::PairRaw<T>::get(x + 2 * k + 2 * Q * r);
-                                else pra[u][r] = ct::PairLoad<T>::get(x + 2 * k + 2 * Q * r);
+                                if constexpr (INT_T) pra[u][r] = ct::PairRaw<T>::get(xb + 2 * k + 2 * Q * r);
+                                else pra[u][r] = ct::PairLoad<T>::get(xb + 2 * k + 2 * Q * r);
+                                if constexpr (PA) {
+                                    if constexpr (INT_T) praa[u][r] = ct::PairRaw<T>::get(x + 2 * k + 2 * Q * r);
+                                    else praa[u][r] = ct::PairLoad<T>::get(x + 2 * k + 2 * Q * r);
+                                }
                             }
                         }
                         wa[u] = P.post[k];
@@ -295,22 +310,29 @@ __global__ __launch_bounds__(SH::NT) void wgs_kernel(PlanDev P, const T *__restr
                         if (in) buf_all[UNIT_ELEMS + pk] = vb;
                     } else {
                         // packed unit: v[k] = (u[2 k], u[2 k + 1]), u[n] = sum_(r < R0 / 2) y[n + 2 Q r]
-                        double2 v;
-                        if constexpr (INT_T) {
-                            int ux = 0, uy = 0;
+                        auto packed_value = [&](const Pr *pr) {
+                            if constexpr (INT_T) {
+                                int ux = 0, uy = 0;
 #pragma unroll
-                            for (int r = 0; r < H0; ++r) { ux += pra[u][r].x0(); uy += pra[u][r].x1(); }
-                            const double c0 = -(double)H0 * mean * inv;
-                            v = make_double2(fma((double)ux, ys, c0), fma((double)uy, ys, c0));
-                        } else {
-                            v = make_double2(0.0, 0.0);
+                                for (int r = 0; r < H0; ++r) { ux += pr[r].x0(); uy += pr[r].x1(); }
+                                const double c0 = -(double)H0 * mean * inv;
+                                return make_double2(fma((double)ux, ys, c0), fma((double)uy, ys, c0));
+                            } else {
+                                double2 v = make_double2(0.0, 0.0);
 #pragma unroll
-                            for (int r = 0; r < H0; ++r) {
-                                v.x += fma(pra[u][r].x, sc, -mean) * inv;
-                                v.y += fma(pra[u][r].y, sc, -mean) * inv;
+                                for (int r = 0; r < H0; ++r) {
+                                    v.x += fma(pr[r].x, sc, -mean) * inv;
+                                    v.y += fma(pr[r].y, sc, -mean) * inv;
+                                }
+                                return v;
                             }
-                        }
+                        };
+                        const double2 v = packed_value(pra[u]);
                         if (in) buf_all[UNIT_ELEMS + pk] = v;
+                        if constexpr (PA) {
+                            const double2 va = packed_value(praa[u]);
+                            if (in) buf_all[pk] = va;
+                        }
                     }
                     if constexpr (TIME) {
                         // energies of the ten entropy blocks (LT = W / 10 samples): register row r covers the samples [Q r, Q r + Q), i.e. the
@@ -371,18 +393,20 @@ __global__ __launch_bounds__(SH::NT) void wgs_kernel(PlanDev P, const T *__restr
             typedef std::integral_constant<int, 0> I0;
             typedef std::integral_constant<int, 1> I1;
             typedef std::integral_constant<int, 2> I2;
+            typedef std::false_type F_;
             if (kAblate & 1) {
                 for (int k = tid; k < Q; k += NT) buf_all[pos_of(k)] = buf_all[UNIT_ELEMS + pos_of(k)] = make_double2(1e-3 * (double)(k & 7), 1e-3);
             } else if (type == 0) {
-                if (time_task) stage0(I1(), I2(), std::true_type());
-                else stage0(I1(), I2(), std::false_type());
+                if (time_task) stage0(I1(), I2(), std::true_type(), F_());
+                else stage0(I1(), I2(), std::false_type(), F_());
             } else if constexpr (R0 == 12) {
-                if (type == 1) stage0(std::integral_constant<int, 3>(), std::integral_constant<int, 4>(), std::false_type());
-                else stage0(std::integral_constant<int, 5>(), I0(), std::false_type());
+                if (type == 1) stage0(std::integral_constant<int, 3>(), std::integral_constant<int, 4>(), std::false_type(), F_());
+                else stage0(std::integral_constant<int, 5>(), I0(), std::false_type(), F_());
             } else if constexpr (R0 == 8) {
-                stage0(std::integral_constant<int, 3>(), I0(), std::false_type());
+                stage0(std::integral_constant<int, 3>(), I0(), std::false_type(), F_());
             } else {
-                stage0(I0(), I0(), std::false_type());
+                if (pair_task) stage0(I0(), I0(), std::false_type(), std::true_type());
+                else stage0(I0(), I0(), std::false_type(), F_());
             }
             __syncthreads();
             if (time_task && wave == NWV - 1) {
@@ -474,7 +498,7 @@ __global__ __launch_bounds__(SH::NT) void wgs_kernel(PlanDev P, const T *__restr
                 for (int n2 = 0; n2 < R3; ++n2) v[n2] = e[n2];
             }
             ct::Dft<R3>::template run<1>(v);
-            const bool packed_unit = packed_task && unit == 1;
+            const bool packed_unit = (packed_task && unit == 1) || pair_task;
             double us = 0.0, uw = 0.0, um = 0.0;          // this thread's part of its unit's sum X, sum (k + 1) X, max X
             if (!packed_unit) {
                 const int q = 2 * type + 1 + unit;
@@ -553,7 +577,8 @@ __global__ __launch_bounds__(SH::NT) void wgs_kernel(PlanDev P, const T *__restr
                 us = wsum(us); uw = wsum(uw); um = wmax_nonneg(um);
                 if (lane == 0) { upart[4 * wave] = us; upart[4 * wave + 1] = uw; upart[4 * wave + 2] = um; }
                 flush_row = cu.row;
-                flush_ua = a_on ? 2 * type : -1;          // unit index of q = 2 type + 1
+                flush_row_b = pair_task ? cu.row + 1 : cu.row;
+                flush_ua = pair_task ? H0 - 1 : (a_on ? 2 * type : -1);          // unit index of q = 2 type + 1
                 flush_ub = packed_task ? H0 - 1 : 2 * type + 1;
             }
         }
@@ -561,7 +586,7 @@ __global__ __launch_bounds__(SH::NT) void wgs_kernel(PlanDev P, const T *__restr
         ti = t_next;
     }
     __syncthreads();
-    if (flush_row >= 0) flush_partials(flush_row, flush_ua, flush_ub);
+    if (flush_row >= 0) flush_partials(flush_row, flush_row_b, flush_ua, flush_ub);
     // the last workgroup out clears the counters for the next launch (they are zeroed once, when the scratch is allocated): a memset in front of
     // every launch was a 5 us fill kernel per counter word
     if (tid_ == 0) {

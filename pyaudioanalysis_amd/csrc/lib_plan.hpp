@@ -414,12 +414,26 @@ static int plan_build(const int64_t *offsets, int64_t n_clips, int sample_kind, 
                 const int n_types = wgs::wgs_task_types(p->wgs_r0);
                 for (auto &ch : p->wg_chunks) {
                     const long long t0 = (long long)p->wg_tasks.size();
-                    for (long long i = ch.first; i < ch.second; ++i)
-                        for (int ty = 0; ty < n_types; ++ty) {
-                            wg::FrameRef f = p->wg_frames[(size_t)i];
-                            f.halo |= ty << 8;
-                            p->wg_tasks.push_back(f);
+                    auto push = [&](long long i, int ty) {
+                        wg::FrameRef f = p->wg_frames[(size_t)i];
+                        f.halo |= ty << 8;
+                        p->wg_tasks.push_back(f);
+                    };
+                    if (p->wgs_r0 == 6) {
+                        // three sub-transforms per frame: {1, 2} and the packed one -- the packed units of two CONSECUTIVE frames of a clip (consecutive
+                        // rows) share a task (type 1, on the first frame's record); a frame without such a partner runs its packed unit alone (type 2)
+                        for (long long i = ch.first; i < ch.second;) {
+                            const wg::FrameRef &a = p->wg_frames[(size_t)i];
+                            const bool pair = i + 1 < ch.second && p->wg_frames[(size_t)i + 1].clip == a.clip && p->wg_frames[(size_t)i + 1].t == a.t + 1 &&
+                                              p->wg_frames[(size_t)i + 1].row == a.row + 1;
+                            push(i, 0);
+                            if (pair) { push(i + 1, 0); push(i, 1); i += 2; }
+                            else { push(i, 2); i += 1; }
                         }
+                    } else {
+                        for (long long i = ch.first; i < ch.second; ++i)
+                            for (int ty = 0; ty < n_types; ++ty) push(i, ty);
+                    }
                     p->wg_task_chunks.emplace_back(t0, (long long)p->wg_tasks.size());
                 }
                 if (p->wg_tasks.size() > 0x7fffffffULL) return fail(PAA_ERR_UNSUPPORTED, "too many frames for the split transform");

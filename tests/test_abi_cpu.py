@@ -232,7 +232,7 @@ def test_real_input_split_plan_reproduces_the_spectrum(window):
     assert lib.paa_debug_wgs_plan(window, info.ctypes.data_as(_ffi.c_i32p), bin_of.ctypes.data_as(_ffi.c_i32p), Nf) == 1
     r0, Q, R1, R2, R3, A, threads, lds, n_types, low_bins, feat_lds, n_blocks, feat_threads = (int(v) for v in info[:13])
     assert r0 * Q == window and R1 * R2 * R3 == Q and A >= R2 * R3 and lds <= 160 * 1024 and 3 * feat_lds <= 160 * 1024
-    assert 2 * R1 * A * 16 <= lds and low_bins * 8 <= feat_lds and n_blocks == -(-Nf // (64 * r0)) and n_types == (r0 // 2 + 1) // 2
+    assert 2 * R1 * A * 16 <= lds and low_bins * 8 <= feat_lds and n_blocks == -(-Nf // (64 * r0)) and n_types == (3 if r0 == 6 else (r0 // 2 + 1) // 2)
     # the feature kernel reads a row as residue streams: 64 consecutive elements of a stream lie in one natural block of 64 r0 bins
     inv = np.empty(Nf, dtype=np.int64)
     inv[bin_of] = np.arange(Nf)
