@@ -1,30 +1,34 @@
-// Even windows of 12 x 3675 or 6 x 3675 samples -- the 1 s window audioSegmentation.music_thumbnailing passes by default
-// (audioSegmentation.py:1134-1138) at 44.1 kHz (44 100 samples) and at 22.05 kHz (22 050): the packed transform (22 050 / 11 025 complex
-// points) does not fit one CU's LDS.  kernels_wg.hpp (round 5) splits the PACKED sequence by r0 = 6 / 3 and has to keep the sub-transforms q
-// and r0 - q side by side (the real-FFT recombination pairs bin k with Nc - k), runs five in-place radix passes over them and leaves the
-// time-domain features to a kernel of their own.  Here (round 6) the REAL sequence is split instead:
+// Long even windows of r0 x Q samples, Q = 3675 or 4000 -- the 1 s window audioSegmentation.music_thumbnailing passes by default
+// (audioSegmentation.py:1134-1138) at the rates music has: 44 100 samples at 44.1 kHz = 12 x 3675, 22 050 = 6 x 3675, 48 000 = 12 x 4000, 32 000 =
+// 8 x 4000, 24 000 = 6 x 4000.  Their packed transform (22 050 complex points = 353 KB) does not fit one CU's LDS.  kernels_wg.hpp (round 5) splits the
+// PACKED sequence by r0 = 6 / 3 and has to keep the sub-transforms q and r0 - q side by side (the real-FFT recombination pairs bin k with Nc - k), runs
+// five in-place radix passes over them and leaves the time-domain features to a kernel of their own.  Here (round 6) the REAL
+// sequence is split instead:
 //
-//   W = r0 Q, Q = 3675 = 7 x 21 x 25.  For q = 1 .. r0/2 - 1 ("complex unit q")
+//   W = r0 Q, Q = 3675 = 7 x 21 x 25 (or 4000 = 8 x 20 x 25).  For q = 1 .. r0/2 - 1 ("complex unit q")
 //       a_q[k] = W_W^(q k) sum_r y[k + Q r] W_r0^(r q),   A_q = FFT_Q(a_q),   X[q + r0 kappa] = A_q[kappa]
 //   -- bins beyond W / 2 are the mirrors of the bins r0 - q + r0 (Q - 1 - kappa), so unit q delivers |X| for every bin = +-q mod r0 -- and
 //   the bins = 0 mod r0 / 2 come from ONE more transform of Q points ("packed unit"): u[n] = sum_(r < r0/2) y[n + 2 Q r] is real and 2 Q long,
 //       v[k] = u[2 k] + i u[2 k + 1],   V = FFT_Q(v),   X[(r0/2) j] = E + W_(2Q)^j O   with E, O from V[j] and V[Q - j].
-//   r0 / 2 units of equal cost per frame, NONE needs another one's outputs.  (scripts/dev/wgs_model.py restates this in NumPy.)
+//   r0 / 2 units of equal cost per frame, NONE needs another one's outputs.  (scripts/dev/wgs_model.py and tests/test_abi_cpu.py restate this in NumPy.)
 //
-//   A TASK is one frame and two units -- {1, 2}, {3, 4}, {5, packed} for r0 = 12; {1, 2}, {packed} for r0 = 6 -- handled by a workgroup of
-//   512 threads, four waves per unit (passes 2 and 3 use three of them); persistent workgroups take tasks from a counter.
-//   stage 0 : all threads: k = tid + 512 i: the r0 samples y[k + Q r] (one coalesced 2-byte load per r), normalised (:567-570); the DFT over r
-//             in difference form (equal samples give exact zeros: a digitally silent frame keeps its exact spectrum) for BOTH units of the
-//             task, times W_W^(q k) (powers of ONE table value) -> a_q[k] into the unit's LDS buffer (natural order; rows of 525 padded to 535)
-//   pass 1  : thread j, j + 175, j + 350 (525 jobs): radix 7 over n0 of a[j + 525 n0], times W_Q^(j k0), back IN PLACE
-//   pass 2  : thread (n2, k0): radix 21 = 3 x 7 (kernels_tri.hpp) over n1 of (k0, n1, n2), times W_525^(n2 k1), in place
-//   pass 3  : thread (k0, k1): radix 25 (kernels_fast.hpp) over n2 -> A[k0 + 7 k1 + 147 k2] in registers:
-//             complex units: |A| / Nf straight to the frame's row (bin q + r0 kappa or its mirror); packed unit: one more exchange (natural
-//             order), then the recombination of the pairs (j, Q - j)
+//   wgs_kernel: a TASK is one frame and two units -- {1, 2}, {3, 4}, {5, packed} for r0 = 12; {1, 2}, {3, packed} for r0 = 8; {1, 2} and the packed
+//   units of two consecutive frames for r0 = 6 -- handled by a workgroup of 512 threads, four waves per unit (passes 2 and 3 use three of them);
+//   persistent workgroups take tasks from one counter per XCD (the tasks of a frame, and frames that overlap, read their samples through one L2).
+//   stage 0 : all threads: k = tid + 512 i: the r0 samples x[k + Q r] (one coalesced 2-byte load per r, four rounds requested together); the DFT
+//             over r in difference form ON INTEGERS (exact; equal samples give exact zeros: a digitally silent frame keeps its exact spectrum; the
+//             clip mean cancels) for BOTH units of the task, scaled (:567-570), times W_W^(q k) (powers of ONE table value) -> a_q[k] into the
+//             unit's LDS buffer (natural order; 3675: rows of 525 padded to 535).  The {1, 2} task also forms the frame's time-domain features
+//             (:22-51) here: its stage 0 sees every sample of the frame
+//   pass 1  : thread j, j + J1T, ... : radix 7 / 8 over n0 of a[j + R2 R3 n0], times W_Q^(j k0), back IN PLACE
+//   pass 2  : thread (n2, k0): radix 21 = 3 x 7 / 20 = 4 x 5 (kernels_tri.hpp) over n1 of (k0, n1, n2), times W_(R2 R3)^(n2 k1), in place
+//   pass 3  : thread (k1, k0): radix 25 (kernels_fast.hpp) over n2 -> A[k0 + R1 k1 + R1 R2 k2] in registers: complex units: |A| / Nf straight to the
+//             frame's row, UNIT-MAJOR (unit q's Q magnitudes side by side: R1 R2 consecutive doubles per store instruction; in natural order the same
+//             stores were 8 bytes every 96: 44 100 write transactions per task = 106 of 182 us) together with the unit's sum X, sum (k + 1) X, max X;
+//             packed unit: one more exchange (natural order), then the recombination of the pairs (j, Q - j).  Spectrogram plans: natural order
 //   Four workgroup barriers per task (six with a packed unit) against the seven of five in-place passes; 60 vector instructions per point.
-//   The time-domain features (:22-51) of a frame are formed by the task that holds units {1, 2}: its stage 0 sees every sample of the frame.
-// Features: kernels_wg.hpp's wg_feat_kernel on the rows, as before.
-// Replaces ShortTermFeatures.py:608-682 (transform part), spectrogram (:415-422), chromagram (:349-359) for these windows.
+//   wgs_feat_kernel: the features of a frame from its unit-major row and the previous frame's, read as residue streams (below).
+// Replaces ShortTermFeatures.py:608-682 (+ helpers :22-140, :236-321), spectrogram (:415-422), chromagram (:349-359) for these windows.
 #pragma once
 #include "kernels_tri.hpp"          // tri::Cd<21>; kernels_generic.hpp: Tabs
 
