@@ -268,11 +268,11 @@ def other_configs(ffi, steps=10):
     run_shape("big_16000_1h", "w16000_16kHz_1h", "1 h at 16 kHz, 16000 / 8000", launches=10)
     run_shape("big_16000_68", "w16000_16kHz_68rows", "10 min at 16 kHz, 16000 / 8000, 68 rows", launches=20)
     run_shape("big_8000_batch", "w8000_batch", "200 clips x 30 s at 16 kHz, 8000 / 4000, one plan", launches=20)
-    run_shape("big_44100", "w44100_44kHz", "5 min at 44.1 kHz, 1 s / 0.5 s (44100 / 22050): real-input split, six transforms of 3675 points on register passes", launches=5)
-    run_shape("big_44100_20min", "w44100_44kHz_20min", "20 min at 44.1 kHz, 44100 / 22050", launches=3)
-    run_shape("big_22050", "w22050_22kHz", "20 min at 22.05 kHz, 1 s / 0.5 s (22050 / 11025): three transforms of 3675 points", launches=5)
-    run_shape("big_48000", "w48000_48kHz", "10 min at 48 kHz, 1 s / 0.5 s (48000 / 24000): real-input split, six transforms of 4000 points", launches=5)
-    run_shape("big_32000", "w32000_32kHz", "10 min at 32 kHz, 1 s / 0.5 s (32000 / 16000): four transforms of 4000 points", launches=5)
+    run_shape("big_44100", "w44100_44kHz", "5 min at 44.1 kHz, 1 s / 0.5 s (44100 / 22050): real-input split, six transforms of 3675 points on register passes", launches=20)
+    run_shape("big_44100_20min", "w44100_44kHz_20min", "20 min at 44.1 kHz, 44100 / 22050", launches=10)
+    run_shape("big_22050", "w22050_22kHz", "20 min at 22.05 kHz, 1 s / 0.5 s (22050 / 11025): three transforms of 3675 points", launches=20)
+    run_shape("big_48000", "w48000_48kHz", "10 min at 48 kHz, 1 s / 0.5 s (48000 / 24000): real-input split, six transforms of 4000 points", launches=20)
+    run_shape("big_32000", "w32000_32kHz", "10 min at 32 kHz, 1 s / 0.5 s (32000 / 16000): four transforms of 4000 points", launches=20)
     return out
 
 
