@@ -143,3 +143,25 @@ def test_more_frames_than_one_chunk_of_the_scratch(gpu_lib):
         Xp = O.magnitude_spectrum(xn[(t - 1) * S:(t - 1) * S + W], tab.nfft)
         v = O.frame_vector(fr, X, Xp, tab)
         assert np.allclose(F[:34, t], v, rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("fs,window,step", [(22050, 22050, 11025), (44100, 44100, 22050), (32000, 32000, 16000)])
+def test_many_short_clips_in_one_plan(gpu_lib, fs, window, step):
+    """240 clips of one to five frames in one plan: more workgroups than tasks per XCD segment at the ends of the list, clip boundaries between
+    almost every pair of frames (r0 = 6: the packed units of two frames share a task only inside a clip), a silent clip among them -- bit-identical
+    to the single-clip calls, a sample of them against the oracle."""
+    rng = np.random.default_rng(window)
+    lens = [window + step * int(rng.integers(0, 5)) + int(rng.integers(0, step)) for _ in range(240)]
+    clips = [synth_clip(7600 + i, n, fs) for i, n in enumerate(lens)]
+    clips[17] = np.zeros(lens[17], dtype=np.int16)
+    res, _ = ShortTermFeatures.feature_extraction_batch(clips, fs, window, step, deltas=True)
+    assert len(res) == len(clips)
+    for i, (c, r) in enumerate(zip(clips, res)):
+        if i % 8 == 0 or i == 17:
+            single, _ = ShortTermFeatures.feature_extraction(c, fs, window, step)
+            assert np.array_equal(single, r), i
+        if i % 40 == 0 or i == 17:
+            ref, _ = O.feature_extraction(c, fs, window, step)
+            assert_parity(r, ref, "clip %d of 240" % i, sig=(c, fs, window, step))
+    again, _ = ShortTermFeatures.feature_extraction_batch(clips, fs, window, step, deltas=True)
+    assert all(np.array_equal(a, b) for a, b in zip(res, again))
